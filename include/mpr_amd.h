@@ -1,0 +1,193 @@
+/*
+ * mpr_amd.h — C ABI of the MI355X-native mpr hot path (libmpr_amd.so).
+ *
+ * The reference (mkeeter/mpr) has no FFI layer: callers use two C++ structs directly,
+ *     mpr::Tape(const libfive::Tree&)                         inc/tape.hpp:24-30
+ *     mpr::Context(int32_t image_size_px)                     inc/context.hpp:38-39
+ *     Context::render2D(tape, Eigen::Matrix3f, float z = 0)   inc/context.hpp:41-42
+ *     Context::render3D(tape, Eigen::Matrix4f)                inc/context.hpp:40
+ *     Context::render2D_brute(...)                            inc/context.hpp:47-49
+ * and then read public members from the host (managed memory): stages[i].filled,
+ * stages[i].tiles, stages[i].tile_array_size, normals, tape_data, *tape_index
+ * (benchmark/render_2d_table.cpp:57-62, render_3d_table.cpp:59-69, circle.cpp:42-103,
+ * tape_shortening.cpp:56-72, render_3d_heatmap.cpp:64).
+ *
+ * This header is the seam a binding would use instead: plain pointers and sizes, opaque
+ * handles, integer status codes (0 = ok) with mpr_last_error() for the message; nothing
+ * here exits the process (the reference's CUDA_CHECK does, inc/util.hpp:19-25).
+ * include/mpr.hpp re-creates mpr::Tape / mpr::Context with the reference's member names on
+ * top of it.  Matrices are column-major like Eigen (element (row,col) at [row + col*N]).
+ *
+ * Threading: one context = one device + one HIP stream; calls on one context must be
+ * serialised by the caller (the reference's Context is not re-entrant either); different
+ * contexts may be used concurrently.
+ */
+#ifndef MPR_AMD_H
+#define MPR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mpr_clause.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPR_OK 0
+#define MPR_ERR_INVALID 1      /* bad argument */
+#define MPR_ERR_PARSE 2        /* malformed .frep */
+#define MPR_ERR_NO_DEVICE 3    /* no usable HIP device / HIP runtime error (see message) */
+#define MPR_ERR_ALLOC 4
+#define MPR_ERR_UNSUPPORTED 5
+
+typedef struct mpr_tree mpr_tree;        /* expression DAG (stand-in for libfive::Tree) */
+typedef struct mpr_tape mpr_tape;        /* flat clause tape (mpr::Tape) */
+typedef struct mpr_context mpr_context;  /* render context (mpr::Context) */
+
+/* Thread-local description of the last failing call. */
+const char* mpr_last_error(void);
+/* Library version string. */
+const char* mpr_version(void);
+
+/* ---- expression front end (host only; replaces the libfive::Tree the reference takes at
+ *      src/tape.cpp:21; opcodes are libfive's packed numbering, see mpr_tree_op below) ---- */
+enum mpr_tree_op {
+    MPR_T_CONSTANT = 1, MPR_T_VAR_X = 2, MPR_T_VAR_Y = 3, MPR_T_VAR_Z = 4,
+    MPR_T_SQUARE = 7, MPR_T_SQRT = 8, MPR_T_NEG = 9, MPR_T_SIN = 10, MPR_T_COS = 11,
+    MPR_T_ASIN = 13, MPR_T_ACOS = 14, MPR_T_ATAN = 15, MPR_T_EXP = 16, MPR_T_ABS = 17,
+    MPR_T_LOG = 18,
+    MPR_T_ADD = 20, MPR_T_MUL = 21, MPR_T_MIN = 22, MPR_T_MAX = 23, MPR_T_SUB = 24,
+    MPR_T_DIV = 25
+};
+int mpr_tree_x(mpr_tree** out);
+int mpr_tree_y(mpr_tree** out);
+int mpr_tree_z(mpr_tree** out);
+int mpr_tree_const(float v, mpr_tree** out);
+int mpr_tree_unary(int op, const mpr_tree* a, mpr_tree** out);
+int mpr_tree_binary(int op, const mpr_tree* a, const mpr_tree* b, mpr_tree** out);
+/* libfive::Tree::remap (benchmark/render_effects.cpp:36) */
+int mpr_tree_remap(const mpr_tree* t, const mpr_tree* x, const mpr_tree* y, const mpr_tree* z,
+                   mpr_tree** out);
+/* libfive::Archive::deserialize(...).shapes.front().tree (benchmark/render_2d_table.cpp:34) */
+int mpr_tree_from_frep(const void* bytes, size_t n, mpr_tree** out);
+int mpr_tree_from_frep_file(const char* path, mpr_tree** out);
+/* libfive::Archive::serialize (gui/main.cpp:394-403); returns needed size in *n */
+int mpr_tree_to_frep(const mpr_tree* t, void* bytes, size_t cap, size_t* n);
+int mpr_tree_size(const mpr_tree* t, size_t* nodes);
+void mpr_tree_free(mpr_tree* t);
+
+/* ---- tape (mpr::Tape, inc/tape.hpp:24-30, src/tape.cpp:21-228); host-side object, a
+ *      context uploads it on first use ---- */
+int mpr_tape_from_tree(const mpr_tree* t, mpr_tape** out);
+/* adopt an already-flattened tape (head clause, clauses, end clause) */
+int mpr_tape_from_clauses(const uint64_t* clauses, int32_t length, mpr_tape** out);
+int32_t mpr_tape_length(const mpr_tape* t);            /* mpr::Tape::length */
+const uint64_t* mpr_tape_data(const mpr_tape* t);      /* mpr::Tape::data (host copy) */
+int32_t mpr_tape_num_slots(const mpr_tape* t);         /* highest slot index + 1 */
+int32_t mpr_tape_num_choices(const mpr_tape* t);       /* number of min/max clauses */
+int32_t mpr_tape_flags(const mpr_tape* t);             /* bit0: slots exhausted (src/tape.cpp:79-81),
+                                                          bit1: unsupported opcodes (:182-196) */
+void mpr_tape_free(mpr_tape* t);
+
+/* ---- context (mpr::Context, inc/context.hpp:38-73, src/context.cpp:17-49) ---- */
+typedef struct mpr_ctx_options {
+    int32_t device;            /* HIP device ordinal */
+    int32_t image_size_px;     /* S; must be a multiple of 64 */
+    int64_t pool_clauses;      /* tape pool capacity in clauses; 0 = MPR_NUM_SUBTAPES_BIG*64
+                                  (inc/parameters.hpp:18-22, BIG_SERVER build) */
+    int32_t flags;             /* MPR_CTX_* */
+} mpr_ctx_options;
+#define MPR_CTX_TIMING 1       /* record HIP events around every kernel (mpr_get_timings) */
+
+int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out);
+int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out);
+void mpr_ctx_destroy(mpr_context* ctx);
+int32_t mpr_ctx_image_size(const mpr_context* ctx);    /* Context::image_size_px */
+
+/* Context::render2D (src/context.cu:1136-1280).  Blocking: returns after the device has
+ * finished, like the reference's cudaDeviceSynchronize at :1279. */
+int mpr_render2d(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9], float z);
+/* Context::render3D (src/context.cu:1282-1458). */
+int mpr_render3d(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmajor[16]);
+/* Context::render2D_brute (src/context.cu:1461-1508). */
+int mpr_render2d_brute(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
+                       float z);
+/* Non-blocking forms: enqueue the frame on the context's stream and return. */
+int mpr_render2d_async(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
+                       float z);
+int mpr_render3d_async(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmajor[16]);
+int mpr_ctx_sync(mpr_context* ctx);
+
+/* Multi-GPU: render only the top-level xy columns owned by `rank`.
+ * `owner` has (S/64)^2 entries (column index = x + y*(S/64)), each the owning rank; columns
+ * of other ranks are skipped at stage 0 and their pixels stay 0. */
+int mpr_render3d_part(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmajor[16],
+                      const int32_t* owner, int32_t rank);
+int mpr_render2d_part(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
+                      float z, const int32_t* owner, int32_t rank);
+/* Deterministic column -> rank deal (identical on every rank).  weights may be NULL
+ * (round-robin) or (S/64)^2 non-negative work estimates (longest-processing-time first). */
+int mpr_partition_columns(int32_t columns, const float* weights, int32_t nranks, int32_t* owner);
+/* Pack the 64x64 blocks of the columns owned by `rank` (heights, then normals when
+ * with_normals) into a device buffer, `capacity_cols` blocks each; and scatter such a pack
+ * (from any rank) into this context's full-size images.  Used around the one RCCL
+ * all-gather per frame. */
+int mpr_pack_columns(mpr_context* ctx, const int32_t* owner, int32_t rank, int32_t capacity_cols,
+                     int32_t with_normals, void* dev_out);
+int mpr_unpack_columns(mpr_context* ctx, const int32_t* owner, int32_t rank, int32_t capacity_cols,
+                       int32_t with_normals, const void* dev_in);
+
+/* ---- results (what callers read from Context's public members) ---- */
+/* stages[stage].filled -> host; (S / {64,16,4,1}[stage])^2 int32, index x + y*side */
+int mpr_read_filled(mpr_context* ctx, int32_t stage, int32_t* host);
+/* normals -> host; S*S uint32 0xFF<<24 | nz<<16 | ny<<8 | nx */
+int mpr_read_normals(mpr_context* ctx, uint32_t* host);
+/* stages[stage].tiles -> host; *n = number of valid entries from the last render
+ * (stage 0: all top-level tiles).  cap in entries. */
+int mpr_read_tiles(mpr_context* ctx, int32_t stage, mpr_tile_node* host, size_t cap, size_t* n);
+/* tape_data / *tape_index -> host; copies min(cap, *tape_index) clauses */
+int mpr_read_tape_pool(mpr_context* ctx, uint64_t* host, size_t cap, int32_t* tape_index);
+/* device pointers (for zero-copy consumers such as the multi-GPU gather) */
+int32_t* mpr_dev_filled(mpr_context* ctx, int32_t stage);
+uint32_t* mpr_dev_normals(mpr_context* ctx);
+void* mpr_ctx_stream(mpr_context* ctx);   /* hipStream_t */
+
+/* Work counters of the last frame; all per frame. */
+typedef struct mpr_counters {
+    int64_t tiles_in[3];        /* tiles evaluated per tile stage (3-D: 64/16/4 px; 2-D: [0],[2]) */
+    int64_t tiles_active[3];    /* tiles surviving each stage (ambiguous and not masked) */
+    int64_t voxel_tiles;        /* smallest tiles handed to the float pass */
+    int64_t clauses_fwd;        /* F: clause visits by wave-groups, forward (all passes) */
+    int64_t clauses_bwd;        /* R: clause visits by wave-groups, backward (tape push) */
+    int64_t clauses_written;    /* W: words written to the pool by tape pushes */
+    int64_t lane_clauses;       /* lane-granular clause evaluations */
+    int64_t normal_pixels;      /* pixels evaluated by the normals pass */
+    int32_t tape_index;         /* pool words in use after the frame */
+    int32_t pool_overflowed;    /* a push ran out of pool and fell back (src/context.cu:336-347) */
+    int32_t slots_exceeded;     /* tape uses more slots than the evaluators hold */
+    int32_t reserved;
+} mpr_counters;
+int mpr_get_counters(mpr_context* ctx, mpr_counters* out);
+
+/* Per-kernel device time of the last frame, HIP events on the context's stream (only with
+ * MPR_CTX_TIMING).  names[i] is a static string; returns count in *n (<= cap). */
+int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
+
+/* ---- device self-tests used by the parity suite: evaluate primitive operations on the GPU
+ *      so they can be compared bit-for-bit with the oracle ---- */
+/* interval primitive `op` (an MPR_OP_* code) on n operand pairs; lo/hi arrays */
+int mpr_test_interval_op(int32_t device, int32_t op, int32_t n, const float* a_lo,
+                         const float* a_hi, const float* b_lo, const float* b_hi, float imm,
+                         float* out_lo, float* out_hi, int32_t* out_choice);
+/* float primitive `op` on n operand pairs */
+int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, const float* b,
+                      float imm, float* out);
+/* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
+int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
+                      float imm, float* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,196 @@
+/*
+ * capi_host.cpp — host-only part of the C ABI (include/mpr_amd.h): expression trees,
+ * .frep archives, tape building, column partitioning.  No GPU needed.
+ */
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mpr_amd.h"
+#include "internal.hpp"
+#include "tape_builder.hpp"
+#include "tree.hpp"
+
+using mpr::front::Tree;
+
+struct mpr_tree {
+    Tree t;
+};
+
+namespace mpr {
+thread_local std::string g_last_error;
+int set_error(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+}  // namespace mpr
+
+extern "C" {
+
+const char* mpr_last_error(void) { return mpr::g_last_error.c_str(); }
+const char* mpr_version(void) { return "mpr_amd 0.1 (gfx950)"; }
+
+const char* mpr_op_str(uint8_t op)
+{
+    /* names as in src/gpu_opcode.cu:17-58 */
+    static const char* names[MPR_OP_COUNT] = {
+        "INVALID", "JUMP", "SQUARE_LHS", "SQRT_LHS", "NEG_LHS", "SIN_LHS", "COS_LHS", "ASIN_LHS",
+        "ACOS_LHS", "ATAN_LHS", "EXP_LHS", "ABS_LHS", "LOG_LHS", "ADD_LHS_IMM", "ADD_LHS_RHS",
+        "MUL_LHS_IMM", "MUL_LHS_RHS", "MIN_LHS_IMM", "MIN_LHS_RHS", "MAX_LHS_IMM", "MAX_LHS_RHS",
+        "SUB_LHS_IMM", "SUB_IMM_RHS", "SUB_LHS_RHS", "DIV_LHS_IMM", "DIV_IMM_RHS", "DIV_LHS_RHS",
+        "COPY_IMM", "COPY_LHS", "COPY_RHS"};
+    return op < MPR_OP_COUNT ? names[op] : "INVALID";
+}
+
+#define MPR_TRY(body)                                                        \
+    try { body }                                                             \
+    catch (const std::bad_alloc&) { return mpr::set_error(MPR_ERR_ALLOC, "out of memory"); } \
+    catch (const std::exception& e) { return mpr::set_error(MPR_ERR_INVALID, e.what()); }
+
+static int wrap(Tree t, mpr_tree** out)
+{
+    if (!out) return mpr::set_error(MPR_ERR_INVALID, "null output pointer");
+    *out = new mpr_tree{std::move(t)};
+    return MPR_OK;
+}
+
+int mpr_tree_x(mpr_tree** out) { MPR_TRY(return wrap(Tree::X(), out);) }
+int mpr_tree_y(mpr_tree** out) { MPR_TRY(return wrap(Tree::Y(), out);) }
+int mpr_tree_z(mpr_tree** out) { MPR_TRY(return wrap(Tree::Z(), out);) }
+int mpr_tree_const(float v, mpr_tree** out) { MPR_TRY(return wrap(Tree(v), out);) }
+int mpr_tree_unary(int op, const mpr_tree* a, mpr_tree** out)
+{
+    if (!a) return mpr::set_error(MPR_ERR_INVALID, "null operand");
+    MPR_TRY(return wrap(Tree::unary((mpr::front::Op)op, a->t), out);)
+}
+int mpr_tree_binary(int op, const mpr_tree* a, const mpr_tree* b, mpr_tree** out)
+{
+    if (!a || !b) return mpr::set_error(MPR_ERR_INVALID, "null operand");
+    MPR_TRY(return wrap(Tree::binary((mpr::front::Op)op, a->t, b->t), out);)
+}
+int mpr_tree_remap(const mpr_tree* t, const mpr_tree* x, const mpr_tree* y, const mpr_tree* z,
+                   mpr_tree** out)
+{
+    if (!t || !x || !y || !z) return mpr::set_error(MPR_ERR_INVALID, "null operand");
+    MPR_TRY(return wrap(t->t.remap(x->t, y->t, z->t), out);)
+}
+int mpr_tree_from_frep(const void* bytes, size_t n, mpr_tree** out)
+{
+    if (!bytes || !out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    try {
+        return wrap(mpr::front::deserialize_frep((const uint8_t*)bytes, n), out);
+    } catch (const std::exception& e) {
+        return mpr::set_error(MPR_ERR_PARSE, e.what());
+    }
+}
+int mpr_tree_from_frep_file(const char* path, mpr_tree** out)
+{
+    if (!path || !out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    try {
+        return wrap(mpr::front::load_frep(path), out);
+    } catch (const std::exception& e) {
+        return mpr::set_error(MPR_ERR_PARSE, e.what());
+    }
+}
+int mpr_tree_to_frep(const mpr_tree* t, void* bytes, size_t cap, size_t* n)
+{
+    if (!t || !n) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    MPR_TRY(
+        auto v = mpr::front::serialize_frep(t->t);
+        *n = v.size();
+        if (bytes && cap >= v.size()) std::memcpy(bytes, v.data(), v.size());
+        return MPR_OK;)
+}
+int mpr_tree_size(const mpr_tree* t, size_t* nodes)
+{
+    if (!t || !nodes) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    MPR_TRY(*nodes = t->t.size(); return MPR_OK;)
+}
+void mpr_tree_free(mpr_tree* t) { delete t; }
+
+/* ---- tape ---- */
+static void finish_tape(mpr_tape* t)
+{
+    int max_slot = 0, choices = 0;
+    for (size_t i = 0; i < t->clauses.size(); ++i) {
+        const uint64_t c = t->clauses[i];
+        max_slot = std::max<int>(max_slot, std::max<int>(mpr_cl_out(c), std::max<int>(mpr_cl_lhs(c), mpr_cl_rhs(c))));
+        if (i > 0 && i + 1 < t->clauses.size() && mpr_op_is_minmax(mpr_cl_op(c))) choices++;
+    }
+    t->num_slots = max_slot + 1;
+    t->num_choices = choices;
+    static std::atomic<uint64_t> serial{1};
+    t->serial = serial++;
+}
+
+int mpr_tape_from_tree(const mpr_tree* tr, mpr_tape** out)
+{
+    if (!tr || !out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    MPR_TRY(
+        mpr::front::TapeBuild tb = mpr::front::build_tape(tr->t);
+        if (!tb.error.empty()) return mpr::set_error(MPR_ERR_INVALID, tb.error);
+        auto* t = new mpr_tape();
+        t->clauses = std::move(tb.clauses);
+        t->flags = (tb.slots_exhausted ? 1 : 0) | (tb.unsupported ? 2 : 0);
+        finish_tape(t);
+        *out = t;
+        return MPR_OK;)
+}
+int mpr_tape_from_clauses(const uint64_t* clauses, int32_t length, mpr_tape** out)
+{
+    if (!clauses || !out || length < 2) return mpr::set_error(MPR_ERR_INVALID, "bad tape");
+    if (mpr_cl_op(clauses[0]) != 0 || mpr_cl_op(clauses[length - 1]) != 0)
+        return mpr::set_error(MPR_ERR_INVALID, "tape must start with a head clause and end with an end clause");
+    for (int32_t i = 1; i + 1 < length; ++i) {
+        const uint32_t op = mpr_cl_op(clauses[i]);
+        if (op < MPR_OP_SQUARE_LHS || op >= MPR_OP_COUNT)
+            return mpr::set_error(MPR_ERR_INVALID, "invalid opcode in tape at clause " + std::to_string(i));
+    }
+    MPR_TRY(
+        auto* t = new mpr_tape();
+        t->clauses.assign(clauses, clauses + length);
+        finish_tape(t);
+        *out = t;
+        return MPR_OK;)
+}
+int32_t mpr_tape_length(const mpr_tape* t) { return t ? (int32_t)t->clauses.size() : 0; }
+const uint64_t* mpr_tape_data(const mpr_tape* t) { return t ? t->clauses.data() : nullptr; }
+int32_t mpr_tape_num_slots(const mpr_tape* t) { return t ? t->num_slots : 0; }
+int32_t mpr_tape_num_choices(const mpr_tape* t) { return t ? t->num_choices : 0; }
+int32_t mpr_tape_flags(const mpr_tape* t) { return t ? t->flags : 0; }
+void mpr_tape_free(mpr_tape* t) { delete t; }
+
+/* ---- column partition: longest-processing-time-first deal ---- */
+int mpr_partition_columns(int32_t columns, const float* weights, int32_t nranks, int32_t* owner)
+{
+    if (columns <= 0 || nranks <= 0 || !owner) return mpr::set_error(MPR_ERR_INVALID, "bad partition arguments");
+    MPR_TRY(
+        if (!weights) {
+            for (int32_t c = 0; c < columns; ++c) owner[c] = c % nranks;
+            return MPR_OK;
+        }
+        std::vector<int32_t> order(columns);
+        std::iota(order.begin(), order.end(), 0);
+        /* heaviest first; ties by index so that every rank computes the same deal */
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int32_t a, int32_t b) { return weights[a] > weights[b]; });
+        std::vector<double> load(nranks, 0.0);
+        std::vector<int32_t> cnt(nranks, 0);
+        for (int32_t c : order) {
+            int best = 0;
+            for (int r = 1; r < nranks; ++r) {
+                if (load[r] < load[best] || (load[r] == load[best] && cnt[r] < cnt[best])) best = r;
+            }
+            owner[c] = best;
+            load[best] += weights[c] > 0 ? weights[c] : 0;
+            cnt[best]++;
+        }
+        return MPR_OK;)
+}
+
+}  // extern "C"
