@@ -99,6 +99,8 @@ typedef struct mpr_ctx_options {
     int32_t flags;             /* MPR_CTX_* */
 } mpr_ctx_options;
 #define MPR_CTX_TIMING 1       /* record HIP events around every kernel (mpr_get_timings) */
+#define MPR_CTX_COUNTERS 2     /* accumulate the work counters of mpr_get_counters on the device
+                                  (costs a few atomics per wave: keep off when timing) */
 
 int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out);
 int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out);
@@ -153,14 +155,17 @@ int32_t* mpr_dev_filled(mpr_context* ctx, int32_t stage);
 uint32_t* mpr_dev_normals(mpr_context* ctx);
 void* mpr_ctx_stream(mpr_context* ctx);   /* hipStream_t */
 
-/* Work counters of the last frame; all per frame. */
+/* Work counters of the last frame; all per frame.  tiles_* and voxel_tiles
+ * are always filled; the clause counters need MPR_CTX_COUNTERS. */
 typedef struct mpr_counters {
-    int64_t tiles_in[3];        /* tiles evaluated per tile stage (3-D: 64/16/4 px; 2-D: [0],[2]) */
+    int64_t tiles_in[3];        /* tiles evaluated per tile stage (3-D: 64/16/4 px; 2-D: 64/8 px in [0],[1]) */
     int64_t tiles_active[3];    /* tiles surviving each stage (ambiguous and not masked) */
     int64_t voxel_tiles;        /* smallest tiles handed to the float pass */
     int64_t clauses_fwd;        /* F: clause visits by wave-groups, forward (all passes) */
     int64_t clauses_bwd;        /* R: clause visits by wave-groups, backward (tape push) */
     int64_t clauses_written;    /* W: words written to the pool by tape pushes */
+    int64_t clauses_fwd_voxels; /*    part of F spent in the float voxel/pixel pass */
+    int64_t clauses_fwd_normals;/*    part of F spent in the normals pass */
     int64_t lane_clauses;       /* lane-granular clause evaluations */
     int64_t normal_pixels;      /* pixels evaluated by the normals pass */
     int32_t tape_index;         /* pool words in use after the frame */

@@ -21,6 +21,12 @@
 
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#define MPR_CL_FN __host__ __device__ static inline
+#else
+#define MPR_CL_FN static inline
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -77,19 +83,19 @@ enum mpr_opcode {
 /* src/context.cu:215,257 — at most 256*16 min/max choices are recorded per tile */
 #define MPR_MAX_CHOICES 4096
 
-static inline uint32_t mpr_cl_op(uint64_t c)  { return (uint32_t)(c & 0xFF); }
-static inline uint32_t mpr_cl_out(uint64_t c) { return (uint32_t)((c >> 8) & 0xFF); }
-static inline uint32_t mpr_cl_lhs(uint64_t c) { return (uint32_t)((c >> 16) & 0xFF); }
-static inline uint32_t mpr_cl_rhs(uint64_t c) { return (uint32_t)((c >> 24) & 0xFF); }
-static inline uint32_t mpr_cl_immbits(uint64_t c) { return (uint32_t)(c >> 32); }
-static inline int32_t  mpr_cl_jump(uint64_t c) { return (int32_t)(uint32_t)(c >> 32); }
-static inline uint64_t mpr_cl_make(uint32_t op, uint32_t out, uint32_t lhs, uint32_t rhs,
+MPR_CL_FN uint32_t mpr_cl_op(uint64_t c)  { return (uint32_t)(c & 0xFF); }
+MPR_CL_FN uint32_t mpr_cl_out(uint64_t c) { return (uint32_t)((c >> 8) & 0xFF); }
+MPR_CL_FN uint32_t mpr_cl_lhs(uint64_t c) { return (uint32_t)((c >> 16) & 0xFF); }
+MPR_CL_FN uint32_t mpr_cl_rhs(uint64_t c) { return (uint32_t)((c >> 24) & 0xFF); }
+MPR_CL_FN uint32_t mpr_cl_immbits(uint64_t c) { return (uint32_t)(c >> 32); }
+MPR_CL_FN int32_t mpr_cl_jump(uint64_t c) { return (int32_t)(uint32_t)(c >> 32); }
+MPR_CL_FN uint64_t mpr_cl_make(uint32_t op, uint32_t out, uint32_t lhs, uint32_t rhs,
                                    uint32_t immbits)
 {
     return (uint64_t)(op & 0xFF) | ((uint64_t)(out & 0xFF) << 8) | ((uint64_t)(lhs & 0xFF) << 16) |
            ((uint64_t)(rhs & 0xFF) << 24) | ((uint64_t)immbits << 32);
 }
-static inline int mpr_op_is_minmax(uint32_t op)
+MPR_CL_FN int mpr_op_is_minmax(uint32_t op)
 {   /* src/context.cu:365-366: tested by range */
     return op >= MPR_OP_MIN_LHS_IMM && op <= MPR_OP_MAX_LHS_RHS;
 }

@@ -191,15 +191,18 @@ MPR_HD float mpr_atanf(float x)
     if (mpr_isnanf(x)) return x;
     const uint32_t sign = mpr_f2u(x) & 0x80000000u;
     float a = mpr_u2f(mpr_f2u(x) & 0x7FFFFFFFu);
-    float y;
+    float yhi, ylo;                          /* pi/2 or pi/4 as hi + lo */
     if (a > 2.414213562373095f) {           /* tan(3pi/8) */
-        y = 1.5707963267948966192f;
+        yhi = 1.5707963705062866f;
+        ylo = -4.371139000186243e-8f;
         a = -(1.0f / a);
     } else if (a > 0.4142135623730950f) {   /* tan(pi/8) */
-        y = 0.7853981633974483096f;
+        yhi = 0.7853981852531433f;
+        ylo = -2.1855695000931215e-8f;
         a = (a - 1.0f) / (a + 1.0f);
     } else {
-        y = 0.0f;
+        yhi = 0.0f;
+        ylo = 0.0f;
     }
     const float z = a * a;
     float p = 8.05374449538e-2f;
@@ -207,8 +210,9 @@ MPR_HD float mpr_atanf(float x)
     p = fmaf(p, z, 1.99777106478E-1f);
     p = fmaf(p, z, -3.33329491539E-1f);
     p = (p * z) * a;
+    p = p + ylo;
     p = p + a;
-    y = y + p;
+    const float y = yhi + p;
     return mpr_u2f(mpr_f2u(y) ^ sign);
 }
 
@@ -236,7 +240,7 @@ MPR_HD float mpr_asinf(float x)
         const float s = sqrtf(z);
         r = mpr_asin_poly(s, z);
         r = r + r;
-        r = 1.5707963267948966192f - r;
+        r = (1.5707963705062866f - r) + -4.371139000186243e-8f;   /* pi/2 = hi + lo */
     } else {
         r = mpr_asin_poly(a, a * a);
     }
@@ -250,7 +254,7 @@ MPR_HD float mpr_acosf(float x)
         const float z = 0.5f * (1.0f + x);
         const float s = sqrtf(z);
         const float r = mpr_asin_poly(s, z);
-        return 3.14159265358979323846f - (r + r);
+        return (3.1415927410125732f - (r + r)) + -8.742278000372485e-8f;   /* pi = hi + lo */
     }
     if (x > 0.5f) {
         const float z = 0.5f * (1.0f - x);
@@ -258,7 +262,7 @@ MPR_HD float mpr_acosf(float x)
         const float r = mpr_asin_poly(s, z);
         return r + r;
     }
-    return 1.5707963267948966192f - mpr_asinf(x);
+    return (1.5707963705062866f - mpr_asinf(x)) + -4.371139000186243e-8f;
 }
 
 #endif

@@ -1,0 +1,622 @@
+/*
+ * context.hip — render context and frame drivers (device side of the C ABI).
+ *
+ * Mirrors the role of the reference's mpr::Context (inc/context.hpp:38-73,
+ * src/context.cpp:17-49) and of Context::render2D / render3D / render2D_brute
+ * (src/context.cu:1136-1508): same stage order, same buffers, same results; different
+ * launch structure (see kernels.hip).  Device memory is plain hipMalloc (no managed
+ * memory); results are copied out on request.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpr_amd.h"
+#include "internal.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+struct KernelTiming {
+    const char* name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct mpr_context {
+    int device = 0;
+    int S = 0;
+    int flags = 0;
+    hipStream_t stream = nullptr;
+
+    int* filled[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t filled_n[4] = {0, 0, 0, 0};
+    uint32_t* normals = nullptr;
+
+    uint64_t* pool = nullptr;          /* Context::tape_data */
+    long long pool_cap = 0;
+    int* tape_index = nullptr;         /* Context::tape_index */
+    int* num_active = nullptr;         /* Context::num_active_tiles */
+    unsigned long long* counters = nullptr;
+
+    mpr_tile_node* tiles[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t tiles_cap[4] = {0, 0, 0, 0};
+    size_t tiles_n[4] = {0, 0, 0, 0};
+
+    int* owner_dev = nullptr;          /* column ownership, (S/64)^2 */
+    int* col_list_dev = nullptr;
+    int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
+
+    uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
+    int tape_len = 0;
+
+    mpr_counters last = {};
+    std::vector<KernelTiming> timings;
+    size_t timings_used = 0;
+    bool frame_pending = false;
+    int pending_dim = 0;
+};
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            return mpr::set_error(MPR_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                    \
+    } while (0)
+
+static int ensure_tiles(mpr_context* c, int stage, size_t n)
+{
+    if (n <= c->tiles_cap[stage]) return MPR_OK;
+    /* grow geometrically so that a sequence of frames settles after a few allocations */
+    size_t cap = std::max(n, c->tiles_cap[stage] + c->tiles_cap[stage] / 2);
+    if (c->tiles[stage]) HIP_TRY(hipFree(c->tiles[stage]));
+    c->tiles[stage] = nullptr;
+    c->tiles_cap[stage] = 0;
+    HIP_TRY(hipMalloc((void**)&c->tiles[stage], cap * sizeof(mpr_tile_node)));
+    c->tiles_cap[stage] = cap;
+    return MPR_OK;
+}
+
+struct TimedScope {
+    mpr_context* c;
+    bool on;
+    size_t idx = 0;
+    TimedScope(mpr_context* ctx, const char* name) : c(ctx), on((ctx->flags & MPR_CTX_TIMING) != 0)
+    {
+        if (!on) return;
+        if (c->timings_used == c->timings.size()) {
+            KernelTiming t;
+            t.name = name;
+            if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
+                on = false;
+                return;
+            }
+            c->timings.push_back(t);
+        }
+        idx = c->timings_used++;
+        c->timings[idx].name = name;
+        (void)hipEventRecord(c->timings[idx].start, c->stream);
+    }
+    ~TimedScope()
+    {
+        if (on) (void)hipEventRecord(c->timings[idx].stop, c->stream);
+    }
+};
+
+extern "C" {
+
+int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
+{
+    if (!opt || !out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    const int S = opt->image_size_px;
+    if (S < 64 || S % 64 != 0 || S > 8192)
+        return mpr::set_error(MPR_ERR_INVALID, "image_size_px must be a multiple of 64 in [64, 8192]");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return mpr::set_error(MPR_ERR_NO_DEVICE, std::string("no HIP device available: ") +
+                                                     (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (opt->device < 0 || opt->device >= ndev) return mpr::set_error(MPR_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(opt->device));
+
+    mpr_context* c = new mpr_context();
+    c->device = opt->device;
+    c->S = S;
+    c->flags = opt->flags;
+    c->pool_cap = opt->pool_clauses > 0 ? opt->pool_clauses : (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK;
+    if (c->pool_cap > 0x7FFFFFFFll) c->pool_cap = 0x7FFFFFFFll;   /* tape indices are int32 (inc/context.hpp:25) */
+    *out = nullptr;
+#define CT(expr)                                                     \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) {                                      \
+            mpr::set_error(MPR_ERR_ALLOC, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            mpr_ctx_destroy(c);                                      \
+            return MPR_ERR_ALLOC;                                    \
+        }                                                            \
+    } while (0)
+    CT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) {                        /* src/context.cpp:21-27 */
+        const int ts = 64 >> (2 * i);
+        c->filled_n[i] = (size_t)(S / ts) * (S / ts);
+        CT(hipMalloc((void**)&c->filled[i], c->filled_n[i] * sizeof(int)));
+    }
+    CT(hipMalloc((void**)&c->normals, (size_t)S * S * sizeof(uint32_t)));
+    CT(hipMalloc((void**)&c->pool, (size_t)c->pool_cap * sizeof(uint64_t)));
+    CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
+    CT(hipMalloc((void**)&c->num_active, sizeof(int)));
+    CT(hipMalloc((void**)&c->counters, mprk::CNT_COUNT * sizeof(unsigned long long)));
+    CT(hipMalloc((void**)&c->owner_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
+    CT(hipMalloc((void**)&c->col_list_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
+    CT(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    CT(hipMemsetAsync(c->normals, 0, (size_t)S * S * sizeof(uint32_t), c->stream));
+    for (int i = 0; i < 4; ++i) CT(hipMemsetAsync(c->filled[i], 0, c->filled_n[i] * sizeof(int), c->stream));
+    CT(hipStreamSynchronize(c->stream));
+#undef CT
+    *out = c;
+    return MPR_OK;
+}
+
+int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out)
+{
+    mpr_ctx_options o;
+    std::memset(&o, 0, sizeof(o));
+    o.device = device;
+    o.image_size_px = image_size_px;
+    return mpr_ctx_create_ex(&o, out);
+}
+
+void mpr_ctx_destroy(mpr_context* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 4; ++i) {
+        if (c->filled[i]) (void)hipFree(c->filled[i]);
+        if (c->tiles[i]) (void)hipFree(c->tiles[i]);
+    }
+    if (c->normals) (void)hipFree(c->normals);
+    if (c->pool) (void)hipFree(c->pool);
+    if (c->tape_index) (void)hipFree(c->tape_index);
+    if (c->num_active) (void)hipFree(c->num_active);
+    if (c->counters) (void)hipFree(c->counters);
+    if (c->owner_dev) (void)hipFree(c->owner_dev);
+    if (c->col_list_dev) (void)hipFree(c->col_list_dev);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (auto& t : c->timings) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t mpr_ctx_image_size(const mpr_context* c) { return c ? c->S : 0; }
+
+}  // extern "C"
+
+/* ---- the frame ------------------------------------------------------------------------- */
+static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owner)
+{
+    if (!c || !tape) return mpr::set_error(MPR_ERR_INVALID, "null context or tape");
+    HIP_TRY(hipSetDevice(c->device));
+    const int len = (int)tape->clauses.size();
+    if (len < 2 || (long long)len >= c->pool_cap) return mpr::set_error(MPR_ERR_INVALID, "tape does not fit the pool");
+    if (c->frame_pending) HIP_TRY(hipStreamSynchronize(c->stream));
+    c->frame_pending = false;
+    /* copy the tape to pool[0..len) (src/context.cu:1139-1142); skipped when already resident,
+     * the pool's first len words are never overwritten by pushes */
+    if (c->tape_serial != tape->serial) {
+        HIP_TRY(hipMemcpyAsync(c->pool, tape->clauses.data(), (size_t)len * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   /* pageable source must stay valid */
+        c->tape_serial = tape->serial;
+        c->tape_len = len;
+    }
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->tape_index, len, 1, c->stream));
+    if (c->flags & MPR_CTX_COUNTERS)
+        HIP_TRY(hipMemsetAsync(c->counters, 0, mprk::CNT_COUNT * sizeof(unsigned long long), c->stream));
+    if (owner) {
+        const size_t cols = (size_t)(c->S / 64) * (c->S / 64);
+        HIP_TRY(hipMemcpyAsync(c->owner_dev, owner, cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->timings_used = 0;
+    std::memset(&c->last, 0, sizeof(c->last));
+    for (int i = 0; i < 4; ++i) c->tiles_n[i] = 0;
+    return MPR_OK;
+}
+
+static int read_active(mpr_context* c, int* out)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_pinned, c->num_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c->h_pinned[0];
+    return MPR_OK;
+}
+
+static void fill_mat(float dst[16], const float* src, int n)
+{
+    std::memset(dst, 0, 16 * sizeof(float));
+    std::memcpy(dst, src, (size_t)n * sizeof(float));
+}
+
+static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const float* mat, float z,
+                        const int32_t* owner, int rank, bool brute, bool blocking)
+{
+    int rc = begin_frame(c, tape, owner);
+    if (rc) return rc;
+    if (!mat) return mpr::set_error(MPR_ERR_INVALID, "null matrix");
+    const int S = c->S;
+    hipStream_t s = c->stream;
+    unsigned long long* cnt = (c->flags & MPR_CTX_COUNTERS) ? c->counters : nullptr;
+    const int nslots = std::max(tape->num_slots, 1);
+    const int choice_cap = std::min(tape->num_choices, (int)MPR_MAX_CHOICES);
+    if (tape->num_slots > MPR_KERNEL_SLOTS) c->last.slots_exceeded = 1;
+
+    /* device limits: LDS per workgroup */
+    const size_t lds_limit = 160 * 1024;
+    if (mprk::tile_stage_lds_bytes(nslots, choice_cap) > lds_limit || mprk::normals_lds_bytes(nslots) > lds_limit ||
+        mprk::voxel_lds_bytes(nslots) > lds_limit)
+        return mpr::set_error(MPR_ERR_UNSUPPORTED, "tape needs more LDS than one workgroup can hold");
+
+    /* reset the images (src/context.cu:1146-1151, :1295-1301) */
+    if (dim == 3) {
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipMemsetAsync(c->filled[i], 0, c->filled_n[i] * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(c->normals, 0, (size_t)S * S * sizeof(uint32_t), s));
+    } else if (brute) {
+        HIP_TRY(hipMemsetAsync(c->filled[3], 0, c->filled_n[3] * sizeof(int), s));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->filled[0], 0, c->filled_n[0] * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(c->filled[2], 0, c->filled_n[2] * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(c->filled[3], 0, c->filled_n[3] * sizeof(int), s));
+    }
+
+    int stage_list[3];
+    int nstages = 0;
+    if (brute) nstages = 0;
+    else if (dim == 3) { stage_list[0] = 0; stage_list[1] = 1; stage_list[2] = 2; nstages = 3; }
+    else { stage_list[0] = 0; stage_list[1] = 2; nstages = 2; }
+
+    int count;
+    if (!brute) {
+        const int t0 = S / 64;
+        count = t0 * t0 * (dim == 3 ? t0 : 1);
+        rc = ensure_tiles(c, 0, (size_t)count);
+        if (rc) return rc;
+        TimedScope ts(c, "preload_tiles");
+        mprk::launch_preload(s, c->tiles[0], count, t0 * t0, owner ? c->owner_dev : nullptr, rank);
+        c->tiles_n[0] = (size_t)count;
+    } else {
+        const int t8 = S / 8;
+        count = t8 * t8;
+        rc = ensure_tiles(c, 3, (size_t)count);
+        if (rc) return rc;
+        TimedScope ts(c, "preload_tiles");
+        mprk::launch_preload(s, c->tiles[3], count, count, nullptr, 0);
+        c->tiles_n[3] = (size_t)count;
+    }
+
+    for (int si = 0; si < nstages; ++si) {
+        const int i = stage_list[si];
+        const bool last = (si == nstages - 1);
+        const int next = (dim == 3) ? i + 1 : (i ? 3 : 2);
+        const int sub = (dim == 3) ? 4 : 8;
+        const int tile_size_px = (dim == 3) ? (64 >> (2 * i)) : (i ? 8 : 64);
+        const int tps = S / tile_size_px;
+        c->last.tiles_in[si] = count;
+
+        if (count > 0) {
+            mprk::TileStageArgs a;
+            a.tape_ro = c->pool;
+            a.tape_wr = c->pool;
+            a.tape_index = c->tape_index;
+            a.pool_cap = c->pool_cap;
+            a.image = c->filled[i];
+            a.tps = tps;
+            a.tiles = c->tiles[i];
+            a.count = count;
+            a.nslots = nslots;
+            a.choice_cap = choice_cap;
+            a.z = z;
+            fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
+            a.counters = cnt;
+            TimedScope ts(c, "eval_tiles_i");
+            mprk::launch_eval_tiles(s, dim, a);
+        }
+        HIP_TRY(hipMemsetAsync(c->num_active, 0, sizeof(int), s));
+        /* worst case: every tile survives */
+        rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
+        if (rc) return rc;
+        if (count > 0) {
+            TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
+            mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next]);
+        }
+        int active = 0;
+        rc = read_active(c, &active);      /* the reference's blocking read-back (:1209, :1375) */
+        if (rc) return rc;
+        c->last.tiles_active[si] = active;
+        {
+            TimedScope ts(c, "copy_filled");
+            mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
+        }
+        count = last ? active : active * 64;
+        c->tiles_n[next] = (size_t)count;
+    }
+
+    c->last.voxel_tiles = count;
+    if (count > 0) {
+        mprk::VoxelArgs v;
+        v.tape_ro = c->pool;
+        v.image = c->filled[3];
+        v.tps = S / (dim == 3 ? 4 : 8);
+        v.tiles = c->tiles[3];
+        v.count = count;
+        v.nslots = nslots;
+        v.z = z;
+        fill_mat(v.mat, mat, dim == 3 ? 16 : 9);
+        v.counters = cnt;
+        TimedScope ts(c, "eval_voxels_f");
+        mprk::launch_eval_voxels(s, dim, v);
+    }
+    if (dim == 3) {
+        mprk::NormalArgs n;
+        n.tape_ro = c->pool;
+        n.image = c->filled[3];
+        n.output = c->normals;
+        n.size = S;
+        n.nslots = nslots;
+        fill_mat(n.mat, mat, 16);
+        n.tiles = c->tiles[0];
+        n.subtiles = c->tiles[1];
+        n.microtiles = c->tiles[2];
+        n.counters = cnt;
+        TimedScope ts(c, "eval_pixels_d");
+        mprk::launch_eval_normals(s, n);
+    }
+    HIP_TRY(hipGetLastError());
+    c->frame_pending = true;
+    c->pending_dim = dim;
+    if (blocking) return mpr_ctx_sync(c);
+    return MPR_OK;
+}
+
+extern "C" {
+
+int mpr_ctx_sync(mpr_context* c)
+{
+    if (!c) return mpr::set_error(MPR_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->frame_pending = false;
+    return MPR_OK;
+}
+
+int mpr_render2d(mpr_context* c, const mpr_tape* t, const float m[9], float z)
+{
+    return render_frame(c, t, 2, m, z, nullptr, 0, false, true);
+}
+int mpr_render3d(mpr_context* c, const mpr_tape* t, const float m[16])
+{
+    return render_frame(c, t, 3, m, 0.0f, nullptr, 0, false, true);
+}
+int mpr_render2d_brute(mpr_context* c, const mpr_tape* t, const float m[9], float z)
+{
+    return render_frame(c, t, 2, m, z, nullptr, 0, true, true);
+}
+int mpr_render2d_async(mpr_context* c, const mpr_tape* t, const float m[9], float z)
+{
+    return render_frame(c, t, 2, m, z, nullptr, 0, false, false);
+}
+int mpr_render3d_async(mpr_context* c, const mpr_tape* t, const float m[16])
+{
+    return render_frame(c, t, 3, m, 0.0f, nullptr, 0, false, false);
+}
+int mpr_render3d_part(mpr_context* c, const mpr_tape* t, const float m[16], const int32_t* owner, int32_t rank)
+{
+    if (!owner) return mpr::set_error(MPR_ERR_INVALID, "null owner table");
+    return render_frame(c, t, 3, m, 0.0f, owner, rank, false, true);
+}
+int mpr_render2d_part(mpr_context* c, const mpr_tape* t, const float m[9], float z, const int32_t* owner, int32_t rank)
+{
+    if (!owner) return mpr::set_error(MPR_ERR_INVALID, "null owner table");
+    return render_frame(c, t, 2, m, z, owner, rank, false, true);
+}
+
+static int column_list(mpr_context* c, const int32_t* owner, int rank, int capacity, int* ncols)
+{
+    const int cols = (c->S / 64) * (c->S / 64);
+    std::vector<int> list;
+    for (int i = 0; i < cols; ++i) if (owner[i] == rank) list.push_back(i);
+    if ((int)list.size() > capacity) return mpr::set_error(MPR_ERR_INVALID, "capacity_cols too small for this rank");
+    *ncols = (int)list.size();
+    if (!list.empty()) {
+        HIP_TRY(hipMemcpyAsync(c->col_list_dev, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MPR_OK;
+}
+
+int mpr_pack_columns(mpr_context* c, const int32_t* owner, int32_t rank, int32_t capacity_cols,
+                     int32_t with_normals, void* dev_out)
+{
+    if (!c || !owner || !dev_out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int ncols = 0;
+    int rc = column_list(c, owner, rank, capacity_cols, &ncols);
+    if (rc) return rc;
+    mprk::launch_pack(c->stream, c->filled[3], c->normals, c->S, c->col_list_dev, ncols, capacity_cols, with_normals, (int*)dev_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPR_OK;
+}
+int mpr_unpack_columns(mpr_context* c, const int32_t* owner, int32_t rank, int32_t capacity_cols,
+                       int32_t with_normals, const void* dev_in)
+{
+    if (!c || !owner || !dev_in) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int ncols = 0;
+    int rc = column_list(c, owner, rank, capacity_cols, &ncols);
+    if (rc) return rc;
+    mprk::launch_unpack(c->stream, c->filled[3], c->normals, c->S, c->col_list_dev, ncols, capacity_cols, with_normals, (const int*)dev_in);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPR_OK;
+}
+
+/* ---- results ---- */
+int mpr_read_filled(mpr_context* c, int32_t stage, int32_t* host)
+{
+    if (!c || !host || stage < 0 || stage > 3) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->filled[stage], c->filled_n[stage] * sizeof(int), hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int mpr_read_normals(mpr_context* c, uint32_t* host)
+{
+    if (!c || !host) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host, c->normals, (size_t)c->S * c->S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int mpr_read_tiles(mpr_context* c, int32_t stage, mpr_tile_node* host, size_t cap, size_t* n)
+{
+    if (!c || stage < 0 || stage > 3 || !n) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n = c->tiles_n[stage];
+    if (host) {
+        const size_t m = std::min(cap, c->tiles_n[stage]);
+        if (m) HIP_TRY(hipMemcpy(host, c->tiles[stage], m * sizeof(mpr_tile_node), hipMemcpyDeviceToHost));
+    }
+    return MPR_OK;
+}
+int mpr_read_tape_pool(mpr_context* c, uint64_t* host, size_t cap, int32_t* tape_index)
+{
+    if (!c || !tape_index) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int ti = 0;
+    HIP_TRY(hipMemcpy(&ti, c->tape_index, sizeof(int), hipMemcpyDeviceToHost));
+    *tape_index = ti;
+    if (host) {
+        const size_t m = std::min<size_t>(cap, (size_t)std::min<long long>(std::max(ti, 0), c->pool_cap));
+        if (m) HIP_TRY(hipMemcpy(host, c->pool, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return MPR_OK;
+}
+int32_t* mpr_dev_filled(mpr_context* c, int32_t stage) { return (c && stage >= 0 && stage <= 3) ? c->filled[stage] : nullptr; }
+uint32_t* mpr_dev_normals(mpr_context* c) { return c ? c->normals : nullptr; }
+void* mpr_ctx_stream(mpr_context* c) { return c ? (void*)c->stream : nullptr; }
+
+int mpr_get_counters(mpr_context* c, mpr_counters* out)
+{
+    if (!c || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int ti = 0;
+    HIP_TRY(hipMemcpy(&ti, c->tape_index, sizeof(int), hipMemcpyDeviceToHost));
+    c->last.tape_index = ti;
+    if (c->flags & MPR_CTX_COUNTERS) {
+        unsigned long long h[mprk::CNT_COUNT];
+        HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+        c->last.clauses_fwd = (int64_t)h[mprk::CNT_FWD];
+        c->last.clauses_bwd = (int64_t)h[mprk::CNT_BWD];
+        c->last.clauses_written = (int64_t)h[mprk::CNT_WRITTEN];
+        c->last.lane_clauses = (int64_t)h[mprk::CNT_LANE];
+        c->last.clauses_fwd_voxels = (int64_t)h[mprk::CNT_FWD_VOX];
+        c->last.clauses_fwd_normals = (int64_t)h[mprk::CNT_FWD_NORM];
+        c->last.normal_pixels = (int64_t)h[mprk::CNT_NORMAL_PX];
+        c->last.pool_overflowed = h[mprk::CNT_OVERFLOW] ? 1 : 0;
+    }
+    if ((long long)ti >= c->pool_cap) c->last.pool_overflowed = 1;
+    *out = c->last;
+    return MPR_OK;
+}
+
+int mpr_get_timings(mpr_context* c, const char** names, float* ms, int32_t cap, int32_t* n)
+{
+    if (!c || !n) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int32_t k = 0;
+    for (size_t i = 0; i < c->timings_used && k < cap; ++i, ++k) {
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, c->timings[i].start, c->timings[i].stop));
+        if (names) names[k] = c->timings[i].name;
+        if (ms) ms[k] = t;
+    }
+    *n = k;
+    return MPR_OK;
+}
+
+/* ---- primitive self-tests ---- */
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+};
+}  // namespace
+
+int mpr_test_interval_op(int32_t device, int32_t op, int32_t n, const float* a_lo, const float* a_hi,
+                         const float* b_lo, const float* b_hi, float imm, float* out_lo, float* out_hi,
+                         int32_t* out_choice)
+{
+    if (n <= 0 || !a_lo || !a_hi || !out_lo || !out_hi) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)n * 4;
+    DevBuf al, ah, bl, bh, ol, oh, ch;
+    HIP_TRY(al.alloc(bytes)); HIP_TRY(ah.alloc(bytes)); HIP_TRY(bl.alloc(bytes)); HIP_TRY(bh.alloc(bytes));
+    HIP_TRY(ol.alloc(bytes)); HIP_TRY(oh.alloc(bytes)); HIP_TRY(ch.alloc(bytes));
+    HIP_TRY(hipMemcpy(al.p, a_lo, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ah.p, a_hi, bytes, hipMemcpyHostToDevice));
+    if (b_lo) HIP_TRY(hipMemcpy(bl.p, b_lo, bytes, hipMemcpyHostToDevice));
+    if (b_hi) HIP_TRY(hipMemcpy(bh.p, b_hi, bytes, hipMemcpyHostToDevice));
+    mprk::launch_test_interval(nullptr, op, n, (float*)al.p, (float*)ah.p, b_lo ? (float*)bl.p : nullptr,
+                               b_hi ? (float*)bh.p : nullptr, imm, (float*)ol.p, (float*)oh.p, (int*)ch.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
+    if (out_choice) HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, const float* b, float imm, float* out)
+{
+    if (n <= 0 || !a || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)n * 4;
+    DevBuf da, db, dout;
+    HIP_TRY(da.alloc(bytes)); HIP_TRY(db.alloc(bytes)); HIP_TRY(dout.alloc(bytes));
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    mprk::launch_test_float(nullptr, op, n, (float*)da.p, b ? (float*)db.p : nullptr, imm, (float*)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4, float imm, float* out4)
+{
+    if (n <= 0 || !a4 || !out4) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)n * 16;
+    DevBuf da, db, dout;
+    HIP_TRY(da.alloc(bytes)); HIP_TRY(db.alloc(bytes)); HIP_TRY(dout.alloc(bytes));
+    HIP_TRY(hipMemcpy(da.p, a4, bytes, hipMemcpyHostToDevice));
+    if (b4) HIP_TRY(hipMemcpy(db.p, b4, bytes, hipMemcpyHostToDevice));
+    mprk::launch_test_deriv(nullptr, op, n, (float*)da.p, b4 ? (float*)db.p : nullptr, imm, (float*)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out4, dout.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+
+}  // extern "C"

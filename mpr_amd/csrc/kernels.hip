@@ -1,0 +1,802 @@
+/*
+ * kernels.hip — gfx950 kernels of the hierarchical tape-evaluation renderer.
+ *
+ * Design (not a translation of the reference's CUDA kernels, src/context.cu:45-1132):
+ *
+ *  - ONE WAVE64 = ONE GROUP THAT SHARES A TAPE.  subdivide writes the 64 children of a tile
+ *    contiguously and they inherit its tape (reference :590, :619), stage 0 shares tape 0,
+ *    so 64 consecutive list entries always walk the same tape.  A wave therefore fetches each
+ *    clause ONCE through the scalar path (s_load via a wave-uniform pointer), decodes it on
+ *    the SALU and dispatches with scalar branches; the 64 lanes are 64 tiles (interval
+ *    stages), the 64 voxels / pixels of one smallest tile (float pass), or 64 pixels of an
+ *    8x8 patch (normals).  The reference's one-thread-per-tile / 32-threads-per-tile layouts
+ *    are warp-32 artefacts and are not reproduced.
+ *  - slot files live in LDS, structure-of-arrays `slot[s][lane]` (8 B, 4 B or 16 B per lane:
+ *    conflict-free ds_read_b64 / b32 / b128), sized by the tape's real slot count instead of
+ *    a fixed 128.
+ *  - choices and the backward "active" set are kept TRANSPOSED: per min/max clause two
+ *    64-bit lane masks (who chose lhs / rhs, from __ballot), per slot one 64-bit lane mask
+ *    (for whom the slot is live).  The backward walk of tape pushing is then scalar mask
+ *    arithmetic; only the final 8-byte store of a surviving clause is per lane.
+ *  - sub-tape chunks are claimed with one wave-aggregated atomic per event (ballot + prefix),
+ *    compaction uses ballot + mbcnt + one atomic per wave and writes the children in the same
+ *    kernel; calculate_intervals / calculate_voxels / mask_filled_tiles are fused into their
+ *    consumers (the reference split them only to stay under 32 registers on NVIDIA, :69-76).
+ *
+ * The sub-tape format in HBM is the reference's (64-clause chunks, embedded JUMP links,
+ * :340-458) so a tape pool read back from the device is interchangeable.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace mprk {
+
+struct int4_ { int x, y, z, w; };
+/* src/context.cu:23-30 */
+DEV int4_ unpack(int pos, int tps)
+{
+    int4_ r;
+    r.x = pos % tps;
+    r.y = (pos / tps) % tps;
+    r.z = (pos / tps) / tps;
+    r.w = pos % (tps * tps);
+    return r;
+}
+
+DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+DEV uint64_t ballot(bool p) { return __ballot(p); }
+DEV int rank_in(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
+DEV uint64_t rfl64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+DEV float immf(uint64_t d) { return mpr_u2f((uint32_t)(d >> 32)); }
+
+/* ------------------------------------------------------------------------------------ */
+/* preload_tiles — reference :45-57, plus column ownership for the multi-GPU mode        */
+/* ------------------------------------------------------------------------------------ */
+__global__ void k_preload_tiles(mpr_tile_node* __restrict__ tiles, int count, int cols,
+                                const int* __restrict__ owner, int rank)
+{
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= count) return;
+    mpr_tile_node n;
+    n.position = i;
+    n.tape = 0;
+    n.next = -1;
+    if (owner && owner[i % cols] != rank) n.position = -1;
+    tiles[i] = n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* eval_tiles_i — interval walk + classification + tape pushing (reference :188-459),    */
+/* with calculate_intervals (:78-159) and the first mask_filled_tiles (:471-495) fused   */
+/* ------------------------------------------------------------------------------------ */
+template <int DIM>
+__global__ void __launch_bounds__(64)
+k_eval_tiles(TileStageArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* const slots = reinterpret_cast<float2*>(smem);                       /* [nslots][64] */
+    uint64_t* const act = reinterpret_cast<uint64_t*>(smem + (size_t)a.nslots * 512);     /* [256] */
+    ulonglong2* const choices = reinterpret_cast<ulonglong2*>(smem + (size_t)a.nslots * 512 + 2048);
+
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    uint64_t* __restrict__ const twr = a.tape_wr;
+
+    const int lane = threadIdx.x;
+    const int gidx = blockIdx.x * 64 + lane;
+    const bool valid = gidx < a.count;
+    mpr_tile_node node;
+    node.position = -1;
+    node.tape = 0;
+    node.next = -1;
+    if (valid) node = a.tiles[gidx];
+    bool alive = valid && node.position != -1;
+    int4_ pos = unpack(alive ? node.position : 0, a.tps);
+
+    /* mask_filled_tiles before evaluation (3-D) */
+    if (DIM == 3 && alive) {
+        if (a.image[pos.w] > pos.z) {
+            alive = false;
+            a.tiles[gidx].position = -1;
+        }
+    }
+    const uint64_t alive_mask = ballot(alive);
+    if (alive_mask == 0) return;
+    const int leader = __ffsll((long long)alive_mask) - 1;
+    const int tape = __builtin_amdgcn_readlane(node.tape, leader);
+
+    /* tile corners in round-to-nearest (reference :91-96) */
+    const float t = (float)a.tps;
+    float c0 = (pos.x / t - 0.5f) * 2.0f, c1 = ((pos.x + 1) / t - 0.5f) * 2.0f;
+    float c2 = (pos.y / t - 0.5f) * 2.0f, c3 = ((pos.y + 1) / t - 0.5f) * 2.0f;
+    float c4 = 0.0f, c5 = 0.0f;
+    if (DIM == 3) {
+        c4 = (pos.z / t - 0.5f) * 2.0f;
+        c5 = ((pos.z + 1) / t - 0.5f) * 2.0f;
+    }
+    round_up_begin(c0, c1, c2, c3, c4, c5);
+    /* ---- from here on: f32 round-up mode, rounded f32 arithmetic only through device_math ---- */
+
+    ival ix = iv(c0, c1), iy = iv(c2, c3), iz = iv(c4, c5);
+    ival vx, vy, vz;
+    if (DIM == 3) {
+        ival r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[i] = i_add_f(i_add(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 4])),
+                                 i_mul_f(iz, a.mat[i + 8])), a.mat[i + 12]);
+        }
+        vx = i_div(r[0], r[3]);
+        vy = i_div(r[1], r[3]);
+        vz = i_div(r[2], r[3]);
+    } else {
+        ival r[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            r[i] = i_add_f(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 3])), a.mat[i + 6]);
+        }
+        vx = i_div(r[0], r[2]);
+        vy = i_div(r[1], r[2]);
+        vz = iv(a.z, a.z);
+    }
+
+    const uint64_t head0 = tro[0];
+    slots[((head0 >> 8) & 0xFF) * 64 + lane] = make_float2(vx.lo, vx.hi);
+    slots[((head0 >> 16) & 0xFF) * 64 + lane] = make_float2(vy.lo, vy.hi);
+    slots[((head0 >> 24) & 0xFF) * 64 + lane] = make_float2(vz.lo, vz.hi);
+
+    /* ---- forward walk ---- */
+    const uint64_t* data = tro + tape;
+    int ci = 0;
+    uint64_t any_choice = 0;
+    int fwd_words = 0, nclauses = 0;
+    for (;;) {
+        const uint64_t d = *++data;
+        ++fwd_words;
+        const uint32_t op = (uint32_t)d & 0xFF;
+        if (!op) break;
+        if (op == MPR_OP_JUMP) {
+            data += (int32_t)(d >> 32);
+            continue;
+        }
+        const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+        const float2 lv = slots[l * 64 + lane];
+        const float2 rv = slots[r * 64 + lane];
+        int c = 0;
+        const ival out = interval_clause(op, iv(lv.x, lv.y), iv(rv.x, rv.y), immf(d), c);
+        slots[o * 64 + lane] = make_float2(out.lo, out.hi);
+        ++nclauses;
+        if (mpr_op_is_minmax(op)) {
+            const uint64_t m1 = ballot(c == 1) & alive_mask;
+            const uint64_t m2 = ballot(c == 2) & alive_mask;
+            if (ci < a.choice_cap && lane == 0) choices[ci] = make_ulonglong2(m1, m2);
+            ++ci;
+            any_choice |= m1 | m2;
+        }
+    }
+    const uint64_t end_clause = *data;
+    const uint32_t i_out = (uint32_t)(end_clause >> 8) & 0xFF;
+    const float2 res = slots[i_out * 64 + lane];
+
+    /* ---- classification (reference :293-321) ---- */
+    bool ambiguous = false;
+    if (alive) {
+        if (res.x > 0.0f) {                                   /* empty */
+            a.tiles[gidx].position = -1;
+        } else if (DIM == 3 && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
+            a.tiles[gidx].position = -1;                      /* masked */
+        } else if (res.y < 0.0f) {                            /* filled */
+            a.tiles[gidx].position = -1;
+            if (DIM == 3) atomicMax(&a.image[pos.w], pos.z);
+            else a.image[pos.w] = 1;
+        } else {
+            ambiguous = true;
+        }
+    }
+    const bool push = ambiguous && ((any_choice >> lane) & 1);
+    uint64_t live = ballot(push);     /* lanes still writing a tape */
+
+    long long written = 0;
+    int bwd_words = 0;
+    bool overflow = false;
+    if (live != 0) {
+        /* ---- tape pushing (reference :323-458) ---- */
+        for (int i = lane; i < 256; i += 64) act[i] = 0;
+        __syncthreads();
+
+        int out_index = 0, out_offset = 0;
+        {   /* claim the first chunk of every pushing lane with one atomic */
+            const int cnt = __popcll(live);
+            int base = 0;
+            int cur = 0;
+            if (lane == 0) cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            bool ok = (long long)cur < a.pool_cap;
+            if (ok) {
+                if (lane == 0) base = atomicAdd(a.tape_index, MPR_SUBTAPE_CHUNK * cnt);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            if (push) {
+                out_index = base + MPR_SUBTAPE_CHUNK * rank_in(live, lane);
+                out_offset = MPR_SUBTAPE_CHUNK;
+                if (!ok || (long long)out_index + out_offset >= a.pool_cap) overflow = true;
+            }
+            live &= ~ballot(overflow);
+        }
+        bool writing = push && !overflow;
+        if (writing) {
+            out_offset--;
+            twr[out_index + out_offset] = end_clause;
+            written++;
+        }
+        if (lane == 0) act[i_out] = live;
+        __syncthreads();
+
+        for (;;) {
+            const uint64_t d = *--data;
+            ++bwd_words;
+            const uint32_t op = (uint32_t)d & 0xFF;
+            if (!op) break;
+            if (op == MPR_OP_JUMP) {
+                data += (int32_t)(d >> 32);
+                continue;
+            }
+            const bool has_choice = mpr_op_is_minmax(op);
+            ci -= has_choice ? 1 : 0;
+            const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+            uint64_t am = rfl64(act[o]) & live;
+            if (am == 0) continue;
+
+            uint64_t m1 = 0, m2 = 0;
+            if (has_choice && ci < a.choice_cap) {
+                const ulonglong2 ch = choices[ci];
+                m1 = rfl64(ch.x);
+                m2 = rfl64(ch.y);
+            }
+            const bool mine = (am >> lane) & 1;
+            if (mine) --out_offset;
+            const bool need = mine && out_offset == 0;
+            const uint64_t need_mask = ballot(need);
+            if (need_mask) {
+                /* chunk full: claim the next ones and write both links (reference :384-413) */
+                const int cnt = __popcll(need_mask);
+                int base = 0, cur = 0;
+                if (lane == 0) cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur = __builtin_amdgcn_readfirstlane(cur);
+                const bool ok = (long long)cur < a.pool_cap;
+                if (ok) {
+                    if (lane == 0) base = atomicAdd(a.tape_index, MPR_SUBTAPE_CHUNK * cnt);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                }
+                if (need) {
+                    const int prev_index = out_index;
+                    out_index = base + MPR_SUBTAPE_CHUNK * rank_in(need_mask, lane);
+                    out_offset = MPR_SUBTAPE_CHUNK;
+                    if (!ok || (long long)out_index + out_offset >= a.pool_cap) {
+                        overflow = true;
+                        writing = false;
+                    } else {
+                        --out_offset;
+                        const int delta = prev_index - (out_index + out_offset);
+                        twr[out_index + out_offset] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)delta << 32);
+                        twr[prev_index] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)(-delta) << 32);
+                        written += 2;
+                        --out_offset;
+                    }
+                }
+                const uint64_t lost = ballot(need && overflow);
+                live &= ~lost;
+                am &= ~lost;
+            }
+
+            /* scalar bookkeeping of the active sets */
+            const uint64_t a1 = am & m1, a2 = am & m2, a0 = am & ~(m1 | m2);
+            if (lane == 0) {
+                act[o] = 0;
+                if (a0) {
+                    if (l) act[l] |= a0;
+                    if (r) act[r] |= a0;
+                }
+                if (a1) act[l] |= a1;
+                if (a2 && r) act[r] |= a2;
+            }
+            __syncthreads();
+
+            if (mine && writing) {
+                uint64_t w = d;
+                bool emit = true;
+                if ((a1 >> lane) & 1) {
+                    if (l == o) { ++out_offset; emit = false; }
+                    else w = (d & ~0xFFull) | MPR_OP_COPY_LHS;
+                } else if ((a2 >> lane) & 1) {
+                    if (r) {
+                        if (r == o) { ++out_offset; emit = false; }
+                        else w = (d & ~0xFFull) | MPR_OP_COPY_RHS;
+                    } else {
+                        w = (d & ~0xFFull) | MPR_OP_COPY_IMM;
+                    }
+                }
+                if (emit) {
+                    twr[out_index + out_offset] = w;
+                    written++;
+                }
+            }
+        }
+        if (writing) {
+            out_offset--;
+            twr[out_index + out_offset] = *data;     /* head: copy of the parent's head */
+            written++;
+            a.tiles[gidx].tape = out_index + out_offset;
+        }
+    }
+
+    if (a.counters) {
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)fwd_words);
+            atomicAdd((unsigned long long*)&a.counters[CNT_BWD], (unsigned long long)bwd_words);
+            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)nclauses * __popcll(alive_mask));
+        }
+        if (written) atomicAdd((unsigned long long*)&a.counters[CNT_WRITTEN], (unsigned long long)written);
+        if (overflow) a.counters[CNT_OVERFLOW] = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* second mask_filled_tiles + assign_next_nodes + subdivide / copy_active_tiles          */
+/* (reference :471-651) in one pass: ballot + prefix + one atomic per wave               */
+/* ------------------------------------------------------------------------------------ */
+template <int DIM, bool LAST>
+__global__ void __launch_bounds__(256)
+k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
+                    const int* __restrict__ image, int* __restrict__ num_active,
+                    mpr_tile_node* __restrict__ out)
+{
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = gidx < count;
+    mpr_tile_node n;
+    n.position = -1;
+    n.tape = 0;
+    n.next = -1;
+    if (valid) n = tiles[gidx];
+    bool active = valid && n.position != -1;
+    if (DIM == 3 && active) {
+        const int4_ p = unpack(n.position, tps);
+        if (image[p.w] > p.z) {
+            active = false;
+            tiles[gidx].position = -1;
+        }
+    }
+    const uint64_t mask = ballot(active);
+    int base = 0;
+    if (mask) {
+        if (lane == 0) base = atomicAdd(num_active, __popcll(mask));
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    const int next = active ? base + rank_in(mask, lane) : -1;
+    if (valid) tiles[gidx].next = LAST ? -1 : next;   /* copy_active_tiles resets next (:650) */
+    if (LAST) {
+        if (active) {
+            mpr_tile_node o;
+            o.position = n.position;
+            o.tape = n.tape;
+            o.next = -1;
+            out[next] = o;
+        }
+        return;
+    }
+    /* every active tile -> 64 children, written by the whole wave (768 B contiguous) */
+    uint64_t todo = mask;
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    const int sps = tps * SUB;
+    const int4_ sp = unpack(lane, SUB);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ppos = __builtin_amdgcn_readlane(n.position, src);
+        const int ptape = __builtin_amdgcn_readlane(n.tape, src);
+        const int pnext = __builtin_amdgcn_readlane(next, src);
+        const int4_ p = unpack(ppos, tps);
+        mpr_tile_node o;
+        if (DIM == 3) o.position = (p.x * 4 + sp.x) + (p.y * 4 + sp.y) * sps + (p.z * 4 + sp.z) * sps * sps;
+        else o.position = (p.x * 8 + sp.x) + (p.y * 8 + sp.y) * sps;
+        o.tape = ptape;
+        o.next = -1;
+        out[(size_t)pnext * 64 + lane] = o;
+    }
+}
+
+/* copy_filled — reference :664-692 */
+template <int DIM>
+__global__ void k_copy_filled(const int* __restrict__ prev, int* __restrict__ image, int size)
+{
+    const int x = threadIdx.x + blockIdx.x * blockDim.x;
+    const int y = threadIdx.y + blockIdx.y * blockDim.y;
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    if (x < size && y < size) {
+        const int t = prev[x / SUB + (y / SUB) * (size / SUB)];
+        if (t) image[x + y * size] = (DIM == 3) ? t * 4 + 3 : 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* eval_voxels_f with calculate_voxels / calculate_pixels fused (reference :707-964)     */
+/* one wave = the 64 voxels (4x4x4) or pixels (8x8) of one smallest tile                 */
+/* ------------------------------------------------------------------------------------ */
+template <int DIM>
+__global__ void __launch_bounds__(256)
+k_eval_voxels(VoxelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    float* const slots = reinterpret_cast<float*>(smem) + (size_t)wave * a.nslots * 64;
+
+    const int tile_index = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (tile_index >= a.count) return;
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const int position = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].position);
+    const int tape = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].tape);
+
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    const int S = a.tps * SUB;
+    const int4_ pos = unpack(position, a.tps);
+    const int4_ sub = unpack(lane, SUB);
+    const int px = pos.x * SUB + sub.x;
+    const int py = pos.y * SUB + sub.y;
+    const int pz = (DIM == 3) ? pos.z * 4 + sub.z : 0;
+
+    bool skip = false;
+    if (DIM == 3) {
+        /* reference :852-864: the thread owning (pz_low, pz_low + 2) leaves when image >= pz_low + 2 */
+        const int pz_low = pos.z * 4 + (sub.z & 1);
+        skip = a.image[px + py * S] >= pz_low + 2;
+        if (ballot(!skip) == 0) return;
+    }
+
+    const float size_recip = 1.0f / (float)(unsigned)(a.tps * SUB);
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    float vx, vy, vz;
+    if (DIM == 3) {
+        const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+        const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+        vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+        vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+        vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+    } else {
+        const float fw = a.mat[2] * fx + a.mat[5] * fy + a.mat[8];
+        vx = (a.mat[0] * fx + a.mat[3] * fy + a.mat[6]) / fw;
+        vy = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
+        vz = a.z;
+    }
+    const uint64_t head0 = tro[0];
+    slots[((head0 >> 8) & 0xFF) * 64 + lane] = vx;
+    slots[((head0 >> 16) & 0xFF) * 64 + lane] = vy;
+    slots[((head0 >> 24) & 0xFF) * 64 + lane] = vz;
+
+    const uint64_t* data = tro + tape;
+    int words = 0, nclauses = 0;
+    for (;;) {
+        const uint64_t d = *++data;
+        ++words;
+        const uint32_t op = (uint32_t)d & 0xFF;
+        if (!op) break;
+        if (op == MPR_OP_JUMP) {
+            data += (int32_t)(d >> 32);
+            continue;
+        }
+        const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+        const float lv = slots[l * 64 + lane];
+        const float rv = slots[r * 64 + lane];
+        slots[o * 64 + lane] = float_clause(op, lv, rv, immf(d));
+        ++nclauses;
+    }
+    const uint32_t i_out = (uint32_t)(*data >> 8) & 0xFF;
+    const float res = slots[i_out * 64 + lane];
+    if (!skip && res < 0.0f) {
+        if (DIM == 3) {
+            int* p = &a.image[px + py * S];
+            if (*p < pz) atomicMax(p, pz);
+        } else {
+            a.image[px + py * S] = 1;
+        }
+    }
+    if (a.counters && lane == 0) {
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words);
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD_VOX], (unsigned long long)words);
+        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)nclauses * 64ull);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* eval_pixels_d — normals by forward-mode AD (reference :978-1132)                      */
+/* one wave = an 8x8 pixel patch; lanes are grouped by the tape they need               */
+/* ------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(64)
+k_eval_normals(NormalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* const slots = reinterpret_cast<float4*>(smem);     /* [nslots][64] (dx,dy,dz,v) */
+    const int lane = threadIdx.x;
+    const int S = a.size;
+    const int patches = S / 8;
+    const int px = (blockIdx.x % patches) * 8 + (lane & 7);
+    const int py = (blockIdx.x / patches) * 8 + (lane >> 3);
+    const int pxy = px + py * S;
+    int pz = a.image[pxy];
+    const bool filled = pz != 0;
+    uint64_t todo = ballot(filled);
+    if (todo == 0) return;
+    if (pz < S - 1) pz += 1;                                   /* :1003-1005 */
+
+    const float size_recip = 1.0f / (float)(unsigned)S;
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+    const float vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+    const float vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+    const float vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+
+    /* deepest tile's tape (:1034-1066) */
+    int my_tape = 0;
+    if (filled) {
+        const int t64 = S / 64;
+        const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
+        const mpr_tile_node tn = a.tiles[tile];
+        if (tn.next == -1) {
+            my_tape = tn.tape;
+        } else {
+            const int subtile = tn.next * 64 + (px % 64) / 16 + ((py % 64) / 16) * 4 + ((pz % 64) / 16) * 16;
+            const mpr_tile_node sn = a.subtiles[subtile];
+            if (sn.next == -1) {
+                my_tape = sn.tape;
+            } else {
+                const int micro = sn.next * 64 + (px % 16) / 4 + ((py % 16) / 4) * 4 + ((pz % 16) / 4) * 16;
+                my_tape = a.microtiles[micro].tape;
+            }
+        }
+    }
+
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const uint64_t head0 = tro[0];
+    const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
+    deriv result = d_const(0.0f);
+    long long words_total = 0;
+    long long lane_clauses = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int tape = __builtin_amdgcn_readlane(my_tape, leader);
+        const bool mine = filled && my_tape == tape;
+        const uint64_t grp = ballot(mine);
+        todo &= ~grp;
+
+        /* :1021-1031 — value first, then the unit partials (unused axes alias slot 0) */
+        slots[sx * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vx);
+        slots[sy * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vy);
+        slots[sz * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vz);
+        slots[sx * 64 + lane].x = 1.0f;
+        slots[sy * 64 + lane].y = 1.0f;
+        slots[sz * 64 + lane].z = 1.0f;
+
+        const uint64_t* data = tro + tape;
+        int words = 0, ncl = 0;
+        for (;;) {
+            const uint64_t d = *++data;
+            ++words;
+            const uint32_t op = (uint32_t)d & 0xFF;
+            if (!op) break;
+            if (op == MPR_OP_JUMP) {
+                data += (int32_t)(d >> 32);
+                continue;
+            }
+            const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+            const float4 lv = slots[l * 64 + lane];
+            const float4 rv = slots[r * 64 + lane];
+            const deriv out = deriv_clause(op, dv(lv.w, lv.x, lv.y, lv.z), dv(rv.w, rv.x, rv.y, rv.z), immf(d));
+            slots[o * 64 + lane] = make_float4(out.dx, out.dy, out.dz, out.v);
+            ++ncl;
+        }
+        const uint32_t i_out = (uint32_t)(*data >> 8) & 0xFF;
+        const float4 rr = slots[i_out * 64 + lane];
+        if (mine) result = dv(rr.w, rr.x, rr.y, rr.z);
+        words_total += words;
+        lane_clauses += (long long)ncl * __popcll(grp);
+    }
+
+    if (filled) {
+        /* :1123-1131 */
+        const float norm = __builtin_sqrtf(result.dx * result.dx + result.dy * result.dy + result.dz * result.dz);
+        const uint32_t dx = f2u8((result.dx / norm) * 127 + 128);
+        const uint32_t dy = f2u8((result.dy / norm) * 127 + 128);
+        const uint32_t dz = f2u8((result.dz / norm) * 127 + 128);
+        a.output[pxy] = (0xFFu << 24) | (dz << 16) | (dy << 8) | dx;
+    }
+    if (a.counters) {
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
+            atomicAdd((unsigned long long*)&a.counters[CNT_FWD_NORM], (unsigned long long)words_total);
+            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
+            atomicAdd((unsigned long long*)&a.counters[CNT_NORMAL_PX], (unsigned long long)__popcll(ballot(filled)));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* multi-GPU: pack / unpack 64x64 blocks of owned columns              */
+/* ------------------------------------------------------------------------------------ */
+__global__ void k_pack_columns(const int* __restrict__ heights, const uint32_t* __restrict__ normals,
+                               int S, const int* __restrict__ col_list, int ncols, int capacity,
+                               int with_normals, int* __restrict__ out)
+{
+    /* grid: (64 rows, ncols); block: 64 threads = one row of a block */
+    const int c = blockIdx.y;
+    if (c >= ncols) return;
+    const int col = col_list[c];
+    const int cols = S / 64;
+    const int x = (col % cols) * 64 + threadIdx.x;
+    const int y = (col / cols) * 64 + blockIdx.x;
+    const size_t dst = (size_t)c * 4096 + blockIdx.x * 64 + threadIdx.x;
+    out[dst] = heights[x + y * S];
+    if (with_normals) out[(size_t)capacity * 4096 + dst] = (int)normals[x + y * S];
+}
+__global__ void k_unpack_columns(int* __restrict__ heights, uint32_t* __restrict__ normals, int S,
+                                 const int* __restrict__ col_list, int ncols, int capacity,
+                                 int with_normals, const int* __restrict__ in)
+{
+    const int c = blockIdx.y;
+    if (c >= ncols) return;
+    const int col = col_list[c];
+    const int cols = S / 64;
+    const int x = (col % cols) * 64 + threadIdx.x;
+    const int y = (col / cols) * 64 + blockIdx.x;
+    const size_t src = (size_t)c * 4096 + blockIdx.x * 64 + threadIdx.x;
+    heights[x + y * S] = in[src];
+    if (with_normals) normals[x + y * S] = (uint32_t)in[(size_t)capacity * 4096 + src];
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* primitive test kernels (parity fuzzing against the oracle)                            */
+/* ------------------------------------------------------------------------------------ */
+__global__ void k_test_interval(int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
+                                const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice)
+{
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    float al = 0, ah = 0, bl = 0, bh = 0, e = 0, f = 0;
+    if (i < n) {
+        al = a_lo[i];
+        ah = a_hi[i];
+        if (b_lo) bl = b_lo[i];
+        if (b_hi) bh = b_hi[i];
+    }
+    round_up_begin(al, ah, bl, bh, e, f);
+    int c = 0;
+    const ival r = interval_clause((uint32_t)op, iv(al, ah), iv(bl, bh), imm, c);
+    if (i < n) {
+        out_lo[i] = r.lo;
+        out_hi[i] = r.hi;
+        if (choice) choice[i] = c;
+    }
+}
+__global__ void k_test_float(int op, int n, const float* a, const float* b, float imm, float* out)
+{
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i < n) out[i] = float_clause((uint32_t)op, a[i], b ? b[i] : 0.0f, imm);
+}
+__global__ void k_test_deriv(int op, int n, const float4* a, const float4* b, float imm, float4* out)
+{
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i < n) {
+        const float4 x = a[i];
+        float4 y = make_float4(0, 0, 0, 0);
+        if (b) y = b[i];
+        const deriv r = deriv_clause((uint32_t)op, dv(x.w, x.x, x.y, x.z), dv(y.w, y.x, y.y, y.z), imm);
+        out[i] = make_float4(r.dx, r.dy, r.dz, r.v);
+    }
+}
+
+/* ---- launchers ---------------------------------------------------------------------- */
+/* gfx950 offers 160 KiB of LDS per workgroup; anything above the 64 KiB default must be opted in */
+template <typename K>
+static void allow_big_lds(K kernel)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+static void opt_in_once()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    allow_big_lds(k_eval_tiles<2>);
+    allow_big_lds(k_eval_tiles<3>);
+    allow_big_lds(k_eval_voxels<2>);
+    allow_big_lds(k_eval_voxels<3>);
+    allow_big_lds(k_eval_normals);
+}
+void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
+{
+    hipLaunchKernelGGL(k_preload_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, cols, owner, rank);
+}
+size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + 2048 + (size_t)choice_cap * 16; }
+void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
+{
+    opt_in_once();
+    const int groups = (a.count + 63) / 64;
+    const size_t lds = tile_stage_lds_bytes(a.nslots, a.choice_cap);
+    if (dim == 3) hipLaunchKernelGGL(k_eval_tiles<3>, dim3(groups), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(k_eval_tiles<2>, dim3(groups), dim3(64), lds, s, a);
+}
+void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
+                              const int* image, int* num_active, mpr_tile_node* out)
+{
+    const dim3 g((count + 255) / 256), b(256);
+    if (dim == 3) {
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out);
+    } else {
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out);
+    }
+}
+void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size)
+{
+    const dim3 b(32, 8), g((size + 31) / 32, (size + 7) / 8);
+    if (dim == 3) hipLaunchKernelGGL(k_copy_filled<3>, g, b, 0, s, prev, image, size);
+    else hipLaunchKernelGGL(k_copy_filled<2>, g, b, 0, s, prev, image, size);
+}
+size_t voxel_lds_bytes(int nslots) { return (size_t)nslots * 256 * 4; }
+void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a)
+{
+    if (a.count <= 0) return;
+    opt_in_once();
+    const dim3 g((a.count + 3) / 4), b(256);
+    const size_t lds = voxel_lds_bytes(a.nslots);
+    if (dim == 3) hipLaunchKernelGGL(k_eval_voxels<3>, g, b, lds, s, a);
+    else hipLaunchKernelGGL(k_eval_voxels<2>, g, b, lds, s, a);
+}
+size_t normals_lds_bytes(int nslots) { return (size_t)nslots * 1024; }
+void launch_eval_normals(hipStream_t s, const NormalArgs& a)
+{
+    opt_in_once();
+    const int patches = a.size / 8;
+    hipLaunchKernelGGL(k_eval_normals, dim3(patches * patches), dim3(64), normals_lds_bytes(a.nslots), s, a);
+}
+void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
+                 int ncols, int capacity, int with_normals, int* out)
+{
+    if (ncols <= 0) return;
+    hipLaunchKernelGGL(k_pack_columns, dim3(64, ncols), dim3(64), 0, s, heights, normals, S, col_list, ncols,
+                       capacity, with_normals, out);
+}
+void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const int* col_list, int ncols,
+                   int capacity, int with_normals, const int* in)
+{
+    if (ncols <= 0) return;
+    hipLaunchKernelGGL(k_unpack_columns, dim3(64, ncols), dim3(64), 0, s, heights, normals, S, col_list, ncols,
+                       capacity, with_normals, in);
+}
+void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
+                          const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice)
+{
+    hipLaunchKernelGGL(k_test_interval, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a_lo, a_hi, b_lo, b_hi, imm,
+                       out_lo, out_hi, choice);
+}
+void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out)
+{
+    hipLaunchKernelGGL(k_test_float, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a, b, imm, out);
+}
+void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out)
+{
+    hipLaunchKernelGGL(k_test_deriv, dim3((n + 255) / 256), dim3(256), 0, s, op, n, (const float4*)a,
+                       (const float4*)b, imm, (float4*)out);
+}
+
+}  // namespace mprk

@@ -1,0 +1,83 @@
+/* kernels.hpp — argument blocks and host-side launchers of the gfx950 kernels (kernels.hip) */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpr_clause.h"
+
+namespace mprk {
+
+/* device counter slots (uint64 each) */
+enum {
+    CNT_FWD = 0,       /* words fetched forward, all passes */
+    CNT_BWD,           /* words fetched backward */
+    CNT_WRITTEN,       /* words written by tape pushes */
+    CNT_LANE,          /* lane-granular clause evaluations */
+    CNT_FWD_VOX,       /* forward words of the float pass */
+    CNT_FWD_NORM,      /* forward words of the normals pass */
+    CNT_NORMAL_PX,
+    CNT_OVERFLOW,
+    CNT_COUNT
+};
+
+struct TileStageArgs {
+    const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
+    uint64_t* tape_wr;         /* same pool, write side (freshly claimed chunks) */
+    int* tape_index;
+    long long pool_cap;
+    int* image;                /* this level's filled image */
+    int tps;                   /* tiles per side at this level */
+    mpr_tile_node* tiles;
+    int count;
+    int nslots;                /* slots of the root tape (LDS slot file height) */
+    int choice_cap;            /* min/max clauses recorded (<= 4096) */
+    float z;                   /* 2-D: constant Z */
+    float mat[16];             /* column-major 4x4 (3-D) or 3x3 (2-D, first 9) */
+    unsigned long long* counters;
+};
+
+struct VoxelArgs {
+    const uint64_t* tape_ro;
+    int* image;                /* S x S output */
+    int tps;                   /* smallest tiles per side (S/4 in 3-D, S/8 in 2-D) */
+    const mpr_tile_node* tiles;
+    int count;
+    int nslots;
+    float z;
+    float mat[16];
+    unsigned long long* counters;
+};
+
+struct NormalArgs {
+    const uint64_t* tape_ro;
+    const int* image;
+    uint32_t* output;
+    int size;
+    int nslots;
+    float mat[16];
+    const mpr_tile_node* tiles;
+    const mpr_tile_node* subtiles;
+    const mpr_tile_node* microtiles;
+    unsigned long long* counters;
+};
+
+void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
+size_t tile_stage_lds_bytes(int nslots, int choice_cap);
+void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
+void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
+                              const int* image, int* num_active, mpr_tile_node* out);
+void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
+size_t voxel_lds_bytes(int nslots);
+void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
+size_t normals_lds_bytes(int nslots);
+void launch_eval_normals(hipStream_t s, const NormalArgs& a);
+void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
+                 int ncols, int capacity, int with_normals, int* out);
+void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const int* col_list, int ncols,
+                   int capacity, int with_normals, const int* in);
+void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
+                          const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice);
+void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
+void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
+
+}  // namespace mprk

@@ -1,0 +1,98 @@
+"""GPU primitives vs oracle, bit for bit: interval ops (directed rounding on gfx950), float
+ops (shared fmath), derivative ops.  Calls go through the C ABI (mpr_test_*_op)."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 16
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return both_nan | (a.view(np.uint32) == b.view(np.uint32))
+
+
+def gen_floats(rng, n, kind):
+    if kind == "bits":       # any bit pattern: subnormals, infinities, NaN, extreme exponents
+        return rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    if kind == "unit":
+        return rng.uniform(-2, 2, n).astype(np.float32)
+    if kind == "wide":
+        return (rng.standard_normal(n) * np.exp(rng.uniform(-30, 30, n))).astype(np.float32)
+    if kind == "special":
+        pool = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, -3.4e38,
+                         1.17549435e-38, 0.5, 2.0, 1e-20, -1e-20, 16777216.0, 0.1, -0.1, 3.0], dtype=np.float32)
+        return pool[rng.integers(0, pool.size, n)]
+    raise ValueError(kind)
+
+
+def gen_intervals(rng, n, kind):
+    a = gen_floats(rng, n, kind)
+    b = gen_floats(rng, n, kind)
+    if kind in ("bits", "special"):
+        # not necessarily ordered: the reference never checks lower <= upper either
+        return a, b
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    pt = rng.random(n) < 0.1          # some point intervals
+    hi = np.where(pt, lo, hi)
+    return lo, hi
+
+
+INTERVAL_OPS = ["SQUARE_LHS", "SQRT_LHS", "NEG_LHS", "SIN_LHS", "COS_LHS", "ASIN_LHS", "ACOS_LHS", "ATAN_LHS",
+                "EXP_LHS", "ABS_LHS", "LOG_LHS", "ADD_LHS_IMM", "ADD_LHS_RHS", "MUL_LHS_IMM", "MUL_LHS_RHS",
+                "MIN_LHS_IMM", "MIN_LHS_RHS", "MAX_LHS_IMM", "MAX_LHS_RHS", "SUB_LHS_IMM", "SUB_IMM_RHS",
+                "SUB_LHS_RHS", "DIV_LHS_IMM", "DIV_IMM_RHS", "DIV_LHS_RHS", "COPY_IMM", "COPY_LHS", "COPY_RHS"]
+
+
+@pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
+@pytest.mark.parametrize("opname", INTERVAL_OPS)
+def test_interval_ops_bit_exact(mpr, orc, opname, kind):
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32((opname + kind).encode()))
+    a_lo, a_hi = gen_intervals(rng, N, kind)
+    b_lo, b_hi = gen_intervals(rng, N, kind)
+    for imm in (0.75, -1.25, 0.0):
+        g_lo, g_hi, g_ch = mpr.dev_interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
+        o_lo, o_hi, o_ch = orc.interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
+        ok = same_bits(g_lo, o_lo) & same_bits(g_hi, o_hi) & (g_ch == o_ch)
+        if kind == "bits" and opname in ("DIV_LHS_IMM", "DIV_IMM_RHS", "DIV_LHS_RHS", "SQRT_LHS"):
+            # documented limit of the residual-based directed division / sqrt: operands
+            # whose exact residual underflows (results within 2^-100 of the subnormal range)
+            tiny = (np.abs(o_lo) < 1e-30) | (np.abs(o_hi) < 1e-30) | (np.abs(a_lo) < 1e-30) | (np.abs(a_hi) < 1e-30) | \
+                   (np.abs(b_lo) < 1e-30) | (np.abs(b_hi) < 1e-30)
+            ok = ok | tiny
+        bad = np.flatnonzero(~ok)
+        assert bad.size == 0, (opname, kind, imm, bad.size,
+                               [(a_lo[i], a_hi[i], b_lo[i], b_hi[i], g_lo[i], g_hi[i], o_lo[i], o_hi[i], g_ch[i], o_ch[i]) for i in bad[:5]])
+
+
+@pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
+@pytest.mark.parametrize("opname", INTERVAL_OPS)
+def test_float_ops_bit_exact(mpr, orc, opname, kind):
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32((opname + kind + "f").encode()))
+    a = gen_floats(rng, N, kind)
+    b = gen_floats(rng, N, kind)
+    for imm in (0.75, -1.25):
+        g = mpr.dev_float_op(op, a, b, imm)
+        o = orc.float_op(op, a, b, imm)
+        bad = np.flatnonzero(~same_bits(g, o))
+        assert bad.size == 0, (opname, kind, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:5]])
+
+
+@pytest.mark.parametrize("kind", ["unit", "wide", "special"])
+@pytest.mark.parametrize("opname", INTERVAL_OPS)
+def test_deriv_ops_bit_exact(mpr, orc, opname, kind):
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32((opname + kind + "d").encode()))
+    a = gen_floats(rng, N * 4, kind).reshape(-1, 4)
+    b = gen_floats(rng, N * 4, kind).reshape(-1, 4)
+    g = mpr.dev_deriv_op(op, a, b, 0.75)
+    o = orc.deriv_op(op, a, b, 0.75)
+    bad = np.flatnonzero(~same_bits(g, o).all(axis=1))
+    assert bad.size == 0, (opname, kind, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:3]])

@@ -1,0 +1,194 @@
+"""Frames on the GPU vs the oracle: bit-exact images, normals, per-stage tile sets and
+shortened tapes; plus size-independent properties at the BASELINE sizes."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import view2, view3
+
+pytestmark = pytest.mark.gpu
+
+
+def active_positions(tiles):
+    return np.sort(tiles["position"][tiles["next"] != -1])
+
+
+def compare_frame(mpr, orc, tape, dim, S, mat, z=0.0, check_tapes=True):
+    ctx = mpr.Context(S, flags=mpr.CTX_COUNTERS)
+    ref = orc.Frame(tape.data, dim, S, mpr.colmajor(mat, dim + 1), z=z, threads=0)
+    if dim == 2:
+        ctx.render2D(tape, mat, z)
+    else:
+        ctx.render3D(tape, mat)
+    cnt = ctx.counters()
+    assert cnt["pool_overflowed"] == 0 and ref.counters["pool_overflowed"] == 0
+    stages = [0, 1, 2, 3] if dim == 3 else [0, 2, 3]
+    for s in stages:
+        got = ctx.stages[s].filled
+        assert np.array_equal(got, ref.filled[s]), "filled image of stage %d differs (%d cells)" % (
+            s, int((got != ref.filled[s]).sum()))
+    if dim == 3:
+        gn, rn = ctx.normals, ref.normals
+        assert np.array_equal(gn, rn), "normals differ at %d pixels" % int((gn != rn).sum())
+    # per-stage tile occupancy: the SET of surviving tiles (order is timing dependent)
+    tile_stages = [0, 1, 2] if dim == 3 else [0, 2]
+    pool = ctx.tape_data if check_tapes else None
+    for k, s in enumerate(tile_stages):
+        gt, rt = ctx.stages[s].tiles, ref.tiles[s]
+        assert gt.size == rt.size
+        last = (k == len(tile_stages) - 1)
+        nxt = s + 1 if dim == 3 else (3 if s else 2)
+        g_next, r_next = ctx.stages[nxt].tiles, ref.tiles[nxt]
+        assert g_next.size == r_next.size, "stage %d hands %d tiles on, oracle %d" % (s, g_next.size, r_next.size)
+        assert cnt["tiles_in"][k] == ref.counters["tiles_in"][k]
+        assert cnt["tiles_active"][k] == ref.counters["tiles_active"][k]
+        go, ro = np.argsort(g_next["position"], kind="stable"), np.argsort(r_next["position"], kind="stable")
+        assert np.array_equal(g_next["position"][go], r_next["position"][ro])
+        if not last:
+            assert np.array_equal(active_positions(gt), active_positions(rt))
+        if check_tapes:
+            # the shortened tape every surviving tile carries: same clause sequence
+            glen, ghash = orc.tiles_digest(pool, g_next[go])
+            rlen, rhash = orc.tiles_digest(ref.pool, r_next[ro])
+            assert np.array_equal(glen, rlen), "shortened tape lengths differ at stage %d" % s
+            assert np.array_equal(ghash, rhash), "shortened tape contents differ at stage %d" % s
+    # forward clause fetches of the float pass are a deterministic function of the tile set
+    assert cnt["clauses_fwd_voxels"] == ref.counters["clauses_fwd_voxels"] or dim == 3
+    ctx.close()
+    return cnt, ref
+
+
+@pytest.mark.parametrize("name,S", [("circle", 128), ("circle", 256), ("two_spheres", 256), ("ring", 256),
+                                    ("hello_world", 256), ("prospero", 256), ("involute_gear_2d", 512),
+                                    ("trig", 256), ("architecture", 256)])
+def test_render2d_matches_oracle(mpr, orc, tapes, name, S):
+    compare_frame(mpr, orc, tapes(name), 2, S, view2())
+
+
+def test_render2d_general_view(mpr, orc, tapes):
+    m = np.array([[0.9, 0.2, 0.1], [-0.15, 1.1, -0.05], [0.1, 0.05, 1.0]], dtype=np.float32)
+    compare_frame(mpr, orc, tapes("hello_world"), 2, 256, m, z=0.1)
+
+
+@pytest.mark.parametrize("name,S", [("sphere", 128), ("two_spheres", 256), ("hello_world", 256), ("bear", 256),
+                                    ("architecture", 256), ("involute_gear_3d", 256), ("trig", 128)])
+def test_render3d_matches_oracle(mpr, orc, tapes, name, S):
+    compare_frame(mpr, orc, tapes(name), 3, S, view3())
+
+
+def test_render3d_general_view(mpr, orc, tapes):
+    c, s = np.float32(np.cos(0.4)), np.float32(np.sin(0.4))
+    m = np.array([[c, 0, s, 0.05], [0, 1, 0, -0.02], [-s, 0, c, 0], [0, 0.1, 0.25, 1]], dtype=np.float32)
+    compare_frame(mpr, orc, tapes("hello_world"), 3, 256, m)
+
+
+def test_brute_equals_hierarchy_prospero_1024(mpr, tapes):
+    """BASELINE config 2 at full size: the hierarchical image must equal the brute-force one
+    (the invariant benchmark/brute.cu:102-155 relies on)."""
+    tape = tapes("prospero")
+    ctx = mpr.Context(1024)
+    ctx.render2D(tape, view2())
+    img = ctx.image
+    ctx.render2D_brute(tape, view2())
+    assert np.array_equal(img, ctx.image)
+    assert 0 < img.sum() < img.size
+    ctx.render2D(tape, view2())       # idempotent
+    assert np.array_equal(img, ctx.image)
+    ctx.close()
+
+
+def test_gears_4096_brute_equals_hierarchy(mpr, tapes):
+    """BASELINE config 3 (deep tape, 4096^2)."""
+    tape = tapes("involute_gear_2d")
+    ctx = mpr.Context(4096)
+    ctx.render2D(tape, view2())
+    img = ctx.image
+    ctx.render2D_brute(tape, view2())
+    assert np.array_equal(img, ctx.image)
+    ctx.close()
+
+
+def test_bear_1024_properties(mpr, orc, tapes):
+    """BASELINE config 4 at full size: every heightmap value is the top of a filled voxel
+    (the oracle's float walk of the root tape is < 0 there and >= 0 just above), normals
+    exist exactly on filled pixels, and the frame is reproducible."""
+    tape = tapes("bear")
+    S = 1024
+    ctx = mpr.Context(S)
+    ctx.render3D(tape, view3())
+    h, n = ctx.image, ctx.normals
+    assert np.array_equal(n != 0, h != 0)
+    assert (h > 0).sum() > 300000
+    ctx.render3D(tape, view3())
+    assert np.array_equal(h, ctx.image) and np.array_equal(n, ctx.normals)
+    ctx.close()
+    # spot-check 4096 filled pixels against a float evaluation of the ROOT tape by the oracle's
+    # primitives: f(x, y, h) < 0 and f(x, y, z) >= 0 for every z > h
+    rng = np.random.default_rng(3)
+    ys, xs = np.nonzero(h)
+    pick = rng.choice(ys.size, 512, replace=False)
+    data = tape.data
+    T = view3()
+
+    def feval(px, py, pz):
+        fx = ((px + np.float32(0.5)) * np.float32(1.0 / S) - np.float32(0.5)) * np.float32(2)
+        fy = ((py + np.float32(0.5)) * np.float32(1.0 / S) - np.float32(0.5)) * np.float32(2)
+        fz = ((pz + np.float32(0.5)) * np.float32(1.0 / S) - np.float32(0.5)) * np.float32(2)
+        fw = np.float32(T[3, 2]) * fz + np.float32(1)
+        slots = {}
+        h0 = int(data[0])
+        slots[(h0 >> 8) & 255] = (fx / fw).astype(np.float32)
+        slots[(h0 >> 16) & 255] = (fy / fw).astype(np.float32)
+        slots[(h0 >> 24) & 255] = (fz / fw).astype(np.float32)
+        for c in data[1:-1]:
+            c = int(c)
+            op, o, l, r = c & 255, (c >> 8) & 255, (c >> 16) & 255, (c >> 24) & 255
+            imm = float(np.uint32(c >> 32).view(np.float32))
+            a = slots.get(l, np.zeros_like(fx))
+            b = slots.get(r, np.zeros_like(fx))
+            slots[o] = orc.float_op(op, a, b, imm)
+        return slots[(int(data[-1]) >> 8) & 255]
+
+    px, py = xs[pick].astype(np.float32), ys[pick].astype(np.float32)
+    hz = h[ys[pick], xs[pick]]
+    assert (feval(px, py, hz.astype(np.float32)) < 0).all()
+    for dz in (1, 2, 5, 17):
+        zz = np.minimum(hz + dz, S - 1)
+        above = feval(px, py, zz.astype(np.float32))
+        assert ((above >= 0) | (zz == hz)).all()
+
+
+def test_pool_overflow_falls_back(mpr, orc, tapes):
+    """A pool too small for the pushes: tiles keep their parent's tape (reference
+    src/context.cu:336-347) and the image is unchanged."""
+    tape = tapes("hello_world")
+    full = mpr.Context(256)
+    full.render2D(tape, view2())
+    img = full.image
+    full.close()
+    small = mpr.Context(256, pool_clauses=tape.length + 64 * 40, flags=mpr.CTX_COUNTERS)
+    small.render2D(tape, view2())
+    assert small.counters()["pool_overflowed"] == 1
+    assert np.array_equal(small.image, img)
+    small.close()
+
+
+def test_golden_images(mpr, tapes):
+    """Committed golden digests (tests/golden/frames.json, produced by the oracle)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "frames.json")) as f:
+        golden = json.load(f)
+    for g in golden["frames"]:
+        tape = tapes(g["model"])
+        assert hashlib.sha256(tape.data.tobytes()).hexdigest() == g["tape_sha256"]
+        ctx = mpr.Context(g["size"])
+        if g["dim"] == 2:
+            ctx.render2D(tape, view2())
+        else:
+            ctx.render3D(tape, view3())
+        assert hashlib.sha256(ctx.image.tobytes()).hexdigest() == g["image_sha256"], g
+        if g["dim"] == 3:
+            assert hashlib.sha256(ctx.normals.tobytes()).hexdigest() == g["normals_sha256"], g
+        ctx.close()
