@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py — the reference's headline benchmark on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model bear] [--size 1024]
+
+A "step" is one whole frame of the hot path: Context::render3D of benchmark/files/bear.frep
+at 1024^3 with the reference's benchmark view (identity, T(3,2) = 0.3;
+benchmark/render_3d_table.cpp:48-49), a blocking call like the reference's get_stats protocol
+times (benchmark/stats.cpp:19-47).  The tape is resident in HBM before the timed region.
+With N > 1 the top-level tile columns of the SAME frame are dealt to the N ranks and the
+image is all-gathered over RCCL (strong scaling; mpr_amd/multigpu.py).
+
+Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      dominant kernel (eval_voxels_f): algorithmic bytes / HIP-event duration vs 8 TB/s
+  cpu_baseline  the CPU oracle (a port, not the reference) on a bounded sample, all host cores
+  also          the reference's other headline config (prospero render2D 1024^2), for which
+                BASELINE.md holds the only published number (V100, 3.856 ms/frame)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+V100_PROSPERO_1024_MS = 3.85596     # BASELINE.md / reference README.md:111
+
+
+def view3():
+    T = np.eye(4, dtype=np.float32)
+    T[3, 2] = 0.3
+    return T
+
+
+def stats(ms):
+    ms = np.asarray(ms, dtype=np.float64)
+    return float(ms.mean()), float(ms.std(ddof=1)) if ms.size > 1 else 0.0
+
+
+def time_frames(fn, warmup, steps, barrier, sync):
+    for _ in range(warmup):
+        fn()
+    barrier()
+    sync()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s = time.perf_counter()
+        fn()
+        per.append((time.perf_counter() - s) * 1e3)
+    sync()
+    barrier()
+    total = time.perf_counter() - t0
+    return total, per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)     # benchmark/stats.hpp:14: 100 timed
+    ap.add_argument("--warmup", type=int, default=20)     #                         20 warm-up
+    ap.add_argument("--model", default="bear")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the prospero 2-D side measurement")
+    args = ap.parse_args()
+
+    import torch
+    import mpr_amd as m
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def sync():
+        torch.cuda.synchronize()
+
+    m.build()
+    tape = m.Tape(m.model(args.model))
+    S = args.size
+    T = view3()
+
+    # ---- instrumented frame (counters on): algorithmic work of the dominant kernel ----
+    cctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS)
+    cctx.render3D(tape, T)
+    work = cctx.counters()
+    cctx.close()
+
+    ctx = m.Context(S, device=local_rank, flags=m.CTX_TIMING)
+    kernel_ms = {}
+    frames_timed = [0]
+
+    if world > 1:
+        from mpr_amd.multigpu import TileParallelRenderer
+
+        def make_buffer(n):
+            t = torch.empty(n, dtype=torch.int32, device="cuda")
+            return t, t.data_ptr()
+
+        def all_gather(out, inp):
+            dist.all_gather_into_tensor(out, inp)
+            torch.cuda.synchronize()
+
+        tpr = TileParallelRenderer(ctx, m, rank, world, make_buffer, all_gather, dim=3)
+        tpr.plan(tape, T)
+
+        def frame():
+            tpr.render(tape, T)
+    else:
+        def frame():
+            ctx.render3D(tape, T)
+
+    def timed_frame():
+        frame()
+        for name, ms in ctx.timings():
+            kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
+        frames_timed[0] += 1
+
+    for _ in range(args.warmup):
+        frame()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    per = []
+    for _ in range(args.steps):
+        s = time.perf_counter()
+        timed_frame()
+        per.append((time.perf_counter() - s) * 1e3)
+    sync()
+    barrier()
+    total_s = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([total_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total_s = float(tt.item())
+    ms_per_step = total_s * 1e3 / args.steps
+    mean_ms, std_ms = stats(per)
+
+    # ---- roofline of the dominant kernel (eval_voxels_f) ----
+    nframes = max(frames_timed[0], 1)
+    avg = {k: v / nframes for k, v in kernel_ms.items()}
+    vox_ms = avg.get("eval_voxels_f", 0.0)
+    # algorithmic bytes per launch: one 8-byte clause per wave-group
+    # visit + the 12-byte tile record of every smallest tile
+    b_alg = 8 * work["clauses_fwd_voxels"] + 12 * work["voxel_tiles"]
+    if world > 1:
+        b_alg = None     # per-rank share is not measured in the multi-GPU run
+    roofline = None
+    if vox_ms > 0 and b_alg:
+        achieved = b_alg / (vox_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("eval_voxels_f", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "k_eval_voxels<3>", "bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "algorithmic_bytes": int(b_alg), "kernel_ms": round(vox_ms, 4),
+                    "kernel_ms_all": {k: round(v, 4) for k, v in avg.items()},
+                    "lane_clauses_per_frame": int(work["lane_clauses"])}
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mpixel/s, render3D bear 1024^3 (ms/frame in ms_per_step)",
+            "value": round(S * S / (ms_per_step * 1e-3) / 1e6, 3),
+            "unit": "Mpixel/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_frame_mean": round(mean_ms, 4),
+            "ms_per_frame_std": round(std_ms, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "benchmark model %s.frep (copied from the reference's benchmark/files), identity view with T(3,2)=0.3" % args.model,
+            "config": {"workload": "%s.frep render3D heightmap+normals at %d^3" % (args.model, S),
+                       "image_size_px": S, "tape_clauses": tape.length - 2, "tape_slots": tape.num_slots,
+                       "parallelism": "tile-columns x%d" % world,
+                       "voxel_tiles": int(work["voxel_tiles"])},
+            "roofline": roofline,
+        }
+
+    # ---- side measurement: prospero render2D 1024^2 (the published V100 number's config) ----
+    if rank == 0 and world == 1 and not args.no_also:
+        ptape = m.Tape(m.model("prospero"))
+        pctx = m.Context(1024, device=local_rank)
+        _, pper = time_frames(lambda: pctx.render2D(ptape), args.warmup, args.steps, lambda: None, sync)
+        pm, ps = stats(pper)
+        pctx.close()
+        out["also"] = [{"workload": "prospero.frep render2D at 1024^2", "ms_per_frame_mean": round(pm, 4),
+                        "ms_per_frame_std": round(ps, 4), "value": round(1024 * 1024 / (pm * 1e-3) / 1e6, 2),
+                        "unit": "Mpixel/s", "vs_baseline": round(V100_PROSPERO_1024_MS / pm, 3),
+                        "baseline": "3.85596 ms/frame on 1x V100 (reference README.md:111)"}]
+
+    # ---- CPU baseline: the oracle (a port of the algorithm, NOT libfive's renderer) ----
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import orc
+        cs = 512 if S >= 512 else S
+        cores = os.cpu_count() or 1
+        orc.lib()
+        t1 = time.perf_counter()
+        orc.Frame(tape.data, 3, cs, m.colmajor(T, 4), threads=cores, keep_pool=False)
+        cpu_s = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(cs * cs / cpu_s / 1e6, 4), "unit": "Mpixel/s", "cores": cores,
+                               "kind": "port", "ms_per_frame": round(cpu_s * 1e3, 1),
+                               "sample": "%s.frep render3D at %d^3 (1/%d of the voxels of the GPU workload), one frame, "
+                                         "oracle/mpr_oracle.c with OpenMP over tile groups" % (args.model, cs, (S // cs) ** 3)}
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""Tile-parallel rendering of ONE frame on N GPUs.
+
+The unit of partitioning is a top-level xy column (a 64x64 pixel footprint with all of its
+S/64 z tiles): columns never interact (3-D tiles only talk to the heightmap of their own
+column, reference src/context.cu:299-316, :489-494, :861, :941-947), so a rank that renders
+only its columns produces exactly the pixels the single-GPU frame has there.  Per frame:
+
+    render the owned columns  ->  pack their 64x64 blocks  ->  ONE all-gather (RCCL over
+    xGMI; point-to-point links, every rank pushes its pack to every peer)  ->  unpack
+
+No reduction is involved, so the result is bit-identical to the single-GPU frame.
+
+The column -> rank deal is the longest-processing-time-first heuristic on per-column work
+measured on a previous frame (every rank renders one full frame during warm-up and counts the
+smallest tiles per column; the counts are deterministic, hence the deal is identical on all
+ranks without communication).
+
+The class is written against a small "context" protocol (render3D / render3D_part /
+pack_columns / unpack_columns / stages[3].tiles) so that the world-size-2 gloo test in
+tests/test_distributed.py can drive the same code with a CPU stand-in.
+"""
+import numpy as np
+
+
+def column_weights(tiles, size, dim=3):
+    """Per-column work proxy: number of smallest tiles (4^3 voxels / 8^2 pixels) per 64x64 column."""
+    cols = size // 64
+    sub = 4 if dim == 3 else 8
+    tps = size // sub
+    pos = np.asarray(tiles["position"], dtype=np.int64)
+    pos = pos[pos >= 0]
+    x = pos % tps
+    y = (pos // tps) % tps
+    col = (x * sub // 64) + (y * sub // 64) * cols
+    return np.bincount(col, minlength=cols * cols).astype(np.float32)
+
+
+class TileParallelRenderer:
+    def __init__(self, ctx, mpr, rank, world, make_buffer, all_gather, dim=3):
+        """ctx: an mpr_amd.Context (or stand-in) on this rank's device.
+        make_buffer(n_int32) -> (handle, device_pointer): gather staging memory.
+        all_gather(out_handle, in_handle): collective over equal-size int32 buffers."""
+        self.ctx, self.mpr = ctx, mpr
+        self.rank, self.world = rank, world
+        self.dim = dim
+        self.size = ctx.image_size_px
+        self.cols = (self.size // 64) ** 2
+        self.make_buffer, self.all_gather = make_buffer, all_gather
+        self.owner = None
+        self.capacity = 0
+        self.with_normals = dim == 3
+
+    def plan(self, tape, mat, z=0.0):
+        """Measure per-column work on one full frame and deal the columns (identical on all ranks)."""
+        if self.dim == 3:
+            self.ctx.render3D(tape, mat)
+        else:
+            self.ctx.render2D(tape, mat, z)
+        w = column_weights(self.ctx.stages[3].tiles, self.size, self.dim)
+        self.set_owner(self.mpr.partition_columns(self.cols, self.world, w))
+        return self.owner
+
+    def set_owner(self, owner):
+        self.owner = np.ascontiguousarray(owner, dtype=np.int32)
+        counts = np.bincount(self.owner, minlength=self.world)
+        self.capacity = int(counts.max())
+        per_rank = self.capacity * 4096 * (2 if self.with_normals else 1)
+        self.send, self.send_ptr = self.make_buffer(per_rank)
+        self.recv, self.recv_ptr = self.make_buffer(per_rank * self.world)
+        self.per_rank = per_rank
+
+    def render(self, tape, mat, z=0.0):
+        """One frame: afterwards ctx.image / ctx.normals hold the complete result on every rank."""
+        if self.world == 1:
+            if self.dim == 3:
+                self.ctx.render3D(tape, mat)
+            else:
+                self.ctx.render2D(tape, mat, z)
+            return
+        if self.dim == 3:
+            self.ctx.render3D_part(tape, mat, self.owner, self.rank)
+        else:
+            self.ctx.render2D_part(tape, mat, z, self.owner, self.rank)
+        self.ctx.pack_columns(self.owner, self.rank, self.capacity, self.with_normals, self.send_ptr)
+        self.all_gather(self.recv, self.send)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            self.ctx.unpack_columns(self.owner, r, self.capacity, self.with_normals,
+                                    self.recv_ptr + r * self.per_rank * 4)
