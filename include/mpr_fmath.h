@@ -36,7 +36,14 @@ MPR_HD float mpr_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 MPR_HD int mpr_isnanf(float f) { return (mpr_f2u(f) & 0x7FFFFFFFu) > 0x7F800000u; }
 
 /* fminf / fmaxf with fully specified semantics (IEEE-754-2019 minimumNumber /
- * maximumNumber: a NaN operand is ignored, -0 orders below +0). */
+ * maximumNumber: a quiet-NaN operand is ignored, -0 orders below +0).  On gfx950 this is
+ * exactly v_min_f32 / v_max_f32 (CDNA ISA: NaN operand -> the other one, -0 < +0), so the
+ * device build uses the instruction; tests/test_gpu_primitives.py checks the two definitions
+ * against each other (signalling NaNs, which no arithmetic produces, excepted). */
+#if defined(__HIP_DEVICE_COMPILE__)
+MPR_HD float mpr_fminf(float a, float b) { return __builtin_fminf(a, b); }
+MPR_HD float mpr_fmaxf(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
 MPR_HD float mpr_fminf(float a, float b)
 {
     if (mpr_isnanf(a)) return b;
@@ -51,6 +58,7 @@ MPR_HD float mpr_fmaxf(float a, float b)
     if (a == b) return (mpr_f2u(a) & 0x80000000u) ? b : a;
     return a > b ? a : b;
 }
+#endif
 
 /* ---- expf ------------------------------------------------------------------------- */
 MPR_HD float mpr_expf(float x)

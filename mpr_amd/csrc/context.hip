@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,9 +48,17 @@ struct mpr_context {
     size_t tiles_cap[4] = {0, 0, 0, 0};
     size_t tiles_n[4] = {0, 0, 0, 0};
 
+    mprk::GroupInfo* groups = nullptr; /* per sibling group of the last tile stage */
+    size_t groups_cap = 0;
+    ulonglong2* choice_masks = nullptr;
+    size_t masks_cap = 0;
+
     int* owner_dev = nullptr;          /* column ownership, (S/64)^2 */
     int* col_list_dev = nullptr;
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
+
+    int voxel_k = 0;                   /* float pass: 0 = one wave per smallest tile walking its own sub-tape (default);
+                                          1, 2, 4 = children per batch of the grouped form (MPR_VOXEL_K, experimental) */
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     int tape_len = 0;
@@ -79,6 +88,19 @@ static int ensure_tiles(mpr_context* c, int stage, size_t n)
     c->tiles_cap[stage] = 0;
     HIP_TRY(hipMalloc((void**)&c->tiles[stage], cap * sizeof(mpr_tile_node)));
     c->tiles_cap[stage] = cap;
+    return MPR_OK;
+}
+
+template <typename T>
+static int ensure_buffer(T** ptr, size_t* cap, size_t n)
+{
+    if (n <= *cap) return MPR_OK;
+    const size_t want = std::max(n, *cap + *cap / 2);
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc((void**)ptr, want * sizeof(T)));
+    *cap = want;
     return MPR_OK;
 }
 
@@ -128,6 +150,10 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->device = opt->device;
     c->S = S;
     c->flags = opt->flags;
+    if (const char* e = getenv("MPR_VOXEL_K")) {
+        const int k = atoi(e);
+        if (k == 0 || k == 1 || k == 2 || k == 4) c->voxel_k = k;
+    }
     c->pool_cap = opt->pool_clauses > 0 ? opt->pool_clauses : (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK;
     if (c->pool_cap > 0x7FFFFFFFll) c->pool_cap = 0x7FFFFFFFll;   /* tape indices are int32 (inc/context.hpp:25) */
     *out = nullptr;
@@ -147,7 +173,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
         CT(hipMalloc((void**)&c->filled[i], c->filled_n[i] * sizeof(int)));
     }
     CT(hipMalloc((void**)&c->normals, (size_t)S * S * sizeof(uint32_t)));
-    CT(hipMalloc((void**)&c->pool, (size_t)c->pool_cap * sizeof(uint64_t)));
+    CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
     CT(hipMalloc((void**)&c->num_active, sizeof(int)));
     CT(hipMalloc((void**)&c->counters, mprk::CNT_COUNT * sizeof(unsigned long long)));
@@ -185,6 +211,8 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->tape_index) (void)hipFree(c->tape_index);
     if (c->num_active) (void)hipFree(c->num_active);
     if (c->counters) (void)hipFree(c->counters);
+    if (c->groups) (void)hipFree(c->groups);
+    if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->owner_dev) (void)hipFree(c->owner_dev);
     if (c->col_list_dev) (void)hipFree(c->col_list_dev);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -261,7 +289,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     /* device limits: LDS per workgroup */
     const size_t lds_limit = 160 * 1024;
     if (mprk::tile_stage_lds_bytes(nslots, choice_cap) > lds_limit || mprk::normals_lds_bytes(nslots) > lds_limit ||
-        mprk::voxel_lds_bytes(nslots) > lds_limit)
+        mprk::voxel_lds_bytes(nslots) > lds_limit || mprk::grouped_voxel_lds_bytes(nslots, 4) > lds_limit)
         return mpr::set_error(MPR_ERR_UNSUPPORTED, "tape needs more LDS than one workgroup can hold");
 
     /* reset the images (src/context.cu:1146-1151, :1295-1301) */
@@ -283,6 +311,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     else { stage_list[0] = 0; stage_list[1] = 2; nstages = 2; }
 
     int count;
+    int last_ngroups = 0, last_stage = -1;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
@@ -310,8 +339,20 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         const int tps = S / tile_size_px;
         c->last.tiles_in[si] = count;
 
+        const int ngroups = (count + 63) / 64;
+        if (last && count > 0) {
+            /* the float pass walks each group's tape with the group's choice masks */
+            rc = ensure_buffer(&c->groups, &c->groups_cap, (size_t)ngroups);
+            if (rc) return rc;
+            rc = ensure_buffer(&c->choice_masks, &c->masks_cap, (size_t)ngroups * std::max(choice_cap, 1));
+            if (rc) return rc;
+            last_ngroups = ngroups;
+            last_stage = i;
+        }
         if (count > 0) {
             mprk::TileStageArgs a;
+            a.groups = last ? c->groups : nullptr;
+            a.choice_masks = last ? c->choice_masks : nullptr;
             a.tape_ro = c->pool;
             a.tape_wr = c->pool;
             a.tape_index = c->tape_index;
@@ -349,7 +390,23 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     }
 
     c->last.voxel_tiles = count;
-    if (count > 0) {
+    if (!brute && last_ngroups > 0 && count > 0 && c->voxel_k > 0) {
+        mprk::GroupedVoxelArgs v;
+        v.tape_ro = c->pool;
+        v.image = c->filled[3];
+        v.tps = S / (dim == 3 ? 4 : 8);
+        v.tiles = c->tiles[last_stage];
+        v.ngroups = last_ngroups;
+        v.nslots = nslots;
+        v.choice_cap = std::max(choice_cap, 1);
+        v.z = z;
+        fill_mat(v.mat, mat, dim == 3 ? 16 : 9);
+        v.groups = c->groups;
+        v.choice_masks = c->choice_masks;
+        v.counters = cnt;
+        TimedScope ts(c, "eval_voxels_f");
+        mprk::launch_eval_voxels_grouped(s, dim, c->voxel_k, v);
+    } else if (count > 0) {
         mprk::VoxelArgs v;
         v.tape_ro = c->pool;
         v.image = c->filled[3];

@@ -20,6 +20,18 @@ enum {
     CNT_COUNT
 };
 
+/* Per sibling group (64 consecutive entries of a tile list = the children of one tile) of the
+ * LAST tile stage: what the float pass needs to evaluate any child without its own sub-tape:
+ * the tape the group walked and where the group's min/max decisions were stored
+ * (choice_masks[mask_off + i] = {lanes that chose lhs, lanes that chose rhs} for the i-th
+ * min/max clause of that tape). */
+struct GroupInfo {
+    int tape;
+    int mask_off;
+    int nchoices;
+    int pad;
+};
+
 struct TileStageArgs {
     const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
     uint64_t* tape_wr;         /* same pool, write side (freshly claimed chunks) */
@@ -34,6 +46,8 @@ struct TileStageArgs {
     float z;                   /* 2-D: constant Z */
     float mat[16];             /* column-major 4x4 (3-D) or 3x3 (2-D, first 9) */
     unsigned long long* counters;
+    GroupInfo* groups;         /* last tile stage only (else null): per-group record ...      */
+    ulonglong2* choice_masks;  /* ... and choice masks, choice_cap entries per group          */
 };
 
 struct VoxelArgs {
@@ -45,6 +59,22 @@ struct VoxelArgs {
     int nslots;
     float z;
     float mat[16];
+    unsigned long long* counters;
+};
+
+/* float pass over sibling groups: K children of one group at a time walk the group's tape */
+struct GroupedVoxelArgs {
+    const uint64_t* tape_ro;
+    int* image;
+    int tps;
+    const mpr_tile_node* tiles;      /* the last tile stage's list (after its evaluation) */
+    int ngroups;
+    int nslots;
+    int choice_cap;
+    float z;
+    float mat[16];
+    const GroupInfo* groups;
+    const ulonglong2* choice_masks;
     unsigned long long* counters;
 };
 
@@ -69,6 +99,8 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
+size_t grouped_voxel_lds_bytes(int nslots, int k);
+void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a);   /* k = 1, 2 or 4 children per batch */
 size_t normals_lds_bytes(int nslots);
 void launch_eval_normals(hipStream_t s, const NormalArgs& a);
 void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
