@@ -340,7 +340,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->last.tiles_in[si] = count;
 
         const int ngroups = (count + 63) / 64;
-        if (last && count > 0) {
+        const bool grouped = last && count > 0 && c->voxel_k > 0;
+        if (grouped) {
             /* the float pass walks each group's tape with the group's choice masks */
             rc = ensure_buffer(&c->groups, &c->groups_cap, (size_t)ngroups);
             if (rc) return rc;
@@ -351,8 +352,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         }
         if (count > 0) {
             mprk::TileStageArgs a;
-            a.groups = last ? c->groups : nullptr;
-            a.choice_masks = last ? c->choice_masks : nullptr;
+            a.groups = grouped ? c->groups : nullptr;
+            a.choice_masks = grouped ? c->choice_masks : nullptr;
             a.tape_ro = c->pool;
             a.tape_wr = c->pool;
             a.tape_index = c->tape_index;

@@ -197,3 +197,58 @@ def test_golden_images(mpr, tapes):
         if g["dim"] == 3:
             assert hashlib.sha256(ctx.normals.tobytes()).hexdigest() == g["normals_sha256"], g
         ctx.close()
+
+
+def test_column_partition_pack_unpack(mpr, orc, tapes):
+    """The multi-GPU data path on one device: two contexts play rank 0 and rank 1, each renders
+    its columns (LPT deal on measured work), packs them, and unpacks the other's pack; both end
+    up with the single-GPU frame, bit for bit."""
+    import torch
+    from mpr_amd.multigpu import column_weights
+    tape = tapes("bear")
+    S, world = 256, 2
+    T = view3()
+    full = mpr.Context(S)
+    full.render3D(tape, T)
+    want_h, want_n = full.image, full.normals
+    owner = mpr.partition_columns((S // 64) ** 2, world, column_weights(full.stages[3].tiles, S))
+    full.close()
+    cap = int(np.bincount(owner, minlength=world).max())
+    ctxs = [mpr.Context(S) for _ in range(world)]
+    packs = [torch.zeros(cap * 4096 * 2, dtype=torch.int32, device="cuda") for _ in range(world)]
+    for r in range(world):
+        ctxs[r].render3D_part(tape, T, owner, r)
+        mask = np.kron(owner.reshape(S // 64, S // 64) == r, np.ones((64, 64), dtype=bool))
+        got = ctxs[r].image
+        assert not got[~mask].any() and np.array_equal(got[mask], want_h[mask])
+        ctxs[r].pack_columns(owner, r, cap, True, packs[r].data_ptr())
+    torch.cuda.synchronize()
+    for r in range(world):
+        for o in range(world):
+            if o != r:
+                ctxs[r].unpack_columns(owner, o, cap, True, packs[o].data_ptr())
+        assert np.array_equal(ctxs[r].image, want_h)
+        assert np.array_equal(ctxs[r].normals, want_n)
+        ctxs[r].close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 4])
+def test_grouped_float_pass_is_bit_identical(mpr, tapes, k, monkeypatch):
+    """MPR_VOXEL_K: the experimental grouped float pass (K children walk the group's tape with
+    the stored choice masks) must give the same image as the per-tile walk."""
+    for name, dim, S in (("hello_world", 2, 256), ("bear", 3, 256), ("architecture", 3, 128)):
+        tape = tapes(name)
+        monkeypatch.setenv("MPR_VOXEL_K", "0")
+        a = mpr.Context(S)
+        monkeypatch.setenv("MPR_VOXEL_K", str(k))
+        b = mpr.Context(S)
+        for ctx in (a, b):
+            if dim == 2:
+                ctx.render2D(tape, view2())
+            else:
+                ctx.render3D(tape, view3())
+        assert np.array_equal(a.image, b.image)
+        if dim == 3:
+            assert np.array_equal(a.normals, b.normals)
+        a.close()
+        b.close()

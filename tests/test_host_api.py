@@ -1,0 +1,110 @@
+"""The C ABI: the library loads without a GPU, exports every symbol include/*.h declares, and
+its host-side pieces (.frep reader, tape builder, partitioner, error reporting) behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for hdr in ("mpr_amd.h", "mpr_clause.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(mpr_[a-z0-9_]+)\s*\(", text, flags=re.M):
+            line_start = text.rfind("\n", 0, m.start()) + 1
+            line = text[line_start:m.end()]
+            if "MPR_CL_FN" in line or "static" in line or "typedef" in line:
+                continue
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(mpr):
+    L = ctypes.CDLL(mpr.LIB_PATH)
+    names = declared_functions()
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_gpu_fails_loudly(mpr):
+    """Without a device, creating a context is an error with a message, never a CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(mpr.MprError) as e:
+        mpr.Context(256)
+    assert "HIP device" in str(e.value) or "hip" in str(e.value).lower()
+
+
+def test_argument_errors(mpr):
+    L = mpr.lib()
+    h = ctypes.c_void_p()
+    assert L.mpr_tree_from_frep(b"garbage", 7, ctypes.byref(h)) == 2          # MPR_ERR_PARSE
+    assert b"frep" in L.mpr_last_error()
+    assert L.mpr_tree_from_frep_file(b"/nonexistent.frep", ctypes.byref(h)) == 2
+    bad = np.array([1, 2, 3], dtype=np.uint64)
+    assert L.mpr_tape_from_clauses(bad.ctypes.data_as(ctypes.c_void_p), 3, ctypes.byref(h)) == 1
+    o = mpr.CtxOptions(0, 100, 0, 0)                                           # not a multiple of 64
+    assert L.mpr_ctx_create_ex(ctypes.byref(o), ctypes.byref(h)) == 1
+    assert L.mpr_render3d(None, None, None) != 0
+    assert L.mpr_op_str(14) == b"ADD_LHS_RHS" and L.mpr_op_str(200) == b"INVALID"
+
+
+def test_frep_round_trip(mpr):
+    for name in ("bear", "hello_world", "prospero"):
+        t = mpr.model(name)
+        blob = t.to_frep()
+        t2 = mpr.Tree.from_frep(blob)
+        assert t2.size() == t.size()
+        assert np.array_equal(mpr.Tape(t2).data, mpr.Tape(t).data)
+    raw = open(os.path.join(mpr.MODELS_DIR, "bear.frep"), "rb").read()
+    assert np.array_equal(mpr.Tape(mpr.Tree.from_frep(raw)).data, mpr.Tape(mpr.model("bear")).data)
+
+
+def test_tree_front_end(mpr):
+    X, Y = mpr.Tree.X(), mpr.Tree.Y()
+    a = (X + 1) * (X + 1)
+    rows = mpr.decode(mpr.Tape(a).data)
+    # hash-consing: X + 1 appears once, x * x of the same node is SQUARE
+    assert [r[0] for r in rows] == ["INVALID", "ADD_LHS_IMM", "SQUARE_LHS", "INVALID"]
+    assert mpr.decode(mpr.Tape(X * 1 + 0).data)[1:-1] == []        # identities fold away
+    rows = mpr.decode(mpr.Tape(2 - X).data)
+    assert rows[1][0] == "SUB_IMM_RHS" and rows[1][4] == 2.0
+    rows = mpr.decode(mpr.Tape(X / Y).data)
+    assert rows[1][0] == "DIV_LHS_RHS"
+    # remap (benchmark/render_effects.cpp:36): swapping axes swaps the head slots' roles
+    t = mpr.sqrt(X * X + Y * 4)
+    r1 = mpr.decode(mpr.Tape(t.remap(Y, X, mpr.Tree.Z())).data)
+    r0 = mpr.decode(mpr.Tape(mpr.sqrt(Y * Y + X * 4)).data)
+    assert r0 == r1
+
+
+def test_slot_exhaustion_flag(mpr):
+    """src/tape.cpp:79-81: more than 254 live values -> flag set, slot 0 used."""
+    X = mpr.Tree.X()
+    terms = [mpr.sin(X * float(i + 2)) for i in range(300)]
+    # keep all 300 values alive at once: sum them only after all were computed (right-deep)
+    acc = terms[-1]
+    for t in reversed(terms[:-1]):
+        acc = t + acc
+    tape = mpr.Tape(acc)
+    assert tape.flags & 1
+
+
+def test_partition_columns(mpr):
+    own = mpr.partition_columns(256, 8)
+    assert sorted(np.bincount(own)) == [32] * 8
+    w = np.zeros(256, dtype=np.float32)
+    w[:16] = 100.0
+    w[16:] = 1.0
+    own = mpr.partition_columns(256, 8, w)
+    load = np.bincount(own, weights=w, minlength=8)
+    assert load.max() / load.mean() < 1.05                         # LPT balances 16 heavy + 240 light
+    assert np.array_equal(own, mpr.partition_columns(256, 8, w))   # deterministic
+    assert set(own[:16]) == set(range(8))                          # heavy columns spread over all ranks
