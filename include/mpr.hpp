@@ -1,0 +1,231 @@
+/*
+ * mpr.hpp — header-only C++ façade over the C ABI (mpr_amd.h) that restores the API the
+ * reference's callers are written against:
+ *
+ *     auto tape = mpr::Tape(tree);                    inc/tape.hpp:24-30
+ *     auto ctx  = mpr::Context(size);                 inc/context.hpp:38-39
+ *     ctx.render2D(tape, Matrix3f::Identity());       inc/context.hpp:41-42
+ *     ctx.render3D(tape, T);                          inc/context.hpp:40
+ *     ctx.stages[3].filled[i], ctx.normals[i], ctx.stages[k].tiles[i],
+ *     ctx.stages[k].tile_array_size, ctx.tape_data[j], *ctx.tape_index
+ *
+ * The reference exposes managed-memory pointers; here the members are host mirrors that are
+ * refreshed by every render call (cheap next to a frame: S*S*8 bytes) or, for the bulky ones
+ * (tiles, tape_data), on first access after a render.  Eigen is not required: Matrix3f /
+ * Matrix4f below are minimal column-major matrices with Eigen's (row, col) indexing; an Eigen
+ * matrix's .data() can be passed to the *_raw overloads directly.
+ *
+ * libfive is not part of this repository; libfive::Tree below is the small expression front
+ * end of libmpr_amd (operators, sqrt/min/max/..., .frep archives) under libfive's names so that
+ * the reference's benchmark mains compile unchanged against this header.
+ */
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mpr_amd.h"
+
+namespace mpr {
+
+inline void check(int rc)
+{
+    if (rc != MPR_OK) throw std::runtime_error(std::string("mpr: ") + mpr_last_error());
+}
+
+template <int N>
+struct MatrixNf {
+    float m[N * N];
+    static MatrixNf Identity()
+    {
+        MatrixNf r;
+        for (int i = 0; i < N * N; ++i) r.m[i] = 0.0f;
+        for (int i = 0; i < N; ++i) r.m[i + i * N] = 1.0f;
+        return r;
+    }
+    float& operator()(int row, int col) { return m[row + col * N]; }
+    float operator()(int row, int col) const { return m[row + col * N]; }
+    const float* data() const { return m; }
+};
+using Matrix3f = MatrixNf<3>;
+using Matrix4f = MatrixNf<4>;
+
+}  // namespace mpr
+
+namespace libfive {
+
+/* stand-in for libfive::Tree (see tree.hpp in the library sources) */
+class Tree {
+public:
+    Tree() = default;
+    Tree(float v) { mpr_tree* t = nullptr; mpr::check(mpr_tree_const(v, &t)); reset(t); }
+    Tree(double v) : Tree((float)v) {}
+    Tree(int v) : Tree((float)v) {}
+    static Tree X() { mpr_tree* t = nullptr; mpr::check(mpr_tree_x(&t)); return Tree(t); }
+    static Tree Y() { mpr_tree* t = nullptr; mpr::check(mpr_tree_y(&t)); return Tree(t); }
+    static Tree Z() { mpr_tree* t = nullptr; mpr::check(mpr_tree_z(&t)); return Tree(t); }
+    static Tree unary(int op, const Tree& a)
+    {
+        mpr_tree* t = nullptr;
+        mpr::check(mpr_tree_unary(op, a.get(), &t));
+        return Tree(t);
+    }
+    static Tree binary(int op, const Tree& a, const Tree& b)
+    {
+        mpr_tree* t = nullptr;
+        mpr::check(mpr_tree_binary(op, a.get(), b.get(), &t));
+        return Tree(t);
+    }
+    Tree remap(const Tree& x, const Tree& y, const Tree& z) const
+    {
+        mpr_tree* t = nullptr;
+        mpr::check(mpr_tree_remap(get(), x.get(), y.get(), z.get(), &t));
+        return Tree(t);
+    }
+    /* Archive::deserialize(in).shapes.front().tree */
+    static Tree load(const std::string& frep_path)
+    {
+        mpr_tree* t = nullptr;
+        mpr::check(mpr_tree_from_frep_file(frep_path.c_str(), &t));
+        return Tree(t);
+    }
+    const mpr_tree* get() const { return p.get(); }
+
+private:
+    explicit Tree(mpr_tree* t) { reset(t); }
+    void reset(mpr_tree* t) { p = std::shared_ptr<mpr_tree>(t, mpr_tree_free); }
+    std::shared_ptr<mpr_tree> p;
+};
+inline Tree operator+(const Tree& a, const Tree& b) { return Tree::binary(MPR_T_ADD, a, b); }
+inline Tree operator-(const Tree& a, const Tree& b) { return Tree::binary(MPR_T_SUB, a, b); }
+inline Tree operator*(const Tree& a, const Tree& b) { return Tree::binary(MPR_T_MUL, a, b); }
+inline Tree operator/(const Tree& a, const Tree& b) { return Tree::binary(MPR_T_DIV, a, b); }
+inline Tree operator-(const Tree& a) { return Tree::unary(MPR_T_NEG, a); }
+inline Tree min(const Tree& a, const Tree& b) { return Tree::binary(MPR_T_MIN, a, b); }
+inline Tree max(const Tree& a, const Tree& b) { return Tree::binary(MPR_T_MAX, a, b); }
+inline Tree sqrt(const Tree& a) { return Tree::unary(MPR_T_SQRT, a); }
+inline Tree square(const Tree& a) { return Tree::unary(MPR_T_SQUARE, a); }
+inline Tree abs(const Tree& a) { return Tree::unary(MPR_T_ABS, a); }
+inline Tree sin(const Tree& a) { return Tree::unary(MPR_T_SIN, a); }
+inline Tree cos(const Tree& a) { return Tree::unary(MPR_T_COS, a); }
+inline Tree asin(const Tree& a) { return Tree::unary(MPR_T_ASIN, a); }
+inline Tree acos(const Tree& a) { return Tree::unary(MPR_T_ACOS, a); }
+inline Tree atan(const Tree& a) { return Tree::unary(MPR_T_ATAN, a); }
+inline Tree exp(const Tree& a) { return Tree::unary(MPR_T_EXP, a); }
+inline Tree log(const Tree& a) { return Tree::unary(MPR_T_LOG, a); }
+
+}  // namespace libfive
+
+namespace mpr {
+
+struct Tape {
+    explicit Tape(const libfive::Tree& tree)
+    {
+        mpr_tape* t = nullptr;
+        check(mpr_tape_from_tree(tree.get(), &t));
+        handle = std::shared_ptr<mpr_tape>(t, mpr_tape_free);
+        data = mpr_tape_data(t);
+        length = mpr_tape_length(t);
+    }
+    const uint64_t* data = nullptr;   /* host copy; the device copy lives in the Context's pool */
+    int32_t length = 0;
+    std::shared_ptr<mpr_tape> handle;
+};
+
+using TileNode = mpr_tile_node;
+
+struct Context;
+
+struct Tiles {
+    std::vector<int32_t> filled;      /* refreshed by every render call */
+    /* tiles / tile_array_size: fetched on demand */
+    const std::vector<TileNode>& tile_list() const;
+    size_t tile_array_size() const { return tile_list().size(); }
+    Context* owner = nullptr;
+    int index = 0;
+    mutable std::vector<TileNode> tiles_cache;
+    mutable bool tiles_valid = false;
+};
+
+struct Context {
+    explicit Context(int32_t image_size_px, int32_t device = 0) : image_size_px(image_size_px)
+    {
+        mpr_context* c = nullptr;
+        check(mpr_ctx_create(device, image_size_px, &c));
+        handle = std::shared_ptr<mpr_context>(c, mpr_ctx_destroy);
+        for (int i = 0; i < 4; ++i) {
+            stages[i].owner = this;
+            stages[i].index = i;
+        }
+    }
+    void render2D(const Tape& tape, const Matrix3f& mat, const float z = 0.0f)
+    {
+        check(mpr_render2d(handle.get(), tape.handle.get(), mat.data(), z));
+        refresh(false);
+    }
+    void render3D(const Tape& tape, const Matrix4f& mat)
+    {
+        check(mpr_render3d(handle.get(), tape.handle.get(), mat.data()));
+        refresh(true);
+    }
+    void render2D_brute(const Tape& tape, const Matrix3f& mat, const float z = 0.0f)
+    {
+        check(mpr_render2d_brute(handle.get(), tape.handle.get(), mat.data(), z));
+        refresh(false);
+    }
+    /* tape_data / *tape_index (benchmark/tape_shortening.cpp:56-72, render_3d_heatmap.cpp:64) */
+    const std::vector<uint64_t>& tape_data()
+    {
+        if (!pool_valid) {
+            int32_t ti = 0;
+            check(mpr_read_tape_pool(handle.get(), nullptr, 0, &ti));
+            pool.resize(ti > 0 ? (size_t)ti : 0);
+            if (!pool.empty()) check(mpr_read_tape_pool(handle.get(), pool.data(), pool.size(), &ti));
+            tape_index = ti;
+            pool_valid = true;
+        }
+        return pool;
+    }
+
+    int32_t image_size_px;
+    Tiles stages[4];
+    std::vector<uint32_t> normals;
+    int32_t tape_index = 0;
+    std::shared_ptr<mpr_context> handle;
+
+private:
+    friend struct Tiles;
+    void refresh(bool with_normals)
+    {
+        stages[3].filled.resize((size_t)image_size_px * image_size_px);
+        check(mpr_read_filled(handle.get(), 3, stages[3].filled.data()));
+        if (with_normals) {
+            normals.resize((size_t)image_size_px * image_size_px);
+            check(mpr_read_normals(handle.get(), normals.data()));
+        }
+        for (auto& s : stages) s.tiles_valid = false;
+        pool_valid = false;
+        mpr_counters c;
+        check(mpr_get_counters(handle.get(), &c));
+        tape_index = c.tape_index;
+    }
+    std::vector<uint64_t> pool;
+    bool pool_valid = false;
+};
+
+inline const std::vector<TileNode>& Tiles::tile_list() const
+{
+    if (!tiles_valid) {
+        size_t n = 0;
+        check(mpr_read_tiles(owner->handle.get(), index, nullptr, 0, &n));
+        tiles_cache.resize(n);
+        if (n) check(mpr_read_tiles(owner->handle.get(), index, tiles_cache.data(), n, &n));
+        tiles_valid = true;
+    }
+    return tiles_cache;
+}
+
+}  // namespace mpr

@@ -108,3 +108,11 @@ def test_partition_columns(mpr):
     assert load.max() / load.mean() < 1.05                         # LPT balances 16 heavy + 240 light
     assert np.array_equal(own, mpr.partition_columns(256, 8, w))   # deterministic
     assert set(own[:16]) == set(range(8))                          # heavy columns spread over all ranks
+
+
+def test_cpp_facade_compiles():
+    """include/mpr.hpp + the table benchmark written against it are valid C++17 (syntax check;
+    linking needs nothing beyond libmpr_amd.so)."""
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "benchmark", "render_table.cpp")])
