@@ -12,12 +12,13 @@ when the library or a device is missing.
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libmpr_amd.so")
+LIB_PATH = os.environ.get("MPR_AMD_LIB", os.path.join(_HERE, "libmpr_amd.so"))   # override: A/B builds
 MODELS_DIR = os.path.join(_ROOT, "fixtures", "models")
 
 TILE_DTYPE = np.dtype([("position", "<i4"), ("tape", "<i4"), ("next", "<i4")])
@@ -91,6 +92,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise MprError("libmpr_amd.so is missing: run mpr_amd.build() / __graft_entry__.build() first "
                        "(there is no CPU fallback)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; loading it first lets
+    # libmpr_amd.so bind to the same copy, so that torch tensors (multi-GPU gather buffers) and
+    # this library can share the device.  The other order leaves torch unable to see the GPU.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, f32, P = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.POINTER
     L.mpr_last_error.restype = ctypes.c_char_p

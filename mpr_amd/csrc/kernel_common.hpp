@@ -1,0 +1,35 @@
+/* kernel_common.hpp — small device helpers shared by kernels.hip and kernels_float.hip */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace mprk {
+
+struct int4_ { int x, y, z, w; };
+/* src/context.cu:23-30 */
+DEV int4_ unpack(int pos, int tps)
+{
+    int4_ r;
+    r.x = pos % tps;
+    r.y = (pos / tps) % tps;
+    r.z = (pos / tps) / tps;
+    r.w = pos % (tps * tps);
+    return r;
+}
+
+DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+DEV uint64_t ballot(bool p) { return __ballot(p); }
+DEV int rank_in(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
+DEV uint64_t rfl64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+DEV float immf(uint64_t d) { return mpr_u2f((uint32_t)(d >> 32)); }
+
+
+}  // namespace mprk

@@ -1,0 +1,562 @@
+/*
+ * kernels_float.hip — the round-to-nearest walkers: float voxel / pixel pass and the
+ * derivative (normals) pass.  See kernels.hip for the overall design.
+ *
+ * This translation unit is compiled with -mllvm -structurizecfg-skip-uniform-regions=1: the
+ * opcode dispatch of an interpreter is wave-uniform control flow, and without that option the
+ * AMDGPU structurizer rewrites the decision tree into flag-and-retest chains that double the
+ * scalar instructions per clause (the scalar ALU, 0.95 instr/clk/CU, is what bounds these
+ * kernels — scripts/ubench/issue_rates.hip).  The interval kernel (kernels.hip) is built
+ * without it (it miscompiles there: the parity suite fails).
+ */
+#include "kernel_common.hpp"
+
+namespace mprk {
+
+/* ------------------------------------------------------------------------------------ */
+/* eval_voxels_f with calculate_voxels / calculate_pixels fused (reference :707-964)     */
+/* one wave = the 64 voxels (4x4x4) or pixels (8x8) of one smallest tile                 */
+/* ------------------------------------------------------------------------------------ */
+/* Make a wave-uniform value live in a VGPR and opaque to the compiler's uniformity analysis, so
+ * that arithmetic on it is issued on the VALU (1.65 wave-instr/clk/CU, four pipes per CU)
+ * instead of the single scalar ALU of the CU (0.95 instr/clk/CU), which is the bottleneck of
+ * a tape interpreter (scripts/ubench/issue_rates.hip). */
+DEV uint32_t to_vgpr(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+/* rare, long opcodes: kept out of line so that the hot loop stays small in the I-cache */
+__device__ __noinline__ float rare_unary(uint32_t op, float v)
+{
+    switch (op) {
+        case MPR_OP_SIN_LHS: return mpr_sinf(v);
+        case MPR_OP_COS_LHS: return mpr_cosf(v);
+        case MPR_OP_ASIN_LHS: return mpr_asinf(v);
+        case MPR_OP_ACOS_LHS: return mpr_acosf(v);
+        case MPR_OP_ATAN_LHS: return mpr_atanf(v);
+        case MPR_OP_EXP_LHS: return mpr_expf(v);
+        default: return mpr_logf(v);
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+k_eval_voxels(VoxelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    unsigned char* const myslot = smem + (size_t)wave * a.nslots * 256 + lane * 4;   /* slot s: myslot + s*256 */
+
+    const int tile_index = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (tile_index >= a.count) return;
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const int position = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].position);
+    const int tape = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].tape);
+
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    const int S = a.tps * SUB;
+    const int4_ pos = unpack(position, a.tps);
+    const int4_ sub = unpack(lane, SUB);
+    const int px = pos.x * SUB + sub.x;
+    const int py = pos.y * SUB + sub.y;
+    const int pz = (DIM == 3) ? pos.z * 4 + sub.z : 0;
+
+    bool skip = false;
+    if (DIM == 3) {
+        /* reference :852-864: the thread owning (pz_low, pz_low + 2) leaves when image >= pz_low + 2 */
+        const int pz_low = pos.z * 4 + (sub.z & 1);
+        skip = a.image[px + py * S] >= pz_low + 2;
+        if (ballot(!skip) == 0) return;
+    }
+
+    const float size_recip = 1.0f / (float)(unsigned)(a.tps * SUB);
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    float vx, vy, vz;
+    if (DIM == 3) {
+        const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+        const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+        vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+        vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+        vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+    } else {
+        const float fw = a.mat[2] * fx + a.mat[5] * fy + a.mat[8];
+        vx = (a.mat[0] * fx + a.mat[3] * fy + a.mat[6]) / fw;
+        vy = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
+        vz = a.z;
+    }
+    const uint64_t head0 = tro[0];
+    *reinterpret_cast<float*>(myslot + ((head0 >> 8) & 0xFF) * 256) = vx;
+    *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
+    *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
+
+    /* Clause stream: 64 clauses per coalesced 512-byte load (lane j holds clause j), handed out
+     * with v_readlane.  Fields are decoded on the VALU from a VGPR copy of the clause; only the
+     * opcode goes to the scalar unit, for the branch. */
+    int base = tape + 1;
+    uint64_t blk = tro[base + lane];
+    int j = 0, words = 0;
+    uint32_t dlo = 0, dhi = 0;
+    for (;;) {
+        if (j == 64) {
+            base += 64;
+            blk = tro[base + lane];
+            j = 0;
+        }
+        dlo = __builtin_amdgcn_readlane((uint32_t)blk, j);
+        dhi = __builtin_amdgcn_readlane((uint32_t)(blk >> 32), j);
+        ++words;
+        const uint32_t op = dlo & 0xFF;
+        if (op < 2) {
+            if (op == 0) break;
+            base = base + j + (int32_t)dhi + 1;      /* JUMP */
+            blk = tro[base + lane];
+            j = 0;
+            continue;
+        }
+        ++j;
+        const uint32_t vlo = to_vgpr(dlo);
+        const float imm = mpr_u2f(to_vgpr(dhi));
+        const uint32_t r8 = vlo >> 24;
+        const float A = *reinterpret_cast<const float*>(myslot + ((vlo >> 8) & 0xFF00));
+        const float Bs = *reinterpret_cast<const float*>(myslot + (r8 << 8));
+        float* const outp = reinterpret_cast<float*>(myslot + (vlo & 0xFF00));
+        const float B = r8 ? Bs : imm;              /* immediate forms carry rhs == 0 */
+        float out;
+        if (op >= MPR_OP_ADD_LHS_IMM) {
+            if (op <= MPR_OP_MAX_LHS_RHS) {
+                if (op <= MPR_OP_MUL_LHS_RHS) out = (op <= MPR_OP_ADD_LHS_RHS) ? A + B : A * B;
+                else out = (op <= MPR_OP_MIN_LHS_RHS) ? mpr_fminf(A, B) : mpr_fmaxf(A, B);
+            } else if (op <= MPR_OP_DIV_LHS_RHS) {
+                /* B is already the immediate in the LHS_IMM forms; IMM_RHS swaps it in as lhs */
+                const float X = (op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_DIV_IMM_RHS) ? imm : A;
+                out = (op <= MPR_OP_SUB_LHS_RHS) ? X - B : X / B;
+            } else {
+                out = (op == MPR_OP_COPY_LHS) ? A : B;      /* COPY_IMM has rhs == 0 */
+            }
+        } else if (op <= MPR_OP_NEG_LHS) {
+            if (op == MPR_OP_SQUARE_LHS) out = A * A;
+            else out = (op == MPR_OP_NEG_LHS) ? -A : __builtin_sqrtf(A);
+        } else if (op == MPR_OP_ABS_LHS) {
+            out = __builtin_fabsf(A);
+        } else {
+            out = rare_unary(op, A);
+        }
+        *outp = out;
+    }
+    const float res = *reinterpret_cast<const float*>(myslot + (dlo & 0xFF00));
+    if (!skip && res < 0.0f) {
+        if (DIM == 3) {
+            int* p = &a.image[px + py * S];
+            if (*p < pz) atomicMax(p, pz);
+        } else {
+            a.image[px + py * S] = 1;
+        }
+    }
+    if (a.counters && lane == 0) {
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words);
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD_VOX], (unsigned long long)words);
+        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)(words - 1) * 64ull);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* float pass, grouped form.  The smallest tiles that survive are the children of the    */
+/* last tile stage's groups; a child's shortened tape is its group's tape with the       */
+/* child's min/max decisions applied, and clauses the shortening dropped can be          */
+/* evaluated harmlessly (their output slot is dead for that child).  So K = 4 children   */
+/* walk the GROUP's tape together: one clause fetch + decode per 256 voxels, the slot    */
+/* file is float4 per lane (ds_read_b128 / ds_write_b128, conflict-free), and a min/max  */
+/* clause resolves per child from the stored choice masks (wave-uniform per child).      */
+/* Bit-identical to walking each child's own sub-tape (k_eval_voxels).                   */
+/* Clauses are fetched 64 at a time with one coalesced 512-byte load (lane j holds        */
+/* clause j) and handed out with v_readlane.                                             */
+/* ------------------------------------------------------------------------------------ */
+/* K floats per lane as one LDS vector (K = 1, 2, 4 -> ds_read_b32 / b64 / b128) */
+template <int K> struct VecK;
+template <> struct VecK<1> { typedef float type; };
+template <> struct VecK<2> { typedef float2 type; };
+template <> struct VecK<4> { typedef float4 type; };
+template <int K> struct Pack {
+    float v[K];
+    DEV void load(const typename VecK<K>::type* p)
+    {
+        const typename VecK<K>::type t = *p;
+        __builtin_memcpy(v, &t, sizeof(t));
+    }
+    DEV void store(typename VecK<K>::type* p) const
+    {
+        typename VecK<K>::type t;
+        __builtin_memcpy(&t, v, sizeof(t));
+        *p = t;
+    }
+    DEV void splat(float f)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = f;
+    }
+};
+
+template <int DIM, int K>
+__global__ void __launch_bounds__(64)
+k_eval_voxels_grouped(GroupedVoxelArgs a)
+{
+    typedef typename VecK<K>::type vec_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    vec_t* const slots = reinterpret_cast<vec_t*>(smem);            /* [nslots][64], K floats per lane */
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    const mpr_tile_node nd = a.tiles[(size_t)g * 64 + lane];
+    uint64_t amask = ballot(nd.position != -1);
+    if (amask == 0) return;
+
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const int tape = __builtin_amdgcn_readfirstlane(a.groups[g].tape);
+    const int nchoices = __builtin_amdgcn_readfirstlane(a.groups[g].nchoices);
+    const ulonglong2* __restrict__ const masks = a.choice_masks + (size_t)g * a.choice_cap;
+    const uint64_t head0 = tro[0];
+    const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
+
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    const int S = a.tps * SUB;
+    const int4_ sub = unpack(lane, SUB);
+    const float size_recip = 1.0f / (float)(unsigned)S;
+    vec_t* const myslot = slots + lane;                  /* slot s of this lane: myslot[s * 64] */
+    long long words_total = 0, lane_clauses = 0;
+
+    while (amask) {
+        int c[K];
+        bool valid[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            valid[k] = amask != 0;
+            if (valid[k]) {
+                c[k] = __ffsll((long long)amask) - 1;
+                amask &= amask - 1;
+            } else {
+                c[k] = c[k - 1 < 0 ? 0 : k - 1];
+            }
+        }
+        int px[K], py[K], pz[K];
+        bool skip[K];
+        Pack<K> vx, vy, vz;
+        bool all_skip = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int4_ pos = unpack(__builtin_amdgcn_readlane(nd.position, c[k]), a.tps);
+            px[k] = pos.x * SUB + sub.x;
+            py[k] = pos.y * SUB + sub.y;
+            pz[k] = (DIM == 3) ? pos.z * 4 + sub.z : 0;
+            skip[k] = !valid[k];
+            if (DIM == 3) {
+                const int pz_low = pos.z * 4 + (sub.z & 1);      /* reference :852-864 */
+                skip[k] = skip[k] || (a.image[px[k] + py[k] * S] >= pz_low + 2);
+            }
+            all_skip = all_skip && skip[k];
+            const float fx = ((px[k] + 0.5f) * size_recip - 0.5f) * 2.0f;
+            const float fy = ((py[k] + 0.5f) * size_recip - 0.5f) * 2.0f;
+            if (DIM == 3) {
+                const float fz = ((pz[k] + 0.5f) * size_recip - 0.5f) * 2.0f;
+                const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+                vx.v[k] = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+                vy.v[k] = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+                vz.v[k] = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+            } else {
+                const float fw = a.mat[2] * fx + a.mat[5] * fy + a.mat[8];
+                vx.v[k] = (a.mat[0] * fx + a.mat[3] * fy + a.mat[6]) / fw;
+                vy.v[k] = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
+                vz.v[k] = a.z;
+            }
+        }
+        if (ballot(!all_skip) == 0) continue;
+
+        vx.store(&myslot[sx * 64]);
+        vy.store(&myslot[sy * 64]);
+        vz.store(&myslot[sz * 64]);
+
+        int base = tape + 1;                 /* pool index of the block's first word */
+        uint64_t blk = tro[base + lane];
+        int j = 0, ci = 0, words = 0, ncl = 0;
+        uint32_t dlo = 0, dhi = 0;
+        for (;;) {
+            if (j == 64) {
+                base += 64;
+                blk = tro[base + lane];
+                j = 0;
+            }
+            dlo = __builtin_amdgcn_readlane((uint32_t)blk, j);
+            dhi = __builtin_amdgcn_readlane((uint32_t)(blk >> 32), j);
+            ++words;
+            const uint32_t op = dlo & 0xFF;
+            if (op < 2) {
+                if (op == 0) break;
+                base = base + j + (int32_t)dhi + 1;      /* JUMP: relative to the JUMP word, then pre-increment */
+                blk = tro[base + lane];
+                j = 0;
+                continue;
+            }
+            ++j;
+            ++ncl;
+            const uint32_t o = (dlo >> 8) & 0xFF, l = (dlo >> 16) & 0xFF, r = dlo >> 24;
+            const float imm = mpr_u2f(dhi);
+            Pack<K> A, B, out;
+            A.load(&myslot[l * 64]);
+            B.load(&myslot[r * 64]);        /* slot 0 when the clause has no rhs: both reads in flight together */
+            if (op >= MPR_OP_ADD_LHS_IMM) {
+                if (r == 0) B.splat(imm);
+                if (op <= MPR_OP_MUL_LHS_RHS) {
+                    if (op <= MPR_OP_ADD_LHS_RHS) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] + B.v[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] * B.v[k];
+                    }
+                } else if (op <= MPR_OP_MAX_LHS_RHS) {
+                    /* min / max: the child's recorded decision replaces the operation */
+                    uint64_t m1 = 0, m2 = 0;
+                    if (ci < nchoices) {
+                        const ulonglong2 m = masks[ci];
+                        m1 = m.x;
+                        m2 = m.y;
+                    }
+                    ++ci;
+                    const bool is_min = op <= MPR_OP_MIN_LHS_RHS;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float mm = is_min ? mpr_fminf(A.v[k], B.v[k]) : mpr_fmaxf(A.v[k], B.v[k]);
+                        out.v[k] = ((m1 >> c[k]) & 1) ? A.v[k] : (((m2 >> c[k]) & 1) ? B.v[k] : mm);
+                    }
+                } else if (op <= MPR_OP_DIV_LHS_RHS) {
+                    /* SUB / DIV: B is already the immediate in the LHS_IMM form (r == 0) */
+                    if (op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_DIV_IMM_RHS) A.splat(imm);
+                    if (op <= MPR_OP_SUB_LHS_RHS) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] - B.v[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] / B.v[k];
+                    }
+                } else {
+                    out = (op == MPR_OP_COPY_LHS) ? A : B;     /* COPY_IMM: r == 0, B is the immediate */
+                }
+            } else if (op == MPR_OP_SQUARE_LHS) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) out.v[k] = A.v[k] * A.v[k];
+            } else if (op == MPR_OP_NEG_LHS) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) out.v[k] = -A.v[k];
+            } else if (op == MPR_OP_SQRT_LHS) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) out.v[k] = __builtin_sqrtf(A.v[k]);
+            } else if (op == MPR_OP_ABS_LHS) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) out.v[k] = __builtin_fabsf(A.v[k]);
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < K; ++k) out.v[k] = rare_unary(op, A.v[k]);
+            }
+            out.store(&myslot[o * 64]);
+        }
+        const uint32_t i_out = (dlo >> 8) & 0xFF;
+        Pack<K> res;
+        res.load(&myslot[i_out * 64]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (DIM == 3) {
+                /* the four lanes lane&15 share an (x, y): keep the tallest filled voxel */
+                int zv = (!skip[k] && res.v[k] < 0.0f) ? pz[k] : -1;
+                zv = max(zv, __shfl_xor(zv, 16));
+                zv = max(zv, __shfl_xor(zv, 32));
+                if (valid[k] && lane < 16 && zv >= 0) {
+                    int* p = &a.image[px[k] + py[k] * S];
+                    if (*p < zv) atomicMax(p, zv);
+                }
+            } else if (!skip[k] && res.v[k] < 0.0f) {
+                a.image[px[k] + py[k] * S] = 1;
+            }
+        }
+        words_total += words;
+        int nvalid = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) nvalid += valid[k] ? 1 : 0;
+        lane_clauses += (long long)ncl * 64 * nvalid;
+    }
+    if (a.counters && lane == 0) {
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD_VOX], (unsigned long long)words_total);
+        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* eval_pixels_d — normals by forward-mode AD (reference :978-1132)                      */
+/* one wave = an 8x8 pixel patch; lanes are grouped by the tape they need               */
+/* ------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(64)
+k_eval_normals(NormalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* const slots = reinterpret_cast<float4*>(smem);     /* [nslots][64] (dx,dy,dz,v) */
+    const int lane = threadIdx.x;
+    const int S = a.size;
+    const int patches = S / 8;
+    const int px = (blockIdx.x % patches) * 8 + (lane & 7);
+    const int py = (blockIdx.x / patches) * 8 + (lane >> 3);
+    const int pxy = px + py * S;
+    int pz = a.image[pxy];
+    const bool filled = pz != 0;
+    uint64_t todo = ballot(filled);
+    if (todo == 0) return;
+    if (pz < S - 1) pz += 1;                                   /* :1003-1005 */
+
+    const float size_recip = 1.0f / (float)(unsigned)S;
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+    const float vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+    const float vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+    const float vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+
+    /* deepest tile's tape (:1034-1066) */
+    int my_tape = 0;
+    if (filled) {
+        const int t64 = S / 64;
+        const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
+        const mpr_tile_node tn = a.tiles[tile];
+        if (tn.next == -1) {
+            my_tape = tn.tape;
+        } else {
+            const int subtile = tn.next * 64 + (px % 64) / 16 + ((py % 64) / 16) * 4 + ((pz % 64) / 16) * 16;
+            const mpr_tile_node sn = a.subtiles[subtile];
+            if (sn.next == -1) {
+                my_tape = sn.tape;
+            } else {
+                const int micro = sn.next * 64 + (px % 16) / 4 + ((py % 16) / 4) * 4 + ((pz % 16) / 4) * 16;
+                my_tape = a.microtiles[micro].tape;
+            }
+        }
+    }
+
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const uint64_t head0 = tro[0];
+    const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
+    deriv result = d_const(0.0f);
+    long long words_total = 0;
+    long long lane_clauses = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int tape = __builtin_amdgcn_readlane(my_tape, leader);
+        const bool mine = filled && my_tape == tape;
+        const uint64_t grp = ballot(mine);
+        todo &= ~grp;
+
+        /* :1021-1031 — value first, then the unit partials (unused axes alias slot 0) */
+        slots[sx * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vx);
+        slots[sy * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vy);
+        slots[sz * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vz);
+        slots[sx * 64 + lane].x = 1.0f;
+        slots[sy * 64 + lane].y = 1.0f;
+        slots[sz * 64 + lane].z = 1.0f;
+
+        const uint64_t* data = tro + tape;
+        int words = 0, ncl = 0;
+        for (;;) {
+            const uint64_t d = *++data;
+            ++words;
+            const uint32_t op = (uint32_t)d & 0xFF;
+            if (!op) break;
+            if (op == MPR_OP_JUMP) {
+                data += (int32_t)(d >> 32);
+                continue;
+            }
+            const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+            const float4 lv = slots[l * 64 + lane];
+            const float4 rv = slots[r * 64 + lane];
+            const deriv out = deriv_clause(op, dv(lv.w, lv.x, lv.y, lv.z), dv(rv.w, rv.x, rv.y, rv.z), immf(d));
+            slots[o * 64 + lane] = make_float4(out.dx, out.dy, out.dz, out.v);
+            ++ncl;
+        }
+        const uint32_t i_out = (uint32_t)(*data >> 8) & 0xFF;
+        const float4 rr = slots[i_out * 64 + lane];
+        if (mine) result = dv(rr.w, rr.x, rr.y, rr.z);
+        words_total += words;
+        lane_clauses += (long long)ncl * __popcll(grp);
+    }
+
+    if (filled) {
+        /* :1123-1131 */
+        const float norm = __builtin_sqrtf(result.dx * result.dx + result.dy * result.dy + result.dz * result.dz);
+        const uint32_t dx = f2u8((result.dx / norm) * 127 + 128);
+        const uint32_t dy = f2u8((result.dy / norm) * 127 + 128);
+        const uint32_t dz = f2u8((result.dz / norm) * 127 + 128);
+        a.output[pxy] = (0xFFu << 24) | (dz << 16) | (dy << 8) | dx;
+    }
+    if (a.counters) {
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
+            atomicAdd((unsigned long long*)&a.counters[CNT_FWD_NORM], (unsigned long long)words_total);
+            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
+            atomicAdd((unsigned long long*)&a.counters[CNT_NORMAL_PX], (unsigned long long)__popcll(ballot(filled)));
+        }
+    }
+}
+
+/* ---- launchers ---------------------------------------------------------------------- */
+/* gfx950 offers 160 KiB of LDS per workgroup; anything above the 64 KiB default must be opted in */
+template <typename K>
+static void allow_big_lds(K kernel)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+static void opt_in_once()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    allow_big_lds(k_eval_voxels<2>);
+    allow_big_lds(k_eval_voxels<3>);
+    allow_big_lds(k_eval_normals);
+    allow_big_lds(k_eval_voxels_grouped<2, 4>);
+    allow_big_lds(k_eval_voxels_grouped<3, 4>);
+}
+size_t voxel_lds_bytes(int nslots) { return (size_t)nslots * 256 * 4; }
+void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a)
+{
+    if (a.count <= 0) return;
+    opt_in_once();
+    const dim3 g((a.count + 3) / 4), b(256);
+    const size_t lds = voxel_lds_bytes(a.nslots);
+    if (dim == 3) hipLaunchKernelGGL(k_eval_voxels<3>, g, b, lds, s, a);
+    else hipLaunchKernelGGL(k_eval_voxels<2>, g, b, lds, s, a);
+}
+size_t grouped_voxel_lds_bytes(int nslots, int k) { return (size_t)nslots * 256 * k; }
+void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a)
+{
+    if (a.ngroups <= 0) return;
+    opt_in_once();
+    const size_t lds = grouped_voxel_lds_bytes(a.nslots, k);
+    const dim3 g(a.ngroups), b(64);
+    if (dim == 3) {
+        if (k == 1) hipLaunchKernelGGL((k_eval_voxels_grouped<3, 1>), g, b, lds, s, a);
+        else if (k == 2) hipLaunchKernelGGL((k_eval_voxels_grouped<3, 2>), g, b, lds, s, a);
+        else hipLaunchKernelGGL((k_eval_voxels_grouped<3, 4>), g, b, lds, s, a);
+    } else {
+        if (k == 1) hipLaunchKernelGGL((k_eval_voxels_grouped<2, 1>), g, b, lds, s, a);
+        else if (k == 2) hipLaunchKernelGGL((k_eval_voxels_grouped<2, 2>), g, b, lds, s, a);
+        else hipLaunchKernelGGL((k_eval_voxels_grouped<2, 4>), g, b, lds, s, a);
+    }
+}
+size_t normals_lds_bytes(int nslots) { return (size_t)nslots * 1024; }
+void launch_eval_normals(hipStream_t s, const NormalArgs& a)
+{
+    opt_in_once();
+    const int patches = a.size / 8;
+    hipLaunchKernelGGL(k_eval_normals, dim3(patches * patches), dim3(64), normals_lds_bytes(a.nslots), s, a);
+}
+
+}  // namespace mprk
