@@ -135,43 +135,32 @@ DEV float d2f_ru(double d)
 DEV ival i_neg(ival x) { return iv(-x.hi, -x.lo); }                                      /* :66-68 */
 DEV ival i_add(ival x, ival y) { return iv(rd_add(x.lo, y.lo), ru_add(x.hi, y.hi)); }    /* :72-74 */
 DEV ival i_add_f(ival x, float y) { return iv(rd_add(x.lo, y), ru_add(x.hi, y)); }       /* :76-78 */
+/* Sign-case table of inc/gpu_interval.hpp:86-146, evaluated without branches (lanes of a
+ * wave are 64 different tiles and would diverge over the nine cases).  With the classes
+ *   M: lo < 0 && hi > 0   N: lo < 0 && !(hi > 0)   P: !(lo < 0) && hi > 0   Z: neither
+ * the table's lower bound is RD(p*q), its upper bound RU(r*s) with
+ *   p = y:P ? x.lo : y:N ? x.hi : (x:N ? x.lo : x.hi)      q = (x:N || (x:M && y:P)) ? y.hi : y.lo
+ *   r = (y:P || (x:P && y:M)) ? x.hi : x.lo                s = (x:P || (x:M && y:P)) ? y.hi : y.lo
+ * M*M additionally takes min / max with RD(x.lo*y.hi) and RU(x.hi*y.hi); any Z operand gives
+ * [0, 0].  (Comparisons with NaN are false exactly as in the nested ifs.) */
 DEV ival i_mul(ival x, ival y)                                                           /* :86-146 */
 {
-    if (x.lo < 0.0f) {
-        if (x.hi > 0.0f) {
-            if (y.lo < 0.0f) {
-                if (y.hi > 0.0f) {
-                    return iv(mpr_fminf(rd_mul(x.lo, y.hi), rd_mul(x.hi, y.lo)),
-                              mpr_fmaxf(ru_mul(x.lo, y.lo), ru_mul(x.hi, y.hi)));
-                } else {
-                    return iv(rd_mul(x.hi, y.lo), ru_mul(x.lo, y.lo));
-                }
-            } else {
-                if (y.hi > 0.0f) return iv(rd_mul(x.lo, y.hi), ru_mul(x.hi, y.hi));
-                else return iv(0.0f, 0.0f);
-            }
-        } else {
-            if (y.lo < 0.0f) {
-                if (y.hi > 0.0f) return iv(rd_mul(x.lo, y.hi), ru_mul(x.lo, y.lo));
-                else return iv(rd_mul(x.hi, y.hi), ru_mul(x.lo, y.lo));
-            } else {
-                if (y.hi > 0.0f) return iv(rd_mul(x.lo, y.hi), ru_mul(x.hi, y.lo));
-                else return iv(0.0f, 0.0f);
-            }
-        }
-    } else {
-        if (x.hi > 0.0f) {
-            if (y.lo < 0.0f) {
-                if (y.hi > 0.0f) return iv(rd_mul(x.hi, y.lo), ru_mul(x.hi, y.hi));
-                else return iv(rd_mul(x.hi, y.lo), ru_mul(x.lo, y.hi));
-            } else {
-                if (y.hi > 0.0f) return iv(rd_mul(x.lo, y.lo), ru_mul(x.hi, y.hi));
-                else return iv(0.0f, 0.0f);
-            }
-        } else {
-            return iv(0.0f, 0.0f);
-        }
-    }
+    const bool xn = x.lo < 0.0f, xp = x.hi > 0.0f, yn = y.lo < 0.0f, yp = y.hi > 0.0f;
+    const bool xM = xn && xp, xN = xn && !xp, xP = !xn && xp;
+    const bool yM = yn && yp, yN = yn && !yp, yP = !yn && yp;
+    const float p = yP ? x.lo : (yN ? x.hi : (xN ? x.lo : x.hi));
+    const float q = (xN || (xM && yP)) ? y.hi : y.lo;
+    const float r = (yP || (xP && yM)) ? x.hi : x.lo;
+    const float s = (xP || (xM && yP)) ? y.hi : y.lo;
+    float lo = rd_mul(p, q);
+    float hi = ru_mul(r, s);
+    const float lo2 = rd_mul(x.lo, y.hi);
+    const float hi2 = ru_mul(x.hi, y.hi);
+    const bool mm = xM && yM;
+    lo = mm ? mpr_fminf(lo2, lo) : lo;
+    hi = mm ? mpr_fmaxf(hi, hi2) : hi;
+    const bool zero = !(xn || xp) || !(yn || yp);
+    return iv(zero ? 0.0f : lo, zero ? 0.0f : hi);
 }
 DEV ival i_mul_f(ival x, float y)                                                        /* :148-154 */
 {
@@ -204,40 +193,34 @@ DEV ival i_div_f(ival x, float y)                                               
 DEV ival i_fdiv(float x, ival y) { return i_div(iv(x, x), y); }                          /* :202-204 */
 DEV ival i_min(ival x, ival y, int& choice)                                              /* :208-216 */
 {
-    if (x.hi < y.lo) { choice = 1; return x; }
-    else if (y.hi < x.lo) { choice = 2; return y; }
-    return iv(mpr_fminf(x.lo, y.lo), mpr_fminf(x.hi, y.hi));
+    const bool c1 = x.hi < y.lo;
+    const bool c2 = !c1 && (y.hi < x.lo);
+    choice = c1 ? 1 : (c2 ? 2 : choice);
+    const float lo = mpr_fminf(x.lo, y.lo), hi = mpr_fminf(x.hi, y.hi);
+    return iv(c1 ? x.lo : (c2 ? y.lo : lo), c1 ? x.hi : (c2 ? y.hi : hi));
 }
-DEV ival i_min_f(ival x, float y, int& choice)                                           /* :218-228 */
-{
-    if (x.hi < y) { choice = 1; return x; }
-    else if (y < x.lo) { choice = 2; return iv(y, y); }
-    return iv(mpr_fminf(x.lo, y), mpr_fminf(x.hi, y));
-}
+DEV ival i_min_f(ival x, float y, int& choice) { return i_min(x, iv(y, y), choice); }    /* :218-228 */
 DEV ival i_max(ival x, ival y, int& choice)                                              /* :232-240 */
 {
-    if (x.lo > y.hi) { choice = 1; return x; }
-    else if (y.lo > x.hi) { choice = 2; return y; }
-    return iv(mpr_fmaxf(x.lo, y.lo), mpr_fmaxf(x.hi, y.hi));
+    const bool c1 = x.lo > y.hi;
+    const bool c2 = !c1 && (y.lo > x.hi);
+    choice = c1 ? 1 : (c2 ? 2 : choice);
+    const float lo = mpr_fmaxf(x.lo, y.lo), hi = mpr_fmaxf(x.hi, y.hi);
+    return iv(c1 ? x.lo : (c2 ? y.lo : lo), c1 ? x.hi : (c2 ? y.hi : hi));
 }
-DEV ival i_max_f(ival x, float y, int& choice)                                           /* :242-252 */
-{
-    if (x.lo > y) { choice = 1; return x; }
-    else if (y > x.hi) { choice = 2; return iv(y, y); }
-    return iv(mpr_fmaxf(x.lo, y), mpr_fmaxf(x.hi, y));
-}
+DEV ival i_max_f(ival x, float y, int& choice) { return i_max(x, iv(y, y), choice); }    /* :242-252 */
 DEV ival i_square(ival x)                                                                /* :256-266 */
 {
-    if (x.hi < 0.0f) return iv(rd_mul(x.hi, x.hi), ru_mul(x.lo, x.lo));
-    else if (x.lo > 0.0f) return iv(rd_mul(x.lo, x.lo), ru_mul(x.hi, x.hi));
-    else if (-x.lo > x.hi) return iv(0.0f, ru_mul(x.lo, x.lo));
-    else return iv(0.0f, ru_mul(x.hi, x.hi));
+    const float a = ru_mul(x.lo, x.lo), b = ru_mul(x.hi, x.hi);
+    const float c = rd_mul(x.lo, x.lo), d = rd_mul(x.hi, x.hi);
+    const bool neg = x.hi < 0.0f, pos = x.lo > 0.0f, big = -x.lo > x.hi;
+    return iv(neg ? d : (pos ? c : 0.0f), neg ? a : (pos ? b : (big ? a : b)));
 }
 DEV ival i_abs(ival x)                                                                   /* :268-276 */
 {
-    if (x.lo >= 0.0f) return x;
-    else if (x.hi < 0.0f) return i_neg(x);
-    else return iv(0.0f, mpr_fmaxf(-x.lo, x.hi));
+    const bool nonneg = x.lo >= 0.0f, neg = x.hi < 0.0f;
+    const float m = mpr_fmaxf(-x.lo, x.hi);
+    return iv(nonneg ? x.lo : (neg ? -x.hi : 0.0f), nonneg ? x.hi : (neg ? -x.lo : m));
 }
 DEV ival i_sub(ival x, ival y) { return iv(rd_sub(x.lo, y.hi), ru_sub(x.hi, y.lo)); }    /* :284-286 */
 DEV ival i_sub_f(ival x, float y) { return iv(rd_sub(x.lo, y), ru_sub(x.hi, y)); }       /* :288-290 */

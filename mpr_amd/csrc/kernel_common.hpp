@@ -32,4 +32,14 @@ DEV uint64_t rfl64(uint64_t v)
 DEV float immf(uint64_t d) { return mpr_u2f((uint32_t)(d >> 32)); }
 
 
+/* Make a wave-uniform value live in a VGPR and opaque to the compiler's uniformity analysis, so
+ * that arithmetic on it is issued on the VALU (1.65 wave-instr/clk/CU, four pipes per CU)
+ * instead of the single scalar ALU of the CU (0.95 instr/clk/CU), which is the bottleneck of
+ * a tape interpreter (scripts/ubench/issue_rates.hip). */
+DEV uint32_t to_vgpr(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 }  // namespace mprk

@@ -17,16 +17,6 @@ namespace mprk {
 /* eval_voxels_f with calculate_voxels / calculate_pixels fused (reference :707-964)     */
 /* one wave = the 64 voxels (4x4x4) or pixels (8x8) of one smallest tile                 */
 /* ------------------------------------------------------------------------------------ */
-/* Make a wave-uniform value live in a VGPR and opaque to the compiler's uniformity analysis, so
- * that arithmetic on it is issued on the VALU (1.65 wave-instr/clk/CU, four pipes per CU)
- * instead of the single scalar ALU of the CU (0.95 instr/clk/CU), which is the bottleneck of
- * a tape interpreter (scripts/ubench/issue_rates.hip). */
-DEV uint32_t to_vgpr(uint32_t x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
 /* rare, long opcodes: kept out of line so that the hot loop stays small in the I-cache */
 __device__ __noinline__ float rare_unary(uint32_t op, float v)
 {
