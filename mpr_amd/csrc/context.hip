@@ -367,6 +367,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
+            a.debug = getenv("MPR_DEBUG_TILES") ? atoi(getenv("MPR_DEBUG_TILES")) : 0;
             TimedScope ts(c, "eval_tiles_i");
             mprk::launch_eval_tiles(s, dim, a);
         }

@@ -29,6 +29,12 @@ DEV uint64_t rfl64(uint64_t v)
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+/* The readlane / readfirstlane builtins return a signed int: always go through these so that
+ * widening to 64 bits cannot sign-extend (a mask with bit 31 set would otherwise turn its upper
+ * half into all ones). */
+DEV uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+DEV uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DEV uint64_t rdlane64(uint64_t v, uint32_t l) { return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l); }
 DEV float immf(uint64_t d) { return mpr_u2f((uint32_t)(d >> 32)); }
 
 

@@ -53,14 +53,50 @@ __global__ void k_preload_tiles(mpr_tile_node* __restrict__ tiles, int count, in
 /* eval_tiles_i — interval walk + classification + tape pushing (reference :188-459),    */
 /* with calculate_intervals (:78-159) and the first mask_filled_tiles (:471-495) fused   */
 /* ------------------------------------------------------------------------------------ */
+/* 256 64-bit lane masks (one per slot) held in VGPR lanes: slot s lives in lane s & 63 of
+ * register pair s >> 6.  Reads and writes are v_readlane / v_writelane with a scalar lane
+ * index: no memory, no latency to hide. */
+struct LaneMasks {
+    uint32_t lo0, hi0, lo1, hi1;     /* slots 0..63 and 64..127: lane = slot & 63 */
+    uint64_t* spill;                 /* slots 128..255 (beyond what the reference's kernels hold): LDS */
+};
+/* v_writelane: this clang has no builtin for it; a lane-id compare + select is two VALU ops */
+DEV uint32_t write_lane(uint32_t old, uint32_t value, uint32_t target_lane)
+{
+    return ((uint32_t)lane_id() == target_lane) ? value : old;
+}
+DEV uint64_t lm_get(const LaneMasks& m, uint32_t s)
+{
+    const uint32_t i = s & 63;
+    if (s < 64) return ((uint64_t)rdlane(m.hi0, i) << 32) | rdlane(m.lo0, i);
+    if (s < 128) return ((uint64_t)rdlane(m.hi1, i) << 32) | rdlane(m.lo1, i);
+    return rfl64(m.spill[s - 128]);
+}
+DEV void lm_set(LaneMasks& m, uint32_t s, uint64_t v)
+{
+    const uint32_t i = s & 63, lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (s < 64) { m.lo0 = write_lane(m.lo0, lo, i); m.hi0 = write_lane(m.hi0, hi, i); }
+    else if (s < 128) { m.lo1 = write_lane(m.lo1, lo, i); m.hi1 = write_lane(m.hi1, hi, i); }
+    else if (lane_id() == 0) m.spill[s - 128] = v;
+}
+
+/* long / rare interval operations (sqrt, division, the double-precision transcendentals), out of
+ * line: the hot loop stays small and the kernel's register budget is not set by OCML's exp/log */
+__device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, float imm)
+{
+    int c = 0;
+    const ival o = interval_clause(op, iv(l.x, l.y), iv(r.x, r.y), imm, c);
+    return make_float2(o.lo, o.hi);
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(64)
 k_eval_tiles(TileStageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2* const slots = reinterpret_cast<float2*>(smem);                       /* [nslots][64] */
-    uint64_t* const act = reinterpret_cast<uint64_t*>(smem + (size_t)a.nslots * 512);     /* [256] */
-    ulonglong2* const choices = reinterpret_cast<ulonglong2*>(smem + (size_t)a.nslots * 512 + 2048);
+    ulonglong2* const choices = reinterpret_cast<ulonglong2*>(smem + (size_t)a.nslots * 512);       /* [choice_cap] */
+    uint64_t* const act = reinterpret_cast<uint64_t*>(smem + (size_t)a.nslots * 512 + (size_t)a.choice_cap * 16);   /* [128], nslots > 128 only */
 
     const uint64_t* __restrict__ const tro = a.tape_ro;
     uint64_t* __restrict__ const twr = a.tape_wr;
@@ -128,25 +164,62 @@ k_eval_tiles(TileStageArgs a)
     slots[((head0 >> 16) & 0xFF) * 64 + lane] = make_float2(vy.lo, vy.hi);
     slots[((head0 >> 24) & 0xFF) * 64 + lane] = make_float2(vz.lo, vz.hi);
 
-    /* ---- forward walk ---- */
-    const uint64_t* data = tro + tape;
+    /* ---- forward walk: 64 clauses per coalesced 512-byte load (lane j holds clause j), handed
+     *      out with v_readlane ---- */
+    int base = tape + 1;
+    uint64_t blk = tro[base + lane];
+    int j = 0;
     int ci = 0;
     uint64_t any_choice = 0;
     int fwd_words = 0, nclauses = 0;
+    uint64_t d = 0;
     for (;;) {
-        const uint64_t d = *++data;
+        if (j == 64) {
+            base += 64;
+            blk = tro[base + lane];
+            j = 0;
+        }
+        d = rdlane64(blk, j);
         ++fwd_words;
         const uint32_t op = (uint32_t)d & 0xFF;
         if (!op) break;
         if (op == MPR_OP_JUMP) {
-            data += (int32_t)(d >> 32);
+            base = base + j + (int32_t)(d >> 32) + 1;
+            blk = tro[base + lane];
+            j = 0;
             continue;
         }
+        ++j;
         const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
         const float2 lv = slots[l * 64 + lane];
         const float2 rv = slots[r * 64 + lane];
         int c = 0;
-        const ival out = interval_clause(op, iv(lv.x, lv.y), iv(rv.x, rv.y), immf(d), c);
+        const float imm = immf(d);
+        const ival A = iv(lv.x, lv.y);
+        const ival B = r ? iv(rv.x, rv.y) : iv(imm, imm);      /* immediate forms carry rhs == 0 */
+        ival out;
+        if (op >= MPR_OP_ADD_LHS_IMM && op <= MPR_OP_SUB_LHS_RHS) {
+            if (op <= MPR_OP_MUL_LHS_RHS) {
+                if (op <= MPR_OP_ADD_LHS_RHS) out = i_add(A, B);
+                else if (op == MPR_OP_MUL_LHS_IMM) out = i_mul_f(A, imm);
+                else out = i_mul(A, B);
+            } else if (op <= MPR_OP_MAX_LHS_RHS) {
+                out = (op <= MPR_OP_MIN_LHS_RHS) ? i_min(A, B, c) : i_max(A, B, c);
+            } else {
+                out = (op == MPR_OP_SUB_IMM_RHS) ? i_sub(iv(imm, imm), B) : i_sub(A, B);
+            }
+        } else if (op == MPR_OP_SQUARE_LHS) {
+            out = i_square(A);
+        } else if (op == MPR_OP_NEG_LHS) {
+            out = i_neg(A);
+        } else if (op == MPR_OP_ABS_LHS) {
+            out = i_abs(A);
+        } else if (op >= MPR_OP_COPY_IMM) {
+            out = (op == MPR_OP_COPY_LHS) ? A : B;              /* COPY_IMM: rhs == 0, B is the immediate */
+        } else {
+            const float2 o2 = interval_rare(op, lv, rv, imm);
+            out = iv(o2.x, o2.y);
+        }
         slots[o * 64 + lane] = make_float2(out.lo, out.hi);
         ++nclauses;
         if (mpr_op_is_minmax(op)) {
@@ -157,7 +230,7 @@ k_eval_tiles(TileStageArgs a)
             any_choice |= m1 | m2;
         }
     }
-    const uint64_t end_clause = *data;
+    const uint64_t end_clause = d;
     const uint32_t i_out = (uint32_t)(end_clause >> 8) & 0xFF;
     const float2 res = slots[i_out * 64 + lane];
 
@@ -180,7 +253,6 @@ k_eval_tiles(TileStageArgs a)
         /* last tile stage: keep the group's min/max decisions for the float pass, which walks
          * THIS tape for every surviving child (k_eval_voxels_grouped) */
         const int nrec = ci < a.choice_cap ? ci : a.choice_cap;
-        __syncthreads();
         ulonglong2* const dst = a.choice_masks + (size_t)blockIdx.x * a.choice_cap;
         for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
         if (lane == 0) {
@@ -192,7 +264,7 @@ k_eval_tiles(TileStageArgs a)
             a.groups[blockIdx.x] = gi;
         }
     }
-    const bool push = ambiguous && ((any_choice >> lane) & 1);
+    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1);
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 
     long long written = 0;
@@ -200,8 +272,11 @@ k_eval_tiles(TileStageArgs a)
     bool overflow = false;
     if (live != 0) {
         /* ---- tape pushing (reference :323-458) ---- */
-        for (int i = lane; i < 256; i += 64) act[i] = 0;
-        __syncthreads();
+        LaneMasks lm = {0, 0, 0, 0, act};
+        if (a.nslots > 128) {
+            act[lane] = 0;
+            act[lane + 64] = 0;
+        }
 
         int out_index = 0, out_offset = 0;
         {   /* claim the first chunk of every pushing lane with one atomic */
@@ -228,22 +303,34 @@ k_eval_tiles(TileStageArgs a)
             twr[out_index + out_offset] = end_clause;
             written++;
         }
-        if (lane == 0) act[i_out] = live;
-        __syncthreads();
+        lm_set(lm, i_out, live);
 
+        /* backward walk, again 64 words per load: lane jj holds word bbase + jj */
+        int cur = base + j - 1;               /* pool index of the next word to visit */
+        int bbase = cur - 63;
+        uint64_t bblk = tro[max(bbase + lane, 0)];
         for (;;) {
-            const uint64_t d = *--data;
+            int jj = cur - bbase;
+            if (jj < 0) {
+                bbase = cur - 63;
+                bblk = tro[max(bbase + lane, 0)];
+                jj = 63;
+            }
+            d = rdlane64(bblk, jj);
             ++bwd_words;
             const uint32_t op = (uint32_t)d & 0xFF;
             if (!op) break;
             if (op == MPR_OP_JUMP) {
-                data += (int32_t)(d >> 32);
+                cur = cur + (int32_t)(d >> 32) - 1;       /* JUMP, then pre-decrement */
+                bbase = cur - 63;
+                bblk = tro[max(bbase + lane, 0)];
                 continue;
             }
+            --cur;
             const bool has_choice = mpr_op_is_minmax(op);
             ci -= has_choice ? 1 : 0;
             const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
-            uint64_t am = rfl64(act[o]) & live;
+            uint64_t am = lm_get(lm, o) & live;
             if (am == 0) continue;
 
             uint64_t m1 = 0, m2 = 0;
@@ -290,17 +377,14 @@ k_eval_tiles(TileStageArgs a)
 
             /* scalar bookkeeping of the active sets */
             const uint64_t a1 = am & m1, a2 = am & m2, a0 = am & ~(m1 | m2);
-            if (lane == 0) {
-                act[o] = 0;
-                if (a0) {
-                    if (l) act[l] |= a0;
-                    if (r) act[r] |= a0;
-                }
-                if (a1) act[l] |= a1;
-                if (a2 && r) act[r] |= a2;
+            lm_set(lm, o, 0);
+            if (a0) {
+                if (l) lm_set(lm, l, lm_get(lm, l) | a0);
+                if (r) lm_set(lm, r, lm_get(lm, r) | a0);
             }
-            __syncthreads();
-
+            if (a1) lm_set(lm, l, lm_get(lm, l) | a1);
+            if (a2 && r) lm_set(lm, r, lm_get(lm, r) | a2);
+    
             if (mine && writing) {
                 uint64_t w = d;
                 bool emit = true;
@@ -323,7 +407,7 @@ k_eval_tiles(TileStageArgs a)
         }
         if (writing) {
             out_offset--;
-            twr[out_index + out_offset] = *data;     /* head: copy of the parent's head */
+            twr[out_index + out_offset] = d;         /* head: copy of the parent's head */
             written++;
             a.tiles[gidx].tape = out_index + out_offset;
         }
@@ -505,7 +589,7 @@ void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, co
 {
     hipLaunchKernelGGL(k_preload_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, cols, owner, rank);
 }
-size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + 2048 + (size_t)choice_cap * 16; }
+size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + (size_t)choice_cap * 16 + (nslots > 128 ? 1024 : 0); }
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
 {
     opt_in_once();

@@ -48,6 +48,7 @@ struct TileStageArgs {
     unsigned long long* counters;
     GroupInfo* groups;         /* last tile stage only (else null): per-group record ...      */
     ulonglong2* choice_masks;  /* ... and choice masks, choice_cap entries per group          */
+    int debug;                 /* development only (MPR_DEBUG_TILES): 1 = skip tape pushing, 2 = skip the arithmetic */
 };
 
 struct VoxelArgs {

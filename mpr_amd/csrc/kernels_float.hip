@@ -96,8 +96,8 @@ k_eval_voxels(VoxelArgs a)
             blk = tro[base + lane];
             j = 0;
         }
-        dlo = __builtin_amdgcn_readlane((uint32_t)blk, j);
-        dhi = __builtin_amdgcn_readlane((uint32_t)(blk >> 32), j);
+        dlo = rdlane((uint32_t)blk, j);
+        dhi = rdlane((uint32_t)(blk >> 32), j);
         ++words;
         const uint32_t op = dlo & 0xFF;
         if (op < 2) {
@@ -277,8 +277,8 @@ k_eval_voxels_grouped(GroupedVoxelArgs a)
                 blk = tro[base + lane];
                 j = 0;
             }
-            dlo = __builtin_amdgcn_readlane((uint32_t)blk, j);
-            dhi = __builtin_amdgcn_readlane((uint32_t)(blk >> 32), j);
+            dlo = rdlane((uint32_t)blk, j);
+            dhi = rdlane((uint32_t)(blk >> 32), j);
             ++words;
             const uint32_t op = dlo & 0xFF;
             if (op < 2) {
