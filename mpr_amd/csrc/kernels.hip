@@ -279,19 +279,30 @@ k_eval_tiles(TileStageArgs a)
         }
 
         int out_index = 0, out_offset = 0;
-        {   /* claim the first chunk of every pushing lane with one atomic */
+        /* ONE pool claim per wave: every pushing lane reserves the chunks it can need at most (its
+         * shortened tape is never longer than the tape just walked), as one contiguous run; a
+         * lane that fills a chunk simply moves to the next one of its run.  (The reference claims
+         * chunk by chunk with one atomic per thread and chunk, src/context.cu:341,392 — 2*10^5
+         * atomics on one word per bear frame; on this part same-address atomics serialise at
+         * ~12 ns each.)  Unused chunks of a run are left behind, as are the reference's chunks of
+         * tiles that get culled later. */
+        const int run_chunks = (fwd_words + 1 + 61) / 62 + 1;
+        int run_end = 0;                     /* first pool index past this lane's run */
+        {
             const int cnt = __popcll(live);
             int base = 0;
             int cur = 0;
             if (lane == 0) cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cur = __builtin_amdgcn_readfirstlane(cur);
-            bool ok = (long long)cur < a.pool_cap;
+            const long long want = (long long)MPR_SUBTAPE_CHUNK * cnt * run_chunks;
+            bool ok = (long long)cur < a.pool_cap && (long long)cur + want < 0x7FFFFFFFll;
             if (ok) {
-                if (lane == 0) base = atomicAdd(a.tape_index, MPR_SUBTAPE_CHUNK * cnt);
+                if (lane == 0) base = atomicAdd(a.tape_index, (int)want);
                 base = __builtin_amdgcn_readfirstlane(base);
             }
             if (push) {
-                out_index = base + MPR_SUBTAPE_CHUNK * rank_in(live, lane);
+                out_index = base + MPR_SUBTAPE_CHUNK * run_chunks * rank_in(live, lane);
+                run_end = out_index + MPR_SUBTAPE_CHUNK * run_chunks;
                 out_offset = MPR_SUBTAPE_CHUNK;
                 if (!ok || (long long)out_index + out_offset >= a.pool_cap) overflow = true;
             }
@@ -344,21 +355,13 @@ k_eval_tiles(TileStageArgs a)
             const bool need = mine && out_offset == 0;
             const uint64_t need_mask = ballot(need);
             if (need_mask) {
-                /* chunk full: claim the next ones and write both links (reference :384-413) */
-                const int cnt = __popcll(need_mask);
-                int base = 0, cur = 0;
-                if (lane == 0) cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cur = __builtin_amdgcn_readfirstlane(cur);
-                const bool ok = (long long)cur < a.pool_cap;
-                if (ok) {
-                    if (lane == 0) base = atomicAdd(a.tape_index, MPR_SUBTAPE_CHUNK * cnt);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                }
+                /* chunk full: continue in the next chunk of the lane's run and write both links
+                 * (reference :384-413) */
                 if (need) {
                     const int prev_index = out_index;
-                    out_index = base + MPR_SUBTAPE_CHUNK * rank_in(need_mask, lane);
+                    out_index += MPR_SUBTAPE_CHUNK;
                     out_offset = MPR_SUBTAPE_CHUNK;
-                    if (!ok || (long long)out_index + out_offset >= a.pool_cap) {
+                    if (out_index >= run_end || (long long)out_index + out_offset >= a.pool_cap) {
                         overflow = true;
                         writing = false;
                     } else {
