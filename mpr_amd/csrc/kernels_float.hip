@@ -383,19 +383,63 @@ k_eval_voxels_grouped(GroupedVoxelArgs a)
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* eval_pixels_d — normals by forward-mode AD (reference :978-1132)                      */
-/* one wave = an 8x8 pixel patch; lanes are grouped by the tape they need               */
+/* eval_pixels_d, quad layout.  A Deriv is four floats (dx, dy, dz, v); instead of giving   */
+/* each lane a whole Deriv (16-byte slots, an 8x8 patch per wave, up to a dozen different   */
+/* tapes per patch) a pixel is spread over FOUR lanes, one component each: a wave is the    */
+/* 16 pixels of one 4x4 footprint (pixels of a footprint share their micro-tile's tape      */
+/* unless their heights fall into different tiles), slots are 4 bytes per lane, and the      */
+/* value component is broadcast inside each quad with a DPP quad_perm move where the         */
+/* product / quotient / chain rules need it.  Same operations per component as Deriv        */
+/* (inc/gpu_deriv.hpp), hence the same bits.                                                */
 /* ------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(64)
-k_eval_normals(NormalArgs a)
+DEV float quad_bcast(float x, int which)
+{
+    const int v = (int)mpr_f2u(x);
+    int r;
+    switch (which) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, true); break;
+        case 1: r = __builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, true); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, true); break;
+        default: r = __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, true); break;
+    }
+    return mpr_u2f((uint32_t)r);
+}
+
+/* rare / long opcodes of the quad layout, out of line.  a, b: this lane's component of lhs / rhs;
+ * av, bv: their value components; isv: this lane holds the value component. */
+__device__ __noinline__ float deriv_rare_q(uint32_t op, float a, float av, float b, float bv, float imm, bool isv)
+{
+    switch (op) {
+        case MPR_OP_SQRT_LHS: { const float s = __builtin_sqrtf(av); const float d = 2 * s; return isv ? s : a / d; }
+        case MPR_OP_SIN_LHS: { const float c = mpr_cosf(av); return isv ? mpr_sinf(av) : c * a; }
+        case MPR_OP_COS_LHS: { const float s = -mpr_sinf(av); return isv ? mpr_cosf(av) : s * a; }
+        case MPR_OP_ASIN_LHS: { const float d = __builtin_sqrtf(1 - av * av); return isv ? mpr_asinf(av) : a / d; }
+        case MPR_OP_ACOS_LHS: { const float d = -__builtin_sqrtf(1 - av * av); return isv ? mpr_acosf(av) : a / d; }
+        case MPR_OP_ATAN_LHS: { const float d = av * av + 1; return isv ? mpr_atanf(av) : a / d; }
+        case MPR_OP_EXP_LHS: { const float v = mpr_expf(av); return isv ? v : v * a; }
+        case MPR_OP_LOG_LHS: return isv ? mpr_logf(av) : a / av;
+        case MPR_OP_DIV_LHS_IMM: return a / imm;
+        case MPR_OP_DIV_IMM_RHS: { const float d = bv * bv; return isv ? imm / b : (-imm * b) / d; }
+        default: { const float d = bv * bv; return isv ? a / b : (bv * a - av * b) / d; }      /* DIV_LHS_RHS */
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_eval_normals_q(NormalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4* const slots = reinterpret_cast<float4*>(smem);     /* [nslots][64] (dx,dy,dz,v) */
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    unsigned char* const myslot = smem + (size_t)wave * a.nslots * 256 + lane * 4;   /* slot s: myslot + s*256 */
     const int S = a.size;
+    const int fps = S / 4;                                   /* footprints per side */
+    /* a block is a 2x2 group of footprints = one 8x8 patch */
     const int patches = S / 8;
-    const int px = (blockIdx.x % patches) * 8 + (lane & 7);
-    const int py = (blockIdx.x / patches) * 8 + (lane >> 3);
+    const int fxi = (blockIdx.x % patches) * 2 + (wave & 1), fyi = (blockIdx.x / patches) * 2 + (wave >> 1);
+    (void)fps;
+    const int pix = lane >> 2, comp = lane & 3;
+    const bool isv = comp == 3;
+    const int px = fxi * 4 + (pix & 3), py = fyi * 4 + (pix >> 2);
     const int pxy = px + py * S;
     int pz = a.image[pxy];
     const bool filled = pz != 0;
@@ -435,9 +479,8 @@ k_eval_normals(NormalArgs a)
     const uint64_t* __restrict__ const tro = a.tape_ro;
     const uint64_t head0 = tro[0];
     const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
-    deriv result = d_const(0.0f);
-    long long words_total = 0;
-    long long lane_clauses = 0;
+    float result = 0.0f;
+    long long words_total = 0, lane_clauses = 0;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int tape = __builtin_amdgcn_readlane(my_tape, leader);
@@ -446,53 +489,92 @@ k_eval_normals(NormalArgs a)
         todo &= ~grp;
 
         /* :1021-1031 — value first, then the unit partials (unused axes alias slot 0) */
-        slots[sx * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vx);
-        slots[sy * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vy);
-        slots[sz * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, vz);
-        slots[sx * 64 + lane].x = 1.0f;
-        slots[sy * 64 + lane].y = 1.0f;
-        slots[sz * 64 + lane].z = 1.0f;
+        *reinterpret_cast<float*>(myslot + sx * 256) = isv ? vx : 0.0f;
+        *reinterpret_cast<float*>(myslot + sy * 256) = isv ? vy : 0.0f;
+        *reinterpret_cast<float*>(myslot + sz * 256) = isv ? vz : 0.0f;
+        if (comp == 0) *reinterpret_cast<float*>(myslot + sx * 256) = 1.0f;
+        if (comp == 1) *reinterpret_cast<float*>(myslot + sy * 256) = 1.0f;
+        if (comp == 2) *reinterpret_cast<float*>(myslot + sz * 256) = 1.0f;
 
-        const uint64_t* data = tro + tape;
-        int words = 0, ncl = 0;
+        int base = tape + 1;
+        uint64_t blk = tro[base + lane];
+        int j = 0, words = 0;
+        uint32_t dlo = 0, dhi = 0;
         for (;;) {
-            const uint64_t d = *++data;
+            if (j == 64) {
+                base += 64;
+                blk = tro[base + lane];
+                j = 0;
+            }
+            dlo = rdlane((uint32_t)blk, j);
+            dhi = rdlane((uint32_t)(blk >> 32), j);
             ++words;
-            const uint32_t op = (uint32_t)d & 0xFF;
-            if (!op) break;
-            if (op == MPR_OP_JUMP) {
-                data += (int32_t)(d >> 32);
+            const uint32_t op = dlo & 0xFF;
+            if (op < 2) {
+                if (op == 0) break;
+                base = base + j + (int32_t)dhi + 1;      /* JUMP */
+                blk = tro[base + lane];
+                j = 0;
                 continue;
             }
-            const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
-            const float4 lv = slots[l * 64 + lane];
-            const float4 rv = slots[r * 64 + lane];
-            const deriv out = deriv_clause(op, dv(lv.w, lv.x, lv.y, lv.z), dv(rv.w, rv.x, rv.y, rv.z), immf(d));
-            slots[o * 64 + lane] = make_float4(out.dx, out.dy, out.dz, out.v);
-            ++ncl;
+            ++j;
+            const uint32_t vlo = to_vgpr(dlo);
+            const float imm = mpr_u2f(to_vgpr(dhi));
+            const uint32_t r8 = vlo >> 24;
+            const float A = *reinterpret_cast<const float*>(myslot + ((vlo >> 8) & 0xFF00));
+            const float Bs = *reinterpret_cast<const float*>(myslot + (r8 << 8));
+            float* const outp = reinterpret_cast<float*>(myslot + (vlo & 0xFF00));
+            const float av = quad_bcast(A, 3);
+            /* rhs as a Deriv: a slot, or the constant (0, 0, 0, imm) of the immediate forms */
+            const float B = r8 ? Bs : (isv ? imm : 0.0f);
+            const float bv = r8 ? quad_bcast(Bs, 3) : imm;
+            float out;
+            if (op >= MPR_OP_ADD_LHS_IMM) {
+                if (op <= MPR_OP_MUL_LHS_RHS) {
+                    if (op <= MPR_OP_ADD_LHS_RHS) out = (r8 || isv) ? A + B : A;       /* a + float leaves the partials alone */
+                    else if (op == MPR_OP_MUL_LHS_IMM) out = A * imm;
+                    else out = isv ? A * B : A * bv + B * av;
+                } else if (op <= MPR_OP_MAX_LHS_RHS) {
+                    const bool take_a = (op <= MPR_OP_MIN_LHS_RHS) ? (av < bv) : (av >= bv);
+                    out = take_a ? A : B;
+                } else if (op <= MPR_OP_SUB_LHS_RHS) {
+                    if (op == MPR_OP_SUB_LHS_IMM) out = isv ? A - imm : A;
+                    else if (op == MPR_OP_SUB_IMM_RHS) out = isv ? imm - B : -B;
+                    else out = A - B;
+                } else if (op <= MPR_OP_DIV_LHS_RHS) {
+                    out = deriv_rare_q(op, A, av, B, bv, imm, isv);
+                } else {
+                    out = (op == MPR_OP_COPY_LHS) ? A : B;          /* COPY_IMM: rhs == 0, B is (0,0,0,imm) */
+                }
+            } else if (op == MPR_OP_SQUARE_LHS) {
+                out = isv ? A * A : A * av + A * av;                /* evaluated as lhs * lhs (:1081) */
+            } else if (op == MPR_OP_NEG_LHS) {
+                out = -A;
+            } else if (op == MPR_OP_ABS_LHS) {
+                out = (av < 0.0f) ? -A : A;
+            } else {
+                out = deriv_rare_q(op, A, av, B, bv, imm, isv);
+            }
+            *outp = out;
         }
-        const uint32_t i_out = (uint32_t)(*data >> 8) & 0xFF;
-        const float4 rr = slots[i_out * 64 + lane];
-        if (mine) result = dv(rr.w, rr.x, rr.y, rr.z);
+        const float rr = *reinterpret_cast<const float*>(myslot + (dlo & 0xFF00));
+        if (mine) result = rr;
         words_total += words;
-        lane_clauses += (long long)ncl * __popcll(grp);
+        lane_clauses += (long long)(words - 1) * (__popcll(grp) / 4);
     }
 
-    if (filled) {
-        /* :1123-1131 */
-        const float norm = __builtin_sqrtf(result.dx * result.dx + result.dy * result.dy + result.dz * result.dz);
-        const uint32_t dx = f2u8((result.dx / norm) * 127 + 128);
-        const uint32_t dy = f2u8((result.dy / norm) * 127 + 128);
-        const uint32_t dz = f2u8((result.dz / norm) * 127 + 128);
-        a.output[pxy] = (0xFFu << 24) | (dz << 16) | (dy << 8) | dx;
-    }
-    if (a.counters) {
-        if (lane == 0) {
-            atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
-            atomicAdd((unsigned long long*)&a.counters[CNT_FWD_NORM], (unsigned long long)words_total);
-            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
-            atomicAdd((unsigned long long*)&a.counters[CNT_NORMAL_PX], (unsigned long long)__popcll(ballot(filled)));
-        }
+    /* :1123-1131 */
+    const float gx = quad_bcast(result, 0), gy = quad_bcast(result, 1), gz = quad_bcast(result, 2);
+    const float norm = __builtin_sqrtf(gx * gx + gy * gy + gz * gz);
+    const uint32_t u = f2u8((result / norm) * 127 + 128);
+    const uint32_t ux = mpr_f2u(quad_bcast(mpr_u2f(u), 0)), uy = mpr_f2u(quad_bcast(mpr_u2f(u), 1)),
+                   uz = mpr_f2u(quad_bcast(mpr_u2f(u), 2));
+    if (filled && comp == 0) a.output[pxy] = (0xFFu << 24) | (uz << 16) | (uy << 8) | ux;
+    if (a.counters && lane == 0) {
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
+        atomicAdd((unsigned long long*)&a.counters[CNT_FWD_NORM], (unsigned long long)words_total);
+        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
+        atomicAdd((unsigned long long*)&a.counters[CNT_NORMAL_PX], (unsigned long long)(__popcll(ballot(filled)) / 4));
     }
 }
 
@@ -510,7 +592,7 @@ static void opt_in_once()
     done = true;
     allow_big_lds(k_eval_voxels<2>);
     allow_big_lds(k_eval_voxels<3>);
-    allow_big_lds(k_eval_normals);
+    allow_big_lds(k_eval_normals_q);
     allow_big_lds(k_eval_voxels_grouped<2, 4>);
     allow_big_lds(k_eval_voxels_grouped<3, 4>);
 }
@@ -541,12 +623,13 @@ void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxe
         else hipLaunchKernelGGL((k_eval_voxels_grouped<2, 4>), g, b, lds, s, a);
     }
 }
-size_t normals_lds_bytes(int nslots) { return (size_t)nslots * 1024; }
+size_t normals_lds_bytes(int nslots) { return (size_t)nslots * 1024; }   /* 4 waves x nslots x 64 lanes x 4 B */
 void launch_eval_normals(hipStream_t s, const NormalArgs& a)
 {
     opt_in_once();
     const int patches = a.size / 8;
-    hipLaunchKernelGGL(k_eval_normals, dim3(patches * patches), dim3(64), normals_lds_bytes(a.nslots), s, a);
+    /* quad layout: 4 waves per 8x8 patch, 4-byte slots */
+    hipLaunchKernelGGL(k_eval_normals_q, dim3(patches * patches), dim3(256), normals_lds_bytes(a.nslots), s, a);
 }
 
 }  // namespace mprk
