@@ -2,12 +2,8 @@
  * kernels_float.hip — the round-to-nearest walkers: float voxel / pixel pass and the
  * derivative (normals) pass.  See kernels.hip for the overall design.
  *
- * This translation unit is compiled with -mllvm -structurizecfg-skip-uniform-regions=1: the
- * opcode dispatch of an interpreter is wave-uniform control flow, and without that option the
- * AMDGPU structurizer rewrites the decision tree into flag-and-retest chains that double the
- * scalar instructions per clause (the scalar ALU, 0.95 instr/clk/CU, is what bounds these
- * kernels — scripts/ubench/issue_rates.hip).  The interval kernel (kernels.hip) is built
- * without it (it miscompiles there: the parity suite fails).
+ * Like kernels.hip this file is compiled with -mllvm -structurizecfg-skip-uniform-regions=1
+ * (see the Makefile): the opcode dispatch of an interpreter is wave-uniform control flow.
  */
 #include "kernel_common.hpp"
 
