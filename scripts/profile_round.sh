@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): bench line, rocprofv3 kernel stats of the same command, and the two
+# HBM counter passes (FETCH_SIZE and WRITE_SIZE in separate runs, --kernel-trace only).
+# usage: scripts/profile_round.sh <tag>       outputs under gpurun_out/<tag>/
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $ROOT
+BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-also"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- $BENCH > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $BENCH > $OUT/pmc_write.log 2>&1
+cd $ROOT
+python scripts/profile_summary.py $TAG > /dev/null      # pmc_summary.json -> bench's roofline.traffic
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+find $OUT -name '*.csv' | head -20
+python scripts/profile_summary.py $TAG
