@@ -57,6 +57,7 @@ struct mpr_context {
     int* col_list_dev = nullptr;
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
 
+    bool voxel_asm = true;             /* float pass interpreter: gfx950 assembly (default) or the compiled C++ one */
     int voxel_k = 0;                   /* float pass: 0 = one wave per smallest tile walking its own sub-tape (default);
                                           1, 2, 4 = children per batch of the grouped form (MPR_VOXEL_K, experimental) */
 
@@ -150,6 +151,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->device = opt->device;
     c->S = S;
     c->flags = opt->flags;
+    if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_K")) {
         const int k = atoi(e);
         if (k == 0 || k == 1 || k == 2 || k == 4) c->voxel_k = k;
@@ -420,7 +422,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         fill_mat(v.mat, mat, dim == 3 ? 16 : 9);
         v.counters = cnt;
         TimedScope ts(c, "eval_voxels_f");
-        mprk::launch_eval_voxels(s, dim, v);
+        /* the assembly interpreter keeps no work counters: instrumented frames use the C++ one */
+        if (c->voxel_asm && !cnt) mprk::launch_eval_voxels_asm(s, dim, v);
+        else mprk::launch_eval_voxels(s, dim, v);
     }
     if (dim == 3) {
         mprk::NormalArgs n;
@@ -657,6 +661,27 @@ int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, con
     HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
     if (b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
     mprk::launch_test_float(nullptr, op, n, (float*)da.p, b ? (float*)db.p : nullptr, imm, (float*)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t n, const float* a, const float* b, float imm, float* out)
+{
+    if (n <= 0 || !a || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)n * 4;
+    DevBuf da, db, dout, dt;
+    HIP_TRY(da.alloc(bytes)); HIP_TRY(db.alloc(bytes)); HIP_TRY(dout.alloc(bytes)); HIP_TRY(dt.alloc(64 * 8));
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    uint32_t immbits;
+    memcpy(&immbits, &imm, 4);
+    /* 64 clauses so that the interpreter's 63-clause block fetch stays inside the buffer */
+    uint64_t tape3[64] = {mpr_cl_make(0, 1, 2, 3, 0), mpr_cl_make((uint32_t)op, 4, 1, b ? 2 : 0, immbits),
+                          mpr_cl_make(0, 4, 0, 0, 0)};
+    HIP_TRY(hipMemcpy(dt.p, tape3, sizeof(tape3), hipMemcpyHostToDevice));
+    mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));

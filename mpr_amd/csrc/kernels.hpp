@@ -100,6 +100,9 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
+/* same pass, interpreter in gfx950 assembly (kernels_voxel_asm.hip); no counters */
+void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
+void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
 size_t grouped_voxel_lds_bytes(int nslots, int k);
 void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a);   /* k = 1, 2 or 4 children per batch */
 size_t normals_lds_bytes(int nslots);

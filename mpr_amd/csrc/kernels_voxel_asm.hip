@@ -1,0 +1,416 @@
+/*
+ * kernels_voxel_asm.hip — the float voxel / pixel pass (reference src/context.cu:707-964,
+ * eval_voxels_f + calculate_voxels / calculate_pixels) with the tape interpreter written
+ * directly in gfx950 assembly.
+ *
+ * Why: the compiled interpreter (kernels_float.hip, k_eval_voxels) spends ~16 scalar
+ * instructions per clause on loop control and on the opcode decision tree, and a CU has ONE
+ * scalar ALU for its four SIMDs (0.95 instr/clk/CU, scripts/ubench/issue_rates.hip): the pass
+ * is bound by scalar issue, not by VALU, LDS or HBM.  Here a clause costs 2 scalar instructions:
+ *
+ *   - clauses are fetched 63 at a time (one coalesced load, lane j holds clause j); per block the
+ *     VALU computes, for all 63 clauses at once, the ADDRESS of each clause's handler
+ *     (table base + op * 128) into a VGPR pair; lane 63 always holds the address of the
+ *     "fetch the next block" handler, so running off the end of a block needs no test;
+ *   - per clause: s_add (clause counter), 4 x v_readlane (handler address, clause lo / hi),
+ *     s_setpc_b64.  The handlers are threaded code: each ends with that same sequence;
+ *   - operand addresses in LDS come from one v_perm_b32 each: byte 0 = lane * 4, byte 1 = slot
+ *     (slot s of lane l lives at s * 256 + l * 4; one wave per workgroup, LDS base 0);
+ *   - immediates are used straight from the SGPR the clause was read into.
+ *
+ * Arithmetic is the same instruction selection the compiler makes for the C++ interpreter
+ * (v_add/v_mul/v_min/v_max/v_sub_f32, the IEEE division and square-root expansions), so the
+ * results are bit-identical to k_eval_voxels and to the oracle; tests/test_gpu_render.py compares
+ * both kernels frame by frame.  The long transcendental opcodes (sin, cos, asin, acos, atan, exp,
+ * log) leave the assembly block, are evaluated by the shared C++ routines of mpr_fmath.h, and
+ * re-enter it.
+ *
+ * Software-visible hazards of gfx940/gfx950 that the assembler does not fix up in inline asm
+ * (LLVM GCNHazardRecognizer): VALU-written SGPR/VCC -> VALU read needs 2 wait states,
+ * VALU-written VGPR -> v_readlane of it 1, transcendental result -> VALU use 1, VALU-written VCC
+ * -> v_div_fmas 4.  The s_nop's below are those.
+ */
+#include "kernel_common.hpp"
+
+namespace mprk {
+
+/* out of line, one function per opcode: the switch below runs on the scalar unit (op is uniform) */
+__device__ __noinline__ float na_sin(float v) { return mpr_sinf(v); }
+__device__ __noinline__ float na_cos(float v) { return mpr_cosf(v); }
+__device__ __noinline__ float na_asin(float v) { return mpr_asinf(v); }
+__device__ __noinline__ float na_acos(float v) { return mpr_acosf(v); }
+__device__ __noinline__ float na_atan(float v) { return mpr_atanf(v); }
+__device__ __noinline__ float na_exp(float v) { return mpr_expf(v); }
+__device__ __noinline__ float na_log(float v) { return mpr_logf(v); }
+DEV float rare_unary_a(uint32_t op, float v)
+{
+    switch (op) {
+        case MPR_OP_SIN_LHS: return na_sin(v);
+        case MPR_OP_COS_LHS: return na_cos(v);
+        case MPR_OP_ASIN_LHS: return na_asin(v);
+        case MPR_OP_ACOS_LHS: return na_acos(v);
+        case MPR_OP_ATAN_LHS: return na_atan(v);
+        case MPR_OP_EXP_LHS: return na_exp(v);
+        default: return na_log(v);
+    }
+}
+
+/* Fixed registers of the interpreter (declared as clobbers):
+ *   s[80:81] handler address      s[82:83] handler table base     s[84:85] block address
+ *   s86 / s87 clause lo / hi      s88 clause counter in block     s89 block base (clause index)
+ *   s90 0x260 (class mask)        s[92:93] v_div_scale sdst
+ *   v32 aA  v33 aB  v34 aO  v35 A  v36 B  v37 out  v38..v42 temporaries                       */
+#define MPR_DISPATCH                                   \
+    "s_add_u32 s88, s88, 1\n"                          \
+    "v_readlane_b32 s80, %[plo], s88\n"                \
+    "v_readlane_b32 s81, %[phi], s88\n"                \
+    "v_readlane_b32 s86, %[blo], s88\n"                \
+    "v_readlane_b32 s87, %[bhi], s88\n"                \
+    "s_setpc_b64 s[80:81]\n"
+#define MPR_AL "v_perm_b32 v32, s86, %[lb], %[selL]\n ds_read_b32 v35, v32\n"
+#define MPR_AR "v_perm_b32 v33, s86, %[lb], %[selR]\n ds_read_b32 v36, v33\n"
+#define MPR_AO "v_perm_b32 v34, s86, %[lb], %[selO]\n"
+#define MPR_W "s_waitcnt lgkmcnt(0)\n"
+#define MPR_ST "ds_write_b32 v34, v37\n"
+#define MPR_H(n) ".p2align 7\nL_h" #n "_%=:\n"
+#define MPR_EXIT "s_branch L_exit_%=\n"
+#define MPR_UN(insn) MPR_AL MPR_AO MPR_W insn MPR_ST MPR_DISPATCH
+#define MPR_BIN_IMM(insn) MPR_AL MPR_AO MPR_W insn " v37, s87, v35\n" MPR_ST MPR_DISPATCH
+/* min / max: operands canonicalised first (a signalling NaN must lose against a number, like fminf) */
+#define MPR_MM_IMM(insn) MPR_AL MPR_AO "v_max_f32 v36, s87, s87\n" MPR_W "v_max_f32 v35, v35, v35\n" insn " v37, v35, v36\n" MPR_ST MPR_DISPATCH
+#define MPR_MM_RHS(insn) MPR_AL MPR_AR MPR_AO MPR_W "v_max_f32 v35, v35, v35\n v_max_f32 v36, v36, v36\n" insn " v37, v35, v36\n" MPR_ST MPR_DISPATCH
+#define MPR_BIN_RHS(insn) MPR_AL MPR_AR MPR_AO MPR_W insn " v37, v35, v36\n" MPR_ST MPR_DISPATCH
+
+/* Walks the tape whose first clause is tro[first] over the slot file at LDS offset 0 (slot s of
+ * lane l at s * 256 + l * 4) and returns the low word of the end clause (result slot in byte 1). */
+DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane)
+{
+    unsigned char* const myslot = smem + lane * 4;
+    /* state of the assembly interpreter that has to survive a trip through C++ */
+    uint32_t blo = 0, bhi = 0, plo = 0, phi = 0;     /* clause block and handler addresses, lane j = clause j */
+    uint32_t base = first, sj = 0, dlo = 0, dhi = 0;
+    /* the v_perm_b32 address trick needs the dynamic LDS segment at offset 0 (no static LDS here) */
+    const uint32_t lb = (uint32_t)(uintptr_t)smem + (uint32_t)lane * 4u;
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    /* v_perm_b32 selectors: byte 0 <- lb byte 0, byte 1 <- clause byte 1 (out) / 2 (lhs) / 3 (rhs) */
+    const uint32_t selO = to_vgpr(0x0c0c0500u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
+    const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    uint32_t mode = 0;                               /* 0: fetch the block at `base`; 1: continue after `sj` */
+
+    for (;;) {
+        base = rdfirst(base);
+        sj = rdfirst(sj);
+        mode = rdfirst(mode);
+        asm volatile(
+            "s_mov_b32 s89, %[base]\n"
+            "s_mov_b32 s88, %[sj]\n"
+            "s_mov_b32 s90, 0x260\n"
+            "s_getpc_b64 s[82:83]\n"
+            "L_pc_%=:\n"
+            "s_add_u32 s82, s82, L_h0_%=-L_pc_%=\n"
+            "s_addc_u32 s83, s83, 0\n"
+            "s_cmp_eq_u32 %[mode], 0\n"
+            "s_cbranch_scc1 L_load_%=\n"
+            MPR_DISPATCH
+            /* ---- fetch 63 clauses at s89, build the handler addresses ---- */
+            "L_load_%=:\n"
+            "s_mov_b32 s84, s89\n"
+            "s_mov_b32 s85, 0\n"
+            "s_lshl_b64 s[84:85], s[84:85], 3\n"
+            "s_add_u32 s84, s84, %[tlo]\n"
+            "s_addc_u32 s85, s85, %[thi]\n"
+            "global_load_dword %[blo], %[lane8], s[84:85]\n"
+            "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
+            "s_mov_b32 s88, -1\n"
+            "v_mov_b32 v39, 0xf80\n"                    /* handler 31 = next block */
+            "v_mov_b32 %[phi], s83\n"
+            "s_waitcnt vmcnt(0)\n"
+            "v_and_b32 v38, 0xff, %[blo]\n"
+            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"       /* lane 63 */
+            "v_min_u32 v38, 30, v38\n"                   /* unknown opcodes -> handler 30 */
+            "v_lshlrev_b32 v38, 7, v38\n"
+            "v_cndmask_b32 v38, v38, v39, vcc\n"
+            "v_add_co_u32 %[plo], vcc, s82, v38\n"
+            "s_nop 1\n"
+            "v_addc_co_u32 %[phi], vcc, 0, %[phi], vcc\n"
+            "s_nop 0\n"
+            MPR_DISPATCH
+            /* ---- handlers, 128 bytes apart, indexed by opcode ---- */
+            MPR_H(0) MPR_EXIT                                             /* end of tape */
+            MPR_H(1)                                                      /* JUMP: base += j + imm + 1 */
+            "s_add_u32 s89, s89, s88\n"
+            "s_add_u32 s89, s89, s87\n"
+            "s_add_u32 s89, s89, 1\n"
+            "s_branch L_load_%=\n"
+            MPR_H(2) MPR_UN("v_mul_f32 v37, v35, v35\n")                  /* SQUARE */
+            MPR_H(3) MPR_AL MPR_AO MPR_W "s_branch L_sqrt_%=\n"           /* SQRT */
+            MPR_H(4) MPR_UN("v_xor_b32 v37, 0x80000000, v35\n")           /* NEG */
+            MPR_H(5) MPR_EXIT
+            MPR_H(6) MPR_EXIT
+            MPR_H(7) MPR_EXIT
+            MPR_H(8) MPR_EXIT
+            MPR_H(9) MPR_EXIT
+            MPR_H(10) MPR_AL MPR_AO MPR_W "s_branch L_exp_%=\n"           /* EXP */
+            MPR_H(11) MPR_UN("v_and_b32 v37, 0x7fffffff, v35\n")          /* ABS */
+            MPR_H(12) MPR_AL MPR_AO MPR_W "s_branch L_log_%=\n"           /* LOG */
+            MPR_H(13) MPR_BIN_IMM("v_add_f32")
+            MPR_H(14) MPR_BIN_RHS("v_add_f32")
+            MPR_H(15) MPR_BIN_IMM("v_mul_f32")
+            MPR_H(16) MPR_BIN_RHS("v_mul_f32")
+            MPR_H(17) MPR_MM_IMM("v_min_f32")
+            MPR_H(18) MPR_MM_RHS("v_min_f32")
+            MPR_H(19) MPR_MM_IMM("v_max_f32")
+            MPR_H(20) MPR_MM_RHS("v_max_f32")
+            MPR_H(21) MPR_BIN_IMM("v_subrev_f32")                         /* lhs - imm */
+            MPR_H(22) MPR_AR MPR_AO MPR_W "v_sub_f32 v37, s87, v36\n" MPR_ST MPR_DISPATCH   /* imm - rhs */
+            MPR_H(23) MPR_BIN_RHS("v_sub_f32")
+            MPR_H(24) MPR_AL MPR_AO MPR_W "v_mov_b32 v36, s87\n s_branch L_div_%=\n"         /* lhs / imm */
+            MPR_H(25) MPR_AR MPR_AO MPR_W "v_mov_b32 v35, s87\n s_branch L_div_%=\n"         /* imm / rhs */
+            MPR_H(26) MPR_AL MPR_AR MPR_AO MPR_W "s_branch L_div_%=\n"                       /* lhs / rhs */
+            MPR_H(27) MPR_AO "s_nop 0\n v_mov_b32 v37, s87\n" MPR_ST MPR_DISPATCH           /* COPY_IMM */
+            MPR_H(28) MPR_AL MPR_AO MPR_W "ds_write_b32 v34, v35\n" MPR_DISPATCH            /* COPY_LHS */
+            MPR_H(29) MPR_AR MPR_AO MPR_W "ds_write_b32 v34, v36\n" MPR_DISPATCH            /* COPY_RHS */
+            MPR_H(30) MPR_EXIT                                            /* not an opcode */
+            MPR_H(31)                                                     /* lane 63: next block */
+            "s_add_u32 s89, s89, 63\n"
+            "s_branch L_load_%=\n"
+            /* ---- v37 = v35 / v36, correctly rounded ---- */
+            ".p2align 7\n"
+            "L_div_%=:\n"
+            "v_div_scale_f32 v38, s[92:93], v36, v36, v35\n"
+            "v_rcp_f32 v39, v38\n"
+            "v_div_scale_f32 v40, vcc, v35, v36, v35\n"
+            "v_fma_f32 v41, -v38, v39, 1.0\n"
+            "v_fmac_f32 v39, v41, v39\n"
+            "v_mul_f32 v41, v40, v39\n"
+            "v_fma_f32 v42, -v38, v41, v40\n"
+            "v_fmac_f32 v41, v42, v39\n"
+            "v_fma_f32 v38, -v38, v41, v40\n"
+            "v_div_fmas_f32 v38, v38, v39, v41\n"
+            "v_div_fixup_f32 v37, v38, v36, v35\n"
+            MPR_ST MPR_DISPATCH
+            /* ---- v37 = sqrt(v35), correctly rounded ---- */
+            "L_sqrt_%=:\n"
+            "v_mul_f32 v38, 0x4f800000, v35\n"
+            "v_cmp_gt_f32 vcc, 0xf800000, v35\n"
+            "s_nop 1\n"
+            "v_cndmask_b32 v38, v35, v38, vcc\n"
+            "v_sqrt_f32 v39, v38\n"
+            "s_nop 0\n"
+            "v_add_u32 v40, -1, v39\n"
+            "v_fma_f32 v41, -v40, v39, v38\n"
+            "v_cmp_ge_f32 s[92:93], 0, v41\n"
+            "v_add_u32 v41, 1, v39\n"
+            "s_nop 0\n"
+            "v_cndmask_b32 v40, v39, v40, s[92:93]\n"
+            "v_fma_f32 v39, -v41, v39, v38\n"
+            "v_cmp_lt_f32 s[92:93], 0, v39\n"
+            "s_nop 1\n"
+            "v_cndmask_b32 v39, v40, v41, s[92:93]\n"
+            "v_mul_f32 v40, 0x37800000, v39\n"
+            "v_cndmask_b32 v39, v39, v40, vcc\n"
+            "v_cmp_class_f32 vcc, v38, s90\n"
+            "s_nop 1\n"
+            "v_cndmask_b32 v37, v39, v38, vcc\n"
+            MPR_ST MPR_DISPATCH
+            /* ---- v37 = mpr_expf(v35) (include/mpr_fmath.h), same operations in the same order ---- */
+            "L_exp_%=:\n"
+            "v_mul_f32 v38, 0x3fb8aa3b, v35\n"
+            "v_add_f32 v38, 0x4b400000, v38\n"
+            "v_add_f32 v38, 0xcb400000, v38\n"              /* kf = round(x / ln 2) */
+            "v_fmamk_f32 v39, v38, 0xbf318000, v35\n"
+            "v_fmamk_f32 v39, v38, 0x395e8083, v39\n"       /* r */
+            "v_mov_b32 v40, 0x3ab743ce\n"
+            "v_fmac_f32 v40, 0x39506967, v39\n"
+            "v_fmaak_f32 v40, v40, v39, 0x3c088908\n"
+            "v_cvt_i32_f32 v38, v38\n"                      /* k */
+            "v_fmaak_f32 v40, v40, v39, 0x3d2aa9c1\n"
+            "v_fmaak_f32 v40, v40, v39, 0x3e2aaaaa\n"
+            "v_mul_f32 v41, v39, v39\n"
+            "v_fma_f32 v40, v40, v39, 0.5\n"
+            "v_fmac_f32 v39, v40, v41\n"
+            "v_lshrrev_b32 v41, 31, v38\n"
+            "v_add_u32 v41, v38, v41\n"
+            "v_ashrrev_i32 v41, 1, v41\n"                   /* k1 = k / 2 (toward zero) */
+            "v_add_f32 v39, 1.0, v39\n"
+            "v_sub_u32 v38, v38, v41\n"                     /* k2 = k - k1 */
+            "v_lshl_add_u32 v41, v41, 23, 1.0\n"
+            "v_lshl_add_u32 v38, v38, 23, 1.0\n"
+            "v_mul_f32 v39, v39, v41\n"
+            "v_mul_f32 v37, v39, v38\n"
+            "s_mov_b32 s91, 0x42b17218\n"
+            "v_cmp_ngt_f32 vcc, 0xc2cff5c3, v35\n"          /* !(x < -103.98) */
+            "v_cmp_nlt_f32 s[92:93], s91, v35\n"            /* !(x > 88.72284) */
+            "v_cmp_o_f32 s[94:95], v35, v35\n"
+            "v_mov_b32 v40, 0x7f800000\n"
+            "v_cndmask_b32 v37, 0, v37, vcc\n"
+            "v_cndmask_b32 v37, v40, v37, s[92:93]\n"
+            "v_cndmask_b32 v37, v35, v37, s[94:95]\n"
+            MPR_ST MPR_DISPATCH
+            /* ---- v37 = mpr_logf(v35) ---- */
+            "L_log_%=:\n"
+            "v_mul_f32 v38, 0x4b000000, v35\n"
+            "v_cmp_gt_u32 vcc, 0x800000, v35\n"             /* subnormal: scale by 2^23 */
+            "v_mov_b32 v40, 0xffffff82\n"
+            "v_mov_b32 v41, 0xffffff6b\n"
+            "v_cndmask_b32 v38, v35, v38, vcc\n"
+            "v_cndmask_b32 v40, v40, v41, vcc\n"
+            "v_lshrrev_b32 v39, 23, v38\n"
+            "v_add_u32 v39, v39, v40\n"                     /* e */
+            "v_and_b32 v38, 0x7fffff, v38\n"
+            "v_or_b32 v38, 0x3f000000, v38\n"               /* m in [0.5, 1) */
+            "v_cmp_gt_f32 vcc, 0x3f3504f3, v38\n"
+            "v_bfrev_b32 v41, 1\n"
+            "s_nop 0\n"
+            "v_subbrev_co_u32 v39, s[92:93], 0, v39, vcc\n" /* e -= (m < sqrt(1/2)) */
+            "v_cndmask_b32 v41, v41, v38, vcc\n"
+            "v_add_f32 v38, v41, v38\n"                     /* m + m, or m + (-0) */
+            "v_add_f32 v38, -1.0, v38\n"
+            "v_mov_b32 v40, 0xbdebd1b8\n"
+            "v_fmac_f32 v40, 0x3d9021bb, v38\n"
+            "v_fmaak_f32 v40, v40, v38, 0x3def251a\n"
+            "v_fmaak_f32 v40, v40, v38, 0xbdfe5d4f\n"
+            "v_fmaak_f32 v40, v40, v38, 0x3e11e9bf\n"
+            "v_fmaak_f32 v40, v40, v38, 0xbe2aae50\n"
+            "v_fmaak_f32 v40, v40, v38, 0x3e4cceac\n"
+            "v_fmaak_f32 v40, v40, v38, 0xbe7ffffc\n"
+            "v_cvt_f32_i32 v39, v39\n"                      /* fe */
+            "v_fmaak_f32 v40, v40, v38, 0x3eaaaaaa\n"
+            "v_mul_f32 v41, v38, v38\n"                     /* z */
+            "v_mul_f32 v40, v40, v38\n"
+            "v_mul_f32 v40, v40, v41\n"                     /* (y * m) * z */
+            "v_fmamk_f32 v40, v39, 0xb95e8083, v40\n"
+            "v_fmac_f32 v40, -0.5, v41\n"
+            "v_add_f32 v40, v38, v40\n"
+            "v_fmamk_f32 v37, v39, 0x3f318000, v40\n"
+            "v_cmp_ne_u32 vcc, 0x7f800000, v35\n"           /* log(+inf) = +inf */
+            "v_mov_b32 v40, 0xff800000\n"
+            "v_mov_b32 v41, 0x7fc00000\n"
+            "v_cndmask_b32 v37, v35, v37, vcc\n"
+            "v_cmp_eq_f32 vcc, 0, v35\n"                    /* log(+-0) = -inf */
+            "s_nop 1\n"
+            "v_cndmask_b32 v37, v37, v40, vcc\n"
+            "v_cmp_gt_f32 vcc, 0, v35\n"                    /* log(x < 0) = NaN */
+            "s_nop 1\n"
+            "v_cndmask_b32 v37, v37, v41, vcc\n"
+            "v_cmp_u_f32 vcc, v35, v35\n"                   /* NaN in, the same NaN out */
+            "s_nop 1\n"
+            "v_cndmask_b32 v37, v37, v35, vcc\n"
+            MPR_ST MPR_DISPATCH
+            /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
+            "L_exit_%=:\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_mov_b32 %[dlo], s86\n"
+            "s_mov_b32 %[dhi], s87\n"
+            "s_mov_b32 %[base], s89\n"
+            "s_mov_b32 %[sj], s88\n"
+            : [blo] "+v"(blo), [bhi] "+v"(bhi), [plo] "+v"(plo), [phi] "+v"(phi),
+              [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
+            : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
+              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode)
+            : "memory", "vcc", "scc",
+              "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
+              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42");
+        const uint32_t op = dlo & 0xFF;
+        if (op == 0) break;
+        /* sin .. log (and anything that is not an opcode, like k_eval_voxels) */
+        const float A = *reinterpret_cast<const float*>(myslot + ((dlo >> 8) & 0xFF00));
+        *reinterpret_cast<float*>(myslot + (dlo & 0xFF00)) = rare_unary_a(op, A);
+        mode = 1;
+    }
+    return dlo;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(64)
+k_eval_voxels_asm(VoxelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    unsigned char* const myslot = smem + lane * 4;            /* slot s: myslot + s * 256 */
+
+    const int tile_index = blockIdx.x;
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const int position = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].position);
+    const int tape = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].tape);
+
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    const int S = a.tps * SUB;
+    const int4_ pos = unpack(position, a.tps);
+    const int4_ sub = unpack(lane, SUB);
+    const int px = pos.x * SUB + sub.x;
+    const int py = pos.y * SUB + sub.y;
+    const int pz = (DIM == 3) ? pos.z * 4 + sub.z : 0;
+
+    bool skip = false;
+    if (DIM == 3) {
+        /* reference :852-864: the thread owning (pz_low, pz_low + 2) leaves when image >= pz_low + 2 */
+        const int pz_low = pos.z * 4 + (sub.z & 1);
+        skip = a.image[px + py * S] >= pz_low + 2;
+        if (ballot(!skip) == 0) return;
+    }
+    const float size_recip = 1.0f / (float)(unsigned)(a.tps * SUB);
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    float vx, vy, vz;
+    if (DIM == 3) {
+        const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+        const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+        vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+        vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+        vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+    } else {
+        const float fw = a.mat[2] * fx + a.mat[5] * fy + a.mat[8];
+        vx = (a.mat[0] * fx + a.mat[3] * fy + a.mat[6]) / fw;
+        vy = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
+        vz = a.z;
+    }
+    const uint64_t head0 = tro[0];
+    *reinterpret_cast<float*>(myslot + ((head0 >> 8) & 0xFF) * 256) = vx;
+    *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
+    *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
+
+    const uint32_t dlo = interp_asm(tro, (uint32_t)(tape + 1), smem, lane);
+    const float res = *reinterpret_cast<const float*>(myslot + (dlo & 0xFF00));
+    if (!skip && res < 0.0f) {
+        if (DIM == 3) {
+            int* p = &a.image[px + py * S];
+            if (*p < pz) atomicMax(p, pz);
+        } else {
+            a.image[px + py * S] = 1;
+        }
+    }
+}
+
+/* one clause through the assembly interpreter: tape3 = {head (x,y,z in slots 1,2,3), the clause
+ * (lhs = slot 1, rhs = slot 2, out = slot 4), end (result slot 4)} */
+__global__ void __launch_bounds__(64)
+k_test_float_asm(const uint64_t* tape3, int n, const float* a, const float* b, float* out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    float* const myslot = reinterpret_cast<float*>(smem + lane * 4);
+    myslot[1 * 64] = i < n ? a[i] : 0.0f;
+    myslot[2 * 64] = (i < n && b) ? b[i] : 0.0f;
+    myslot[3 * 64] = 0.0f;
+    const uint32_t dlo = interp_asm(tape3, 1u, smem, lane);
+    const float r = myslot[((dlo >> 8) & 0xFF) * 64];
+    if (i < n) out[i] = r;
+}
+void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out)
+{
+    hipLaunchKernelGGL(k_test_float_asm, dim3((n + 63) / 64), dim3(64), 8 * 256, s, tape3, n, a, b, out);
+}
+
+size_t voxel_asm_lds_bytes(int nslots) { return (size_t)nslots * 256; }
+void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a)
+{
+    if (a.count <= 0) return;
+    const dim3 g(a.count), b(64);
+    const size_t lds = voxel_asm_lds_bytes(a.nslots);
+    if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_asm<3>, g, b, lds, s, a);
+    else hipLaunchKernelGGL(k_eval_voxels_asm<2>, g, b, lds, s, a);
+}
+
+}  // namespace mprk

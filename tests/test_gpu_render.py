@@ -252,3 +252,33 @@ def test_grouped_float_pass_is_bit_identical(mpr, tapes, k, monkeypatch):
             assert np.array_equal(a.normals, b.normals)
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("name,dim,S", [
+    ("hello_world", 2, 256), ("prospero", 2, 512), ("involute_gear_2d", 2, 512),
+    ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128),
+])
+def test_assembly_float_pass_matches_compiled_one(mpr, tapes, name, dim, S, monkeypatch):
+    """The float pass runs an interpreter written in gfx950 assembly (kernels_voxel_asm.hip);
+    MPR_VOXEL_ASM=0 selects the compiled C++ interpreter.  Same frame, bit for bit — including
+    the models with division, sqrt and the transcendental opcodes that leave the assembly loop."""
+    tape = tapes(name)
+    monkeypatch.setenv("MPR_VOXEL_ASM", "0")
+    a = mpr.Context(S)
+    monkeypatch.setenv("MPR_VOXEL_ASM", "1")
+    b = mpr.Context(S)
+    for ctx in (a, b):
+        if dim == 2:
+            ctx.render2D(tape, view2())
+        else:
+            ctx.render3D(tape, view3())
+    assert a.image.any()
+    assert np.array_equal(a.image, b.image)
+    if dim == 3:
+        assert np.array_equal(a.normals, b.normals)
+    if dim == 2:
+        a.render2D_brute(tape, view2())
+        b.render2D_brute(tape, view2())
+        assert np.array_equal(a.image, b.image)
+    a.close()
+    b.close()
