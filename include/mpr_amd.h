@@ -188,9 +188,10 @@ int mpr_test_interval_op(int32_t device, int32_t op, int32_t n, const float* a_l
 /* float primitive `op` on n operand pairs */
 int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, const float* b,
                       float imm, float* out);
-/* the same primitive through the float pass's assembly interpreter (kernels_voxel_asm.hip) */
-int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t n, const float* a, const float* b,
-                          float imm, float* out);
+/* the same primitive through the float pass's assembly interpreter (kernels_voxel_asm.hip);
+ * variant 0: operands from the slot file, 1 / 2: lhs / rhs forwarded from the previous clause */
+int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n, const float* a,
+                          const float* b, float imm, float* out);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
                       float imm, float* out4);

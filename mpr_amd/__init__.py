@@ -153,7 +153,7 @@ def lib():
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
     L.mpr_test_interval_op.argtypes = [i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]
     L.mpr_test_float_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
-    L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, vp, vp, f32, vp]
+    L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     _LIB = L
     return L
@@ -504,14 +504,17 @@ def dev_interval_op(op, a_lo, a_hi, b_lo=None, b_hi=None, imm=0.0, device=0):
     return lo, hi, ch
 
 
-def dev_float_op(op, a, b=None, imm=0.0, device=0, asm=False):
+def dev_float_op(op, a, b=None, imm=0.0, device=0, asm=False, variant=0):
     """One float clause on the device: the compiled float_clause, or (asm=True) the float pass's
-    assembly interpreter run over a one-clause tape."""
+    assembly interpreter run over a short tape (variant 1 / 2: lhs / rhs is the previous clause's
+    result, which the interpreter forwards in a register)."""
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
     out = np.empty_like(a)
-    fn = lib().mpr_test_float_op_asm if asm else lib().mpr_test_float_op
-    _check(fn(device, op, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
+    if asm:
+        _check(lib().mpr_test_float_op_asm(device, op, variant, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
+    else:
+        _check(lib().mpr_test_float_op(device, op, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
     return out
 
 

@@ -666,7 +666,7 @@ int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, con
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
-int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t n, const float* a, const float* b, float imm, float* out)
+int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n, const float* a, const float* b, float imm, float* out)
 {
     if (n <= 0 || !a || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(device));
@@ -678,8 +678,11 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t n, const float* a,
     uint32_t immbits;
     memcpy(&immbits, &imm, 4);
     /* 64 clauses so that the interpreter's 63-clause block fetch stays inside the buffer */
-    uint64_t tape3[64] = {mpr_cl_make(0, 1, 2, 3, 0), mpr_cl_make((uint32_t)op, 4, 1, b ? 2 : 0, immbits),
-                          mpr_cl_make(0, 4, 0, 0, 0)};
+    /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding) */
+    const uint32_t lhs = variant == 1 ? 5 : 1, rhs = b ? (variant == 2 ? 5 : 2) : 0;
+    uint64_t tape3[64] = {mpr_cl_make(0, 1, 2, 3, 0),
+                          variant == 2 ? mpr_cl_make(MPR_OP_COPY_RHS, 5, 0, 2, 0) : mpr_cl_make(MPR_OP_COPY_LHS, 5, 1, 0, 0),
+                          mpr_cl_make((uint32_t)op, 4, lhs, rhs, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
     HIP_TRY(hipMemcpy(dt.p, tape3, sizeof(tape3), hipMemcpyHostToDevice));
     mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
     HIP_TRY(hipGetLastError());

@@ -58,43 +58,87 @@ DEV float rare_unary_a(uint32_t op, float v)
 /* Fixed registers of the interpreter (declared as clobbers):
  *   s[80:81] handler address      s[82:83] handler table base     s[84:85] block address
  *   s86 / s87 clause lo / hi      s88 clause counter in block     s89 block base (clause index)
- *   s90 0x260 (class mask)        s[92:93] v_div_scale sdst
- *   v32 aA  v33 aB  v34 aO  v35 A  v36 B  v37 out  v38..v42 temporaries                       */
+ *   s90 0x260 (class mask)        s91, s[92:95] scratch (compare masks, v_div_scale sdst)
+ *   v32 aA  v33 aB  v34 aO  v35 A  v36 B  v37 result of the clause (and of the previous one)
+ *   v38..v44 temporaries                                                                       */
 #define MPR_DISPATCH                                   \
     "s_add_u32 s88, s88, 1\n"                          \
-    "v_readlane_b32 s80, %[plo], s88\n"                \
-    "v_readlane_b32 s81, %[phi], s88\n"                \
     "v_readlane_b32 s86, %[blo], s88\n"                \
-    "v_readlane_b32 s87, %[bhi], s88\n"                \
+    "s_and_b32 s80, s86, s96\n"                        \
+    "s_add_u32 s80, s80, s82\n"                        \
+    "s_addc_u32 s81, s83, 0\n"                         \
     "s_setpc_b64 s[80:81]\n"
+/* the immediate (or jump distance) is fetched only by the handlers that use it */
+#define MPR_IMM "v_readlane_b32 s87, %[bhi], s88\n"
 #define MPR_AL "v_perm_b32 v32, s86, %[lb], %[selL]\n ds_read_b32 v35, v32\n"
 #define MPR_AR "v_perm_b32 v33, s86, %[lb], %[selR]\n ds_read_b32 v36, v33\n"
 #define MPR_AO "v_perm_b32 v34, s86, %[lb], %[selO]\n"
 #define MPR_W "s_waitcnt lgkmcnt(0)\n"
 #define MPR_ST "ds_write_b32 v34, v37\n"
-#define MPR_H(n) ".p2align 7\nL_h" #n "_%=:\n"
+#define MPR_H(v, n) ".p2align 8\nL_h" #v "_" #n "_%=:\n"
 #define MPR_EXIT "s_branch L_exit_%=\n"
-#define MPR_UN(insn) MPR_AL MPR_AO MPR_W insn MPR_ST MPR_DISPATCH
-#define MPR_BIN_IMM(insn) MPR_AL MPR_AO MPR_W insn " v37, s87, v35\n" MPR_ST MPR_DISPATCH
-/* min / max: operands canonicalised first (a signalling NaN must lose against a number, like fminf) */
-#define MPR_MM_IMM(insn) MPR_AL MPR_AO "v_max_f32 v36, s87, s87\n" MPR_W "v_max_f32 v35, v35, v35\n" insn " v37, v35, v36\n" MPR_ST MPR_DISPATCH
-#define MPR_MM_RHS(insn) MPR_AL MPR_AR MPR_AO MPR_W "v_max_f32 v35, v35, v35\n v_max_f32 v36, v36, v36\n" insn " v37, v35, v36\n" MPR_ST MPR_DISPATCH
-#define MPR_BIN_RHS(insn) MPR_AL MPR_AR MPR_AO MPR_W insn " v37, v35, v36\n" MPR_ST MPR_DISPATCH
+#define MPR_END MPR_ST MPR_DISPATCH
+
+/* One handler table, 32 entries of 128 bytes, indexed by opcode.  There are three of them:
+ *   table 0: operands come from the slot file in LDS;
+ *   table 1: the lhs slot is the previous clause's out slot -> take it from v37, no LDS read;
+ *   table 2: the rhs slot is.
+ * (70-80% of the clauses of the benchmark models consume the previous result.)  Every result is
+ * still written to its slot, so a table-0 handler is always correct; which table a clause uses
+ * is decided per 63-clause block on the VALU (see L_load) and costs nothing per clause.
+ *   LDL / LDR  load lhs / rhs (or nothing), A / B the register the operand is then in,
+ *   WL / WR / WLR  s_waitcnt if lhs / rhs / either was loaded,
+ *   MVA / MVB  copy a forwarded operand into v35 / v36 for the shared long sequences,
+ *   NL / NR  the wait state still owed between the v_readlane of the immediate and its first
+ *   VALU use when no load of lhs / rhs sits in between.                                         */
+#define MPR_TABLE(v, LDL, A, LDR, B, WL, WR, WLR, MVA, MVB, NL, NR)                                               \
+    MPR_H(v, 0) MPR_EXIT                                              /* end of tape */                   \
+    MPR_H(v, 1)                                                       /* JUMP: base += j + imm + 1 */     \
+    MPR_IMM "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n"   \
+    MPR_H(v, 2) LDL MPR_AO WL "v_mul_f32 v37, " A ", " A "\n" MPR_END                                     \
+    MPR_H(v, 3) LDL MPR_AO WL MVA "s_branch L_sqrt_%=\n"                                                  \
+    MPR_H(v, 4) LDL MPR_AO WL "v_xor_b32 v37, 0x80000000, " A "\n" MPR_END                                \
+    MPR_H(v, 5) MPR_EXIT MPR_H(v, 6) MPR_EXIT MPR_H(v, 7) MPR_EXIT MPR_H(v, 8) MPR_EXIT MPR_H(v, 9) MPR_EXIT \
+    MPR_H(v, 10) LDL MPR_AO WL MVA "s_branch L_exp_%=\n"                                                  \
+    MPR_H(v, 11) LDL MPR_AO WL "v_and_b32 v37, 0x7fffffff, " A "\n" MPR_END                               \
+    MPR_H(v, 12) LDL MPR_AO WL MVA "s_branch L_log_%=\n"                                                  \
+    MPR_H(v, 13) MPR_IMM LDL MPR_AO WL NL "v_add_f32 v37, s87, " A "\n" MPR_END                                      \
+    MPR_H(v, 14) LDL LDR MPR_AO WLR "v_add_f32 v37, " A ", " B "\n" MPR_END                               \
+    MPR_H(v, 15) MPR_IMM LDL MPR_AO WL NL "v_mul_f32 v37, s87, " A "\n" MPR_END                                      \
+    MPR_H(v, 16) LDL LDR MPR_AO WLR "v_mul_f32 v37, " A ", " B "\n" MPR_END                               \
+    /* min / max: operands canonicalised first (a signalling NaN loses against a number, like fminf) */  \
+    MPR_H(v, 17) MPR_IMM LDL MPR_AO NL "v_max_f32 v36, s87, s87\n" WL "v_max_f32 v35, " A ", " A "\n v_min_f32 v37, v35, v36\n" MPR_END \
+    MPR_H(v, 18) LDL LDR MPR_AO WLR "v_max_f32 v35, " A ", " A "\n v_max_f32 v36, " B ", " B "\n v_min_f32 v37, v35, v36\n" MPR_END \
+    MPR_H(v, 19) MPR_IMM LDL MPR_AO NL "v_max_f32 v36, s87, s87\n" WL "v_max_f32 v35, " A ", " A "\n v_max_f32 v37, v35, v36\n" MPR_END \
+    MPR_H(v, 20) LDL LDR MPR_AO WLR "v_max_f32 v35, " A ", " A "\n v_max_f32 v36, " B ", " B "\n v_max_f32 v37, v35, v36\n" MPR_END \
+    MPR_H(v, 21) MPR_IMM LDL MPR_AO WL NL "v_subrev_f32 v37, s87, " A "\n" MPR_END          /* lhs - imm */         \
+    MPR_H(v, 22) MPR_IMM LDR MPR_AO WR NR "v_sub_f32 v37, s87, " B "\n" MPR_END             /* imm - rhs */         \
+    MPR_H(v, 23) LDL LDR MPR_AO WLR "v_sub_f32 v37, " A ", " B "\n" MPR_END                               \
+    MPR_H(v, 24) MPR_IMM LDL MPR_AO WL MVA "v_mov_b32 v36, s87\n s_branch L_div_%=\n"    /* lhs / imm */         \
+    MPR_H(v, 25) MPR_IMM LDR MPR_AO WR MVB "v_mov_b32 v35, s87\n s_branch L_div_%=\n"    /* imm / rhs */         \
+    MPR_H(v, 26) LDL LDR MPR_AO WLR MVA MVB "s_branch L_div_%=\n"                                         \
+    MPR_H(v, 27) MPR_IMM MPR_AO "s_nop 0\n v_mov_b32 v37, s87\n" MPR_END                 /* COPY_IMM */          \
+    MPR_H(v, 28) LDL MPR_AO WL "v_mov_b32 v37, " A "\n" MPR_END                  /* COPY_LHS */          \
+    MPR_H(v, 29) LDR MPR_AO WR "v_mov_b32 v37, " B "\n" MPR_END                  /* COPY_RHS */          \
+    MPR_H(v, 30) MPR_EXIT                                                         /* not an opcode */     \
+    MPR_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"                  /* lane 63: next block */
 
 /* Walks the tape whose first clause is tro[first] over the slot file at LDS offset 0 (slot s of
- * lane l at s * 256 + l * 4) and returns the low word of the end clause (result slot in byte 1). */
+ * lane l at s * 256 + l * 4) and returns the result slot named by the end clause. */
 DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane)
 {
     unsigned char* const myslot = smem + lane * 4;
     /* state of the assembly interpreter that has to survive a trip through C++ */
-    uint32_t blo = 0, bhi = 0, plo = 0, phi = 0;     /* clause block and handler addresses, lane j = clause j */
+    uint32_t blo = 0, bhi = 0;                       /* the clause block: lane j = clause j */
     uint32_t base = first, sj = 0, dlo = 0, dhi = 0;
     /* the v_perm_b32 address trick needs the dynamic LDS segment at offset 0 (no static LDS here) */
     const uint32_t lb = (uint32_t)(uintptr_t)smem + (uint32_t)lane * 4u;
     const uint32_t lane8 = (uint32_t)lane * 8u;
-    /* v_perm_b32 selectors: byte 0 <- lb byte 0, byte 1 <- clause byte 1 (out) / 2 (lhs) / 3 (rhs) */
-    const uint32_t selO = to_vgpr(0x0c0c0500u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
+    /* v_perm_b32 selectors: byte 0 <- lb byte 0, byte 1 <- byte 0 (out) / 2 (lhs) / 3 (rhs) of the
+     * clause word as rewritten per block (see L_load) */
+    const uint32_t selO = to_vgpr(0x0c0c0400u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
     const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    float prev = 0.0f;
     uint32_t mode = 0;                               /* 0: fetch the block at `base`; 1: continue after `sj` */
 
     for (;;) {
@@ -105,9 +149,11 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_mov_b32 s89, %[base]\n"
             "s_mov_b32 s88, %[sj]\n"
             "s_mov_b32 s90, 0x260\n"
+            "s_mov_b32 s96, 0xff00\n"
+            "v_mov_b32 v37, %[prev]\n"
             "s_getpc_b64 s[82:83]\n"
             "L_pc_%=:\n"
-            "s_add_u32 s82, s82, L_h0_%=-L_pc_%=\n"
+            "s_add_u32 s82, s82, L_h0_0_%=-L_pc_%=\n"
             "s_addc_u32 s83, s83, 0\n"
             "s_cmp_eq_u32 %[mode], 0\n"
             "s_cbranch_scc1 L_load_%=\n"
@@ -122,58 +168,36 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "global_load_dword %[blo], %[lane8], s[84:85]\n"
             "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
             "s_mov_b32 s88, -1\n"
-            "v_mov_b32 v39, 0xf80\n"                    /* handler 31 = next block */
-            "v_mov_b32 %[phi], s83\n"
+            "v_mov_b32 v41, 0\n"
+            "v_mov_b32 v43, 32\n"
+            "v_mov_b32 v44, 64\n"
             "s_waitcnt vmcnt(0)\n"
+            "v_bfe_u32 v40, %[blo], 8, 8\n"                 /* out slot */
             "v_and_b32 v38, 0xff, %[blo]\n"
-            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"       /* lane 63 */
-            "v_min_u32 v38, 30, v38\n"                   /* unknown opcodes -> handler 30 */
-            "v_lshlrev_b32 v38, 7, v38\n"
-            "v_cndmask_b32 v38, v38, v39, vcc\n"
-            "v_add_co_u32 %[plo], vcc, s82, v38\n"
-            "s_nop 1\n"
-            "v_addc_co_u32 %[phi], vcc, 0, %[phi], vcc\n"
+            "v_min_u32 v38, 30, v38\n"                       /* opcode; unknown ones -> handler 30 */
+            "v_mov_b32_dpp v41, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */
+            "v_bfe_u32 v42, %[blo], 16, 8\n"                /* lhs slot */
+            "v_lshrrev_b32 v39, 24, %[blo]\n"               /* rhs slot */
+            "v_cmp_eq_u32 s[92:93], v39, v41\n"
+            "v_cmp_eq_u32 vcc, v42, v41\n"
+            "v_cmp_ne_u32 s[94:95], 0, v41\n"
+            "v_cndmask_b32 v42, 0, v44, s[92:93]\n"          /* rhs forwarded: table 2 */
+            "v_cndmask_b32 v42, v42, v43, vcc\n"             /* lhs forwarded: table 1 */
+            "v_cndmask_b32 v42, 0, v42, s[94:95]\n"
+            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */
+            "v_mov_b32 v39, 31\n"
+            "v_add_u32 v38, v38, v42\n"
+            "v_cndmask_b32 v38, v38, v39, vcc\n"             /* handler index = table * 32 + opcode */
+            /* clause word as the handlers see it: byte 0 out slot, byte 1 handler index, bytes 2, 3 lhs, rhs */
+            "v_lshl_or_b32 v38, v38, 8, v40\n"
+            "v_and_b32 %[blo], 0xffff0000, %[blo]\n"
+            "v_or_b32 %[blo], %[blo], v38\n"
             "s_nop 0\n"
             MPR_DISPATCH
-            /* ---- handlers, 128 bytes apart, indexed by opcode ---- */
-            MPR_H(0) MPR_EXIT                                             /* end of tape */
-            MPR_H(1)                                                      /* JUMP: base += j + imm + 1 */
-            "s_add_u32 s89, s89, s88\n"
-            "s_add_u32 s89, s89, s87\n"
-            "s_add_u32 s89, s89, 1\n"
-            "s_branch L_load_%=\n"
-            MPR_H(2) MPR_UN("v_mul_f32 v37, v35, v35\n")                  /* SQUARE */
-            MPR_H(3) MPR_AL MPR_AO MPR_W "s_branch L_sqrt_%=\n"           /* SQRT */
-            MPR_H(4) MPR_UN("v_xor_b32 v37, 0x80000000, v35\n")           /* NEG */
-            MPR_H(5) MPR_EXIT
-            MPR_H(6) MPR_EXIT
-            MPR_H(7) MPR_EXIT
-            MPR_H(8) MPR_EXIT
-            MPR_H(9) MPR_EXIT
-            MPR_H(10) MPR_AL MPR_AO MPR_W "s_branch L_exp_%=\n"           /* EXP */
-            MPR_H(11) MPR_UN("v_and_b32 v37, 0x7fffffff, v35\n")          /* ABS */
-            MPR_H(12) MPR_AL MPR_AO MPR_W "s_branch L_log_%=\n"           /* LOG */
-            MPR_H(13) MPR_BIN_IMM("v_add_f32")
-            MPR_H(14) MPR_BIN_RHS("v_add_f32")
-            MPR_H(15) MPR_BIN_IMM("v_mul_f32")
-            MPR_H(16) MPR_BIN_RHS("v_mul_f32")
-            MPR_H(17) MPR_MM_IMM("v_min_f32")
-            MPR_H(18) MPR_MM_RHS("v_min_f32")
-            MPR_H(19) MPR_MM_IMM("v_max_f32")
-            MPR_H(20) MPR_MM_RHS("v_max_f32")
-            MPR_H(21) MPR_BIN_IMM("v_subrev_f32")                         /* lhs - imm */
-            MPR_H(22) MPR_AR MPR_AO MPR_W "v_sub_f32 v37, s87, v36\n" MPR_ST MPR_DISPATCH   /* imm - rhs */
-            MPR_H(23) MPR_BIN_RHS("v_sub_f32")
-            MPR_H(24) MPR_AL MPR_AO MPR_W "v_mov_b32 v36, s87\n s_branch L_div_%=\n"         /* lhs / imm */
-            MPR_H(25) MPR_AR MPR_AO MPR_W "v_mov_b32 v35, s87\n s_branch L_div_%=\n"         /* imm / rhs */
-            MPR_H(26) MPR_AL MPR_AR MPR_AO MPR_W "s_branch L_div_%=\n"                       /* lhs / rhs */
-            MPR_H(27) MPR_AO "s_nop 0\n v_mov_b32 v37, s87\n" MPR_ST MPR_DISPATCH           /* COPY_IMM */
-            MPR_H(28) MPR_AL MPR_AO MPR_W "ds_write_b32 v34, v35\n" MPR_DISPATCH            /* COPY_LHS */
-            MPR_H(29) MPR_AR MPR_AO MPR_W "ds_write_b32 v34, v36\n" MPR_DISPATCH            /* COPY_RHS */
-            MPR_H(30) MPR_EXIT                                            /* not an opcode */
-            MPR_H(31)                                                     /* lane 63: next block */
-            "s_add_u32 s89, s89, 63\n"
-            "s_branch L_load_%=\n"
+            /* ---- handlers: three tables of 32 x 128 bytes ---- */
+            MPR_TABLE(0, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "")
+            MPR_TABLE(1, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "")
+            MPR_TABLE(2, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n")
             /* ---- v37 = v35 / v36, correctly rounded ---- */
             ".p2align 7\n"
             "L_div_%=:\n"
@@ -304,21 +328,23 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_mov_b32 %[dhi], s87\n"
             "s_mov_b32 %[base], s89\n"
             "s_mov_b32 %[sj], s88\n"
-            : [blo] "+v"(blo), [bhi] "+v"(bhi), [plo] "+v"(plo), [phi] "+v"(phi),
+            : [blo] "+v"(blo), [bhi] "+v"(bhi),
               [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
-              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode)
+              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev)
             : "memory", "vcc", "scc",
-              "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42");
-        const uint32_t op = dlo & 0xFF;
+              "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
+              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44");
+        /* dlo is the rewritten clause word: byte 0 out slot, byte 1 handler index (opcode in its low 5 bits) */
+        const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
         /* sin .. log (and anything that is not an opcode, like k_eval_voxels) */
         const float A = *reinterpret_cast<const float*>(myslot + ((dlo >> 8) & 0xFF00));
-        *reinterpret_cast<float*>(myslot + (dlo & 0xFF00)) = rare_unary_a(op, A);
+        prev = rare_unary_a(op, A);      /* re-enters as "the previous clause's result" (operand forwarding) */
+        *reinterpret_cast<float*>(myslot + ((dlo & 0xFF) << 8)) = prev;
         mode = 1;
     }
-    return dlo;
+    return dlo & 0xFF;
 }
 
 template <int DIM>
@@ -370,8 +396,8 @@ k_eval_voxels_asm(VoxelArgs a)
     *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
     *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
 
-    const uint32_t dlo = interp_asm(tro, (uint32_t)(tape + 1), smem, lane);
-    const float res = *reinterpret_cast<const float*>(myslot + (dlo & 0xFF00));
+    const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane);
+    const float res = *reinterpret_cast<const float*>(myslot + rslot * 256);
     if (!skip && res < 0.0f) {
         if (DIM == 3) {
             int* p = &a.image[px + py * S];
@@ -394,8 +420,8 @@ k_test_float_asm(const uint64_t* tape3, int n, const float* a, const float* b, f
     myslot[1 * 64] = i < n ? a[i] : 0.0f;
     myslot[2 * 64] = (i < n && b) ? b[i] : 0.0f;
     myslot[3 * 64] = 0.0f;
-    const uint32_t dlo = interp_asm(tape3, 1u, smem, lane);
-    const float r = myslot[((dlo >> 8) & 0xFF) * 64];
+    const uint32_t rslot = interp_asm(tape3, 1u, smem, lane);
+    const float r = myslot[rslot * 64];
     if (i < n) out[i] = r;
 }
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out)
