@@ -124,6 +124,7 @@ static void finish_tape(mpr_tape* t)
     }
     t->num_slots = max_slot + 1;
     t->num_choices = choices;
+    t->schedule = mpr::build_schedule(t->clauses.data(), (int32_t)t->clauses.size());
     static std::atomic<uint64_t> serial{1};
     t->serial = serial++;
 }

@@ -62,6 +62,12 @@ struct mpr_context {
                                           1, 2, 4 = children per batch of the grouped form (MPR_VOXEL_K, experimental) */
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
+    void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
+    int* sched_levels = nullptr;
+    size_t sched_recs_cap = 0, sched_levels_cap = 0;
+    bool sched_ok = false;
+    int sched_nlevels = 0, sched_nclauses = 0, sched_root = 0;
+    bool wide_stage0 = true;           /* MPR_WIDE_STAGE0=0: first stage with the one-lane-per-tile kernel */
     int tape_len = 0;
 
     mpr_counters last = {};
@@ -152,6 +158,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->S = S;
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_K")) {
         const int k = atoi(e);
         if (k == 0 || k == 1 || k == 2 || k == 4) c->voxel_k = k;
@@ -222,6 +229,8 @@ void mpr_ctx_destroy(mpr_context* c)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    if (c->sched_recs) (void)hipFree(c->sched_recs);
+    if (c->sched_levels) (void)hipFree(c->sched_levels);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -246,6 +255,32 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         HIP_TRY(hipStreamSynchronize(c->stream));   /* pageable source must stay valid */
         c->tape_serial = tape->serial;
         c->tape_len = len;
+        /* the tape's level schedule for the wide first-stage kernel */
+        const mpr::TapeSchedule& sc = tape->schedule;
+        c->sched_ok = sc.ok && mprk::wide_stage_fits(sc.nclauses);
+        if (c->sched_ok) {
+            const size_t rb = sc.recs.size() * sizeof(mpr::SchedRec), lb = sc.level_start.size() * sizeof(int32_t);
+            if (rb > c->sched_recs_cap) {
+                if (c->sched_recs) (void)hipFree(c->sched_recs);
+                c->sched_recs = nullptr;
+                c->sched_recs_cap = 0;
+                HIP_TRY(hipMalloc(&c->sched_recs, rb));
+                c->sched_recs_cap = rb;
+            }
+            if (lb > c->sched_levels_cap) {
+                if (c->sched_levels) (void)hipFree(c->sched_levels);
+                c->sched_levels = nullptr;
+                c->sched_levels_cap = 0;
+                HIP_TRY(hipMalloc((void**)&c->sched_levels, lb));
+                c->sched_levels_cap = lb;
+            }
+            HIP_TRY(hipMemcpyAsync(c->sched_recs, sc.recs.data(), rb, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->sched_levels, sc.level_start.data(), lb, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->sched_nlevels = (int)sc.level_start.size() - 1;
+            c->sched_nclauses = sc.nclauses;
+            c->sched_root = sc.root_val;
+        }
     }
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->tape_index, len, 1, c->stream));
     if (c->flags & MPR_CTX_COUNTERS)
@@ -371,7 +406,19 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.counters = cnt;
             a.debug = getenv("MPR_DEBUG_TILES") ? atoi(getenv("MPR_DEBUG_TILES")) : 0;
             TimedScope ts(c, "eval_tiles_i");
-            mprk::launch_eval_tiles(s, dim, a);
+            if (si == 0 && c->wide_stage0 && c->sched_ok && !grouped && !a.debug) {
+                /* first stage: few tiles, all on the root tape -> one workgroup per tile, level by level */
+                mprk::WideStageArgs w;
+                w.t = a;
+                w.recs = c->sched_recs;
+                w.level_start = c->sched_levels;
+                w.nlevels = c->sched_nlevels;
+                w.nclauses = c->sched_nclauses;
+                w.root_val = c->sched_root;
+                mprk::launch_eval_tiles_wide(s, dim, w);
+            } else {
+                mprk::launch_eval_tiles(s, dim, a);
+            }
         }
         HIP_TRY(hipMemsetAsync(c->num_active, 0, sizeof(int), s));
         /* worst case: every tile survives */

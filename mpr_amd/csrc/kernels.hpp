@@ -51,6 +51,17 @@ struct TileStageArgs {
     int debug;                 /* development only (MPR_DEBUG_TILES): 1 = skip tape pushing, 2 = skip the arithmetic */
 };
 
+/* first tile stage, one workgroup per tile, level by level over the root tape's DAG
+ * (kernels_wide.hip, tape_schedule.hpp) */
+struct WideStageArgs {
+    TileStageArgs t;
+    const void* recs;          /* SchedRec[nclauses] in (level, opcode) order */
+    const int* level_start;    /* nlevels + 1 offsets into recs */
+    int nlevels;
+    int nclauses;
+    int root_val;              /* value index of the result (0..2 = X, Y, Z; 3 + i = clause i) */
+};
+
 struct VoxelArgs {
     const uint64_t* tape_ro;
     int* image;                /* S x S output */
@@ -95,6 +106,8 @@ struct NormalArgs {
 void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
+bool wide_stage_fits(int nclauses);
+void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out);
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);

@@ -1,0 +1,305 @@
+/*
+ * kernels_wide.hip — eval_tiles_i for the FIRST tile stage, one workgroup per tile.
+ *
+ * The reference evaluates a tile with one thread that walks the tape clause by clause
+ * (src/context.cu:77-458), and so does k_eval_tiles (kernels.hip), one lane per tile.  At the
+ * first stage there are only (S/64)^2 or (S/64)^3 tiles — 256 at 1024^2 — and every one walks the
+ * whole root tape: four wavefronts stepping through prospero's 6056 clauses twice is 3.9 ms of
+ * pure dependent-instruction latency on an otherwise idle chip, 90 % of that frame.
+ *
+ * The root tape's dependency DAG is shallow (tape_schedule.hpp: prospero 22 levels, bear 72), so
+ * here the 256 threads of a workgroup evaluate one tile LEVEL BY LEVEL:
+ *   forward   every thread takes clauses of the current level (16-byte records: clause, operand
+ *             value indices, clause index, choice ordinal; records of a level are sorted by
+ *             opcode), reads its operands' intervals from the value array in LDS, runs the same
+ *             interval_clause() as everybody else (device_math.hpp, round-up mode), stores the
+ *             result interval and the min/max choice;
+ *   classify  empty / masked / filled / ambiguous exactly as reference :293-321;
+ *   shorten   (ambiguous tiles that made a choice) liveness is propagated from the result down
+ *             the levels — the same def-use reachability the reference's backward walk computes
+ *             with its per-slot "active" flags (:351-458) — then the live clauses are ranked in
+ *             reverse tape order by a block-wide prefix sum and written to freshly claimed chunks
+ *             in the reference's layout: 62 clauses per 64-word chunk, links in word 0 and 63,
+ *             decided min/max clauses rewritten to COPY_LHS / COPY_RHS / COPY_IMM or dropped when
+ *             the copy would be onto itself.
+ * The values, choices, tile states and shortened tapes are those of the serial walk; the tests
+ * compare both kernels and the oracle (tests/test_gpu_render.py).
+ */
+#include "kernel_common.hpp"
+
+namespace mprk {
+
+DEV void mark_val(unsigned char* act, uint32_t v)
+{
+    if (v >= 3) act[v - 3] = 1;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+k_eval_tiles_wide(WideStageArgs w)
+{
+    const TileStageArgs& a = w.t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = w.nclauses;
+    float2* const V = reinterpret_cast<float2*>(smem);                                   /* [n + 3] values */
+    unsigned char* const ch = smem + (size_t)(n + 3) * 8;                                /* [n] choice of clause i */
+    unsigned char* const act = ch + n;                                                   /* [n] live flags */
+    int* const sh = reinterpret_cast<int*>(smem + (((size_t)(n + 3) * 8 + 2 * (size_t)n + 15) & ~(size_t)15));   /* [272] */
+    /* sh[0] any choice, sh[1] state (0 dead, 1 ambiguous), sh[2] pool base, sh[3] ok, sh[4] min live-and-dropped i,
+     * sh[5] min written i, sh[8..8+256] scan */
+
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;                              /* 64 for narrow tapes, 256 for wide ones */
+    const int gidx = blockIdx.x;
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    uint64_t* __restrict__ const twr = a.tape_wr;
+
+    /* tile state: read once (other workgroups update the image while this one runs) */
+    if (tid == 0) {
+        const mpr_tile_node node = a.tiles[gidx];
+        int alive = node.position != -1;
+        if (DIM == 3 && alive) {
+            const int4_ p = unpack(node.position, a.tps);
+            if (a.image[p.w] > p.z) {                       /* mask_filled_tiles before evaluation */
+                alive = 0;
+                a.tiles[gidx].position = -1;
+            }
+        }
+        sh[0] = 0;
+        sh[1] = alive;
+        sh[6] = node.position;
+        sh[7] = node.tape;
+        sh[4] = 0x7FFFFFFF;
+        sh[5] = 0x7FFFFFFF;
+    }
+    for (int i = tid; i < n; i += nt) act[i] = 0;
+    __syncthreads();
+    if (sh[1] == 0) return;
+    const int4_ pos = unpack(sh[6], a.tps);
+    const int tape = sh[7];                                 /* the root tape: 0 */
+
+    /* tile corners in round-to-nearest (reference :91-96), then the view transform in round-up mode */
+    const float t = (float)a.tps;
+    float c0 = (pos.x / t - 0.5f) * 2.0f, c1 = ((pos.x + 1) / t - 0.5f) * 2.0f;
+    float c2 = (pos.y / t - 0.5f) * 2.0f, c3 = ((pos.y + 1) / t - 0.5f) * 2.0f;
+    float c4 = 0.0f, c5 = 0.0f;
+    if (DIM == 3) {
+        c4 = (pos.z / t - 0.5f) * 2.0f;
+        c5 = ((pos.z + 1) / t - 0.5f) * 2.0f;
+    }
+    round_up_begin(c0, c1, c2, c3, c4, c5);
+    /* ---- from here on: f32 round-up mode, rounded f32 arithmetic only through device_math ---- */
+    if (tid == 0) {
+        const ival ix = iv(c0, c1), iy = iv(c2, c3), iz = iv(c4, c5);
+        ival vx, vy, vz;
+        if (DIM == 3) {
+            ival r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[i] = i_add_f(i_add(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 4])),
+                                     i_mul_f(iz, a.mat[i + 8])), a.mat[i + 12]);
+            }
+            vx = i_div(r[0], r[3]);
+            vy = i_div(r[1], r[3]);
+            vz = i_div(r[2], r[3]);
+        } else {
+            ival r[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                r[i] = i_add_f(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 3])), a.mat[i + 6]);
+            }
+            vx = i_div(r[0], r[2]);
+            vy = i_div(r[1], r[2]);
+            vz = iv(a.z, a.z);
+        }
+        V[0] = make_float2(vx.lo, vx.hi);
+        V[1] = make_float2(vy.lo, vy.hi);
+        V[2] = make_float2(vz.lo, vz.hi);
+    }
+    __syncthreads();
+
+    /* ---- forward, level by level ---- */
+    const uint4* __restrict__ const recs = reinterpret_cast<const uint4*>(w.recs);
+    bool my_choice = false;
+    for (int lv = 0; lv < w.nlevels; ++lv) {
+        const int begin = w.level_start[lv], end = w.level_start[lv + 1];
+        for (int k = begin + tid; k < end; k += nt) {
+            const uint4 q = recs[k];
+            const uint32_t op = q.x & 0xFF, r8 = q.x >> 24;
+            const uint32_t pl = q.z & 0xFFFF, pr = q.z >> 16, idx = q.w & 0xFFFF, ord = q.w >> 16;
+            const float imm = mpr_u2f(q.y);
+            const float2 lv2 = V[pl];
+            const float2 rv2 = V[pr];
+            int c = 0;
+            const ival B = r8 ? iv(rv2.x, rv2.y) : iv(imm, imm);       /* immediate forms carry rhs == 0 */
+            const ival out = interval_clause(op, iv(lv2.x, lv2.y), B, imm, c);
+            V[3 + idx] = make_float2(out.lo, out.hi);
+            /* choices past choice_cap are not recorded by the reference (:257): they still make the
+             * tile push a tape, but the backward pass keeps both sides of such a clause */
+            ch[idx] = (unsigned char)(((int)ord < a.choice_cap) ? c : 0);
+            my_choice |= c != 0;
+        }
+        __syncthreads();
+    }
+    if (my_choice) sh[0] = 1;
+    const float2 res = V[w.root_val];
+
+    /* ---- classification (reference :293-321) ---- */
+    if (tid == 0) {
+        int state = 0;
+        if (res.x > 0.0f) {                                   /* empty */
+            a.tiles[gidx].position = -1;
+        } else if (DIM == 3 && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
+            a.tiles[gidx].position = -1;                      /* masked */
+        } else if (res.y < 0.0f) {                            /* filled */
+            a.tiles[gidx].position = -1;
+            if (DIM == 3) atomicMax(&a.image[pos.w], pos.z);
+            else a.image[pos.w] = 1;
+        } else {
+            state = 1;
+        }
+        sh[1] = state;
+        if (a.counters) {
+            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)n);
+            if ((gidx & 63) == 0) atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)(n + 1));
+        }
+    }
+    __syncthreads();
+    if (!(sh[1] == 1 && sh[0] != 0)) return;       /* only ambiguous tiles that chose a side shorten their tape */
+
+    /* ---- liveness, from the result down the levels (reference :351-458, def-use form) ---- */
+    if (tid == 0) mark_val(act, (uint32_t)w.root_val);
+    __syncthreads();
+    for (int lv = w.nlevels - 1; lv >= 0; --lv) {
+        const int begin = w.level_start[lv], end = w.level_start[lv + 1];
+        for (int k = begin + tid; k < end; k += nt) {
+            const uint4 q = recs[k];
+            const uint32_t idx = q.w & 0xFFFF;
+            if (!act[idx]) continue;
+            const uint32_t op = q.x & 0xFF, l8 = (q.x >> 16) & 0xFF, r8 = q.x >> 24;
+            const uint32_t pl = q.z & 0xFFFF, pr = q.z >> 16;
+            const int c = mpr_op_is_minmax(op) ? ch[idx] : 0;
+            if (c == 1) {
+                mark_val(act, pl);
+            } else if (c == 2) {
+                if (r8) mark_val(act, pr);
+            } else {
+                if (l8) mark_val(act, pl);
+                if (r8) mark_val(act, pr);
+            }
+        }
+        __syncthreads();
+    }
+
+    /* ---- rank the clauses that get written, in reverse tape order ---- */
+    const int per = (n + nt - 1) / nt;
+    const int hi_i = n - 1 - tid * per;                  /* this thread: i = hi_i, hi_i - 1, ... > lo_i */
+    const int lo_i = max(hi_i - per, -1);
+    int mine = 0;
+    int min_drop = 0x7FFFFFFF, min_emit = 0x7FFFFFFF;
+    for (int i = hi_i; i > lo_i; --i) {
+        if (!act[i]) continue;
+        const uint64_t d = tro[tape + 1 + i];
+        const uint32_t op = (uint32_t)d & 0xFF, o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF,
+                       r = (uint32_t)(d >> 24) & 0xFF;
+        const int c = mpr_op_is_minmax(op) ? ch[i] : 0;
+        const bool drop = (c == 1 && l == o) || (c == 2 && r != 0 && r == o);
+        if (drop) {
+            min_drop = i;
+            act[i] = 2;                                   /* live, nothing written */
+        } else {
+            ++mine;
+            min_emit = i;
+        }
+    }
+    sh[8 + tid] = mine;
+    if (min_drop != 0x7FFFFFFF) atomicMin(&sh[4], min_drop);
+    if (min_emit != 0x7FFFFFFF) atomicMin(&sh[5], min_emit);
+    __syncthreads();
+    /* exclusive scan of the per-thread counts (Hillis-Steele in LDS) */
+    int incl = mine;
+    for (int off = 1; off < nt; off <<= 1) {
+        const int other = tid >= off ? sh[8 + tid - off] : 0;
+        __syncthreads();
+        incl += other;
+        sh[8 + tid] = incl;
+        __syncthreads();
+    }
+    const int total = sh[8 + nt - 1];
+    int rank = incl - mine;                               /* clauses written before this thread's first */
+
+    /* chunks: the end clause and 62 clauses in the first, 62 per further chunk; the reference opens
+     * a chunk when a live clause arrives at a full one — even if that clause is then dropped */
+    const bool spurious = total > 0 && total % 62 == 0 && sh[4] < sh[5];
+    const int nchunks = (total == 0 ? 1 : (total - 1) / 62 + 1) + (spurious ? 1 : 0);
+    if (tid == 0) {
+        const long long want = (long long)MPR_SUBTAPE_CHUNK * nchunks;
+        const int cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = (long long)cur < a.pool_cap && (long long)cur + want < 0x7FFFFFFFll;
+        int base = 0;
+        if (ok) {
+            base = atomicAdd(a.tape_index, (int)want);
+            if ((long long)base + want >= a.pool_cap) ok = 0;
+        }
+        sh[2] = base;
+        sh[3] = ok;
+        if (!ok && a.counters) a.counters[CNT_OVERFLOW] = 1;
+    }
+    __syncthreads();
+    if (!sh[3]) return;                                   /* pool exhausted: the tile keeps its parent's tape */
+    const int base = sh[2];
+
+    for (int i = hi_i; i > lo_i; --i) {
+        if (act[i] != 1) continue;
+        uint64_t d = tro[tape + 1 + i];
+        const uint32_t op = (uint32_t)d & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+        if (mpr_op_is_minmax(op)) {
+            const int c = ch[i];
+            if (c == 1) d = (d & ~0xFFull) | MPR_OP_COPY_LHS;
+            else if (c == 2) d = (d & ~0xFFull) | (r ? MPR_OP_COPY_RHS : MPR_OP_COPY_IMM);
+        }
+        twr[base + MPR_SUBTAPE_CHUNK * (rank / 62) + 62 - rank % 62] = d;
+        ++rank;
+    }
+    if (tid == 0) {
+        twr[base + 63] = tro[tape + 1 + n];                       /* end clause */
+        /* head: copy of the parent's head, after the last clause written */
+        const int last_chunk = nchunks - 1;
+        const int in_last = total - 62 * last_chunk;       /* 0 when the last chunk was opened for a dropped clause */
+        const int head_at = base + MPR_SUBTAPE_CHUNK * last_chunk + 62 - in_last;
+        twr[head_at] = tro[tape];
+        a.tiles[gidx].tape = head_at;
+        if (a.counters) atomicAdd((unsigned long long*)&a.counters[CNT_WRITTEN], (unsigned long long)(total + 2 + 2 * (nchunks - 1)));
+    }
+    /* links between consecutive chunks (reference :384-413): word 63 of the newer chunk jumps back
+     * to the older one, word 0 of the older chunk forward to the newer */
+    for (int k = 1 + tid; k < nchunks; k += nt) {
+        const int prev_index = base + MPR_SUBTAPE_CHUNK * (k - 1);
+        const int out_index = base + MPR_SUBTAPE_CHUNK * k;
+        const int delta = prev_index - (out_index + 63);
+        twr[out_index + 63] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)delta << 32);
+        twr[prev_index] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)(-delta) << 32);
+    }
+}
+
+size_t wide_stage_lds_bytes(int nclauses)
+{
+    return (((size_t)(nclauses + 3) * 8 + 2 * (size_t)nclauses + 15) & ~(size_t)15) + 272 * sizeof(int);
+}
+bool wide_stage_fits(int nclauses) { return wide_stage_lds_bytes(nclauses) <= 150 * 1024; }
+void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w)
+{
+    static bool once = false;
+    if (!once) {
+        once = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    const size_t lds = wide_stage_lds_bytes(w.nclauses);
+    /* one wavefront per tile when the levels are narrow (no cross-wave barriers), four otherwise */
+    const int threads = (w.nclauses / (w.nlevels > 0 ? w.nlevels : 1) >= 48) ? 256 : 64;
+    if (dim == 3) hipLaunchKernelGGL(k_eval_tiles_wide<3>, dim3(w.t.count), dim3(threads), lds, s, w);
+    else hipLaunchKernelGGL(k_eval_tiles_wide<2>, dim3(w.t.count), dim3(threads), lds, s, w);
+}
+
+}  // namespace mprk

@@ -282,3 +282,14 @@ def test_assembly_float_pass_matches_compiled_one(mpr, tapes, name, dim, S, monk
         assert np.array_equal(a.image, b.image)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("hello_world", 2, 256),
+                                        ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128)])
+def test_serial_first_stage_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):
+    """By default the first tile stage runs one workgroup per tile, level by level over the tape's
+    DAG (kernels_wide.hip); MPR_WIDE_STAGE0=0 selects the one-lane-per-tile walk for that stage
+    too.  Both must give the oracle's tiles, images and shortened tapes (the default path is what
+    every other test in this file exercises)."""
+    monkeypatch.setenv("MPR_WIDE_STAGE0", "0")
+    compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
