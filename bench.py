@@ -174,7 +174,7 @@ def main():
                     traffic = json.load(f).get("eval_voxels_f", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_eval_voxels<3>", "bound": "hbm", "achieved": round(achieved, 2),
+        roofline = {"kernel": "k_eval_voxels_asm<3>", "bound": "hbm", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "algorithmic_bytes": int(b_alg), "kernel_ms": round(vox_ms, 4),
                     "kernel_ms_all": {k: round(v, 4) for k, v in avg.items()},

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -185,7 +186,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
     CT(hipMalloc((void**)&c->num_active, sizeof(int)));
-    CT(hipMalloc((void**)&c->counters, mprk::CNT_COUNT * sizeof(unsigned long long)));
+    CT(hipMalloc((void**)&c->counters, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long)));
     CT(hipMalloc((void**)&c->owner_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipMalloc((void**)&c->col_list_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -284,7 +285,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
     }
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->tape_index, len, 1, c->stream));
     if (c->flags & MPR_CTX_COUNTERS)
-        HIP_TRY(hipMemsetAsync(c->counters, 0, mprk::CNT_COUNT * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(c->counters, 0, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long), c->stream));
     if (owner) {
         const size_t cols = (size_t)(c->S / 64) * (c->S / 64);
         HIP_TRY(hipMemcpyAsync(c->owner_dev, owner, cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -405,8 +406,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
             a.debug = getenv("MPR_DEBUG_TILES") ? atoi(getenv("MPR_DEBUG_TILES")) : 0;
+            if (a.debug & 4) a.debug |= si << 4;
             TimedScope ts(c, "eval_tiles_i");
-            if (si == 0 && c->wide_stage0 && c->sched_ok && !grouped && !a.debug) {
+            if (si == 0 && c->wide_stage0 && c->sched_ok && !grouped && !(a.debug & 3)) {
                 /* first stage: few tiles, all on the root tape -> one workgroup per tile, level by level */
                 mprk::WideStageArgs w;
                 w.t = a;
@@ -644,6 +646,16 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
         c->last.clauses_fwd_normals = (int64_t)h[mprk::CNT_FWD_NORM];
         c->last.normal_pixels = (int64_t)h[mprk::CNT_NORMAL_PX];
         c->last.pool_overflowed = h[mprk::CNT_OVERFLOW] ? 1 : 0;
+        if (getenv("MPR_DEBUG_TILES") && (atoi(getenv("MPR_DEBUG_TILES")) & 4)) {
+            /* development: per-stage cycle breakdown of k_eval_tiles (sum over wavefronts) */
+            unsigned long long ph[32];
+            HIP_TRY(hipMemcpy(ph, c->counters + mprk::CNT_COUNT, sizeof(ph), hipMemcpyDeviceToHost));
+            for (int st = 0; st < 3; ++st)
+                fprintf(stderr, "stage %d: waves %llu  cycles/wave: prologue %.0f forward %.0f classify+claim %.0f backward %.0f head %.0f\n", st,
+                        ph[st * 6 + 5], ph[st * 6 + 0] / (double)std::max(1ull, ph[st * 6 + 5]), ph[st * 6 + 1] / (double)std::max(1ull, ph[st * 6 + 5]),
+                        ph[st * 6 + 2] / (double)std::max(1ull, ph[st * 6 + 5]), ph[st * 6 + 3] / (double)std::max(1ull, ph[st * 6 + 5]),
+                        ph[st * 6 + 4] / (double)std::max(1ull, ph[st * 6 + 5]));
+        }
     }
     if ((long long)ti >= c->pool_cap) c->last.pool_overflowed = 1;
     *out = c->last;

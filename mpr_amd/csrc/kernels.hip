@@ -159,6 +159,10 @@ k_eval_tiles(TileStageArgs a)
         vz = iv(a.z, a.z);
     }
 
+    const bool prof = (a.debug & 4) && a.counters;      /* development: cycle breakdown per phase */
+    unsigned long long* const pc = a.counters + CNT_COUNT + ((a.debug >> 4) & 3) * 6;
+    long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define MPR_PHASE(k) do { if (prof) { const long long tn = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&pc[k], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     const uint64_t head0 = tro[0];
     slots[((head0 >> 8) & 0xFF) * 64 + lane] = make_float2(vx.lo, vx.hi);
     slots[((head0 >> 16) & 0xFF) * 64 + lane] = make_float2(vy.lo, vy.hi);
@@ -166,6 +170,7 @@ k_eval_tiles(TileStageArgs a)
 
     /* ---- forward walk: 64 clauses per coalesced 512-byte load (lane j holds clause j), handed
      *      out with v_readlane ---- */
+    MPR_PHASE(0);
     int base = tape + 1;
     uint64_t blk = tro[base + lane];
     int j = 0;
@@ -230,6 +235,7 @@ k_eval_tiles(TileStageArgs a)
             any_choice |= m1 | m2;
         }
     }
+    MPR_PHASE(1);
     const uint64_t end_clause = d;
     const uint32_t i_out = (uint32_t)(end_clause >> 8) & 0xFF;
     const float2 res = slots[i_out * 64 + lane];
@@ -316,6 +322,7 @@ k_eval_tiles(TileStageArgs a)
         }
         lm_set(lm, i_out, live);
 
+        MPR_PHASE(2);
         /* backward walk, again 64 words per load: lane jj holds word bbase + jj */
         int cur = base + j - 1;               /* pool index of the next word to visit */
         int bbase = cur - 63;
@@ -408,6 +415,7 @@ k_eval_tiles(TileStageArgs a)
                 }
             }
         }
+        MPR_PHASE(3);
         if (writing) {
             out_offset--;
             twr[out_index + out_offset] = d;         /* head: copy of the parent's head */
@@ -416,6 +424,8 @@ k_eval_tiles(TileStageArgs a)
         }
     }
 
+    MPR_PHASE(4);
+    if (prof && lane == 0) atomicAdd(&pc[5], 1ull);
     if (a.counters) {
         if (lane == 0) {
             atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)fwd_words);
