@@ -185,6 +185,11 @@ int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap
 int mpr_test_interval_op(int32_t device, int32_t op, int32_t n, const float* a_lo,
                          const float* a_hi, const float* b_lo, const float* b_hi, float imm,
                          float* out_lo, float* out_hi, int32_t* out_choice);
+/* the same through the tile stages' assembly forward walk (tile_interp_asm.hpp); variant 0:
+ * operands from the slot file, 1 / 2: lhs / rhs forwarded from the previous clause */
+int mpr_test_interval_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n, const float* a_lo,
+                             const float* a_hi, const float* b_lo, const float* b_hi, float imm,
+                             float* out_lo, float* out_hi, int32_t* out_choice);
 /* float primitive `op` on n operand pairs */
 int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, const float* b,
                       float imm, float* out);

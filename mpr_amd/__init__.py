@@ -152,6 +152,7 @@ def lib():
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
     L.mpr_test_interval_op.argtypes = [i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]
+    L.mpr_test_interval_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]
     L.mpr_test_float_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
@@ -492,15 +493,21 @@ def partition_columns(columns, nranks, weights=None):
 
 
 # ---- device primitive tests (parity fuzzing) ----
-def dev_interval_op(op, a_lo, a_hi, b_lo=None, b_hi=None, imm=0.0, device=0):
+def dev_interval_op(op, a_lo, a_hi, b_lo=None, b_hi=None, imm=0.0, device=0, asm=False, variant=0):
+    """One interval clause on the device: the compiled interval_clause, or (asm=True) the tile
+    stages' assembly forward walk over a short tape (variant 1 / 2: lhs / rhs forwarded)."""
     a_lo = np.ascontiguousarray(a_lo, dtype=np.float32)
     a_hi = np.ascontiguousarray(a_hi, dtype=np.float32)
     b_lo = None if b_lo is None else np.ascontiguousarray(b_lo, dtype=np.float32)
     b_hi = None if b_hi is None else np.ascontiguousarray(b_hi, dtype=np.float32)
     lo, hi = np.empty_like(a_lo), np.empty_like(a_lo)
     ch = np.zeros(a_lo.size, dtype=np.int32)
-    _check(lib().mpr_test_interval_op(device, op, a_lo.size, _ptr(a_lo), _ptr(a_hi), _ptr(b_lo), _ptr(b_hi), imm,
-                                      _ptr(lo), _ptr(hi), _ptr(ch)))
+    if asm:
+        _check(lib().mpr_test_interval_op_asm(device, op, variant, a_lo.size, _ptr(a_lo), _ptr(a_hi), _ptr(b_lo),
+                                              _ptr(b_hi), imm, _ptr(lo), _ptr(hi), _ptr(ch)))
+    else:
+        _check(lib().mpr_test_interval_op(device, op, a_lo.size, _ptr(a_lo), _ptr(a_hi), _ptr(b_lo), _ptr(b_hi), imm,
+                                          _ptr(lo), _ptr(hi), _ptr(ch)))
     return lo, hi, ch
 
 

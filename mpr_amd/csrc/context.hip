@@ -710,6 +710,38 @@ int mpr_test_interval_op(int32_t device, int32_t op, int32_t n, const float* a_l
     if (out_choice) HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
+int mpr_test_interval_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n, const float* a_lo, const float* a_hi,
+                             const float* b_lo, const float* b_hi, float imm, float* out_lo, float* out_hi,
+                             int32_t* out_choice)
+{
+    if (n <= 0 || !a_lo || !a_hi || !out_lo || !out_hi) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)n * 4;
+    DevBuf al, ah, bl, bh, ol, oh, ch, dt;
+    HIP_TRY(al.alloc(bytes)); HIP_TRY(ah.alloc(bytes)); HIP_TRY(bl.alloc(bytes)); HIP_TRY(bh.alloc(bytes));
+    HIP_TRY(ol.alloc(bytes)); HIP_TRY(oh.alloc(bytes)); HIP_TRY(ch.alloc(bytes)); HIP_TRY(dt.alloc(64 * 8));
+    HIP_TRY(hipMemcpy(al.p, a_lo, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ah.p, a_hi, bytes, hipMemcpyHostToDevice));
+    if (b_lo) HIP_TRY(hipMemcpy(bl.p, b_lo, bytes, hipMemcpyHostToDevice));
+    if (b_hi) HIP_TRY(hipMemcpy(bh.p, b_hi, bytes, hipMemcpyHostToDevice));
+    uint32_t immbits;
+    memcpy(&immbits, &imm, 4);
+    /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding) */
+    const bool has_b = b_lo && b_hi;
+    const uint32_t lhs = variant == 1 ? 5 : 1, rhs = has_b ? (variant == 2 ? 5 : 2) : 0;
+    uint64_t tape[64] = {mpr_cl_make(0, 1, 2, 3, 0),
+                         variant == 2 ? mpr_cl_make(MPR_OP_COPY_RHS, 5, 0, 2, 0) : mpr_cl_make(MPR_OP_COPY_LHS, 5, 1, 0, 0),
+                         mpr_cl_make((uint32_t)op, 4, lhs, rhs, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
+    HIP_TRY(hipMemcpy(dt.p, tape, sizeof(tape), hipMemcpyHostToDevice));
+    mprk::launch_test_interval_asm(nullptr, (const uint64_t*)dt.p, n, (float*)al.p, (float*)ah.p, b_lo ? (float*)bl.p : nullptr,
+                                   b_hi ? (float*)bh.p : nullptr, (float*)ol.p, (float*)oh.p, (int*)ch.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
+    if (out_choice) HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
 int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, const float* b, float imm, float* out)
 {
     if (n <= 0 || !a || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");

@@ -29,7 +29,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "kernel_common.hpp"
+#include "tile_interp_asm.hpp"
 
 namespace mprk {
 
@@ -89,12 +92,15 @@ __device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, fl
     return make_float2(o.lo, o.hi);
 }
 
-template <int DIM>
+/* ASM: forward walk by the assembly interpreter (tile_interp_asm.hpp; slot file as lo / hi planes,
+ * nslots <= 128), else the compiled loop below (slot file float2 per lane) */
+template <int DIM, bool ASM>
 __global__ void __launch_bounds__(64)
 k_eval_tiles(TileStageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2* const slots = reinterpret_cast<float2*>(smem);                       /* [nslots][64] */
+    float* const plane = reinterpret_cast<float*>(smem);                         /* ASM: slot s = plane[s * 128 + lane], + 64 */
     ulonglong2* const choices = reinterpret_cast<ulonglong2*>(smem + (size_t)a.nslots * 512);       /* [choice_cap] */
     uint64_t* const act = reinterpret_cast<uint64_t*>(smem + (size_t)a.nslots * 512 + (size_t)a.choice_cap * 16);   /* [128], nslots > 128 only */
 
@@ -164,81 +170,101 @@ k_eval_tiles(TileStageArgs a)
     long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define MPR_PHASE(k) do { if (prof) { const long long tn = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&pc[k], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     const uint64_t head0 = tro[0];
-    slots[((head0 >> 8) & 0xFF) * 64 + lane] = make_float2(vx.lo, vx.hi);
-    slots[((head0 >> 16) & 0xFF) * 64 + lane] = make_float2(vy.lo, vy.hi);
-    slots[((head0 >> 24) & 0xFF) * 64 + lane] = make_float2(vz.lo, vz.hi);
+    if (ASM) {
+        const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
+        plane[sx * 128 + lane] = vx.lo; plane[sx * 128 + 64 + lane] = vx.hi;
+        plane[sy * 128 + lane] = vy.lo; plane[sy * 128 + 64 + lane] = vy.hi;
+        plane[sz * 128 + lane] = vz.lo; plane[sz * 128 + 64 + lane] = vz.hi;
+    } else {
+        slots[((head0 >> 8) & 0xFF) * 64 + lane] = make_float2(vx.lo, vx.hi);
+        slots[((head0 >> 16) & 0xFF) * 64 + lane] = make_float2(vy.lo, vy.hi);
+        slots[((head0 >> 24) & 0xFF) * 64 + lane] = make_float2(vz.lo, vz.hi);
+    }
 
     /* ---- forward walk: 64 clauses per coalesced 512-byte load (lane j holds clause j), handed
      *      out with v_readlane ---- */
     MPR_PHASE(0);
-    int base = tape + 1;
-    uint64_t blk = tro[base + lane];
-    int j = 0;
     int ci = 0;
     uint64_t any_choice = 0;
     int fwd_words = 0, nclauses = 0;
+    int end_index = 0;                 /* pool index of the end clause */
     uint64_t d = 0;
-    for (;;) {
-        if (j == 64) {
-            base += 64;
-            blk = tro[base + lane];
-            j = 0;
-        }
-        d = rdlane64(blk, j);
-        ++fwd_words;
-        const uint32_t op = (uint32_t)d & 0xFF;
-        if (!op) break;
-        if (op == MPR_OP_JUMP) {
-            base = base + j + (int32_t)(d >> 32) + 1;
-            blk = tro[base + lane];
-            j = 0;
-            continue;
-        }
-        ++j;
-        const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
-        const float2 lv = slots[l * 64 + lane];
-        const float2 rv = slots[r * 64 + lane];
-        int c = 0;
-        const float imm = immf(d);
-        const ival A = iv(lv.x, lv.y);
-        const ival B = r ? iv(rv.x, rv.y) : iv(imm, imm);      /* immediate forms carry rhs == 0 */
-        ival out;
-        if (op >= MPR_OP_ADD_LHS_IMM && op <= MPR_OP_SUB_LHS_RHS) {
-            if (op <= MPR_OP_MUL_LHS_RHS) {
-                if (op <= MPR_OP_ADD_LHS_RHS) out = i_add(A, B);
-                else if (op == MPR_OP_MUL_LHS_IMM) out = i_mul_f(A, imm);
-                else out = i_mul(A, B);
-            } else if (op <= MPR_OP_MAX_LHS_RHS) {
-                out = (op <= MPR_OP_MIN_LHS_RHS) ? i_min(A, B, c) : i_max(A, B, c);
-            } else {
-                out = (op == MPR_OP_SUB_IMM_RHS) ? i_sub(iv(imm, imm), B) : i_sub(A, B);
+    if (ASM) {
+        const TileInterpResult ir = tile_interp_asm(tro, (uint32_t)(tape + 1), smem, lane, alive_mask,
+                                                    (uint32_t)a.nslots * 512u, a.choice_cap);
+        ci = ir.nchoices;
+        any_choice = ir.any_choice;
+        fwd_words = ir.words;
+        nclauses = ir.words - 1;
+        end_index = ir.end_index;
+        d = tro[end_index];
+    } else {
+        int base = tape + 1;
+        uint64_t blk = tro[base + lane];
+        int j = 0;
+        for (;;) {
+            if (j == 64) {
+                base += 64;
+                blk = tro[base + lane];
+                j = 0;
             }
-        } else if (op == MPR_OP_SQUARE_LHS) {
-            out = i_square(A);
-        } else if (op == MPR_OP_NEG_LHS) {
-            out = i_neg(A);
-        } else if (op == MPR_OP_ABS_LHS) {
-            out = i_abs(A);
-        } else if (op >= MPR_OP_COPY_IMM) {
-            out = (op == MPR_OP_COPY_LHS) ? A : B;              /* COPY_IMM: rhs == 0, B is the immediate */
-        } else {
-            const float2 o2 = interval_rare(op, lv, rv, imm);
-            out = iv(o2.x, o2.y);
+            d = rdlane64(blk, j);
+            ++fwd_words;
+            const uint32_t op = (uint32_t)d & 0xFF;
+            if (!op) break;
+            if (op == MPR_OP_JUMP) {
+                base = base + j + (int32_t)(d >> 32) + 1;
+                blk = tro[base + lane];
+                j = 0;
+                continue;
+            }
+            ++j;
+            const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+            const float2 lv = slots[l * 64 + lane];
+            const float2 rv = slots[r * 64 + lane];
+            int c = 0;
+            const float imm = immf(d);
+            const ival A = iv(lv.x, lv.y);
+            const ival B = r ? iv(rv.x, rv.y) : iv(imm, imm);      /* immediate forms carry rhs == 0 */
+            ival out;
+            if (op >= MPR_OP_ADD_LHS_IMM && op <= MPR_OP_SUB_LHS_RHS) {
+                if (op <= MPR_OP_MUL_LHS_RHS) {
+                    if (op <= MPR_OP_ADD_LHS_RHS) out = i_add(A, B);
+                    else if (op == MPR_OP_MUL_LHS_IMM) out = i_mul_f(A, imm);
+                    else out = i_mul(A, B);
+                } else if (op <= MPR_OP_MAX_LHS_RHS) {
+                    out = (op <= MPR_OP_MIN_LHS_RHS) ? i_min(A, B, c) : i_max(A, B, c);
+                } else {
+                    out = (op == MPR_OP_SUB_IMM_RHS) ? i_sub(iv(imm, imm), B) : i_sub(A, B);
+                }
+            } else if (op == MPR_OP_SQUARE_LHS) {
+                out = i_square(A);
+            } else if (op == MPR_OP_NEG_LHS) {
+                out = i_neg(A);
+            } else if (op == MPR_OP_ABS_LHS) {
+                out = i_abs(A);
+            } else if (op >= MPR_OP_COPY_IMM) {
+                out = (op == MPR_OP_COPY_LHS) ? A : B;              /* COPY_IMM: rhs == 0, B is the immediate */
+            } else {
+                const float2 o2 = interval_rare(op, lv, rv, imm);
+                out = iv(o2.x, o2.y);
+            }
+            slots[o * 64 + lane] = make_float2(out.lo, out.hi);
+            ++nclauses;
+            if (mpr_op_is_minmax(op)) {
+                const uint64_t m1 = ballot(c == 1) & alive_mask;
+                const uint64_t m2 = ballot(c == 2) & alive_mask;
+                if (ci < a.choice_cap && lane == 0) choices[ci] = make_ulonglong2(m1, m2);
+                ++ci;
+                any_choice |= m1 | m2;
+            }
         }
-        slots[o * 64 + lane] = make_float2(out.lo, out.hi);
-        ++nclauses;
-        if (mpr_op_is_minmax(op)) {
-            const uint64_t m1 = ballot(c == 1) & alive_mask;
-            const uint64_t m2 = ballot(c == 2) & alive_mask;
-            if (ci < a.choice_cap && lane == 0) choices[ci] = make_ulonglong2(m1, m2);
-            ++ci;
-            any_choice |= m1 | m2;
-        }
+        end_index = base + j;
     }
     MPR_PHASE(1);
     const uint64_t end_clause = d;
     const uint32_t i_out = (uint32_t)(end_clause >> 8) & 0xFF;
-    const float2 res = slots[i_out * 64 + lane];
+    const float2 res = ASM ? make_float2(plane[i_out * 128 + lane], plane[i_out * 128 + 64 + lane]) : slots[i_out * 64 + lane];
 
     /* ---- classification (reference :293-321) ---- */
     bool ambiguous = false;
@@ -324,7 +350,7 @@ k_eval_tiles(TileStageArgs a)
 
         MPR_PHASE(2);
         /* backward walk, again 64 words per load: lane jj holds word bbase + jj */
-        int cur = base + j - 1;               /* pool index of the next word to visit */
+        int cur = end_index - 1;              /* pool index of the next word to visit */
         int bbase = cur - 63;
         uint64_t bblk = tro[max(bbase + lane, 0)];
         for (;;) {
@@ -571,6 +597,35 @@ __global__ void k_test_interval(int op, int n, const float* a_lo, const float* a
         if (choice) choice[i] = c;
     }
 }
+/* one clause through the assembly forward walk of the tile stages: tape = {head (slots 1, 2, 3),
+ * [copy], the clause (out = slot 4), end}; 64 operand pairs per wave; slot 3 is unused */
+__global__ void __launch_bounds__(64)
+k_test_interval_asm(const uint64_t* tape, int n, const float* a_lo, const float* a_hi, const float* b_lo,
+                    const float* b_hi, float* out_lo, float* out_hi, int* choice)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* const plane = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    float al = 0, ah = 0, bl = 0, bh = 0, e = 0, f = 0;
+    if (i < n) {
+        al = a_lo[i];
+        ah = a_hi[i];
+        if (b_lo) bl = b_lo[i];
+        if (b_hi) bh = b_hi[i];
+    }
+    round_up_begin(al, ah, bl, bh, e, f);
+    plane[1 * 128 + lane] = al; plane[1 * 128 + 64 + lane] = ah;
+    plane[2 * 128 + lane] = bl; plane[2 * 128 + 64 + lane] = bh;
+    plane[3 * 128 + lane] = 0.0f; plane[3 * 128 + 64 + lane] = 0.0f;
+    const TileInterpResult r = tile_interp_asm(tape, 1u, smem, lane, ~0ull, 8u * 512u, 4);
+    const ulonglong2 m = *reinterpret_cast<const ulonglong2*>(smem + 8 * 512);
+    if (i < n) {
+        out_lo[i] = plane[r.result_slot * 128 + lane];
+        out_hi[i] = plane[r.result_slot * 128 + 64 + lane];
+        if (choice) choice[i] = (r.nchoices > 0) ? (((m.x >> lane) & 1) ? 1 : (((m.y >> lane) & 1) ? 2 : 0)) : 0;
+    }
+}
 __global__ void k_test_float(int op, int n, const float* a, const float* b, float imm, float* out)
 {
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -595,8 +650,10 @@ static void opt_in_once()
     static bool done = false;
     if (done) return;
     done = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
 {
@@ -608,8 +665,17 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     opt_in_once();
     const int groups = (a.count + 63) / 64;
     const size_t lds = tile_stage_lds_bytes(a.nslots, a.choice_cap);
-    if (dim == 3) hipLaunchKernelGGL(k_eval_tiles<3>, dim3(groups), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(k_eval_tiles<2>, dim3(groups), dim3(64), lds, s, a);
+    /* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers */
+    const char* const env = getenv("MPR_TILES_ASM");      /* development: 0 = compiled forward walk */
+    const bool asm_ok = !(env && atoi(env) == 0);
+    const bool use_asm = asm_ok && a.nslots <= 128 && !(a.debug & 3);
+    if (dim == 3) {
+        if (use_asm) hipLaunchKernelGGL((k_eval_tiles<3, true>), dim3(groups), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((k_eval_tiles<3, false>), dim3(groups), dim3(64), lds, s, a);
+    } else {
+        if (use_asm) hipLaunchKernelGGL((k_eval_tiles<2, true>), dim3(groups), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((k_eval_tiles<2, false>), dim3(groups), dim3(64), lds, s, a);
+    }
 }
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out)
@@ -648,6 +714,12 @@ void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const
 {
     hipLaunchKernelGGL(k_test_interval, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a_lo, a_hi, b_lo, b_hi, imm,
                        out_lo, out_hi, choice);
+}
+void launch_test_interval_asm(hipStream_t s, const uint64_t* tape, int n, const float* a_lo, const float* a_hi,
+                              const float* b_lo, const float* b_hi, float* out_lo, float* out_hi, int* choice)
+{
+    hipLaunchKernelGGL(k_test_interval_asm, dim3((n + 63) / 64), dim3(64), 8 * 512 + 4 * 16, s, tape, n, a_lo, a_hi,
+                       b_lo, b_hi, out_lo, out_hi, choice);
 }
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out)
 {

@@ -124,6 +124,8 @@ void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int
                  int ncols, int capacity, int with_normals, int* out);
 void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const int* col_list, int ncols,
                    int capacity, int with_normals, const int* in);
+void launch_test_interval_asm(hipStream_t s, const uint64_t* tape, int n, const float* a_lo, const float* a_hi,
+                              const float* b_lo, const float* b_hi, float* out_lo, float* out_hi, int* choice);
 void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
                           const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice);
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);

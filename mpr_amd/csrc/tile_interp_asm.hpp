@@ -1,0 +1,389 @@
+/*
+ * tile_interp_asm.hpp — forward walk of eval_tiles_i (reference src/context.cu:236-279, the
+ * interval clause loop) as a threaded interpreter in gfx950 assembly, for k_eval_tiles.
+ *
+ * Same construction as the float pass's interpreter (kernels_voxel_asm.hip, read that header
+ * first): 63-clause blocks, clause words rewritten per block to {out slot, handler index, lhs,
+ * rhs}, handler address computed on the scalar unit, three handler tables (operands from LDS /
+ * lhs forwarded / rhs forwarded from the previous clause's result registers).  Differences:
+ *   - a slot holds an interval: lo plane at s * 512 + lane * 4, hi plane 256 bytes further
+ *     (ds_read2st64_b32 / ds_write2st64_b32 move both with one instruction; the slot bytes of the
+ *     rewritten clause word are pre-doubled so that one v_perm_b32 still forms the address:
+ *     nslots <= 128, the reference's own limit);
+ *   - arithmetic is the interval arithmetic of device_math.hpp in round-up mode (lower bounds by
+ *     negation), instruction for instruction what the compiler makes of those functions;
+ *   - min / max record their choice masks (lanes that chose lhs / rhs) in LDS and in the running
+ *     "any choice" mask, exactly like the compiled loop;
+ *   - sqrt, division, exp, log and the trigonometric intervals (double-precision libm inside) leave
+ *     the block, are evaluated by device_math.hpp and re-enter.
+ * The wave must be in round-up mode and have all 64 lanes enabled.
+ */
+#pragma once
+#include "kernel_common.hpp"
+
+namespace mprk {
+
+template <uint32_t OP>
+__device__ __noinline__ float2 rare_interval_op(float2 l, float2 r, float imm)
+{
+    int c = 0;
+    const ival o = interval_clause(OP, iv(l.x, l.y), iv(r.x, r.y), imm, c);
+    return make_float2(o.lo, o.hi);
+}
+/* op is wave-uniform: the switch runs on the scalar unit, each case is one out-of-line routine */
+DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
+{
+    switch (op) {
+        case MPR_OP_SQRT_LHS: return rare_interval_op<MPR_OP_SQRT_LHS>(l, r, imm);
+        case MPR_OP_SIN_LHS: return rare_interval_op<MPR_OP_SIN_LHS>(l, r, imm);
+        case MPR_OP_COS_LHS: return rare_interval_op<MPR_OP_COS_LHS>(l, r, imm);
+        case MPR_OP_ASIN_LHS: return rare_interval_op<MPR_OP_ASIN_LHS>(l, r, imm);
+        case MPR_OP_ACOS_LHS: return rare_interval_op<MPR_OP_ACOS_LHS>(l, r, imm);
+        case MPR_OP_ATAN_LHS: return rare_interval_op<MPR_OP_ATAN_LHS>(l, r, imm);
+        case MPR_OP_EXP_LHS: return rare_interval_op<MPR_OP_EXP_LHS>(l, r, imm);
+        case MPR_OP_LOG_LHS: return rare_interval_op<MPR_OP_LOG_LHS>(l, r, imm);
+        case MPR_OP_DIV_LHS_IMM: return rare_interval_op<MPR_OP_DIV_LHS_IMM>(l, r, imm);
+        case MPR_OP_DIV_IMM_RHS: return rare_interval_op<MPR_OP_DIV_IMM_RHS>(l, r, imm);
+        case MPR_OP_DIV_LHS_RHS: return rare_interval_op<MPR_OP_DIV_LHS_RHS>(l, r, imm);
+        default: return rare_interval_op<MPR_OP_COUNT>(l, r, imm);      /* not an opcode: NaN */
+    }
+}
+
+/* Fixed registers (declared as clobbers):
+ *   s[80:81] handler address   s[82:83] table base   s[84:85] block address   s86 clause word
+ *   s87 immediate   s88 clause counter in block   s89 block base   s96 0xff00
+ *   s[72:73] alive lanes   s74 next choice entry (LDS address)   s75 end of the choice array
+ *   s[76:77] any-choice mask   s78 choice count   s79 words fetched
+ *   s[40:59], s[92:95] scratch masks
+ *   v32 aA  v33 aB  v34 aO   v[36:37] A (lo, hi)   v[38:39] B   v[40:41] result (and previous result)
+ *   v42..v49 temporaries                                                                        */
+#define TI_DISPATCH                                    \
+    "s_add_u32 s88, s88, 1\n"                          \
+    "v_readlane_b32 s86, %[blo], s88\n"                \
+    "s_and_b32 s80, s86, s96\n"                        \
+    "s_add_u32 s80, s80, s82\n"                        \
+    "s_addc_u32 s81, s83, 0\n"                         \
+    "s_setpc_b64 s[80:81]\n"
+#define TI_IMM "v_readlane_b32 s87, %[bhi], s88\n"
+#define TI_AL "v_perm_b32 v32, s86, %[lb], %[selL]\n ds_read2st64_b32 v[36:37], v32 offset1:1\n"
+#define TI_AR "v_perm_b32 v33, s86, %[lb], %[selR]\n ds_read2st64_b32 v[38:39], v33 offset1:1\n"
+#define TI_FL "v_mov_b32 v36, v40\n v_mov_b32 v37, v41\n"      /* lhs = previous result */
+#define TI_FR "v_mov_b32 v38, v40\n v_mov_b32 v39, v41\n"      /* rhs = previous result */
+#define TI_AO "v_perm_b32 v34, s86, %[lb], %[selO]\n"
+#define TI_W "s_waitcnt lgkmcnt(0)\n"
+#define TI_ST "ds_write2st64_b32 v34, v40, v41 offset1:1\n"
+#define TI_H(v, n) ".p2align 8\nL_t" #v "_" #n "_%=:\n"
+#define TI_EXIT TI_IMM "s_branch L_exit_%=\n"
+#define TI_END TI_ST TI_DISPATCH
+#define TI_NEGLO "v_xor_b32 v40, 0x80000000, v40\n"
+
+/* LDL / LDR: bring lhs into v[36:37] / rhs into v[38:39] (load, or copy of the previous result);
+ * WL / WR / WLR: s_waitcnt when lhs / rhs / either was loaded from LDS */
+#define TI_TABLE(v, LDL, LDR, WL, WR, WLR)                                                                  \
+    TI_H(v, 0) "s_add_u32 s79, s79, s88\n s_add_u32 s79, s79, 1\n s_branch L_exit_%=\n"    /* end of tape */ \
+    TI_H(v, 1) TI_IMM                                                  /* JUMP: base += j + imm + 1 */     \
+    "s_add_u32 s79, s79, s88\n s_add_u32 s79, s79, 1\n"                                                     \
+    "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n"     \
+    TI_H(v, 2) LDL TI_AO WL "s_branch L_square_%=\n"                                                        \
+    TI_H(v, 3) TI_EXIT                                                                                      \
+    TI_H(v, 4) LDL TI_AO WL "v_xor_b32 v40, 0x80000000, v37\n v_xor_b32 v41, 0x80000000, v36\n" TI_END     \
+    TI_H(v, 5) TI_EXIT TI_H(v, 6) TI_EXIT TI_H(v, 7) TI_EXIT TI_H(v, 8) TI_EXIT TI_H(v, 9) TI_EXIT        \
+    TI_H(v, 10) TI_EXIT                                                                                     \
+    TI_H(v, 11) LDL TI_AO WL "s_branch L_abs_%=\n"                                                          \
+    TI_H(v, 12) TI_EXIT                                                                                     \
+    TI_H(v, 13) TI_IMM LDL TI_AO WL                                                    /* ADD_LHS_IMM */    \
+    "v_add_f32_e64 v40, -v36, -s87\n v_add_f32 v41, s87, v37\n" TI_NEGLO TI_END                            \
+    TI_H(v, 14) LDL LDR TI_AO WLR                                                      /* ADD_LHS_RHS */    \
+    "v_add_f32_e64 v40, -v36, -v38\n v_add_f32 v41, v37, v39\n" TI_NEGLO TI_END                            \
+    TI_H(v, 15) TI_IMM LDL TI_AO WL                                                    /* MUL_LHS_IMM */    \
+    "v_mov_b32 v42, s87\n v_cmp_gt_f32 vcc, 0, v42\n s_nop 1\n"                                            \
+    "v_cndmask_b32 v43, v36, v37, vcc\n v_cndmask_b32 v44, v37, v36, vcc\n"                                \
+    "v_mul_f32_e64 v40, -v43, v42\n v_mul_f32 v41, v44, v42\n" TI_NEGLO TI_END                             \
+    TI_H(v, 16) LDL LDR TI_AO WLR "s_branch L_mul_%=\n"                                                     \
+    TI_H(v, 17) TI_IMM LDL TI_AO WL "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n s_branch L_min_%=\n"        \
+    TI_H(v, 18) LDL LDR TI_AO WLR "s_branch L_min_%=\n"                                                     \
+    TI_H(v, 19) TI_IMM LDL TI_AO WL "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n s_branch L_max_%=\n"        \
+    TI_H(v, 20) LDL LDR TI_AO WLR "s_branch L_max_%=\n"                                                     \
+    TI_H(v, 21) TI_IMM LDL TI_AO WL                                                    /* lhs - imm */      \
+    "v_sub_f32 v40, s87, v36\n v_subrev_f32 v41, s87, v37\n" TI_NEGLO TI_END                               \
+    TI_H(v, 22) TI_IMM LDR TI_AO WR                                                    /* imm - rhs */      \
+    "v_subrev_f32 v40, s87, v39\n v_sub_f32 v41, s87, v38\n" TI_NEGLO TI_END                               \
+    TI_H(v, 23) LDL LDR TI_AO WLR                                                      /* lhs - rhs */      \
+    "v_sub_f32 v40, v39, v36\n v_sub_f32 v41, v37, v38\n" TI_NEGLO TI_END                                  \
+    TI_H(v, 24) TI_EXIT TI_H(v, 25) TI_EXIT TI_H(v, 26) TI_EXIT                                             \
+    TI_H(v, 27) TI_IMM TI_AO "s_nop 0\n v_mov_b32 v40, s87\n v_mov_b32 v41, s87\n" TI_END                  \
+    TI_H(v, 28) LDL TI_AO WL "v_mov_b32 v40, v36\n v_mov_b32 v41, v37\n" TI_END                            \
+    TI_H(v, 29) LDR TI_AO WR "v_mov_b32 v40, v38\n v_mov_b32 v41, v39\n" TI_END                            \
+    TI_H(v, 30) TI_EXIT                                                                                     \
+    TI_H(v, 31) "s_add_u32 s79, s79, 63\n s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"   /* lane 63: next block */
+
+struct TileInterpResult {
+    uint32_t result_slot;     /* slot named by the end clause */
+    int nchoices;             /* min/max clauses met (= entries of the choice array, capped by the caller) */
+    uint64_t any_choice;      /* lanes that chose a side at least once */
+    int words;                /* clause words fetched, jumps and end included */
+    int end_index;            /* pool index of the end clause */
+};
+
+/* smem: slot planes at LDS offset 0 (see the header); choices: ulonglong2[choice_cap] at LDS byte
+ * offset choice_off */
+DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane,
+                                     uint64_t alive_mask, uint32_t choice_off, int choice_cap)
+{
+    float* const plane = reinterpret_cast<float*>(smem);                  /* slot s: plane[s * 128 + lane], + 64 */
+    uint32_t blo = 0, bhi = 0;
+    uint32_t base = first, sj = 0, dlo = 0, dhi = 0;
+    const uint32_t lb = (uint32_t)(uintptr_t)smem + (uint32_t)lane * 4u;
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t selO = to_vgpr(0x0c0c0400u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
+    const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    const uint32_t alo = (uint32_t)alive_mask, ahi = (uint32_t)(alive_mask >> 32);
+    uint32_t caddr = (uint32_t)(uintptr_t)smem + choice_off;
+    const uint32_t cend = caddr + (uint32_t)choice_cap * 16u;
+    uint32_t ci = 0, words = 0, anylo = 0, anyhi = 0;
+    float plo = 0.0f, phi = 0.0f;
+    uint32_t mode = 0;
+
+    for (;;) {
+        base = rdfirst(base);
+        sj = rdfirst(sj);
+        mode = rdfirst(mode);
+        caddr = rdfirst(caddr);
+        ci = rdfirst(ci);
+        words = rdfirst(words);
+        anylo = rdfirst(anylo);
+        anyhi = rdfirst(anyhi);
+        asm volatile(
+            "s_mov_b32 s89, %[base]\n"
+            "s_mov_b32 s88, %[sj]\n"
+            "s_mov_b32 s96, 0xff00\n"
+            "s_mov_b32 s72, %[alo]\n"
+            "s_mov_b32 s73, %[ahi]\n"
+            "s_mov_b32 s74, %[caddr]\n"
+            "s_mov_b32 s75, %[cend]\n"
+            "s_mov_b32 s76, %[anylo]\n"
+            "s_mov_b32 s77, %[anyhi]\n"
+            "s_mov_b32 s78, %[ci]\n"
+            "s_mov_b32 s79, %[words]\n"
+            "v_mov_b32 v40, %[plo]\n"
+            "v_mov_b32 v41, %[phi]\n"
+            "s_getpc_b64 s[82:83]\n"
+            "L_pc_%=:\n"
+            "s_add_u32 s82, s82, L_t0_0_%=-L_pc_%=\n"
+            "s_addc_u32 s83, s83, 0\n"
+            "s_cmp_eq_u32 %[mode], 0\n"
+            "s_cbranch_scc1 L_load_%=\n"
+            TI_DISPATCH
+            /* ---- fetch 63 clauses at s89, rewrite the clause words ---- */
+            "L_load_%=:\n"
+            "s_mov_b32 s84, s89\n"
+            "s_mov_b32 s85, 0\n"
+            "s_lshl_b64 s[84:85], s[84:85], 3\n"
+            "s_add_u32 s84, s84, %[tlo]\n"
+            "s_addc_u32 s85, s85, %[thi]\n"
+            "global_load_dword %[blo], %[lane8], s[84:85]\n"
+            "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
+            "s_mov_b32 s88, -1\n"
+            "v_mov_b32 v45, 0\n"
+            "v_mov_b32 v47, 32\n"
+            "v_mov_b32 v48, 64\n"
+            "s_waitcnt vmcnt(0)\n"
+            "v_bfe_u32 v44, %[blo], 8, 8\n"                 /* out slot */
+            "v_and_b32 v42, 0xff, %[blo]\n"
+            "v_min_u32 v42, 30, v42\n"                       /* opcode; unknown ones -> handler 30 */
+            "v_mov_b32_dpp v45, v44 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */
+            "v_bfe_u32 v46, %[blo], 16, 8\n"                /* lhs slot */
+            "v_lshrrev_b32 v43, 24, %[blo]\n"               /* rhs slot */
+            "v_cmp_eq_u32 s[92:93], v43, v45\n"
+            "v_cmp_eq_u32 vcc, v46, v45\n"
+            "v_cmp_ne_u32 s[94:95], 0, v45\n"
+            "v_cndmask_b32 v46, 0, v48, s[92:93]\n"          /* rhs forwarded: table 2 */
+            "v_cndmask_b32 v46, v46, v47, vcc\n"             /* lhs forwarded: table 1 */
+            "v_cndmask_b32 v46, 0, v46, s[94:95]\n"
+            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */
+            "v_mov_b32 v43, 31\n"
+            "v_add_u32 v42, v42, v46\n"
+            "v_cndmask_b32 v42, v42, v43, vcc\n"             /* handler index = table * 32 + opcode */
+            /* clause word as the handlers see it: byte 0 = 2 * out slot, byte 1 = handler index,
+             * bytes 2, 3 = 2 * lhs, 2 * rhs (slots < 128) */
+            "v_lshlrev_b32 v44, 1, v44\n"
+            "v_lshl_or_b32 v42, v42, 8, v44\n"
+            "v_and_b32 %[blo], 0xffff0000, %[blo]\n"
+            "v_lshlrev_b32 %[blo], 1, %[blo]\n"
+            "v_or_b32 %[blo], %[blo], v42\n"
+            "s_nop 0\n"
+            TI_DISPATCH
+            /* ---- handlers: three tables of 32 x 256 bytes ---- */
+            TI_TABLE(0, TI_AL, TI_AR, TI_W, TI_W, TI_W)
+            TI_TABLE(1, TI_FL, TI_AR, "", TI_W, TI_W)
+            TI_TABLE(2, TI_AL, TI_FR, TI_W, "", TI_W)
+            /* ---- i_square(v[36:37]) (device_math.hpp) ---- */
+            ".p2align 8\n"
+            "L_square_%=:\n"
+            "v_cmp_lt_f32 s[92:93], v37, -v36\n"             /* big: -lo > hi */
+            "v_mul_f32 v42, v36, v36\n"                      /* a = RU(lo * lo) */
+            "v_mul_f32 v43, v37, v37\n"                      /* b = RU(hi * hi) */
+            "v_mul_f32_e64 v44, -v36, v36\n"                 /* -c, c = RD(lo * lo) */
+            "v_cmp_lt_f32 vcc, 0, v36\n"                     /* pos */
+            "v_cmp_gt_f32 s[94:95], 0, v37\n"                /* neg */
+            "v_cndmask_b32 v45, v43, v42, s[92:93]\n"
+            "v_cndmask_b32 v40, 0, -v44, vcc\n"
+            "v_cndmask_b32 v45, v45, v43, vcc\n"
+            "v_mul_f32_e64 v46, -v37, v37\n"                 /* -d, d = RD(hi * hi) */
+            "v_cndmask_b32 v41, v45, v42, s[94:95]\n"
+            "v_cndmask_b32 v40, v40, -v46, s[94:95]\n"
+            TI_END
+            /* ---- i_abs(v[36:37]) ---- */
+            "L_abs_%=:\n"
+            "v_max_f32 v42, v37, v37\n"
+            "v_max_f32_e64 v43, -v36, -v36\n"
+            "v_max_f32 v43, v43, v42\n"                      /* m = fmax(-lo, hi) */
+            "v_cmp_gt_f32 vcc, 0, v37\n"                     /* neg: hi < 0 */
+            "v_cmp_le_f32 s[92:93], 0, v36\n"                /* nonneg: lo >= 0 */
+            "s_nop 0\n"
+            "v_cndmask_b32 v42, 0, -v37, vcc\n"
+            "v_cndmask_b32 v43, v43, -v36, vcc\n"
+            "v_cndmask_b32 v40, v42, v36, s[92:93]\n"
+            "v_cndmask_b32 v41, v43, v37, s[92:93]\n"
+            TI_END
+            /* ---- i_mul(v[36:37], v[38:39]): sign-case table without branches ---- */
+            "L_mul_%=:\n"
+            "v_cmp_gt_f32 s[40:41], 0, v36\n"                /* xn */
+            "v_cmp_nlt_f32 s[42:43], 0, v37\n"               /* !xp */
+            "v_cmp_ngt_f32 s[46:47], 0, v38\n"               /* !yn */
+            "v_cmp_lt_f32 s[50:51], 0, v39\n"                /* yp */
+            "v_cmp_lt_f32 s[44:45], 0, v37\n"                /* xp */
+            "s_and_b64 s[42:43], s[40:41], s[42:43]\n"       /* xN */
+            "s_and_b64 s[58:59], s[46:47], s[50:51]\n"       /* yP */
+            "s_or_b64 s[46:47], s[46:47], s[50:51]\n"        /* !yN */
+            "v_cmp_ngt_f32 vcc, 0, v36\n"                    /* !xn */
+            "v_cmp_gt_f32 s[48:49], 0, v38\n"                /* yn */
+            "s_and_b64 s[52:53], s[40:41], s[44:45]\n"       /* xM */
+            "s_and_b64 s[46:47], s[46:47], s[42:43]\n"       /* !yN & xN */
+            "s_and_b64 s[54:55], vcc, s[44:45]\n"            /* xP */
+            "s_and_b64 s[56:57], s[48:49], s[50:51]\n"       /* yM */
+            "s_or_b64 vcc, s[58:59], s[46:47]\n"             /* p is x.lo */
+            "s_and_b64 s[46:47], s[52:53], s[58:59]\n"       /* xM & yP */
+            "v_cndmask_b32 v42, v37, v36, vcc\n"             /* p */
+            "s_or_b64 vcc, s[42:43], s[46:47]\n"             /* q is y.hi */
+            "s_and_b64 s[42:43], s[54:55], s[56:57]\n"       /* xP & yM */
+            "v_cndmask_b32 v43, v38, v39, vcc\n"             /* q */
+            "s_or_b64 vcc, s[58:59], s[42:43]\n"             /* r is x.hi */
+            "v_cndmask_b32 v44, v36, v37, vcc\n"             /* r */
+            "s_or_b64 vcc, s[54:55], s[46:47]\n"             /* s is y.hi */
+            "v_cndmask_b32 v45, v38, v39, vcc\n"             /* s */
+            "v_mul_f32_e64 v42, -v42, v43\n"                 /* -lo = RU(-p * q) */
+            "v_mul_f32 v43, v44, v45\n"                      /* hi = RU(r * s) */
+            "v_mul_f32_e64 v44, -v36, v39\n"                 /* -lo2 = RU(-x.lo * y.hi) */
+            "v_mul_f32 v45, v37, v39\n"                      /* hi2 = RU(x.hi * y.hi) */
+            "s_and_b64 vcc, s[52:53], s[56:57]\n"            /* M * M */
+            "v_max_f32 v46, v42, v42\n"
+            "v_max_f32 v44, v44, v44\n"
+            "v_max_f32 v44, v44, v46\n"                      /* -min(lo2, lo) */
+            "v_cndmask_b32 v40, v42, v44, vcc\n"
+            "v_max_f32 v44, v43, v43\n"
+            "v_max_f32 v45, v45, v45\n"
+            "v_max_f32 v45, v44, v45\n"                      /* max(hi, hi2) */
+            "s_or_b64 s[40:41], s[40:41], s[44:45]\n"        /* xn | xp */
+            "s_or_b64 s[42:43], s[48:49], s[50:51]\n"        /* yn | yp */
+            "v_xor_b32 v40, 0x80000000, v40\n"
+            "v_cndmask_b32 v41, v43, v45, vcc\n"
+            "s_and_b64 vcc, s[40:41], s[42:43]\n"            /* neither operand is the zero class */
+            "v_cndmask_b32 v40, 0, v40, vcc\n"
+            "v_cndmask_b32 v41, 0, v41, vcc\n"
+            TI_END
+            /* ---- i_min(v[36:37], v[38:39]) + choice ---- */
+            "L_min_%=:\n"
+            "v_max_f32 v42, v38, v38\n"
+            "v_max_f32 v43, v36, v36\n"
+            "v_max_f32 v44, v39, v39\n"
+            "v_cmp_nlt_f32 vcc, v37, v38\n"                  /* !c1, c1: x.hi < y.lo */
+            "v_cmp_gt_f32 s[92:93], v36, v39\n"              /* y.hi < x.lo */
+            "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
+            "v_min_f32 v42, v43, v42\n"
+            "v_max_f32 v43, v37, v37\n"
+            "v_min_f32 v43, v43, v44\n"
+            "s_branch L_choice_%=\n"
+            /* ---- i_max ---- */
+            "L_max_%=:\n"
+            "v_max_f32 v42, v38, v38\n"
+            "v_max_f32 v43, v36, v36\n"
+            "v_max_f32 v44, v39, v39\n"
+            "v_cmp_ngt_f32 vcc, v36, v39\n"                  /* !c1, c1: x.lo > y.hi */
+            "v_cmp_lt_f32 s[92:93], v37, v38\n"              /* y.lo > x.hi */
+            "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
+            "v_max_f32 v42, v43, v42\n"
+            "v_max_f32 v43, v37, v37\n"
+            "v_max_f32 v43, v43, v44\n"
+            /* result = c1 ? x : c2 ? y : (v42, v43); record {lanes that chose lhs, lanes that chose rhs} */
+            "L_choice_%=:\n"
+            "v_cndmask_b32 v40, v42, v38, s[92:93]\n"
+            "v_cndmask_b32 v41, v43, v39, s[92:93]\n"
+            "v_cndmask_b32 v40, v36, v40, vcc\n"
+            "v_cndmask_b32 v41, v37, v41, vcc\n"
+            "s_andn2_b64 s[94:95], s[72:73], vcc\n"          /* chose lhs */
+            "s_and_b64 s[92:93], s[92:93], s[72:73]\n"       /* chose rhs */
+            "s_or_b64 s[76:77], s[76:77], s[94:95]\n"
+            "s_or_b64 s[76:77], s[76:77], s[92:93]\n"
+            "s_cmp_lt_u32 s74, s75\n"
+            "s_cbranch_scc0 L_nochoice_%=\n"
+            "s_mov_b64 exec, 1\n"
+            "v_mov_b32 v42, s94\n"
+            "v_mov_b32 v43, s95\n"
+            "v_mov_b32 v44, s92\n"
+            "v_mov_b32 v45, s93\n"
+            "v_mov_b32 v46, s74\n"
+            "ds_write_b128 v46, v[42:45]\n"
+            "s_mov_b64 exec, -1\n"
+            "L_nochoice_%=:\n"
+            "s_add_u32 s74, s74, 16\n"
+            "s_add_u32 s78, s78, 1\n"
+            TI_END
+            /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
+            "L_exit_%=:\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_mov_b32 %[dlo], s86\n"
+            "s_mov_b32 %[dhi], s87\n"
+            "s_mov_b32 %[base], s89\n"
+            "s_mov_b32 %[sj], s88\n"
+            "s_mov_b32 %[caddr], s74\n"
+            "s_mov_b32 %[anylo], s76\n"
+            "s_mov_b32 %[anyhi], s77\n"
+            "s_mov_b32 %[ci], s78\n"
+            "s_mov_b32 %[words], s79\n"
+            : [blo] "+v"(blo), [bhi] "+v"(bhi), [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),
+              [caddr] "+s"(caddr), [anylo] "+s"(anylo), [anyhi] "+s"(anyhi), [ci] "+s"(ci), [words] "+s"(words)
+            : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
+              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [plo] "v"(plo), [phi] "v"(phi),
+              [alo] "s"(alo), [ahi] "s"(ahi), [cend] "s"(cend)
+            : "memory", "vcc", "scc",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
+              "s55", "s56", "s57", "s58", "s59",
+              "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
+              "s87", "s88", "s89", "s92", "s93", "s94", "s95", "s96",
+              "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+              "v48", "v49");
+        const uint32_t op = (dlo >> 8) & 31;
+        if (op == 0) break;
+        /* sqrt, division, exp, log, trigonometry (and anything that is not an opcode) */
+        const uint32_t l2 = (dlo >> 16) & 0xFF, r2 = dlo >> 24, o2 = dlo & 0xFF;      /* 2 * slot */
+        const float imm = mpr_u2f(dhi);
+        const float2 A = make_float2(plane[l2 * 64 + lane], plane[l2 * 64 + 64 + lane]);
+        const float2 B = r2 ? make_float2(plane[r2 * 64 + lane], plane[r2 * 64 + 64 + lane]) : make_float2(imm, imm);
+        const float2 R = rare_interval(op, A, B, imm);
+        plane[o2 * 64 + lane] = R.x;
+        plane[o2 * 64 + 64 + lane] = R.y;
+        plo = R.x;
+        phi = R.y;
+        mode = 1;
+    }
+    TileInterpResult r;
+    r.result_slot = (dlo & 0xFF) >> 1;
+    r.nchoices = (int)ci;
+    r.any_choice = ((uint64_t)anyhi << 32) | anylo;
+    r.words = (int)words;
+    r.end_index = (int)(base + sj);
+    return r;
+}
+
+}  // namespace mprk

@@ -49,15 +49,20 @@ INTERVAL_OPS = ["SQUARE_LHS", "SQRT_LHS", "NEG_LHS", "SIN_LHS", "COS_LHS", "ASIN
                 "SUB_LHS_RHS", "DIV_LHS_IMM", "DIV_IMM_RHS", "DIV_LHS_RHS", "COPY_IMM", "COPY_LHS", "COPY_RHS"]
 
 
+@pytest.mark.parametrize("path", ["compiled", "asm", "asm-lhs-forwarded", "asm-rhs-forwarded"])
 @pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
 @pytest.mark.parametrize("opname", INTERVAL_OPS)
-def test_interval_ops_bit_exact(mpr, orc, opname, kind):
+def test_interval_ops_bit_exact(mpr, orc, opname, kind, path):
+    """interval_clause (device_math.hpp) and the tile stages' assembly forward walk
+    (tile_interp_asm.hpp, all three handler tables) against the oracle: bounds and min/max choice."""
     op = mpr.OP[opname]
     rng = np.random.default_rng(zlib.crc32((opname + kind).encode()))
     a_lo, a_hi = gen_intervals(rng, N, kind)
     b_lo, b_hi = gen_intervals(rng, N, kind)
+    kw = {"compiled": {}, "asm": dict(asm=True), "asm-lhs-forwarded": dict(asm=True, variant=1),
+          "asm-rhs-forwarded": dict(asm=True, variant=2)}[path]
     for imm in (0.75, -1.25, 0.0):
-        g_lo, g_hi, g_ch = mpr.dev_interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
+        g_lo, g_hi, g_ch = mpr.dev_interval_op(op, a_lo, a_hi, b_lo, b_hi, imm, **kw)
         o_lo, o_hi, o_ch = orc.interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
         ok = same_bits(g_lo, o_lo) & same_bits(g_hi, o_hi) & (g_ch == o_ch)
         if opname in ("DIV_LHS_IMM", "DIV_IMM_RHS", "DIV_LHS_RHS", "SQRT_LHS"):

@@ -293,3 +293,14 @@ def test_serial_first_stage_matches_oracle(mpr, orc, tapes, name, dim, S, monkey
     every other test in this file exercises)."""
     monkeypatch.setenv("MPR_WIDE_STAGE0", "0")
     compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
+
+
+@pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("trig", 2, 256),
+                                        ("bear", 3, 256), ("architecture", 3, 256)])
+def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):
+    """The tile stages' forward walk runs an assembly interpreter (tile_interp_asm.hpp) when the
+    tape uses at most 128 slots; MPR_TILES_ASM=0 selects the compiled loop, which is also what tapes
+    with more slots get.  Both must give the oracle's frame (the default path is what every other
+    test in this file exercises)."""
+    monkeypatch.setenv("MPR_TILES_ASM", "0")
+    compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
