@@ -349,95 +349,115 @@ k_eval_tiles(TileStageArgs a)
         lm_set(lm, i_out, live);
 
         MPR_PHASE(2);
-        /* backward walk, again 64 words per load: lane jj holds word bbase + jj */
-        int cur = end_index - 1;              /* pool index of the next word to visit */
-        int bbase = cur - 63;
-        uint64_t bblk = tro[max(bbase + lane, 0)];
-        for (;;) {
-            int jj = cur - bbase;
-            if (jj < 0) {
-                bbase = cur - 63;
-                bblk = tro[max(bbase + lane, 0)];
-                jj = 63;
-            }
-            d = rdlane64(bblk, jj);
-            ++bwd_words;
-            const uint32_t op = (uint32_t)d & 0xFF;
-            if (!op) break;
-            if (op == MPR_OP_JUMP) {
-                cur = cur + (int32_t)(d >> 32) - 1;       /* JUMP, then pre-decrement */
-                bbase = cur - 63;
-                bblk = tro[max(bbase + lane, 0)];
-                continue;
-            }
-            --cur;
-            const bool has_choice = mpr_op_is_minmax(op);
-            ci -= has_choice ? 1 : 0;
-            const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
-            uint64_t am = lm_get(lm, o) & live;
-            if (am == 0) continue;
-
-            uint64_t m1 = 0, m2 = 0;
-            if (has_choice && ci < a.choice_cap) {
-                const ulonglong2 ch = choices[ci];
-                m1 = rfl64(ch.x);
-                m2 = rfl64(ch.y);
-            }
-            const bool mine = (am >> lane) & 1;
-            if (mine) --out_offset;
-            const bool need = mine && out_offset == 0;
-            const uint64_t need_mask = ballot(need);
-            if (need_mask) {
-                /* chunk full: continue in the next chunk of the lane's run and write both links
-                 * (reference :384-413) */
-                if (need) {
-                    const int prev_index = out_index;
-                    out_index += MPR_SUBTAPE_CHUNK;
-                    out_offset = MPR_SUBTAPE_CHUNK;
-                    if (out_index >= run_end || (long long)out_index + out_offset >= a.pool_cap) {
-                        overflow = true;
-                        writing = false;
-                    } else {
-                        --out_offset;
-                        const int delta = prev_index - (out_index + out_offset);
-                        twr[out_index + out_offset] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)delta << 32);
-                        twr[prev_index] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)(-delta) << 32);
-                        written += 2;
-                        --out_offset;
-                    }
+        if (ASM) {
+            /* backward walk by the assembly interpreter (tile_interp_asm.hpp) */
+            TilePushState st;
+            st.a0l = lm.lo0; st.a0h = lm.hi0; st.a1l = lm.lo1; st.a1h = lm.hi1;
+            st.out_index = (uint32_t)out_index;
+            st.out_offset = (uint32_t)out_offset;
+            st.overflow = overflow ? 1u : 0u;
+            st.live = live;
+            const long long lim = a.pool_cap - 65;
+            tile_push_asm(tro, end_index - 1, smem, lane, st, (uint32_t)run_end, ci, (uint32_t)a.nslots * 512u, a.choice_cap,
+                          (uint32_t)(lim < 0 ? 0 : (lim > 0x7FFFFF00ll ? 0x7FFFFF00ll : lim)));
+            out_index = (int)st.out_index;
+            out_offset = (int)st.out_offset;
+            overflow = st.overflow != 0;
+            writing = push && !overflow;
+            live = st.live;
+            bwd_words = st.words;
+            d = tro[st.head_index];
+        } else {
+            /* backward walk, again 64 words per load: lane jj holds word bbase + jj */
+            int cur = end_index - 1;              /* pool index of the next word to visit */
+            int bbase = cur - 63;
+            uint64_t bblk = tro[max(bbase + lane, 0)];
+            for (;;) {
+                int jj = cur - bbase;
+                if (jj < 0) {
+                    bbase = cur - 63;
+                    bblk = tro[max(bbase + lane, 0)];
+                    jj = 63;
                 }
-                const uint64_t lost = ballot(need && overflow);
-                live &= ~lost;
-                am &= ~lost;
-            }
+                d = rdlane64(bblk, jj);
+                ++bwd_words;
+                const uint32_t op = (uint32_t)d & 0xFF;
+                if (!op) break;
+                if (op == MPR_OP_JUMP) {
+                    cur = cur + (int32_t)(d >> 32) - 1;       /* JUMP, then pre-decrement */
+                    bbase = cur - 63;
+                    bblk = tro[max(bbase + lane, 0)];
+                    continue;
+                }
+                --cur;
+                const bool has_choice = mpr_op_is_minmax(op);
+                ci -= has_choice ? 1 : 0;
+                const uint32_t o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
+                uint64_t am = lm_get(lm, o) & live;
+                if (am == 0) continue;
 
-            /* scalar bookkeeping of the active sets */
-            const uint64_t a1 = am & m1, a2 = am & m2, a0 = am & ~(m1 | m2);
-            lm_set(lm, o, 0);
-            if (a0) {
-                if (l) lm_set(lm, l, lm_get(lm, l) | a0);
-                if (r) lm_set(lm, r, lm_get(lm, r) | a0);
-            }
-            if (a1) lm_set(lm, l, lm_get(lm, l) | a1);
-            if (a2 && r) lm_set(lm, r, lm_get(lm, r) | a2);
+                uint64_t m1 = 0, m2 = 0;
+                if (has_choice && ci < a.choice_cap) {
+                    const ulonglong2 ch = choices[ci];
+                    m1 = rfl64(ch.x);
+                    m2 = rfl64(ch.y);
+                }
+                const bool mine = (am >> lane) & 1;
+                if (mine) --out_offset;
+                const bool need = mine && out_offset == 0;
+                const uint64_t need_mask = ballot(need);
+                if (need_mask) {
+                    /* chunk full: continue in the next chunk of the lane's run and write both links
+                     * (reference :384-413) */
+                    if (need) {
+                        const int prev_index = out_index;
+                        out_index += MPR_SUBTAPE_CHUNK;
+                        out_offset = MPR_SUBTAPE_CHUNK;
+                        if (out_index >= run_end || (long long)out_index + out_offset >= a.pool_cap) {
+                            overflow = true;
+                            writing = false;
+                        } else {
+                            --out_offset;
+                            const int delta = prev_index - (out_index + out_offset);
+                            twr[out_index + out_offset] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)delta << 32);
+                            twr[prev_index] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)(-delta) << 32);
+                            written += 2;
+                            --out_offset;
+                        }
+                    }
+                    const uint64_t lost = ballot(need && overflow);
+                    live &= ~lost;
+                    am &= ~lost;
+                }
+
+                /* scalar bookkeeping of the active sets */
+                const uint64_t a1 = am & m1, a2 = am & m2, a0 = am & ~(m1 | m2);
+                lm_set(lm, o, 0);
+                if (a0) {
+                    if (l) lm_set(lm, l, lm_get(lm, l) | a0);
+                    if (r) lm_set(lm, r, lm_get(lm, r) | a0);
+                }
+                if (a1) lm_set(lm, l, lm_get(lm, l) | a1);
+                if (a2 && r) lm_set(lm, r, lm_get(lm, r) | a2);
     
-            if (mine && writing) {
-                uint64_t w = d;
-                bool emit = true;
-                if ((a1 >> lane) & 1) {
-                    if (l == o) { ++out_offset; emit = false; }
-                    else w = (d & ~0xFFull) | MPR_OP_COPY_LHS;
-                } else if ((a2 >> lane) & 1) {
-                    if (r) {
-                        if (r == o) { ++out_offset; emit = false; }
-                        else w = (d & ~0xFFull) | MPR_OP_COPY_RHS;
-                    } else {
-                        w = (d & ~0xFFull) | MPR_OP_COPY_IMM;
+                if (mine && writing) {
+                    uint64_t w = d;
+                    bool emit = true;
+                    if ((a1 >> lane) & 1) {
+                        if (l == o) { ++out_offset; emit = false; }
+                        else w = (d & ~0xFFull) | MPR_OP_COPY_LHS;
+                    } else if ((a2 >> lane) & 1) {
+                        if (r) {
+                            if (r == o) { ++out_offset; emit = false; }
+                            else w = (d & ~0xFFull) | MPR_OP_COPY_RHS;
+                        } else {
+                            w = (d & ~0xFFull) | MPR_OP_COPY_IMM;
+                        }
                     }
-                }
-                if (emit) {
-                    twr[out_index + out_offset] = w;
-                    written++;
+                    if (emit) {
+                        twr[out_index + out_offset] = w;
+                        written++;
+                    }
                 }
             }
         }

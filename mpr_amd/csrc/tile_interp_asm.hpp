@@ -386,4 +386,298 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     return r;
 }
 
+
+/* ====================================================================================== */
+/* Backward walk of tape pushing (reference src/context.cu:351-458) in assembly.            */
+/*                                                                                          */
+/* State: the active set is transposed as in the compiled walk — slot s is live for the     */
+/* lanes (tiles) in the 64-bit mask held by lane s & 63 of VGPR pair s >> 6 — and is        */
+/* updated in place with exec = 1 << lane instead of v_readlane / v_writelane round trips.  */
+/* Slot 0 is nobody's output (tape_builder.cpp reserves it), so its entry absorbs the       */
+/* updates of absent operands.  Words are fetched 63 at a time (lane 0 of a block is the    */
+/* "fetch the previous block" handler) and classified per block on the VALU: handler index  */
+/* = kind (plain / min-max / jump / head) x which VGPR pair out, lhs and rhs live in, so a  */
+/* handler is straight-line code.  Per word the scalar unit does the bookkeeping on 64-bit  */
+/* masks; only the offset arithmetic and the 8-byte store of a surviving clause are per     */
+/* lane.  Chunks come from the lane's pre-claimed run (kernels.hip).                         */
+/* ====================================================================================== */
+/* s[80:81] pc  s[82:83] table  s86 classified word  s[70:71] clause  s88 j  s89 block base
+ * s[72:73] live lanes  s74 choice entry address  s75 end of recorded choices  s78 choice count
+ * s79 words  s[76:77] pool  s98 last pool index a chunk may start at
+ * s[60:61] am  s[62:63] a1  s[64:65] a2  s[66:67] a0 / x  s[68:69] x  s[90:95] scratch
+ * v32..v37 temporaries  v38 1  v[40:43] choice entry / jump words v[44:45] v[46:47]            */
+#define TP_DISPATCH                                    \
+    "s_sub_u32 s88, s88, 1\n"                          \
+    "v_readlane_b32 s86, %[bw], s88\n"                 \
+    "s_and_b32 s80, s86, s96\n"                        \
+    "s_add_u32 s80, s80, s82\n"                        \
+    "s_addc_u32 s81, s83, 0\n"                         \
+    "s_setpc_b64 s[80:81]\n"
+#define TP_H(n) ".p2align 8\nL_p" #n "_%=:\n"
+#define TP_H4(n) ".p2align 10\nL_p" #n "_%=:\n"        /* handlers of up to 1 KiB: index multiples of 4 */
+/* am = live lanes whose out slot is active; none: next word */
+#define TP_AM(POL, POH, tag)                                                    \
+    "s_bfe_u32 s92, s86, 0x60000\n"                                            \
+    "v_readlane_b32 s60, " POL ", s92\n"                                       \
+    "v_readlane_b32 s61, " POH ", s92\n"                                       \
+    "s_and_b64 s[60:61], s[60:61], s[72:73]\n"                                 \
+    "s_cbranch_scc1 L_act" tag "_%=\n"                                         \
+    TP_DISPATCH                                                                 \
+    "L_act" tag "_%=:\n"                                                       \
+    "v_readlane_b32 s70, %[blo], s88\n"                                        \
+    "v_readlane_b32 s71, %[bhi], s88\n"
+/* every lane of am takes the next word of its chunk; lanes that fill it move to the next chunk of
+ * their run and write the two links (reference :384-413) or, out of room, stop pushing */
+#define TP_OFFSET(tag)                                                          \
+    "v_add_u32 v32, -1, %[oo]\n"                                               \
+    "v_cndmask_b32 %[oo], %[oo], v32, s[60:61]\n"                              \
+    "v_cmp_eq_u32 s[90:91], 0, %[oo]\n"                                        \
+    "s_and_b64 s[90:91], s[90:91], s[60:61]\n"                                 \
+    "s_cbranch_scc0 L_nosw" tag "_%=\n"                                        \
+    "s_mov_b64 exec, s[90:91]\n"                                               \
+    "v_mov_b32 v33, %[oi]\n"                                                   \
+    "v_add_u32 %[oi], 64, %[oi]\n"                                             \
+    "v_cmp_ge_u32 vcc, %[oi], %[rend]\n"                                       \
+    "v_cmp_gt_u32 s[92:93], %[oi], s98\n"                                      \
+    "s_or_b64 vcc, vcc, s[92:93]\n"                                            \
+    "v_cndmask_b32 %[ovf], %[ovf], v38, vcc\n"                                 \
+    "s_andn2_b64 s[72:73], s[72:73], vcc\n"                                    \
+    "s_andn2_b64 s[60:61], s[60:61], vcc\n"                                    \
+    "s_andn2_b64 exec, exec, vcc\n"                                            \
+    "v_add_lshl_u32 v34, %[oi], 63, 3\n"                                       \
+    "v_lshlrev_b32 v35, 3, v33\n"                                              \
+    "global_store_dwordx2 v34, v[44:45], s[76:77]\n"                           \
+    "global_store_dwordx2 v35, v[46:47], s[76:77]\n"                           \
+    "v_mov_b32 %[oo], 62\n"                                                    \
+    "s_mov_b64 exec, -1\n"                                                     \
+    "L_nosw" tag "_%=:\n"
+/* active[o] = 0; active[l] |= s[XL]; active[r] |= s[XR] */
+#define TP_UPDATE(POL, POH, PLL, PLH, PRL, PRH, XL0, XL1, XR0, XR1)             \
+    "s_lshl_b64 exec, 1, s92\n"                                                \
+    "v_mov_b32 " POL ", 0\n v_mov_b32 " POH ", 0\n"                            \
+    "s_bfe_u32 s93, s86, 0x60010\n"                                            \
+    "s_lshl_b64 exec, 1, s93\n"                                                \
+    "v_or_b32 " PLL ", " XL0 ", " PLL "\n v_or_b32 " PLH ", " XL1 ", " PLH "\n"  \
+    "s_bfe_u32 s93, s86, 0x60018\n"                                            \
+    "s_lshl_b64 exec, 1, s93\n"                                                \
+    "v_or_b32 " PRL ", " XR0 ", " PRL "\n v_or_b32 " PRH ", " XR1 ", " PRH "\n"
+/* a clause that is neither min nor max: live lanes keep it as it is, both operands become live */
+#define TP_PLAIN(n, POL, POH, PLL, PLH, PRL, PRH)                               \
+    TP_H4(n) TP_AM(POL, POH, #n) TP_OFFSET(#n)                                   \
+    "s_bfe_u32 s92, s86, 0x60000\n"                                            \
+    TP_UPDATE(POL, POH, PLL, PLH, PRL, PRH, "s60", "s61", "s60", "s61")        \
+    "s_mov_b64 exec, s[60:61]\n"                                               \
+    "v_add_lshl_u32 v34, %[oi], %[oo], 3\n"                                    \
+    "v_mov_b32 v36, s70\n v_mov_b32 v37, s71\n"                                \
+    "global_store_dwordx2 v34, v[36:37], s[76:77]\n"                           \
+    "s_mov_b64 exec, -1\n"                                                     \
+    TP_DISPATCH
+/* min / max: lanes that chose a side keep only that operand and get a COPY (or nothing, when the
+ * copy would be onto itself); bit 6 / 7 of byte 0: lhs == out / rhs == out, bit 6 of byte 2: no rhs */
+#define TP_MINMAX(n, POL, POH, PLL, PLH, PRL, PRH)                              \
+    TP_H4(n) "s_sub_u32 s78, s78, 1\n s_sub_u32 s74, s74, 16\n"                  \
+    TP_AM(POL, POH, #n)                                                         \
+    "s_mov_b64 s[62:63], 0\n s_mov_b64 s[64:65], 0\n"                          \
+    "s_cmp_lt_u32 s74, s75\n"                                                  \
+    "s_cbranch_scc0 L_noch" #n "_%=\n"                                         \
+    "v_mov_b32 v32, s74\n"                                                     \
+    "ds_read_b128 v[40:43], v32\n"                                             \
+    "s_waitcnt lgkmcnt(0)\n"                                                   \
+    "v_readfirstlane_b32 s62, v40\n v_readfirstlane_b32 s63, v41\n"            \
+    "v_readfirstlane_b32 s64, v42\n v_readfirstlane_b32 s65, v43\n"            \
+    "L_noch" #n "_%=:\n"                                                       \
+    TP_OFFSET(#n)                                                               \
+    "s_or_b64 s[66:67], s[62:63], s[64:65]\n"                                  \
+    "s_andn2_b64 s[66:67], s[60:61], s[66:67]\n"          /* a0 */             \
+    "s_and_b64 s[62:63], s[62:63], s[60:61]\n"            /* a1 */             \
+    "s_and_b64 s[64:65], s[64:65], s[60:61]\n"            /* a2 */             \
+    "s_or_b64 s[68:69], s[66:67], s[62:63]\n"             /* lhs live for a0 | a1 */ \
+    "s_or_b64 s[66:67], s[66:67], s[64:65]\n"             /* rhs live for a0 | a2 */ \
+    "s_bfe_u32 s92, s86, 0x60000\n"                                            \
+    TP_UPDATE(POL, POH, PLL, PLH, PRL, PRH, "s68", "s69", "s66", "s67")        \
+    "s_mov_b64 exec, -1\n"                                                     \
+    "s_andn2_b32 s92, s70, 0xff\n"                                             \
+    "s_or_b32 s93, s92, 28\n"                              /* COPY_LHS */      \
+    "s_bitcmp1_b32 s86, 22\n"                                                  \
+    "s_cselect_b32 s94, 27, 29\n"                          /* COPY_IMM : COPY_RHS */ \
+    "s_or_b32 s94, s92, s94\n"                                                 \
+    "v_mov_b32 v36, s70\n v_mov_b32 v33, s93\n v_mov_b32 v35, s94\n"           \
+    "v_cndmask_b32 v36, v36, v33, s[62:63]\n"                                  \
+    "v_cndmask_b32 v36, v36, v35, s[64:65]\n"                                  \
+    "s_bitcmp1_b32 s86, 6\n"                                                   \
+    "s_cselect_b64 s[90:91], s[62:63], 0\n"                                    \
+    "s_bitcmp1_b32 s86, 7\n"                                                   \
+    "s_cselect_b64 s[92:93], s[64:65], 0\n"                                    \
+    "s_or_b64 s[90:91], s[90:91], s[92:93]\n"             /* lanes whose copy is dropped */ \
+    "v_add_lshl_u32 v34, %[oi], %[oo], 3\n"                                    \
+    "v_add_u32 v32, 1, %[oo]\n"                                                \
+    "v_cndmask_b32 %[oo], %[oo], v32, s[90:91]\n"                              \
+    "s_andn2_b64 exec, s[60:61], s[90:91]\n"                                   \
+    "v_mov_b32 v37, s71\n"                                                     \
+    "global_store_dwordx2 v34, v[36:37], s[76:77]\n"                           \
+    "s_mov_b64 exec, -1\n"                                                     \
+    TP_DISPATCH
+
+struct TilePushState {
+    uint32_t a0l, a0h, a1l, a1h;      /* active set: slots 0..63 in lanes of (a0l, a0h), 64..127 in (a1l, a1h) */
+    uint32_t out_index, out_offset;   /* per lane: current chunk and next free word + 1 */
+    uint32_t overflow;                /* per lane: ran out of chunks */
+    uint64_t live;                    /* lanes still pushing */
+    int head_index;                   /* out: pool index of the head clause the walk ended on */
+    int words;
+};
+
+/* Walks backward from pool index `cur` (the word before the end clause).  `ci` = number of choices
+ * the forward walk met; choices at LDS byte offset choice_off.  pool_limit = last pool index at
+ * which a chunk may start. */
+DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char* smem, int lane, TilePushState& st,
+                       uint32_t run_end, int ci, uint32_t choice_off, int choice_cap, uint32_t pool_limit)
+{
+    uint32_t blo = 0, bhi = 0, bw = 0;
+    uint32_t a0l = st.a0l, a0h = st.a0h, a1l = st.a1l, a1h = st.a1h, oi = st.out_index, oo = st.out_offset, ovf = st.overflow;
+    uint32_t livelo = rdfirst((uint32_t)st.live), livehi = rdfirst((uint32_t)(st.live >> 32));
+    const uint32_t plo = rdfirst((uint32_t)(uintptr_t)pool), phi = rdfirst((uint32_t)((uintptr_t)pool >> 32));
+    const uint32_t cbase = (uint32_t)(uintptr_t)smem + choice_off;
+    uint32_t caddr = rdfirst(cbase + (uint32_t)ci * 16u), uci = rdfirst((uint32_t)ci);
+    const uint32_t cend = rdfirst(cbase + (uint32_t)choice_cap * 16u);
+    uint32_t bbase = rdfirst((uint32_t)(cur - 63)), sj = 0, words = 0;
+    const uint32_t lane1 = (uint32_t)lane;
+    const uint32_t plim = rdfirst(pool_limit);
+    asm volatile(
+        "s_mov_b32 s89, %[bbase]\n"
+        "s_mov_b32 s96, 0xff00\n"
+        "s_mov_b32 s72, %[livelo]\n"
+        "s_mov_b32 s73, %[livehi]\n"
+        "s_mov_b32 s74, %[caddr]\n"
+        "s_mov_b32 s75, %[cend]\n"
+        "s_mov_b32 s76, %[plo]\n"
+        "s_mov_b32 s77, %[phi]\n"
+        "s_mov_b32 s78, %[ci]\n"
+        "s_mov_b32 s79, 0\n"
+        "s_mov_b32 s98, %[plim]\n"
+        "v_mov_b32 v38, 1\n"
+        "v_mov_b32 v44, 1\n"                      /* word 63 of a new chunk: JUMP back to the previous one (-127) */
+        "v_mov_b32 v45, 0xffffff81\n"
+        "v_mov_b32 v46, 1\n"                      /* word 0 of the previous chunk: JUMP forward (+127) */
+        "v_mov_b32 v47, 127\n"
+        "s_getpc_b64 s[82:83]\n"
+        "L_pc_%=:\n"
+        "s_add_u32 s82, s82, L_p0_%=-L_pc_%=\n"
+        "s_addc_u32 s83, s83, 0\n"
+        /* ---- fetch words s89 .. s89 + 63 (lane 0: sentinel), classify ---- */
+        "L_load_%=:\n"
+        "v_add_u32 v32, s89, %[lane]\n"
+        "v_max_i32 v32, 0, v32\n"
+        "v_lshlrev_b32 v32, 3, v32\n"
+        "global_load_dword %[blo], v32, s[76:77]\n"
+        "global_load_dword %[bhi], v32, s[76:77] offset:4\n"
+        "s_mov_b32 s88, 64\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_and_b32 v33, 0xff, %[blo]\n"                 /* op */
+        "v_bfe_u32 v34, %[blo], 8, 8\n"                 /* out */
+        "v_bfe_u32 v35, %[blo], 16, 8\n"                /* lhs */
+        "v_lshrrev_b32 v36, 24, %[blo]\n"               /* rhs */
+        /* variant = 4 * (out >= 64) + 2 * (lhs >= 64) + (rhs >= 64) */
+        "v_lshrrev_b32 v37, 6, v34\n"
+        "v_lshrrev_b32 v32, 6, v35\n"
+        "v_lshl_or_b32 v37, v37, 1, v32\n"
+        "v_lshrrev_b32 v32, 6, v36\n"
+        "v_lshl_or_b32 v37, v37, 1, v32\n"
+        /* handler index (x 256 bytes; a handler may be up to 1 KiB): plain 4 * variant, min / max
+         * (17..20) 32 + 4 * variant, jump 64, head 65, lane 0: 66 */
+        "v_add_u32 v32, -17, v33\n"
+        "v_cmp_gt_u32 vcc, 4, v32\n"
+        "v_lshlrev_b32 v37, 2, v37\n"
+        "v_add_u32 v32, 32, v37\n"
+        "v_cndmask_b32 v37, v37, v32, vcc\n"
+        "v_cmp_eq_u32 vcc, 1, v33\n"
+        "v_mov_b32 v32, 64\n"
+        "s_nop 0\n"
+        "v_cndmask_b32 v37, v37, v32, vcc\n"
+        "v_cmp_eq_u32 vcc, 0, v33\n"
+        "v_mov_b32 v32, 65\n"
+        "s_nop 0\n"
+        "v_cndmask_b32 v37, v37, v32, vcc\n"
+        "v_cmp_eq_u32 vcc, 0, %[lane]\n"
+        "v_mov_b32 v32, 66\n"
+        "s_nop 0\n"
+        "v_cndmask_b32 v37, v37, v32, vcc\n"
+        /* byte 0: out & 63, bit 6 lhs == out, bit 7 rhs != 0 && rhs == out */
+        "v_and_b32 v32, 63, v34\n"
+        "v_cmp_eq_u32 vcc, v35, v34\n"
+        "v_or_b32 v33, 64, v32\n"
+        "s_nop 0\n"
+        "v_cndmask_b32 v32, v32, v33, vcc\n"
+        "v_cmp_eq_u32 vcc, v36, v34\n"
+        "v_cmp_ne_u32 s[92:93], 0, v36\n"
+        "s_and_b64 vcc, vcc, s[92:93]\n"
+        "v_or_b32 v33, 0x80, v32\n"
+        "v_cndmask_b32 v32, v32, v33, vcc\n"
+        "v_lshl_or_b32 v32, v37, 8, v32\n"              /* byte 1: handler index */
+        /* byte 2: lhs & 63, bit 6: no rhs; byte 3: rhs & 63 */
+        "v_and_b32 v35, 63, v35\n"
+        "v_cmp_eq_u32 vcc, 0, v36\n"
+        "v_or_b32 v33, 64, v35\n"
+        "s_nop 0\n"
+        "v_cndmask_b32 v35, v35, v33, vcc\n"
+        "v_lshl_or_b32 v32, v35, 16, v32\n"
+        "v_and_b32 v36, 63, v36\n"
+        "v_lshl_or_b32 %[bw], v36, 24, v32\n"
+        "s_nop 0\n"
+        TP_DISPATCH
+        TP_PLAIN(0, "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]")
+        TP_PLAIN(4, "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]")
+        TP_PLAIN(8, "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]")
+        TP_PLAIN(12, "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]")
+        TP_PLAIN(16, "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]")
+        TP_PLAIN(20, "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]")
+        TP_PLAIN(24, "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]")
+        TP_PLAIN(28, "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]")
+        TP_MINMAX(32, "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]")
+        TP_MINMAX(36, "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]")
+        TP_MINMAX(40, "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]")
+        TP_MINMAX(44, "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]")
+        TP_MINMAX(48, "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]", "%[a0l]", "%[a0h]")
+        TP_MINMAX(52, "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]", "%[a1l]", "%[a1h]")
+        TP_MINMAX(56, "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]", "%[a0l]", "%[a0h]")
+        TP_MINMAX(60, "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]", "%[a1l]", "%[a1h]")
+        TP_H4(64)                                        /* JUMP: cur += imm - 1, then fetch around the new cur */
+        "v_readlane_b32 s71, %[bhi], s88\n"
+        "s_sub_u32 s92, 64, s88\n s_add_u32 s79, s79, s92\n"
+        "s_add_u32 s89, s89, s88\n"
+        "s_add_u32 s89, s89, s71\n"
+        "s_sub_u32 s89, s89, 64\n"                       /* block base = new cur - 63 */
+        "s_branch L_load_%=\n"
+        TP_H(65)                                         /* head clause: done */
+        "s_sub_u32 s92, 64, s88\n s_add_u32 s79, s79, s92\n"
+        "s_branch L_exit_%=\n"
+        TP_H(66)                                         /* lane 0: the previous 63 words */
+        "s_add_u32 s79, s79, 63\n"
+        "s_sub_u32 s89, s89, 63\n"
+        "s_branch L_load_%=\n"
+        "L_exit_%=:\n"
+        "s_mov_b32 %[bbase], s89\n"
+        "s_mov_b32 %[sj], s88\n"
+        "s_mov_b32 %[livelo], s72\n"
+        "s_mov_b32 %[livehi], s73\n"
+        "s_mov_b32 %[words], s79\n"
+        : [blo] "+v"(blo), [bhi] "+v"(bhi), [bw] "+v"(bw), [a0l] "+v"(a0l), [a0h] "+v"(a0h), [a1l] "+v"(a1l), [a1h] "+v"(a1h),
+          [oi] "+v"(oi), [oo] "+v"(oo), [ovf] "+v"(ovf), [bbase] "+s"(bbase), [sj] "=&s"(sj), [livelo] "+s"(livelo),
+          [livehi] "+s"(livehi), [words] "=&s"(words)
+        : [lane] "v"(lane1), [rend] "v"(run_end), [caddr] "s"(caddr), [cend] "s"(cend), [plo] "s"(plo), [phi] "s"(phi),
+          [ci] "s"(uci), [plim] "s"(plim)
+        : "memory", "vcc", "scc",
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
+          "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s86", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
+          "s95", "s96", "s98",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+    st.a0l = a0l; st.a0h = a0h; st.a1l = a1l; st.a1h = a1h;
+    st.out_index = oi;
+    st.out_offset = oo;
+    st.overflow = ovf;
+    st.live = ((uint64_t)livehi << 32) | livelo;
+    st.head_index = (int)(bbase + sj);
+    st.words = (int)words;
+}
+
 }  // namespace mprk
