@@ -1,0 +1,128 @@
+/*
+ * asm_float_bodies.hpp — round-to-nearest float routines shared by the assembly interpreters of
+ * the float pass (kernels_voxel_asm.hip) and of the normals pass (kernels_normals_asm.hip), as
+ * inline-asm text.  Register convention: argument v35 (division: v35 / v36), result v37,
+ * temporaries v38..v42, s91, s[92:95], vcc; s90 must hold 0x260 (class mask of the square root).
+ * Each is, instruction for instruction, what the compiler makes of the C++ definition
+ * (IEEE division and square root expansions; mpr_expf / mpr_logf of include/mpr_fmath.h), so the
+ * results are bit-identical to the compiled interpreters and to the oracle.
+ */
+#pragma once
+
+#define MPR_ASM_DIV_BODY \
+    "v_div_scale_f32 v38, s[92:93], v36, v36, v35\n" \
+    "v_rcp_f32 v39, v38\n" \
+    "v_div_scale_f32 v40, vcc, v35, v36, v35\n" \
+    "v_fma_f32 v41, -v38, v39, 1.0\n" \
+    "v_fmac_f32 v39, v41, v39\n" \
+    "v_mul_f32 v41, v40, v39\n" \
+    "v_fma_f32 v42, -v38, v41, v40\n" \
+    "v_fmac_f32 v41, v42, v39\n" \
+    "v_fma_f32 v38, -v38, v41, v40\n" \
+    "v_div_fmas_f32 v38, v38, v39, v41\n" \
+    "v_div_fixup_f32 v37, v38, v36, v35\n"
+
+#define MPR_ASM_SQRT_BODY \
+    "v_mul_f32 v38, 0x4f800000, v35\n" \
+    "v_cmp_gt_f32 vcc, 0xf800000, v35\n" \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v38, v35, v38, vcc\n" \
+    "v_sqrt_f32 v39, v38\n" \
+    "s_nop 0\n" \
+    "v_add_u32 v40, -1, v39\n" \
+    "v_fma_f32 v41, -v40, v39, v38\n" \
+    "v_cmp_ge_f32 s[92:93], 0, v41\n" \
+    "v_add_u32 v41, 1, v39\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v40, v39, v40, s[92:93]\n" \
+    "v_fma_f32 v39, -v41, v39, v38\n" \
+    "v_cmp_lt_f32 s[92:93], 0, v39\n" \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v39, v40, v41, s[92:93]\n" \
+    "v_mul_f32 v40, 0x37800000, v39\n" \
+    "v_cndmask_b32 v39, v39, v40, vcc\n" \
+    "v_cmp_class_f32 vcc, v38, s90\n" \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v37, v39, v38, vcc\n"
+
+#define MPR_ASM_EXP_BODY \
+    "v_mul_f32 v38, 0x3fb8aa3b, v35\n" \
+    "v_add_f32 v38, 0x4b400000, v38\n" \
+    "v_add_f32 v38, 0xcb400000, v38\n"              /* kf = round(x / ln 2) */ \
+    "v_fmamk_f32 v39, v38, 0xbf318000, v35\n" \
+    "v_fmamk_f32 v39, v38, 0x395e8083, v39\n"       /* r */ \
+    "v_mov_b32 v40, 0x3ab743ce\n" \
+    "v_fmac_f32 v40, 0x39506967, v39\n" \
+    "v_fmaak_f32 v40, v40, v39, 0x3c088908\n" \
+    "v_cvt_i32_f32 v38, v38\n"                      /* k */ \
+    "v_fmaak_f32 v40, v40, v39, 0x3d2aa9c1\n" \
+    "v_fmaak_f32 v40, v40, v39, 0x3e2aaaaa\n" \
+    "v_mul_f32 v41, v39, v39\n" \
+    "v_fma_f32 v40, v40, v39, 0.5\n" \
+    "v_fmac_f32 v39, v40, v41\n" \
+    "v_lshrrev_b32 v41, 31, v38\n" \
+    "v_add_u32 v41, v38, v41\n" \
+    "v_ashrrev_i32 v41, 1, v41\n"                   /* k1 = k / 2 (toward zero) */ \
+    "v_add_f32 v39, 1.0, v39\n" \
+    "v_sub_u32 v38, v38, v41\n"                     /* k2 = k - k1 */ \
+    "v_lshl_add_u32 v41, v41, 23, 1.0\n" \
+    "v_lshl_add_u32 v38, v38, 23, 1.0\n" \
+    "v_mul_f32 v39, v39, v41\n" \
+    "v_mul_f32 v37, v39, v38\n" \
+    "s_mov_b32 s91, 0x42b17218\n" \
+    "v_cmp_ngt_f32 vcc, 0xc2cff5c3, v35\n"          /* !(x < -103.98) */ \
+    "v_cmp_nlt_f32 s[92:93], s91, v35\n"            /* !(x > 88.72284) */ \
+    "v_cmp_o_f32 s[94:95], v35, v35\n" \
+    "v_mov_b32 v40, 0x7f800000\n" \
+    "v_cndmask_b32 v37, 0, v37, vcc\n" \
+    "v_cndmask_b32 v37, v40, v37, s[92:93]\n" \
+    "v_cndmask_b32 v37, v35, v37, s[94:95]\n"
+
+#define MPR_ASM_LOG_BODY \
+    "v_mul_f32 v38, 0x4b000000, v35\n" \
+    "v_cmp_gt_u32 vcc, 0x800000, v35\n"             /* subnormal: scale by 2^23 */ \
+    "v_mov_b32 v40, 0xffffff82\n" \
+    "v_mov_b32 v41, 0xffffff6b\n" \
+    "v_cndmask_b32 v38, v35, v38, vcc\n" \
+    "v_cndmask_b32 v40, v40, v41, vcc\n" \
+    "v_lshrrev_b32 v39, 23, v38\n" \
+    "v_add_u32 v39, v39, v40\n"                     /* e */ \
+    "v_and_b32 v38, 0x7fffff, v38\n" \
+    "v_or_b32 v38, 0x3f000000, v38\n"               /* m in [0.5, 1) */ \
+    "v_cmp_gt_f32 vcc, 0x3f3504f3, v38\n" \
+    "v_bfrev_b32 v41, 1\n" \
+    "s_nop 0\n" \
+    "v_subbrev_co_u32 v39, s[92:93], 0, v39, vcc\n" /* e -= (m < sqrt(1/2)) */ \
+    "v_cndmask_b32 v41, v41, v38, vcc\n" \
+    "v_add_f32 v38, v41, v38\n"                     /* m + m, or m + (-0) */ \
+    "v_add_f32 v38, -1.0, v38\n" \
+    "v_mov_b32 v40, 0xbdebd1b8\n" \
+    "v_fmac_f32 v40, 0x3d9021bb, v38\n" \
+    "v_fmaak_f32 v40, v40, v38, 0x3def251a\n" \
+    "v_fmaak_f32 v40, v40, v38, 0xbdfe5d4f\n" \
+    "v_fmaak_f32 v40, v40, v38, 0x3e11e9bf\n" \
+    "v_fmaak_f32 v40, v40, v38, 0xbe2aae50\n" \
+    "v_fmaak_f32 v40, v40, v38, 0x3e4cceac\n" \
+    "v_fmaak_f32 v40, v40, v38, 0xbe7ffffc\n" \
+    "v_cvt_f32_i32 v39, v39\n"                      /* fe */ \
+    "v_fmaak_f32 v40, v40, v38, 0x3eaaaaaa\n" \
+    "v_mul_f32 v41, v38, v38\n"                     /* z */ \
+    "v_mul_f32 v40, v40, v38\n" \
+    "v_mul_f32 v40, v40, v41\n"                     /* (y * m) * z */ \
+    "v_fmamk_f32 v40, v39, 0xb95e8083, v40\n" \
+    "v_fmac_f32 v40, -0.5, v41\n" \
+    "v_add_f32 v40, v38, v40\n" \
+    "v_fmamk_f32 v37, v39, 0x3f318000, v40\n" \
+    "v_cmp_ne_u32 vcc, 0x7f800000, v35\n"           /* log(+inf) = +inf */ \
+    "v_mov_b32 v40, 0xff800000\n" \
+    "v_mov_b32 v41, 0x7fc00000\n" \
+    "v_cndmask_b32 v37, v35, v37, vcc\n" \
+    "v_cmp_eq_f32 vcc, 0, v35\n"                    /* log(+-0) = -inf */ \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v37, v37, v40, vcc\n" \
+    "v_cmp_gt_f32 vcc, 0, v35\n"                    /* log(x < 0) = NaN */ \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v37, v37, v41, vcc\n" \
+    "v_cmp_u_f32 vcc, v35, v35\n"                   /* NaN in, the same NaN out */ \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v37, v37, v35, vcc\n"

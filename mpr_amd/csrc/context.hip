@@ -58,6 +58,7 @@ struct mpr_context {
     int* col_list_dev = nullptr;
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
 
+    bool normals_asm = true;           /* normals pass interpreter: gfx950 assembly (default) or compiled (MPR_NORMALS_ASM=0) */
     bool voxel_asm = true;             /* float pass interpreter: gfx950 assembly (default) or the compiled C++ one */
     int voxel_k = 0;                   /* float pass: 0 = one wave per smallest tile walking its own sub-tape (default);
                                           1, 2, 4 = children per batch of the grouped form (MPR_VOXEL_K, experimental) */
@@ -159,6 +160,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->S = S;
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_K")) {
         const int k = atoi(e);
@@ -488,7 +490,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.microtiles = c->tiles[2];
         n.counters = cnt;
         TimedScope ts(c, "eval_pixels_d");
-        mprk::launch_eval_normals(s, n);
+        if (c->normals_asm && !cnt) mprk::launch_eval_normals_asm(s, n);
+        else mprk::launch_eval_normals(s, n);
     }
     HIP_TRY(hipGetLastError());
     c->frame_pending = true;
@@ -740,6 +743,21 @@ int mpr_test_interval_op_asm(int32_t device, int32_t op, int32_t variant, int32_
     HIP_TRY(hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
     if (out_choice) HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+/* development aid (scripts/interp_cycles.py): cycles per forward walk of `clauses` (head, body, end) */
+extern "C" int mpr_debug_interp_cycles(int32_t device, const uint64_t* clauses, int32_t length, int32_t reps, int32_t waves, long long* out)
+{
+    HIP_TRY(hipSetDevice(device));
+    DevBuf dt, dout;
+    HIP_TRY(dt.alloc((size_t)(length + 128) * 8));
+    HIP_TRY(dout.alloc((size_t)reps * 8));
+    HIP_TRY(hipMemset(dt.p, 0, (size_t)(length + 128) * 8));
+    HIP_TRY(hipMemcpy(dt.p, clauses, (size_t)length * 8, hipMemcpyHostToDevice));
+    mprk::launch_debug_interp_cycles(nullptr, (const uint64_t*)dt.p, reps, (long long*)dout.p, waves);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)reps * 8, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
 int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, const float* b, float imm, float* out)

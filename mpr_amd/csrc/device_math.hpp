@@ -167,28 +167,30 @@ DEV ival i_mul_f(ival x, float y)                                               
     if (y < 0.0f) return iv(rd_mul(x.hi, y), ru_mul(x.lo, y));
     return iv(rd_mul(x.lo, y), ru_mul(x.hi, y));
 }
+/* The six sign cases of inc/gpu_interval.hpp:162-190 pick the operands of the two directed
+ * quotients; picking them with selects (same conditions, same nesting) keeps the 64 tiles of a
+ * wave on one path instead of up to six:
+ *        x.hi < 0          x.lo < 0 (else)      otherwise
+ *   lo:  (yn?x.hi:x.lo)/y.lo   (yn?x.hi:x.lo)/(yn?y.hi:y.lo)   (yn?x.hi:x.lo)/y.hi        yn: y.hi < 0
+ *   hi:  (yn?x.lo:x.hi)/y.hi   (yn?x.lo:x.hi)/(yn?y.hi:y.lo)   (yn?x.lo:x.hi)/y.lo                  */
 DEV ival i_div(ival x, ival y)                                                           /* :162-190 */
 {
     const float inf = mpr_u2f(0x7F800000u);
-    if (y.lo <= 0.0f && y.hi >= 0.0f) {
-        return iv(-inf, inf);
-    } else if (x.hi < 0.0f) {
-        if (y.hi < 0.0f) return div_dir(x.hi, y.lo, x.lo, y.hi);
-        else return div_dir(x.lo, y.lo, x.hi, y.hi);
-    } else if (x.lo < 0.0f) {
-        if (y.hi < 0.0f) return div_dir(x.hi, y.hi, x.lo, y.hi);
-        else return div_dir(x.lo, y.lo, x.hi, y.lo);
-    } else {
-        if (y.hi < 0.0f) return div_dir(x.hi, y.hi, x.lo, y.lo);
-        else return div_dir(x.lo, y.hi, x.hi, y.lo);
-    }
+    const bool yz = y.lo <= 0.0f && y.hi >= 0.0f;
+    const bool xn = x.hi < 0.0f, xm = !xn && x.lo < 0.0f, yn = y.hi < 0.0f;
+    const float a1 = yn ? x.hi : x.lo, a2 = yn ? x.lo : x.hi;
+    const float ym = yn ? y.hi : y.lo;
+    const float b1 = xn ? y.lo : (xm ? ym : y.hi);
+    const float b2 = xn ? y.hi : (xm ? ym : y.lo);
+    const ival r = div_dir(a1, b1, a2, b2);
+    return iv(yz ? -inf : r.lo, yz ? inf : r.hi);
 }
 DEV ival i_div_f(ival x, float y)                                                        /* :192-200 */
 {
     const float inf = mpr_u2f(0x7F800000u);
-    if (y < 0.0f) return div_dir(x.hi, y, x.lo, y);
-    else if (y > 0.0f) return div_dir(x.lo, y, x.hi, y);
-    else return iv(-inf, inf);
+    const bool neg = y < 0.0f, pos = y > 0.0f;
+    const ival r = div_dir(neg ? x.hi : x.lo, y, neg ? x.lo : x.hi, y);
+    return iv((neg || pos) ? r.lo : -inf, (neg || pos) ? r.hi : inf);
 }
 DEV ival i_fdiv(float x, ival y) { return i_div(iv(x, x), y); }                          /* :202-204 */
 DEV ival i_min(ival x, ival y, int& choice)                                              /* :208-216 */
@@ -228,9 +230,10 @@ DEV ival i_fsub(float x, ival y) { return iv(rd_sub(x, y.hi), ru_sub(x, y.lo)); 
 DEV ival i_sqrt(ival x)                                                                  /* :296-304 */
 {
     const float nan = mpr_u2f(0x7FC00000u);
-    if (x.hi < 0.0f) return iv(nan, nan);
-    else if (x.lo <= 0.0f) return iv(0.0f, sqrt_dir(0.0f, x.hi).hi);
-    else return sqrt_dir(x.lo, x.hi);
+    /* x.hi < 0: NaN; x.lo <= 0: [0, RU(sqrt(x.hi))] (RD(sqrt(+0)) is +0); else both bounds */
+    const ival r = sqrt_dir((x.lo <= 0.0f) ? 0.0f : x.lo, x.hi);
+    const bool bad = x.hi < 0.0f;
+    return iv(bad ? nan : r.lo, bad ? nan : r.hi);
 }
 DEV ival i_acos(ival x)                                                                  /* :306-314 */
 {

@@ -646,6 +646,27 @@ k_test_interval_asm(const uint64_t* tape, int n, const float* a_lo, const float*
         if (choice) choice[i] = (r.nchoices > 0) ? (((m.x >> lane) & 1) ? 1 : (((m.y >> lane) & 1) ? 2 : 0)) : 0;
     }
 }
+/* development: cycles one wavefront needs to walk a tape forward with the assembly interpreter
+ * (interval intervals all [0.25, 0.5]); out[r] = cycles of repetition r */
+__global__ void __launch_bounds__(64)
+k_debug_interp_cycles(const uint64_t* tape, int reps, long long* out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* const plane = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x;
+    float al = 0.25f, ah = 0.5f, bl = 0.25f, bh = 0.5f, e = 0, f = 0;
+    round_up_begin(al, ah, bl, bh, e, f);
+    for (int s = 0; s < 8; ++s) {
+        plane[s * 128 + lane] = al;
+        plane[s * 128 + 64 + lane] = ah;
+    }
+    for (int r = 0; r < reps; ++r) {
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        const TileInterpResult ir = tile_interp_asm(tape, 1u, smem, lane, ~0ull, 8u * 512u, 64);
+        const long long t1 = (long long)__builtin_readcyclecounter();
+        if (lane == 0) out[r] = (t1 - t0) + (ir.words & 0);
+    }
+}
 __global__ void k_test_float(int op, int n, const float* a, const float* b, float imm, float* out)
 {
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -740,6 +761,10 @@ void launch_test_interval_asm(hipStream_t s, const uint64_t* tape, int n, const 
 {
     hipLaunchKernelGGL(k_test_interval_asm, dim3((n + 63) / 64), dim3(64), 8 * 512 + 4 * 16, s, tape, n, a_lo, a_hi,
                        b_lo, b_hi, out_lo, out_hi, choice);
+}
+void launch_debug_interp_cycles(hipStream_t s, const uint64_t* tape, int reps, long long* out, int waves)
+{
+    hipLaunchKernelGGL(k_debug_interp_cycles, dim3(waves), dim3(64), 8 * 512 + 64 * 16, s, tape, reps, out);
 }
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out)
 {

@@ -115,17 +115,20 @@ size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
 /* same pass, interpreter in gfx950 assembly (kernels_voxel_asm.hip); no counters */
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
+
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
 size_t grouped_voxel_lds_bytes(int nslots, int k);
 void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a);   /* k = 1, 2 or 4 children per batch */
 size_t normals_lds_bytes(int nslots);
 void launch_eval_normals(hipStream_t s, const NormalArgs& a);
+void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a);   /* kernels_normals_asm.hip; no counters */
 void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
                  int ncols, int capacity, int with_normals, int* out);
 void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const int* col_list, int ncols,
                    int capacity, int with_normals, const int* in);
 void launch_test_interval_asm(hipStream_t s, const uint64_t* tape, int n, const float* a_lo, const float* a_hi,
                               const float* b_lo, const float* b_hi, float* out_lo, float* out_hi, int* choice);
+void launch_debug_interp_cycles(hipStream_t s, const uint64_t* tape, int reps, long long* out, int waves);
 void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
                           const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice);
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);

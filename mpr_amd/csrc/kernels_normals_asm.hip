@@ -1,0 +1,329 @@
+/*
+ * kernels_normals_asm.hip — the normals pass (reference src/context.cu:978-1132, eval_pixels_d)
+ * with the tape interpreter in gfx950 assembly.
+ *
+ * Layout as in k_eval_normals_q (kernels_float.hip): a wavefront is a 4x4 pixel footprint, lane =
+ * pixel * 4 + component of the forward-mode derivative (dx, dy, dz, value), slot file float per
+ * lane in LDS; the value of an operand reaches the three partials of its quad through DPP
+ * quad_perm:[3,3,3,3], folded into the consuming instruction where the ISA allows it.  The
+ * interpreter itself is the float pass's (kernels_voxel_asm.hip — read that header first):
+ * 63-clause blocks rewritten per block to {out, handler index, lhs, rhs}, handler address on the
+ * scalar unit, three handler tables with operand forwarding.  Every operation evaluates exactly
+ * the expression of the compiled kernel (inc/gpu_deriv.hpp order of operations, no contraction),
+ * with division, square root, exp and log in line through the shared routines of
+ * asm_float_bodies.hpp; the inverse trigonometric functions and sin / cos leave the block.
+ * One wave per workgroup (LDS base 0 for the v_perm_b32 address trick).
+ */
+#include "asm_float_bodies.hpp"
+#include "kernel_common.hpp"
+
+namespace mprk {
+
+DEV float quad_bcast_a(float x, int which)
+{
+    const int v = (int)mpr_f2u(x);
+    int r;
+    switch (which) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, true); break;
+        case 1: r = __builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, true); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, true); break;
+        default: r = __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, true); break;
+    }
+    return mpr_u2f((uint32_t)r);
+}
+__device__ __noinline__ float deriv_trig_q(uint32_t op, float a, float av, bool isv)
+{
+    switch (op) {
+        case MPR_OP_SIN_LHS: { const float c = mpr_cosf(av); return isv ? mpr_sinf(av) : c * a; }
+        case MPR_OP_COS_LHS: { const float s = -mpr_sinf(av); return isv ? mpr_cosf(av) : s * a; }
+        case MPR_OP_ASIN_LHS: { const float d = __builtin_sqrtf(1 - av * av); return isv ? mpr_asinf(av) : a / d; }
+        case MPR_OP_ACOS_LHS: { const float d = -__builtin_sqrtf(1 - av * av); return isv ? mpr_acosf(av) : a / d; }
+        case MPR_OP_ATAN_LHS: { const float d = av * av + 1; return isv ? mpr_atanf(av) : a / d; }
+        default: return mpr_u2f(0x7FC00000u);
+    }
+}
+
+/* Fixed registers (clobbers):
+ *   s[80:81] handler address  s[82:83] table base  s[84:85] block address  s86 clause word  s87 immediate
+ *   s88 clause counter  s89 block base  s90 0x260  s96 0xff00  s[98:99] lanes holding the value (comp 3)
+ *   s[70:71] return address of the shared routines, s[72:79] their entry points (div, sqrt, exp, log)
+ *   v32 aA  v33 aB  v34 aO  v35 A  v36 B  v37 result (and previous result)  v38..v47 temporaries      */
+#define NQ_Q3 " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n"
+#define NQ_DISPATCH                                    \
+    "s_add_u32 s88, s88, 1\n"                          \
+    "v_readlane_b32 s86, %[blo], s88\n"                \
+    "s_and_b32 s80, s86, s96\n"                        \
+    "s_add_u32 s80, s80, s82\n"                        \
+    "s_addc_u32 s81, s83, 0\n"                         \
+    "s_setpc_b64 s[80:81]\n"
+#define NQ_IMM "v_readlane_b32 s87, %[bhi], s88\n"
+#define NQ_AL "v_perm_b32 v32, s86, %[lb], %[selL]\n ds_read_b32 v35, v32\n"
+#define NQ_AR "v_perm_b32 v33, s86, %[lb], %[selR]\n ds_read_b32 v36, v33\n"
+#define NQ_FL "v_mov_b32 v35, v37\n"                   /* lhs = previous result */
+#define NQ_FR "v_mov_b32 v36, v37\n"
+#define NQ_AO "v_perm_b32 v34, s86, %[lb], %[selO]\n"
+#define NQ_W "s_waitcnt lgkmcnt(0)\n"
+#define NQ_END "ds_write_b32 v34, v37\n" NQ_DISPATCH
+#define NQ_H(v, n) ".p2align 8\nL_n" #v "_" #n "_%=:\n"
+#define NQ_EXIT NQ_IMM "s_branch L_exit_%=\n"
+#define NQ_CALL(pair) "s_swappc_b64 s[70:71], " pair "\n"
+#define NQ_DIV NQ_CALL("s[72:73]")
+#define NQ_SQRT NQ_CALL("s[74:75]")
+#define NQ_EXP NQ_CALL("s[76:77]")
+#define NQ_LOG NQ_CALL("s[78:79]")
+
+/* Handlers read lhs from v35 and rhs from v36 (LDL / LDR bring them there: LDS load, or a copy of
+ * the previous result) and leave the result in v37.  a = lhs, b = rhs as Derivs, av / bv their
+ * values broadcast over the quad; isv = lanes of component 3. */
+#define NQ_TABLE(v, LDL, LDR, WL, WR, WLR)                                                                   \
+    NQ_H(v, 0) "s_branch L_exit_%=\n"                                                     /* end of tape */  \
+    NQ_H(v, 1) NQ_IMM "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n" \
+    NQ_H(v, 2) LDL NQ_AO WL                                  /* SQUARE: isv ? a*a : a*av + a*av */           \
+    "v_mul_f32_dpp v38, v35, v35" NQ_Q3 "v_mul_f32 v39, v35, v35\n v_add_f32 v38, v38, v38\n"               \
+    "v_cndmask_b32 v37, v38, v39, s[98:99]\n" NQ_END                                                         \
+    NQ_H(v, 3) LDL NQ_AO WL                                  /* SQRT: s = sqrt(av); isv ? s : a / (2 s) */   \
+    "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_SQRT                                              \
+    "v_mov_b32 v44, v37\n v_mul_f32 v36, 2.0, v37\n v_mov_b32 v35, v43\n" NQ_DIV                             \
+    "v_cndmask_b32 v37, v37, v44, s[98:99]\n" NQ_END                                                         \
+    NQ_H(v, 4) LDL NQ_AO WL "v_xor_b32 v37, 0x80000000, v35\n" NQ_END                                        \
+    NQ_H(v, 5) NQ_EXIT NQ_H(v, 6) NQ_EXIT NQ_H(v, 7) NQ_EXIT NQ_H(v, 8) NQ_EXIT NQ_H(v, 9) NQ_EXIT          \
+    NQ_H(v, 10) LDL NQ_AO WL                                 /* EXP: e = exp(av); isv ? e : e * a */         \
+    "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_EXP                                               \
+    "v_mul_f32 v38, v37, v43\n v_cndmask_b32 v37, v38, v37, s[98:99]\n" NQ_END                               \
+    NQ_H(v, 11) LDL NQ_AO WL                                 /* ABS: av < 0 ? -a : a */                      \
+    "v_mov_b32 v39, 0\n v_xor_b32 v38, 0x80000000, v35\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"               \
+    "s_nop 1\n v_cndmask_b32 v37, v35, v38, vcc\n" NQ_END                                                    \
+    NQ_H(v, 12) LDL NQ_AO WL                                 /* LOG: isv ? log(av) : a / av */               \
+    "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 "s_nop 0\n v_mov_b32 v45, v35\n" NQ_LOG              \
+    "v_mov_b32 v44, v37\n v_mov_b32 v35, v43\n v_mov_b32 v36, v45\n" NQ_DIV                                  \
+    "v_cndmask_b32 v37, v37, v44, s[98:99]\n" NQ_END                                                         \
+    NQ_H(v, 13) NQ_IMM LDL NQ_AO WL                          /* a + imm: only the value */                   \
+    "s_nop 0\n v_add_f32 v38, s87, v35\n v_cndmask_b32 v37, v35, v38, s[98:99]\n" NQ_END                     \
+    NQ_H(v, 14) LDL LDR NQ_AO WLR "v_add_f32 v37, v35, v36\n" NQ_END                                         \
+    NQ_H(v, 15) NQ_IMM LDL NQ_AO WL "s_nop 0\n v_mul_f32 v37, s87, v35\n" NQ_END                             \
+    NQ_H(v, 16) LDL LDR NQ_AO WLR                            /* MUL: isv ? a*b : a*bv + b*av */              \
+    "v_mul_f32_dpp v38, v36, v35" NQ_Q3 "v_mul_f32_dpp v39, v35, v36" NQ_Q3                                  \
+    "v_mul_f32 v40, v35, v36\n v_add_f32 v38, v38, v39\n v_cndmask_b32 v37, v38, v40, s[98:99]\n" NQ_END     \
+    NQ_H(v, 17) NQ_IMM LDL NQ_AO WL                          /* MIN_IMM: b = (0, 0, 0, imm); av < imm ? a : b */ \
+    "v_mov_b32 v39, s87\n v_cndmask_b32 v36, 0, v39, s[98:99]\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"        \
+    "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
+    NQ_H(v, 18) LDL LDR NQ_AO WLR                            /* MIN: av < bv ? a : b */                      \
+    "v_mov_b32_dpp v39, v36" NQ_Q3 "s_nop 1\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"                          \
+    "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
+    NQ_H(v, 19) NQ_IMM LDL NQ_AO WL                          /* MAX_IMM: av >= imm ? a : b */                \
+    "v_mov_b32 v39, s87\n v_cndmask_b32 v36, 0, v39, s[98:99]\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_ge_f32 vcc, v46, v39\n"        \
+    "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
+    NQ_H(v, 20) LDL LDR NQ_AO WLR                                                                            \
+    "v_mov_b32_dpp v39, v36" NQ_Q3 "s_nop 1\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_ge_f32 vcc, v46, v39\n"                          \
+    "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
+    NQ_H(v, 21) NQ_IMM LDL NQ_AO WL                          /* a - imm: only the value */                   \
+    "s_nop 0\n v_subrev_f32 v38, s87, v35\n v_cndmask_b32 v37, v35, v38, s[98:99]\n" NQ_END                  \
+    NQ_H(v, 22) NQ_IMM LDR NQ_AO WR                          /* imm - b: isv ? imm - b : -b */               \
+    "s_nop 0\n v_sub_f32 v38, s87, v36\n v_xor_b32 v39, 0x80000000, v36\n v_cndmask_b32 v37, v39, v38, s[98:99]\n" NQ_END \
+    NQ_H(v, 23) LDL LDR NQ_AO WLR "v_sub_f32 v37, v35, v36\n" NQ_END                                         \
+    NQ_H(v, 24) NQ_IMM LDL NQ_AO WL "s_nop 0\n v_mov_b32 v36, s87\n" NQ_DIV NQ_END      /* a / imm, all components */ \
+    NQ_H(v, 25) NQ_IMM LDR NQ_AO WR                          /* imm / b: isv ? imm / b : (-imm * b) / (bv * bv) */ \
+    "v_mov_b32_dpp v41, v36" NQ_Q3 "v_mul_f32_e64 v39, -s87, v36\n v_mov_b32 v40, s87\n v_mul_f32 v38, v41, v41\n" \
+    "v_cndmask_b32 v35, v39, v40, s[98:99]\n v_cndmask_b32 v36, v38, v36, s[98:99]\n" NQ_DIV NQ_END          \
+    NQ_H(v, 26) LDL LDR NQ_AO WLR                            /* a / b: isv ? a / b : (bv*a - av*b) / (bv*bv) */ \
+    "v_mul_f32_dpp v38, v36, v35" NQ_Q3 "v_mul_f32_dpp v39, v35, v36" NQ_Q3 "v_mov_b32_dpp v41, v36" NQ_Q3      \
+    "v_sub_f32 v38, v38, v39\n s_nop 0\n v_mul_f32 v40, v41, v41\n"                                           \
+    "v_cndmask_b32 v35, v38, v35, s[98:99]\n v_cndmask_b32 v36, v40, v36, s[98:99]\n"                         \
+    NQ_DIV NQ_END                                                                                            \
+    NQ_H(v, 27) NQ_IMM NQ_AO "s_nop 0\n v_mov_b32 v39, s87\n v_cndmask_b32 v37, 0, v39, s[98:99]\n" NQ_END   \
+    NQ_H(v, 28) LDL NQ_AO WL "v_mov_b32 v37, v35\n" NQ_END                                                   \
+    NQ_H(v, 29) LDR NQ_AO WR "v_mov_b32 v37, v36\n" NQ_END                                                   \
+    NQ_H(v, 30) NQ_EXIT                                                                                      \
+    NQ_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"
+
+/* Walks the tape at tro[first] over the slot file at LDS offset 0; returns the result slot. */
+DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane, bool isv)
+{
+    unsigned char* const myslot = smem + lane * 4;
+    uint32_t blo = 0, bhi = 0;
+    uint32_t base = first, sj = 0, dlo = 0, dhi = 0;
+    const uint32_t lb = (uint32_t)(uintptr_t)smem + (uint32_t)lane * 4u;
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t selO = to_vgpr(0x0c0c0400u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
+    const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    float prev = 0.0f;
+    uint32_t mode = 0;
+
+    for (;;) {
+        base = rdfirst(base);
+        sj = rdfirst(sj);
+        mode = rdfirst(mode);
+        asm volatile(
+            "s_mov_b32 s89, %[base]\n"
+            "s_mov_b32 s88, %[sj]\n"
+            "s_mov_b32 s90, 0x260\n"
+            "s_mov_b32 s96, 0xff00\n"
+            "s_mov_b32 s98, 0x88888888\n"
+            "s_mov_b32 s99, 0x88888888\n"
+            "v_mov_b32 v37, %[prev]\n"
+            "s_getpc_b64 s[82:83]\n"
+            "L_pc_%=:\n"
+            "s_add_u32 s72, s82, L_div_%=-L_pc_%=\n s_addc_u32 s73, s83, 0\n"
+            "s_add_u32 s74, s82, L_sqrt_%=-L_pc_%=\n s_addc_u32 s75, s83, 0\n"
+            "s_add_u32 s76, s82, L_exp_%=-L_pc_%=\n s_addc_u32 s77, s83, 0\n"
+            "s_add_u32 s78, s82, L_log_%=-L_pc_%=\n s_addc_u32 s79, s83, 0\n"
+            "s_add_u32 s82, s82, L_n0_0_%=-L_pc_%=\n"
+            "s_addc_u32 s83, s83, 0\n"
+            "s_cmp_eq_u32 %[mode], 0\n"
+            "s_cbranch_scc1 L_load_%=\n"
+            NQ_DISPATCH
+            "L_load_%=:\n"
+            "s_mov_b32 s84, s89\n"
+            "s_mov_b32 s85, 0\n"
+            "s_lshl_b64 s[84:85], s[84:85], 3\n"
+            "s_add_u32 s84, s84, %[tlo]\n"
+            "s_addc_u32 s85, s85, %[thi]\n"
+            "global_load_dword %[blo], %[lane8], s[84:85]\n"
+            "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
+            "s_mov_b32 s88, -1\n"
+            "v_mov_b32 v41, 0\n"
+            "v_mov_b32 v43, 32\n"
+            "v_mov_b32 v44, 64\n"
+            "s_waitcnt vmcnt(0)\n"
+            "v_bfe_u32 v40, %[blo], 8, 8\n"
+            "v_and_b32 v38, 0xff, %[blo]\n"
+            "v_min_u32 v38, 30, v38\n"
+            "v_mov_b32_dpp v41, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_bfe_u32 v42, %[blo], 16, 8\n"
+            "v_lshrrev_b32 v39, 24, %[blo]\n"
+            "v_cmp_eq_u32 s[92:93], v39, v41\n"
+            "v_cmp_eq_u32 vcc, v42, v41\n"
+            "v_cmp_ne_u32 s[94:95], 0, v41\n"
+            "v_cndmask_b32 v42, 0, v44, s[92:93]\n"
+            "v_cndmask_b32 v42, v42, v43, vcc\n"
+            "v_cndmask_b32 v42, 0, v42, s[94:95]\n"
+            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"
+            "v_mov_b32 v39, 31\n"
+            "v_add_u32 v38, v38, v42\n"
+            "v_cndmask_b32 v38, v38, v39, vcc\n"
+            "v_lshl_or_b32 v38, v38, 8, v40\n"
+            "v_and_b32 %[blo], 0xffff0000, %[blo]\n"
+            "v_or_b32 %[blo], %[blo], v38\n"
+            "s_nop 0\n"
+            NQ_DISPATCH
+            NQ_TABLE(0, NQ_AL, NQ_AR, NQ_W, NQ_W, NQ_W)
+            NQ_TABLE(1, NQ_FL, NQ_AR, "", NQ_W, NQ_W)
+            NQ_TABLE(2, NQ_AL, NQ_FR, NQ_W, "", NQ_W)
+            /* shared routines: argument v35 (and v36), result v37, return to s[70:71] */
+            ".p2align 8\n"
+            "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[70:71]\n"
+            "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n"
+            "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n"
+            "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n"
+            "L_exit_%=:\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_mov_b32 %[dlo], s86\n"
+            "s_mov_b32 %[dhi], s87\n"
+            "s_mov_b32 %[base], s89\n"
+            "s_mov_b32 %[sj], s88\n"
+            : [blo] "+v"(blo), [bhi] "+v"(bhi), [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
+            : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
+              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev)
+            : "memory", "vcc", "scc",
+              "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+              "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s98", "s99",
+              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+        const uint32_t op = (dlo >> 8) & 31;
+        if (op == 0) break;
+        /* sin, cos, asin, acos, atan (and anything that is not an opcode) */
+        const float A = *reinterpret_cast<const float*>(myslot + ((dlo >> 8) & 0xFF00));
+        prev = deriv_trig_q(op, A, quad_bcast_a(A, 3), isv);
+        *reinterpret_cast<float*>(myslot + ((dlo & 0xFF) << 8)) = prev;
+        mode = 1;
+    }
+    return dlo & 0xFF;
+}
+
+__global__ void __launch_bounds__(64)
+k_eval_normals_asm(NormalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    unsigned char* const myslot = smem + lane * 4;
+    const int S = a.size;
+    const int fside = S / 4;                                  /* footprints per side */
+    const int fxi = blockIdx.x % fside, fyi = blockIdx.x / fside;
+    const int pix = lane >> 2, comp = lane & 3;
+    const bool isv = comp == 3;
+    const int px = fxi * 4 + (pix & 3), py = fyi * 4 + (pix >> 2);
+    const int pxy = px + py * S;
+    int pz = a.image[pxy];
+    const bool filled = pz != 0;
+    uint64_t todo = ballot(filled);
+    if (todo == 0) return;
+    if (pz < S - 1) pz += 1;                                   /* :1003-1005 */
+
+    const float size_recip = 1.0f / (float)(unsigned)S;
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+    const float vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+    const float vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+    const float vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+
+    /* deepest tile's tape (:1034-1066) */
+    int my_tape = 0;
+    if (filled) {
+        const int t64 = S / 64;
+        const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
+        const mpr_tile_node tn = a.tiles[tile];
+        if (tn.next == -1) {
+            my_tape = tn.tape;
+        } else {
+            const int subtile = tn.next * 64 + (px % 64) / 16 + ((py % 64) / 16) * 4 + ((pz % 64) / 16) * 16;
+            const mpr_tile_node sn = a.subtiles[subtile];
+            if (sn.next == -1) {
+                my_tape = sn.tape;
+            } else {
+                const int micro = sn.next * 64 + (px % 16) / 4 + ((py % 16) / 4) * 4 + ((pz % 16) / 4) * 16;
+                my_tape = a.microtiles[micro].tape;
+            }
+        }
+    }
+
+    const uint64_t* __restrict__ const tro = a.tape_ro;
+    const uint64_t head0 = tro[0];
+    const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
+    float result = 0.0f;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int tape = __builtin_amdgcn_readlane(my_tape, leader);
+        const bool mine = filled && my_tape == tape;
+        const uint64_t grp = ballot(mine);
+        todo &= ~grp;
+
+        /* :1021-1031 — value first, then the unit partials (unused axes alias slot 0) */
+        *reinterpret_cast<float*>(myslot + sx * 256) = isv ? vx : 0.0f;
+        *reinterpret_cast<float*>(myslot + sy * 256) = isv ? vy : 0.0f;
+        *reinterpret_cast<float*>(myslot + sz * 256) = isv ? vz : 0.0f;
+        if (comp == 0) *reinterpret_cast<float*>(myslot + sx * 256) = 1.0f;
+        if (comp == 1) *reinterpret_cast<float*>(myslot + sy * 256) = 1.0f;
+        if (comp == 2) *reinterpret_cast<float*>(myslot + sz * 256) = 1.0f;
+
+        const uint32_t rslot = interp_normals_asm(tro, (uint32_t)(tape + 1), smem, lane, isv);
+        const float rr = *reinterpret_cast<const float*>(myslot + rslot * 256);
+        if (mine) result = rr;
+    }
+
+    /* :1123-1131 */
+    const float gx = quad_bcast_a(result, 0), gy = quad_bcast_a(result, 1), gz = quad_bcast_a(result, 2);
+    const float norm = __builtin_sqrtf(gx * gx + gy * gy + gz * gz);
+    const uint32_t u = f2u8((result / norm) * 127 + 128);
+    const uint32_t ux = mpr_f2u(quad_bcast_a(mpr_u2f(u), 0)), uy = mpr_f2u(quad_bcast_a(mpr_u2f(u), 1)),
+                   uz = mpr_f2u(quad_bcast_a(mpr_u2f(u), 2));
+    if (filled && comp == 0) a.output[pxy] = (0xFFu << 24) | (uz << 16) | (uy << 8) | ux;
+}
+
+void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
+{
+    const int fside = a.size / 4;
+    hipLaunchKernelGGL(k_eval_normals_asm, dim3(fside * fside), dim3(64), (size_t)a.nslots * 256, s, a);
+}
+
+}  // namespace mprk

@@ -57,13 +57,17 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
  *   s[40:59], s[92:95] scratch masks
  *   v32 aA  v33 aB  v34 aO   v[36:37] A (lo, hi)   v[38:39] B   v[40:41] result (and previous result)
  *   v42..v49 temporaries                                                                        */
-#define TI_DISPATCH                                    \
+/* next clause: word, handler address ... */
+#define TI_PREP                                        \
     "s_add_u32 s88, s88, 1\n"                          \
     "v_readlane_b32 s86, %[blo], s88\n"                \
     "s_and_b32 s80, s86, s96\n"                        \
     "s_add_u32 s80, s80, s82\n"                        \
-    "s_addc_u32 s81, s83, 0\n"                         \
-    "s_setpc_b64 s[80:81]\n"
+    "s_addc_u32 s81, s83, 0\n"
+/* ... and go.  Handlers run TI_PREP right after issuing their LDS reads, under the reads' latency
+ * (this walk is bound by the latency of its dependent instruction chain, not by issue) */
+#define TI_GO "s_setpc_b64 s[80:81]\n"
+#define TI_DISPATCH TI_PREP TI_GO
 #define TI_IMM "v_readlane_b32 s87, %[bhi], s88\n"
 #define TI_AL "v_perm_b32 v32, s86, %[lb], %[selL]\n ds_read2st64_b32 v[36:37], v32 offset1:1\n"
 #define TI_AR "v_perm_b32 v33, s86, %[lb], %[selR]\n ds_read2st64_b32 v[38:39], v33 offset1:1\n"
@@ -74,7 +78,7 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
 #define TI_ST "ds_write2st64_b32 v34, v40, v41 offset1:1\n"
 #define TI_H(v, n) ".p2align 8\nL_t" #v "_" #n "_%=:\n"
 #define TI_EXIT TI_IMM "s_branch L_exit_%=\n"
-#define TI_END TI_ST TI_DISPATCH
+#define TI_END TI_ST TI_GO
 #define TI_NEGLO "v_xor_b32 v40, 0x80000000, v40\n"
 
 /* LDL / LDR: bring lhs into v[36:37] / rhs into v[38:39] (load, or copy of the previous result);
@@ -84,36 +88,36 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
     TI_H(v, 1) TI_IMM                                                  /* JUMP: base += j + imm + 1 */     \
     "s_add_u32 s79, s79, s88\n s_add_u32 s79, s79, 1\n"                                                     \
     "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n"     \
-    TI_H(v, 2) LDL TI_AO WL "s_branch L_square_%=\n"                                                        \
+    TI_H(v, 2) LDL TI_AO TI_PREP WL "s_branch L_square_%=\n"                                                        \
     TI_H(v, 3) TI_EXIT                                                                                      \
-    TI_H(v, 4) LDL TI_AO WL "v_xor_b32 v40, 0x80000000, v37\n v_xor_b32 v41, 0x80000000, v36\n" TI_END     \
+    TI_H(v, 4) LDL TI_AO TI_PREP WL "v_xor_b32 v40, 0x80000000, v37\n v_xor_b32 v41, 0x80000000, v36\n" TI_END     \
     TI_H(v, 5) TI_EXIT TI_H(v, 6) TI_EXIT TI_H(v, 7) TI_EXIT TI_H(v, 8) TI_EXIT TI_H(v, 9) TI_EXIT        \
     TI_H(v, 10) TI_EXIT                                                                                     \
-    TI_H(v, 11) LDL TI_AO WL "s_branch L_abs_%=\n"                                                          \
+    TI_H(v, 11) LDL TI_AO TI_PREP WL "s_branch L_abs_%=\n"                                                          \
     TI_H(v, 12) TI_EXIT                                                                                     \
-    TI_H(v, 13) TI_IMM LDL TI_AO WL                                                    /* ADD_LHS_IMM */    \
+    TI_H(v, 13) TI_IMM LDL TI_AO TI_PREP WL                                                    /* ADD_LHS_IMM */    \
     "v_add_f32_e64 v40, -v36, -s87\n v_add_f32 v41, s87, v37\n" TI_NEGLO TI_END                            \
-    TI_H(v, 14) LDL LDR TI_AO WLR                                                      /* ADD_LHS_RHS */    \
+    TI_H(v, 14) LDL LDR TI_AO TI_PREP WLR                                                      /* ADD_LHS_RHS */    \
     "v_add_f32_e64 v40, -v36, -v38\n v_add_f32 v41, v37, v39\n" TI_NEGLO TI_END                            \
-    TI_H(v, 15) TI_IMM LDL TI_AO WL                                                    /* MUL_LHS_IMM */    \
+    TI_H(v, 15) TI_IMM LDL TI_AO TI_PREP WL                                                    /* MUL_LHS_IMM */    \
     "v_mov_b32 v42, s87\n v_cmp_gt_f32 vcc, 0, v42\n s_nop 1\n"                                            \
     "v_cndmask_b32 v43, v36, v37, vcc\n v_cndmask_b32 v44, v37, v36, vcc\n"                                \
     "v_mul_f32_e64 v40, -v43, v42\n v_mul_f32 v41, v44, v42\n" TI_NEGLO TI_END                             \
-    TI_H(v, 16) LDL LDR TI_AO WLR "s_branch L_mul_%=\n"                                                     \
-    TI_H(v, 17) TI_IMM LDL TI_AO WL "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n s_branch L_min_%=\n"        \
-    TI_H(v, 18) LDL LDR TI_AO WLR "s_branch L_min_%=\n"                                                     \
-    TI_H(v, 19) TI_IMM LDL TI_AO WL "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n s_branch L_max_%=\n"        \
-    TI_H(v, 20) LDL LDR TI_AO WLR "s_branch L_max_%=\n"                                                     \
-    TI_H(v, 21) TI_IMM LDL TI_AO WL                                                    /* lhs - imm */      \
+    TI_H(v, 16) LDL LDR TI_AO TI_PREP WLR "s_branch L_mul_%=\n"                                                     \
+    TI_H(v, 17) TI_IMM LDL TI_AO TI_PREP WL "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n s_branch L_min_%=\n"        \
+    TI_H(v, 18) LDL LDR TI_AO TI_PREP WLR "s_branch L_min_%=\n"                                                     \
+    TI_H(v, 19) TI_IMM LDL TI_AO TI_PREP WL "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n s_branch L_max_%=\n"        \
+    TI_H(v, 20) LDL LDR TI_AO TI_PREP WLR "s_branch L_max_%=\n"                                                     \
+    TI_H(v, 21) TI_IMM LDL TI_AO TI_PREP WL                                                    /* lhs - imm */      \
     "v_sub_f32 v40, s87, v36\n v_subrev_f32 v41, s87, v37\n" TI_NEGLO TI_END                               \
-    TI_H(v, 22) TI_IMM LDR TI_AO WR                                                    /* imm - rhs */      \
+    TI_H(v, 22) TI_IMM LDR TI_AO TI_PREP WR                                                    /* imm - rhs */      \
     "v_subrev_f32 v40, s87, v39\n v_sub_f32 v41, s87, v38\n" TI_NEGLO TI_END                               \
-    TI_H(v, 23) LDL LDR TI_AO WLR                                                      /* lhs - rhs */      \
+    TI_H(v, 23) LDL LDR TI_AO TI_PREP WLR                                                      /* lhs - rhs */      \
     "v_sub_f32 v40, v39, v36\n v_sub_f32 v41, v37, v38\n" TI_NEGLO TI_END                                  \
     TI_H(v, 24) TI_EXIT TI_H(v, 25) TI_EXIT TI_H(v, 26) TI_EXIT                                             \
-    TI_H(v, 27) TI_IMM TI_AO "s_nop 0\n v_mov_b32 v40, s87\n v_mov_b32 v41, s87\n" TI_END                  \
-    TI_H(v, 28) LDL TI_AO WL "v_mov_b32 v40, v36\n v_mov_b32 v41, v37\n" TI_END                            \
-    TI_H(v, 29) LDR TI_AO WR "v_mov_b32 v40, v38\n v_mov_b32 v41, v39\n" TI_END                            \
+    TI_H(v, 27) TI_IMM TI_AO TI_PREP "s_nop 0\n v_mov_b32 v40, s87\n v_mov_b32 v41, s87\n" TI_END                  \
+    TI_H(v, 28) LDL TI_AO TI_PREP WL "v_mov_b32 v40, v36\n v_mov_b32 v41, v37\n" TI_END                            \
+    TI_H(v, 29) LDR TI_AO TI_PREP WR "v_mov_b32 v40, v38\n v_mov_b32 v41, v39\n" TI_END                            \
     TI_H(v, 30) TI_EXIT                                                                                     \
     TI_H(v, 31) "s_add_u32 s79, s79, 63\n s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"   /* lane 63: next block */
 

@@ -304,3 +304,23 @@ def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, mon
     test in this file exercises)."""
     monkeypatch.setenv("MPR_TILES_ASM", "0")
     compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
+
+
+@pytest.mark.parametrize("name,S", [("bear", 256), ("architecture", 256), ("involute_gear_3d", 256), ("trig", 128), ("sphere", 128),
+                                    ("two_spheres", 128)])
+def test_assembly_normals_pass_matches_compiled_one(mpr, tapes, name, S, monkeypatch):
+    """The normals pass runs an interpreter written in gfx950 assembly (kernels_normals_asm.hip);
+    MPR_NORMALS_ASM=0 selects the compiled one.  Same normals, bit for bit."""
+    tape = tapes(name)
+    monkeypatch.setenv("MPR_NORMALS_ASM", "0")
+    a = mpr.Context(S)
+    monkeypatch.setenv("MPR_NORMALS_ASM", "1")
+    b = mpr.Context(S)
+    for ctx in (a, b):
+        ctx.render3D(tape, view3())
+    assert a.normals.any()
+    assert np.array_equal(a.image, b.image)
+    bad = np.flatnonzero(a.normals.ravel() != b.normals.ravel())
+    assert bad.size == 0, (bad.size, [(hex(a.normals.ravel()[i]), hex(b.normals.ravel()[i])) for i in bad[:5]])
+    a.close()
+    b.close()
