@@ -60,15 +60,14 @@
     "v_mul_f32 v41, v39, v39\n" \
     "v_fma_f32 v40, v40, v39, 0.5\n" \
     "v_fmac_f32 v39, v40, v41\n" \
-    "v_lshrrev_b32 v41, 31, v38\n" \
-    "v_add_u32 v41, v38, v41\n" \
-    "v_ashrrev_i32 v41, 1, v41\n"                   /* k1 = k / 2 (toward zero) */ \
     "v_add_f32 v39, 1.0, v39\n" \
-    "v_sub_u32 v38, v38, v41\n"                     /* k2 = k - k1 */ \
-    "v_lshl_add_u32 v41, v41, 23, 1.0\n" \
-    "v_lshl_add_u32 v38, v38, 23, 1.0\n" \
-    "v_mul_f32 v39, v39, v41\n" \
-    "v_mul_f32 v37, v39, v38\n" \
+    /* p * 2^k: the C++ definition multiplies by 2^(k/2) and 2^(k - k/2), the first product exact, \
+     * i.e. one rounding of p * 2^k — which is what v_ldexp_f32 does in one instruction */ \
+    "v_ldexp_f32 v37, v39, v38\n" \
+    /* |x| <= 87 in every lane (NaN counts as not): none of the three special cases applies */ \
+    "s_mov_b32 s91, 0x42ae0000\n" \
+    "v_cmp_nle_f32 vcc, |v35|, s91\n" \
+    "s_cbranch_vccz L_expdone_%=\n" \
     "s_mov_b32 s91, 0x42b17218\n" \
     "v_cmp_ngt_f32 vcc, 0xc2cff5c3, v35\n"          /* !(x < -103.98) */ \
     "v_cmp_nlt_f32 s[92:93], s91, v35\n"            /* !(x > 88.72284) */ \
@@ -76,15 +75,25 @@
     "v_mov_b32 v40, 0x7f800000\n" \
     "v_cndmask_b32 v37, 0, v37, vcc\n" \
     "v_cndmask_b32 v37, v40, v37, s[92:93]\n" \
-    "v_cndmask_b32 v37, v35, v37, s[94:95]\n"
+    "v_cndmask_b32 v37, v35, v37, s[94:95]\n" \
+    "L_expdone_%=:\n"
 
 #define MPR_ASM_LOG_BODY \
+    /* every lane a positive normal number: no subnormal scaling, none of the special results */ \
+    "s_movk_i32 s91, 0x100\n" \
+    "v_mov_b32 v40, 0xffffff82\n" \
+    "v_cmp_class_f32 vcc, v35, s91\n" \
+    "v_mov_b32 v38, v35\n" \
+    "s_cmp_eq_u64 vcc, exec\n" \
+    "s_cselect_b32 s91, 1, 0\n" \
+    "s_cbranch_scc1 L_logmain_%=\n" \
     "v_mul_f32 v38, 0x4b000000, v35\n" \
     "v_cmp_gt_u32 vcc, 0x800000, v35\n"             /* subnormal: scale by 2^23 */ \
-    "v_mov_b32 v40, 0xffffff82\n" \
     "v_mov_b32 v41, 0xffffff6b\n" \
+    "s_nop 0\n" \
     "v_cndmask_b32 v38, v35, v38, vcc\n" \
     "v_cndmask_b32 v40, v40, v41, vcc\n" \
+    "L_logmain_%=:\n" \
     "v_lshrrev_b32 v39, 23, v38\n" \
     "v_add_u32 v39, v39, v40\n"                     /* e */ \
     "v_and_b32 v38, 0x7fffff, v38\n" \
@@ -113,6 +122,8 @@
     "v_fmac_f32 v40, -0.5, v41\n" \
     "v_add_f32 v40, v38, v40\n" \
     "v_fmamk_f32 v37, v39, 0x3f318000, v40\n" \
+    "s_cmp_eq_u32 s91, 1\n" \
+    "s_cbranch_scc1 L_logdone_%=\n" \
     "v_cmp_ne_u32 vcc, 0x7f800000, v35\n"           /* log(+inf) = +inf */ \
     "v_mov_b32 v40, 0xff800000\n" \
     "v_mov_b32 v41, 0x7fc00000\n" \
@@ -125,4 +136,5 @@
     "v_cndmask_b32 v37, v37, v41, vcc\n" \
     "v_cmp_u_f32 vcc, v35, v35\n"                   /* NaN in, the same NaN out */ \
     "s_nop 1\n" \
-    "v_cndmask_b32 v37, v37, v35, vcc\n"
+    "v_cndmask_b32 v37, v37, v35, vcc\n" \
+    "L_logdone_%=:\n"
