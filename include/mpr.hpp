@@ -216,6 +216,35 @@ private:
     bool pool_valid = false;
 };
 
+/* inc/effects.hpp:21-37 — SSAO and shading over the context's last render3D */
+struct Effects {
+    explicit Effects(int32_t device = 0)
+    {
+        mpr_effects* e = nullptr;
+        check(mpr_effects_create(device, &e));
+        handle = std::shared_ptr<mpr_effects>(e, mpr_effects_destroy);
+    }
+    void drawSSAO(const Context& ctx)
+    {
+        check(mpr_effects_draw_ssao(handle.get(), ctx.handle.get()));
+        refresh(ctx.image_size_px);
+    }
+    void drawShaded(const Context& ctx)
+    {
+        check(mpr_effects_draw_shaded(handle.get(), ctx.handle.get()));
+        refresh(ctx.image_size_px);
+    }
+    std::vector<int32_t> image;       /* host mirror of Effects::image, refreshed by every draw */
+    std::shared_ptr<mpr_effects> handle;
+
+private:
+    void refresh(int32_t size)
+    {
+        image.resize((size_t)size * size);
+        check(mpr_effects_read_image(handle.get(), image.data()));
+    }
+};
+
 inline const std::vector<TileNode>& Tiles::tile_list() const
 {
     if (!tiles_valid) {

@@ -179,6 +179,23 @@ int mpr_get_counters(mpr_context* ctx, mpr_counters* out);
  * MPR_CTX_TIMING).  names[i] is a static string; returns count in *n (<= cap). */
 int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
 
+/* ---- mpr::Effects (reference inc/effects.hpp:21-37, src/effects.cu): image-space passes over the
+ *      heightmap and normals of the context's last render3D ---- */
+typedef struct mpr_effects mpr_effects;
+/* Effects::Effects(): builds the SSAO sample kernel and noise vectors (mpr_effects_tables.h) */
+int mpr_effects_create(int32_t device, mpr_effects** out);
+void mpr_effects_destroy(mpr_effects* fx);
+/* Effects::drawSSAO(ctx): image = blurred ambient occlusion, 0..255 per covered pixel */
+int mpr_effects_draw_ssao(mpr_effects* fx, mpr_context* ctx);
+/* Effects::drawShaded(ctx): image = 0xFFcccccc grey shading (one light, SSAO-dimmed, ambient) */
+int mpr_effects_draw_shaded(mpr_effects* fx, mpr_context* ctx);
+/* Effects::image / Effects::tmp: S*S int32 each; host copies, or the device pointers */
+int mpr_effects_read_image(mpr_effects* fx, int32_t* host);
+int mpr_effects_read_tmp(mpr_effects* fx, int32_t* host);
+int32_t* mpr_effects_dev_image(mpr_effects* fx);
+/* the tables (64 x 3 and 256 x 3 floats, row-major), for inspection */
+int mpr_effects_tables_get(const mpr_effects* fx, float* kernel, float* rvecs);
+
 /* ---- device self-tests used by the parity suite: evaluate primitive operations on the GPU
  *      so they can be compared bit-for-bit with the oracle ---- */
 /* interval primitive `op` (an MPR_OP_* code) on n operand pairs; lo/hi arrays */

@@ -151,6 +151,14 @@ def lib():
     L.mpr_ctx_stream.restype = vp
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
+    L.mpr_effects_create.argtypes = [i32, P(vp)]
+    L.mpr_effects_destroy.argtypes = [vp]
+    L.mpr_effects_destroy.restype = None
+    L.mpr_effects_draw_ssao.argtypes = [vp, vp]
+    L.mpr_effects_draw_shaded.argtypes = [vp, vp]
+    L.mpr_effects_read_image.argtypes = [vp, vp]
+    L.mpr_effects_read_tmp.argtypes = [vp, vp]
+    L.mpr_effects_tables_get.argtypes = [vp, vp, vp]
     L.mpr_test_interval_op.argtypes = [i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]
     L.mpr_test_interval_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]
     L.mpr_test_float_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
@@ -482,6 +490,54 @@ class Context:
 
     def dev_normals(self):
         return lib().mpr_dev_normals(self._h)
+
+
+class Effects:
+    """mpr::Effects (inc/effects.hpp:21-37): SSAO and shading over a context's last render3D."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _check(lib().mpr_effects_create(device, ctypes.byref(h)))
+        self._h = h
+        self._size = 0
+
+    def close(self):
+        if self._h:
+            lib().mpr_effects_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def drawSSAO(self, ctx):
+        _check(lib().mpr_effects_draw_ssao(self._h, ctx._h))
+        self._size = ctx.image_size_px
+
+    def drawShaded(self, ctx):
+        _check(lib().mpr_effects_draw_shaded(self._h, ctx._h))
+        self._size = ctx.image_size_px
+
+    def _read(self, fn):
+        out = np.empty((self._size, self._size), dtype=np.int32)
+        _check(fn(self._h, _ptr(out)))
+        return out
+
+    @property
+    def image(self):
+        return self._read(lib().mpr_effects_read_image)
+
+    @property
+    def tmp(self):
+        return self._read(lib().mpr_effects_read_tmp)
+
+    def tables(self):
+        kernel = np.zeros((64, 3), dtype=np.float32)
+        rvecs = np.zeros((256, 3), dtype=np.float32)
+        _check(lib().mpr_effects_tables_get(self._h, _ptr(kernel), _ptr(rvecs)))
+        return kernel, rvecs
 
 
 def partition_columns(columns, nranks, weights=None):

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/mpr_amd.h"
+#include "../../include/mpr_effects_tables.h"
 #include "internal.hpp"
 #include "kernels.hpp"
 
@@ -629,6 +630,106 @@ int mpr_read_tape_pool(mpr_context* c, uint64_t* host, size_t cap, int32_t* tape
 int32_t* mpr_dev_filled(mpr_context* c, int32_t stage) { return (c && stage >= 0 && stage <= 3) ? c->filled[stage] : nullptr; }
 uint32_t* mpr_dev_normals(mpr_context* c) { return c ? c->normals : nullptr; }
 void* mpr_ctx_stream(mpr_context* c) { return c ? (void*)c->stream : nullptr; }
+
+/* ---- mpr::Effects ------------------------------------------------------------------------ */
+struct mpr_effects {
+    int device = 0;
+    int32_t S = 0;
+    int32_t* tmp = nullptr;
+    int32_t* image = nullptr;
+    void* tables_dev = nullptr;
+    float kernel[64 * 3];
+    float rvecs[256 * 3];
+};
+int mpr_effects_create(int32_t device, mpr_effects** out)
+{
+    if (!out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    mpr_effects* fx = new mpr_effects();
+    fx->device = device;
+    mpr_effects_tables(fx->kernel, fx->rvecs);
+    if (hipMalloc(&fx->tables_dev, mprk::effect_tables_bytes()) != hipSuccess) {
+        delete fx;
+        return mpr::set_error(MPR_ERR_ALLOC, "hipMalloc failed");
+    }
+    float both[64 * 3 + 256 * 3];
+    std::memcpy(both, fx->kernel, sizeof(fx->kernel));
+    std::memcpy(both + 64 * 3, fx->rvecs, sizeof(fx->rvecs));
+    HIP_TRY(hipMemcpy(fx->tables_dev, both, sizeof(both), hipMemcpyHostToDevice));
+    *out = fx;
+    return MPR_OK;
+}
+void mpr_effects_destroy(mpr_effects* fx)
+{
+    if (!fx) return;
+    (void)hipSetDevice(fx->device);
+    if (fx->tmp) (void)hipFree(fx->tmp);
+    if (fx->image) (void)hipFree(fx->image);
+    if (fx->tables_dev) (void)hipFree(fx->tables_dev);
+    delete fx;
+}
+/* Effects::resizeTo, src/effects.cu:238-244 */
+static int effects_resize(mpr_effects* fx, const mpr_context* c)
+{
+    if (fx->S == c->S) return MPR_OK;
+    if (fx->tmp) (void)hipFree(fx->tmp);
+    if (fx->image) (void)hipFree(fx->image);
+    fx->tmp = fx->image = nullptr;
+    fx->S = 0;
+    const size_t bytes = (size_t)c->S * c->S * sizeof(int32_t);
+    HIP_TRY(hipMalloc((void**)&fx->tmp, bytes));
+    HIP_TRY(hipMalloc((void**)&fx->image, bytes));
+    fx->S = c->S;
+    return MPR_OK;
+}
+static int effects_draw(mpr_effects* fx, mpr_context* c, bool shaded)
+{
+    if (!fx || !c) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    if (fx->device != c->device) return mpr::set_error(MPR_ERR_INVALID, "effects and context live on different devices");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = effects_resize(fx, c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;        /* ordered after the frame that produced depth and normals */
+    const size_t bytes = (size_t)fx->S * fx->S * sizeof(int32_t);
+    HIP_TRY(hipMemsetAsync(fx->tmp, 0, bytes, s));
+    HIP_TRY(hipMemsetAsync(fx->image, 0, bytes, s));
+    const int32_t* depth = c->filled[3];
+    if (!shaded) {                    /* drawSSAO, src/effects.cu:246-263 */
+        mprk::launch_draw_ssao(s, depth, c->normals, fx->tables_dev, fx->S, fx->tmp);
+        mprk::launch_blur_ssao(s, depth, fx->tmp, fx->S, fx->image);
+    } else {                          /* drawShaded, src/effects.cu:265-286 */
+        mprk::launch_draw_ssao(s, depth, c->normals, fx->tables_dev, fx->S, fx->image);
+        mprk::launch_blur_ssao(s, depth, fx->image, fx->S, fx->tmp);
+        mprk::launch_draw_shaded(s, depth, c->normals, fx->tmp, fx->S, fx->image);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return MPR_OK;
+}
+int mpr_effects_draw_ssao(mpr_effects* fx, mpr_context* c) { return effects_draw(fx, c, false); }
+int mpr_effects_draw_shaded(mpr_effects* fx, mpr_context* c) { return effects_draw(fx, c, true); }
+int mpr_effects_read_image(mpr_effects* fx, int32_t* host)
+{
+    if (!fx || !host || !fx->image) return mpr::set_error(MPR_ERR_INVALID, "nothing drawn yet");
+    HIP_TRY(hipSetDevice(fx->device));
+    HIP_TRY(hipMemcpy(host, fx->image, (size_t)fx->S * fx->S * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int mpr_effects_read_tmp(mpr_effects* fx, int32_t* host)
+{
+    if (!fx || !host || !fx->tmp) return mpr::set_error(MPR_ERR_INVALID, "nothing drawn yet");
+    HIP_TRY(hipSetDevice(fx->device));
+    HIP_TRY(hipMemcpy(host, fx->tmp, (size_t)fx->S * fx->S * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+int32_t* mpr_effects_dev_image(mpr_effects* fx) { return fx ? fx->image : nullptr; }
+int mpr_effects_tables_get(const mpr_effects* fx, float* kernel, float* rvecs)
+{
+    if (!fx) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    if (kernel) std::memcpy(kernel, fx->kernel, sizeof(fx->kernel));
+    if (rvecs) std::memcpy(rvecs, fx->rvecs, sizeof(fx->rvecs));
+    return MPR_OK;
+}
 
 int mpr_get_counters(mpr_context* c, mpr_counters* out)
 {

@@ -134,4 +134,10 @@ void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
 void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
 
+/* mpr::Effects (kernels_effects.hip) */
+size_t effect_tables_bytes();
+void launch_draw_ssao(hipStream_t s, const int32_t* depth, const uint32_t* norm, const void* tables, int S, int32_t* out);
+void launch_blur_ssao(hipStream_t s, const int32_t* image, const int32_t* ssao, int S, int32_t* out);
+void launch_draw_shaded(hipStream_t s, const int32_t* depth, const uint32_t* norm, const int32_t* ssao, int S, int32_t* out);
+
 }  // namespace mprk

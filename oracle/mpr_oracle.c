@@ -1194,3 +1194,58 @@ void orc_fmath_n(int32_t which, int32_t n, const float* x, float* out)
         }
     }
 }
+
+
+/* ====================================================================================== */
+/* mpr::Effects — reference src/effects.cu:17-286.  Per-pixel arithmetic in                 */
+/* include/mpr_effects_math.h (each function cites its lines); here: the pass structure of  */
+/* drawSSAO (:246-263) and drawShaded (:265-286), in round-to-nearest.                      */
+/* ====================================================================================== */
+#include "../include/mpr_effects_math.h"
+#include "../include/mpr_effects_tables.h"
+
+void orc_effects_tables(float* kernel, float* rvecs)
+{
+    const int old = fegetround();
+    fesetround(FE_TONEAREST);
+    float k[64 * 3], r[256 * 3];
+    mpr_effects_tables(k, r);
+    if (kernel) memcpy(kernel, k, sizeof(k));
+    if (rvecs) memcpy(rvecs, r, sizeof(r));
+    fesetround(old);
+}
+void orc_glibc_rand(uint32_t seed, int32_t n, int32_t* out)
+{
+    mpr_glibc_rand g;
+    mpr_glibc_srand(&g, seed);
+    for (int32_t i = 0; i < n; ++i) out[i] = mpr_glibc_rand_next(&g);
+}
+void orc_effects(int32_t which, int32_t size, const int32_t* depth, const uint32_t* normals, int32_t* image, int32_t* tmp)
+{
+    const int old = fegetround();
+    fesetround(FE_TONEAREST);
+    float kernel[64 * 3], rvecs[256 * 3];
+    mpr_effects_tables(kernel, rvecs);
+    const size_t n = (size_t)size * size;
+    memset(image, 0, n * sizeof(int32_t));
+    memset(tmp, 0, n * sizeof(int32_t));
+    int32_t* const raw = which ? image : tmp;        /* draw_ssao target */
+    int32_t* const blurred = which ? tmp : image;    /* blur_ssao target */
+    for (int y = 0; y < size; ++y)
+        for (int x = 0; x < size; ++x) {
+            const int32_t o = mpr_fx_ssao_pixel(depth, normals, kernel, rvecs, size, x, y);
+            if (o >= 0) raw[x + y * size] = o;
+        }
+    for (int y = 0; y < size; ++y)
+        for (int x = 0; x < size; ++x) blurred[x + y * size] = mpr_fx_blur_pixel(depth, raw, size, x, y);
+    if (which) {
+        /* draw_shaded writes into `image`, which still holds the raw occlusion where it is not
+         * covered — but raw occlusion exists only on covered pixels, which all get overwritten */
+        for (int y = 0; y < size; ++y)
+            for (int x = 0; x < size; ++x) {
+                const uint32_t c = mpr_fx_shade_pixel(depth, normals, blurred, size, x, y);
+                if (c) image[x + y * size] = (int32_t)c;
+            }
+    }
+    fesetround(old);
+}

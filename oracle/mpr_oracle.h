@@ -81,6 +81,14 @@ int64_t orc_selftest_rounding(int64_t n, uint64_t seed);
 /* shared math functions (include/mpr_fmath.h) for accuracy tests */
 void orc_fmath_n(int32_t which, int32_t n, const float* x, float* out);
 
+/* ---- mpr::Effects (reference src/effects.cu) over a finished frame's heightmap + normals ----
+ * which: 0 = drawSSAO (image = blurred occlusion; tmp = raw occlusion), 1 = drawShaded (image =
+ * shading; tmp = blurred occlusion).  image / tmp: size * size int32 each, zeroed first. */
+void orc_effects(int32_t which, int32_t size, const int32_t* depth, const uint32_t* normals, int32_t* image, int32_t* tmp);
+/* the SSAO tables (64 x 3 and 256 x 3 floats) and the first n draws of the restated glibc rand() */
+void orc_effects_tables(float* kernel, float* rvecs);
+void orc_glibc_rand(uint32_t seed, int32_t n, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

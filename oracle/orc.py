@@ -88,6 +88,9 @@ def lib():
     L.orc_selftest_rounding.restype = ctypes.c_int64
     L.orc_selftest_rounding.argtypes = [ctypes.c_int64, ctypes.c_uint64]
     L.orc_fmath_n.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_effects.argtypes = [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4
+    L.orc_effects_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_glibc_rand.argtypes = [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p]
     _LIB = L
     return L
 
@@ -200,3 +203,27 @@ def fmath(name, x):
 
 def selftest_rounding(n=200000, seed=1):
     return lib().orc_selftest_rounding(n, seed)
+
+
+def effects(which, depth, normals):
+    """mpr::Effects over a frame: which = "ssao" or "shaded" -> (image, tmp), (S, S) int32."""
+    depth = np.ascontiguousarray(depth, dtype=np.int32)
+    normals = np.ascontiguousarray(normals, dtype=np.uint32)
+    S = depth.shape[0]
+    image = np.zeros((S, S), dtype=np.int32)
+    tmp = np.zeros((S, S), dtype=np.int32)
+    lib().orc_effects({"ssao": 0, "shaded": 1}[which], S, _ptr(depth), _ptr(normals), _ptr(image), _ptr(tmp))
+    return image, tmp
+
+
+def effects_tables():
+    kernel = np.zeros((64, 3), dtype=np.float32)
+    rvecs = np.zeros((256, 3), dtype=np.float32)
+    lib().orc_effects_tables(_ptr(kernel), _ptr(rvecs))
+    return kernel, rvecs
+
+
+def glibc_rand(n, seed=1):
+    out = np.zeros(n, dtype=np.int32)
+    lib().orc_glibc_rand(seed, n, _ptr(out))
+    return out
