@@ -89,7 +89,7 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
     "s_add_u32 s79, s79, s88\n s_add_u32 s79, s79, 1\n"                                                     \
     "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n"     \
     TI_H(v, 2) LDL TI_AO TI_PREP WL "s_branch L_square_%=\n"                                                        \
-    TI_H(v, 3) TI_EXIT                                                                                      \
+    TI_H(v, 3) LDL TI_AO TI_PREP WL "s_branch L_isqrt_%=\n"                                                        \
     TI_H(v, 4) LDL TI_AO TI_PREP WL "v_xor_b32 v40, 0x80000000, v37\n v_xor_b32 v41, 0x80000000, v36\n" TI_END     \
     TI_H(v, 5) TI_EXIT TI_H(v, 6) TI_EXIT TI_H(v, 7) TI_EXIT TI_H(v, 8) TI_EXIT TI_H(v, 9) TI_EXIT        \
     TI_H(v, 10) TI_EXIT                                                                                     \
@@ -114,12 +114,120 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
     "v_subrev_f32 v40, s87, v39\n v_sub_f32 v41, s87, v38\n" TI_NEGLO TI_END                               \
     TI_H(v, 23) LDL LDR TI_AO TI_PREP WLR                                                      /* lhs - rhs */      \
     "v_sub_f32 v40, v39, v36\n v_sub_f32 v41, v37, v38\n" TI_NEGLO TI_END                                  \
-    TI_H(v, 24) TI_EXIT TI_H(v, 25) TI_EXIT TI_H(v, 26) TI_EXIT                                             \
+    /* division: s[58:59] = lanes whose divisor contains zero (result [-inf, inf]) */                         \
+    TI_H(v, 24) TI_IMM LDL TI_AO TI_PREP WL                                            /* lhs / imm */      \
+    "v_mov_b32 v38, s87\n v_mov_b32 v39, s87\n v_cmp_lg_f32 s[58:59], 0, v38\n s_nop 0\n"                   \
+    "s_not_b64 s[58:59], s[58:59]\n s_branch L_idiv_%=\n"                                                   \
+    TI_H(v, 25) TI_IMM LDR TI_AO TI_PREP WR                                            /* imm / rhs */      \
+    "v_mov_b32 v36, s87\n v_mov_b32 v37, s87\n v_cmp_ge_f32 s[58:59], 0, v38\n v_cmp_le_f32 vcc, 0, v39\n"  \
+    "s_and_b64 s[58:59], s[58:59], vcc\n s_branch L_idiv_%=\n"                                              \
+    TI_H(v, 26) LDL LDR TI_AO TI_PREP WLR                                              /* lhs / rhs */      \
+    "v_cmp_ge_f32 s[58:59], 0, v38\n v_cmp_le_f32 vcc, 0, v39\n"                                            \
+    "s_and_b64 s[58:59], s[58:59], vcc\n s_branch L_idiv_%=\n"                                              \
     TI_H(v, 27) TI_IMM TI_AO TI_PREP "s_nop 0\n v_mov_b32 v40, s87\n v_mov_b32 v41, s87\n" TI_END                  \
     TI_H(v, 28) LDL TI_AO TI_PREP WL "v_mov_b32 v40, v36\n v_mov_b32 v41, v37\n" TI_END                            \
     TI_H(v, 29) LDR TI_AO TI_PREP WR "v_mov_b32 v40, v38\n v_mov_b32 v41, v39\n" TI_END                            \
     TI_H(v, 30) TI_EXIT                                                                                     \
     TI_H(v, 31) "s_add_u32 s79, s79, 63\n s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"   /* lane 63: next block */
+
+/* q = a / b correctly rounded (round-to-nearest must be in effect) and the exact residual
+ * r = a - q * b; temporaries v51..v55, s[44:45], vcc */
+#define TI_DIVQ(q, r, a, b)                                         \
+    "v_div_scale_f32 v51, s[44:45], " b ", " b ", " a "\n"          \
+    "v_rcp_f32 v52, v51\n"                                          \
+    "v_div_scale_f32 v53, vcc, " a ", " b ", " a "\n"               \
+    "v_fma_f32 v54, -v51, v52, 1.0\n"                               \
+    "v_fmac_f32 v52, v54, v52\n"                                    \
+    "v_mul_f32 v54, v53, v52\n"                                     \
+    "v_fma_f32 v55, -v51, v54, v53\n"                               \
+    "v_fmac_f32 v54, v55, v52\n"                                    \
+    "v_fma_f32 v51, -v51, v54, v53\n"                               \
+    "v_div_fmas_f32 v51, v51, v52, v54\n"                           \
+    "v_div_fixup_f32 " q ", v51, " b ", " a "\n"                    \
+    "v_fma_f32 " r ", -" q ", " b ", " a "\n"
+/* next_down / next_up of a finite float q (device_math.hpp), into t2; temporaries t1, t3, s[48:49] */
+#define TI_NEXT_DOWN(q, t1, t2, t3)                                 \
+    "v_and_b32 " t1 ", 0x7fffffff, " q "\n"                         \
+    "v_cmp_lt_i32 s[48:49], -1, " q "\n"                            \
+    "v_mov_b32 " t3 ", 0x80000001\n"                                \
+    "s_nop 0\n"                                                     \
+    "v_cndmask_b32 " t2 ", 1, -1, s[48:49]\n"                       \
+    "v_add_u32 " t2 ", " t2 ", " q "\n"                             \
+    "v_cmp_ne_u32 s[48:49], 0, " t1 "\n"                            \
+    "s_nop 1\n"                                                     \
+    "v_cndmask_b32 " t2 ", " t3 ", " t2 ", s[48:49]\n"
+#define TI_NEXT_UP(q, t1, t2, t3)                                   \
+    "v_and_b32 " t1 ", 0x7fffffff, " q "\n"                         \
+    "v_ashrrev_i32 " t2 ", 31, " q "\n"                             \
+    "v_or_b32 " t2 ", 1, " t2 "\n"                                  \
+    "v_add_u32 " t2 ", " t2 ", " q "\n"                             \
+    "v_cmp_ne_u32 s[48:49], 0, " t1 "\n"                            \
+    "s_nop 1\n"                                                     \
+    "v_cndmask_b32 " t2 ", 1, " t2 ", s[48:49]\n"
+/* div_fix_down / div_fix_up (device_math.hpp): move the round-to-nearest quotient q (residual r) of
+ * a / b to the round-down / round-up one; s56 = 0x1f8 (finite), s57 = 0x198 (finite, not zero) */
+#define TI_FIX_DOWN(out, q, r, a, b)                                \
+    "v_cmp_class_f32 s[44:45], " q ", s56\n"                        \
+    "v_cmp_gt_f32 vcc, 0, " r "\n"                                  \
+    "v_cmp_lt_f32 s[46:47], 0, " b "\n"                             \
+    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
+    "v_cmp_lt_f32 vcc, 0, " r "\n"                                  \
+    "v_cmp_gt_f32 s[48:49], 0, " b "\n"                             \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                           \
+    "s_or_b64 s[46:47], s[46:47], s[48:49]\n"      /* exact quotient below q */ \
+    TI_NEXT_DOWN(q, "v51", "v52", "v53")                            \
+    "v_cndmask_b32 v52, " q ", v52, s[46:47]\n"                     \
+    "v_cmp_lt_f32 vcc, 0, " q "\n"                  /* overflowed to +inf although finite: FLT_MAX */ \
+    "v_cmp_class_f32 s[46:47], " a ", s56\n"                        \
+    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
+    "v_cmp_class_f32 vcc, " b ", s57\n"                             \
+    "s_and_b64 vcc, vcc, s[46:47]\n"                                \
+    "v_mov_b32 v53, 0x7f7fffff\n"                                   \
+    "v_cndmask_b32 v51, " q ", v53, vcc\n"                          \
+    "v_cndmask_b32 " out ", v51, v52, s[44:45]\n"
+#define TI_FIX_UP(out, q, r, a, b)                                  \
+    "v_cmp_class_f32 s[44:45], " q ", s56\n"                        \
+    "v_cmp_lt_f32 vcc, 0, " r "\n"                                  \
+    "v_cmp_lt_f32 s[46:47], 0, " b "\n"                             \
+    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
+    "v_cmp_gt_f32 vcc, 0, " r "\n"                                  \
+    "v_cmp_gt_f32 s[48:49], 0, " b "\n"                             \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                           \
+    "s_or_b64 s[46:47], s[46:47], s[48:49]\n"      /* exact quotient above q */ \
+    TI_NEXT_UP(q, "v51", "v52", "v53")                              \
+    "v_cndmask_b32 v52, " q ", v52, s[46:47]\n"                     \
+    "v_cmp_gt_f32 vcc, 0, " q "\n"                  /* overflowed to -inf although finite: -FLT_MAX */ \
+    "v_cmp_class_f32 s[46:47], " a ", s56\n"                        \
+    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
+    "v_cmp_class_f32 vcc, " b ", s57\n"                             \
+    "s_and_b64 vcc, vcc, s[46:47]\n"                                \
+    "v_mov_b32 v53, 0xff7fffff\n"                                   \
+    "v_cndmask_b32 v51, " q ", v53, vcc\n"                          \
+    "v_cndmask_b32 " out ", v51, v52, s[44:45]\n"
+/* s = sqrt(a) correctly rounded (round-to-nearest in effect), r = a - s * s; temporaries v51..v54 */
+#define TI_SQRTQ(sq, r, a)                                          \
+    "v_mul_f32 v51, 0x4f800000, " a "\n"                            \
+    "v_cmp_gt_f32 vcc, 0xf800000, " a "\n"                          \
+    "s_nop 1\n"                                                     \
+    "v_cndmask_b32 v51, " a ", v51, vcc\n"                          \
+    "v_sqrt_f32 v52, v51\n"                                         \
+    "s_nop 0\n"                                                     \
+    "v_add_u32 v53, -1, v52\n"                                      \
+    "v_fma_f32 v54, -v53, v52, v51\n"                               \
+    "v_cmp_ge_f32 s[46:47], 0, v54\n"                               \
+    "v_add_u32 v54, 1, v52\n"                                       \
+    "s_nop 0\n"                                                     \
+    "v_cndmask_b32 v53, v52, v53, s[46:47]\n"                       \
+    "v_fma_f32 v52, -v54, v52, v51\n"                               \
+    "v_cmp_lt_f32 s[46:47], 0, v52\n"                               \
+    "s_nop 1\n"                                                     \
+    "v_cndmask_b32 v52, v53, v54, s[46:47]\n"                       \
+    "v_mul_f32 v53, 0x37800000, v52\n"                              \
+    "v_cndmask_b32 v52, v52, v53, vcc\n"                            \
+    "v_cmp_class_f32 vcc, v51, s55\n"                               \
+    "s_nop 1\n"                                                     \
+    "v_cndmask_b32 " sq ", v52, v51, vcc\n"                         \
+    "v_fma_f32 " r ", -" sq ", " sq ", " a "\n"
 
 struct TileInterpResult {
     uint32_t result_slot;     /* slot named by the end clause */
@@ -343,6 +451,65 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "s_add_u32 s74, s74, 16\n"
             "s_add_u32 s78, s78, 1\n"
             TI_END
+            /* ---- i_div(v[36:37], v[38:39]) (device_math.hpp: operands of the two directed quotients by
+             *      selects, quotients in a round-to-nearest sandwich, moved one ulp by the residual's sign);
+             *      s[58:59]: lanes whose divisor contains zero ---- */
+            "L_idiv_%=:\n"
+            "s_movk_i32 s56, 0x1f8\n"
+            "s_movk_i32 s57, 0x198\n"
+            "v_cmp_gt_f32 s[40:41], 0, v37\n"                /* xn: x.hi < 0 */
+            "v_cmp_gt_f32 s[42:43], 0, v36\n"                /* x.lo < 0 */
+            "v_cmp_gt_f32 vcc, 0, v39\n"                     /* yn: y.hi < 0 */
+            "s_andn2_b64 s[42:43], s[42:43], s[40:41]\n"     /* xm */
+            "s_nop 0\n"
+            "v_cndmask_b32 v42, v36, v37, vcc\n"             /* a1 = yn ? x.hi : x.lo */
+            "v_cndmask_b32 v43, v37, v36, vcc\n"             /* a2 = yn ? x.lo : x.hi */
+            "v_cndmask_b32 v44, v38, v39, vcc\n"             /* ym = yn ? y.hi : y.lo */
+            "v_cndmask_b32 v45, v39, v44, s[42:43]\n"
+            "v_cndmask_b32 v45, v45, v38, s[40:41]\n"        /* b1 = xn ? y.lo : xm ? ym : y.hi */
+            "v_cndmask_b32 v46, v38, v44, s[42:43]\n"
+            "v_cndmask_b32 v46, v46, v39, s[40:41]\n"        /* b2 = xn ? y.hi : xm ? ym : y.lo */
+            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n"
+            "s_nop 0\n"
+            TI_DIVQ("v47", "v48", "v42", "v45")
+            TI_DIVQ("v49", "v50", "v43", "v46")
+            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1\n"
+            "s_nop 0\n"
+            TI_FIX_DOWN("v40", "v47", "v48", "v42", "v45")
+            TI_FIX_UP("v41", "v49", "v50", "v43", "v46")
+            "v_mov_b32 v51, 0xff800000\n"
+            "v_mov_b32 v52, 0x7f800000\n"
+            "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
+            "v_cndmask_b32 v41, v41, v52, s[58:59]\n"
+            TI_END
+            /* ---- i_sqrt(v[36:37]): x.hi < 0: NaN; lower bound 0 when x.lo <= 0 ---- */
+            "L_isqrt_%=:\n"
+            "s_movk_i32 s55, 0x260\n"
+            "s_movk_i32 s56, 0x1f8\n"
+            "v_cmp_ge_f32 vcc, 0, v36\n"                     /* x.lo <= 0 */
+            "v_cmp_gt_f32 s[58:59], 0, v37\n"                /* x.hi < 0 */
+            "s_nop 0\n"
+            "v_cndmask_b32 v42, v36, 0, vcc\n"               /* a */
+            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n"
+            "s_nop 0\n"
+            TI_SQRTQ("v47", "v48", "v42")
+            TI_SQRTQ("v49", "v50", "v37")
+            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1\n"
+            "s_nop 0\n"
+            "v_cmp_class_f32 s[44:45], v47, s56\n"           /* lo = finite(s1) && r1 < 0 ? next_down(s1) : s1 */
+            "v_cmp_gt_f32 vcc, 0, v48\n"
+            "s_and_b64 s[44:45], s[44:45], vcc\n"
+            TI_NEXT_DOWN("v47", "v51", "v52", "v53")
+            "v_cndmask_b32 v40, v47, v52, s[44:45]\n"
+            "v_cmp_class_f32 s[44:45], v49, s56\n"           /* hi = finite(s2) && r2 > 0 ? next_up(s2) : s2 */
+            "v_cmp_lt_f32 vcc, 0, v50\n"
+            "s_and_b64 s[44:45], s[44:45], vcc\n"
+            TI_NEXT_UP("v49", "v51", "v52", "v53")
+            "v_cndmask_b32 v41, v49, v52, s[44:45]\n"
+            "v_mov_b32 v51, 0x7fc00000\n"
+            "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
+            "v_cndmask_b32 v41, v41, v51, s[58:59]\n"
+            TI_END
             /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
@@ -366,7 +533,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
               "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
               "s87", "s88", "s89", "s92", "s93", "s94", "s95", "s96",
               "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-              "v48", "v49");
+              "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
         /* sqrt, division, exp, log, trigonometry (and anything that is not an opcode) */
