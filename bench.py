@@ -80,11 +80,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # MPR_BENCH_BACKEND=gloo + MPR_BENCH_SHARE_GPU=1: development check of the N > 1 code path on a
+    # box with a single GPU (all ranks on device 0, gather through gloo); not a measurement
+    share = os.environ.get("MPR_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MPR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
@@ -113,11 +122,16 @@ def main():
 
         def make_buffer(n):
             t = torch.empty(n, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
             return t, t.data_ptr()
 
+        # the collective is ordered after the context's stream (render + pack) and the unpack after
+        # the collective, all on the device: no host synchronisation inside a frame
+        ctx_stream = torch.cuda.ExternalStream(ctx.stream)
+
         def all_gather(out, inp):
-            dist.all_gather_into_tensor(out, inp)
-            torch.cuda.synchronize()
+            with torch.cuda.stream(ctx_stream):
+                dist.all_gather_into_tensor(out, inp)
 
         tpr = TileParallelRenderer(ctx, m, rank, world, make_buffer, all_gather, dim=3)
         tpr.plan(tape, T)
@@ -134,6 +148,18 @@ def main():
             kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
         frames_timed[0] += 1
 
+    verified = None
+    if world > 1 and os.environ.get("MPR_BENCH_VERIFY") == "1":
+        # the gathered frame of every rank against a full single-GPU frame
+        frame()
+        got_h, got_n = ctx.image.copy(), ctx.normals.copy()
+        ref = m.Context(S, device=local_rank)
+        ref.render3D(tape, T)
+        verified = bool((got_h == ref.image).all() and (got_n == ref.normals).all())
+        ref.close()
+        vt = torch.tensor([1 if verified else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(vt, op=dist.ReduceOp.MIN)
+        verified = bool(vt.item())
     for _ in range(args.warmup):
         frame()
     barrier()
@@ -203,6 +229,8 @@ def main():
                        "voxel_tiles": int(work["voxel_tiles"])},
             "roofline": roofline,
         }
+        if verified is not None:
+            out["verified_against_single_gpu"] = verified
 
     # ---- side measurement: prospero render2D 1024^2 (the published V100 number's config) ----
     if rank == 0 and world == 1 and not args.no_also:

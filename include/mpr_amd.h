@@ -128,6 +128,21 @@ int mpr_render3d_part(mpr_context* ctx, const mpr_tape* tape, const float mat4_c
                       const int32_t* owner, int32_t rank);
 int mpr_render2d_part(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
                       float z, const int32_t* owner, int32_t rank);
+/* the same, not waiting for the frame (mpr_ctx_sync, or any blocking call, does) */
+int mpr_render3d_part_async(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmajor[16],
+                            const int32_t* owner, int32_t rank);
+int mpr_render2d_part_async(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9], float z,
+                            const int32_t* owner, int32_t rank);
+/* Gather with a resident plan, for the steady state of a multi-GPU loop: mpr_gather_plan uploads
+ * the ownership table once (and derives every column's position inside its owner's pack); then
+ * per frame mpr_render3d_part_async -> mpr_pack_planned_async -> the caller's all-gather, ordered
+ * after the context's stream (mpr_ctx_stream) -> mpr_unpack_planned_async (one launch for all
+ * foreign columns; rank r's pack at dev_in_all + r * capacity_cols * 4096 * (with_normals ? 2 : 1)
+ * ints) -> mpr_ctx_sync.  Nothing is uploaded and the host never waits in between. */
+int mpr_gather_plan(mpr_context* ctx, const int32_t* owner, int32_t rank, int32_t world, int32_t capacity_cols,
+                    int32_t with_normals);
+int mpr_pack_planned_async(mpr_context* ctx, void* dev_out);
+int mpr_unpack_planned_async(mpr_context* ctx, const void* dev_in_all);
 /* Deterministic column -> rank deal (identical on every rank).  weights may be NULL
  * (round-robin) or (S/64)^2 non-negative work estimates (longest-processing-time first). */
 int mpr_partition_columns(int32_t columns, const float* weights, int32_t nranks, int32_t* owner);

@@ -137,6 +137,11 @@ def lib():
     L.mpr_render3d_part.argtypes = [vp, vp, vp, vp, i32]
     L.mpr_render2d_part.argtypes = [vp, vp, vp, f32, vp, i32]
     L.mpr_partition_columns.argtypes = [i32, vp, i32, vp]
+    L.mpr_render3d_part_async.argtypes = [vp, vp, vp, vp, i32]
+    L.mpr_render2d_part_async.argtypes = [vp, vp, vp, f32, vp, i32]
+    L.mpr_gather_plan.argtypes = [vp, vp, i32, i32, i32, i32]
+    L.mpr_pack_planned_async.argtypes = [vp, vp]
+    L.mpr_unpack_planned_async.argtypes = [vp, vp]
     L.mpr_pack_columns.argtypes = [vp, vp, i32, i32, i32, vp]
     L.mpr_unpack_columns.argtypes = [vp, vp, i32, i32, i32, vp]
     L.mpr_read_filled.argtypes = [vp, i32, vp]
@@ -424,15 +429,34 @@ class Context:
         m = colmajor(np.eye(3) if mat is None else mat, 3)
         _check(lib().mpr_render2d_brute(self._h, tape._h, _ptr(m), z))
 
-    def render3D_part(self, tape, mat, owner, rank):
+    def render3D_part(self, tape, mat, owner, rank, blocking=True):
         m = colmajor(mat, 4)
         own = np.ascontiguousarray(owner, dtype=np.int32)
-        _check(lib().mpr_render3d_part(self._h, tape._h, _ptr(m), _ptr(own), rank))
+        fn = lib().mpr_render3d_part if blocking else lib().mpr_render3d_part_async
+        _check(fn(self._h, tape._h, _ptr(m), _ptr(own), rank))
 
-    def render2D_part(self, tape, mat, z, owner, rank):
+    def render2D_part(self, tape, mat, z, owner, rank, blocking=True):
         m = colmajor(mat, 3)
         own = np.ascontiguousarray(owner, dtype=np.int32)
-        _check(lib().mpr_render2d_part(self._h, tape._h, _ptr(m), z, _ptr(own), rank))
+        fn = lib().mpr_render2d_part if blocking else lib().mpr_render2d_part_async
+        _check(fn(self._h, tape._h, _ptr(m), z, _ptr(own), rank))
+
+    def gather_plan(self, owner, rank, world, capacity_cols, with_normals):
+        """Make the ownership table resident: afterwards pack_planned / unpack_planned need no
+        uploads and no host synchronisation (the steady state of the multi-GPU loop)."""
+        own = np.ascontiguousarray(owner, dtype=np.int32)
+        _check(lib().mpr_gather_plan(self._h, _ptr(own), rank, world, capacity_cols, int(with_normals)))
+
+    def pack_planned(self, dev_ptr):
+        _check(lib().mpr_pack_planned_async(self._h, ctypes.c_void_p(dev_ptr)))
+
+    def unpack_planned(self, dev_ptr):
+        _check(lib().mpr_unpack_planned_async(self._h, ctypes.c_void_p(dev_ptr)))
+
+    @property
+    def stream(self):
+        """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return lib().mpr_ctx_stream(self._h)
 
     def pack_columns(self, owner, rank, capacity_cols, with_normals, dev_ptr):
         own = np.ascontiguousarray(owner, dtype=np.int32)

@@ -56,6 +56,12 @@ struct mpr_context {
     size_t masks_cap = 0;
 
     int* owner_dev = nullptr;          /* column ownership, (S/64)^2 */
+    std::vector<int32_t> owner_host;   /* what owner_dev holds (uploads are skipped when unchanged) */
+    uint64_t owner_gen = 0;            /* bumped whenever owner_host changes */
+    int my_cols_rank = -1, my_ncols = 0;
+    uint64_t my_cols_gen = ~0ull;      /* col_list_dev holds rank my_cols_rank's columns of generation my_cols_gen */
+    int* slot_dev = nullptr;           /* gather plan: position of a column inside its owner's pack */
+    int plan_rank = -1, plan_world = 0, plan_capacity = 0, plan_normals = 0;
     int* col_list_dev = nullptr;
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
 
@@ -192,6 +198,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipMalloc((void**)&c->counters, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long)));
     CT(hipMalloc((void**)&c->owner_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipMalloc((void**)&c->col_list_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
+    CT(hipMalloc((void**)&c->slot_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(unsigned long long), hipHostMallocDefault));
     CT(hipMemsetAsync(c->normals, 0, (size_t)S * S * sizeof(uint32_t), c->stream));
     for (int i = 0; i < 4; ++i) CT(hipMemsetAsync(c->filled[i], 0, c->filled_n[i] * sizeof(int), c->stream));
@@ -228,6 +235,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->owner_dev) (void)hipFree(c->owner_dev);
     if (c->col_list_dev) (void)hipFree(c->col_list_dev);
+    if (c->slot_dev) (void)hipFree(c->slot_dev);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (auto& t : c->timings) {
         (void)hipEventDestroy(t.start);
@@ -291,8 +299,11 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         HIP_TRY(hipMemsetAsync(c->counters, 0, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long), c->stream));
     if (owner) {
         const size_t cols = (size_t)(c->S / 64) * (c->S / 64);
-        HIP_TRY(hipMemcpyAsync(c->owner_dev, owner, cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->owner_host.size() != cols || std::memcmp(c->owner_host.data(), owner, cols * sizeof(int32_t)) != 0) {
+            c->owner_host.assign(owner, owner + cols);
+            c->owner_gen++;
+            HIP_TRY(hipMemcpyAsync(c->owner_dev, c->owner_host.data(), cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        }
     }
     c->timings_used = 0;
     std::memset(&c->last, 0, sizeof(c->last));
@@ -490,6 +501,21 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.subtiles = c->tiles[1];
         n.microtiles = c->tiles[2];
         n.counters = cnt;
+        n.col_list = nullptr;
+        n.ncols = 0;
+        if (owner && c->normals_asm && !cnt) {
+            /* owned columns only; the list is rebuilt when the ownership table or the rank changes */
+            if (c->my_cols_rank != rank || c->my_cols_gen != c->owner_gen) {
+                std::vector<int> list;
+                for (size_t i = 0; i < c->owner_host.size(); ++i) if (c->owner_host[i] == rank) list.push_back((int)i);
+                c->my_ncols = (int)list.size();
+                if (!list.empty()) HIP_TRY(hipMemcpy(c->col_list_dev, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
+                c->my_cols_rank = rank;
+                c->my_cols_gen = c->owner_gen;
+            }
+            n.col_list = c->col_list_dev;
+            n.ncols = c->my_ncols;
+        }
         TimedScope ts(c, "eval_pixels_d");
         if (c->normals_asm && !cnt) mprk::launch_eval_normals_asm(s, n);
         else mprk::launch_eval_normals(s, n);
@@ -537,6 +563,16 @@ int mpr_render3d_part(mpr_context* c, const mpr_tape* t, const float m[16], cons
     if (!owner) return mpr::set_error(MPR_ERR_INVALID, "null owner table");
     return render_frame(c, t, 3, m, 0.0f, owner, rank, false, true);
 }
+int mpr_render3d_part_async(mpr_context* c, const mpr_tape* t, const float m[16], const int32_t* owner, int32_t rank)
+{
+    if (!owner) return mpr::set_error(MPR_ERR_INVALID, "null owner table");
+    return render_frame(c, t, 3, m, 0.0f, owner, rank, false, false);
+}
+int mpr_render2d_part_async(mpr_context* c, const mpr_tape* t, const float m[9], float z, const int32_t* owner, int32_t rank)
+{
+    if (!owner) return mpr::set_error(MPR_ERR_INVALID, "null owner table");
+    return render_frame(c, t, 2, m, z, owner, rank, false, false);
+}
 int mpr_render2d_part(mpr_context* c, const mpr_tape* t, const float m[9], float z, const int32_t* owner, int32_t rank)
 {
     if (!owner) return mpr::set_error(MPR_ERR_INVALID, "null owner table");
@@ -550,6 +586,7 @@ static int column_list(mpr_context* c, const int32_t* owner, int rank, int capac
     for (int i = 0; i < cols; ++i) if (owner[i] == rank) list.push_back(i);
     if ((int)list.size() > capacity) return mpr::set_error(MPR_ERR_INVALID, "capacity_cols too small for this rank");
     *ncols = (int)list.size();
+    c->my_cols_rank = -1;              /* col_list_dev is about to hold this list instead of the normals pass's */
     if (!list.empty()) {
         HIP_TRY(hipMemcpyAsync(c->col_list_dev, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -581,6 +618,49 @@ int mpr_unpack_columns(mpr_context* c, const int32_t* owner, int32_t rank, int32
     mprk::launch_unpack(c->stream, c->filled[3], c->normals, c->S, c->col_list_dev, ncols, capacity_cols, with_normals, (const int*)dev_in);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPR_OK;
+}
+
+/* ---- one-plan gather: no per-frame uploads or host synchronisation ---- */
+int mpr_gather_plan(mpr_context* c, const int32_t* owner, int32_t rank, int32_t world, int32_t capacity_cols, int32_t with_normals)
+{
+    if (!c || !owner || world < 1 || rank < 0 || rank >= world) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t cols = (size_t)(c->S / 64) * (c->S / 64);
+    std::vector<int32_t> slot(cols, 0), fill((size_t)world, 0);
+    for (size_t i = 0; i < cols; ++i) {
+        if (owner[i] < 0 || owner[i] >= world) return mpr::set_error(MPR_ERR_INVALID, "owner entry out of range");
+        slot[i] = fill[(size_t)owner[i]]++;
+        if (slot[i] >= capacity_cols) return mpr::set_error(MPR_ERR_INVALID, "capacity_cols too small");
+    }
+    c->owner_host.assign(owner, owner + cols);
+    c->owner_gen++;
+    HIP_TRY(hipMemcpyAsync(c->owner_dev, c->owner_host.data(), cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->slot_dev, slot.data(), cols * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));        /* the host vectors go out of scope */
+    c->plan_rank = rank;
+    c->plan_world = world;
+    c->plan_capacity = capacity_cols;
+    c->plan_normals = with_normals;
+    return MPR_OK;
+}
+int mpr_pack_planned_async(mpr_context* c, void* dev_out)
+{
+    if (!c || !dev_out || c->plan_rank < 0) return mpr::set_error(MPR_ERR_INVALID, "no gather plan");
+    HIP_TRY(hipSetDevice(c->device));
+    mprk::launch_pack_planned(c->stream, c->filled[3], c->normals, c->S, c->owner_dev, c->slot_dev, c->plan_rank, c->plan_capacity,
+                              c->plan_normals, (int*)dev_out);
+    HIP_TRY(hipGetLastError());
+    return MPR_OK;
+}
+int mpr_unpack_planned_async(mpr_context* c, const void* dev_in_all)
+{
+    if (!c || !dev_in_all || c->plan_rank < 0) return mpr::set_error(MPR_ERR_INVALID, "no gather plan");
+    HIP_TRY(hipSetDevice(c->device));
+    mprk::launch_unpack_planned(c->stream, c->filled[3], c->normals, c->S, c->owner_dev, c->slot_dev, c->plan_rank, c->plan_capacity,
+                                c->plan_normals, (const int*)dev_in_all);
+    HIP_TRY(hipGetLastError());
+    c->frame_pending = true;
     return MPR_OK;
 }
 

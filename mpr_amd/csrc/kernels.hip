@@ -608,6 +608,38 @@ __global__ void k_unpack_columns(int* __restrict__ heights, uint32_t* __restrict
     if (with_normals) normals[x + y * S] = (uint32_t)in[(size_t)capacity * 4096 + src];
 }
 
+/* the same with a resident plan (owner[col], slot[col] = index of the column inside its owner's
+ * pack): one launch over all columns, nothing to upload per frame.  Rank r's pack sits at
+ * in_all + r * capacity * 4096 * (with_normals ? 2 : 1). */
+__global__ void k_pack_planned(const int* __restrict__ heights, const uint32_t* __restrict__ normals, int S,
+                               const int* __restrict__ owner, const int* __restrict__ slot, int rank, int capacity,
+                               int with_normals, int* __restrict__ out)
+{
+    const int col = blockIdx.y;
+    if (owner[col] != rank) return;
+    const int cols = S / 64;
+    const int x = (col % cols) * 64 + threadIdx.x;
+    const int y = (col / cols) * 64 + blockIdx.x;
+    const size_t dst = (size_t)slot[col] * 4096 + blockIdx.x * 64 + threadIdx.x;
+    out[dst] = heights[x + y * S];
+    if (with_normals) out[(size_t)capacity * 4096 + dst] = (int)normals[x + y * S];
+}
+__global__ void k_unpack_planned(int* __restrict__ heights, uint32_t* __restrict__ normals, int S,
+                                 const int* __restrict__ owner, const int* __restrict__ slot, int rank, int capacity,
+                                 int with_normals, const int* __restrict__ in_all)
+{
+    const int col = blockIdx.y;
+    const int r = owner[col];
+    if (r == rank) return;
+    const int cols = S / 64;
+    const int x = (col % cols) * 64 + threadIdx.x;
+    const int y = (col / cols) * 64 + blockIdx.x;
+    const size_t per_rank = (size_t)capacity * 4096 * (with_normals ? 2 : 1);
+    const size_t src = (size_t)r * per_rank + (size_t)slot[col] * 4096 + blockIdx.x * 64 + threadIdx.x;
+    heights[x + y * S] = in_all[src];
+    if (with_normals) normals[x + y * S] = (uint32_t)in_all[(size_t)capacity * 4096 + src];
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* primitive test kernels (parity fuzzing against the oracle)                            */
 /* ------------------------------------------------------------------------------------ */
@@ -756,6 +788,18 @@ void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int
     if (ncols <= 0) return;
     hipLaunchKernelGGL(k_pack_columns, dim3(64, ncols), dim3(64), 0, s, heights, normals, S, col_list, ncols,
                        capacity, with_normals, out);
+}
+void launch_pack_planned(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* owner, const int* slot,
+                         int rank, int capacity, int with_normals, int* out)
+{
+    const int cols = (S / 64) * (S / 64);
+    hipLaunchKernelGGL(k_pack_planned, dim3(64, cols), dim3(64), 0, s, heights, normals, S, owner, slot, rank, capacity, with_normals, out);
+}
+void launch_unpack_planned(hipStream_t s, int* heights, uint32_t* normals, int S, const int* owner, const int* slot, int rank,
+                           int capacity, int with_normals, const int* in_all)
+{
+    const int cols = (S / 64) * (S / 64);
+    hipLaunchKernelGGL(k_unpack_planned, dim3(64, cols), dim3(64), 0, s, heights, normals, S, owner, slot, rank, capacity, with_normals, in_all);
 }
 void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const int* col_list, int ncols,
                    int capacity, int with_normals, const int* in)

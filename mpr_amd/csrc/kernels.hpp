@@ -101,6 +101,8 @@ struct NormalArgs {
     const mpr_tile_node* subtiles;
     const mpr_tile_node* microtiles;
     unsigned long long* counters;
+    const int* col_list;       /* multi-GPU: the 64 x 64 columns this rank owns (null: all) ... */
+    int ncols;                 /* ... and how many */
 };
 
 void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
@@ -124,6 +126,10 @@ void launch_eval_normals(hipStream_t s, const NormalArgs& a);
 void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a);   /* kernels_normals_asm.hip; no counters */
 void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
                  int ncols, int capacity, int with_normals, int* out);
+void launch_pack_planned(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* owner, const int* slot,
+                         int rank, int capacity, int with_normals, int* out);
+void launch_unpack_planned(hipStream_t s, int* heights, uint32_t* normals, int S, const int* owner, const int* slot, int rank,
+                           int capacity, int with_normals, const int* in_all);
 void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const int* col_list, int ncols,
                    int capacity, int with_normals, const int* in);
 void launch_test_interval_asm(hipStream_t s, const uint64_t* tape, int n, const float* a_lo, const float* a_hi,

@@ -247,7 +247,16 @@ k_eval_normals_asm(NormalArgs a)
     unsigned char* const myslot = smem + lane * 4;
     const int S = a.size;
     const int fside = S / 4;                                  /* footprints per side */
-    const int fxi = blockIdx.x % fside, fyi = blockIdx.x / fside;
+    int fxi, fyi;
+    if (a.col_list) {
+        /* a rank of a multi-GPU frame visits only the columns it owns: 256 footprints per column */
+        const int col = a.col_list[blockIdx.x >> 8], f = blockIdx.x & 255, cols = S / 64;
+        fxi = (col % cols) * 16 + (f & 15);
+        fyi = (col / cols) * 16 + (f >> 4);
+    } else {
+        fxi = blockIdx.x % fside;
+        fyi = blockIdx.x / fside;
+    }
     const int pix = lane >> 2, comp = lane & 3;
     const bool isv = comp == 3;
     const int px = fxi * 4 + (pix & 3), py = fyi * 4 + (pix >> 2);
@@ -323,7 +332,9 @@ k_eval_normals_asm(NormalArgs a)
 void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
 {
     const int fside = a.size / 4;
-    hipLaunchKernelGGL(k_eval_normals_asm, dim3(fside * fside), dim3(64), (size_t)a.nslots * 256, s, a);
+    const int groups = a.col_list ? a.ncols * 256 : fside * fside;
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_eval_normals_asm, dim3(groups), dim3(64), (size_t)a.nslots * 256, s, a);
 }
 
 }  // namespace mprk

@@ -68,6 +68,10 @@ class TileParallelRenderer:
         self.send, self.send_ptr = self.make_buffer(per_rank)
         self.recv, self.recv_ptr = self.make_buffer(per_rank * self.world)
         self.per_rank = per_rank
+        # steady-state path: resident plan, one pack and one unpack launch, no host waits in between
+        self.planned = hasattr(self.ctx, "gather_plan")
+        if self.planned:
+            self.ctx.gather_plan(self.owner, self.rank, self.world, self.capacity, self.with_normals)
 
     def render(self, tape, mat, z=0.0):
         """One frame: afterwards ctx.image / ctx.normals hold the complete result on every rank."""
@@ -76,6 +80,18 @@ class TileParallelRenderer:
                 self.ctx.render3D(tape, mat)
             else:
                 self.ctx.render2D(tape, mat, z)
+            return
+        if self.planned:
+            # everything is enqueued on the context's stream; `all_gather` must order the collective
+            # after that stream (bench.py runs it under torch.cuda.stream(ExternalStream(ctx.stream)))
+            if self.dim == 3:
+                self.ctx.render3D_part(tape, mat, self.owner, self.rank, blocking=False)
+            else:
+                self.ctx.render2D_part(tape, mat, z, self.owner, self.rank, blocking=False)
+            self.ctx.pack_planned(self.send_ptr)
+            self.all_gather(self.recv, self.send)
+            self.ctx.unpack_planned(self.recv_ptr)
+            self.ctx.sync()
             return
         if self.dim == 3:
             self.ctx.render3D_part(tape, mat, self.owner, self.rank)

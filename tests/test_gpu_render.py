@@ -232,6 +232,53 @@ def test_column_partition_pack_unpack(mpr, orc, tapes):
         ctxs[r].close()
 
 
+def test_planned_gather_through_the_renderer(mpr, tapes):
+    """The steady-state multi-GPU loop (resident plan, asynchronous frame, one pack and one unpack
+    launch, collective ordered on the context's stream) on one device: three TileParallelRenderers
+    play ranks 0..2, the "all-gather" concatenates their packs with torch copies issued on each
+    context's own stream.  Every rank ends up with the single-GPU frame."""
+    import torch
+    from mpr_amd.multigpu import TileParallelRenderer
+    tape = tapes("bear")
+    S, world = 256, 3
+    T = view3()
+    full = mpr.Context(S)
+    full.render3D(tape, T)
+    want_h, want_n = full.image, full.normals
+    full.close()
+    ctxs = [mpr.Context(S) for _ in range(world)]
+    sends = {}
+
+    def make_buffer(n):
+        t = torch.zeros(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        return t, t.data_ptr()
+
+    rs = []
+    for r in range(world):
+        def all_gather(out, inp, r=r):
+            sends[r] = (out, inp)
+        tpr = TileParallelRenderer(ctxs[r], mpr, r, world, make_buffer, all_gather, dim=3)
+        tpr.plan(tape, T)
+        rs.append(tpr)
+    assert all(np.array_equal(rs[0].owner, t.owner) for t in rs) and rs[0].planned
+    # frame, by hand in the order render() uses, with the collective emulated after all packs exist
+    for r, t in enumerate(rs):
+        ctxs[r].render3D_part(tape, T, t.owner, r, blocking=False)
+        ctxs[r].pack_planned(t.send_ptr)
+    for r, t in enumerate(rs):
+        for o, u in enumerate(rs):
+            ctxs[o].sync()
+            with torch.cuda.stream(torch.cuda.ExternalStream(ctxs[r].stream)):
+                t.recv[o * t.per_rank:(o + 1) * t.per_rank].copy_(u.send)
+        ctxs[r].unpack_planned(t.recv_ptr)
+        ctxs[r].sync()
+        assert np.array_equal(ctxs[r].image, want_h)
+        assert np.array_equal(ctxs[r].normals, want_n)
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("k", [1, 2, 4])
 def test_grouped_float_pass_is_bit_identical(mpr, tapes, k, monkeypatch):
     """MPR_VOXEL_K: the experimental grouped float pass (K children walk the group's tape with
