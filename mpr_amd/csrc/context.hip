@@ -65,6 +65,11 @@ struct mpr_context {
     int* col_list_dev = nullptr;
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
 
+    bool voxel_pairs = false;          /* float pass: sibling tiles on a common tape two at a time (experiment, MPR_VOXEL_PAIRS=1;
+                                          measured slower than the single-tile interpreter) */
+    mpr_tile_node* vox_singles = nullptr;
+    int4* vox_pairs = nullptr;
+    size_t vox_singles_cap = 0, vox_pairs_cap = 0;
     bool normals_asm = true;           /* normals pass interpreter: gfx950 assembly (default) or compiled (MPR_NORMALS_ASM=0) */
     bool voxel_asm = true;             /* float pass interpreter: gfx950 assembly (default) or the compiled C++ one */
     int voxel_k = 0;                   /* float pass: 0 = one wave per smallest tile walking its own sub-tape (default);
@@ -168,6 +173,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_PAIRS")) c->voxel_pairs = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_K")) {
         const int k = atoi(e);
@@ -194,7 +200,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipMalloc((void**)&c->normals, (size_t)S * S * sizeof(uint32_t)));
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
-    CT(hipMalloc((void**)&c->num_active, sizeof(int)));
+    CT(hipMalloc((void**)&c->num_active, 4 * sizeof(int)));
     CT(hipMalloc((void**)&c->counters, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long)));
     CT(hipMalloc((void**)&c->owner_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipMalloc((void**)&c->col_list_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
@@ -241,6 +247,8 @@ void mpr_ctx_destroy(mpr_context* c)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    if (c->vox_singles) (void)hipFree(c->vox_singles);
+    if (c->vox_pairs) (void)hipFree(c->vox_pairs);
     if (c->sched_recs) (void)hipFree(c->sched_recs);
     if (c->sched_levels) (void)hipFree(c->sched_levels);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -273,7 +281,9 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         if (c->sched_ok) {
             const size_t rb = sc.recs.size() * sizeof(mpr::SchedRec), lb = sc.level_start.size() * sizeof(int32_t);
             if (rb > c->sched_recs_cap) {
-                if (c->sched_recs) (void)hipFree(c->sched_recs);
+                if (c->vox_singles) (void)hipFree(c->vox_singles);
+    if (c->vox_pairs) (void)hipFree(c->vox_pairs);
+    if (c->sched_recs) (void)hipFree(c->sched_recs);
                 c->sched_recs = nullptr;
                 c->sched_recs_cap = 0;
                 HIP_TRY(hipMalloc(&c->sched_recs, rb));
@@ -311,11 +321,14 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
     return MPR_OK;
 }
 
-static int read_active(mpr_context* c, int* out)
+/* out[0] survivors; out[1], out[2]: single tiles and pairs of the float pass (last stage with pairing) */
+static int read_active(mpr_context* c, int out[3])
 {
-    HIP_TRY(hipMemcpyAsync(c->h_pinned, c->num_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_pinned, c->num_active, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    *out = c->h_pinned[0];
+    out[0] = c->h_pinned[0];
+    out[1] = c->h_pinned[1];
+    out[2] = c->h_pinned[2];
     return MPR_OK;
 }
 
@@ -364,6 +377,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
 
     int count;
     int last_ngroups = 0, last_stage = -1;
+    bool pairing = false;
+    int n_singles = 0, n_pairs = 0;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
@@ -436,17 +451,29 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 mprk::launch_eval_tiles(s, dim, a);
             }
         }
-        HIP_TRY(hipMemsetAsync(c->num_active, 0, sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(c->num_active, 0, 4 * sizeof(int), s));
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
         if (rc) return rc;
+        /* last 3-D stage: siblings that share a tape are paired up for the float pass */
+        pairing = last && dim == 3 && c->voxel_pairs && c->voxel_asm && !cnt && nslots <= 128 && c->voxel_k == 0;
+        if (pairing) {
+            rc = ensure_buffer(&c->vox_singles, &c->vox_singles_cap, (size_t)std::max(count, 1));
+            if (rc) return rc;
+            rc = ensure_buffer(&c->vox_pairs, &c->vox_pairs_cap, (size_t)std::max(count, 2) / 2 + 1);
+            if (rc) return rc;
+        }
         if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
-            mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next]);
+            mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
+                                           pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr);
         }
-        int active = 0;
-        rc = read_active(c, &active);      /* the reference's blocking read-back (:1209, :1375) */
+        int act3[3] = {0, 0, 0};
+        rc = read_active(c, act3);         /* the reference's blocking read-back (:1209, :1375) */
         if (rc) return rc;
+        const int active = act3[0];
+        n_singles = act3[1];
+        n_pairs = act3[2];
         c->last.tiles_active[si] = active;
         {
             TimedScope ts(c, "copy_filled");
@@ -486,7 +513,21 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         v.counters = cnt;
         TimedScope ts(c, "eval_voxels_f");
         /* the assembly interpreter keeps no work counters: instrumented frames use the C++ one */
-        if (c->voxel_asm && !cnt) mprk::launch_eval_voxels_asm(s, dim, v);
+        if (pairing) {
+            /* pairs of siblings on a common tape, then the tiles with a tape of their own */
+            mprk::PairVoxelArgs pv;
+            pv.tape_ro = c->pool;
+            pv.image = c->filled[3];
+            pv.tps = v.tps;
+            pv.pairs = c->vox_pairs;
+            pv.count = n_pairs;
+            pv.nslots = nslots;
+            fill_mat(pv.mat, mat, 16);
+            mprk::launch_eval_voxel_pairs_asm(s, pv);
+            v.tiles = c->vox_singles;
+            v.count = n_singles;
+            mprk::launch_eval_voxels_asm(s, dim, v);
+        } else if (c->voxel_asm && !cnt) mprk::launch_eval_voxels_asm(s, dim, v);
         else mprk::launch_eval_voxels(s, dim, v);
     }
     if (dim == 3) {
@@ -968,13 +1009,17 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
     uint32_t immbits;
     memcpy(&immbits, &imm, 4);
     /* 64 clauses so that the interpreter's 63-clause block fetch stays inside the buffer */
-    /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding) */
+    /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding);
+     * 3..5: the same three through the two-tiles-per-wave interpreter (kernels_voxel_pair_asm.hip) */
+    const bool pair = variant >= 3;
+    if (pair) variant -= 3;
     const uint32_t lhs = variant == 1 ? 5 : 1, rhs = b ? (variant == 2 ? 5 : 2) : 0;
     uint64_t tape3[64] = {mpr_cl_make(0, 1, 2, 3, 0),
                           variant == 2 ? mpr_cl_make(MPR_OP_COPY_RHS, 5, 0, 2, 0) : mpr_cl_make(MPR_OP_COPY_LHS, 5, 1, 0, 0),
                           mpr_cl_make((uint32_t)op, 4, lhs, rhs, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
     HIP_TRY(hipMemcpy(dt.p, tape3, sizeof(tape3), hipMemcpyHostToDevice));
-    mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
+    if (pair) mprk::launch_test_float_pair_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
+    else mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));

@@ -491,7 +491,7 @@ template <int DIM, bool LAST>
 __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
-                    mpr_tile_node* __restrict__ out)
+                    mpr_tile_node* __restrict__ out, mpr_tile_node* __restrict__ singles, int4* __restrict__ pairs)
 {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -513,22 +513,39 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
     /* one atomic per 1024 tiles: same-address atomics serialise at ~12 ns each on this part, and the
      * last stage of a 1024^3 frame has 1.3 M tiles.  Waves keep their order inside the block, so
      * the survivors of one sibling group (= one wave) stay contiguous. */
-    __shared__ int wave_count[16], wave_base[16];
+    __shared__ int wave_count[3][16], wave_base[3][16];
     const int wave = threadIdx.x >> 6;
-    if (lane == 0) wave_count[wave] = __popcll(mask);
+    /* Last stage, float pass in pairs (kernels_voxel_pair_asm.hip): survivors of one sibling group
+     * (= this wave) that still carry the group's common tape — the smallest tape index among them;
+     * a tile's own shortened tape is always allocated later — are paired up; everything else, and
+     * the odd one out, goes to the single-tile list. */
+    uint64_t shared = 0;
+    if (LAST && pairs) {
+        int t = active ? n.tape : 0x7FFFFFFF;
+        for (int off = 32; off > 0; off >>= 1) t = min(t, __shfl_xor(t, off));
+        shared = ballot(active && n.tape == t);
+        if (__popcll(shared) & 1) shared &= ~(1ull << (63 - __builtin_clzll(shared)));   /* keep an even number */
+    }
+    const uint64_t single_mask = mask & ~shared;
+    if (lane == 0) {
+        wave_count[0][wave] = __popcll(mask);
+        wave_count[1][wave] = __popcll(single_mask);
+        wave_count[2][wave] = __popcll(shared) / 2;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
         int total = 0;
         const int nw = (blockDim.x + 63) >> 6;
         for (int w = 0; w < nw; ++w) {
-            wave_base[w] = total;
-            total += wave_count[w];
+            wave_base[k][w] = total;
+            total += wave_count[k][w];
         }
-        const int b0 = total ? atomicAdd(num_active, total) : 0;
-        for (int w = 0; w < nw; ++w) wave_base[w] += b0;
+        const int b0 = total ? atomicAdd(num_active + k, total) : 0;
+        for (int w = 0; w < nw; ++w) wave_base[k][w] += b0;
     }
     __syncthreads();
-    const int base = wave_base[wave];
+    const int base = wave_base[0][wave];
     const int next = active ? base + rank_in(mask, lane) : -1;
     if (valid) tiles[gidx].next = LAST ? -1 : next;   /* copy_active_tiles resets next (:650) */
     if (LAST) {
@@ -538,6 +555,16 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
             o.tape = n.tape;
             o.next = -1;
             out[next] = o;
+            if (pairs) {
+                if ((shared >> lane) & 1) {
+                    const int r = rank_in(shared, lane);
+                    int* const item = reinterpret_cast<int*>(&pairs[wave_base[2][wave] + r / 2]);
+                    item[r & 1] = n.position;
+                    if ((r & 1) == 0) { item[2] = n.tape; item[3] = 0; }
+                } else {
+                    singles[wave_base[1][wave] + rank_in(single_mask, lane)] = o;
+                }
+            }
         }
         return;
     }
@@ -765,15 +792,15 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     }
 }
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
-                              const int* image, int* num_active, mpr_tile_node* out)
+                              const int* image, int* num_active, mpr_tile_node* out, mpr_tile_node* singles, int4* pairs)
 {
     const dim3 g((count + 1023) / 1024), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
     }
 }
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size)

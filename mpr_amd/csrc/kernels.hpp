@@ -74,6 +74,17 @@ struct VoxelArgs {
     unsigned long long* counters;
 };
 
+/* float pass over pairs of smallest tiles that share a tape (kernels_voxel_pair_asm.hip) */
+struct PairVoxelArgs {
+    const uint64_t* tape_ro;
+    int* image;
+    int tps;                   /* smallest tiles per side */
+    const int4* pairs;         /* {position 0, position 1, tape, -} */
+    int count;
+    int nslots;                /* <= 128 */
+    float mat[16];
+};
+
 /* float pass over sibling groups: K children of one group at a time walk the group's tape */
 struct GroupedVoxelArgs {
     const uint64_t* tape_ro;
@@ -111,13 +122,17 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
 bool wide_stage_fits(int nclauses);
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
-                              const int* image, int* num_active, mpr_tile_node* out);
+                              const int* image, int* num_active, mpr_tile_node* out,
+                              mpr_tile_node* singles = nullptr, int4* pairs = nullptr);
+/* num_active points at three counters: survivors, and (last stage with pairing) single tiles and pairs */
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
 /* same pass, interpreter in gfx950 assembly (kernels_voxel_asm.hip); no counters */
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
 
+void launch_eval_voxel_pairs_asm(hipStream_t s, const PairVoxelArgs& a);
+void launch_test_float_pair_asm(hipStream_t s, const uint64_t* tape, int n, const float* a, const float* b, float* out);
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
 size_t grouped_voxel_lds_bytes(int nslots, int k);
 void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a);   /* k = 1, 2 or 4 children per batch */

@@ -93,13 +93,14 @@ def test_float_ops_bit_exact(mpr, orc, opname, kind):
         assert bad.size == 0, (opname, kind, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:5]])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
 @pytest.mark.parametrize("opname", INTERVAL_OPS)
 def test_float_ops_assembly_interpreter_bit_exact(mpr, orc, opname, kind, variant):
     """Every opcode through the float pass's assembly interpreter (short tapes): same bits as the
     oracle, including NaN / inf / subnormal / signed-zero operands, in all three handler tables
-    (operands from the slot file; lhs forwarded; rhs forwarded)."""
+    (operands from the slot file; lhs forwarded; rhs forwarded) of the single-tile interpreter
+    (variants 0..2) and of the two-tiles-per-wave one with packed FP32 arithmetic (3..5)."""
     op = mpr.OP[opname]
     rng = np.random.default_rng(zlib.crc32((opname + kind + "f").encode()))
     a = gen_floats(rng, N, kind)

@@ -371,3 +371,22 @@ def test_assembly_normals_pass_matches_compiled_one(mpr, tapes, name, S, monkeyp
     assert bad.size == 0, (bad.size, [(hex(a.normals.ravel()[i]), hex(b.normals.ravel()[i])) for i in bad[:5]])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("name,S", [("bear", 256), ("architecture", 256), ("involute_gear_3d", 128), ("trig", 128)])
+def test_paired_float_pass_matches_single_tile_one(mpr, tapes, name, S, monkeypatch):
+    """Sibling tiles that share a tape go through the float pass two at a time (packed FP32,
+    kernels_voxel_pair_asm.hip); MPR_VOXEL_PAIRS=0 sends every tile through the single-tile
+    interpreter.  Same heightmap and normals."""
+    tape = tapes(name)
+    monkeypatch.setenv("MPR_VOXEL_PAIRS", "0")
+    a = mpr.Context(S)
+    monkeypatch.setenv("MPR_VOXEL_PAIRS", "1")
+    b = mpr.Context(S)
+    for ctx in (a, b):
+        ctx.render3D(tape, view3())
+    assert a.image.any()
+    assert np.array_equal(a.image, b.image)
+    assert np.array_equal(a.normals, b.normals)
+    a.close()
+    b.close()
