@@ -9,9 +9,9 @@
  *     ctx.stages[3].filled[i], ctx.normals[i], ctx.stages[k].tiles[i],
  *     ctx.stages[k].tile_array_size, ctx.tape_data[j], *ctx.tape_index
  *
- * The reference exposes managed-memory pointers; here the members are host mirrors that are
- * refreshed by every render call (cheap next to a frame: S*S*8 bytes) or, for the bulky ones
- * (tiles, tape_data), on first access after a render.  Eigen is not required: Matrix3f /
+ * The reference exposes managed-memory pointers; here the members are host mirrors (Mirror<T>:
+ * operator[], get(), size()) fetched from the device on first access after a render, so a timing
+ * loop that only renders pays for nothing else.  Eigen is not required: Matrix3f /
  * Matrix4f below are minimal column-major matrices with Eigen's (row, col) indexing; an Eigen
  * matrix's .data() can be passed to the *_raw overloads directly.
  *
@@ -22,6 +22,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -121,6 +122,33 @@ inline Tree log(const Tree& a) { return Tree::unary(MPR_T_LOG, a); }
 
 namespace mpr {
 
+/* Host mirror of a device array that the reference exposes as a managed-memory Ptr<T[]>
+ * (inc/util.hpp): indexable, .get()-able, fetched from the device on first use after a render. */
+template <typename T>
+struct Mirror {
+    const T& operator[](size_t i) const { return fetch()[i]; }
+    const T* get() const { return fetch().data(); }
+    const T* data() const { return fetch().data(); }
+    size_t size() const { return fetch().size(); }
+    typename std::vector<T>::const_iterator begin() const { return fetch().begin(); }
+    typename std::vector<T>::const_iterator end() const { return fetch().end(); }
+    operator const std::vector<T>&() const { return fetch(); }
+    void invalidate() { valid = false; }
+    std::function<void(std::vector<T>&)> loader;
+
+private:
+    const std::vector<T>& fetch() const
+    {
+        if (!valid && loader) {
+            loader(cache);
+            valid = true;
+        }
+        return cache;
+    }
+    mutable std::vector<T> cache;
+    mutable bool valid = false;
+};
+
 struct Tape {
     explicit Tape(const libfive::Tree& tree)
     {
@@ -140,7 +168,7 @@ using TileNode = mpr_tile_node;
 struct Context;
 
 struct Tiles {
-    std::vector<int32_t> filled;      /* refreshed by every render call */
+    Mirror<int32_t> filled;           /* stages[3].filled: fetched on first use after a render */
     /* tiles / tile_array_size: fetched on demand */
     const std::vector<TileNode>& tile_list() const;
     size_t tile_array_size() const { return tile_list().size(); }
@@ -159,7 +187,20 @@ struct Context {
         for (int i = 0; i < 4; ++i) {
             stages[i].owner = this;
             stages[i].index = i;
+            mpr_context* const h = handle.get();
+            stages[i].filled.loader = [h, i](std::vector<int32_t>& v) {
+                const int32_t S = mpr_ctx_image_size(h);
+                const int32_t side = (i == 3) ? S : (i == 2 ? S / 4 : (i == 1 ? S / 16 : S / 64));
+                v.resize((size_t)side * side);
+                check(mpr_read_filled(h, i, v.data()));
+            };
         }
+        mpr_context* const h = handle.get();
+        normals.loader = [h](std::vector<uint32_t>& v) {
+            const int32_t S = mpr_ctx_image_size(h);
+            v.resize((size_t)S * S);
+            check(mpr_read_normals(h, v.data()));
+        };
     }
     void render2D(const Tape& tape, const Matrix3f& mat, const float z = 0.0f)
     {
@@ -192,21 +233,19 @@ struct Context {
 
     int32_t image_size_px;
     Tiles stages[4];
-    std::vector<uint32_t> normals;
+    Mirror<uint32_t> normals;
     int32_t tape_index = 0;
     std::shared_ptr<mpr_context> handle;
 
 private:
     friend struct Tiles;
-    void refresh(bool with_normals)
+    void refresh(bool)
     {
-        stages[3].filled.resize((size_t)image_size_px * image_size_px);
-        check(mpr_read_filled(handle.get(), 3, stages[3].filled.data()));
-        if (with_normals) {
-            normals.resize((size_t)image_size_px * image_size_px);
-            check(mpr_read_normals(handle.get(), normals.data()));
+        for (auto& s : stages) {
+            s.tiles_valid = false;
+            s.filled.invalidate();
         }
-        for (auto& s : stages) s.tiles_valid = false;
+        normals.invalidate();
         pool_valid = false;
         mpr_counters c;
         check(mpr_get_counters(handle.get(), &c));
@@ -234,14 +273,18 @@ struct Effects {
         check(mpr_effects_draw_shaded(handle.get(), ctx.handle.get()));
         refresh(ctx.image_size_px);
     }
-    std::vector<int32_t> image;       /* host mirror of Effects::image, refreshed by every draw */
+    Mirror<int32_t> image;            /* Effects::image: fetched on first use after a draw */
     std::shared_ptr<mpr_effects> handle;
 
 private:
     void refresh(int32_t size)
     {
-        image.resize((size_t)size * size);
-        check(mpr_effects_read_image(handle.get(), image.data()));
+        mpr_effects* const h = handle.get();
+        image.loader = [h, size](std::vector<int32_t>& v) {
+            v.resize((size_t)size * size);
+            check(mpr_effects_read_image(h, v.data()));
+        };
+        image.invalidate();
     }
 };
 
