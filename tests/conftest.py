@@ -53,6 +53,15 @@ def tapes(mpr):
             t = mpr.tmin(mpr.sin(X * 3) + mpr.cos(Y * 2) * 0.5 + mpr.atan(Z + X) * 0.3 - 0.2,
                          mpr.tmax(mpr.exp(X) * 0.2 - mpr.log(Y * Y + 1.5) + mpr.asin(X * 0.5) * mpr.acos(Y * 0.5) * 0.1,
                                   mpr.tabs(Z) - 0.8 + X / (Y * Y + 2.0)))
+        elif name == "many_slots":    # > 128 simultaneously live values: every s_i is used by a product and, later, a sum
+            terms = [(X - (i % 13) * 0.11 + 0.6) * (Y + (i % 7) * 0.13 - 0.4) + Z * (0.01 * i) for i in range(150)]
+            prod = terms[0]
+            for s_ in terms[1:]:
+                prod = mpr.tmax(prod * 0.5, s_)
+            total = terms[0]
+            for s_ in terms[1:]:
+                total = total + s_
+            t = mpr.tmin(prod - 0.2, total * 0.01 - 0.05)
         else:
             t = mpr.model(name)
         cache[name] = mpr.Tape(t)

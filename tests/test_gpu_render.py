@@ -390,3 +390,13 @@ def test_paired_float_pass_matches_single_tile_one(mpr, tapes, name, S, monkeypa
     assert np.array_equal(a.normals, b.normals)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("dim,S", [(2, 128), (3, 128)])
+def test_tape_with_more_than_128_slots(mpr, orc, tapes, dim, S):
+    """More live values than the reference's kernels hold (128): the interval stages fall back to
+    the compiled forward / backward walks (the assembly ones address slots through a pre-doubled
+    byte), the active set spills to LDS; float and normals passes address up to 255 slots."""
+    tape = tapes("many_slots")
+    assert tape.num_slots > 128
+    compare_frame(mpr, orc, tape, dim, S, view2() if dim == 2 else view3())
