@@ -277,7 +277,11 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         c->tape_len = len;
         /* the tape's level schedule for the wide first-stage kernel */
         const mpr::TapeSchedule& sc = tape->schedule;
-        c->sched_ok = sc.ok && mprk::wide_stage_fits(sc.nclauses);
+        /* level-parallel first stage only for DAGs that are wide enough to feed a wavefront: with a
+         * handful of clauses per level (bear: 544 clauses in 72 levels) the 64 tiles-per-wave walk,
+         * whose latency per clause the assembly interpreter cut to a third, is the faster one */
+        c->sched_ok = sc.ok && mprk::wide_stage_fits(sc.nclauses) &&
+                      sc.nclauses >= 12 * ((int)sc.level_start.size() - 1);
         if (c->sched_ok) {
             const size_t rb = sc.recs.size() * sizeof(mpr::SchedRec), lb = sc.level_start.size() * sizeof(int32_t);
             if (rb > c->sched_recs_cap) {
