@@ -91,7 +91,10 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
     TI_H(v, 2) LDL TI_AO TI_PREP WL "s_branch L_square_%=\n"                                                        \
     TI_H(v, 3) LDL TI_AO TI_PREP WL "s_branch L_isqrt_%=\n"                                                        \
     TI_H(v, 4) LDL TI_AO TI_PREP WL "v_xor_b32 v40, 0x80000000, v37\n v_xor_b32 v41, 0x80000000, v36\n" TI_END     \
-    TI_H(v, 5) TI_EXIT TI_H(v, 6) TI_EXIT TI_H(v, 7) TI_EXIT TI_H(v, 8) TI_EXIT TI_H(v, 9) TI_EXIT        \
+    /* i_sin / i_cos are the constant interval [-1, 1] (inc/gpu_interval.hpp:346-380) */                     \
+    TI_H(v, 5) TI_AO TI_PREP "v_mov_b32 v40, -1.0\n v_mov_b32 v41, 1.0\n" TI_END                            \
+    TI_H(v, 6) TI_AO TI_PREP "v_mov_b32 v40, -1.0\n v_mov_b32 v41, 1.0\n" TI_END                            \
+    TI_H(v, 7) TI_EXIT TI_H(v, 8) TI_EXIT TI_H(v, 9) TI_EXIT                                                \
     TI_H(v, 10) TI_EXIT                                                                                     \
     TI_H(v, 11) LDL TI_AO TI_PREP WL "s_branch L_abs_%=\n"                                                          \
     TI_H(v, 12) TI_EXIT                                                                                     \
