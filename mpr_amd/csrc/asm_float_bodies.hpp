@@ -138,3 +138,57 @@
     "s_nop 1\n" \
     "v_cndmask_b32 v37, v37, v35, vcc\n" \
     "L_logdone_%=:\n"
+
+/* v37 = mpr_sinf(v35), v36 = mpr_cosf(v35) (include/mpr_fmath.h): double-precision Cody-Waite
+ * reduction by pi/2, the two Cephes polynomials, quadrant by selects instead of the switch.
+ * (long long)j & 3 is taken as (int)j & 3: |x| < 2^31 there, so j fits 32 bits.  Temporaries
+ * v[38:41] (double), v42..v47, s[40:49], vcc. */
+#define MPR_ASM_SINCOS_BODY \
+    "s_mov_b32 s40, 0x6dc9c883\n s_mov_b32 s41, 0x3fe45f30\n"      /* 2 / pi */ \
+    "s_mov_b32 s42, 0\n s_mov_b32 s43, 0x43380000\n"               /* 1.5 * 2^52 */ \
+    "s_mov_b32 s44, 0x54442d18\n s_mov_b32 s45, 0xbff921fb\n"      /* -pi/2 (high part) */ \
+    "s_mov_b32 s46, 0x33145c07\n s_mov_b32 s47, 0xbc91a626\n"      /* -pi/2 (low part) */ \
+    "v_cvt_f64_f32 v[38:39], v35\n" \
+    "v_mul_f64 v[40:41], v[38:39], s[40:41]\n" \
+    "v_add_f64 v[40:41], v[40:41], s[42:43]\n" \
+    "v_add_f64 v[40:41], v[40:41], -s[42:43]\n"                    /* j = round(x * 2 / pi) */ \
+    "v_fma_f64 v[38:39], v[40:41], s[44:45], v[38:39]\n" \
+    "v_fma_f64 v[38:39], v[40:41], s[46:47], v[38:39]\n"           /* r */ \
+    "v_cvt_i32_f64 v42, v[40:41]\n" \
+    "v_cvt_f32_f64 v43, v[38:39]\n" \
+    "v_and_b32 v42, 3, v42\n"                                       /* quadrant */ \
+    "v_mul_f32 v44, v43, v43\n"                                     /* z */ \
+    "v_mov_b32 v45, 0x3c08839e\n" \
+    "v_fmac_f32 v45, 0xb94ca1f9, v44\n" \
+    "v_fmaak_f32 v45, v45, v44, 0xbe2aaaa3\n" \
+    "v_mul_f32 v45, v44, v45\n" \
+    "v_mul_f32 v45, v45, v43\n" \
+    "v_add_f32 v45, v45, v43\n"                                     /* sin polynomial */ \
+    "v_mov_b32 v46, 0xbab6061a\n" \
+    "v_fmac_f32 v46, 0x37ccf5ce, v44\n" \
+    "v_fmaak_f32 v46, v46, v44, 0x3d2aaaa5\n" \
+    "v_mul_f32 v46, v44, v46\n" \
+    "v_mul_f32 v46, v44, v46\n" \
+    "v_fmac_f32 v46, -0.5, v44\n" \
+    "v_add_f32 v46, 1.0, v46\n"                                     /* cos polynomial */ \
+    "v_and_b32 v47, 1, v42\n" \
+    "v_cmp_eq_u32 vcc, 1, v47\n" \
+    "v_lshlrev_b32 v47, 30, v42\n"                                  /* quadrants 2, 3: sin negated */ \
+    "v_add_u32 v42, 1, v42\n" \
+    "v_cndmask_b32 v37, v45, v46, vcc\n"                            /* sin: odd quadrant -> cos polynomial */ \
+    "v_cndmask_b32 v36, v46, v45, vcc\n"                            /* cos: odd quadrant -> sin polynomial */ \
+    "v_and_b32 v47, 0x80000000, v47\n" \
+    "v_lshlrev_b32 v42, 30, v42\n"                                  /* quadrants 1, 2: cos negated */ \
+    "v_xor_b32 v37, v37, v47\n" \
+    "v_and_b32 v42, 0x80000000, v42\n" \
+    "v_and_b32 v47, 0x7fffffff, v35\n" \
+    "v_xor_b32 v36, v36, v42\n" \
+    "v_cmp_le_u32 vcc, 0x4f000000, v47\n"                           /* |x| >= 2^31: sin 0, cos 1 */ \
+    "v_mov_b32 v44, 0x7fc00000\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v37, v37, 0, vcc\n" \
+    "v_cndmask_b32 v36, v36, 1.0, vcc\n" \
+    "v_cmp_le_u32 vcc, 0x7f800000, v47\n"                           /* inf / NaN: NaN */ \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v37, v37, v44, vcc\n" \
+    "v_cndmask_b32 v36, v36, v44, vcc\n"

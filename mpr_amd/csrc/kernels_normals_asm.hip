@@ -86,7 +86,13 @@ __device__ __noinline__ float deriv_trig_q(uint32_t op, float a, float av, bool 
     "v_mov_b32 v44, v37\n v_mul_f32 v36, 2.0, v37\n v_mov_b32 v35, v43\n" NQ_DIV                             \
     "v_cndmask_b32 v37, v37, v44, s[98:99]\n" NQ_END                                                         \
     NQ_H(v, 4) LDL NQ_AO WL "v_xor_b32 v37, 0x80000000, v35\n" NQ_END                                        \
-    NQ_H(v, 5) NQ_EXIT NQ_H(v, 6) NQ_EXIT NQ_H(v, 7) NQ_EXIT NQ_H(v, 8) NQ_EXIT NQ_H(v, 9) NQ_EXIT          \
+    NQ_H(v, 5) LDL NQ_AO WL                                  /* SIN: isv ? sin(av) : cos(av) * a */          \
+    "v_mov_b32 v48, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_CALL("s[68:69]")                                  \
+    "v_mul_f32 v38, v36, v48\n v_cndmask_b32 v37, v38, v37, s[98:99]\n" NQ_END                              \
+    NQ_H(v, 6) LDL NQ_AO WL                                  /* COS: isv ? cos(av) : -sin(av) * a */         \
+    "v_mov_b32 v48, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_CALL("s[68:69]")                                  \
+    "v_mul_f32_e64 v38, -v37, v48\n v_cndmask_b32 v37, v38, v36, s[98:99]\n" NQ_END                         \
+    NQ_H(v, 7) NQ_EXIT NQ_H(v, 8) NQ_EXIT NQ_H(v, 9) NQ_EXIT                                                \
     NQ_H(v, 10) LDL NQ_AO WL                                 /* EXP: e = exp(av); isv ? e : e * a */         \
     "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_EXP                                               \
     "v_mul_f32 v38, v37, v43\n v_cndmask_b32 v37, v38, v37, s[98:99]\n" NQ_END                               \
@@ -167,6 +173,7 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             "s_add_u32 s74, s82, L_sqrt_%=-L_pc_%=\n s_addc_u32 s75, s83, 0\n"
             "s_add_u32 s76, s82, L_exp_%=-L_pc_%=\n s_addc_u32 s77, s83, 0\n"
             "s_add_u32 s78, s82, L_log_%=-L_pc_%=\n s_addc_u32 s79, s83, 0\n"
+            "s_add_u32 s68, s82, L_sincos_%=-L_pc_%=\n s_addc_u32 s69, s83, 0\n"
             "s_add_u32 s82, s82, L_n0_0_%=-L_pc_%=\n"
             "s_addc_u32 s83, s83, 0\n"
             "s_cmp_eq_u32 %[mode], 0\n"
@@ -215,6 +222,7 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n"
             "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n"
             "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n"
+            "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n"
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
             "s_mov_b32 %[dlo], s86\n"
@@ -225,9 +233,9 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
               [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev)
             : "memory", "vcc", "scc",
-              "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
               "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s98", "s99",
-              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48");
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
         /* sin, cos, asin, acos, atan (and anything that is not an opcode) */

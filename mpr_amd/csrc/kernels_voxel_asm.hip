@@ -21,8 +21,7 @@
  * Arithmetic is the same instruction selection the compiler makes for the C++ interpreter
  * (v_add/v_mul/v_min/v_max/v_sub_f32, the IEEE division and square-root expansions), so the
  * results are bit-identical to k_eval_voxels and to the oracle; tests/test_gpu_render.py compares
- * both kernels frame by frame.  The long transcendental opcodes (sin, cos, asin, acos, atan, exp,
- * log) leave the assembly block, are evaluated by the shared C++ routines of mpr_fmath.h, and
+ * both kernels frame by frame.  The inverse trigonometric opcodes (asin, acos, atan) leave the assembly block, are evaluated by the shared C++ routines of mpr_fmath.h, and
  * re-enter it.
  *
  * Software-visible hazards of gfx940/gfx950 that the assembler does not fix up in inline asm
@@ -99,7 +98,9 @@ DEV float rare_unary_a(uint32_t op, float v)
     MPR_H(v, 2) LDL MPR_AO WL "v_mul_f32 v37, " A ", " A "\n" MPR_END                                     \
     MPR_H(v, 3) LDL MPR_AO WL MVA "s_branch L_sqrt_%=\n"                                                  \
     MPR_H(v, 4) LDL MPR_AO WL "v_xor_b32 v37, 0x80000000, " A "\n" MPR_END                                \
-    MPR_H(v, 5) MPR_EXIT MPR_H(v, 6) MPR_EXIT MPR_H(v, 7) MPR_EXIT MPR_H(v, 8) MPR_EXIT MPR_H(v, 9) MPR_EXIT \
+    MPR_H(v, 5) LDL MPR_AO WL MVA "s_branch L_sin_%=\n"                                                  \
+    MPR_H(v, 6) LDL MPR_AO WL MVA "s_branch L_cos_%=\n"                                                  \
+    MPR_H(v, 7) MPR_EXIT MPR_H(v, 8) MPR_EXIT MPR_H(v, 9) MPR_EXIT                                        \
     MPR_H(v, 10) LDL MPR_AO WL MVA "s_branch L_exp_%=\n"                                                  \
     MPR_H(v, 11) LDL MPR_AO WL "v_and_b32 v37, 0x7fffffff, " A "\n" MPR_END                               \
     MPR_H(v, 12) LDL MPR_AO WL MVA "s_branch L_log_%=\n"                                                  \
@@ -216,6 +217,14 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "L_log_%=:\n"
             MPR_ASM_LOG_BODY
             MPR_ST MPR_DISPATCH
+            /* ---- v37 = mpr_sinf(v35) / mpr_cosf(v35) ---- */
+            "L_sin_%=:\n"
+            MPR_ASM_SINCOS_BODY
+            MPR_ST MPR_DISPATCH
+            "L_cos_%=:\n"
+            MPR_ASM_SINCOS_BODY
+            "v_mov_b32 v37, v36\n"
+            MPR_ST MPR_DISPATCH
             /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
@@ -229,7 +238,8 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
               [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev)
             : "memory", "vcc", "scc",
               "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
-              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44");
+              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
         /* dlo is the rewritten clause word: byte 0 out slot, byte 1 handler index (opcode in its low 5 bits) */
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
