@@ -782,7 +782,8 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     /* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers */
     const char* const env = getenv("MPR_TILES_ASM");      /* development: 0 = compiled forward walk */
     const bool asm_ok = !(env && atoi(env) == 0);
-    const bool use_asm = asm_ok && a.nslots <= 128 && !(a.debug & 3);
+    /* ... and the assembly backward walk forms 32-bit byte offsets into the pool */
+    const bool use_asm = asm_ok && a.nslots <= 128 && !(a.debug & 3) && a.pool_cap < (1ll << 29);
     if (dim == 3) {
         if (use_asm) hipLaunchKernelGGL((k_eval_tiles<3, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<3, false>), dim3(groups), dim3(64), lds, s, a);
