@@ -81,6 +81,10 @@ void mpr_tree_free(mpr_tree* t);
  *      context uploads it on first use ---- */
 int mpr_tape_from_tree(const mpr_tree* t, mpr_tape** out);
 /* adopt an already-flattened tape (head clause, clauses, end clause) */
+/* The tape's dependency levels (operands renamed to the clause that produced them; clauses of one
+ * level are independent): what the level-parallel first tile stage walks.  levels: one int per body
+ * clause (length - 2), or null. */
+int mpr_tape_schedule_info(const mpr_tape* tape, int32_t* nlevels, int32_t* max_width, int32_t* levels);
 int mpr_tape_from_clauses(const uint64_t* clauses, int32_t length, mpr_tape** out);
 int32_t mpr_tape_length(const mpr_tape* t);            /* mpr::Tape::length */
 const uint64_t* mpr_tape_data(const mpr_tape* t);      /* mpr::Tape::data (host copy) */

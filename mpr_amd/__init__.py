@@ -156,6 +156,7 @@ def lib():
     L.mpr_ctx_stream.restype = vp
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
+    L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
     L.mpr_effects_create.argtypes = [i32, P(vp)]
     L.mpr_effects_destroy.argtypes = [vp]
     L.mpr_effects_destroy.restype = None
@@ -330,6 +331,13 @@ class Tape:
     def data(self):
         n = self.length
         return np.ctypeslib.as_array(lib().mpr_tape_data(self._h), (n,)).copy()
+
+    def schedule_levels(self):
+        """Dependency level of every body clause (tape_schedule.hpp) -> (levels, nlevels, max_width)."""
+        nl, mw = ctypes.c_int32(), ctypes.c_int32()
+        lv = np.zeros(max(self.length - 2, 0), dtype=np.int32)
+        _check(lib().mpr_tape_schedule_info(self._h, ctypes.byref(nl), ctypes.byref(mw), _ptr(lv)))
+        return lv, nl.value, mw.value
 
     @property
     def num_slots(self):

@@ -142,6 +142,24 @@ int mpr_tape_from_tree(const mpr_tree* tr, mpr_tape** out)
         *out = t;
         return MPR_OK;)
 }
+/* dependency-level schedule of the tape (tape_schedule.hpp): number of levels, widest level, and
+ * for every body clause its level (levels may be null) */
+int mpr_tape_schedule_info(const mpr_tape* t, int32_t* nlevels, int32_t* max_width, int32_t* levels)
+{
+    if (!t) return mpr::set_error(MPR_ERR_INVALID, "null tape");
+    const mpr::TapeSchedule& sc = t->schedule;
+    if (!sc.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "tape has no level schedule (too long, or jumps inside)");
+    const int32_t nl = (int32_t)sc.level_start.size() - 1;
+    if (nlevels) *nlevels = nl;
+    int32_t mw = 0;
+    for (int32_t l = 0; l < nl; ++l) {
+        const int32_t w = sc.level_start[(size_t)l + 1] - sc.level_start[(size_t)l];
+        mw = std::max(mw, w);
+        if (levels) for (int32_t k = sc.level_start[(size_t)l]; k < sc.level_start[(size_t)l + 1]; ++k) levels[sc.recs[(size_t)k].idx] = l;
+    }
+    if (max_width) *max_width = mw;
+    return MPR_OK;
+}
 int mpr_tape_from_clauses(const uint64_t* clauses, int32_t length, mpr_tape** out)
 {
     if (!clauses || !out || length < 2) return mpr::set_error(MPR_ERR_INVALID, "bad tape");

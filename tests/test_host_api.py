@@ -116,3 +116,29 @@ def test_cpp_facade_compiles():
     import subprocess
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "benchmark", "render_table.cpp")])
+
+
+def test_tape_dependency_levels(mpr):
+    """The level schedule the first tile stage walks (tape_schedule.hpp): every clause sits one
+    level above the later of its operands' producers; depths of the benchmark models."""
+    depth = {}
+    for name in ("prospero", "architecture", "bear", "hello_world"):
+        tape = mpr.Tape(mpr.model(name))
+        lv, nlevels, max_width = tape.schedule_levels()
+        depth[name] = nlevels
+        d = tape.data
+        body = d[1:-1]
+        assert lv.size == body.size and lv.min() == 0 and lv.max() == nlevels - 1
+        assert np.bincount(lv).max() == max_width
+        # recompute: producer of a slot = last clause that wrote it (or X / Y / Z from the head)
+        last = {}
+        for k, c in enumerate(body):
+            c = int(c)
+            out, lhs, rhs = (c >> 8) & 0xFF, (c >> 16) & 0xFF, (c >> 24) & 0xFF
+            want = 0
+            for s in (lhs, rhs):
+                if s and s in last:
+                    want = max(want, lv[last[s]] + 1)
+            assert lv[k] == want, (name, k)
+            last[out] = k
+    assert depth == {"prospero": 22, "architecture": 19, "bear": 72, "hello_world": 18}
