@@ -198,6 +198,16 @@ int mpr_get_counters(mpr_context* ctx, mpr_counters* out);
  * MPR_CTX_TIMING).  names[i] is a static string; returns count in *n (<= cap). */
 int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
 
+/* ---- compiled-expression baseline (reference benchmark/dump_tape.cpp + benchmark/brute.cu): the
+ *      tape as straight-line HIP source, compiled for the device at run time (hiprtc), evaluated
+ *      for every pixel without hierarchy.  Same image as mpr_render2d_brute. ---- */
+typedef struct mpr_compiled mpr_compiled;
+int mpr_compiled_create(int32_t device, const mpr_tape* tape, mpr_compiled** out);
+void mpr_compiled_destroy(mpr_compiled* k);
+const char* mpr_compiled_source(const mpr_compiled* k);
+/* dev_image: size * size int32 on the device (e.g. mpr_dev_filled(ctx, 3)); blocking */
+int mpr_compiled_render2d(mpr_compiled* k, int32_t size, const float mat3_colmajor[9], float z, int32_t* dev_image);
+
 /* ---- mpr::Effects (reference inc/effects.hpp:21-37, src/effects.cu): image-space passes over the
  *      heightmap and normals of the context's last render3D ---- */
 typedef struct mpr_effects mpr_effects;

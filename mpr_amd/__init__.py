@@ -157,6 +157,14 @@ def lib():
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
+    L.mpr_compiled_create.argtypes = [i32, vp, P(vp)]
+    L.mpr_compiled_destroy.argtypes = [vp]
+    L.mpr_compiled_destroy.restype = None
+    L.mpr_compiled_source.argtypes = [vp]
+    L.mpr_compiled_source.restype = ctypes.c_char_p
+    L.mpr_compiled_render2d.argtypes = [vp, i32, vp, f32, vp]
+    L.mpr_dev_filled.argtypes = [vp, i32]
+    L.mpr_dev_filled.restype = vp
     L.mpr_effects_create.argtypes = [i32, P(vp)]
     L.mpr_effects_destroy.argtypes = [vp]
     L.mpr_effects_destroy.restype = None
@@ -522,6 +530,37 @@ class Context:
 
     def dev_normals(self):
         return lib().mpr_dev_normals(self._h)
+
+
+class CompiledTape:
+    """The compiled-expression baseline (benchmark/dump_tape.cpp + brute.cu of the reference): the
+    tape as straight-line HIP source compiled at run time, evaluated for every pixel."""
+
+    def __init__(self, tape, device=0):
+        h = ctypes.c_void_p()
+        _check(lib().mpr_compiled_create(device, tape._h, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().mpr_compiled_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def source(self):
+        return lib().mpr_compiled_source(self._h).decode()
+
+    def render2D(self, ctx, mat=None, z=0.0):
+        """Evaluates into ctx.image (the context's stages[3].filled)."""
+        m = colmajor(np.eye(3) if mat is None else mat, 3)
+        ctx.sync()
+        _check(lib().mpr_compiled_render2d(self._h, ctx.image_size_px, _ptr(m), z, lib().mpr_dev_filled(ctx._h, 3)))
 
 
 class Effects:

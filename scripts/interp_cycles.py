@@ -28,3 +28,6 @@ run("min, from LDS", [m.clause(OP["MIN_LHS_RHS"], 4 + (i & 1), 1, 2, 0.0) for i 
 run("sqrt (leaves the block), LDS", [m.clause(OP["SQRT_LHS"], 4 + (i & 1), 1, 0, 0.0) for i in range(N)])
 run("exp (leaves the block), LDS", [m.clause(OP["EXP_LHS"], 4 + (i & 1), 1, 0, 0.0) for i in range(N)])
 run("div (leaves the block), LDS", [m.clause(OP["DIV_LHS_RHS"], 4 + (i & 1), 1, 2, 0.0) for i in range(N)])
+run("not an opcode (exit overhead only)", [m.clause(30, 4 + (i & 1), 1, 0, 0.0) for i in range(N)])
+run("log (leaves the block), LDS", [m.clause(OP["LOG_LHS"], 4 + (i & 1), 1, 0, 0.0) for i in range(N)])
+run("atan (leaves the block), LDS", [m.clause(OP["ATAN_LHS"], 4 + (i & 1), 1, 0, 0.0) for i in range(N)])

@@ -400,3 +400,20 @@ def test_tape_with_more_than_128_slots(mpr, orc, tapes, dim, S):
     tape = tapes("many_slots")
     assert tape.num_slots > 128
     compare_frame(mpr, orc, tape, dim, S, view2() if dim == 2 else view3())
+
+
+@pytest.mark.parametrize("name,S", [("two_spheres", 256), ("hello_world", 256), ("trig", 128), ("involute_gear_2d", 256)])
+def test_compiled_expression_baseline_equals_brute_force(mpr, tapes, name, S):
+    """The tape as straight-line HIP source, compiled at run time (compiled_baseline.cpp: the
+    reference's dump_tape + brute.cu comparison point), gives the image of render2D_brute."""
+    tape = tapes(name)
+    ctx = mpr.Context(S)
+    ctx.render2D_brute(tape, view2())
+    want = ctx.image.copy()
+    k = mpr.CompiledTape(tape)
+    assert "mpr_compiled" in k.source
+    k.render2D(ctx, view2())
+    got = ctx.image
+    assert want.any() and np.array_equal(got, want), int((got != want).sum())
+    k.close()
+    ctx.close()
