@@ -217,6 +217,21 @@ struct Context {
         check(mpr_render2d_brute(handle.get(), tape.handle.get(), mat.data(), z));
         refresh(false);
     }
+    /* inc/context.hpp:51-58.  Upstream returns a managed float array; here a host vector. */
+    std::vector<float> render2D_heatmap(const Tape& tape, const Matrix3f& mat, const float z = 0.0f)
+    {
+        std::vector<float> heat((size_t)image_size_px * image_size_px);
+        check(mpr_render2d_heatmap(handle.get(), tape.handle.get(), mat.data(), z, heat.data()));
+        refresh(false);
+        return heat;
+    }
+    std::vector<float> render3D_heatmap(const Tape& tape, const Matrix4f& mat)
+    {
+        std::vector<float> heat((size_t)image_size_px * image_size_px);
+        check(mpr_render3d_heatmap(handle.get(), tape.handle.get(), mat.data(), heat.data()));
+        refresh(true);
+        return heat;
+    }
     /* tape_data / *tape_index (benchmark/tape_shortening.cpp:56-72, render_3d_heatmap.cpp:64) */
     const std::vector<uint64_t>& tape_data()
     {

@@ -119,6 +119,17 @@ int mpr_render3d(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmaj
 /* Context::render2D_brute (src/context.cu:1461-1508). */
 int mpr_render2d_brute(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
                        float z);
+/* Context::render2D_heatmap / render3D_heatmap (inc/context.hpp:51-58; src/context.cu:1984-2146,
+ * :2148-2339): a normal frame (image / heightmap / normals are produced as usual) that also returns
+ * the amortised work per pixel: every tile adds the tape words it walked, divided by its area in
+ * pixels, to the pixels it covers, the float pass adds its walk per pixel, and the total is divided
+ * by the root tape's clause count.  heat_out: image_size^2 floats on the host, x + y * image_size.
+ * 2-D heatmaps are reproducible bit for bit; in 3-D the order of the float additions, and the work
+ * of tiles culled by a concurrent tile's fill, depend on timing (as upstream). */
+int mpr_render2d_heatmap(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
+                         float z, float* heat_out);
+int mpr_render3d_heatmap(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmajor[16],
+                         float* heat_out);
 /* Non-blocking forms: enqueue the frame on the context's stream and return. */
 int mpr_render2d_async(mpr_context* ctx, const mpr_tape* tape, const float mat3_colmajor[9],
                        float z);

@@ -131,6 +131,8 @@ def lib():
     L.mpr_render2d.argtypes = [vp, vp, vp, f32]
     L.mpr_render3d.argtypes = [vp, vp, vp]
     L.mpr_render2d_brute.argtypes = [vp, vp, vp, f32]
+    L.mpr_render2d_heatmap.argtypes = [vp, vp, vp, f32, vp]
+    L.mpr_render3d_heatmap.argtypes = [vp, vp, vp, vp]
     L.mpr_render2d_async.argtypes = [vp, vp, vp, f32]
     L.mpr_render3d_async.argtypes = [vp, vp, vp]
     L.mpr_ctx_sync.argtypes = [vp]
@@ -444,6 +446,20 @@ class Context:
     def render2D_brute(self, tape, mat=None, z=0.0):
         m = colmajor(np.eye(3) if mat is None else mat, 3)
         _check(lib().mpr_render2d_brute(self._h, tape._h, _ptr(m), z))
+
+    def render2D_heatmap(self, tape, mat=None, z=0.0):
+        """Context::render2D_heatmap (inc/context.hpp:51-56): renders, and returns work per pixel [y, x]."""
+        m = colmajor(np.eye(3) if mat is None else mat, 3)
+        heat = np.empty((self.image_size_px, self.image_size_px), dtype=np.float32)
+        _check(lib().mpr_render2d_heatmap(self._h, tape._h, _ptr(m), z, _ptr(heat)))
+        return heat
+
+    def render3D_heatmap(self, tape, mat=None):
+        """Context::render3D_heatmap (inc/context.hpp:57-58)."""
+        m = colmajor(np.eye(4) if mat is None else mat, 4)
+        heat = np.empty((self.image_size_px, self.image_size_px), dtype=np.float32)
+        _check(lib().mpr_render3d_heatmap(self._h, tape._h, _ptr(m), _ptr(heat)))
+        return heat
 
     def render3D_part(self, tape, mat, owner, rank, blocking=True):
         m = colmajor(mat, 4)

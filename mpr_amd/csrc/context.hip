@@ -63,6 +63,8 @@ struct mpr_context {
     int* slot_dev = nullptr;           /* gather plan: position of a column inside its owner's pack */
     int plan_rank = -1, plan_world = 0, plan_capacity = 0, plan_normals = 0;
     int* col_list_dev = nullptr;
+    float* heat = nullptr;             /* render*_heatmap: S x S floats, allocated on first use */
+    bool heat_frame = false;           /* the frame being issued accumulates into heat */
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
 
     bool voxel_pairs = false;          /* float pass: sibling tiles on a common tape two at a time (experiment, MPR_VOXEL_PAIRS=1;
@@ -241,6 +243,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->owner_dev) (void)hipFree(c->owner_dev);
     if (c->col_list_dev) (void)hipFree(c->col_list_dev);
+    if (c->heat) (void)hipFree(c->heat);
     if (c->slot_dev) (void)hipFree(c->slot_dev);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (auto& t : c->timings) {
@@ -351,6 +354,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     const int S = c->S;
     hipStream_t s = c->stream;
     unsigned long long* cnt = (c->flags & MPR_CTX_COUNTERS) ? c->counters : nullptr;
+    float* const heat = c->heat_frame ? c->heat : nullptr;
+    if (heat) HIP_TRY(hipMemsetAsync(heat, 0, (size_t)S * S * sizeof(float), s));
     const int nslots = std::max(tape->num_slots, 1);
     const int choice_cap = std::min(tape->num_choices, (int)MPR_MAX_CHOICES);
     if (tape->num_slots > MPR_KERNEL_SLOTS) c->last.slots_exceeded = 1;
@@ -411,7 +416,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->last.tiles_in[si] = count;
 
         const int ngroups = (count + 63) / 64;
-        const bool grouped = last && count > 0 && c->voxel_k > 0;
+        const bool grouped = last && count > 0 && c->voxel_k > 0 && !heat;
         if (grouped) {
             /* the float pass walks each group's tape with the group's choice masks */
             rc = ensure_buffer(&c->groups, &c->groups_cap, (size_t)ngroups);
@@ -438,12 +443,15 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
+            a.heat = heat;
+            a.heat_stride = S;
             a.debug = getenv("MPR_DEBUG_TILES") ? atoi(getenv("MPR_DEBUG_TILES")) : 0;
             if (a.debug & 4) a.debug |= si << 4;
+            if (heat && dim == 3) mprk::launch_mask_filled(s, c->tiles[i], count, tps, c->filled[i]);
             TimedScope ts(c, "eval_tiles_i");
             /* ... and only while the stage has few tiles (a workgroup per tile is latency-bound at low lane
              * utilisation: with 32768 tiles at 2048^3 the 64-tiles-per-wave walk is 1.5x faster) */
-            if (si == 0 && c->wide_stage0 && c->sched_ok && !grouped && !(a.debug & 3) && count <= 8192) {
+            if (si == 0 && c->wide_stage0 && c->sched_ok && !grouped && !heat && !(a.debug & 3) && count <= 8192) {
                 /* first stage: few tiles, all on the root tape -> one workgroup per tile, level by level */
                 mprk::WideStageArgs w;
                 w.t = a;
@@ -462,7 +470,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
         if (rc) return rc;
         /* last 3-D stage: siblings that share a tape are paired up for the float pass */
-        pairing = last && dim == 3 && c->voxel_pairs && c->voxel_asm && !cnt && nslots <= 128 && c->voxel_k == 0;
+        pairing = last && dim == 3 && c->voxel_pairs && c->voxel_asm && !cnt && !heat && nslots <= 128 && c->voxel_k == 0;
         if (pairing) {
             rc = ensure_buffer(&c->vox_singles, &c->vox_singles_cap, (size_t)std::max(count, 1));
             if (rc) return rc;
@@ -490,7 +498,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     }
 
     c->last.voxel_tiles = count;
-    if (!brute && last_ngroups > 0 && count > 0 && c->voxel_k > 0) {
+    if (!brute && last_ngroups > 0 && count > 0 && c->voxel_k > 0 && !heat) {
         mprk::GroupedVoxelArgs v;
         v.tape_ro = c->pool;
         v.image = c->filled[3];
@@ -517,8 +525,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         v.z = z;
         fill_mat(v.mat, mat, dim == 3 ? 16 : 9);
         v.counters = cnt;
+        v.heat = heat;
         TimedScope ts(c, "eval_voxels_f");
-        /* the assembly interpreter keeps no work counters: instrumented frames use the C++ one */
+        /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
         if (pairing) {
             /* pairs of siblings on a common tape, then the tiles with a tape of their own */
             mprk::PairVoxelArgs pv;
@@ -533,7 +542,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             v.tiles = c->vox_singles;
             v.count = n_singles;
             mprk::launch_eval_voxels_asm(s, dim, v);
-        } else if (c->voxel_asm && !cnt) mprk::launch_eval_voxels_asm(s, dim, v);
+        } else if (c->voxel_asm && !cnt && !heat) mprk::launch_eval_voxels_asm(s, dim, v);
         else mprk::launch_eval_voxels(s, dim, v);
     }
     if (dim == 3) {
@@ -592,6 +601,35 @@ int mpr_render2d(mpr_context* c, const mpr_tape* t, const float m[9], float z)
 int mpr_render3d(mpr_context* c, const mpr_tape* t, const float m[16])
 {
     return render_frame(c, t, 3, m, 0.0f, nullptr, 0, false, true);
+}
+/* Context::render2D_heatmap / render3D_heatmap (inc/context.hpp:51-58, src/context.cu:1984-2339): a
+ * normal frame whose tile and pixel kernels also accumulate the words they walk, spread over the
+ * pixels they cover; the sum is divided by the tape's clause count on the host as upstream does. */
+static int render_heatmap(mpr_context* c, const mpr_tape* t, int dim, const float* m, float z, float* out)
+{
+    if (!c || !t || !out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->S * c->S;
+    if (!c->heat && hipMalloc(&c->heat, n * sizeof(float)) != hipSuccess) {
+        c->heat = nullptr;
+        return mpr::set_error(MPR_ERR_ALLOC, "heatmap allocation failed");
+    }
+    c->heat_frame = true;
+    const int rc = render_frame(c, t, dim, m, z, nullptr, 0, false, true);
+    c->heat_frame = false;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->heat, n * sizeof(float), hipMemcpyDeviceToHost));
+    const float clauses = (float)((long long)t->clauses.size() - 2);       /* src/context.cu:2142, :2336 (integer divisor) */
+    for (size_t i = 0; i < n; ++i) out[i] /= clauses;
+    return MPR_OK;
+}
+int mpr_render2d_heatmap(mpr_context* c, const mpr_tape* t, const float m[9], float z, float* out)
+{
+    return render_heatmap(c, t, 2, m, z, out);
+}
+int mpr_render3d_heatmap(mpr_context* c, const mpr_tape* t, const float m[16], float* out)
+{
+    return render_heatmap(c, t, 3, m, 0.0f, out);
 }
 int mpr_render2d_brute(mpr_context* c, const mpr_tape* t, const float m[9], float z)
 {

@@ -118,8 +118,10 @@ k_eval_tiles(TileStageArgs a)
     bool alive = valid && node.position != -1;
     int4_ pos = unpack(alive ? node.position : 0, a.tps);
 
-    /* mask_filled_tiles before evaluation (3-D) */
-    if (DIM == 3 && alive) {
+    /* mask_filled_tiles before evaluation (3-D).  Fused here it also sees fills of waves of this very
+     * launch (same image, less work); heatmap frames count work, so they run the reference's separate
+     * pass (k_mask_filled_tiles) instead and get the reference's deterministic set of evaluated tiles */
+    if (DIM == 3 && alive && !a.heat) {
         if (a.image[pos.w] > pos.z) {
             alive = false;
             a.tiles[gidx].position = -1;
@@ -472,6 +474,30 @@ k_eval_tiles(TileStageArgs a)
 
     MPR_PHASE(4);
     if (prof && lane == 0) atomicAdd(&pc[5], 1ull);
+    if (a.heat) {
+        /* heatmap frames (reference eval_tiles_i_heatmap, src/context.cu:1622-1632, :1817-1826): the
+         * words a tile walked forward (terminator excluded) spread over its xy footprint, then the
+         * words of its backward walk the same way.  The wave splats one tile at a time so that the
+         * atomics of a row are adjacent. */
+        const int tpx = (a.tps > 0) ? (int)((unsigned)a.heat_stride / (unsigned)a.tps) : 0;
+        const float area = (float)(tpx * tpx);
+        const float hf = (float)(unsigned)(fwd_words - 1) / area;
+        const float hb = (float)(unsigned)(bwd_words > 0 ? bwd_words - 1 : 0) / area;
+        const uint64_t pushed = ballot(push);
+        uint64_t m = alive_mask;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int x0 = __builtin_amdgcn_readlane(pos.x, l) * tpx;
+            const int y0 = __builtin_amdgcn_readlane(pos.y, l) * tpx;
+            const bool pb = (pushed >> l) & 1;
+            for (int i = lane; i < tpx * tpx; i += 64) {
+                float* const h = &a.heat[(x0 + i % tpx) + (size_t)(y0 + i / tpx) * a.heat_stride];
+                atomicAdd(h, hf);
+                if (pb) atomicAdd(h, hb);
+            }
+        }
+    }
     if (a.counters) {
         if (lane == 0) {
             atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)fwd_words);
@@ -768,6 +794,20 @@ static void opt_in_once()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+/* mask_filled_tiles, src/context.cu:471-493, as its own launch (heatmap frames only) */
+__global__ void k_mask_filled_tiles(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int position = tiles[i].position;
+    if (position == -1) return;
+    const int4_ pos = unpack(position, tps);
+    if (image[pos.w] > pos.z) tiles[i].position = -1;
+}
+void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image)
+{
+    hipLaunchKernelGGL(k_mask_filled_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, tps, image);
 }
 void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
 {

@@ -49,6 +49,8 @@ struct TileStageArgs {
     GroupInfo* groups;         /* last tile stage only (else null): per-group record ...      */
     ulonglong2* choice_masks;  /* ... and choice masks, choice_cap entries per group          */
     int debug;                 /* development only (MPR_DEBUG_TILES): 1 = skip tape pushing, 2 = skip the arithmetic */
+    float* heat;               /* heatmap frames (render*_heatmap): S x S amortised work per pixel, else null */
+    int heat_stride;           /* = image size in pixels */
 };
 
 /* first tile stage, one workgroup per tile, level by level over the root tape's DAG
@@ -72,6 +74,7 @@ struct VoxelArgs {
     float z;
     float mat[16];
     unsigned long long* counters;
+    float* heat;               /* heatmap frames: S x S work per pixel, else null */
 };
 
 /* float pass over pairs of smallest tiles that share a tape (kernels_voxel_pair_asm.hip) */
@@ -117,6 +120,7 @@ struct NormalArgs {
 };
 
 void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
+void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
 bool wide_stage_fits(int nclauses);

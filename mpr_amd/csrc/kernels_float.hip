@@ -147,6 +147,18 @@ k_eval_voxels(VoxelArgs a)
         atomicAdd((unsigned long long*)&a.counters[CNT_FWD_VOX], (unsigned long long)words);
         atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)(words - 1) * 64ull);
     }
+    if (a.heat) {
+        /* heatmap frames (reference eval_voxels_f_heatmap, src/context.cu:1960-1980).  The reference
+         * runs 32 threads per tile, two voxels each: in 3-D every thread that was not skipped adds its
+         * walk to its (px, py) — the lanes with sub.z < 2 stand for those threads here — and in 2-D a
+         * thread adds half of it to each of its two pixels. */
+        const float work = (float)(unsigned)(words - 1);
+        if (DIM == 3) {
+            if (!skip && sub.z < 2) atomicAdd(&a.heat[px + (size_t)py * S], work);
+        } else {
+            atomicAdd(&a.heat[px + (size_t)py * S], work / 2.0f);
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */

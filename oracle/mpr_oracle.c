@@ -461,6 +461,7 @@ struct orc_frame {
     int64_t pool_cap;
     int32_t tape_index;
     orc_counters c;
+    float* heat;          /* heatmap frames (flags bit2): S x S work per pixel, else NULL */
 };
 
 static inline float imm_of(uint64_t d) { return mpr_u2f(mpr_cl_immbits(d)); }
@@ -526,7 +527,7 @@ enum { T_EMPTY = 0, T_MASKED = 1, T_FILLED = 2, T_AMBIG = 3, T_PUSHED = 4, T_OVE
 
 static int eval_tile_i(orc_frame* f, int dim, int32_t* image, int32_t tps, mpr_tile_node* tile,
                        const float* mat, float z, int64_t* fwd, int64_t* bwd, int64_t* written,
-                       int64_t* nclauses, int* slots_exceeded)
+                       int64_t* nclauses, int* slots_exceeded, int* would_push)
 {
     uint64_t* const tape_data = f->pool;
     const int64_t POOL = f->pool_cap;
@@ -578,7 +579,13 @@ static int eval_tile_i(orc_frame* f, int dim, int32_t* image, int32_t tps, mpr_t
     /* Masked — :299-305 */
     if (dim == 3) {
         const int4_ pos = unpack(tile->position, tps);
-        if (__atomic_load_n(&image[pos.w], __ATOMIC_RELAXED) > pos.z) { tile->position = -1; return T_MASKED; }
+        if (__atomic_load_n(&image[pos.w], __ATOMIC_RELAXED) > pos.z) {
+            /* culled by a tile that filled this column during the stage: with other timing it would
+             * have gone on to push a tape (heatmap bounds only) */
+            *would_push = !(result.hi < 0.0f) && has_any_choice;
+            tile->position = -1;
+            return T_MASKED;
+        }
     }
     /* Filled — :308-317 */
     if (result.hi < 0.0f) {
@@ -669,6 +676,22 @@ static int eval_tile_i(orc_frame* f, int dim, int32_t* image, int32_t tps, mpr_t
     return T_PUSHED;
 }
 
+/* Heatmap frames — eval_tiles_i_heatmap, src/context.cu:1622-1632 and :1817-1826: a tile's walk is
+ * spread over the pixels of its xy footprint.  In 3-D several tiles of one pixel column add
+ * concurrently (atomicAdd upstream), so the order of the float additions is timing dependent. */
+static void heat_splat(float* heat, int32_t S, int32_t position, int32_t tps, int32_t tile_px, int64_t work)
+{
+    const int4_ pos = unpack(position, tps);
+    const float v = (float)(uint32_t)work / (float)(tile_px * tile_px);
+    for (int32_t y = 0; y < tile_px; ++y) {
+        for (int32_t x = 0; x < tile_px; ++x) {
+            float* const h = &heat[(pos.x * tile_px + x) + (size_t)(pos.y * tile_px + y) * S];
+#pragma omp atomic
+            *h += v;
+        }
+    }
+}
+
 /* ---- float walk of one tape for one point — src/context.cu:866-921 ---- */
 static float eval_point_f(const uint64_t* tape_data, int32_t tape, float x, float y, float z,
                           int64_t* words)
@@ -739,6 +762,11 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
     if (!tape || length < 2 || (dim != 2 && dim != 3) || S < 64 || S % 64) return NULL;
     const int brute = (flags & 1) && dim == 2;
     const int skip_normals = (flags & 2) != 0;
+    /* heatmap: 1 = as executed here, 2 = lower bound, 3 = upper bound over the timing-dependent
+     * parts of a 3-D frame (a tile culled mid-stage by a neighbour's fill does not push; a voxel
+     * pair is skipped when the heightmap it reads is already above it) */
+    const int heat_mode = brute ? 0 : (flags & 4) ? 1 : (flags & 8) ? 2 : (flags & 16) ? 3 : 0;
+    const int want_heat = heat_mode != 0;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #else
@@ -760,6 +788,7 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
         f->filled[i] = (int32_t*)calloc(f->filled_n[i], sizeof(int32_t));
     }
     f->normals = (uint32_t*)calloc((size_t)S * S, sizeof(uint32_t));
+    if (want_heat) f->heat = (float*)calloc((size_t)S * S, sizeof(float));
 
     int64_t F_tiles = 0, F_vox = 0, F_norm = 0, R = 0, W = 0, LC = 0;
     int slots_exceeded = 0, overflowed = 0;
@@ -815,6 +844,9 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
             }
         }
 
+        /* heatmap lower bound: backward work only of tiles that also survive the stage */
+        int32_t* pushed_words = (heat_mode == 2) ? (int32_t*)calloc(count ? count : 1, sizeof(int32_t)) : NULL;
+
         /* eval_tiles_i — :1185 / :1342.  Groups of 64 consecutive tiles share a tape. */
         int64_t n_empty = 0, n_filled = 0, n_pushed = 0, n_ambig = 0;
         const size_t ngroups = (count + 63) / 64;
@@ -827,8 +859,21 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
             for (size_t t = g * 64; t < hi; ++t) {
                 if (tiles[t].position == -1) continue;   /* :204-206 */
                 int64_t fwd = 0, bwd = 0, wr = 0, nc = 0;
-                int se = 0;
-                const int r = eval_tile_i(f, dim, image, tps, &tiles[t], mat, z, &fwd, &bwd, &wr, &nc, &se);
+                int se = 0, would_push = 0;
+                const int32_t position0 = tiles[t].position;
+                const int r = eval_tile_i(f, dim, image, tps, &tiles[t], mat, z, &fwd, &bwd, &wr, &nc, &se, &would_push);
+                if (f->heat) {
+                    /* forward words without the terminator (:1551-1556), then, for a tile that pushed a
+                     * tape, the words of the backward walk (:1700-1704), which visits the same words */
+                    heat_splat(f->heat, S, position0, tps, tile_size_px, fwd - 1);
+                    if (heat_mode == 2) {
+                        if (r == T_PUSHED) pushed_words[t] = (int32_t)(bwd - 1);
+                    } else if (r == T_PUSHED) {
+                        heat_splat(f->heat, S, position0, tps, tile_size_px, bwd - 1);
+                    } else if (heat_mode == 3 && r == T_MASKED && would_push) {
+                        heat_splat(f->heat, S, position0, tps, tile_size_px, fwd - 1);
+                    }
+                }
                 slots_exceeded |= se;
                 LC += nc;
                 W += wr;
@@ -854,6 +899,14 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                 const int4_ pos = unpack(tiles[t].position, tps);
                 if (image[pos.w] > pos.z) { tiles[t].position = -1; masked++; n_ambig--; }
             }
+        }
+
+        if (pushed_words) {
+            for (size_t t = 0; t < count; ++t) {
+                if (pushed_words[t] && tiles[t].position != -1)
+                    heat_splat(f->heat, S, tiles[t].position, tps, tile_size_px, pushed_words[t]);
+            }
+            free(pushed_words);
         }
 
         /* assign_next_nodes — :512-551 (here: in list order; the reference's order is
@@ -923,10 +976,17 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
         const int sub = (dim == 3) ? 4 : 8;
         const int32_t tps = S / sub;
         const float size_recip = 1.0f / (float)(tps * sub);
+        /* heatmap bounds (3-D): the walk of every smallest tile, for the second pass below */
+        int32_t* tile_words = (dim == 3 && heat_mode >= 2) ? (int32_t*)calloc(count ? count : 1, sizeof(int32_t)) : NULL;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : F_vox, LC)
         for (size_t t = 0; t < count; ++t) {
             const int4_ pos = unpack(vt[t].position, tps);
             int64_t words_max = 0;
+            if (tile_words) {
+                int64_t w = 0;
+                (void)eval_point_f(f->pool, vt[t].tape, 0.0f, 0.0f, 0.0f, &w);
+                tile_words[t] = (int32_t)(w - 1);
+            }
             for (int s = 0; s < 64; ++s) {
                 const int4_ sp = unpack(s, sub);
                 int64_t words = 0;
@@ -944,6 +1004,14 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                         v[k] = (M4(k, 0) * fx + M4(k, 1) * fy + M4(k, 2) * fz + M4(k, 3)) / fw;
                     const float r = eval_point_f(f->pool, vt[t].tape, v[0], v[1], v[2], &words);
                     if (r < 0.0f) atomic_max_i32(&image[px + py * S], pz);
+                    /* eval_voxels_f_heatmap, :1960-1962: one add per reference thread (voxels z and
+                     * z + 2 share a thread), i.e. by the voxels with sp.z < 2 */
+                    if (heat_mode == 1 && sp.z < 2) {
+                        float* const h = &f->heat[px + (size_t)py * S];
+                        const float w = (float)(uint32_t)(words - 1);
+#pragma omp atomic
+                        *h += w;
+                    }
                 } else {
                     const int32_t px = pos.x * 8 + sp.x, py = pos.y * 8 + sp.y;
                     const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
@@ -953,11 +1021,28 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                     for (int k = 0; k < 2; ++k) v[k] = (M3(k, 0) * fx + M3(k, 1) * fy + M3(k, 2)) / fw;
                     const float r = eval_point_f(f->pool, vt[t].tape, v[0], v[1], z, &words);
                     if (r < 0.0f) image[px + py * S] = 1;
+                    /* :1977-1980: half of the thread's walk to each of its two pixels */
+                    if (f->heat) f->heat[px + (size_t)py * S] += (float)(uint32_t)(words - 1) / 2.0f;
                 }
                 LC += words;
                 if (words > words_max) words_max = words;
             }
             F_vox += words_max;
+        }
+        if (tile_words) {
+            /* lower bound: only the voxel pairs that no order of execution can skip (the final
+             * heightmap is still below them); upper bound: nothing is skipped */
+            for (size_t t = 0; t < count; ++t) {
+                const int4_ pos = unpack(vt[t].position, tps);
+                for (int s = 0; s < 32; ++s) {
+                    const int4_ sp = unpack(s, sub);
+                    const int32_t px = pos.x * 4 + sp.x, py = pos.y * 4 + sp.y;
+                    const int32_t pz_low = pos.z * 4 + (sp.z & 1);
+                    if (heat_mode == 2 && image[px + py * S] >= pz_low + 2) continue;
+                    f->heat[px + (size_t)py * S] += (float)(uint32_t)tile_words[t];
+                }
+            }
+            free(tile_words);
         }
     }
 
@@ -1034,6 +1119,11 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
     f->c.tape_index = f->tape_index;
     f->c.pool_overflowed = overflowed;
     f->c.slots_exceeded = slots_exceeded;
+    if (f->heat) {
+        /* src/context.cu:2140-2144, :2334-2338 */
+        const float clauses = (float)(length - 2);
+        for (size_t i = 0; i < (size_t)S * S; ++i) f->heat[i] /= clauses;
+    }
     return f;
 }
 
@@ -1042,6 +1132,7 @@ void orc_frame_free(orc_frame* f)
     if (!f) return;
     for (int i = 0; i < 4; ++i) { free(f->filled[i]); free(f->tiles[i]); }
     free(f->normals);
+    free(f->heat);
     free(f->pool);
     free(f);
 }
@@ -1056,6 +1147,12 @@ const uint32_t* orc_normals(const orc_frame* f, size_t* n)
     if (!f) return NULL;
     if (n) *n = (size_t)f->S * f->S;
     return f->normals;
+}
+const float* orc_heatmap(const orc_frame* f, size_t* n)
+{
+    if (!f || !f->heat) return NULL;
+    if (n) *n = (size_t)f->S * f->S;
+    return f->heat;
 }
 const mpr_tile_node* orc_tiles(const orc_frame* f, int32_t stage, size_t* n)
 {

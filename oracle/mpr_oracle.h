@@ -42,7 +42,12 @@ typedef struct orc_counters {
 /* Render a frame.  dim = 2 or 3.  mat: column-major 3x3 (dim 2) or 4x4 (dim 3).
  * pool_clauses: capacity of the tape pool (0 = MPR_NUM_SUBTAPES_BIG*64).
  * threads: OpenMP threads (<=0: all).  owner/rank: optional column partition (NULL = all).
- * flags: bit0 = brute force (render2D_brute, dim 2 only), bit1 = skip the normals pass.  */
+ * flags: bit0 = brute force (render2D_brute, dim 2 only), bit1 = skip the normals pass,
+ *        bit2 = heatmap frame (Context::render2D_heatmap / render3D_heatmap, src/context.cu:1984-2339):
+ *        also accumulate the amortised work per pixel, read back with orc_heatmap;
+ *        bit3 / bit4 instead of bit2 = the lower / upper bound of that heatmap over the parts of a
+ *        3-D frame that depend on timing upstream too (mid-stage culling of tiles by a neighbour's
+ *        fill, the float pass's skip test) — any execution order lands between the two.  */
 orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t image_size_px,
                       const float* mat, float z, int64_t pool_clauses, int32_t threads,
                       const int32_t* owner, int32_t rank, int32_t flags);
@@ -50,6 +55,7 @@ void orc_frame_free(orc_frame* f);
 
 const int32_t* orc_filled(const orc_frame* f, int32_t stage, size_t* n);
 const uint32_t* orc_normals(const orc_frame* f, size_t* n);
+const float* orc_heatmap(const orc_frame* f, size_t* n);      /* NULL unless flags bit2 was set */
 const mpr_tile_node* orc_tiles(const orc_frame* f, int32_t stage, size_t* n);
 const uint64_t* orc_tape_pool(const orc_frame* f, int32_t* tape_index);
 void orc_get_counters(const orc_frame* f, orc_counters* out);

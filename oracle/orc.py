@@ -70,6 +70,8 @@ def lib():
     L.orc_filled.argtypes = [ctypes.c_void_p, ctypes.c_int32, P(ctypes.c_size_t)]
     L.orc_normals.restype = P(ctypes.c_uint32)
     L.orc_normals.argtypes = [ctypes.c_void_p, P(ctypes.c_size_t)]
+    L.orc_heatmap.restype = P(ctypes.c_float)
+    L.orc_heatmap.argtypes = [ctypes.c_void_p, P(ctypes.c_size_t)]
     L.orc_tiles.restype = ctypes.c_void_p
     L.orc_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int32, P(ctypes.c_size_t)]
     L.orc_tape_pool.restype = P(ctypes.c_uint64)
@@ -103,13 +105,15 @@ class Frame:
     """Result of one oracle frame; arrays are copied out, the C frame is freed."""
 
     def __init__(self, tape, dim, size, mat, z=0.0, pool_clauses=0, threads=1, owner=None, rank=0,
-                 brute=False, skip_normals=False, keep_pool=True):
+                 brute=False, skip_normals=False, keep_pool=True, heatmap=False):
         L = lib()
         tape = np.ascontiguousarray(tape, dtype=np.uint64)
         mat = np.ascontiguousarray(mat, dtype=np.float32).reshape(-1)
         assert mat.size == (9 if dim == 2 else 16)
         own = None if owner is None else np.ascontiguousarray(owner, dtype=np.int32)
-        flags = (1 if brute else 0) | (2 if skip_normals else 0)
+        # heatmap: True = as executed; "lower" / "upper" = bounds over the timing-dependent parts
+        hbit = {False: 0, None: 0, True: 4, "lower": 8, "upper": 16}[heatmap]
+        flags = (1 if brute else 0) | (2 if skip_normals else 0) | hbit
         f = L.orc_render(_ptr(tape), tape.size, dim, size, _ptr(mat), z, pool_clauses, threads,
                          _ptr(own), rank, flags)
         if not f:
@@ -124,6 +128,10 @@ class Frame:
                 self.filled.append(np.ctypeslib.as_array(p, (n.value,)).copy().reshape(side, side))
             p = L.orc_normals(f, ctypes.byref(n))
             self.normals = np.ctypeslib.as_array(p, (n.value,)).copy().reshape(size, size)
+            self.heatmap = None
+            if heatmap:
+                p = L.orc_heatmap(f, ctypes.byref(n))
+                self.heatmap = np.ctypeslib.as_array(p, (n.value,)).copy().reshape(size, size)
             self.tiles = []
             for s in range(4):
                 p = L.orc_tiles(f, s, ctypes.byref(n))
