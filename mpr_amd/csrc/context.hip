@@ -63,6 +63,9 @@ struct mpr_context {
     int* slot_dev = nullptr;           /* gather plan: position of a column inside its owner's pack */
     int plan_rank = -1, plan_world = 0, plan_capacity = 0, plan_normals = 0;
     int* col_list_dev = nullptr;
+    int* zs_hist = nullptr;            /* front-to-back compaction (3-D): per-layer counts and cursors */
+    int* zs_cursor = nullptr;
+    int zsort = 3;                     /* MPR_ZSORT: bit0 = tile stages, bit1 = the list of the float pass */
     float* heat = nullptr;             /* render*_heatmap: S x S floats, allocated on first use */
     bool heat_frame = false;           /* the frame being issued accumulates into heat */
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
@@ -174,6 +177,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->S = S;
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_PAIRS")) c->voxel_pairs = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
@@ -203,6 +207,9 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
     CT(hipMalloc((void**)&c->num_active, 4 * sizeof(int)));
+    CT(hipMalloc((void**)&c->zs_hist, 1024 * sizeof(int)));
+    CT(hipMalloc((void**)&c->zs_cursor, 1024 * sizeof(int)));
+    CT(hipMemsetAsync(c->zs_hist, 0, 1024 * sizeof(int), c->stream));
     CT(hipMalloc((void**)&c->counters, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long)));
     CT(hipMalloc((void**)&c->owner_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipMalloc((void**)&c->col_list_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
@@ -238,6 +245,8 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->pool) (void)hipFree(c->pool);
     if (c->tape_index) (void)hipFree(c->tape_index);
     if (c->num_active) (void)hipFree(c->num_active);
+    if (c->zs_hist) (void)hipFree(c->zs_hist);
+    if (c->zs_cursor) (void)hipFree(c->zs_cursor);
     if (c->counters) (void)hipFree(c->counters);
     if (c->groups) (void)hipFree(c->groups);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
@@ -477,7 +486,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             rc = ensure_buffer(&c->vox_pairs, &c->vox_pairs_cap, (size_t)std::max(count, 2) / 2 + 1);
             if (rc) return rc;
         }
-        if (count > 0) {
+        const bool zs = dim == 3 && !pairing && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
+        if (count > 0 && zs) {
+            TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
+            mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
+                                         c->zs_hist, c->zs_cursor);
+        } else if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
                                            pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr);

@@ -615,6 +615,115 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* 3-D, front to back: the same compaction, but the survivors are handed on ordered by    */
+/* descending z (the viewer looks down -z: larger z is nearer).  Workgroups start in list  */
+/* order, so the next launch works through the frame front to back and the tiles behind a  */
+/* surface find the heightmap already above them: tile stages cull them at the mask test,  */
+/* the float pass skips their voxels (src/context.cu:852-864) — the reference's order is   */
+/* whatever assign_next_nodes' atomics produce.  Counting sort over the tps z-layers:      */
+/* histogram (+ the second mask_filled_tiles), descending scan, scatter.                   */
+/* ------------------------------------------------------------------------------------ */
+constexpr int ZS_MAX_BINS = 1024;
+
+__global__ void __launch_bounds__(1024)
+k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ hist)
+{
+    __shared__ int lh[ZS_MAX_BINS];
+    for (int i = threadIdx.x; i < tps; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gidx < count) {
+        const int position = tiles[gidx].position;
+        if (position != -1) {
+            const int4_ p = unpack(position, tps);
+            if (image[p.w] > p.z) tiles[gidx].position = -1;        /* mask_filled_tiles after evaluation */
+            else atomicAdd(&lh[p.z], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tps; i += blockDim.x) {
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    }
+}
+
+/* one workgroup: cursor[z] = number of survivors in front of layer z; hist is cleared for the next use */
+__global__ void __launch_bounds__(ZS_MAX_BINS)
+k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ num_active)
+{
+    __shared__ int sc[ZS_MAX_BINS];
+    const int t = threadIdx.x;
+    const int z = tps - 1 - t;                 /* thread 0 = nearest layer */
+    const int mine = (t < tps) ? hist[z] : 0;
+    if (t < tps) hist[z] = 0;
+    sc[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < ZS_MAX_BINS; off <<= 1) {
+        const int v = (t >= off) ? sc[t - off] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    if (t < tps) cursor[z] = sc[t] - mine;
+    if (t == ZS_MAX_BINS - 1) num_active[0] = sc[t];
+}
+
+template <bool LAST>
+__global__ void __launch_bounds__(1024)
+k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restrict__ cursor, mpr_tile_node* __restrict__ out)
+{
+    __shared__ int lh[ZS_MAX_BINS], gb[ZS_MAX_BINS];
+    for (int i = threadIdx.x; i < tps; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = gidx < count;
+    mpr_tile_node n;
+    n.position = -1;
+    n.tape = 0;
+    n.next = -1;
+    if (valid) n = tiles[gidx];
+    const bool active = valid && n.position != -1;
+    int z = 0, r = 0;
+    if (active) {
+        z = unpack(n.position, tps).z;
+        r = atomicAdd(&lh[z], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tps; i += blockDim.x) {
+        if (lh[i]) gb[i] = atomicAdd(&cursor[i], lh[i]);
+    }
+    __syncthreads();
+    const int next = active ? gb[z] + r : -1;
+    if (valid) tiles[gidx].next = LAST ? -1 : next;
+    if (LAST) {
+        if (active) {
+            mpr_tile_node o;
+            o.position = n.position;
+            o.tape = n.tape;
+            o.next = -1;
+            out[next] = o;
+        }
+        return;
+    }
+    uint64_t todo = ballot(active);
+    const int sps = tps * 4;
+    const int4_ sp = unpack(lane, 4);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ppos = __builtin_amdgcn_readlane(n.position, src);
+        const int ptape = __builtin_amdgcn_readlane(n.tape, src);
+        const int pnext = __builtin_amdgcn_readlane(next, src);
+        const int4_ p = unpack(ppos, tps);
+        mpr_tile_node o;
+        o.position = (p.x * 4 + sp.x) + (p.y * 4 + sp.y) * sps + (p.z * 4 + sp.z) * sps * sps;
+        o.tape = ptape;
+        o.next = -1;
+        out[(size_t)pnext * 64 + lane] = o;
+    }
+}
+
 /* copy_filled — reference :664-692 */
 template <int DIM>
 __global__ void k_copy_filled(const int* __restrict__ prev, int* __restrict__ image, int size)
@@ -843,6 +952,16 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
         if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
         else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
     }
+}
+bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
+void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
+                            int* num_active, mpr_tile_node* out, int* hist, int* cursor)
+{
+    const dim3 g((count + 1023) / 1024), b(1024);
+    hipLaunchKernelGGL(k_zs_hist, g, b, 0, s, tiles, count, tps, image, hist);
+    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, num_active);
+    if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out);
+    else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out);
 }
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size)
 {

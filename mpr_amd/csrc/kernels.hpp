@@ -120,6 +120,9 @@ struct NormalArgs {
 };
 
 void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
+bool zsort_supported(int tps);
+void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
+                            int* num_active, mpr_tile_node* out, int* hist, int* cursor);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);

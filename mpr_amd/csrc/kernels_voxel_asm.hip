@@ -277,7 +277,8 @@ k_eval_voxels_asm(VoxelArgs a)
     if (DIM == 3) {
         /* reference :852-864: the thread owning (pz_low, pz_low + 2) leaves when image >= pz_low + 2 */
         const int pz_low = pos.z * 4 + (sub.z & 1);
-        skip = a.image[px + py * S] >= pz_low + 2;
+        /* read past this CU's vector L1: the heights other tiles of the column have written so far */
+        skip = __hip_atomic_load(&a.image[px + py * S], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= pz_low + 2;
         if (ballot(!skip) == 0) return;
     }
     const float size_recip = 1.0f / (float)(unsigned)(a.tps * SUB);
