@@ -69,6 +69,11 @@ struct mpr_context {
     float* heat = nullptr;             /* render*_heatmap: S x S floats, allocated on first use */
     bool heat_frame = false;           /* the frame being issued accumulates into heat */
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
+    int* arena = nullptr;              /* filled[0..3] | normals, one allocation */
+    size_t arena_images_words = 0, arena_words = 0;
+    int* pub_host = nullptr;           /* host-coherent: survivor counts + sequence number, written by the compaction */
+    int* pub_dev = nullptr;            /* the same words as the device sees them */
+    int pub_seq = 0;
 
     bool voxel_pairs = false;          /* float pass: sibling tiles on a common tape two at a time (experiment, MPR_VOXEL_PAIRS=1;
                                           measured slower than the single-tile interpreter) */
@@ -198,12 +203,24 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
         }                                                            \
     } while (0)
     CT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i) {                        /* src/context.cpp:21-27 */
-        const int ts = 64 >> (2 * i);
-        c->filled_n[i] = (size_t)(S / ts) * (S / ts);
-        CT(hipMalloc((void**)&c->filled[i], c->filled_n[i] * sizeof(int)));
+    {
+        /* the four filled images and the normals (src/context.cpp:21-27) live in one allocation, in this
+         * order, so that one kernel resets them at the start of a frame (mprk::launch_begin_frame) */
+        size_t off[5], words = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int ts = 64 >> (2 * i);
+            c->filled_n[i] = (size_t)(S / ts) * (S / ts);
+            off[i] = words;
+            words += (c->filled_n[i] + 63) & ~(size_t)63;
+        }
+        off[4] = words;
+        words += (size_t)S * S;
+        CT(hipMalloc((void**)&c->arena, words * sizeof(int)));
+        for (int i = 0; i < 4; ++i) c->filled[i] = c->arena + off[i];
+        c->normals = reinterpret_cast<uint32_t*>(c->arena + off[4]);
+        c->arena_images_words = off[4];
+        c->arena_words = words;
     }
-    CT(hipMalloc((void**)&c->normals, (size_t)S * S * sizeof(uint32_t)));
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
     CT(hipMalloc((void**)&c->num_active, 4 * sizeof(int)));
@@ -215,8 +232,11 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipMalloc((void**)&c->col_list_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipMalloc((void**)&c->slot_dev, (size_t)(S / 64) * (S / 64) * sizeof(int)));
     CT(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(unsigned long long), hipHostMallocDefault));
-    CT(hipMemsetAsync(c->normals, 0, (size_t)S * S * sizeof(uint32_t), c->stream));
-    for (int i = 0; i < 4; ++i) CT(hipMemsetAsync(c->filled[i], 0, c->filled_n[i] * sizeof(int), c->stream));
+    CT(hipHostMalloc((void**)&c->pub_host, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->pub_host, 0, 16 * sizeof(int));
+    CT(hipHostGetDevicePointer((void**)&c->pub_dev, c->pub_host, 0));
+    CT(hipMemsetAsync(c->num_active, 0, 4 * sizeof(int), c->stream));
+    CT(hipMemsetAsync(c->arena, 0, c->arena_words * sizeof(int), c->stream));
     CT(hipStreamSynchronize(c->stream));
 #undef CT
     *out = c;
@@ -238,10 +258,10 @@ void mpr_ctx_destroy(mpr_context* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 4; ++i) {
-        if (c->filled[i]) (void)hipFree(c->filled[i]);
+        c->filled[i] = nullptr;
         if (c->tiles[i]) (void)hipFree(c->tiles[i]);
     }
-    if (c->normals) (void)hipFree(c->normals);
+    if (c->arena) (void)hipFree(c->arena);
     if (c->pool) (void)hipFree(c->pool);
     if (c->tape_index) (void)hipFree(c->tape_index);
     if (c->num_active) (void)hipFree(c->num_active);
@@ -255,6 +275,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->heat) (void)hipFree(c->heat);
     if (c->slot_dev) (void)hipFree(c->slot_dev);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->pub_host) (void)hipHostFree(c->pub_host);
     for (auto& t : c->timings) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
@@ -297,9 +318,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         if (c->sched_ok) {
             const size_t rb = sc.recs.size() * sizeof(mpr::SchedRec), lb = sc.level_start.size() * sizeof(int32_t);
             if (rb > c->sched_recs_cap) {
-                if (c->vox_singles) (void)hipFree(c->vox_singles);
-    if (c->vox_pairs) (void)hipFree(c->vox_pairs);
-    if (c->sched_recs) (void)hipFree(c->sched_recs);
+                if (c->sched_recs) (void)hipFree(c->sched_recs);
                 c->sched_recs = nullptr;
                 c->sched_recs_cap = 0;
                 HIP_TRY(hipMalloc(&c->sched_recs, rb));
@@ -320,7 +339,6 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
             c->sched_root = sc.root_val;
         }
     }
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->tape_index, len, 1, c->stream));
     if (c->flags & MPR_CTX_COUNTERS)
         HIP_TRY(hipMemsetAsync(c->counters, 0, (mprk::CNT_COUNT + 32) * sizeof(unsigned long long), c->stream));
     if (owner) {
@@ -338,13 +356,26 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
 }
 
 /* out[0] survivors; out[1], out[2]: single tiles and pairs of the float pass (last stage with pairing) */
-static int read_active(mpr_context* c, int out[3])
+/* The compaction publishes the counts into host-coherent memory and releases the sequence number
+ * `seq` behind them (kernels.hip: publish_counts); spin until it shows up.  The stream is polled now
+ * and then so that a failed launch cannot hang the caller. */
+static int read_active(mpr_context* c, int seq, int out[3])
 {
-    HIP_TRY(hipMemcpyAsync(c->h_pinned, c->num_active, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    out[0] = c->h_pinned[0];
-    out[1] = c->h_pinned[1];
-    out[2] = c->h_pinned[2];
+    volatile int* const p = c->pub_host;
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(&c->pub_host[3], __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xFFF) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&c->pub_host[3], __ATOMIC_ACQUIRE) == seq) break;
+                return mpr::set_error(MPR_ERR_NO_DEVICE, "the compaction finished without publishing its counts");
+            }
+            if (q != hipErrorNotReady) return mpr::set_error(MPR_ERR_NO_DEVICE, std::string("stage failed: ") + hipGetErrorString(q));
+        }
+    }
+    out[0] = p[0];
+    out[1] = p[1];
+    out[2] = p[2];
     return MPR_OK;
 }
 
@@ -375,17 +406,10 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         mprk::voxel_lds_bytes(nslots) > lds_limit || mprk::grouped_voxel_lds_bytes(nslots, 4) > lds_limit)
         return mpr::set_error(MPR_ERR_UNSUPPORTED, "tape needs more LDS than one workgroup can hold");
 
-    /* reset the images (src/context.cu:1146-1151, :1295-1301) */
-    if (dim == 3) {
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipMemsetAsync(c->filled[i], 0, c->filled_n[i] * sizeof(int), s));
-        HIP_TRY(hipMemsetAsync(c->normals, 0, (size_t)S * S * sizeof(uint32_t), s));
-    } else if (brute) {
-        HIP_TRY(hipMemsetAsync(c->filled[3], 0, c->filled_n[3] * sizeof(int), s));
-    } else {
-        HIP_TRY(hipMemsetAsync(c->filled[0], 0, c->filled_n[0] * sizeof(int), s));
-        HIP_TRY(hipMemsetAsync(c->filled[2], 0, c->filled_n[2] * sizeof(int), s));
-        HIP_TRY(hipMemsetAsync(c->filled[3], 0, c->filled_n[3] * sizeof(int), s));
-    }
+    /* ONE launch resets the images (src/context.cu:1146-1151, :1295-1301: five cudaMemsetAsync), sets
+     * *tape_index (:1137) and writes the first tile list (preload_tiles): 3-D frames clear the filled
+     * images and the normals, 2-D frames the filled images only */
+    const size_t zero_words = (dim == 3) ? c->arena_words : c->arena_images_words;
 
     int stage_list[3];
     int nstages = 0;
@@ -403,7 +427,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         rc = ensure_tiles(c, 0, (size_t)count);
         if (rc) return rc;
         TimedScope ts(c, "preload_tiles");
-        mprk::launch_preload(s, c->tiles[0], count, t0 * t0, owner ? c->owner_dev : nullptr, rank);
+        mprk::launch_begin_frame(s, c->arena, zero_words, c->tape_index, (int)tape->clauses.size(), c->num_active,
+                                 c->tiles[0], count, t0 * t0, owner ? c->owner_dev : nullptr, rank);
         c->tiles_n[0] = (size_t)count;
     } else {
         const int t8 = S / 8;
@@ -411,7 +436,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         rc = ensure_tiles(c, 3, (size_t)count);
         if (rc) return rc;
         TimedScope ts(c, "preload_tiles");
-        mprk::launch_preload(s, c->tiles[3], count, count, nullptr, 0);
+        mprk::launch_begin_frame(s, c->arena, zero_words, c->tape_index, (int)tape->clauses.size(), c->num_active,
+                                 c->tiles[3], count, count, nullptr, 0);
         c->tiles_n[3] = (size_t)count;
     }
 
@@ -474,7 +500,6 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 mprk::launch_eval_tiles(s, dim, a);
             }
         }
-        HIP_TRY(hipMemsetAsync(c->num_active, 0, 4 * sizeof(int), s));
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
         if (rc) return rc;
@@ -486,27 +511,31 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             rc = ensure_buffer(&c->vox_pairs, &c->vox_pairs_cap, (size_t)std::max(count, 2) / 2 + 1);
             if (rc) return rc;
         }
+        const int seq = ++c->pub_seq;
         const bool zs = dim == 3 && !pairing && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
         if (count > 0 && zs) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
-            mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                         c->zs_hist, c->zs_cursor);
+            mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
+                                         c->zs_hist, c->zs_cursor, c->pub_dev, seq);
         } else if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                           pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr);
+                                           pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr, c->pub_dev, seq);
+        }
+        {
+            /* does not depend on the count: queued before the host waits for it */
+            TimedScope ts(c, "copy_filled");
+            mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
         }
         int act3[3] = {0, 0, 0};
-        rc = read_active(c, act3);         /* the reference's blocking read-back (:1209, :1375) */
-        if (rc) return rc;
+        if (count > 0) {
+            rc = read_active(c, seq, act3);         /* the reference's blocking read-back (:1209, :1375) */
+            if (rc) return rc;
+        }
         const int active = act3[0];
         n_singles = act3[1];
         n_pairs = act3[2];
         c->last.tiles_active[si] = active;
-        {
-            TimedScope ts(c, "copy_filled");
-            mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
-        }
         count = last ? active : active * 64;
         c->tiles_n[next] = (size_t)count;
     }

@@ -39,17 +39,26 @@ namespace mprk {
 /* ------------------------------------------------------------------------------------ */
 /* preload_tiles — reference :45-57, plus column ownership for the multi-GPU mode        */
 /* ------------------------------------------------------------------------------------ */
-__global__ void k_preload_tiles(mpr_tile_node* __restrict__ tiles, int count, int cols,
-                                const int* __restrict__ owner, int rank)
+__global__ void __launch_bounds__(256)
+k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, int* __restrict__ tape_index, int tape_len,
+                int* __restrict__ num_active, mpr_tile_node* __restrict__ tiles, int count, int cols,
+                const int* __restrict__ owner, int rank)
 {
-    const int i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i >= count) return;
-    mpr_tile_node n;
-    n.position = i;
-    n.tape = 0;
-    n.next = -1;
-    if (owner && owner[i % cols] != rank) n.position = -1;
-    tiles[i] = n;
+    /* frame start in one launch: reset the filled images (+ normals), *tape_index, the compaction's
+     * counters (they also clear themselves after use), and write the first tile list */
+    const size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < zero_n4; k += stride) zero_base[k] = make_int4(0, 0, 0, 0);
+    if (i < 4) num_active[i] = 0;
+    if (i == 0) *tape_index = tape_len;
+    for (size_t k = i; k < (size_t)count; k += stride) {
+        mpr_tile_node n;
+        n.position = (int)k;
+        n.tape = 0;
+        n.next = -1;
+        if (owner && owner[k % cols] != rank) n.position = -1;
+        tiles[k] = n;
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -509,6 +518,18 @@ k_eval_tiles(TileStageArgs a)
     }
 }
 
+/* The host sizes the next stage's launch from the number of survivors (the reference's blocking
+ * cudaMemcpy of num_active_tiles, src/context.cu:1209, :1375).  Here the kernel that knows the
+ * count stores it straight into host-coherent pinned memory and releases a sequence number behind
+ * it; the host spins on that word — no copy kernel, no stream synchronisation. */
+DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2)
+{
+    pub[0] = n0;
+    pub[1] = n1;
+    pub[2] = n2;
+    __hip_atomic_store(&pub[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* second mask_filled_tiles + assign_next_nodes + subdivide / copy_active_tiles          */
 /* (reference :471-651) in one pass: ballot + prefix + one atomic per wave               */
@@ -517,7 +538,8 @@ template <int DIM, bool LAST>
 __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
-                    mpr_tile_node* __restrict__ out, mpr_tile_node* __restrict__ singles, int4* __restrict__ pairs)
+                    mpr_tile_node* __restrict__ out, mpr_tile_node* __restrict__ singles, int4* __restrict__ pairs,
+                    int* __restrict__ pub, int seq)
 {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -571,6 +593,19 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
         for (int w = 0; w < nw; ++w) wave_base[k][w] += b0;
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        /* the last workgroup through here has every count: hand them to the host and leave the
+         * counters cleared for the next launch */
+        __threadfence();
+        if (atomicAdd(num_active + 3, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int n1 = __hip_atomic_exchange(num_active + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int n2 = __hip_atomic_exchange(num_active + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish_counts(pub, seq, n0, n1, n2);
+        }
+    }
     const int base = wave_base[0][wave];
     const int next = active ? base + rank_in(mask, lane) : -1;
     if (valid) tiles[gidx].next = LAST ? -1 : next;   /* copy_active_tiles resets next (:650) */
@@ -649,7 +684,7 @@ k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __re
 
 /* one workgroup: cursor[z] = number of survivors in front of layer z; hist is cleared for the next use */
 __global__ void __launch_bounds__(ZS_MAX_BINS)
-k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ num_active)
+k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ pub, int seq)
 {
     __shared__ int sc[ZS_MAX_BINS];
     const int t = threadIdx.x;
@@ -665,7 +700,7 @@ k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __rest
         __syncthreads();
     }
     if (t < tps) cursor[z] = sc[t] - mine;
-    if (t == ZS_MAX_BINS - 1) num_active[0] = sc[t];
+    if (t == ZS_MAX_BINS - 1) publish_counts(pub, seq, sc[t], 0, 0);      /* the scatter is still to come: the host can already size the next launch */
 }
 
 template <bool LAST>
@@ -918,9 +953,14 @@ void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps,
 {
     hipLaunchKernelGGL(k_mask_filled_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, tps, image);
 }
-void launch_preload(hipStream_t s, mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
+void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, int* tape_index, int tape_len, int* num_active,
+                        mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
 {
-    hipLaunchKernelGGL(k_preload_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, cols, owner, rank);
+    const size_t n4 = zero_words / 4;             /* the arena's parts are padded to 64 words */
+    const size_t want = std::max(n4, (size_t)count);
+    const int blocks = (int)std::min<size_t>((want + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_preload_tiles, dim3(std::max(blocks, 1)), dim3(256), 0, s, reinterpret_cast<int4*>(zero_base), n4,
+                       tape_index, tape_len, num_active, tiles, count, cols, owner, rank);
 }
 size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + (size_t)choice_cap * 16 + (nslots > 128 ? 1024 : 0); }
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
@@ -942,24 +982,25 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     }
 }
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
-                              const int* image, int* num_active, mpr_tile_node* out, mpr_tile_node* singles, int4* pairs)
+                              const int* image, int* num_active, mpr_tile_node* out, mpr_tile_node* singles, int4* pairs,
+                              int* pub, int seq)
 {
     const dim3 g((count + 1023) / 1024), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
-                            int* num_active, mpr_tile_node* out, int* hist, int* cursor)
+                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq)
 {
     const dim3 g((count + 1023) / 1024), b(1024);
     hipLaunchKernelGGL(k_zs_hist, g, b, 0, s, tiles, count, tps, image, hist);
-    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, num_active);
+    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq);
     if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out);
     else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out);
 }

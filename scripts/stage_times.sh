@@ -10,8 +10,10 @@ rows=list(csv.DictReader(open("$OUT/t_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # last frame only: find last k_preload_tiles
 idx=[i for i,r in enumerate(rows) if "preload" in r["Kernel_Name"]][-1]
+t0=int(rows[idx]["Start_Timestamp"]); prev=t0
 for r in rows[idx:]:
     n=r["Kernel_Name"].replace("void mprk::","").split("(")[0]
-    if "rocclr" in n: continue
-    print("%-34s grid=%8s %9.1f us" % (n, r.get("Grid_Size", r.get("Grid_Size_X","?")), (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3))
+    b,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
+    print("%-34s grid=%8s %9.1f us   start +%8.1f us  gap %6.1f us" % (n[:34], r.get("Grid_Size", r.get("Grid_Size_X","?")), (e-b)/1e3, (b-t0)/1e3, (b-prev)/1e3))
+    prev=e
 PY
