@@ -43,6 +43,32 @@ __device__ __noinline__ float deriv_trig_q(uint32_t op, float a, float av, bool 
     }
 }
 
+/* asin / acos / atan as routines the assembly loop calls (NQ_CALLC): leaf functions of the AMDGPU
+ * calling convention — a in v0, "this lane holds the value component" in v1, result in v0, return
+ * address s[30:31] — with the very expressions of deriv_trig_q.  They keep v40..v47 and every SGPR from
+ * s34 up, where the interpreter's state lives. */
+__device__ __attribute__((noinline, used)) float nq_asin(float a, int isv) __asm__("mpr_nq_asin");
+__device__ __attribute__((noinline, used)) float nq_acos(float a, int isv) __asm__("mpr_nq_acos");
+__device__ __attribute__((noinline, used)) float nq_atan(float a, int isv) __asm__("mpr_nq_atan");
+__device__ float nq_asin(float a, int isv)
+{
+    const float av = quad_bcast_a(a, 3);
+    const float d = __builtin_sqrtf(1 - av * av);
+    return isv ? mpr_asinf(av) : a / d;
+}
+__device__ float nq_acos(float a, int isv)
+{
+    const float av = quad_bcast_a(a, 3);
+    const float d = -__builtin_sqrtf(1 - av * av);
+    return isv ? mpr_acosf(av) : a / d;
+}
+__device__ float nq_atan(float a, int isv)
+{
+    const float av = quad_bcast_a(a, 3);
+    const float d = av * av + 1;
+    return isv ? mpr_atanf(av) : a / d;
+}
+
 /* Fixed registers (clobbers):
  *   s[80:81] handler address  s[82:83] table base  s[84:85] block address  s86 clause word  s87 immediate
  *   s88 clause counter  s89 block base  s90 0x260  s96 0xff00  s[98:99] lanes holding the value (comp 3)
@@ -67,6 +93,14 @@ __device__ __noinline__ float deriv_trig_q(uint32_t op, float a, float av, bool 
 #define NQ_H(v, n) ".p2align 8\nL_n" #v "_" #n "_%=:\n"
 #define NQ_EXIT NQ_IMM "s_branch L_exit_%=\n"
 #define NQ_CALL(pair) "s_swappc_b64 s[70:71], " pair "\n"
+/* v37 = sym(v35) by a compiled routine; v34 (address of the out slot) survives in v44 */
+#define NQ_CALLC(sym)                                                                            \
+    "v_mov_b32 v44, v34\n v_mov_b32 v0, v35\n v_cndmask_b32_e64 v1, 0, 1, s[98:99]\n"            \
+    "s_getpc_b64 s[40:41]\n"                                                                     \
+    "s_add_u32 s40, s40, " sym "@rel32@lo+4\n"                                                   \
+    "s_addc_u32 s41, s41, " sym "@rel32@hi+12\n"                                                 \
+    "s_swappc_b64 s[30:31], s[40:41]\n"                                                          \
+    "v_mov_b32 v37, v0\n v_mov_b32 v34, v44\n" NQ_END
 #define NQ_DIV NQ_CALL("s[72:73]")
 #define NQ_SQRT NQ_CALL("s[74:75]")
 #define NQ_EXP NQ_CALL("s[76:77]")
@@ -92,7 +126,9 @@ __device__ __noinline__ float deriv_trig_q(uint32_t op, float a, float av, bool 
     NQ_H(v, 6) LDL NQ_AO WL                                  /* COS: isv ? cos(av) : -sin(av) * a */         \
     "v_mov_b32 v48, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_CALL("s[68:69]")                                  \
     "v_mul_f32_e64 v38, -v37, v48\n v_cndmask_b32 v37, v38, v36, s[98:99]\n" NQ_END                         \
-    NQ_H(v, 7) NQ_EXIT NQ_H(v, 8) NQ_EXIT NQ_H(v, 9) NQ_EXIT                                                \
+    NQ_H(v, 7) LDL NQ_AO WL "s_branch L_casin_%=\n"                                                         \
+    NQ_H(v, 8) LDL NQ_AO WL "s_branch L_cacos_%=\n"                                                         \
+    NQ_H(v, 9) LDL NQ_AO WL "s_branch L_catan_%=\n"                                                         \
     NQ_H(v, 10) LDL NQ_AO WL                                 /* EXP: e = exp(av); isv ? e : e * a */         \
     "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_EXP                                               \
     "v_mul_f32 v38, v37, v43\n v_cndmask_b32 v37, v38, v37, s[98:99]\n" NQ_END                               \
@@ -223,6 +259,9 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n"
             "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n"
             "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n"
+            "L_casin_%=:\n" NQ_CALLC("mpr_nq_asin")
+            "L_cacos_%=:\n" NQ_CALLC("mpr_nq_acos")
+            "L_catan_%=:\n" NQ_CALLC("mpr_nq_atan")
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
             "s_mov_b32 %[dlo], s86\n"
@@ -235,7 +274,12 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             : "memory", "vcc", "scc",
               "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
               "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s98", "s99",
-              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48");
+              "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
+              /* what the called routines may use on top (NQ_CALLC) */
+              "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+              "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+              "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+              "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
         /* sin, cos, asin, acos, atan (and anything that is not an opcode) */

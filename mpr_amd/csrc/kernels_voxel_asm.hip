@@ -37,9 +37,14 @@ namespace mprk {
 /* out of line, one function per opcode: the switch below runs on the scalar unit (op is uniform) */
 __device__ __noinline__ float na_sin(float v) { return mpr_sinf(v); }
 __device__ __noinline__ float na_cos(float v) { return mpr_cosf(v); }
-__device__ __noinline__ float na_asin(float v) { return mpr_asinf(v); }
-__device__ __noinline__ float na_acos(float v) { return mpr_acosf(v); }
-__device__ __noinline__ float na_atan(float v) { return mpr_atanf(v); }
+/* asin / acos / atan are also called from inside the assembly loop (MPR_CALL) under these names: leaf
+ * functions of the AMDGPU calling convention, argument and result in v0, return address s[30:31] */
+__device__ __attribute__((noinline, used)) float na_asin(float v) __asm__("mpr_fa_asin");
+__device__ __attribute__((noinline, used)) float na_acos(float v) __asm__("mpr_fa_acos");
+__device__ __attribute__((noinline, used)) float na_atan(float v) __asm__("mpr_fa_atan");
+__device__ float na_asin(float v) { return mpr_asinf(v); }
+__device__ float na_acos(float v) { return mpr_acosf(v); }
+__device__ float na_atan(float v) { return mpr_atanf(v); }
 __device__ __noinline__ float na_exp(float v) { return mpr_expf(v); }
 __device__ __noinline__ float na_log(float v) { return mpr_logf(v); }
 DEV float rare_unary_a(uint32_t op, float v)
@@ -78,6 +83,15 @@ DEV float rare_unary_a(uint32_t op, float v)
 #define MPR_H(v, n) ".p2align 8\nL_h" #v "_" #n "_%=:\n"
 #define MPR_EXIT "s_branch L_exit_%=\n"
 #define MPR_END MPR_ST MPR_DISPATCH
+/* v37 = sym(v35) by a compiled routine; v34 (address of the out slot) survives in v44.  The routines
+ * keep v40..v47 and every SGPR from s34 up (calling convention), where the interpreter's state is. */
+#define MPR_CALL(sym)                                                                            \
+    "v_mov_b32 v44, v34\n v_mov_b32 v0, v35\n"                                                   \
+    "s_getpc_b64 s[40:41]\n"                                                                     \
+    "s_add_u32 s40, s40, " sym "@rel32@lo+4\n"                                                   \
+    "s_addc_u32 s41, s41, " sym "@rel32@hi+12\n"                                                 \
+    "s_swappc_b64 s[30:31], s[40:41]\n"                                                          \
+    "v_mov_b32 v37, v0\n v_mov_b32 v34, v44\n" MPR_ST MPR_DISPATCH
 
 /* One handler table, 32 entries of 128 bytes, indexed by opcode.  There are three of them:
  *   table 0: operands come from the slot file in LDS;
@@ -100,7 +114,9 @@ DEV float rare_unary_a(uint32_t op, float v)
     MPR_H(v, 4) LDL MPR_AO WL "v_xor_b32 v37, 0x80000000, " A "\n" MPR_END                                \
     MPR_H(v, 5) LDL MPR_AO WL MVA "s_branch L_sin_%=\n"                                                  \
     MPR_H(v, 6) LDL MPR_AO WL MVA "s_branch L_cos_%=\n"                                                  \
-    MPR_H(v, 7) MPR_EXIT MPR_H(v, 8) MPR_EXIT MPR_H(v, 9) MPR_EXIT                                        \
+    MPR_H(v, 7) LDL MPR_AO WL MVA "s_branch L_casin_%=\n"                                                \
+    MPR_H(v, 8) LDL MPR_AO WL MVA "s_branch L_cacos_%=\n"                                                \
+    MPR_H(v, 9) LDL MPR_AO WL MVA "s_branch L_catan_%=\n"                                                \
     MPR_H(v, 10) LDL MPR_AO WL MVA "s_branch L_exp_%=\n"                                                  \
     MPR_H(v, 11) LDL MPR_AO WL "v_and_b32 v37, 0x7fffffff, " A "\n" MPR_END                               \
     MPR_H(v, 12) LDL MPR_AO WL MVA "s_branch L_log_%=\n"                                                  \
@@ -225,6 +241,10 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             MPR_ASM_SINCOS_BODY
             "v_mov_b32 v37, v36\n"
             MPR_ST MPR_DISPATCH
+            /* ---- v37 = mpr_asinf / mpr_acosf / mpr_atanf(v35): compiled routines, called ---- */
+            "L_casin_%=:\n" MPR_CALL("mpr_fa_asin")
+            "L_cacos_%=:\n" MPR_CALL("mpr_fa_acos")
+            "L_catan_%=:\n" MPR_CALL("mpr_fa_atan")
             /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
@@ -239,7 +259,12 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             : "memory", "vcc", "scc",
               "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
               "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+              /* what the called routines may use on top (MPR_CALL) */
+              "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+              "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+              "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+              "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
         /* dlo is the rewritten clause word: byte 0 out slot, byte 1 handler index (opcode in its low 5 bits) */
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;

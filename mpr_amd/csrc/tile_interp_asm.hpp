@@ -49,6 +49,27 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
     }
 }
 
+/* The same routines under fixed symbol names: the assembly walk calls them with s_swappc_b64 (TI_CALL)
+ * instead of leaving to C++ and coming back, which cost ~650 cycles per clause (10% of the clauses of
+ * the involute gears are acos / atan, 7% of bear's exp / log).  Leaf functions of the AMDGPU calling
+ * convention: operand in v0 (lo), v1 (hi), result in v0, v1, return address s[30:31]; they use
+ * v0..v39, v48..v55, v64..v69 and s4..s31 at most (checked against the compiler's resource remarks) and
+ * keep v40..v47, v56..v63 and s34 and up, where the walk's own state lives. */
+#define MPR_TI_NAMED(NAME, OP)                                                                        \
+    static __device__ __attribute__((noinline, used)) float2 ti_named_##NAME(float2 l) __asm__("mpr_ti_" #NAME);   \
+    static __device__ float2 ti_named_##NAME(float2 l)                                                \
+    {                                                                                                 \
+        int c = 0;                                                                                    \
+        const ival o = interval_clause(OP, iv(l.x, l.y), iv(0.0f, 0.0f), 0.0f, c);                    \
+        return make_float2(o.lo, o.hi);                                                               \
+    }
+MPR_TI_NAMED(asin, MPR_OP_ASIN_LHS)
+MPR_TI_NAMED(acos, MPR_OP_ACOS_LHS)
+MPR_TI_NAMED(atan, MPR_OP_ATAN_LHS)
+MPR_TI_NAMED(exp, MPR_OP_EXP_LHS)
+MPR_TI_NAMED(log, MPR_OP_LOG_LHS)
+#undef MPR_TI_NAMED
+
 /* Fixed registers (declared as clobbers):
  *   s[80:81] handler address   s[82:83] table base   s[84:85] block address   s86 clause word
  *   s87 immediate   s88 clause counter in block   s89 block base   s96 0xff00
@@ -80,6 +101,14 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
 #define TI_EXIT TI_IMM "s_branch L_exit_%=\n"
 #define TI_END TI_ST TI_GO
 #define TI_NEGLO "v_xor_b32 v40, 0x80000000, v40\n"
+/* call a compiled routine on v[36:37]; v34 (address of the out slot) survives in v42 */
+#define TI_CALL(sym)                                                                             \
+    "v_mov_b32 v42, v34\n v_mov_b32 v0, v36\n v_mov_b32 v1, v37\n"                               \
+    "s_getpc_b64 s[40:41]\n"                                                                     \
+    "s_add_u32 s40, s40, " sym "@rel32@lo+4\n"                                                   \
+    "s_addc_u32 s41, s41, " sym "@rel32@hi+12\n"                                                 \
+    "s_swappc_b64 s[30:31], s[40:41]\n"                                                          \
+    "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v42\n" TI_END
 
 /* LDL / LDR: bring lhs into v[36:37] / rhs into v[38:39] (load, or copy of the previous result);
  * WL / WR / WLR: s_waitcnt when lhs / rhs / either was loaded from LDS */
@@ -94,10 +123,12 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
     /* i_sin / i_cos are the constant interval [-1, 1] (inc/gpu_interval.hpp:346-380) */                     \
     TI_H(v, 5) TI_AO TI_PREP "v_mov_b32 v40, -1.0\n v_mov_b32 v41, 1.0\n" TI_END                            \
     TI_H(v, 6) TI_AO TI_PREP "v_mov_b32 v40, -1.0\n v_mov_b32 v41, 1.0\n" TI_END                            \
-    TI_H(v, 7) TI_EXIT TI_H(v, 8) TI_EXIT TI_H(v, 9) TI_EXIT                                                \
-    TI_H(v, 10) TI_EXIT                                                                                     \
+    TI_H(v, 7) LDL TI_AO TI_PREP WL "s_branch L_casin_%=\n"                                                \
+    TI_H(v, 8) LDL TI_AO TI_PREP WL "s_branch L_cacos_%=\n"                                                \
+    TI_H(v, 9) LDL TI_AO TI_PREP WL "s_branch L_catan_%=\n"                                                \
+    TI_H(v, 10) LDL TI_AO TI_PREP WL "s_branch L_cexp_%=\n"                                                \
     TI_H(v, 11) LDL TI_AO TI_PREP WL "s_branch L_abs_%=\n"                                                          \
-    TI_H(v, 12) TI_EXIT                                                                                     \
+    TI_H(v, 12) LDL TI_AO TI_PREP WL "s_branch L_clog_%=\n"                                                \
     TI_H(v, 13) TI_IMM LDL TI_AO TI_PREP WL                                                    /* ADD_LHS_IMM */    \
     "v_add_f32_e64 v40, -v36, -s87\n v_add_f32 v41, s87, v37\n" TI_NEGLO TI_END                            \
     TI_H(v, 14) LDL LDR TI_AO TI_PREP WLR                                                      /* ADD_LHS_RHS */    \
@@ -513,6 +544,12 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
             "v_cndmask_b32 v41, v41, v51, s[58:59]\n"
             TI_END
+            /* ---- compiled routines (double precision inside): called, not left for ---- */
+            "L_casin_%=:\n" TI_CALL("mpr_ti_asin")
+            "L_cacos_%=:\n" TI_CALL("mpr_ti_acos")
+            "L_catan_%=:\n" TI_CALL("mpr_ti_atan")
+            "L_cexp_%=:\n" TI_CALL("mpr_ti_exp")
+            "L_clog_%=:\n" TI_CALL("mpr_ti_log")
             /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
@@ -536,7 +573,13 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
               "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
               "s87", "s88", "s89", "s92", "s93", "s94", "s95", "s96",
               "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-              "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+              "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+              /* what the called routines may use on top (TI_CALL) */
+              "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+              "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
+              "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+              "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+              "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
         /* sqrt, division, exp, log, trigonometry (and anything that is not an opcode) */
