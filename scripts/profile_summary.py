@@ -60,8 +60,8 @@ def per_kernel(sub, counter):
 
 fetch = per_kernel("pmc_fetch", "FETCH_SIZE")
 write = per_kernel("pmc_write", "WRITE_SIZE")
-names = {"eval_voxels_f": "k_eval_voxels_asm<3>", "eval_tiles_i": "k_eval_tiles<3>", "eval_tiles_wide": "k_eval_tiles_wide<3>",
-         "eval_pixels_d": "mprk::k_eval_normals_q"}
+names = {"eval_voxels_f": "k_eval_voxels_asm<3>", "eval_tiles_i": "k_eval_tiles<3, true>", "eval_tiles_wide": "k_eval_tiles_wide<3>",
+         "eval_pixels_d": "mprk::k_eval_normals_asm"}
 out = {"_note": "KiB counters x1024; read bytes doubled per the gfx950 FETCH_SIZE correction; "
                 "per launch = mean over all launches of that kernel in the run (tile stages: mean over the 3 stages)",
        "_source": "gpurun_out/%s/pmc_fetch, pmc_write (scripts/profile_round.sh)" % tag}
