@@ -623,13 +623,18 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
  * s79 words  s[76:77] pool  s98 last pool index a chunk may start at
  * s[60:61] am  s[62:63] a1  s[64:65] a2  s[66:67] a0 / x  s[68:69] x  s[90:95] scratch
  * v32..v37 temporaries  v38 1  v[40:43] choice entry / jump words v[44:45] v[46:47]            */
-#define TP_DISPATCH                                    \
+/* next word: classified word, handler address ... */
+#define TP_PREP                                        \
     "s_sub_u32 s88, s88, 1\n"                          \
     "v_readlane_b32 s86, %[bw], s88\n"                 \
     "s_and_b32 s80, s86, s96\n"                        \
     "s_add_u32 s80, s80, s82\n"                        \
-    "s_addc_u32 s81, s83, 0\n"                         \
-    "s_setpc_b64 s[80:81]\n"
+    "s_addc_u32 s81, s83, 0\n"
+/* ... and go.  The clause handlers run TP_PREP at their very start, under the latency of the active-set
+ * lookup, and keep their own word and index in s99 / s97 (the walk is bound by the latency of its
+ * dependent chain, like the forward one) */
+#define TP_GO "s_setpc_b64 s[80:81]\n"
+#define TP_DISPATCH TP_PREP TP_GO
 #define TP_H(n) ".p2align 8\nL_p" #n "_%=:\n"
 #define TP_H4(n) ".p2align 10\nL_p" #n "_%=:\n"        /* handlers of up to 1 KiB: index multiples of 4 */
 /* am = live lanes whose out slot is active; none: next word */
@@ -637,12 +642,15 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     "s_bfe_u32 s92, s86, 0x60000\n"                                            \
     "v_readlane_b32 s60, " POL ", s92\n"                                       \
     "v_readlane_b32 s61, " POH ", s92\n"                                       \
+    "s_mov_b32 s97, s88\n"                                                     \
+    "s_mov_b32 s99, s86\n"                                                     \
+    TP_PREP                                                                     \
     "s_and_b64 s[60:61], s[60:61], s[72:73]\n"                                 \
     "s_cbranch_scc1 L_act" tag "_%=\n"                                         \
-    TP_DISPATCH                                                                 \
+    TP_GO                                                                       \
     "L_act" tag "_%=:\n"                                                       \
-    "v_readlane_b32 s70, %[blo], s88\n"                                        \
-    "v_readlane_b32 s71, %[bhi], s88\n"
+    "v_readlane_b32 s70, %[blo], s97\n"                                        \
+    "v_readlane_b32 s71, %[bhi], s97\n"
 /* every lane of am takes the next word of its chunk; lanes that fill it move to the next chunk of
  * their run and write the two links (reference :384-413) or, out of room, stop pushing */
 #define TP_OFFSET(tag)                                                          \
@@ -672,23 +680,23 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
 #define TP_UPDATE(POL, POH, PLL, PLH, PRL, PRH, XL0, XL1, XR0, XR1)             \
     "s_lshl_b64 exec, 1, s92\n"                                                \
     "v_mov_b32 " POL ", 0\n v_mov_b32 " POH ", 0\n"                            \
-    "s_bfe_u32 s93, s86, 0x60010\n"                                            \
+    "s_bfe_u32 s93, s99, 0x60010\n"                                            \
     "s_lshl_b64 exec, 1, s93\n"                                                \
     "v_or_b32 " PLL ", " XL0 ", " PLL "\n v_or_b32 " PLH ", " XL1 ", " PLH "\n"  \
-    "s_bfe_u32 s93, s86, 0x60018\n"                                            \
+    "s_bfe_u32 s93, s99, 0x60018\n"                                            \
     "s_lshl_b64 exec, 1, s93\n"                                                \
     "v_or_b32 " PRL ", " XR0 ", " PRL "\n v_or_b32 " PRH ", " XR1 ", " PRH "\n"
 /* a clause that is neither min nor max: live lanes keep it as it is, both operands become live */
 #define TP_PLAIN(n, POL, POH, PLL, PLH, PRL, PRH)                               \
     TP_H4(n) TP_AM(POL, POH, #n) TP_OFFSET(#n)                                   \
-    "s_bfe_u32 s92, s86, 0x60000\n"                                            \
+    "s_bfe_u32 s92, s99, 0x60000\n"                                            \
     TP_UPDATE(POL, POH, PLL, PLH, PRL, PRH, "s60", "s61", "s60", "s61")        \
     "s_mov_b64 exec, s[60:61]\n"                                               \
     "v_add_lshl_u32 v34, %[oi], %[oo], 3\n"                                    \
     "v_mov_b32 v36, s70\n v_mov_b32 v37, s71\n"                                \
     "global_store_dwordx2 v34, v[36:37], s[76:77]\n"                           \
     "s_mov_b64 exec, -1\n"                                                     \
-    TP_DISPATCH
+    TP_GO
 /* min / max: lanes that chose a side keep only that operand and get a COPY (or nothing, when the
  * copy would be onto itself); bit 6 / 7 of byte 0: lhs == out / rhs == out, bit 6 of byte 2: no rhs */
 #define TP_MINMAX(n, POL, POH, PLL, PLH, PRL, PRH)                              \
@@ -710,20 +718,20 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     "s_and_b64 s[64:65], s[64:65], s[60:61]\n"            /* a2 */             \
     "s_or_b64 s[68:69], s[66:67], s[62:63]\n"             /* lhs live for a0 | a1 */ \
     "s_or_b64 s[66:67], s[66:67], s[64:65]\n"             /* rhs live for a0 | a2 */ \
-    "s_bfe_u32 s92, s86, 0x60000\n"                                            \
+    "s_bfe_u32 s92, s99, 0x60000\n"                                            \
     TP_UPDATE(POL, POH, PLL, PLH, PRL, PRH, "s68", "s69", "s66", "s67")        \
     "s_mov_b64 exec, -1\n"                                                     \
     "s_andn2_b32 s92, s70, 0xff\n"                                             \
     "s_or_b32 s93, s92, 28\n"                              /* COPY_LHS */      \
-    "s_bitcmp1_b32 s86, 22\n"                                                  \
+    "s_bitcmp1_b32 s99, 22\n"                                                  \
     "s_cselect_b32 s94, 27, 29\n"                          /* COPY_IMM : COPY_RHS */ \
     "s_or_b32 s94, s92, s94\n"                                                 \
     "v_mov_b32 v36, s70\n v_mov_b32 v33, s93\n v_mov_b32 v35, s94\n"           \
     "v_cndmask_b32 v36, v36, v33, s[62:63]\n"                                  \
     "v_cndmask_b32 v36, v36, v35, s[64:65]\n"                                  \
-    "s_bitcmp1_b32 s86, 6\n"                                                   \
+    "s_bitcmp1_b32 s99, 6\n"                                                   \
     "s_cselect_b64 s[90:91], s[62:63], 0\n"                                    \
-    "s_bitcmp1_b32 s86, 7\n"                                                   \
+    "s_bitcmp1_b32 s99, 7\n"                                                   \
     "s_cselect_b64 s[92:93], s[64:65], 0\n"                                    \
     "s_or_b64 s[90:91], s[90:91], s[92:93]\n"             /* lanes whose copy is dropped */ \
     "v_add_lshl_u32 v34, %[oi], %[oo], 3\n"                                    \
@@ -733,7 +741,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     "v_mov_b32 v37, s71\n"                                                     \
     "global_store_dwordx2 v34, v[36:37], s[76:77]\n"                           \
     "s_mov_b64 exec, -1\n"                                                     \
-    TP_DISPATCH
+    TP_GO
 
 struct TilePushState {
     uint32_t a0l, a0h, a1l, a1h;      /* active set: slots 0..63 in lanes of (a0l, a0h), 64..127 in (a1l, a1h) */
@@ -886,7 +894,7 @@ DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char
         : "memory", "vcc", "scc",
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
           "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s86", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-          "s95", "s96", "s98",
+          "s95", "s96", "s97", "s98", "s99",
           "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
     st.a0l = a0l; st.a0h = a0h; st.a1l = a1l; st.a1h = a1h;
     st.out_index = oi;
