@@ -104,40 +104,44 @@ DEV float rare_unary_a(uint32_t op, float v)
  *   WL / WR / WLR  s_waitcnt if lhs / rhs / either was loaded,
  *   MVA / MVB  copy a forwarded operand into v35 / v36 for the shared long sequences,
  *   NL / NR  the wait state still owed between the v_readlane of the immediate and its first
- *   VALU use when no load of lhs / rhs sits in between.                                         */
-#define MPR_TABLE(v, LDL, A, LDR, B, WL, WR, WLR, MVA, MVB, NL, NR)                                               \
+ *   VALU use when no load of lhs / rhs sits in between,
+ *   AO / END  tables 3-5 are tables 0-2 for clauses whose result dies in the next clause (which takes
+ *   it from v37 and overwrites the same slot — half of the clauses of the benchmark models): the
+ *   one-instruction handlers neither compute the slot's address (a s_nop keeps the wait states) nor
+ *   store.                                                                                       */
+#define MPR_TABLE(v, LDL, A, LDR, B, WL, WR, WLR, MVA, MVB, NL, NR, AO, END)                                               \
     MPR_H(v, 0) MPR_EXIT                                              /* end of tape */                   \
     MPR_H(v, 1)                                                       /* JUMP: base += j + imm + 1 */     \
     MPR_IMM "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n"   \
-    MPR_H(v, 2) LDL MPR_AO WL "v_mul_f32 v37, " A ", " A "\n" MPR_END                                     \
+    MPR_H(v, 2) LDL AO WL "v_mul_f32 v37, " A ", " A "\n" END                                     \
     MPR_H(v, 3) LDL MPR_AO WL MVA "s_branch L_sqrt_%=\n"                                                  \
-    MPR_H(v, 4) LDL MPR_AO WL "v_xor_b32 v37, 0x80000000, " A "\n" MPR_END                                \
+    MPR_H(v, 4) LDL AO WL "v_xor_b32 v37, 0x80000000, " A "\n" END                                \
     MPR_H(v, 5) LDL MPR_AO WL MVA "s_branch L_sin_%=\n"                                                  \
     MPR_H(v, 6) LDL MPR_AO WL MVA "s_branch L_cos_%=\n"                                                  \
     MPR_H(v, 7) LDL MPR_AO WL MVA "s_branch L_casin_%=\n"                                                \
     MPR_H(v, 8) LDL MPR_AO WL MVA "s_branch L_cacos_%=\n"                                                \
     MPR_H(v, 9) LDL MPR_AO WL MVA "s_branch L_catan_%=\n"                                                \
     MPR_H(v, 10) LDL MPR_AO WL MVA "s_branch L_exp_%=\n"                                                  \
-    MPR_H(v, 11) LDL MPR_AO WL "v_and_b32 v37, 0x7fffffff, " A "\n" MPR_END                               \
+    MPR_H(v, 11) LDL AO WL "v_and_b32 v37, 0x7fffffff, " A "\n" END                               \
     MPR_H(v, 12) LDL MPR_AO WL MVA "s_branch L_log_%=\n"                                                  \
-    MPR_H(v, 13) MPR_IMM LDL MPR_AO WL NL "v_add_f32 v37, s87, " A "\n" MPR_END                                      \
-    MPR_H(v, 14) LDL LDR MPR_AO WLR "v_add_f32 v37, " A ", " B "\n" MPR_END                               \
-    MPR_H(v, 15) MPR_IMM LDL MPR_AO WL NL "v_mul_f32 v37, s87, " A "\n" MPR_END                                      \
-    MPR_H(v, 16) LDL LDR MPR_AO WLR "v_mul_f32 v37, " A ", " B "\n" MPR_END                               \
+    MPR_H(v, 13) MPR_IMM LDL AO WL NL "v_add_f32 v37, s87, " A "\n" END                                      \
+    MPR_H(v, 14) LDL LDR AO WLR "v_add_f32 v37, " A ", " B "\n" END                               \
+    MPR_H(v, 15) MPR_IMM LDL AO WL NL "v_mul_f32 v37, s87, " A "\n" END                                      \
+    MPR_H(v, 16) LDL LDR AO WLR "v_mul_f32 v37, " A ", " B "\n" END                               \
     /* min / max: operands canonicalised first (a signalling NaN loses against a number, like fminf) */  \
-    MPR_H(v, 17) MPR_IMM LDL MPR_AO NL "v_max_f32 v36, s87, s87\n" WL "v_max_f32 v35, " A ", " A "\n v_min_f32 v37, v35, v36\n" MPR_END \
-    MPR_H(v, 18) LDL LDR MPR_AO WLR "v_max_f32 v35, " A ", " A "\n v_max_f32 v36, " B ", " B "\n v_min_f32 v37, v35, v36\n" MPR_END \
-    MPR_H(v, 19) MPR_IMM LDL MPR_AO NL "v_max_f32 v36, s87, s87\n" WL "v_max_f32 v35, " A ", " A "\n v_max_f32 v37, v35, v36\n" MPR_END \
-    MPR_H(v, 20) LDL LDR MPR_AO WLR "v_max_f32 v35, " A ", " A "\n v_max_f32 v36, " B ", " B "\n v_max_f32 v37, v35, v36\n" MPR_END \
-    MPR_H(v, 21) MPR_IMM LDL MPR_AO WL NL "v_subrev_f32 v37, s87, " A "\n" MPR_END          /* lhs - imm */         \
-    MPR_H(v, 22) MPR_IMM LDR MPR_AO WR NR "v_sub_f32 v37, s87, " B "\n" MPR_END             /* imm - rhs */         \
-    MPR_H(v, 23) LDL LDR MPR_AO WLR "v_sub_f32 v37, " A ", " B "\n" MPR_END                               \
+    MPR_H(v, 17) MPR_IMM LDL AO NL "v_max_f32 v36, s87, s87\n" WL "v_max_f32 v35, " A ", " A "\n v_min_f32 v37, v35, v36\n" END \
+    MPR_H(v, 18) LDL LDR AO WLR "v_max_f32 v35, " A ", " A "\n v_max_f32 v36, " B ", " B "\n v_min_f32 v37, v35, v36\n" END \
+    MPR_H(v, 19) MPR_IMM LDL AO NL "v_max_f32 v36, s87, s87\n" WL "v_max_f32 v35, " A ", " A "\n v_max_f32 v37, v35, v36\n" END \
+    MPR_H(v, 20) LDL LDR AO WLR "v_max_f32 v35, " A ", " A "\n v_max_f32 v36, " B ", " B "\n v_max_f32 v37, v35, v36\n" END \
+    MPR_H(v, 21) MPR_IMM LDL AO WL NL "v_subrev_f32 v37, s87, " A "\n" END          /* lhs - imm */         \
+    MPR_H(v, 22) MPR_IMM LDR AO WR NR "v_sub_f32 v37, s87, " B "\n" END             /* imm - rhs */         \
+    MPR_H(v, 23) LDL LDR AO WLR "v_sub_f32 v37, " A ", " B "\n" END                               \
     MPR_H(v, 24) MPR_IMM LDL MPR_AO WL MVA "v_mov_b32 v36, s87\n s_branch L_div_%=\n"    /* lhs / imm */         \
     MPR_H(v, 25) MPR_IMM LDR MPR_AO WR MVB "v_mov_b32 v35, s87\n s_branch L_div_%=\n"    /* imm / rhs */         \
     MPR_H(v, 26) LDL LDR MPR_AO WLR MVA MVB "s_branch L_div_%=\n"                                         \
-    MPR_H(v, 27) MPR_IMM MPR_AO "s_nop 0\n v_mov_b32 v37, s87\n" MPR_END                 /* COPY_IMM */          \
-    MPR_H(v, 28) LDL MPR_AO WL "v_mov_b32 v37, " A "\n" MPR_END                  /* COPY_LHS */          \
-    MPR_H(v, 29) LDR MPR_AO WR "v_mov_b32 v37, " B "\n" MPR_END                  /* COPY_RHS */          \
+    MPR_H(v, 27) MPR_IMM AO "s_nop 0\n v_mov_b32 v37, s87\n" END                 /* COPY_IMM */          \
+    MPR_H(v, 28) LDL AO WL "v_mov_b32 v37, " A "\n" END                  /* COPY_LHS */          \
+    MPR_H(v, 29) LDR AO WR "v_mov_b32 v37, " B "\n" END                  /* COPY_RHS */          \
     MPR_H(v, 30) MPR_EXIT                                                         /* not an opcode */     \
     MPR_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"                  /* lane 63: next block */
 
@@ -202,9 +206,26 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "v_cndmask_b32 v42, 0, v44, s[92:93]\n"          /* rhs forwarded: table 2 */
             "v_cndmask_b32 v42, v42, v43, vcc\n"             /* lhs forwarded: table 1 */
             "v_cndmask_b32 v42, 0, v42, s[94:95]\n"
+            /* this clause takes the previous result from v37 (exactly one operand), writes the same slot
+             * and is an ordinary opcode: the previous clause need not store (tables 3-5 = +96) */
+            "s_xor_b64 s[40:41], s[92:93], vcc\n"
+            "s_and_b64 s[40:41], s[40:41], s[94:95]\n"
+            "v_cmp_eq_u32 s[42:43], v40, v41\n"
+            "v_add_u32 v45, -2, v38\n"
+            "v_cmp_gt_u32 s[44:45], 28, v45\n"
+            "v_cmp_ne_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63's clause runs as lane 0 of the next block: from LDS */
+            "s_and_b64 s[40:41], s[40:41], s[42:43]\n"
+            "s_and_b64 s[44:45], s[44:45], vcc\n"
+            "s_and_b64 s[40:41], s[40:41], s[44:45]\n"
+            "v_mov_b32 v46, 0\n"
+            "v_mov_b32 v47, 0x60\n"
+            "v_cndmask_b32 v45, 0, v47, s[40:41]\n"
+            "v_add_u32 v38, v38, v42\n"
+            "s_nop 0\n"
+            "v_mov_b32_dpp v46, v45 wave_shl:1 row_mask:0xf bank_mask:0xf\n"   /* lane j <- lane j + 1 (lane 63: 0) */
             "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */
             "v_mov_b32 v39, 31\n"
-            "v_add_u32 v38, v38, v42\n"
+            "v_add_u32 v38, v38, v46\n"
             "v_cndmask_b32 v38, v38, v39, vcc\n"             /* handler index = table * 32 + opcode */
             /* clause word as the handlers see it: byte 0 out slot, byte 1 handler index, bytes 2, 3 lhs, rhs */
             "v_lshl_or_b32 v38, v38, 8, v40\n"
@@ -213,9 +234,12 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_nop 0\n"
             MPR_DISPATCH
             /* ---- handlers: three tables of 32 x 128 bytes ---- */
-            MPR_TABLE(0, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "")
-            MPR_TABLE(1, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "")
-            MPR_TABLE(2, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n")
+            MPR_TABLE(0, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "", MPR_AO, MPR_END)
+            MPR_TABLE(1, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "", MPR_AO, MPR_END)
+            MPR_TABLE(2, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n", MPR_AO, MPR_END)
+            MPR_TABLE(3, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "", "s_nop 0\n", MPR_DISPATCH)
+            MPR_TABLE(4, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "", "s_nop 0\n", MPR_DISPATCH)
+            MPR_TABLE(5, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n", "s_nop 0\n", MPR_DISPATCH)
             /* ---- v37 = v35 / v36, correctly rounded ---- */
             ".p2align 7\n"
             "L_div_%=:\n"
