@@ -516,14 +516,15 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (count > 0 && zs) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
-                                         c->zs_hist, c->zs_cursor, c->pub_dev, seq);
+                                         c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub));
         } else if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                           pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr, c->pub_dev, seq);
+                                           pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr, c->pub_dev, seq,
+                                           c->filled[next], S / (tile_size_px / sub));
         }
-        {
-            /* does not depend on the count: queued before the host waits for it */
+        if (count == 0) {
+            /* copy_filled rides in the compaction's launch; no compaction, a launch of its own */
             TimedScope ts(c, "copy_filled");
             mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
         }

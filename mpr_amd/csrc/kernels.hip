@@ -518,6 +518,25 @@ k_eval_tiles(TileStageArgs a)
     }
 }
 
+/* copy_filled (reference :664-692) rides along in the compaction's launch as extra workgroups: it only
+ * needs the stage's finished image, and a launch of its own costs more than the work */
+struct CopyFilled {
+    const int* prev;      /* this level's image */
+    int* next;            /* the next level's image */
+    int size;             /* the next level's tiles per side */
+    int first_block;      /* workgroups from here on copy */
+};
+template <int DIM>
+DEV void copy_filled_block(const CopyFilled& cf, int block, int nthreads, int tid)
+{
+    constexpr int SUB = (DIM == 3) ? 4 : 8;
+    const long long idx = (long long)block * nthreads + tid;
+    if (idx >= (long long)cf.size * cf.size) return;
+    const int x = (int)(idx % cf.size), y = (int)(idx / cf.size);
+    const int t = cf.prev[x / SUB + (y / SUB) * (cf.size / SUB)];
+    if (t) cf.next[x + y * cf.size] = (DIM == 3) ? t * 4 + 3 : 1;
+}
+
 /* The host sizes the next stage's launch from the number of survivors (the reference's blocking
  * cudaMemcpy of num_active_tiles, src/context.cu:1209, :1375).  Here the kernel that knows the
  * count stores it straight into host-coherent pinned memory and releases a sequence number behind
@@ -539,8 +558,12 @@ __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
                     mpr_tile_node* __restrict__ out, mpr_tile_node* __restrict__ singles, int4* __restrict__ pairs,
-                    int* __restrict__ pub, int seq)
+                    int* __restrict__ pub, int seq, CopyFilled cf)
 {
+    if ((int)blockIdx.x >= cf.first_block) {
+        copy_filled_block<DIM>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
+        return;
+    }
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = gidx < count;
@@ -597,7 +620,7 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
         /* the last workgroup through here has every count: hand them to the host and leave the
          * counters cleared for the next launch */
         __threadfence();
-        if (atomicAdd(num_active + 3, 1) == (int)gridDim.x - 1) {
+        if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
             __threadfence();
             const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int n1 = __hip_atomic_exchange(num_active + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -662,8 +685,13 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
 constexpr int ZS_MAX_BINS = 1024;
 
 __global__ void __launch_bounds__(1024)
-k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ hist)
+k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ hist,
+          CopyFilled cf)
 {
+    if ((int)blockIdx.x >= cf.first_block) {
+        copy_filled_block<3>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
+        return;
+    }
     __shared__ int lh[ZS_MAX_BINS];
     for (int i = threadIdx.x; i < tps; i += blockDim.x) lh[i] = 0;
     __syncthreads();
@@ -981,25 +1009,41 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
         else hipLaunchKernelGGL((k_eval_tiles<2, false>), dim3(groups), dim3(64), lds, s, a);
     }
 }
+static CopyFilled copy_filled_args(const int* prev, int* next, int size, int first_block, unsigned* extra)
+{
+    CopyFilled cf;
+    cf.prev = prev;
+    cf.next = next;
+    cf.size = size;
+    cf.first_block = first_block;
+    *extra = (unsigned)(((long long)size * size + 1023) / 1024);
+    return cf;
+}
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out, mpr_tile_node* singles, int4* pairs,
-                              int* pub, int seq)
+                              int* pub, int seq, int* next_image, int next_size)
 {
-    const dim3 g((count + 1023) / 1024), b(1024);
+    const unsigned nb = (unsigned)((count + 1023) / 1024);
+    unsigned extra = 0;
+    const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
+    const dim3 g(nb + extra), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
-                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq)
+                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size)
 {
-    const dim3 g((count + 1023) / 1024), b(1024);
-    hipLaunchKernelGGL(k_zs_hist, g, b, 0, s, tiles, count, tps, image, hist);
+    const unsigned nb = (unsigned)((count + 1023) / 1024);
+    unsigned extra = 0;
+    const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
+    const dim3 g(nb), b(1024);
+    hipLaunchKernelGGL(k_zs_hist, dim3(nb + extra), b, 0, s, tiles, count, tps, image, hist, cf);
     hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq);
     if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out);
     else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out);

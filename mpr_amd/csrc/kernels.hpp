@@ -123,7 +123,7 @@ void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, int* t
                         mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
-                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq);
+                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
@@ -131,7 +131,7 @@ bool wide_stage_fits(int nclauses);
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
-                              mpr_tile_node* singles, int4* pairs, int* pub, int seq);
+                              mpr_tile_node* singles, int4* pairs, int* pub, int seq, int* next_image, int next_size);
 /* num_active points at three counters: survivors, and (last stage with pairing) single tiles and pairs */
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
