@@ -35,7 +35,7 @@ DEV void mark_val(unsigned char* act, uint32_t v)
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_eval_tiles_wide(WideStageArgs w)
 {
     const TileStageArgs& a = w.t;
@@ -44,12 +44,12 @@ k_eval_tiles_wide(WideStageArgs w)
     float2* const V = reinterpret_cast<float2*>(smem);                                   /* [n + 3] values */
     unsigned char* const ch = smem + (size_t)(n + 3) * 8;                                /* [n] choice of clause i */
     unsigned char* const act = ch + n;                                                   /* [n] live flags */
-    int* const sh = reinterpret_cast<int*>(smem + (((size_t)(n + 3) * 8 + 2 * (size_t)n + 15) & ~(size_t)15));   /* [272] */
+    int* const sh = reinterpret_cast<int*>(smem + (((size_t)(n + 3) * 8 + 2 * (size_t)n + 15) & ~(size_t)15));   /* [1040] */
     /* sh[0] any choice, sh[1] state (0 dead, 1 ambiguous), sh[2] pool base, sh[3] ok, sh[4] min live-and-dropped i,
-     * sh[5] min written i, sh[8..8+256] scan */
+     * sh[5] min written i, sh[8..8+1024] scan */
 
     const int tid = threadIdx.x;
-    const int nt = blockDim.x;                              /* 64 for narrow tapes, 256 for wide ones */
+    const int nt = blockDim.x;                              /* 64 for narrow tapes, 256 for wide ones, 1024 when the tiles are few */
     const int gidx = blockIdx.x;
     const uint64_t* __restrict__ const tro = a.tape_ro;
     uint64_t* __restrict__ const twr = a.tape_wr;
@@ -284,7 +284,7 @@ k_eval_tiles_wide(WideStageArgs w)
 
 size_t wide_stage_lds_bytes(int nclauses)
 {
-    return (((size_t)(nclauses + 3) * 8 + 2 * (size_t)nclauses + 15) & ~(size_t)15) + 272 * sizeof(int);
+    return (((size_t)(nclauses + 3) * 8 + 2 * (size_t)nclauses + 15) & ~(size_t)15) + 1040 * sizeof(int);
 }
 bool wide_stage_fits(int nclauses) { return wide_stage_lds_bytes(nclauses) <= 150 * 1024; }
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w)
@@ -297,7 +297,13 @@ void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w)
     }
     const size_t lds = wide_stage_lds_bytes(w.nclauses);
     /* one wavefront per tile when the levels are narrow (no cross-wave barriers), four otherwise */
-    const int threads = (w.nclauses / (w.nlevels > 0 ? w.nlevels : 1) >= 48) ? 256 : 64;
+    const int width = w.nclauses / (w.nlevels > 0 ? w.nlevels : 1);
+    int threads = (width >= 48) ? 256 : 64;
+    /* a frame with no more tiles than compute units (256 at 1024^2): sixteen wavefronts per tile shorten
+     * both the levels (one clause per thread) and the serial ranking / writing loops */
+    if (const char* e = getenv("MPR_WIDE_THREADS")) threads = atoi(e);
+    else if (width >= 192 && w.t.count <= 256) threads = 1024;
+    else if (width >= 192 && w.t.count <= 1024) threads = 512;
     if (dim == 3) hipLaunchKernelGGL(k_eval_tiles_wide<3>, dim3(w.t.count), dim3(threads), lds, s, w);
     else hipLaunchKernelGGL(k_eval_tiles_wide<2>, dim3(w.t.count), dim3(threads), lds, s, w);
 }
