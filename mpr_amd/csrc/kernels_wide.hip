@@ -121,10 +121,18 @@ k_eval_tiles_wide(WideStageArgs w)
     /* ---- forward, level by level ---- */
     const uint4* __restrict__ const recs = reinterpret_cast<const uint4*>(w.recs);
     bool my_choice = false;
+    /* the first record of the NEXT level is fetched before this level's arithmetic: a level is one
+     * clause per thread more often than not, and the fetch (an L2 hit, every tile reads the same
+     * records) would otherwise sit on the critical path of every level */
+    int begin = w.level_start[0], end = w.nlevels > 0 ? w.level_start[1] : 0;
+    uint4 qn = make_uint4(0, 0, 0, 0);
+    if (begin + tid < end) qn = recs[begin + tid];
     for (int lv = 0; lv < w.nlevels; ++lv) {
-        const int begin = w.level_start[lv], end = w.level_start[lv + 1];
+        const int nbegin = end, nend = (lv + 1 < w.nlevels) ? w.level_start[lv + 2] : end;
+        uint4 q = qn;
+        if (nbegin + tid < nend) qn = recs[nbegin + tid];
         for (int k = begin + tid; k < end; k += nt) {
-            const uint4 q = recs[k];
+            if (k != begin + tid) q = recs[k];
             const uint32_t op = q.x & 0xFF, r8 = q.x >> 24;
             const uint32_t pl = q.z & 0xFFFF, pr = q.z >> 16, idx = q.w & 0xFFFF, ord = q.w >> 16;
             const float imm = mpr_u2f(q.y);
@@ -140,6 +148,8 @@ k_eval_tiles_wide(WideStageArgs w)
             my_choice |= c != 0;
         }
         __syncthreads();
+        begin = nbegin;
+        end = nend;
     }
     if (my_choice) sh[0] = 1;
     const float2 res = V[w.root_val];
