@@ -147,7 +147,10 @@ DEV float rare_unary_a(uint32_t op, float v)
 
 /* Walks the tape whose first clause is tro[first] over the slot file at LDS offset 0 (slot s of
  * lane l at s * 256 + l * 4) and returns the result slot named by the end clause. */
-DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane)
+/* first_block: the 64 words at tro[first + lane], when the caller has already fetched them (under
+ * other latencies of its prologue), else null */
+DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane,
+                        const uint64_t* first_block = nullptr)
 {
     unsigned char* const myslot = smem + lane * 4;
     /* state of the assembly interpreter that has to survive a trip through C++ */
@@ -161,7 +164,12 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
     const uint32_t selO = to_vgpr(0x0c0c0400u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
     const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
     float prev = 0.0f;
-    uint32_t mode = 0;                               /* 0: fetch the block at `base`; 1: continue after `sj` */
+    uint32_t mode = 0;                               /* 0: fetch the block at `base`; 1: continue after `sj`; 2: block is there */
+    if (first_block) {
+        blo = (uint32_t)*first_block;
+        bhi = (uint32_t)(*first_block >> 32);
+        mode = 2;
+    }
 
     for (;;) {
         base = rdfirst(base);
@@ -179,6 +187,8 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_addc_u32 s83, s83, 0\n"
             "s_cmp_eq_u32 %[mode], 0\n"
             "s_cbranch_scc1 L_load_%=\n"
+            "s_cmp_eq_u32 %[mode], 2\n"
+            "s_cbranch_scc1 L_loaded_%=\n"
             MPR_DISPATCH
             /* ---- fetch 63 clauses at s89, build the handler addresses ---- */
             "L_load_%=:\n"
@@ -189,6 +199,7 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_addc_u32 s85, s85, %[thi]\n"
             "global_load_dword %[blo], %[lane8], s[84:85]\n"
             "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
+            "L_loaded_%=:\n"
             "s_mov_b32 s88, -1\n"
             "v_mov_b32 v41, 0\n"
             "v_mov_b32 v43, 32\n"
@@ -313,6 +324,11 @@ k_eval_voxels_asm(VoxelArgs a)
     const uint64_t* __restrict__ const tro = a.tape_ro;
     const int position = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].position);
     const int tape = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].tape);
+    /* the tape's first 64 words and the root head are requested now, so that they travel together with
+     * the heightmap read of the skip test instead of after it (three dependent round trips to L2 per
+     * tile otherwise; tiles with short tapes are bound by exactly that) */
+    const uint64_t first_block = tro[tape + 1 + lane];
+    const uint64_t head0 = tro[0];
 
     constexpr int SUB = (DIM == 3) ? 4 : 8;
     const int S = a.tps * SUB;
@@ -346,12 +362,11 @@ k_eval_voxels_asm(VoxelArgs a)
         vy = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
         vz = a.z;
     }
-    const uint64_t head0 = tro[0];
     *reinterpret_cast<float*>(myslot + ((head0 >> 8) & 0xFF) * 256) = vx;
     *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
     *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
 
-    const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane);
+    const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane, &first_block);
     const float res = *reinterpret_cast<const float*>(myslot + rslot * 256);
     if (!skip && res < 0.0f) {
         if (DIM == 3) {
