@@ -140,6 +140,9 @@ k_eval_tiles(TileStageArgs a)
     if (alive_mask == 0) return;
     const int leader = __ffsll((long long)alive_mask) - 1;
     const int tape = __builtin_amdgcn_readlane(node.tape, leader);
+    /* the tape's first 64 words travel under the interval arithmetic of the prologue */
+    uint64_t first_block = 0;
+    if (ASM) first_block = a.tape_ro[tape + 1 + lane];
 
     /* tile corners in round-to-nearest (reference :91-96) */
     const float t = (float)a.tps;
@@ -202,7 +205,7 @@ k_eval_tiles(TileStageArgs a)
     uint64_t d = 0;
     if (ASM) {
         const TileInterpResult ir = tile_interp_asm(tro, (uint32_t)(tape + 1), smem, lane, alive_mask,
-                                                    (uint32_t)a.nslots * 512u, a.choice_cap);
+                                                    (uint32_t)a.nslots * 512u, a.choice_cap, &first_block);
         ci = ir.nchoices;
         any_choice = ir.any_choice;
         fwd_words = ir.words;

@@ -274,7 +274,8 @@ struct TileInterpResult {
 /* smem: slot planes at LDS offset 0 (see the header); choices: ulonglong2[choice_cap] at LDS byte
  * offset choice_off */
 DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane,
-                                     uint64_t alive_mask, uint32_t choice_off, int choice_cap)
+                                     uint64_t alive_mask, uint32_t choice_off, int choice_cap,
+                                     const uint64_t* first_block = nullptr)
 {
     float* const plane = reinterpret_cast<float*>(smem);                  /* slot s: plane[s * 128 + lane], + 64 */
     uint32_t blo = 0, bhi = 0;
@@ -289,6 +290,11 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     uint32_t ci = 0, words = 0, anylo = 0, anyhi = 0;
     float plo = 0.0f, phi = 0.0f;
     uint32_t mode = 0;
+    if (first_block) {                 /* the caller fetched tro[first + lane] under its own prologue */
+        blo = (uint32_t)*first_block;
+        bhi = (uint32_t)(*first_block >> 32);
+        mode = 2;
+    }
 
     for (;;) {
         base = rdfirst(base);
@@ -319,6 +325,8 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "s_addc_u32 s83, s83, 0\n"
             "s_cmp_eq_u32 %[mode], 0\n"
             "s_cbranch_scc1 L_load_%=\n"
+            "s_cmp_eq_u32 %[mode], 2\n"
+            "s_cbranch_scc1 L_loaded_%=\n"
             TI_DISPATCH
             /* ---- fetch 63 clauses at s89, rewrite the clause words ---- */
             "L_load_%=:\n"
@@ -329,6 +337,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "s_addc_u32 s85, s85, %[thi]\n"
             "global_load_dword %[blo], %[lane8], s[84:85]\n"
             "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
+            "L_loaded_%=:\n"
             "s_mov_b32 s88, -1\n"
             "v_mov_b32 v45, 0\n"
             "v_mov_b32 v47, 32\n"
