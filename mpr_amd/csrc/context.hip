@@ -223,7 +223,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     }
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
-    CT(hipMalloc((void**)&c->num_active, 4 * sizeof(int)));
+    CT(hipMalloc((void**)&c->num_active, 8 * sizeof(int)));      /* [0..2] counts, [3] workgroups done, [4] choices the next stage needs */
     CT(hipMalloc((void**)&c->zs_hist, 1024 * sizeof(int)));
     CT(hipMalloc((void**)&c->zs_cursor, 1024 * sizeof(int)));
     CT(hipMemsetAsync(c->zs_hist, 0, 1024 * sizeof(int), c->stream));
@@ -235,7 +235,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipHostMalloc((void**)&c->pub_host, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->pub_host, 0, 16 * sizeof(int));
     CT(hipHostGetDevicePointer((void**)&c->pub_dev, c->pub_host, 0));
-    CT(hipMemsetAsync(c->num_active, 0, 4 * sizeof(int), c->stream));
+    CT(hipMemsetAsync(c->num_active, 0, 8 * sizeof(int), c->stream));
     CT(hipMemsetAsync(c->arena, 0, c->arena_words * sizeof(int), c->stream));
     CT(hipStreamSynchronize(c->stream));
 #undef CT
@@ -359,7 +359,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
 /* The compaction publishes the counts into host-coherent memory and releases the sequence number
  * `seq` behind them (kernels.hip: publish_counts); spin until it shows up.  The stream is polled now
  * and then so that a failed launch cannot hang the caller. */
-static int read_active(mpr_context* c, int seq, int out[3])
+static int read_active(mpr_context* c, int seq, int out[4])
 {
     volatile int* const p = c->pub_host;
     for (unsigned spins = 1;; ++spins) {
@@ -376,6 +376,7 @@ static int read_active(mpr_context* c, int seq, int out[3])
     out[0] = p[0];
     out[1] = p[1];
     out[2] = p[2];
+    out[3] = p[4];
     return MPR_OK;
 }
 
@@ -418,6 +419,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     else { stage_list[0] = 0; stage_list[1] = 2; nstages = 2; }
 
     int count;
+    /* the choice array of a stage is sized by what the previous stage reports its tapes can need (an
+     * upper bound counted by the backward walks), not by the root tape's min / max count: with 488 of
+     * them architecture fits two waves per CU in its last tile stage, with the 58 it needs, three */
+    int stage_choice_cap = choice_cap;
+    const bool dynamic_choices = c->voxel_k == 0 && !(getenv("MPR_DYNAMIC_CHOICES") && atoi(getenv("MPR_DYNAMIC_CHOICES")) == 0);
     int last_ngroups = 0, last_stage = -1;
     bool pairing = false;
     int n_singles = 0, n_pairs = 0;
@@ -474,7 +480,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.tiles = c->tiles[i];
             a.count = count;
             a.nslots = nslots;
-            a.choice_cap = choice_cap;
+            a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
+            a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
@@ -516,7 +523,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (count > 0 && zs) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
-                                         c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub));
+                                         c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub),
+                                         c->num_active + 4);
         } else if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
@@ -528,7 +536,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             TimedScope ts(c, "copy_filled");
             mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
         }
-        int act3[3] = {0, 0, 0};
+        int act3[4] = {0, 0, 0, 0};
         if (count > 0) {
             rc = read_active(c, seq, act3);         /* the reference's blocking read-back (:1209, :1375) */
             if (rc) return rc;
@@ -536,6 +544,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         const int active = act3[0];
         n_singles = act3[1];
         n_pairs = act3[2];
+        if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
+        if (getenv("MPR_DEBUG_CHOICES")) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d)\n", si, count, act3[3], choice_cap);
         c->last.tiles_active[si] = active;
         count = last ? active : active * 64;
         c->tiles_n[next] = (size_t)count;

@@ -49,7 +49,7 @@ k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, int* __restrict__ 
     const size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = i; k < zero_n4; k += stride) zero_base[k] = make_int4(0, 0, 0, 0);
-    if (i < 4) num_active[i] = 0;
+    if (i < 8) num_active[i] = 0;
     if (i == 0) *tape_index = tape_len;
     for (size_t k = i; k < (size_t)count; k += stride) {
         mpr_tile_node n;
@@ -276,6 +276,7 @@ k_eval_tiles(TileStageArgs a)
         end_index = base + j;
     }
     MPR_PHASE(1);
+    const int nchoices_fwd = ci;       /* min / max clauses of the tape just walked */
     const uint64_t end_clause = d;
     const uint32_t i_out = (uint32_t)(end_clause >> 8) & 0xFF;
     const float2 res = ASM ? make_float2(plane[i_out * 128 + lane], plane[i_out * 128 + 64 + lane]) : slots[i_out * 64 + lane];
@@ -315,6 +316,7 @@ k_eval_tiles(TileStageArgs a)
 
     long long written = 0;
     int bwd_words = 0;
+    int kept_minmax = 0;              /* min / max words some lane kept undecided: bounds the choices of the pushed tapes */
     bool overflow = false;
     if (live != 0) {
         /* ---- tape pushing (reference :323-458) ---- */
@@ -380,6 +382,7 @@ k_eval_tiles(TileStageArgs a)
             writing = push && !overflow;
             live = st.live;
             bwd_words = st.words;
+            kept_minmax = st.kept_minmax;
             d = tro[st.head_index];
         } else {
             /* backward walk, again 64 words per load: lane jj holds word bbase + jj */
@@ -446,6 +449,7 @@ k_eval_tiles(TileStageArgs a)
 
                 /* scalar bookkeeping of the active sets */
                 const uint64_t a1 = am & m1, a2 = am & m2, a0 = am & ~(m1 | m2);
+                if (has_choice && a0) ++kept_minmax;
                 lm_set(lm, o, 0);
                 if (a0) {
                     if (l) lm_set(lm, l, lm_get(lm, l) | a0);
@@ -485,6 +489,13 @@ k_eval_tiles(TileStageArgs a)
     }
 
     MPR_PHASE(4);
+    if (a.next_choices) {
+        /* the next stage walks the tapes pushed here (at most kept_minmax undecided min / max clauses
+         * each) or, for an ambiguous tile that did not push one, this very tape again */
+        int need = kept_minmax;
+        if (ballot(ambiguous && !(push && !overflow)) != 0) need = max(need, nchoices_fwd);
+        if (need > 0 && lane == 0) atomicMax(a.next_choices, need);
+    }
     if (prof && lane == 0) atomicAdd(&pc[5], 1ull);
     if (a.heat) {
         /* heatmap frames (reference eval_tiles_i_heatmap, src/context.cu:1622-1632, :1817-1826): the
@@ -544,11 +555,14 @@ DEV void copy_filled_block(const CopyFilled& cf, int block, int nthreads, int ti
  * cudaMemcpy of num_active_tiles, src/context.cu:1209, :1375).  Here the kernel that knows the
  * count stores it straight into host-coherent pinned memory and releases a sequence number behind
  * it; the host spins on that word — no copy kernel, no stream synchronisation. */
-DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2)
+DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2, int* need)
 {
     pub[0] = n0;
     pub[1] = n1;
     pub[2] = n2;
+    /* the evaluation that just finished left an upper bound on the min / max clauses of the tapes it
+     * pushed (TileStageArgs::next_choices): it sizes the next stage's choice array; cleared for the next use */
+    pub[4] = __hip_atomic_exchange(need, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&pub[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -629,7 +643,7 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
             const int n1 = __hip_atomic_exchange(num_active + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int n2 = __hip_atomic_exchange(num_active + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish_counts(pub, seq, n0, n1, n2);
+            publish_counts(pub, seq, n0, n1, n2, num_active + 4);
         }
     }
     const int base = wave_base[0][wave];
@@ -715,7 +729,7 @@ k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __re
 
 /* one workgroup: cursor[z] = number of survivors in front of layer z; hist is cleared for the next use */
 __global__ void __launch_bounds__(ZS_MAX_BINS)
-k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ pub, int seq)
+k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ pub, int seq, int* __restrict__ need)
 {
     __shared__ int sc[ZS_MAX_BINS];
     const int t = threadIdx.x;
@@ -731,7 +745,7 @@ k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __rest
         __syncthreads();
     }
     if (t < tps) cursor[z] = sc[t] - mine;
-    if (t == ZS_MAX_BINS - 1) publish_counts(pub, seq, sc[t], 0, 0);      /* the scatter is still to come: the host can already size the next launch */
+    if (t == ZS_MAX_BINS - 1) publish_counts(pub, seq, sc[t], 0, 0, need);      /* the scatter is still to come: the host can already size the next launch */
 }
 
 template <bool LAST>
@@ -1040,14 +1054,15 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
-                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size)
+                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
+                            int* need)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb), b(1024);
     hipLaunchKernelGGL(k_zs_hist, dim3(nb + extra), b, 0, s, tiles, count, tps, image, hist, cf);
-    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq);
+    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need);
     if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out);
     else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out);
 }

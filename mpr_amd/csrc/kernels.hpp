@@ -51,6 +51,8 @@ struct TileStageArgs {
     int debug;                 /* development only (MPR_DEBUG_TILES): 1 = skip tape pushing, 2 = skip the arithmetic */
     float* heat;               /* heatmap frames (render*_heatmap): S x S amortised work per pixel, else null */
     int heat_stride;           /* = image size in pixels */
+    int* next_choices;         /* device counter (atomicMax): an upper bound on the min / max clauses of any tape this
+                                * stage pushes; sizes the next stage's choice array */
 };
 
 /* first tile stage, one workgroup per tile, level by level over the root tape's DAG
@@ -123,7 +125,8 @@ void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, int* t
                         mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
-                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size);
+                            mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
+                            int* need);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);

@@ -71,6 +71,7 @@ k_eval_tiles_wide(WideStageArgs w)
         sh[7] = node.tape;
         sh[4] = 0x7FFFFFFF;
         sh[5] = 0x7FFFFFFF;
+        sh[1036] = 0;                                       /* min / max clauses the shortened tape keeps undecided */
     }
     for (int i = tid; i < n; i += nt) act[i] = 0;
     __syncthreads();
@@ -175,7 +176,11 @@ k_eval_tiles_wide(WideStageArgs w)
         }
     }
     __syncthreads();
-    if (!(sh[1] == 1 && sh[0] != 0)) return;       /* only ambiguous tiles that chose a side shorten their tape */
+    if (!(sh[1] == 1 && sh[0] != 0)) {             /* only ambiguous tiles that chose a side shorten their tape */
+        /* an ambiguous tile that keeps the root tape: the next stage needs room for all of its choices */
+        if (sh[1] == 1 && tid == 0 && a.next_choices && a.choice_cap > 0) atomicMax(a.next_choices, a.choice_cap);
+        return;
+    }
 
     /* ---- liveness, from the result down the levels (reference :351-458, def-use form) ---- */
     if (tid == 0) mark_val(act, (uint32_t)w.root_val);
@@ -205,7 +210,7 @@ k_eval_tiles_wide(WideStageArgs w)
     const int per = (n + nt - 1) / nt;
     const int hi_i = n - 1 - tid * per;                  /* this thread: i = hi_i, hi_i - 1, ... > lo_i */
     const int lo_i = max(hi_i - per, -1);
-    int mine = 0;
+    int mine = 0, kept = 0;
     int min_drop = 0x7FFFFFFF, min_emit = 0x7FFFFFFF;
     for (int i = hi_i; i > lo_i; --i) {
         if (!act[i]) continue;
@@ -213,6 +218,7 @@ k_eval_tiles_wide(WideStageArgs w)
         const uint32_t op = (uint32_t)d & 0xFF, o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF,
                        r = (uint32_t)(d >> 24) & 0xFF;
         const int c = mpr_op_is_minmax(op) ? ch[i] : 0;
+        kept += (mpr_op_is_minmax(op) && c == 0) ? 1 : 0;
         const bool drop = (c == 1 && l == o) || (c == 2 && r != 0 && r == o);
         if (drop) {
             min_drop = i;
@@ -223,6 +229,7 @@ k_eval_tiles_wide(WideStageArgs w)
         }
     }
     sh[8 + tid] = mine;
+    if (kept) atomicAdd(&sh[1036], kept);
     if (min_drop != 0x7FFFFFFF) atomicMin(&sh[4], min_drop);
     if (min_emit != 0x7FFFFFFF) atomicMin(&sh[5], min_emit);
     __syncthreads();
@@ -254,6 +261,10 @@ k_eval_tiles_wide(WideStageArgs w)
         sh[2] = base;
         sh[3] = ok;
         if (!ok && a.counters) a.counters[CNT_OVERFLOW] = 1;
+        if (a.next_choices) {
+            const int need = ok ? sh[1036] : a.choice_cap;      /* pool exhausted: the tile keeps the root tape */
+            if (need > 0) atomicMax(a.next_choices, need);
+        }
     }
     __syncthreads();
     if (!sh[3]) return;                                   /* pool exhausted: the tile keeps its parent's tape */

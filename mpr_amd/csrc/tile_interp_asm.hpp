@@ -723,6 +723,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     TP_OFFSET(#n)                                                               \
     "s_or_b64 s[66:67], s[62:63], s[64:65]\n"                                  \
     "s_andn2_b64 s[66:67], s[60:61], s[66:67]\n"          /* a0 */             \
+    "s_addc_u32 s84, s84, 0\n"                          /* + (a0 != 0): a min / max some lane keeps */ \
     "s_and_b64 s[62:63], s[62:63], s[60:61]\n"            /* a1 */             \
     "s_and_b64 s[64:65], s[64:65], s[60:61]\n"            /* a2 */             \
     "s_or_b64 s[68:69], s[66:67], s[62:63]\n"             /* lhs live for a0 | a1 */ \
@@ -759,6 +760,7 @@ struct TilePushState {
     uint64_t live;                    /* lanes still pushing */
     int head_index;                   /* out: pool index of the head clause the walk ended on */
     int words;
+    int kept_minmax;                  /* out: min / max words at least one lane kept undecided (bounds the choices of every pushed tape) */
 };
 
 /* Walks backward from pool index `cur` (the word before the end clause).  `ci` = number of choices
@@ -774,7 +776,7 @@ DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char
     const uint32_t cbase = (uint32_t)(uintptr_t)smem + choice_off;
     uint32_t caddr = rdfirst(cbase + (uint32_t)ci * 16u), uci = rdfirst((uint32_t)ci);
     const uint32_t cend = rdfirst(cbase + (uint32_t)choice_cap * 16u);
-    uint32_t bbase = rdfirst((uint32_t)(cur - 63)), sj = 0, words = 0;
+    uint32_t bbase = rdfirst((uint32_t)(cur - 63)), sj = 0, words = 0, kept = 0;
     const uint32_t lane1 = (uint32_t)lane;
     const uint32_t plim = rdfirst(pool_limit);
     asm volatile(
@@ -788,6 +790,7 @@ DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char
         "s_mov_b32 s77, %[phi]\n"
         "s_mov_b32 s78, %[ci]\n"
         "s_mov_b32 s79, 0\n"
+        "s_mov_b32 s84, 0\n"
         "s_mov_b32 s98, %[plim]\n"
         "v_mov_b32 v38, 1\n"
         "v_mov_b32 v44, 1\n"                      /* word 63 of a new chunk: JUMP back to the previous one (-127) */
@@ -895,15 +898,16 @@ DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char
         "s_mov_b32 %[livelo], s72\n"
         "s_mov_b32 %[livehi], s73\n"
         "s_mov_b32 %[words], s79\n"
+        "s_mov_b32 %[kept], s84\n"
         : [blo] "+v"(blo), [bhi] "+v"(bhi), [bw] "+v"(bw), [a0l] "+v"(a0l), [a0h] "+v"(a0h), [a1l] "+v"(a1l), [a1h] "+v"(a1h),
           [oi] "+v"(oi), [oo] "+v"(oo), [ovf] "+v"(ovf), [bbase] "+s"(bbase), [sj] "=&s"(sj), [livelo] "+s"(livelo),
-          [livehi] "+s"(livehi), [words] "=&s"(words)
+          [livehi] "+s"(livehi), [words] "=&s"(words), [kept] "=&s"(kept)
         : [lane] "v"(lane1), [rend] "v"(run_end), [caddr] "s"(caddr), [cend] "s"(cend), [plo] "s"(plo), [phi] "s"(phi),
           [ci] "s"(uci), [plim] "s"(plim)
         : "memory", "vcc", "scc",
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
           "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s86", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-          "s95", "s96", "s97", "s98", "s99",
+          "s84", "s95", "s96", "s97", "s98", "s99",
           "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
     st.a0l = a0l; st.a0h = a0h; st.a1l = a1l; st.a1h = a1h;
     st.out_index = oi;
@@ -912,6 +916,7 @@ DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char
     st.live = ((uint64_t)livehi << 32) | livelo;
     st.head_index = (int)(bbase + sj);
     st.words = (int)words;
+    st.kept_minmax = (int)kept;
 }
 
 }  // namespace mprk
