@@ -339,15 +339,14 @@ k_eval_tiles(TileStageArgs a)
         {
             const int cnt = __popcll(live);
             int base = 0;
-            int cur = 0;
-            if (lane == 0) cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cur = __builtin_amdgcn_readfirstlane(cur);
             const long long want = (long long)MPR_SUBTAPE_CHUNK * cnt * run_chunks;
-            bool ok = (long long)cur < a.pool_cap && (long long)cur + want < 0x7FFFFFFFll;
-            if (ok) {
-                if (lane == 0) base = atomicAdd(a.tape_index, (int)want);
-                base = __builtin_amdgcn_readfirstlane(base);
-            }
+            /* one round trip: claim first, look at the old value afterwards (the reference reads the index,
+             * then adds, :336-341); a claim that starts beyond the pool is handed back so that the index
+             * stays near the capacity however many tiles overflow */
+            if (lane == 0) base = atomicAdd(a.tape_index, (int)want);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const bool ok = (long long)base < a.pool_cap && (long long)base + want < 0x7FFFFFFFll;
+            if (!ok && lane == 0) atomicSub(a.tape_index, (int)want);
             if (push) {
                 out_index = base + MPR_SUBTAPE_CHUNK * run_chunks * rank_in(live, lane);
                 run_end = out_index + MPR_SUBTAPE_CHUNK * run_chunks;

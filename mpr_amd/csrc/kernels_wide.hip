@@ -251,13 +251,10 @@ k_eval_tiles_wide(WideStageArgs w)
     const int nchunks = (total == 0 ? 1 : (total - 1) / 62 + 1) + (spurious ? 1 : 0);
     if (tid == 0) {
         const long long want = (long long)MPR_SUBTAPE_CHUNK * nchunks;
-        const int cur = __hip_atomic_load(a.tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = (long long)cur < a.pool_cap && (long long)cur + want < 0x7FFFFFFFll;
-        int base = 0;
-        if (ok) {
-            base = atomicAdd(a.tape_index, (int)want);
-            if ((long long)base + want >= a.pool_cap) ok = 0;
-        }
+        const int base = atomicAdd(a.tape_index, (int)want);
+        int ok = (long long)base < a.pool_cap && (long long)base + want < 0x7FFFFFFFll;
+        if (!ok) atomicSub(a.tape_index, (int)want);        /* claims beyond the pool are handed back */
+        else if ((long long)base + want >= a.pool_cap) ok = 0;
         sh[2] = base;
         sh[3] = ok;
         if (!ok && a.counters) a.counters[CNT_OVERFLOW] = 1;
