@@ -356,27 +356,32 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
 }
 
 /* out[0] survivors; out[1], out[2]: single tiles and pairs of the float pass (last stage with pairing) */
-/* The compaction publishes the counts into host-coherent memory and releases the sequence number
- * `seq` behind them (kernels.hip: publish_counts); spin until it shows up.  The stream is polled now
+/* The compaction publishes the counts into host-coherent memory, each tagged with the sequence number
+ * `seq` (kernels.hip: publish_counts); spin until they show up.  The stream is polled now
  * and then so that a failed launch cannot hang the caller. */
 static int read_active(mpr_context* c, int seq, int out[4])
 {
-    volatile int* const p = c->pub_host;
+    /* four 8-byte words, each {sequence number, value} written by one store (kernels.hip: publish_counts) */
+    const unsigned long long* const p = reinterpret_cast<const unsigned long long*>(c->pub_host);
+    auto arrived = [&]() {
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long w = __atomic_load_n(&p[k], __ATOMIC_ACQUIRE);
+            if ((unsigned)(w >> 32) != (unsigned)seq) return false;
+            out[k] = (int)(unsigned)w;
+        }
+        return true;
+    };
     for (unsigned spins = 1;; ++spins) {
-        if (__atomic_load_n(&c->pub_host[3], __ATOMIC_ACQUIRE) == seq) break;
+        if (arrived()) break;
         if ((spins & 0xFFF) == 0) {
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) {
-                if (__atomic_load_n(&c->pub_host[3], __ATOMIC_ACQUIRE) == seq) break;
+                if (arrived()) break;
                 return mpr::set_error(MPR_ERR_NO_DEVICE, "the compaction finished without publishing its counts");
             }
             if (q != hipErrorNotReady) return mpr::set_error(MPR_ERR_NO_DEVICE, std::string("stage failed: ") + hipGetErrorString(q));
         }
     }
-    out[0] = p[0];
-    out[1] = p[1];
-    out[2] = p[2];
-    out[3] = p[4];
     return MPR_OK;
 }
 

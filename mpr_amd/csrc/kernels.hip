@@ -552,17 +552,21 @@ DEV void copy_filled_block(const CopyFilled& cf, int block, int nthreads, int ti
 
 /* The host sizes the next stage's launch from the number of survivors (the reference's blocking
  * cudaMemcpy of num_active_tiles, src/context.cu:1209, :1375).  Here the kernel that knows the
- * count stores it straight into host-coherent pinned memory and releases a sequence number behind
- * it; the host spins on that word — no copy kernel, no stream synchronisation. */
+ * count stores it straight into host-coherent pinned memory, tagged with a sequence number; the
+ * host spins on those words — no copy kernel, no stream synchronisation. */
 DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2, int* need)
 {
-    pub[0] = n0;
-    pub[1] = n1;
-    pub[2] = n2;
     /* the evaluation that just finished left an upper bound on the min / max clauses of the tapes it
      * pushed (TileStageArgs::next_choices): it sizes the next stage's choice array; cleared for the next use */
-    pub[4] = __hip_atomic_exchange(need, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&pub[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int n3 = __hip_atomic_exchange(need, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* every value travels with the sequence number in ONE 8-byte store: no ordering between the words is
+     * needed, hence no release fence (which is a write-back of the L2 on this part) */
+    unsigned long long* const p = reinterpret_cast<unsigned long long*>(pub);
+    const unsigned long long tag = (unsigned long long)(unsigned)seq << 32;
+    __hip_atomic_store(p + 0, tag | (unsigned)n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 1, tag | (unsigned)n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 2, tag | (unsigned)n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 3, tag | (unsigned)n3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -634,10 +638,11 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
     __syncthreads();
     if (threadIdx.x == 0) {
         /* the last workgroup through here has every count: hand them to the host and leave the
-         * counters cleared for the next launch */
-        __threadfence();
+         * counters cleared for the next launch.  No fence: only device-scope atomics are involved, and this
+         * workgroup's own additions have returned (their results went into wave_base before the barrier).
+         * A device-scope fence is a write-back of the XCD's L2 on this part — 0.3 ms per launch when every
+         * workgroup of a large grid issues one. */
         if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
-            __threadfence();
             const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int n1 = __hip_atomic_exchange(num_active + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int n2 = __hip_atomic_exchange(num_active + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
