@@ -320,7 +320,13 @@ k_eval_voxels_asm(VoxelArgs a)
     const int lane = threadIdx.x;
     unsigned char* const myslot = smem + lane * 4;            /* slot s: myslot + s * 256 */
 
-    const int tile_index = blockIdx.x;
+    /* workgroups go to the eight XCDs round robin, each with an L2 of its own: inside every window of
+     * 64 tiles the map hands eight CONSECUTIVE tiles to one XCD, so that siblings (neighbours in the
+     * list, which mostly walk one tape) fetch it through one L2 instead of eight; the front-to-back
+     * order of the list is kept at that granularity */
+    const int b = blockIdx.x;
+    const int tile_index = (b & ~63) | ((b & 7) << 3) | ((b >> 3) & 7);
+    if (tile_index >= a.count) return;
     const uint64_t* __restrict__ const tro = a.tape_ro;
     const int position = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].position);
     const int tape = __builtin_amdgcn_readfirstlane(a.tiles[tile_index].tape);
@@ -403,7 +409,7 @@ size_t voxel_asm_lds_bytes(int nslots) { return (size_t)nslots * 256; }
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a)
 {
     if (a.count <= 0) return;
-    const dim3 g(a.count), b(64);
+    const dim3 g((a.count + 63) & ~63), b(64);           /* whole windows of 64: the tile map permutes inside them */
     const size_t lds = voxel_asm_lds_bytes(a.nslots);
     if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_asm<3>, g, b, lds, s, a);
     else hipLaunchKernelGGL(k_eval_voxels_asm<2>, g, b, lds, s, a);
