@@ -512,6 +512,76 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "v_cndmask_b32 v45, v45, v38, s[40:41]\n"        /* b1 = xn ? y.lo : xm ? ym : y.hi */
             "v_cndmask_b32 v46, v38, v44, s[42:43]\n"
             "v_cndmask_b32 v46, v46, v39, s[40:41]\n"        /* b2 = xn ? y.hi : xm ? ym : y.lo */
+            /* Fast path, taken when every lane is away from the edges of the format — numerators zero or
+             * 2^-60 <= |a| <= 2^60, divisors 2^-30 <= |b| <= 2^30, so that quotients and residuals stay normal:
+             * reciprocal by v_rcp + one Newton step, quotient by one correction (rounded up for the lower bound,
+             * down for the upper one), then the EXACT residual r = a - q b says on which side of q the true
+             * quotient lies, and the directed result is q or its neighbour.  No switch to
+             * round-to-nearest, a third of the instructions of the general sequence below. */
+            "v_and_b32 v51, 0x7fffffff, v45\n"               /* |b1| */
+            "v_and_b32 v52, 0x7fffffff, v46\n"               /* |b2| */
+            "v_and_b32 v53, 0x7fffffff, v42\n"               /* |a1| */
+            "v_and_b32 v54, 0x7fffffff, v43\n"               /* |a2| */
+            "v_min_u32 v55, v51, v52\n"
+            "v_max_u32 v51, v51, v52\n"
+            "s_mov_b32 s44, 0x30800000\n"                    /* 2^-30 */
+            "s_mov_b32 s45, 0x4e800000\n"                    /* 2^30 */
+            "v_cmp_le_u32 s[46:47], s44, v55\n"
+            "v_cmp_ge_u32 vcc, s45, v51\n"
+            "s_and_b64 s[46:47], s[46:47], vcc\n"
+            "s_mov_b32 s44, 0x21800000\n"                    /* 2^-60 */
+            "s_mov_b32 s45, 0x5d800000\n"                    /* 2^60 */
+            "v_max_u32 v51, v53, v54\n"
+            "v_cmp_ge_u32 vcc, s45, v51\n"
+            "s_and_b64 s[46:47], s[46:47], vcc\n"
+            "v_cmp_le_u32 s[48:49], s44, v53\n"
+            "v_cmp_eq_u32 s[50:51], 0, v53\n"               /* a1 is a zero */
+            "s_or_b64 s[48:49], s[48:49], s[50:51]\n"
+            "s_and_b64 s[46:47], s[46:47], s[48:49]\n"
+            "v_cmp_le_u32 s[48:49], s44, v54\n"
+            "v_cmp_eq_u32 s[52:53], 0, v54\n"               /* a2 is a zero */
+            "s_or_b64 s[48:49], s[48:49], s[52:53]\n"
+            "s_and_b64 s[46:47], s[46:47], s[48:49]\n"
+            "s_cmp_eq_u64 s[46:47], exec\n"
+            "s_cbranch_scc0 L_idiv_slow_%=\n"
+            "v_rcp_f32 v51, v45\n"
+            "v_rcp_f32 v52, v46\n"
+            "s_nop 0\n"
+            "v_fma_f32 v53, -v45, v51, 1.0\n"
+            "v_fma_f32 v54, -v46, v52, 1.0\n"
+            "v_fmac_f32 v51, v53, v51\n"                     /* 1 / b1 */
+            "v_fmac_f32 v52, v54, v52\n"                     /* 1 / b2 */
+            "v_mul_f32 v47, v42, v51\n"
+            "v_mul_f32 v49, v43, v52\n"
+            "v_fma_f32 v48, -v47, v45, v42\n"
+            "v_fma_f32 v50, -v49, v46, v43\n"
+            "v_fma_f32 v53, v48, v51, v47\n"                 /* q1 = RU(S1), S1 = a1 / b1 up to a fraction of an ulp */
+            "v_fma_f32 v54, -v50, v52, -v49\n"               /* -q2 = RU(-S2): q2 = RD(S2) — each quotient errs to */
+            "v_xor_b32 v54, 0x80000000, v54\n"               /* the side its single correction step can undo */
+            "v_cndmask_b32 v47, v53, v47, s[50:51]\n"        /* a zero numerator: the product already is the */
+            "v_cndmask_b32 v49, v54, v49, s[52:53]\n"        /* signed zero (the sum above would lose its sign) */
+            "v_fma_f32 v48, -v47, v45, v42\n"                /* exact residuals */
+            "v_fma_f32 v50, -v49, v46, v43\n"
+            /* lower bound: one ulp down when the true quotient is below q1 (r1 and b1 of opposite sign) */
+            "v_xor_b32 v51, v48, v45\n"
+            "v_ashrrev_i32 v52, 31, v47\n"
+            "v_cmp_gt_i32 vcc, 0, v51\n"
+            "v_cmp_neq_f32 s[44:45], 0, v48\n"
+            "v_or_b32 v52, 1, v52\n"                         /* -1 for a negative q1, else 1 */
+            "s_and_b64 vcc, vcc, s[44:45]\n"
+            "v_sub_u32 v52, v47, v52\n"                      /* next_down(q1) */
+            "v_cndmask_b32 v40, v47, v52, vcc\n"
+            /* upper bound: one ulp up when the true quotient is above q2 (r2 and b2 of the same sign) */
+            "v_xor_b32 v51, v50, v46\n"
+            "v_ashrrev_i32 v52, 31, v49\n"
+            "v_cmp_lt_i32 vcc, -1, v51\n"
+            "v_cmp_neq_f32 s[44:45], 0, v50\n"
+            "v_or_b32 v52, 1, v52\n"
+            "s_and_b64 vcc, vcc, s[44:45]\n"
+            "v_add_u32 v52, v49, v52\n"                      /* next_up(q2) */
+            "v_cndmask_b32 v41, v49, v52, vcc\n"
+            "s_branch L_idiv_tail_%=\n"
+            "L_idiv_slow_%=:\n"
             "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n"
             "s_nop 0\n"
             TI_DIVQ("v47", "v48", "v42", "v45")
@@ -520,6 +590,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "s_nop 0\n"
             TI_FIX_DOWN("v40", "v47", "v48", "v42", "v45")
             TI_FIX_UP("v41", "v49", "v50", "v43", "v46")
+            "L_idiv_tail_%=:\n"
             "v_mov_b32 v51, 0xff800000\n"
             "v_mov_b32 v52, 0x7f800000\n"
             "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
