@@ -135,6 +135,11 @@ def main():
 
         tpr = TileParallelRenderer(ctx, m, rank, world, make_buffer, all_gather, dim=3)
         tpr.plan(tape, T)
+        # this rank's share of the dominant kernel's algorithmic work: an instrumented frame of its columns
+        pctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS)
+        pctx.render3D_part(tape, T, tpr.owner, rank)
+        work = pctx.counters()
+        pctx.close()
 
         def frame():
             tpr.render(tape, T)
@@ -186,21 +191,20 @@ def main():
     vox_ms = avg.get("eval_voxels_f", 0.0)
     # algorithmic bytes per launch: one 8-byte clause per wave-group
     # visit + the 12-byte tile record of every smallest tile
-    b_alg = 8 * work["clauses_fwd_voxels"] + 12 * work["voxel_tiles"]
-    if world > 1:
-        b_alg = None     # per-rank share is not measured in the multi-GPU run
+    b_alg = 8 * work["clauses_fwd_voxels"] + 12 * work["voxel_tiles"]      # N > 1: rank 0's columns, rank 0's kernel time
     roofline = None
     if vox_ms > 0 and b_alg:
         achieved = b_alg / (vox_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if world == 1 and os.path.exists(pmc):         # the counter passes were collected on the full single-GPU frame
             try:
                 with open(pmc) as f:
                     traffic = json.load(f).get("eval_voxels_f", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_eval_voxels_asm<3>", "bound": "hbm", "achieved": round(achieved, 2),
+        roofline = {"kernel": "k_eval_voxels_asm<3>" + (" (rank 0 of %d)" % world if world > 1 else ""), "bound": "hbm",
+                    "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "algorithmic_bytes": int(b_alg), "kernel_ms": round(vox_ms, 4),
                     "kernel_ms_all": {k: round(v, 4) for k, v in avg.items()},
