@@ -322,6 +322,9 @@ void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w)
     if (const char* e = getenv("MPR_WIDE_THREADS")) threads = atoi(e);
     else if (width >= 192 && w.t.count <= 256) threads = 1024;
     else if (width >= 192 && w.t.count <= 1024) threads = 512;
+    /* ... and with thousands of tiles and levels of moderate width two wavefronts per tile (twice the tiles in
+     * flight per CU) beat four (architecture, the involute gears at 1024^3 / 4096^2: -10 % on this stage) */
+    else if (width >= 48 && width < 192 && w.t.count >= 2048) threads = 128;
     if (dim == 3) hipLaunchKernelGGL(k_eval_tiles_wide<3>, dim3(w.t.count), dim3(threads), lds, s, w);
     else hipLaunchKernelGGL(k_eval_tiles_wide<2>, dim3(w.t.count), dim3(threads), lds, s, w);
 }
