@@ -314,7 +314,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
          * handful of clauses per level (bear: 544 clauses in 72 levels) the 64 tiles-per-wave walk,
          * whose latency per clause the assembly interpreter cut to a third, is the faster one */
         c->sched_ok = sc.ok && mprk::wide_stage_fits(sc.nclauses) &&
-                      sc.nclauses >= 12 * ((int)sc.level_start.size() - 1);
+                      (sc.nclauses >= 12 * ((int)sc.level_start.size() - 1) || getenv("MPR_WIDE_FORCE") != nullptr);
         if (c->sched_ok) {
             const size_t rb = sc.recs.size() * sizeof(mpr::SchedRec), lb = sc.level_start.size() * sizeof(int32_t);
             if (rb > c->sched_recs_cap) {
