@@ -604,6 +604,49 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "v_cmp_gt_f32 s[58:59], 0, v37\n"                /* x.hi < 0 */
             "s_nop 0\n"
             "v_cndmask_b32 v42, v36, 0, vcc\n"               /* a */
+            /* Fast path when every lane's operands are zero or 2^-60 <= x <= 2^60 (negative upper ends pass:
+             * their lanes are overwritten with NaN below): v_sqrt_f32 is within one ulp, so the directed
+             * roots are among y - 1 ulp, y, y + 1 ulp, told apart by the signs of x - c^2 (fma).  No switch
+             * to round-to-nearest, half the instructions of the general sequence. */
+            "v_and_b32 v52, 0x7fffffff, v37\n"
+            "s_mov_b32 s44, 0x21800000\n"                    /* 2^-60 */
+            "s_mov_b32 s45, 0x5d800000\n"                    /* 2^60 */
+            "v_cmp_le_u32 s[46:47], s44, v42\n"
+            "v_cmp_eq_u32 s[50:51], 0, v42\n"               /* a is zero */
+            "v_cmp_ge_u32 vcc, s45, v42\n"
+            "s_or_b64 s[46:47], s[46:47], s[50:51]\n"
+            "s_and_b64 s[46:47], s[46:47], vcc\n"
+            "v_cmp_le_u32 s[48:49], s44, v52\n"
+            "v_cmp_eq_u32 s[52:53], 0, v52\n"               /* x.hi is a zero */
+            "v_cmp_ge_u32 vcc, s45, v52\n"
+            "s_or_b64 s[48:49], s[48:49], s[52:53]\n"
+            "s_and_b64 s[48:49], s[48:49], vcc\n"
+            "s_and_b64 s[46:47], s[46:47], s[48:49]\n"
+            "s_cmp_eq_u64 s[46:47], exec\n"
+            "s_cbranch_scc0 L_isqrt_slow_%=\n"
+            "v_sqrt_f32 v47, v42\n"
+            "v_sqrt_f32 v49, v37\n"
+            "s_nop 0\n"
+            "v_add_u32 v51, 1, v47\n"                        /* lower: y + 1 ulp, y - 1 ulp */
+            "v_add_u32 v52, -1, v47\n"
+            "v_add_u32 v54, 1, v49\n"                        /* upper */
+            "v_add_u32 v55, -1, v49\n"
+            "v_fma_f32 v48, -v47, v47, v42\n"                /* x - y^2 */
+            "v_fma_f32 v53, -v51, v51, v42\n"                /* x - (y + 1)^2 */
+            "v_fma_f32 v50, -v49, v49, v37\n"
+            "v_fma_f32 v43, -v55, v55, v37\n"                /* x - (y - 1)^2 */
+            "v_cmp_le_f32 s[44:45], 0, v53\n"               /* y + 1 still not above the root */
+            "v_cmp_gt_f32 s[46:47], 0, v48\n"               /* y above the root */
+            "v_cmp_ge_f32 s[48:49], 0, v43\n"               /* y - 1 still not below the root */
+            "v_cmp_lt_f32 vcc, 0, v50\n"                    /* y below the root */
+            "v_cndmask_b32 v51, v47, v51, s[44:45]\n"
+            "v_cndmask_b32 v55, v49, v55, s[48:49]\n"
+            "v_cndmask_b32 v40, v51, v52, s[46:47]\n"        /* largest c with c^2 <= x */
+            "v_cndmask_b32 v41, v55, v54, vcc\n"             /* smallest c with c^2 >= x */
+            "v_cndmask_b32 v40, v40, v42, s[50:51]\n"        /* the root of a zero is that zero */
+            "v_cndmask_b32 v41, v41, v37, s[52:53]\n"
+            "s_branch L_isqrt_tail_%=\n"
+            "L_isqrt_slow_%=:\n"
             "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n"
             "s_nop 0\n"
             TI_SQRTQ("v47", "v48", "v42")
@@ -620,6 +663,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "s_and_b64 s[44:45], s[44:45], vcc\n"
             TI_NEXT_UP("v49", "v51", "v52", "v53")
             "v_cndmask_b32 v41, v49, v52, s[44:45]\n"
+            "L_isqrt_tail_%=:\n"
             "v_mov_b32 v51, 0x7fc00000\n"
             "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
             "v_cndmask_b32 v41, v41, v51, s[58:59]\n"
