@@ -149,8 +149,15 @@ DEV float rare_unary_a(uint32_t op, float v)
  * lane l at s * 256 + l * 4) and returns the result slot named by the end clause. */
 /* first_block: the 64 words at tro[first + lane], when the caller has already fetched them (under
  * other latencies of its prologue), else null */
+/* image / img_off / hidden_at (3-D frames): whenever a further block of the tape is fetched, the lane's
+ * heightmap entry (byte offset img_off) is read again with it; once every lane finds it at or above
+ * hidden_at — the skip test of src/context.cu:852-864, which another tile of the column has made true
+ * in the meantime — the walk stops and INTERP_ABORTED is returned: nothing this tile could still
+ * write would change the image. */
+constexpr uint32_t INTERP_ABORTED = 0xFFFFFFFFu;
 DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane,
-                        const uint64_t* first_block = nullptr)
+                        const uint64_t* first_block = nullptr, const int* image = nullptr, uint32_t img_off = 0,
+                        int hidden_at = 0)
 {
     unsigned char* const myslot = smem + lane * 4;
     /* state of the assembly interpreter that has to survive a trip through C++ */
@@ -164,6 +171,9 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
     const uint32_t selO = to_vgpr(0x0c0c0400u), selL = to_vgpr(0x0c0c0600u), selR = to_vgpr(0x0c0c0700u);
     const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
     float prev = 0.0f;
+    const uint32_t ilo = rdfirst((uint32_t)(uintptr_t)image), ihi = rdfirst((uint32_t)((uintptr_t)image >> 32));
+    const uint32_t recheck = rdfirst(image ? 1u : 0u);
+    uint32_t aborted = 0;
     uint32_t mode = 0;                               /* 0: fetch the block at `base`; 1: continue after `sj`; 2: block is there */
     if (first_block) {
         blo = (uint32_t)*first_block;
@@ -180,6 +190,8 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_mov_b32 s88, %[sj]\n"
             "s_mov_b32 s90, 0x260\n"
             "s_mov_b32 s96, 0xff00\n"
+            "s_mov_b32 s91, 0\n"                            /* no heightmap value in flight */
+            "s_mov_b32 %[ab], 0\n"
             "v_mov_b32 v37, %[prev]\n"
             "s_getpc_b64 s[82:83]\n"
             "L_pc_%=:\n"
@@ -199,12 +211,25 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_addc_u32 s85, s85, %[thi]\n"
             "global_load_dword %[blo], %[lane8], s[84:85]\n"
             "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
+            "s_mov_b32 s91, %[rck]\n"
+            "s_cmp_eq_u32 s91, 0\n"
+            "s_cbranch_scc1 L_loaded_%=\n"
+            "s_mov_b32 s84, %[ilo]\n"                       /* the lane's heightmap entry, past the L1 */
+            "s_mov_b32 s85, %[ihi]\n"
+            "global_load_dword v45, %[ioff], s[84:85] sc1\n"
             "L_loaded_%=:\n"
             "s_mov_b32 s88, -1\n"
             "v_mov_b32 v41, 0\n"
             "v_mov_b32 v43, 32\n"
             "v_mov_b32 v44, 64\n"
             "s_waitcnt vmcnt(0)\n"
+            "s_cmp_eq_u32 s91, 0\n"
+            "s_cbranch_scc1 L_nocheck_%=\n"
+            "v_cmp_ge_i32 vcc, v45, %[thr]\n"               /* hidden by now? */
+            "s_mov_b32 s91, 0\n"
+            "s_cmp_eq_u64 vcc, exec\n"
+            "s_cbranch_scc1 L_abort_%=\n"
+            "L_nocheck_%=:\n"
             "v_bfe_u32 v40, %[blo], 8, 8\n"                 /* out slot */
             "v_and_b32 v38, 0xff, %[blo]\n"
             "v_min_u32 v38, 30, v38\n"                       /* opcode; unknown ones -> handler 30 */
@@ -280,6 +305,10 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "L_casin_%=:\n" MPR_CALL("mpr_fa_asin")
             "L_cacos_%=:\n" MPR_CALL("mpr_fa_acos")
             "L_catan_%=:\n" MPR_CALL("mpr_fa_atan")
+            /* ---- every lane is hidden: give up ---- */
+            "L_abort_%=:\n"
+            "s_mov_b32 %[ab], 1\n"
+            "s_mov_b32 s86, 0\n"
             /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
             "L_exit_%=:\n"
             "s_waitcnt lgkmcnt(0)\n"
@@ -287,10 +316,11 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
             "s_mov_b32 %[dhi], s87\n"
             "s_mov_b32 %[base], s89\n"
             "s_mov_b32 %[sj], s88\n"
-            : [blo] "+v"(blo), [bhi] "+v"(bhi),
-              [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
+            : [blo] "+&v"(blo), [bhi] "+&v"(bhi),          /* early clobber: an input of equal value must not share them */
+              [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi), [ab] "=&s"(aborted)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
-              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev)
+              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev),
+              [ilo] "s"(ilo), [ihi] "s"(ihi), [rck] "s"(recheck), [ioff] "v"(img_off), [thr] "v"(hidden_at)
             : "memory", "vcc", "scc",
               "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
               "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
@@ -298,9 +328,10 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
               /* what the called routines may use on top (MPR_CALL) */
               "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
               "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
-              "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+              "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
               "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
         /* dlo is the rewritten clause word: byte 0 out slot, byte 1 handler index (opcode in its low 5 bits) */
+        if (aborted) return INTERP_ABORTED;
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
         /* sin .. log (and anything that is not an opcode, like k_eval_voxels) */
@@ -372,7 +403,10 @@ k_eval_voxels_asm(VoxelArgs a)
     *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
     *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
 
-    const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane, &first_block);
+    const int pz_low2 = (DIM == 3) ? pos.z * 4 + (sub.z & 1) + 2 : 0;
+    const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane, &first_block, DIM == 3 ? a.image : nullptr,
+                                      (uint32_t)(px + py * S) * 4u, pz_low2);
+    if (rslot == INTERP_ABORTED) return;
     const float res = *reinterpret_cast<const float*>(myslot + rslot * 256);
     if (!skip && res < 0.0f) {
         if (DIM == 3) {

@@ -53,7 +53,7 @@ DEV float2 rare_interval(uint32_t op, float2 l, float2 r, float imm)
  * instead of leaving to C++ and coming back, which cost ~650 cycles per clause (10% of the clauses of
  * the involute gears are acos / atan, 7% of bear's exp / log).  Leaf functions of the AMDGPU calling
  * convention: operand in v0 (lo), v1 (hi), result in v0, v1, return address s[30:31]; they use
- * v0..v39, v48..v55, v64..v69 and s4..s31 at most (checked against the compiler's resource remarks) and
+ * v0..v39, v48..v55, v64..v69 and s0..s31 at most (checked against the compiler's resource remarks) and
  * keep v40..v47, v56..v63 and s34 and up, where the walk's own state lives. */
 #define MPR_TI_NAMED(NAME, OP)                                                                        \
     static __device__ __attribute__((noinline, used)) float2 ti_named_##NAME(float2 l) __asm__("mpr_ti_" #NAME);   \
@@ -702,7 +702,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
               "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
               "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
               "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
-              "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+              "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
               "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
         const uint32_t op = (dlo >> 8) & 31;
         if (op == 0) break;
