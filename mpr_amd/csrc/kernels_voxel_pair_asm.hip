@@ -192,7 +192,7 @@ DEV uint32_t interp_pair_asm(const uint64_t* __restrict__ tro, uint32_t first, u
             "s_mov_b32 %[dhi], s87\n"
             "s_mov_b32 %[base], s89\n"
             "s_mov_b32 %[sj], s88\n"
-            : [blo] "+v"(blo), [bhi] "+v"(bhi), [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
+            : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
               [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [p0] "v"(p0), [p1] "v"(p1)
             : "memory", "vcc", "scc",

@@ -686,8 +686,8 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "s_mov_b32 %[anyhi], s77\n"
             "s_mov_b32 %[ci], s78\n"
             "s_mov_b32 %[words], s79\n"
-            : [blo] "+v"(blo), [bhi] "+v"(bhi), [base] "+s"(base), [sj] "+s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),
-              [caddr] "+s"(caddr), [anylo] "+s"(anylo), [anyhi] "+s"(anyhi), [ci] "+s"(ci), [words] "+s"(words)
+            : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),
+              [caddr] "+&s"(caddr), [anylo] "+&s"(anylo), [anyhi] "+&s"(anyhi), [ci] "+&s"(ci), [words] "+&s"(words)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
               [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [plo] "v"(plo), [phi] "v"(phi),
               [alo] "s"(alo), [ahi] "s"(ahi), [cend] "s"(cend)
@@ -1014,9 +1014,9 @@ DEV void tile_push_asm(const uint64_t* __restrict__ pool, int cur, unsigned char
         "s_mov_b32 %[livehi], s73\n"
         "s_mov_b32 %[words], s79\n"
         "s_mov_b32 %[kept], s84\n"
-        : [blo] "+v"(blo), [bhi] "+v"(bhi), [bw] "+v"(bw), [a0l] "+v"(a0l), [a0h] "+v"(a0h), [a1l] "+v"(a1l), [a1h] "+v"(a1h),
-          [oi] "+v"(oi), [oo] "+v"(oo), [ovf] "+v"(ovf), [bbase] "+s"(bbase), [sj] "=&s"(sj), [livelo] "+s"(livelo),
-          [livehi] "+s"(livehi), [words] "=&s"(words), [kept] "=&s"(kept)
+        : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [bw] "+&v"(bw), [a0l] "+&v"(a0l), [a0h] "+&v"(a0h), [a1l] "+&v"(a1l), [a1h] "+&v"(a1h),
+          [oi] "+&v"(oi), [oo] "+&v"(oo), [ovf] "+&v"(ovf), [bbase] "+&s"(bbase), [sj] "=&s"(sj), [livelo] "+&s"(livelo),
+          [livehi] "+&s"(livehi), [words] "=&s"(words), [kept] "=&s"(kept)
         : [lane] "v"(lane1), [rend] "v"(run_end), [caddr] "s"(caddr), [cend] "s"(cend), [plo] "s"(plo), [phi] "s"(phi),
           [ci] "s"(uci), [plim] "s"(plim)
         : "memory", "vcc", "scc",
