@@ -1,6 +1,6 @@
 """One-off wider fuzz (development aid): 60 deeper random trees at 256^3 and 512^2 against the oracle.
-    python scripts/fuzz_more.py    (on the GPU box)"""
-import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    python tests/tools/fuzz_more.py    (on the GPU box)"""
+import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, mpr_amd as m
 from oracle import orc
 from test_gpu_fuzz import random_tree

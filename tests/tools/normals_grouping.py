@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """How many distinct tapes does a 4x4 pixel footprint of the normals pass walk?  (One wave walks every
 distinct tape of its footprint with all 64 lanes; only the pixels on that tape use the result.)
-    python scripts/normals_grouping.py bear 1024"""
+    python tests/tools/normals_grouping.py bear 1024"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import mpr_amd as m
 from oracle import orc
 

@@ -4,11 +4,11 @@
 For every smallest tile handed to the float pass: is it entirely behind the finished heightmap
 (every column's height >= the tile's top voxel)?  Such a tile could be skipped if the tiles in
 front of it had been evaluated first.  Also: per-lane fraction of voxel pairs behind the heightmap.
-    python scripts/occlusion_potential.py bear 1024
+    python tests/tools/occlusion_potential.py bear 1024
 """
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import mpr_amd as m
 
 name = sys.argv[1] if len(sys.argv) > 1 else "bear"

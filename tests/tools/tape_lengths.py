@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Length distribution of the tapes each tile stage walks (one wave walks one tape for the 64
 children of a surviving parent; a stage lasts as long as its slowest wave when the machine is
-not full).   python scripts/tape_lengths.py prospero:2:1024 involute_gear_3d:3:1024"""
+not full).   python tests/tools/tape_lengths.py prospero:2:1024 involute_gear_3d:3:1024"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import mpr_amd as m
 from oracle import orc
 

@@ -1,5 +1,5 @@
 """How much of the float pass's work is on tapes shared by several voxel tiles (development aid)."""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, mpr_amd as m
 from oracle import orc
 for name, dim, S in (("bear", 3, 1024), ("architecture", 3, 1024), ("involute_gear_3d", 3, 1024)):
