@@ -1,0 +1,56 @@
+"""Frame comparison shared by the GPU-vs-oracle tests."""
+import numpy as np
+
+
+def active_positions(tiles):
+    return np.sort(tiles["position"][tiles["next"] != -1])
+
+
+def compare_frame(mpr, orc, tape, dim, S, mat, z=0.0, check_tapes=True):
+    ctx = mpr.Context(S, flags=mpr.CTX_COUNTERS)
+    ref = orc.Frame(tape.data, dim, S, mpr.colmajor(mat, dim + 1), z=z, threads=0)
+    if dim == 2:
+        ctx.render2D(tape, mat, z)
+    else:
+        ctx.render3D(tape, mat)
+    cnt = ctx.counters()
+    assert cnt["pool_overflowed"] == 0 and ref.counters["pool_overflowed"] == 0
+    stages = [0, 1, 2, 3] if dim == 3 else [0, 2, 3]
+    for s in stages:
+        got = ctx.stages[s].filled
+        assert np.array_equal(got, ref.filled[s]), "filled image of stage %d differs (%d cells)" % (
+            s, int((got != ref.filled[s]).sum()))
+    if dim == 3:
+        gn, rn = ctx.normals, ref.normals
+        assert np.array_equal(gn, rn), "normals differ at %d pixels" % int((gn != rn).sum())
+    # per-stage tile occupancy: the SET of surviving tiles (order is timing dependent)
+    tile_stages = [0, 1, 2] if dim == 3 else [0, 2]
+    pool = ctx.tape_data if check_tapes else None
+    for k, s in enumerate(tile_stages):
+        gt, rt = ctx.stages[s].tiles, ref.tiles[s]
+        assert gt.size == rt.size
+        last = (k == len(tile_stages) - 1)
+        nxt = s + 1 if dim == 3 else (3 if s else 2)
+        g_next, r_next = ctx.stages[nxt].tiles, ref.tiles[nxt]
+        assert g_next.size == r_next.size, "stage %d hands %d tiles on, oracle %d" % (s, g_next.size, r_next.size)
+        assert cnt["tiles_in"][k] == ref.counters["tiles_in"][k]
+        assert cnt["tiles_active"][k] == ref.counters["tiles_active"][k]
+        if not last:
+            assert np.array_equal(active_positions(gt), active_positions(rt))
+        # The list handed on has been evaluated in place by the NEXT stage (position = -1 for
+        # tiles that died there, tape = the tile's own shortened tape if it pushed one).  Only
+        # survivors are comparable: whether a tile that ends up occluded pushed a tape first is
+        # timing dependent in the reference too (src/context.cu:299-305 vs :312).
+        g_live, r_live = g_next[g_next["position"] != -1], r_next[r_next["position"] != -1]
+        go, ro = np.argsort(g_live["position"]), np.argsort(r_live["position"])
+        assert np.array_equal(g_live["position"][go], r_live["position"][ro]), "survivor sets differ after stage %d" % s
+        if check_tapes and g_live.size:
+            # the shortened tape every surviving tile carries: same clause sequence
+            glen, ghash = orc.tiles_digest(pool, g_live[go])
+            rlen, rhash = orc.tiles_digest(ref.pool, r_live[ro])
+            assert np.array_equal(glen, rlen), "shortened tape lengths differ at stage %d" % s
+            assert np.array_equal(ghash, rhash), "shortened tape contents differ at stage %d" % s
+    # the float pass evaluates exactly the voxels/pixels of the surviving smallest tiles
+    assert cnt["voxel_tiles"] == ref.counters["voxel_tiles"]
+    ctx.close()
+    return cnt, ref

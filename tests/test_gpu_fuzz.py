@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import view2, view3
-from test_gpu_render import compare_frame
+from helpers import compare_frame
 
 pytestmark = pytest.mark.gpu
 
