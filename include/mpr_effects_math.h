@@ -4,9 +4,12 @@
  * HIP kernels of libmpr_amd and into the oracle, like mpr_fmath.h.
  *
  * Restated behaviour, including what looks accidental in the reference:
- *   - Eigen's normalized() is v / sqrt(x*x + y*y + z*z), products and sums left to right;
+ *   - Eigen unrolls fixed-size reductions (dot, squaredNorm, matrix * vector) as first half + second
+ *     half, i.e. t0 + (t1 + t2) for three terms (Eigen/src/Core/Redux.h, redux_novec_unroller);
+ *     normalized() is v / sqrt(squaredNorm) and leaves an all-zero vector alone (Eigen >= 3.3);
  *   - float -> unsigned / uint8 / int32 conversions saturate and map NaN to 0 (CUDA cvt.rzi);
- *   - the occlusion average is finished in double (`1.0 - occlusion / 64`), like the source;
+ *   - `occlusion = 1.0 - (occlusion / rows)` is evaluated in double and stored back into the float
+ *     variable; `occlusion * 255` is then a float product (src/effects.cu:84-85);
  *   - powf(t, 2.0f) is t * t;
  *   - blur_ssao's second pass indexes the window at (xmin + i, ymin + j) WITHOUT the pixel's own
  *     (x, y) (src/effects.cu:124-126), and divides by count - 1 (NaN or inf for windows with
@@ -38,9 +41,12 @@ MPR_HD uint32_t mpr_fx_d2u8(double d)
     if (d >= 255.0) return 255u;
     return (uint32_t)d;
 }
+MPR_HD float mpr_fx_sum3(float t0, float t1, float t2) { return t0 + (t1 + t2); }
 MPR_HD void mpr_fx_normalize(float v[3])
 {
-    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float zz = mpr_fx_sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2]);
+    if (!(zz > 0.0f)) return;
+    const float n = sqrtf(zz);
     v[0] = v[0] / n;
     v[1] = v[1] / n;
     v[2] = v[2] / n;
@@ -64,7 +70,7 @@ MPR_HD int32_t mpr_fx_ssao_pixel(const int32_t* depth, const uint32_t* norm, con
     float normal[3];
     mpr_fx_normal_of(norm[x + y * S], normal);
     const float* rvec = rvecs + 3 * ((x % 16) * 16 + (y % 16));
-    const float rn = rvec[0] * normal[0] + rvec[1] * normal[1] + rvec[2] * normal[2];
+    const float rn = mpr_fx_sum3(rvec[0] * normal[0], rvec[1] * normal[1], rvec[2] * normal[2]);
     float tangent[3] = {rvec[0] - normal[0] * rn, rvec[1] - normal[1] * rn, rvec[2] - normal[2] * rn};
     mpr_fx_normalize(tangent);
     const float bitangent[3] = {normal[1] * tangent[2] - normal[2] * tangent[1],
@@ -75,7 +81,7 @@ MPR_HD int32_t mpr_fx_ssao_pixel(const int32_t* depth, const uint32_t* norm, con
         const float* k = kernel + 3 * i;
         float sp[3];
         for (int c = 0; c < 3; ++c)
-            sp[c] = (tangent[c] * k[0] + bitangent[c] * k[1] + normal[c] * k[2]) * RADIUS + pos[c];
+            sp[c] = mpr_fx_sum3(tangent[c] * k[0], bitangent[c] * k[1], normal[c] * k[2]) * RADIUS + pos[c];
         const uint32_t px = mpr_fx_f2u((sp[0] / 2.0f + 0.5f) * S);
         const uint32_t py = mpr_fx_f2u((sp[1] / 2.0f + 0.5f) * S);
         const uint32_t actual_h = (px < (uint32_t)S && py < (uint32_t)S) ? (uint32_t)depth[px + py * (uint32_t)S] : 0u;
@@ -90,8 +96,8 @@ MPR_HD int32_t mpr_fx_ssao_pixel(const int32_t* depth, const uint32_t* norm, con
             }
         }
     }
-    const double occ = 1.0 - (double)(occlusion / 64);
-    return (int32_t)mpr_fx_d2u8(occ * 255);
+    const float occ = (float)(1.0 - (double)(occlusion / 64));
+    return (int32_t)mpr_fx_d2u8((double)(occ * 255));
 }
 
 /* blur_ssao, src/effects.cu:91-152 */
@@ -141,7 +147,7 @@ MPR_HD uint32_t mpr_fx_shade_pixel(const int32_t* depth, const uint32_t* norm, c
     const float pos[3] = {2.0f * ((x + 0.5f) / S - 0.5f), 2.0f * ((y + 0.5f) / S - 0.5f), 2.0f * ((h + 0.5f) / S - 0.5f)};
     float ld[3] = {5.0f - pos[0], 5.0f - pos[1], 10.0f - pos[2]};
     mpr_fx_normalize(ld);
-    float light = mpr_fmaxf(0.0f, ld[0] * normal[0] + ld[1] * normal[1] + ld[2] * normal[2]) * 0.8f;
+    float light = mpr_fmaxf(0.0f, mpr_fx_sum3(ld[0] * normal[0], ld[1] * normal[1], ld[2] * normal[2])) * 0.8f;
     light *= (float)s / 255.0f;
     light += 0.2f;
     if (light < 0.0f) light = 0.0f;

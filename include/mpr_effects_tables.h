@@ -61,7 +61,7 @@ static inline void mpr_effects_tables(float kernel[64 * 3], float rvecs[256 * 3]
         v[0] = 2.0f * ((float)mpr_glibc_rand_next(&g) / rmax - 0.5f);
         v[1] = 2.0f * ((float)mpr_glibc_rand_next(&g) / rmax - 0.5f);
         v[2] = (float)mpr_glibc_rand_next(&g) / rmax;
-        const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const float n = sqrtf(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]));   /* Eigen's reduction order */
         float scale = (float)i / (float)(64 - 1);
         scale = (scale * scale) * 0.9f + 0.1f;
         for (int k = 0; k < 3; ++k) kernel[i * 3 + k] = (v[k] / n) * scale;
@@ -71,7 +71,7 @@ static inline void mpr_effects_tables(float kernel[64 * 3], float rvecs[256 * 3]
         v[0] = 2.0f * ((float)mpr_glibc_rand_next(&g) / rmax - 0.5f);
         v[1] = 2.0f * ((float)mpr_glibc_rand_next(&g) / rmax - 0.5f);
         v[2] = 0.0f;
-        const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const float n = sqrtf(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]));   /* Eigen's reduction order */
         for (int k = 0; k < 3; ++k) rvecs[i * 3 + k] = v[k] / n;
     }
 }

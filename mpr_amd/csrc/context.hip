@@ -42,7 +42,8 @@ struct mpr_context {
 
     uint64_t* pool = nullptr;          /* Context::tape_data */
     long long pool_cap = 0;
-    int* tape_index = nullptr;         /* Context::tape_index */
+    unsigned long long* tape_index = nullptr;   /* Context::tape_index; 64 bits on the device so that failed claims of
+                                                 * concurrent waves can never wrap it (reported clamped to int32) */
     int* num_active = nullptr;         /* Context::num_active_tiles */
     unsigned long long* counters = nullptr;
 
@@ -222,7 +223,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
         c->arena_words = words;
     }
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
-    CT(hipMalloc((void**)&c->tape_index, sizeof(int)));
+    CT(hipMalloc((void**)&c->tape_index, sizeof(unsigned long long)));
     CT(hipMalloc((void**)&c->num_active, 8 * sizeof(int)));      /* [0..2] counts, [3] workgroups done, [4] choices the next stage needs */
     CT(hipMalloc((void**)&c->zs_hist, 1024 * sizeof(int)));
     CT(hipMalloc((void**)&c->zs_cursor, 1024 * sizeof(int)));
@@ -843,7 +844,9 @@ int mpr_read_tape_pool(mpr_context* c, uint64_t* host, size_t cap, int32_t* tape
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int ti = 0;
-    HIP_TRY(hipMemcpy(&ti, c->tape_index, sizeof(int), hipMemcpyDeviceToHost));
+    unsigned long long ti64 = 0;
+    HIP_TRY(hipMemcpy(&ti64, c->tape_index, sizeof(ti64), hipMemcpyDeviceToHost));
+    ti = (int)std::min<unsigned long long>(ti64, 0x7FFFFFFFull);
     *tape_index = ti;
     if (host) {
         const size_t m = std::min<size_t>(cap, (size_t)std::min<long long>(std::max(ti, 0), c->pool_cap));
@@ -961,7 +964,9 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int ti = 0;
-    HIP_TRY(hipMemcpy(&ti, c->tape_index, sizeof(int), hipMemcpyDeviceToHost));
+    unsigned long long ti64 = 0;
+    HIP_TRY(hipMemcpy(&ti64, c->tape_index, sizeof(ti64), hipMemcpyDeviceToHost));
+    ti = (int)std::min<unsigned long long>(ti64, 0x7FFFFFFFull);
     c->last.tape_index = ti;
     if (c->flags & MPR_CTX_COUNTERS) {
         unsigned long long h[mprk::CNT_COUNT];

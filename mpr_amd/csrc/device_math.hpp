@@ -98,27 +98,6 @@ DEV float div_fix_up(float q, float r, float a, float b)
     if (q < 0.0f && is_finite(a) && is_finite(b) && b != 0.0f) return mpr_u2f(0xFF7FFFFFu);
     return q;
 }
-/* {RD(a1/b1), RU(a2/b2)} */
-DEV ival div_dir(float a1, float b1, float a2, float b2)
-{
-    float q1, r1, q2, r2;
-    rn_div2(a1, b1, a2, b2, q1, r1, q2, r2);
-    return iv(div_fix_down(q1, r1, a1, b1), div_fix_up(q2, r2, a2, b2));
-}
-/* {RD(sqrt(a)), RU(sqrt(b))} */
-DEV ival sqrt_dir(float a, float b)
-{
-    float s1, r1, s2, r2;
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(a), "+v"(b));
-    s1 = __builtin_sqrtf(a);
-    r1 = __builtin_fmaf(-s1, s1, a);
-    s2 = __builtin_sqrtf(b);
-    r2 = __builtin_fmaf(-s2, s2, b);
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1" : "+v"(s1), "+v"(r1), "+v"(s2), "+v"(r2));
-    const float lo = (is_finite(s1) && r1 < 0.0f) ? next_down(s1) : s1;
-    const float hi = (is_finite(s2) && r2 > 0.0f) ? next_up(s2) : s2;
-    return iv(lo, hi);
-}
 /* double -> float, directed; independent of the current f32 rounding mode */
 DEV float d2f_rd(double d)
 {
@@ -130,7 +109,45 @@ DEV float d2f_ru(double d)
     const float f = (float)d;
     return ((double)f < d) ? next_up(f) : f;
 }
-
+/* The residual test above needs a - q b (a - s s) to be representable: it is a multiple of
+ * ulp(q) ulp(b), which drops below the smallest subnormal once |a| < 2^-103, and a residual that
+ * rounds to zero says "exact".  Those operands go through double precision instead: a quotient
+ * (root) of 24-bit numbers that is not itself a 24-bit number is at least 2^-48 (2^-49) away from
+ * one in relative terms, far more than the 2^-53 the double result is off by, so directed rounding
+ * of the double gives the directed rounding of the exact value.  MODE.fp_round's double-precision
+ * field stays round-to-nearest throughout. */
+DEV bool tiny_nonzero(float a) { const uint32_t m = mpr_f2u(a) & 0x7FFFFFFFu; return m != 0 && m < 0x12800000u; }   /* < 2^-90 */
+DEV ival div_dir_exact(float a1, float b1, float a2, float b2)
+{
+    return iv(d2f_rd((double)a1 / (double)b1), d2f_ru((double)a2 / (double)b2));
+}
+DEV ival sqrt_dir_exact(float a, float b)
+{
+    return iv(d2f_rd(__builtin_sqrt((double)a)), d2f_ru(__builtin_sqrt((double)b)));
+}
+/* {RD(a1/b1), RU(a2/b2)} */
+DEV ival div_dir(float a1, float b1, float a2, float b2)
+{
+    if (tiny_nonzero(a1) || tiny_nonzero(a2)) return div_dir_exact(a1, b1, a2, b2);
+    float q1, r1, q2, r2;
+    rn_div2(a1, b1, a2, b2, q1, r1, q2, r2);
+    return iv(div_fix_down(q1, r1, a1, b1), div_fix_up(q2, r2, a2, b2));
+}
+/* {RD(sqrt(a)), RU(sqrt(b))} */
+DEV ival sqrt_dir(float a, float b)
+{
+    if (tiny_nonzero(a) || tiny_nonzero(b)) return sqrt_dir_exact(a, b);
+    float s1, r1, s2, r2;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(a), "+v"(b));
+    s1 = __builtin_sqrtf(a);
+    r1 = __builtin_fmaf(-s1, s1, a);
+    s2 = __builtin_sqrtf(b);
+    r2 = __builtin_fmaf(-s2, s2, b);
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1" : "+v"(s1), "+v"(r1), "+v"(s2), "+v"(r2));
+    const float lo = (is_finite(s1) && r1 < 0.0f) ? next_down(s1) : s1;
+    const float hi = (is_finite(s2) && r2 > 0.0f) ? next_up(s2) : s2;
+    return iv(lo, hi);
+}
 /* ---- Interval operations (same structure as inc/gpu_interval.hpp) -------------------- */
 DEV ival i_neg(ival x) { return iv(-x.hi, -x.lo); }                                      /* :66-68 */
 DEV ival i_add(ival x, ival y) { return iv(rd_add(x.lo, y.lo), ru_add(x.hi, y.hi)); }    /* :72-74 */

@@ -40,7 +40,7 @@ namespace mprk {
 /* preload_tiles — reference :45-57, plus column ownership for the multi-GPU mode        */
 /* ------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(256)
-k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, int* __restrict__ tape_index, int tape_len,
+k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, unsigned long long* __restrict__ tape_index, int tape_len,
                 int* __restrict__ num_active, mpr_tile_node* __restrict__ tiles, int count, int cols,
                 const int* __restrict__ owner, int rank)
 {
@@ -50,7 +50,7 @@ k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, int* __restrict__ 
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = i; k < zero_n4; k += stride) zero_base[k] = make_int4(0, 0, 0, 0);
     if (i < 8) num_active[i] = 0;
-    if (i == 0) *tape_index = tape_len;
+    if (i == 0) *tape_index = (unsigned long long)tape_len;
     for (size_t k = i; k < (size_t)count; k += stride) {
         mpr_tile_node n;
         n.position = (int)k;
@@ -338,15 +338,20 @@ k_eval_tiles(TileStageArgs a)
         int run_end = 0;                     /* first pool index past this lane's run */
         {
             const int cnt = __popcll(live);
-            int base = 0;
-            const long long want = (long long)MPR_SUBTAPE_CHUNK * cnt * run_chunks;
+            const unsigned long long want = (unsigned long long)MPR_SUBTAPE_CHUNK * cnt * run_chunks;
             /* one round trip: claim first, look at the old value afterwards (the reference reads the index,
              * then adds, :336-341); a claim that starts beyond the pool is handed back so that the index
-             * stays near the capacity however many tiles overflow */
-            if (lane == 0) base = atomicAdd(a.tape_index, (int)want);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const bool ok = (long long)base < a.pool_cap && (long long)base + want < 0x7FFFFFFFll;
-            if (!ok && lane == 0) atomicSub(a.tape_index, (int)want);
+             * stays near the capacity however many tiles overflow.  The index is 64 bits wide: between a
+             * failed claim's add and its hand-back any number of other waves may add theirs, and a 32-bit
+             * index could wrap into a value that looks like free space. */
+            unsigned long long base64 = 0;
+            if (lane == 0) base64 = atomicAdd(a.tape_index, want);
+            const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)base64);
+            const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base64 >> 32));
+            base64 = ((unsigned long long)b_hi << 32) | b_lo;
+            const bool ok = base64 < (unsigned long long)a.pool_cap && base64 + want < 0x7FFFFFFFull;
+            if (!ok && lane == 0) atomicAdd(a.tape_index, 0ull - want);
+            const int base = ok ? (int)base64 : 0;
             if (push) {
                 out_index = base + MPR_SUBTAPE_CHUNK * run_chunks * rank_in(live, lane);
                 run_end = out_index + MPR_SUBTAPE_CHUNK * run_chunks;
@@ -1002,7 +1007,7 @@ void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps,
 {
     hipLaunchKernelGGL(k_mask_filled_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, tps, image);
 }
-void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, int* tape_index, int tape_len, int* num_active,
+void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,
                         mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
 {
     const size_t n4 = zero_words / 4;             /* the arena's parts are padded to 64 words */

@@ -35,7 +35,7 @@ struct GroupInfo {
 struct TileStageArgs {
     const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
     uint64_t* tape_wr;         /* same pool, write side (freshly claimed chunks) */
-    int* tape_index;
+    unsigned long long* tape_index;
     long long pool_cap;
     int* image;                /* this level's filled image */
     int tps;                   /* tiles per side at this level */
@@ -121,7 +121,7 @@ struct NormalArgs {
     int ncols;                 /* ... and how many */
 };
 
-void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, int* tape_index, int tape_len, int* num_active,
+void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,
                         mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,

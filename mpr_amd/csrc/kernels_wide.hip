@@ -250,11 +250,12 @@ k_eval_tiles_wide(WideStageArgs w)
     const bool spurious = total > 0 && total % 62 == 0 && sh[4] < sh[5];
     const int nchunks = (total == 0 ? 1 : (total - 1) / 62 + 1) + (spurious ? 1 : 0);
     if (tid == 0) {
-        const long long want = (long long)MPR_SUBTAPE_CHUNK * nchunks;
-        const int base = atomicAdd(a.tape_index, (int)want);
-        int ok = (long long)base < a.pool_cap && (long long)base + want < 0x7FFFFFFFll;
-        if (!ok) atomicSub(a.tape_index, (int)want);        /* claims beyond the pool are handed back */
-        else if ((long long)base + want >= a.pool_cap) ok = 0;
+        const unsigned long long want = (unsigned long long)MPR_SUBTAPE_CHUNK * nchunks;
+        const unsigned long long base64 = atomicAdd(a.tape_index, want);      /* 64-bit index: see k_eval_tiles */
+        int ok = base64 < (unsigned long long)a.pool_cap && base64 + want < 0x7FFFFFFFull;
+        if (!ok) atomicAdd(a.tape_index, 0ull - want);       /* claims beyond the pool are handed back */
+        else if (base64 + want >= (unsigned long long)a.pool_cap) ok = 0;
+        const int base = ok ? (int)base64 : 0;
         sh[2] = base;
         sh[3] = ok;
         if (!ok && a.counters) a.counters[CNT_OVERFLOW] = 1;

@@ -69,6 +69,21 @@ MPR_TI_NAMED(atan, MPR_OP_ATAN_LHS)
 MPR_TI_NAMED(exp, MPR_OP_EXP_LHS)
 MPR_TI_NAMED(log, MPR_OP_LOG_LHS)
 #undef MPR_TI_NAMED
+/* the general directed quotients / roots (device_math.hpp: round-to-nearest sandwich + residual, double
+ * precision for operands below 2^-90), called by the assembly walk when some lane is at the edges of the
+ * format: {RD(a1 / b1), RU(a2 / b2)} and {RD(sqrt(a)), RU(sqrt(b))}; arguments in v0..v3, result in v0, v1 */
+static __device__ __attribute__((noinline, used)) float2 ti_named_divx(float a1, float b1, float a2, float b2) __asm__("mpr_ti_divx");
+static __device__ float2 ti_named_divx(float a1, float b1, float a2, float b2)
+{
+    const ival o = div_dir(a1, b1, a2, b2);
+    return make_float2(o.lo, o.hi);
+}
+static __device__ __attribute__((noinline, used)) float2 ti_named_sqrtx(float a, float b) __asm__("mpr_ti_sqrtx");
+static __device__ float2 ti_named_sqrtx(float a, float b)
+{
+    const ival o = sqrt_dir(a, b);
+    return make_float2(o.lo, o.hi);
+}
 
 /* Fixed registers (declared as clobbers):
  *   s[80:81] handler address   s[82:83] table base   s[84:85] block address   s86 clause word
@@ -164,104 +179,6 @@ MPR_TI_NAMED(log, MPR_OP_LOG_LHS)
     TI_H(v, 30) TI_EXIT                                                                                     \
     TI_H(v, 31) "s_add_u32 s79, s79, 63\n s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"   /* lane 63: next block */
 
-/* q = a / b correctly rounded (round-to-nearest must be in effect) and the exact residual
- * r = a - q * b; temporaries v51..v55, s[44:45], vcc */
-#define TI_DIVQ(q, r, a, b)                                         \
-    "v_div_scale_f32 v51, s[44:45], " b ", " b ", " a "\n"          \
-    "v_rcp_f32 v52, v51\n"                                          \
-    "v_div_scale_f32 v53, vcc, " a ", " b ", " a "\n"               \
-    "v_fma_f32 v54, -v51, v52, 1.0\n"                               \
-    "v_fmac_f32 v52, v54, v52\n"                                    \
-    "v_mul_f32 v54, v53, v52\n"                                     \
-    "v_fma_f32 v55, -v51, v54, v53\n"                               \
-    "v_fmac_f32 v54, v55, v52\n"                                    \
-    "v_fma_f32 v51, -v51, v54, v53\n"                               \
-    "v_div_fmas_f32 v51, v51, v52, v54\n"                           \
-    "v_div_fixup_f32 " q ", v51, " b ", " a "\n"                    \
-    "v_fma_f32 " r ", -" q ", " b ", " a "\n"
-/* next_down / next_up of a finite float q (device_math.hpp), into t2; temporaries t1, t3, s[48:49] */
-#define TI_NEXT_DOWN(q, t1, t2, t3)                                 \
-    "v_and_b32 " t1 ", 0x7fffffff, " q "\n"                         \
-    "v_cmp_lt_i32 s[48:49], -1, " q "\n"                            \
-    "v_mov_b32 " t3 ", 0x80000001\n"                                \
-    "s_nop 0\n"                                                     \
-    "v_cndmask_b32 " t2 ", 1, -1, s[48:49]\n"                       \
-    "v_add_u32 " t2 ", " t2 ", " q "\n"                             \
-    "v_cmp_ne_u32 s[48:49], 0, " t1 "\n"                            \
-    "s_nop 1\n"                                                     \
-    "v_cndmask_b32 " t2 ", " t3 ", " t2 ", s[48:49]\n"
-#define TI_NEXT_UP(q, t1, t2, t3)                                   \
-    "v_and_b32 " t1 ", 0x7fffffff, " q "\n"                         \
-    "v_ashrrev_i32 " t2 ", 31, " q "\n"                             \
-    "v_or_b32 " t2 ", 1, " t2 "\n"                                  \
-    "v_add_u32 " t2 ", " t2 ", " q "\n"                             \
-    "v_cmp_ne_u32 s[48:49], 0, " t1 "\n"                            \
-    "s_nop 1\n"                                                     \
-    "v_cndmask_b32 " t2 ", 1, " t2 ", s[48:49]\n"
-/* div_fix_down / div_fix_up (device_math.hpp): move the round-to-nearest quotient q (residual r) of
- * a / b to the round-down / round-up one; s56 = 0x1f8 (finite), s57 = 0x198 (finite, not zero) */
-#define TI_FIX_DOWN(out, q, r, a, b)                                \
-    "v_cmp_class_f32 s[44:45], " q ", s56\n"                        \
-    "v_cmp_gt_f32 vcc, 0, " r "\n"                                  \
-    "v_cmp_lt_f32 s[46:47], 0, " b "\n"                             \
-    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
-    "v_cmp_lt_f32 vcc, 0, " r "\n"                                  \
-    "v_cmp_gt_f32 s[48:49], 0, " b "\n"                             \
-    "s_and_b64 s[48:49], s[48:49], vcc\n"                           \
-    "s_or_b64 s[46:47], s[46:47], s[48:49]\n"      /* exact quotient below q */ \
-    TI_NEXT_DOWN(q, "v51", "v52", "v53")                            \
-    "v_cndmask_b32 v52, " q ", v52, s[46:47]\n"                     \
-    "v_cmp_lt_f32 vcc, 0, " q "\n"                  /* overflowed to +inf although finite: FLT_MAX */ \
-    "v_cmp_class_f32 s[46:47], " a ", s56\n"                        \
-    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
-    "v_cmp_class_f32 vcc, " b ", s57\n"                             \
-    "s_and_b64 vcc, vcc, s[46:47]\n"                                \
-    "v_mov_b32 v53, 0x7f7fffff\n"                                   \
-    "v_cndmask_b32 v51, " q ", v53, vcc\n"                          \
-    "v_cndmask_b32 " out ", v51, v52, s[44:45]\n"
-#define TI_FIX_UP(out, q, r, a, b)                                  \
-    "v_cmp_class_f32 s[44:45], " q ", s56\n"                        \
-    "v_cmp_lt_f32 vcc, 0, " r "\n"                                  \
-    "v_cmp_lt_f32 s[46:47], 0, " b "\n"                             \
-    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
-    "v_cmp_gt_f32 vcc, 0, " r "\n"                                  \
-    "v_cmp_gt_f32 s[48:49], 0, " b "\n"                             \
-    "s_and_b64 s[48:49], s[48:49], vcc\n"                           \
-    "s_or_b64 s[46:47], s[46:47], s[48:49]\n"      /* exact quotient above q */ \
-    TI_NEXT_UP(q, "v51", "v52", "v53")                              \
-    "v_cndmask_b32 v52, " q ", v52, s[46:47]\n"                     \
-    "v_cmp_gt_f32 vcc, 0, " q "\n"                  /* overflowed to -inf although finite: -FLT_MAX */ \
-    "v_cmp_class_f32 s[46:47], " a ", s56\n"                        \
-    "s_and_b64 s[46:47], s[46:47], vcc\n"                           \
-    "v_cmp_class_f32 vcc, " b ", s57\n"                             \
-    "s_and_b64 vcc, vcc, s[46:47]\n"                                \
-    "v_mov_b32 v53, 0xff7fffff\n"                                   \
-    "v_cndmask_b32 v51, " q ", v53, vcc\n"                          \
-    "v_cndmask_b32 " out ", v51, v52, s[44:45]\n"
-/* s = sqrt(a) correctly rounded (round-to-nearest in effect), r = a - s * s; temporaries v51..v54 */
-#define TI_SQRTQ(sq, r, a)                                          \
-    "v_mul_f32 v51, 0x4f800000, " a "\n"                            \
-    "v_cmp_gt_f32 vcc, 0xf800000, " a "\n"                          \
-    "s_nop 1\n"                                                     \
-    "v_cndmask_b32 v51, " a ", v51, vcc\n"                          \
-    "v_sqrt_f32 v52, v51\n"                                         \
-    "s_nop 0\n"                                                     \
-    "v_add_u32 v53, -1, v52\n"                                      \
-    "v_fma_f32 v54, -v53, v52, v51\n"                               \
-    "v_cmp_ge_f32 s[46:47], 0, v54\n"                               \
-    "v_add_u32 v54, 1, v52\n"                                       \
-    "s_nop 0\n"                                                     \
-    "v_cndmask_b32 v53, v52, v53, s[46:47]\n"                       \
-    "v_fma_f32 v52, -v54, v52, v51\n"                               \
-    "v_cmp_lt_f32 s[46:47], 0, v52\n"                               \
-    "s_nop 1\n"                                                     \
-    "v_cndmask_b32 v52, v53, v54, s[46:47]\n"                       \
-    "v_mul_f32 v53, 0x37800000, v52\n"                              \
-    "v_cndmask_b32 v52, v52, v53, vcc\n"                            \
-    "v_cmp_class_f32 vcc, v51, s55\n"                               \
-    "s_nop 1\n"                                                     \
-    "v_cndmask_b32 " sq ", v52, v51, vcc\n"                         \
-    "v_fma_f32 " r ", -" sq ", " sq ", " a "\n"
 
 struct TileInterpResult {
     uint32_t result_slot;     /* slot named by the end clause */
@@ -581,15 +498,14 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "v_add_u32 v52, v49, v52\n"                      /* next_up(q2) */
             "v_cndmask_b32 v41, v49, v52, vcc\n"
             "s_branch L_idiv_tail_%=\n"
-            "L_idiv_slow_%=:\n"
-            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n"
-            "s_nop 0\n"
-            TI_DIVQ("v47", "v48", "v42", "v45")
-            TI_DIVQ("v49", "v50", "v43", "v46")
-            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1\n"
-            "s_nop 0\n"
-            TI_FIX_DOWN("v40", "v47", "v48", "v42", "v45")
-            TI_FIX_UP("v41", "v49", "v50", "v43", "v46")
+            "L_idiv_slow_%=:\n"                              /* some lane at the edges of the format: compiled routine */
+            "v_mov_b32 v47, v34\n"
+            "v_mov_b32 v0, v42\n v_mov_b32 v1, v45\n v_mov_b32 v2, v43\n v_mov_b32 v3, v46\n"
+            "s_getpc_b64 s[40:41]\n"
+            "s_add_u32 s40, s40, mpr_ti_divx@rel32@lo+4\n"
+            "s_addc_u32 s41, s41, mpr_ti_divx@rel32@hi+12\n"
+            "s_swappc_b64 s[30:31], s[40:41]\n"
+            "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v47\n"
             "L_idiv_tail_%=:\n"
             "v_mov_b32 v51, 0xff800000\n"
             "v_mov_b32 v52, 0x7f800000\n"
@@ -647,22 +563,13 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
             "v_cndmask_b32 v41, v41, v37, s[52:53]\n"
             "s_branch L_isqrt_tail_%=\n"
             "L_isqrt_slow_%=:\n"
-            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n"
-            "s_nop 0\n"
-            TI_SQRTQ("v47", "v48", "v42")
-            TI_SQRTQ("v49", "v50", "v37")
-            "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1\n"
-            "s_nop 0\n"
-            "v_cmp_class_f32 s[44:45], v47, s56\n"           /* lo = finite(s1) && r1 < 0 ? next_down(s1) : s1 */
-            "v_cmp_gt_f32 vcc, 0, v48\n"
-            "s_and_b64 s[44:45], s[44:45], vcc\n"
-            TI_NEXT_DOWN("v47", "v51", "v52", "v53")
-            "v_cndmask_b32 v40, v47, v52, s[44:45]\n"
-            "v_cmp_class_f32 s[44:45], v49, s56\n"           /* hi = finite(s2) && r2 > 0 ? next_up(s2) : s2 */
-            "v_cmp_lt_f32 vcc, 0, v50\n"
-            "s_and_b64 s[44:45], s[44:45], vcc\n"
-            TI_NEXT_UP("v49", "v51", "v52", "v53")
-            "v_cndmask_b32 v41, v49, v52, s[44:45]\n"
+            "v_mov_b32 v47, v34\n"
+            "v_mov_b32 v0, v42\n v_mov_b32 v1, v37\n"
+            "s_getpc_b64 s[40:41]\n"
+            "s_add_u32 s40, s40, mpr_ti_sqrtx@rel32@lo+4\n"
+            "s_addc_u32 s41, s41, mpr_ti_sqrtx@rel32@hi+12\n"
+            "s_swappc_b64 s[30:31], s[40:41]\n"
+            "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v47\n"
             "L_isqrt_tail_%=:\n"
             "v_mov_b32 v51, 0x7fc00000\n"
             "v_cndmask_b32 v40, v40, v51, s[58:59]\n"

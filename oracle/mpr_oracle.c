@@ -26,7 +26,8 @@
  * Deliberate, documented choices where the CUDA toolchain's behaviour cannot be known:
  *   - no FMA contraction anywhere (nvcc may contract; irrelevant for the benchmark views,
  *     SURVEY.md §8(c));
- *   - float transcendentals come from include/mpr_fmath.h (shared with the kernels) instead
+ *   - float transcendentals come from oracle/orc_fmath.h — the oracle's own implementation of the
+ *     algorithm the product defines them by (nothing is shared with include/mpr_fmath.h) — instead
  *     of CUDA libm; double transcendentals inside Interval ops come from glibc;
  *   - powf(x, 2) is x*x (inc/gpu_deriv.hpp:86,100; src/context.cu:1125-1127);
  *   - float -> uint8 conversion of normals saturates and maps NaN to 0 (CUDA cvt.rzi.u8).
@@ -49,7 +50,7 @@
 #include <omp.h>
 #endif
 
-#include "../include/mpr_fmath.h"
+#include "orc_fmath.h"
 
 /* ===================================================================================== */
 /* directed-rounding primitives; FE_UPWARD must be in effect                             */
@@ -91,8 +92,8 @@ static ival i_mul(ival x, ival y)
         if (x.hi > 0.0f) {
             if (y.lo < 0.0f) {
                 if (y.hi > 0.0f) { /* M * M */
-                    return iv(mpr_fminf(rd_mul(x.lo, y.hi), rd_mul(x.hi, y.lo)),
-                              mpr_fmaxf(ru_mul(x.lo, y.lo), ru_mul(x.hi, y.hi)));
+                    return iv(orc_fminf(rd_mul(x.lo, y.hi), rd_mul(x.hi, y.lo)),
+                              orc_fmaxf(ru_mul(x.lo, y.lo), ru_mul(x.hi, y.hi)));
                 } else { /* M * N */
                     return iv(rd_mul(x.hi, y.lo), ru_mul(x.lo, y.lo));
                 }
@@ -174,26 +175,26 @@ static inline ival i_min(ival x, ival y, int* choice)
 {
     if (x.hi < y.lo) { *choice = 1; return x; }
     else if (y.hi < x.lo) { *choice = 2; return y; }
-    return iv(mpr_fminf(x.lo, y.lo), mpr_fminf(x.hi, y.hi));
+    return iv(orc_fminf(x.lo, y.lo), orc_fminf(x.hi, y.hi));
 }
 static inline ival i_min_f(ival x, float y, int* choice)
 {
     if (x.hi < y) { *choice = 1; return x; }
     else if (y < x.lo) { *choice = 2; return iv(y, y); }
-    return iv(mpr_fminf(x.lo, y), mpr_fminf(x.hi, y));
+    return iv(orc_fminf(x.lo, y), orc_fminf(x.hi, y));
 }
 /* :232-252 */
 static inline ival i_max(ival x, ival y, int* choice)
 {
     if (x.lo > y.hi) { *choice = 1; return x; }
     else if (y.lo > x.hi) { *choice = 2; return y; }
-    return iv(mpr_fmaxf(x.lo, y.lo), mpr_fmaxf(x.hi, y.hi));
+    return iv(orc_fmaxf(x.lo, y.lo), orc_fmaxf(x.hi, y.hi));
 }
 static inline ival i_max_f(ival x, float y, int* choice)
 {
     if (x.lo > y) { *choice = 1; return x; }
     else if (y > x.hi) { *choice = 2; return iv(y, y); }
-    return iv(mpr_fmaxf(x.lo, y), mpr_fmaxf(x.hi, y));
+    return iv(orc_fmaxf(x.lo, y), orc_fmaxf(x.hi, y));
 }
 /* :256-266 */
 static inline ival i_square(ival x)
@@ -208,7 +209,7 @@ static inline ival i_abs(ival x)
 {
     if (x.lo >= 0.0f) return x;
     else if (x.hi < 0.0f) return i_neg(x);
-    else return iv(0.0f, mpr_fmaxf(-x.lo, x.hi));
+    else return iv(0.0f, orc_fmaxf(-x.lo, x.hi));
 }
 /* :284-294 */
 static inline ival i_sub(ival x, ival y) { return iv(rd_sub(x.lo, y.hi), ru_sub(x.hi, y.lo)); }
@@ -307,22 +308,22 @@ static inline float float_clause(uint32_t op, float lhs, float rhs, float imm)
         case MPR_OP_SQUARE_LHS: return lhs * lhs;
         case MPR_OP_SQRT_LHS: return sqrtf(lhs);
         case MPR_OP_NEG_LHS: return -lhs;
-        case MPR_OP_SIN_LHS: return mpr_sinf(lhs);
-        case MPR_OP_COS_LHS: return mpr_cosf(lhs);
-        case MPR_OP_ASIN_LHS: return mpr_asinf(lhs);
-        case MPR_OP_ACOS_LHS: return mpr_acosf(lhs);
-        case MPR_OP_ATAN_LHS: return mpr_atanf(lhs);
-        case MPR_OP_EXP_LHS: return mpr_expf(lhs);
+        case MPR_OP_SIN_LHS: return orc_sinf(lhs);
+        case MPR_OP_COS_LHS: return orc_cosf(lhs);
+        case MPR_OP_ASIN_LHS: return orc_asinf(lhs);
+        case MPR_OP_ACOS_LHS: return orc_acosf(lhs);
+        case MPR_OP_ATAN_LHS: return orc_atanf(lhs);
+        case MPR_OP_EXP_LHS: return orc_expf(lhs);
         case MPR_OP_ABS_LHS: return fabsf(lhs);
-        case MPR_OP_LOG_LHS: return mpr_logf(lhs);
+        case MPR_OP_LOG_LHS: return orc_logf(lhs);
         case MPR_OP_ADD_LHS_IMM: return lhs + imm;
         case MPR_OP_ADD_LHS_RHS: return lhs + rhs;
         case MPR_OP_MUL_LHS_IMM: return lhs * imm;
         case MPR_OP_MUL_LHS_RHS: return lhs * rhs;
-        case MPR_OP_MIN_LHS_IMM: return mpr_fminf(lhs, imm);
-        case MPR_OP_MIN_LHS_RHS: return mpr_fminf(lhs, rhs);
-        case MPR_OP_MAX_LHS_IMM: return mpr_fmaxf(lhs, imm);
-        case MPR_OP_MAX_LHS_RHS: return mpr_fmaxf(lhs, rhs);
+        case MPR_OP_MIN_LHS_IMM: return orc_fminf(lhs, imm);
+        case MPR_OP_MIN_LHS_RHS: return orc_fminf(lhs, rhs);
+        case MPR_OP_MAX_LHS_IMM: return orc_fmaxf(lhs, imm);
+        case MPR_OP_MAX_LHS_RHS: return orc_fmaxf(lhs, rhs);
         case MPR_OP_SUB_LHS_IMM: return lhs - imm;
         case MPR_OP_SUB_IMM_RHS: return imm - rhs;
         case MPR_OP_SUB_LHS_RHS: return lhs - rhs;
@@ -378,37 +379,37 @@ static inline deriv d_sqrt(deriv a)                                             
 static inline deriv d_atan(deriv a)                                                          /* :176-179 */
 {
     const float d = a.v * a.v + 1;
-    return dv(mpr_atanf(a.v), a.dx / d, a.dy / d, a.dz / d);
+    return dv(orc_atanf(a.v), a.dx / d, a.dy / d, a.dz / d);
 }
 static inline deriv d_acos(deriv a)                                                          /* :181-184 */
 {
     const float d = -sqrtf(1 - a.v * a.v);
-    return dv(mpr_acosf(a.v), a.dx / d, a.dy / d, a.dz / d);
+    return dv(orc_acosf(a.v), a.dx / d, a.dy / d, a.dz / d);
 }
 static inline deriv d_asin(deriv a)                                                          /* :186-189 */
 {
     const float d = sqrtf(1 - a.v * a.v);
-    return dv(mpr_asinf(a.v), a.dx / d, a.dy / d, a.dz / d);
+    return dv(orc_asinf(a.v), a.dx / d, a.dy / d, a.dz / d);
 }
 static inline deriv d_exp(deriv a)                                                           /* :191-194 */
 {
-    const float v = mpr_expf(a.v);
+    const float v = orc_expf(a.v);
     return dv(v, v * a.dx, v * a.dy, v * a.dz);
 }
 static inline deriv d_cos(deriv a)                                                           /* :196-199 */
 {
-    const float s = -mpr_sinf(a.v);
-    return dv(mpr_cosf(a.v), s * a.dx, s * a.dy, s * a.dz);
+    const float s = -orc_sinf(a.v);
+    return dv(orc_cosf(a.v), s * a.dx, s * a.dy, s * a.dz);
 }
 static inline deriv d_sin(deriv a)                                                           /* :201-204 (upstream :196-199) */
 {
-    const float c = mpr_cosf(a.v);
-    return dv(mpr_sinf(a.v), c * a.dx, c * a.dy, c * a.dz);
+    const float c = orc_cosf(a.v);
+    return dv(orc_sinf(a.v), c * a.dx, c * a.dy, c * a.dz);
 }
 static inline deriv d_log(deriv a)                                                           /* :201-204 */
 {
     const float v = a.v;
-    return dv(mpr_logf(v), a.dx / v, a.dy / v, a.dz / v);
+    return dv(orc_logf(v), a.dx / v, a.dy / v, a.dz / v);
 }
 
 /* one Deriv clause.  src/context.cu:1081-1118; NB SQUARE is evaluated as lhs * lhs (:1081) */
@@ -464,7 +465,7 @@ struct orc_frame {
     float* heat;          /* heatmap frames (flags bit2): S x S work per pixel, else NULL */
 };
 
-static inline float imm_of(uint64_t d) { return mpr_u2f(mpr_cl_immbits(d)); }
+static inline float imm_of(uint64_t d) { return orc_float(mpr_cl_immbits(d)); }
 
 /* src/context.cu:23-30 */
 typedef struct { int32_t x, y, z, w; } int4_;
@@ -1247,7 +1248,7 @@ static inline uint64_t splitmix(uint64_t* s)
 static inline int same_bits(float a, float b)
 {
     if (a != a && b != b) return 1;
-    return mpr_f2u(a) == mpr_f2u(b);
+    return orc_bits(a) == orc_bits(b);
 }
 int64_t orc_selftest_rounding(int64_t n, uint64_t seed)
 {
@@ -1255,10 +1256,10 @@ int64_t orc_selftest_rounding(int64_t n, uint64_t seed)
     for (int64_t i = 0; i < n; ++i) {
         /* random bit patterns: covers subnormals, infinities, NaN, huge exponent gaps */
         uint64_t r = splitmix(&seed);
-        float a = mpr_u2f((uint32_t)r), b = mpr_u2f((uint32_t)(r >> 32));
+        float a = orc_float((uint32_t)r), b = orc_float((uint32_t)(r >> 32));
         if (i & 1) {   /* nearby magnitudes, where cancellation and ties happen */
             const uint64_t q = splitmix(&seed);
-            b = mpr_u2f((mpr_f2u(a) & 0xFF800000u) ^ (uint32_t)(q & 0x80FFFFFFu));
+            b = orc_float((orc_bits(a) & 0xFF800000u) ^ (uint32_t)(q & 0x80FFFFFFu));
         }
         volatile float x = a, y = b;
         fesetround(FE_DOWNWARD);
@@ -1280,13 +1281,13 @@ void orc_fmath_n(int32_t which, int32_t n, const float* x, float* out)
 {
     for (int32_t i = 0; i < n; ++i) {
         switch (which) {
-            case 0: out[i] = mpr_sinf(x[i]); break;
-            case 1: out[i] = mpr_cosf(x[i]); break;
-            case 2: out[i] = mpr_asinf(x[i]); break;
-            case 3: out[i] = mpr_acosf(x[i]); break;
-            case 4: out[i] = mpr_atanf(x[i]); break;
-            case 5: out[i] = mpr_expf(x[i]); break;
-            case 6: out[i] = mpr_logf(x[i]); break;
+            case 0: out[i] = orc_sinf(x[i]); break;
+            case 1: out[i] = orc_cosf(x[i]); break;
+            case 2: out[i] = orc_asinf(x[i]); break;
+            case 3: out[i] = orc_acosf(x[i]); break;
+            case 4: out[i] = orc_atanf(x[i]); break;
+            case 5: out[i] = orc_expf(x[i]); break;
+            case 6: out[i] = orc_logf(x[i]); break;
             default: out[i] = NAN;
         }
     }
@@ -1294,55 +1295,49 @@ void orc_fmath_n(int32_t which, int32_t n, const float* x, float* out)
 
 
 /* ====================================================================================== */
-/* mpr::Effects — reference src/effects.cu:17-286.  Per-pixel arithmetic in                 */
-/* include/mpr_effects_math.h (each function cites its lines); here: the pass structure of  */
-/* drawSSAO (:246-263) and drawShaded (:265-286), in round-to-nearest.                      */
+/* mpr::Effects — reference src/effects.cu:17-286, restated in oracle/orc_effects.h (the     */
+/* oracle's own text; the product's include/mpr_effects_*.h are not used here).              */
 /* ====================================================================================== */
-#include "../include/mpr_effects_math.h"
-#include "../include/mpr_effects_tables.h"
+#include "orc_effects.h"
 
 void orc_effects_tables(float* kernel, float* rvecs)
 {
     const int old = fegetround();
     fesetround(FE_TONEAREST);
-    float k[64 * 3], r[256 * 3];
-    mpr_effects_tables(k, r);
+    orc_v3 k[64], r[256];
+    orc_fx_tables(k, r);
     if (kernel) memcpy(kernel, k, sizeof(k));
     if (rvecs) memcpy(rvecs, r, sizeof(r));
     fesetround(old);
 }
+/* the C library's own rand() sequence for `seed` (private state; rand() == random() in glibc) */
 void orc_glibc_rand(uint32_t seed, int32_t n, int32_t* out)
 {
-    mpr_glibc_rand g;
-    mpr_glibc_srand(&g, seed);
-    for (int32_t i = 0; i < n; ++i) out[i] = mpr_glibc_rand_next(&g);
+    struct random_data rd;
+    char state[128];
+    memset(&rd, 0, sizeof rd);
+    memset(state, 0, sizeof state);
+    initstate_r(seed, state, sizeof state, &rd);
+    for (int32_t i = 0; i < n; ++i) random_r(&rd, &out[i]);
 }
+/* drawSSAO (which = 0, :246-263): tmp = raw occlusion, image = blurred.
+ * drawShaded (which = 1, :265-286): image = raw occlusion, tmp = blurred, then image = shading. */
 void orc_effects(int32_t which, int32_t size, const int32_t* depth, const uint32_t* normals, int32_t* image, int32_t* tmp)
 {
     const int old = fegetround();
     fesetround(FE_TONEAREST);
-    float kernel[64 * 3], rvecs[256 * 3];
-    mpr_effects_tables(kernel, rvecs);
+    orc_v3 kernel[64], rvecs[256];
+    orc_fx_tables(kernel, rvecs);
     const size_t n = (size_t)size * size;
     memset(image, 0, n * sizeof(int32_t));
     memset(tmp, 0, n * sizeof(int32_t));
-    int32_t* const raw = which ? image : tmp;        /* draw_ssao target */
-    int32_t* const blurred = which ? tmp : image;    /* blur_ssao target */
-    for (int y = 0; y < size; ++y)
-        for (int x = 0; x < size; ++x) {
-            const int32_t o = mpr_fx_ssao_pixel(depth, normals, kernel, rvecs, size, x, y);
-            if (o >= 0) raw[x + y * size] = o;
-        }
-    for (int y = 0; y < size; ++y)
-        for (int x = 0; x < size; ++x) blurred[x + y * size] = mpr_fx_blur_pixel(depth, raw, size, x, y);
-    if (which) {
-        /* draw_shaded writes into `image`, which still holds the raw occlusion where it is not
-         * covered — but raw occlusion exists only on covered pixels, which all get overwritten */
-        for (int y = 0; y < size; ++y)
-            for (int x = 0; x < size; ++x) {
-                const uint32_t c = mpr_fx_shade_pixel(depth, normals, blurred, size, x, y);
-                if (c) image[x + y * size] = (int32_t)c;
-            }
+    if (which == 0) {
+        orc_fx_draw_ssao(depth, normals, kernel, rvecs, size, tmp);
+        orc_fx_blur_ssao(depth, tmp, size, image);
+    } else {
+        orc_fx_draw_ssao(depth, normals, kernel, rvecs, size, image);
+        orc_fx_blur_ssao(depth, image, size, tmp);
+        orc_fx_draw_shaded(depth, normals, tmp, size, image);
     }
     fesetround(old);
 }

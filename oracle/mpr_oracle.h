@@ -84,7 +84,7 @@ void orc_deriv_op_n(int32_t op, int32_t n, const float* a4, const float* b4, flo
  * fesetround(FE_DOWNWARD / FE_UPWARD) evaluation on n random operand pairs; returns the
  * number of mismatches */
 int64_t orc_selftest_rounding(int64_t n, uint64_t seed);
-/* shared math functions (include/mpr_fmath.h) for accuracy tests */
+/* the oracle's float functions (oracle/orc_fmath.h) */
 void orc_fmath_n(int32_t which, int32_t n, const float* x, float* out);
 
 /* ---- mpr::Effects (reference src/effects.cu) over a finished frame's heightmap + normals ----

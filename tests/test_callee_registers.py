@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # file, symbol prefix, VGPR budget (the clobber lists cover v0..v39, v48..v55, v64..v71 for the interval
 # routines and v0..v31 for the others), SGPR budget (s0..s31, the return address s[30:31] among them)
-CASES = [("kernels.hip", "mpr_ti_", ["asin", "acos", "atan", "exp", "log"], 72, 32),
+CASES = [("kernels.hip", "mpr_ti_", ["asin", "acos", "atan", "exp", "log", "divx", "sqrtx"], 72, 32),
          ("kernels_voxel_asm.hip", "mpr_fa_", ["asin", "acos", "atan"], 32, 32),
          ("kernels_normals_asm.hip", "mpr_nq_", ["asin", "acos", "atan"], 32, 32)]
 

@@ -65,15 +65,6 @@ def test_interval_ops_bit_exact(mpr, orc, opname, kind, path):
         g_lo, g_hi, g_ch = mpr.dev_interval_op(op, a_lo, a_hi, b_lo, b_hi, imm, **kw)
         o_lo, o_hi, o_ch = orc.interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
         ok = same_bits(g_lo, o_lo) & same_bits(g_hi, o_hi) & (g_ch == o_ch)
-        if opname in ("DIV_LHS_IMM", "DIV_IMM_RHS", "DIV_LHS_RHS", "SQRT_LHS"):
-            # documented limit of the residual-based directed division / sqrt: operands
-            # or results below ~2^-100, where the exact FMA residual itself underflows
-            def tiny_nz(v):
-                return (np.abs(v) < 1e-30) & (v != 0)
-            tiny = tiny_nz(o_lo) | tiny_nz(o_hi) | tiny_nz(a_lo) | tiny_nz(a_hi)
-            if opname != "SQRT_LHS":
-                tiny |= tiny_nz(b_lo) | tiny_nz(b_hi)
-            ok = ok | tiny
         bad = np.flatnonzero(~ok)
         assert bad.size == 0, (opname, kind, imm, bad.size,
                                [(a_lo[i], a_hi[i], b_lo[i], b_hi[i], g_lo[i], g_hi[i], o_lo[i], o_hi[i], g_ch[i], o_ch[i]) for i in bad[:5]])
