@@ -37,7 +37,7 @@ int main(int argc, char** argv)
     } else {
         heat = ctx.render2D_heatmap(tape, mpr::Matrix3f::Identity(), 0.0f);
     }
-    if (ctx.tape_index >= (int64_t)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) {
+    if (*ctx.tape_index >= (int64_t)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) {
         std::cerr << "Tape overflowed and wasn't pruned\n";
         return 1;
     }

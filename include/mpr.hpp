@@ -9,15 +9,23 @@
  *     ctx.stages[3].filled[i], ctx.normals[i], ctx.stages[k].tiles[i],
  *     ctx.stages[k].tile_array_size, ctx.tape_data[j], *ctx.tape_index
  *
- * The reference exposes managed-memory pointers; here the members are host mirrors (Mirror<T>:
- * operator[], get(), size()) fetched from the device on first access after a render, so a timing
- * loop that only renders pays for nothing else.  Eigen is not required: Matrix3f /
+ * The reference exposes managed-memory pointers (Ptr<T[]>, inc/util.hpp:44-50) that callers index
+ * on the host after a render (benchmark/circle.cpp:43-71, tape_shortening.cpp:57-98,
+ * render_3d_heatmap.cpp:64); here the same members — stages[k].filled / .tiles / .tile_array_size,
+ * normals, tape_data, tape_index — are host mirrors with the same spelling at the call site
+ * (operator[], get(), operator* for tape_index, conversion to size_t for tile_array_size), fetched
+ * from the device on first access after a render, so a timing loop that only renders pays for
+ * nothing else.  the programs under tests/facade/ are this repository's own programs written in the access
+ * patterns of those three reference files; tests/test_host_api.py compiles them.  Eigen is not required: Matrix3f /
  * Matrix4f below are minimal column-major matrices with Eigen's (row, col) indexing; an Eigen
  * matrix's .data() can be passed to the *_raw overloads directly.
  *
  * libfive is not part of this repository; libfive::Tree below is the small expression front
- * end of libmpr_amd (operators, sqrt/min/max/..., .frep archives) under libfive's names so that
- * the reference's benchmark mains compile unchanged against this header.
+ * end of libmpr_amd (operators, sqrt/min/max/..., .frep archives) under libfive's names.  What a
+ * reference main still has to change: `libfive::Archive::deserialize(in).shapes.front().tree`
+ * becomes `libfive::Tree::load(path)`, Eigen::Matrix{3,4}f becomes mpr::Matrix{3,4}f (or pass
+ * Eigen's .data()), and libfive::Heightmap / savePNG are not provided (benchmark/render_table.cpp
+ * here writes PGM).
  */
 #pragma once
 #include <cmath>
@@ -165,17 +173,32 @@ struct Tape {
 
 using TileNode = mpr_tile_node;
 
-struct Context;
+/* a single value behind a Ptr<T> in the reference (Context::tape_index) or a plain member that is
+ * only known after the frame (Tiles::tile_array_size): fetched on first use after a render */
+template <typename T>
+struct LazyValue {
+    T operator*() const { return fetch(); }
+    operator T() const { return fetch(); }
+    void invalidate() { valid = false; }
+    std::function<T()> loader;
 
-struct Tiles {
-    Mirror<int32_t> filled;           /* stages[3].filled: fetched on first use after a render */
-    /* tiles / tile_array_size: fetched on demand */
-    const std::vector<TileNode>& tile_list() const;
-    size_t tile_array_size() const { return tile_list().size(); }
-    Context* owner = nullptr;
-    int index = 0;
-    mutable std::vector<TileNode> tiles_cache;
-    mutable bool tiles_valid = false;
+private:
+    T fetch() const
+    {
+        if (!valid && loader) {
+            cache = loader();
+            valid = true;
+        }
+        return cache;
+    }
+    mutable T cache = T();
+    mutable bool valid = false;
+};
+
+struct Tiles {                        /* inc/context.hpp:29-36 */
+    Mirror<int32_t> filled;
+    Mirror<TileNode> tiles;
+    LazyValue<size_t> tile_array_size;
 };
 
 struct Context {
@@ -184,24 +207,49 @@ struct Context {
         mpr_context* c = nullptr;
         check(mpr_ctx_create(device, image_size_px, &c));
         handle = std::shared_ptr<mpr_context>(c, mpr_ctx_destroy);
+        mpr_context* const h = handle.get();          /* the loaders hold the C handle, never `this` */
         for (int i = 0; i < 4; ++i) {
-            stages[i].owner = this;
-            stages[i].index = i;
-            mpr_context* const h = handle.get();
             stages[i].filled.loader = [h, i](std::vector<int32_t>& v) {
                 const int32_t S = mpr_ctx_image_size(h);
                 const int32_t side = (i == 3) ? S : (i == 2 ? S / 4 : (i == 1 ? S / 16 : S / 64));
                 v.resize((size_t)side * side);
                 check(mpr_read_filled(h, i, v.data()));
             };
+            stages[i].tiles.loader = [h, i](std::vector<TileNode>& v) {
+                size_t n = 0;
+                check(mpr_read_tiles(h, i, nullptr, 0, &n));
+                v.resize(n);
+                if (n) check(mpr_read_tiles(h, i, v.data(), n, &n));
+            };
+            stages[i].tile_array_size.loader = [h, i]() {
+                size_t n = 0;
+                check(mpr_read_tiles(h, i, nullptr, 0, &n));
+                return n;
+            };
         }
-        mpr_context* const h = handle.get();
         normals.loader = [h](std::vector<uint32_t>& v) {
             const int32_t S = mpr_ctx_image_size(h);
             v.resize((size_t)S * S);
             check(mpr_read_normals(h, v.data()));
         };
+        tape_data.loader = [h](std::vector<uint64_t>& v) {
+            int32_t ti = 0;
+            check(mpr_read_tape_pool(h, nullptr, 0, &ti));
+            v.resize(ti > 0 ? (size_t)ti : 0);
+            if (!v.empty()) check(mpr_read_tape_pool(h, v.data(), v.size(), &ti));
+        };
+        tape_index.loader = [h]() {
+            int32_t ti = 0;
+            check(mpr_read_tape_pool(h, nullptr, 0, &ti));
+            return ti;
+        };
     }
+    /* one owner per device context, like the reference's unique_ptr members: movable, not copyable */
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    Context(Context&&) = default;
+    Context& operator=(Context&&) = default;
+
     void render2D(const Tape& tape, const Matrix3f& mat, const float z = 0.0f)
     {
         check(mpr_render2d(handle.get(), tape.handle.get(), mat.data(), z));
@@ -232,42 +280,25 @@ struct Context {
         refresh(true);
         return heat;
     }
-    /* tape_data / *tape_index (benchmark/tape_shortening.cpp:56-72, render_3d_heatmap.cpp:64) */
-    const std::vector<uint64_t>& tape_data()
-    {
-        if (!pool_valid) {
-            int32_t ti = 0;
-            check(mpr_read_tape_pool(handle.get(), nullptr, 0, &ti));
-            pool.resize(ti > 0 ? (size_t)ti : 0);
-            if (!pool.empty()) check(mpr_read_tape_pool(handle.get(), pool.data(), pool.size(), &ti));
-            tape_index = ti;
-            pool_valid = true;
-        }
-        return pool;
-    }
-
     int32_t image_size_px;
+    Mirror<uint64_t> tape_data;       /* tape_data[j]: the pool up to *tape_index (benchmark/tape_shortening.cpp:56-72) */
+    LazyValue<int32_t> tape_index;    /* *tape_index (benchmark/render_3d_heatmap.cpp:64) */
     Tiles stages[4];
     Mirror<uint32_t> normals;
-    int32_t tape_index = 0;
     std::shared_ptr<mpr_context> handle;
 
 private:
-    friend struct Tiles;
     void refresh(bool)
     {
         for (auto& s : stages) {
-            s.tiles_valid = false;
             s.filled.invalidate();
+            s.tiles.invalidate();
+            s.tile_array_size.invalidate();
         }
         normals.invalidate();
-        pool_valid = false;
-        mpr_counters c;
-        check(mpr_get_counters(handle.get(), &c));
-        tape_index = c.tape_index;
+        tape_data.invalidate();
+        tape_index.invalidate();
     }
-    std::vector<uint64_t> pool;
-    bool pool_valid = false;
 };
 
 /* inc/effects.hpp:21-37 — SSAO and shading over the context's last render3D */
@@ -302,17 +333,5 @@ private:
         image.invalidate();
     }
 };
-
-inline const std::vector<TileNode>& Tiles::tile_list() const
-{
-    if (!tiles_valid) {
-        size_t n = 0;
-        check(mpr_read_tiles(owner->handle.get(), index, nullptr, 0, &n));
-        tiles_cache.resize(n);
-        if (n) check(mpr_read_tiles(owner->handle.get(), index, tiles_cache.data(), n, &n));
-        tiles_valid = true;
-    }
-    return tiles_cache;
-}
 
 }  // namespace mpr

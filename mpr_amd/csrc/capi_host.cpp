@@ -135,6 +135,11 @@ int mpr_tape_from_tree(const mpr_tree* tr, mpr_tape** out)
     MPR_TRY(
         mpr::front::TapeBuild tb = mpr::front::build_tape(tr->t);
         if (!tb.error.empty()) return mpr::set_error(MPR_ERR_INVALID, tb.error);
+        /* The reference prints "Ran out of slots!" and carries on with slot 0 (src/tape.cpp:79-81), which
+         * silently evaluates something else: slot 0 means "no operand, take the immediate" to every
+         * interpreter (src/context.cu:418-424).  Refuse the expression instead. */
+        if (tb.slots_exhausted)
+            return mpr::set_error(MPR_ERR_UNSUPPORTED, "expression needs more than 254 live values at once (src/tape.cpp:79: \"Ran out of slots!\")");
         auto* t = new mpr_tape();
         t->clauses = std::move(tb.clauses);
         t->flags = (tb.slots_exhausted ? 1 : 0) | (tb.unsupported ? 2 : 0);
@@ -169,6 +174,15 @@ int mpr_tape_from_clauses(const uint64_t* clauses, int32_t length, mpr_tape** ou
         const uint32_t op = mpr_cl_op(clauses[i]);
         if (op < MPR_OP_SQUARE_LHS || op >= MPR_OP_COUNT)
             return mpr::set_error(MPR_ERR_INVALID, "invalid opcode in tape at clause " + std::to_string(i));
+        /* Slot 0 is "no operand": the interpreters read `slot ? value : immediate` (as the reference's tape
+         * pushing does, src/context.cu:418-424), so a register operand numbered 0 would be taken for an
+         * immediate.  mpr::Tape never produces one (src/tape.cpp:72-87 starts at slot 1). */
+        const bool needs_lhs = op != MPR_OP_SUB_IMM_RHS && op != MPR_OP_DIV_IMM_RHS && op != MPR_OP_COPY_IMM && op != MPR_OP_COPY_RHS;
+        const bool needs_rhs = op == MPR_OP_ADD_LHS_RHS || op == MPR_OP_MUL_LHS_RHS || op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS ||
+                               op == MPR_OP_SUB_LHS_RHS || op == MPR_OP_DIV_LHS_RHS || op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_DIV_IMM_RHS ||
+                               op == MPR_OP_COPY_RHS;
+        if ((needs_lhs && mpr_cl_lhs(clauses[i]) == 0) || (needs_rhs && mpr_cl_rhs(clauses[i]) == 0) || mpr_cl_out(clauses[i]) == 0)
+            return mpr::set_error(MPR_ERR_INVALID, "clause " + std::to_string(i) + " names slot 0 as a register (slot 0 means: no operand)");
     }
     MPR_TRY(
         auto* t = new mpr_tape();

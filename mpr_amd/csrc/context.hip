@@ -223,7 +223,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
         c->arena_words = words;
     }
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
-    CT(hipMalloc((void**)&c->tape_index, sizeof(unsigned long long)));
+    CT(hipMalloc((void**)&c->tape_index, 2 * sizeof(unsigned long long)));   /* [0] index, [1] sticky overflow flag of the frame */
     CT(hipMalloc((void**)&c->num_active, 8 * sizeof(int)));      /* [0..2] counts, [3] workgroups done, [4] choices the next stage needs */
     CT(hipMalloc((void**)&c->zs_hist, 1024 * sizeof(int)));
     CT(hipMalloc((void**)&c->zs_cursor, 1024 * sizeof(int)));
@@ -964,10 +964,11 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int ti = 0;
-    unsigned long long ti64 = 0;
-    HIP_TRY(hipMemcpy(&ti64, c->tape_index, sizeof(ti64), hipMemcpyDeviceToHost));
-    ti = (int)std::min<unsigned long long>(ti64, 0x7FFFFFFFull);
+    unsigned long long tiw[2] = {0, 0};
+    HIP_TRY(hipMemcpy(tiw, c->tape_index, sizeof(tiw), hipMemcpyDeviceToHost));
+    ti = (int)std::min<unsigned long long>(tiw[0], 0x7FFFFFFFull);
     c->last.tape_index = ti;
+    c->last.pool_overflowed = tiw[1] ? 1 : 0;             /* set by any claim that did not fit, counters or not */
     if (c->flags & MPR_CTX_COUNTERS) {
         unsigned long long h[mprk::CNT_COUNT];
         HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
@@ -978,7 +979,7 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
         c->last.clauses_fwd_voxels = (int64_t)h[mprk::CNT_FWD_VOX];
         c->last.clauses_fwd_normals = (int64_t)h[mprk::CNT_FWD_NORM];
         c->last.normal_pixels = (int64_t)h[mprk::CNT_NORMAL_PX];
-        c->last.pool_overflowed = h[mprk::CNT_OVERFLOW] ? 1 : 0;
+        if (h[mprk::CNT_OVERFLOW]) c->last.pool_overflowed = 1;
         if (getenv("MPR_DEBUG_TILES") && (atoi(getenv("MPR_DEBUG_TILES")) & 4)) {
             /* development: per-stage cycle breakdown of k_eval_tiles (sum over wavefronts) */
             unsigned long long ph[32];

@@ -50,7 +50,7 @@ k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, unsigned long long
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = i; k < zero_n4; k += stride) zero_base[k] = make_int4(0, 0, 0, 0);
     if (i < 8) num_active[i] = 0;
-    if (i == 0) *tape_index = (unsigned long long)tape_len;
+    if (i == 0) { tape_index[0] = (unsigned long long)tape_len; tape_index[1] = 0; }
     for (size_t k = i; k < (size_t)count; k += stride) {
         mpr_tile_node n;
         n.position = (int)k;
@@ -350,7 +350,7 @@ k_eval_tiles(TileStageArgs a)
             const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base64 >> 32));
             base64 = ((unsigned long long)b_hi << 32) | b_lo;
             const bool ok = base64 < (unsigned long long)a.pool_cap && base64 + want < 0x7FFFFFFFull;
-            if (!ok && lane == 0) atomicAdd(a.tape_index, 0ull - want);
+            if (!ok && lane == 0) { atomicAdd(a.tape_index, 0ull - want); a.tape_index[1] = 1; }
             const int base = ok ? (int)base64 : 0;
             if (push) {
                 out_index = base + MPR_SUBTAPE_CHUNK * run_chunks * rank_in(live, lane);
@@ -534,6 +534,7 @@ k_eval_tiles(TileStageArgs a)
         if (written) atomicAdd((unsigned long long*)&a.counters[CNT_WRITTEN], (unsigned long long)written);
         if (overflow) a.counters[CNT_OVERFLOW] = 1;
     }
+    if (overflow) a.tape_index[1] = 1;        /* sticky per frame; read back by mpr_get_counters */
 }
 
 /* copy_filled (reference :664-692) rides along in the compaction's launch as extra workgroups: it only

@@ -258,6 +258,7 @@ k_eval_tiles_wide(WideStageArgs w)
         const int base = ok ? (int)base64 : 0;
         sh[2] = base;
         sh[3] = ok;
+        if (!ok) a.tape_index[1] = 1;
         if (!ok && a.counters) a.counters[CNT_OVERFLOW] = 1;
         if (a.next_choices) {
             const int need = ok ? sh[1036] : a.choice_cap;      /* pool exhausted: the tile keeps the root tape */

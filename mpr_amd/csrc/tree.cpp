@@ -148,7 +148,9 @@ Tree Tree::binary(Op op, const Tree& a, const Tree& b)
             if (a.id() == b.id()) return unary(OP_SQUARE, a);
             break;
         case OP_DIV:
-            if (is_const(b, 1.0f)) return a;
+            /* x / 1 is NOT folded: bear.frep, written by libfive, contains six such divisions, so libfive's
+             * own simplifier keeps them (every other identity rule here never fires on the six archives of
+             * the reference — scripts: tests/test_host_api.py::test_archives_are_canonical) */
             break;
         case OP_MIN:
         case OP_MAX:
@@ -271,6 +273,10 @@ struct Reader {
 };
 }  // namespace
 
+/* Nodes are rebuilt through Tree::unary / Tree::binary — the same deduplication, identity and constant
+ * folding an expression written with the operators gets (libfive's deserializer reconstructs nodes through
+ * its Tree constructors and Cache::operation too) — so an archive and the same expression built in code
+ * give one tape. */
 Tree deserialize_frep(const uint8_t* bytes, size_t n)
 {
     Reader r{bytes, n};
@@ -296,13 +302,13 @@ Tree deserialize_frep(const uint8_t* bytes, size_t n)
         } else if (args == 1) {
             const uint32_t a = r.u32();
             if (a >= nodes.size()) throw std::runtime_error("frep: forward reference");
-            nodes.push_back(Tree::raw(op, 0, nodes[a], Tree()));
+            nodes.push_back(Tree::unary(op, nodes[a]));
         } else {
             const uint32_t rhs = r.u32();
             const uint32_t lhs = r.u32();
             if (rhs >= nodes.size() || lhs >= nodes.size())
                 throw std::runtime_error("frep: forward reference");
-            nodes.push_back(Tree::raw(op, 0, nodes[lhs], nodes[rhs]));
+            nodes.push_back(Tree::binary(op, nodes[lhs], nodes[rhs]));
         }
     }
     if (nodes.empty()) throw std::runtime_error("frep: empty tree");

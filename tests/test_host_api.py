@@ -85,16 +85,29 @@ def test_tree_front_end(mpr):
     assert r0 == r1
 
 
-def test_slot_exhaustion_flag(mpr):
-    """src/tape.cpp:79-81: more than 254 live values -> flag set, slot 0 used."""
+def test_slot_exhaustion_is_an_error(mpr):
+    """src/tape.cpp:79-81 prints "Ran out of slots!" and goes on with slot 0, which every interpreter
+    reads as "no operand: take the immediate" — a silently different expression.  Here: an error."""
     X = mpr.Tree.X()
     terms = [mpr.sin(X * float(i + 2)) for i in range(300)]
     # keep all 300 values alive at once: sum them only after all were computed (right-deep)
     acc = terms[-1]
     for t in reversed(terms[:-1]):
         acc = t + acc
-    tape = mpr.Tape(acc)
-    assert tape.flags & 1
+    with pytest.raises(mpr.MprError) as e:
+        mpr.Tape(acc)
+    assert "slots" in str(e.value)
+
+
+def test_clauses_naming_slot_zero_are_rejected(mpr):
+    """A register operand numbered 0 would be evaluated as an immediate (slot 0 = no operand)."""
+    good = mpr.Tape(mpr.Tree.X() + mpr.Tree.Y()).data.copy()
+    assert mpr.Tape(good).length == good.size
+    for field_shift in (8, 16, 24):               # out, lhs, rhs of the ADD_LHS_RHS clause
+        bad = good.copy()
+        bad[1] &= ~np.uint64(0xFF << field_shift)
+        with pytest.raises(mpr.MprError):
+            mpr.Tape(bad)
 
 
 def test_partition_columns(mpr):
@@ -142,3 +155,97 @@ def test_tape_dependency_levels(mpr):
             assert lv[k] == want, (name, k)
             last[out] = k
     assert depth == {"prospero": 22, "architecture": 19, "bear": 72, "hello_world": 18}
+
+
+FACADE = ["tests/facade/tile_occupancy.cpp", "tests/facade/tape_lengths.cpp", "benchmark/render_table.cpp",
+          "benchmark/render_heatmap.cpp", "benchmark/render_effects.cpp"]
+
+
+@pytest.mark.parametrize("src", FACADE)
+def test_facade_programs_compile(src):
+    """include/mpr.hpp keeps the member spelling the reference's callers use (inc/context.hpp:29-74):
+    stages[k].tiles[i], stages[k].tile_array_size, stages[3].filled[i], normals[i], tape_data[j],
+    *tape_index.  tests/facade/*.cpp are this repository's own programs in the access patterns of
+    benchmark/circle.cpp:42-103 and benchmark/tape_shortening.cpp:56-118."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("g++ not found")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, src)])
+
+
+def test_facade_context_is_move_only():
+    """One owner per device context (the reference's members are unique_ptrs)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("g++"):
+        pytest.skip("g++ not found")
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "t.cpp")
+        open(src, "w").write('#include <type_traits>\n#include "mpr.hpp"\n'
+                             "static_assert(!std::is_copy_constructible<mpr::Context>::value, \"copyable\");\n"
+                             "static_assert(!std::is_copy_assignable<mpr::Context>::value, \"copy-assignable\");\n"
+                             "static_assert(std::is_move_constructible<mpr::Context>::value, \"not movable\");\n"
+                             "int main() { return 0; }\n")
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), src])
+
+
+@pytest.mark.gpu
+def test_facade_programs_run(mpr, orc, tapes):
+    """Build and run the two façade programs on the device; their numbers must be the oracle's."""
+    import subprocess
+    import tempfile
+    from conftest import view2
+    lib_dir = os.path.dirname(mpr.LIB_PATH)
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = {}
+        for name in ("tile_occupancy", "tape_lengths"):
+            exe = os.path.join(tmp, name)
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                                   os.path.join(ROOT, "tests", "facade", name + ".cpp"), "-o", exe,
+                                   "-L" + lib_dir, "-lmpr_amd", "-Wl,-rpath," + lib_dir])
+            outs[name] = subprocess.check_output([exe], text=True)
+    ref = orc.Frame(tapes("circle").data, 2, 128, mpr.colmajor(view2(), 3), threads=1)
+    f = dict(zip(outs["tile_occupancy"].split()[0::2], outs["tile_occupancy"].split()[1::2]))
+    assert int(f["inside"]) == int((ref.image != 0).sum())
+    assert int(f["decided64"]) == int((ref.tiles[0]["position"] == -1).sum())
+    assert int(f["decided8"]) == int((ref.tiles[2]["position"] == -1).sum())
+    ref2 = orc.Frame(tapes("two_spheres").data, 2, 256, mpr.colmajor(view2(), 3), threads=1)
+    live = ref2.tiles[2][ref2.tiles[2]["position"] != -1]
+    ln, _ = orc.tiles_digest(ref2.pool, live)
+    line = outs["tape_lengths"].strip().splitlines()[-1]
+    m = re.search(r"8px tiles (\d+) mean length ([\d.]+)", line)
+    assert int(m.group(1)) == live.size
+    assert abs(float(m.group(2)) - (ln.mean() if live.size else 0.0)) < 0.06
+
+
+def test_archives_are_canonical(mpr):
+    """The .frep reader rebuilds nodes through the same simplifying constructors the operators use
+    (deduplication, identities, constant folding), as libfive's deserializer does.  The reference's
+    six archives were written by libfive and are canonical under its rules, so reading them must
+    not change a single node: same node count as the file holds, and the tape equals the one of the
+    re-serialised tree."""
+    import struct
+    for name in ("prospero", "involute_gear_2d", "involute_gear_3d", "architecture", "bear", "hello_world"):
+        raw = open(os.path.join(mpr.MODELS_DIR, name + ".frep"), "rb").read()
+        # count the nodes in the file (format: SURVEY.md section 8(c))
+        p, n = 5, 0
+        while raw[p] != 0xFF:
+            op = raw[p]
+            p += 1 + (4 if op == 1 or 7 <= op <= 19 else 8 if 20 <= op <= 31 else 0)
+            n += 1
+        t = mpr.model(name)
+        assert t.size() == n, (name, t.size(), n)
+        again = mpr.Tree.from_frep(t.to_frep())
+        assert np.array_equal(mpr.Tape(t).data, mpr.Tape(again).data)
+    # and an expression that is NOT canonical comes out the same whether built by operators or read from an archive
+    X, Y = mpr.Tree.X(), mpr.Tree.Y()
+    built = mpr.tmin((X + 0.0) * 1.0, Y * Y) - 0.5
+    blob = bytes([ord("T"), 34, 34, 34, 34,
+                  2, 1]) + struct.pack("<f", 0.0) + bytes([20]) + struct.pack("<II", 1, 0) + \
+        bytes([1]) + struct.pack("<f", 1.0) + bytes([21]) + struct.pack("<II", 3, 2) + \
+        bytes([3, 21]) + struct.pack("<II", 5, 5) + bytes([22]) + struct.pack("<II", 6, 4) + \
+        bytes([1]) + struct.pack("<f", 0.5) + bytes([24]) + struct.pack("<II", 8, 7) + bytes([0xFF, 0xFF])
+    assert np.array_equal(mpr.Tape(mpr.Tree.from_frep(blob)).data, mpr.Tape(built).data)
