@@ -51,10 +51,6 @@ struct mpr_context {
     size_t tiles_cap[4] = {0, 0, 0, 0};
     size_t tiles_n[4] = {0, 0, 0, 0};
 
-    mprk::GroupInfo* groups = nullptr; /* per sibling group of the last tile stage */
-    size_t groups_cap = 0;
-    ulonglong2* choice_masks = nullptr;
-    size_t masks_cap = 0;
 
     int* owner_dev = nullptr;          /* column ownership, (S/64)^2 */
     std::vector<int32_t> owner_host;   /* what owner_dev holds (uploads are skipped when unchanged) */
@@ -76,15 +72,8 @@ struct mpr_context {
     int* pub_dev = nullptr;            /* the same words as the device sees them */
     int pub_seq = 0;
 
-    bool voxel_pairs = false;          /* float pass: sibling tiles on a common tape two at a time (experiment, MPR_VOXEL_PAIRS=1;
-                                          measured slower than the single-tile interpreter) */
-    mpr_tile_node* vox_singles = nullptr;
-    int4* vox_pairs = nullptr;
-    size_t vox_singles_cap = 0, vox_pairs_cap = 0;
     bool normals_asm = true;           /* normals pass interpreter: gfx950 assembly (default) or compiled (MPR_NORMALS_ASM=0) */
     bool voxel_asm = true;             /* float pass interpreter: gfx950 assembly (default) or the compiled C++ one */
-    int voxel_k = 0;                   /* float pass: 0 = one wave per smallest tile walking its own sub-tape (default);
-                                          1, 2, 4 = children per batch of the grouped form (MPR_VOXEL_K, experimental) */
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
@@ -93,6 +82,11 @@ struct mpr_context {
     bool sched_ok = false;
     int sched_nlevels = 0, sched_nclauses = 0, sched_root = 0;
     bool wide_stage0 = true;           /* MPR_WIDE_STAGE0=0: first stage with the one-lane-per-tile kernel */
+    /* development switches, read once when the context is created (never per frame) */
+    bool wide_force = false;           /* MPR_WIDE_FORCE: level-parallel first stage whatever the DAG's shape */
+    bool dynamic_choices = true;       /* MPR_DYNAMIC_CHOICES=0: size every stage's choice array by the root tape */
+    int debug_tiles = 0;               /* MPR_DEBUG_TILES: 1 = skip tape pushing, 2 = skip the arithmetic, 4 = cycle breakdown */
+    bool debug_choices = false;        /* MPR_DEBUG_CHOICES */
     int tape_len = 0;
 
     mpr_counters last = {};
@@ -185,12 +179,11 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
-    if (const char* e = getenv("MPR_VOXEL_PAIRS")) c->voxel_pairs = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
-    if (const char* e = getenv("MPR_VOXEL_K")) {
-        const int k = atoi(e);
-        if (k == 0 || k == 1 || k == 2 || k == 4) c->voxel_k = k;
-    }
+    c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
+    if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
+    if (const char* e = getenv("MPR_DEBUG_TILES")) c->debug_tiles = atoi(e);
+    c->debug_choices = getenv("MPR_DEBUG_CHOICES") != nullptr;
     c->pool_cap = opt->pool_clauses > 0 ? opt->pool_clauses : (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK;
     if (c->pool_cap > 0x7FFFFFFFll) c->pool_cap = 0x7FFFFFFFll;   /* tape indices are int32 (inc/context.hpp:25) */
     *out = nullptr;
@@ -269,8 +262,6 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->zs_hist) (void)hipFree(c->zs_hist);
     if (c->zs_cursor) (void)hipFree(c->zs_cursor);
     if (c->counters) (void)hipFree(c->counters);
-    if (c->groups) (void)hipFree(c->groups);
-    if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->owner_dev) (void)hipFree(c->owner_dev);
     if (c->col_list_dev) (void)hipFree(c->col_list_dev);
     if (c->heat) (void)hipFree(c->heat);
@@ -281,8 +272,6 @@ void mpr_ctx_destroy(mpr_context* c)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
-    if (c->vox_singles) (void)hipFree(c->vox_singles);
-    if (c->vox_pairs) (void)hipFree(c->vox_pairs);
     if (c->sched_recs) (void)hipFree(c->sched_recs);
     if (c->sched_levels) (void)hipFree(c->sched_levels);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -315,7 +304,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
          * handful of clauses per level (bear: 544 clauses in 72 levels) the 64 tiles-per-wave walk,
          * whose latency per clause the assembly interpreter cut to a third, is the faster one */
         c->sched_ok = sc.ok && mprk::wide_stage_fits(sc.nclauses) &&
-                      (sc.nclauses >= 12 * ((int)sc.level_start.size() - 1) || getenv("MPR_WIDE_FORCE") != nullptr);
+                      (sc.nclauses >= 12 * ((int)sc.level_start.size() - 1) || c->wide_force);
         if (c->sched_ok) {
             const size_t rb = sc.recs.size() * sizeof(mpr::SchedRec), lb = sc.level_start.size() * sizeof(int32_t);
             if (rb > c->sched_recs_cap) {
@@ -410,7 +399,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     /* device limits: LDS per workgroup */
     const size_t lds_limit = 160 * 1024;
     if (mprk::tile_stage_lds_bytes(nslots, choice_cap) > lds_limit || mprk::normals_lds_bytes(nslots) > lds_limit ||
-        mprk::voxel_lds_bytes(nslots) > lds_limit || mprk::grouped_voxel_lds_bytes(nslots, 4) > lds_limit)
+        mprk::voxel_lds_bytes(nslots) > lds_limit)
         return mpr::set_error(MPR_ERR_UNSUPPORTED, "tape needs more LDS than one workgroup can hold");
 
     /* ONE launch resets the images (src/context.cu:1146-1151, :1295-1301: five cudaMemsetAsync), sets
@@ -429,10 +418,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
      * upper bound counted by the backward walks), not by the root tape's min / max count: with 488 of
      * them architecture fits two waves per CU in its last tile stage, with the 58 it needs, three */
     int stage_choice_cap = choice_cap;
-    const bool dynamic_choices = c->voxel_k == 0 && !(getenv("MPR_DYNAMIC_CHOICES") && atoi(getenv("MPR_DYNAMIC_CHOICES")) == 0);
-    int last_ngroups = 0, last_stage = -1;
-    bool pairing = false;
-    int n_singles = 0, n_pairs = 0;
+    const bool dynamic_choices = c->dynamic_choices;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
@@ -462,21 +448,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         const int tps = S / tile_size_px;
         c->last.tiles_in[si] = count;
 
-        const int ngroups = (count + 63) / 64;
-        const bool grouped = last && count > 0 && c->voxel_k > 0 && !heat;
-        if (grouped) {
-            /* the float pass walks each group's tape with the group's choice masks */
-            rc = ensure_buffer(&c->groups, &c->groups_cap, (size_t)ngroups);
-            if (rc) return rc;
-            rc = ensure_buffer(&c->choice_masks, &c->masks_cap, (size_t)ngroups * std::max(choice_cap, 1));
-            if (rc) return rc;
-            last_ngroups = ngroups;
-            last_stage = i;
-        }
         if (count > 0) {
             mprk::TileStageArgs a;
-            a.groups = grouped ? c->groups : nullptr;
-            a.choice_masks = grouped ? c->choice_masks : nullptr;
             a.tape_ro = c->pool;
             a.tape_wr = c->pool;
             a.tape_index = c->tape_index;
@@ -493,13 +466,13 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.counters = cnt;
             a.heat = heat;
             a.heat_stride = S;
-            a.debug = getenv("MPR_DEBUG_TILES") ? atoi(getenv("MPR_DEBUG_TILES")) : 0;
+            a.debug = c->debug_tiles;
             if (a.debug & 4) a.debug |= si << 4;
             if (heat && dim == 3) mprk::launch_mask_filled(s, c->tiles[i], count, tps, c->filled[i]);
             TimedScope ts(c, "eval_tiles_i");
             /* ... and only while the stage has few tiles (a workgroup per tile is latency-bound at low lane
              * utilisation: with 32768 tiles at 2048^3 the 64-tiles-per-wave walk is 1.5x faster) */
-            if (si == 0 && c->wide_stage0 && c->sched_ok && !grouped && !heat && !(a.debug & 3) && count <= 8192) {
+            if (si == 0 && c->wide_stage0 && c->sched_ok && !heat && !(a.debug & 3) && count <= 8192) {
                 /* first stage: few tiles, all on the root tape -> one workgroup per tile, level by level */
                 mprk::WideStageArgs w;
                 w.t = a;
@@ -516,16 +489,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
         if (rc) return rc;
-        /* last 3-D stage: siblings that share a tape are paired up for the float pass */
-        pairing = last && dim == 3 && c->voxel_pairs && c->voxel_asm && !cnt && !heat && nslots <= 128 && c->voxel_k == 0;
-        if (pairing) {
-            rc = ensure_buffer(&c->vox_singles, &c->vox_singles_cap, (size_t)std::max(count, 1));
-            if (rc) return rc;
-            rc = ensure_buffer(&c->vox_pairs, &c->vox_pairs_cap, (size_t)std::max(count, 2) / 2 + 1);
-            if (rc) return rc;
-        }
         const int seq = ++c->pub_seq;
-        const bool zs = dim == 3 && !pairing && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
+        const bool zs = dim == 3 && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
         if (count > 0 && zs) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
@@ -534,8 +499,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         } else if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                           pairing ? c->vox_singles : nullptr, pairing ? c->vox_pairs : nullptr, c->pub_dev, seq,
-                                           c->filled[next], S / (tile_size_px / sub));
+                                           c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub));
         }
         if (count == 0) {
             /* copy_filled rides in the compaction's launch; no compaction, a launch of its own */
@@ -548,33 +512,15 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             if (rc) return rc;
         }
         const int active = act3[0];
-        n_singles = act3[1];
-        n_pairs = act3[2];
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
-        if (getenv("MPR_DEBUG_CHOICES")) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d)\n", si, count, act3[3], choice_cap);
+        if (c->debug_choices) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d)\n", si, count, act3[3], choice_cap);
         c->last.tiles_active[si] = active;
         count = last ? active : active * 64;
         c->tiles_n[next] = (size_t)count;
     }
 
     c->last.voxel_tiles = count;
-    if (!brute && last_ngroups > 0 && count > 0 && c->voxel_k > 0 && !heat) {
-        mprk::GroupedVoxelArgs v;
-        v.tape_ro = c->pool;
-        v.image = c->filled[3];
-        v.tps = S / (dim == 3 ? 4 : 8);
-        v.tiles = c->tiles[last_stage];
-        v.ngroups = last_ngroups;
-        v.nslots = nslots;
-        v.choice_cap = std::max(choice_cap, 1);
-        v.z = z;
-        fill_mat(v.mat, mat, dim == 3 ? 16 : 9);
-        v.groups = c->groups;
-        v.choice_masks = c->choice_masks;
-        v.counters = cnt;
-        TimedScope ts(c, "eval_voxels_f");
-        mprk::launch_eval_voxels_grouped(s, dim, c->voxel_k, v);
-    } else if (count > 0) {
+    if (count > 0) {
         mprk::VoxelArgs v;
         v.tape_ro = c->pool;
         v.image = c->filled[3];
@@ -588,21 +534,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         v.heat = heat;
         TimedScope ts(c, "eval_voxels_f");
         /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
-        if (pairing) {
-            /* pairs of siblings on a common tape, then the tiles with a tape of their own */
-            mprk::PairVoxelArgs pv;
-            pv.tape_ro = c->pool;
-            pv.image = c->filled[3];
-            pv.tps = v.tps;
-            pv.pairs = c->vox_pairs;
-            pv.count = n_pairs;
-            pv.nslots = nslots;
-            fill_mat(pv.mat, mat, 16);
-            mprk::launch_eval_voxel_pairs_asm(s, pv);
-            v.tiles = c->vox_singles;
-            v.count = n_singles;
-            mprk::launch_eval_voxels_asm(s, dim, v);
-        } else if (c->voxel_asm && !cnt && !heat) mprk::launch_eval_voxels_asm(s, dim, v);
+        if (c->voxel_asm && !cnt && !heat) mprk::launch_eval_voxels_asm(s, dim, v);
         else mprk::launch_eval_voxels(s, dim, v);
     }
     if (dim == 3) {
@@ -980,7 +912,7 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
         c->last.clauses_fwd_normals = (int64_t)h[mprk::CNT_FWD_NORM];
         c->last.normal_pixels = (int64_t)h[mprk::CNT_NORMAL_PX];
         if (h[mprk::CNT_OVERFLOW]) c->last.pool_overflowed = 1;
-        if (getenv("MPR_DEBUG_TILES") && (atoi(getenv("MPR_DEBUG_TILES")) & 4)) {
+        if (c->debug_tiles & 4) {
             /* development: per-stage cycle breakdown of k_eval_tiles (sum over wavefronts) */
             unsigned long long ph[32];
             HIP_TRY(hipMemcpy(ph, c->counters + mprk::CNT_COUNT, sizeof(ph), hipMemcpyDeviceToHost));
@@ -1118,17 +1050,22 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
     uint32_t immbits;
     memcpy(&immbits, &imm, 4);
     /* 64 clauses so that the interpreter's 63-clause block fetch stays inside the buffer */
-    /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding);
-     * 3..5: the same three through the two-tiles-per-wave interpreter (kernels_voxel_pair_asm.hip) */
-    const bool pair = variant >= 3;
-    if (pair) variant -= 3;
+    /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding:
+     * handler tables 1 / 2); 3..5: the same three with two negations of the result behind the clause, so that
+     * its result "dies in the next clause" (tables 3..5: no store, no address); -(-x) is x bit for bit */
+    const bool dies = variant >= 3;
+    if (dies) variant -= 3;
     const uint32_t lhs = variant == 1 ? 5 : 1, rhs = b ? (variant == 2 ? 5 : 2) : 0;
     uint64_t tape3[64] = {mpr_cl_make(0, 1, 2, 3, 0),
                           variant == 2 ? mpr_cl_make(MPR_OP_COPY_RHS, 5, 0, 2, 0) : mpr_cl_make(MPR_OP_COPY_LHS, 5, 1, 0, 0),
                           mpr_cl_make((uint32_t)op, 4, lhs, rhs, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
+    if (dies) {
+        tape3[3] = mpr_cl_make(MPR_OP_NEG_LHS, 4, 4, 0, 0);
+        tape3[4] = mpr_cl_make(MPR_OP_NEG_LHS, 4, 4, 0, 0);
+        tape3[5] = mpr_cl_make(0, 4, 0, 0, 0);
+    }
     HIP_TRY(hipMemcpy(dt.p, tape3, sizeof(tape3), hipMemcpyHostToDevice));
-    if (pair) mprk::launch_test_float_pair_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
-    else mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
+    mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));

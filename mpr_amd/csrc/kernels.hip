@@ -296,21 +296,6 @@ k_eval_tiles(TileStageArgs a)
             ambiguous = true;
         }
     }
-    if (a.groups) {
-        /* last tile stage: keep the group's min/max decisions for the float pass, which walks
-         * THIS tape for every surviving child (k_eval_voxels_grouped) */
-        const int nrec = ci < a.choice_cap ? ci : a.choice_cap;
-        ulonglong2* const dst = a.choice_masks + (size_t)blockIdx.x * a.choice_cap;
-        for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
-        if (lane == 0) {
-            GroupInfo gi;
-            gi.tape = tape;
-            gi.mask_off = 0;
-            gi.nchoices = nrec;
-            gi.pad = 0;
-            a.groups[blockIdx.x] = gi;
-        }
-    }
     const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1);
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 
@@ -583,8 +568,7 @@ template <int DIM, bool LAST>
 __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
-                    mpr_tile_node* __restrict__ out, mpr_tile_node* __restrict__ singles, int4* __restrict__ pairs,
-                    int* __restrict__ pub, int seq, CopyFilled cf)
+                    mpr_tile_node* __restrict__ out, int* __restrict__ pub, int seq, CopyFilled cf)
 {
     if ((int)blockIdx.x >= cf.first_block) {
         copy_filled_block<DIM>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
@@ -610,36 +594,19 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
     /* one atomic per 1024 tiles: same-address atomics serialise at ~12 ns each on this part, and the
      * last stage of a 1024^3 frame has 1.3 M tiles.  Waves keep their order inside the block, so
      * the survivors of one sibling group (= one wave) stay contiguous. */
-    __shared__ int wave_count[3][16], wave_base[3][16];
+    __shared__ int wave_count[16], wave_base[16];
     const int wave = threadIdx.x >> 6;
-    /* Last stage, float pass in pairs (kernels_voxel_pair_asm.hip): survivors of one sibling group
-     * (= this wave) that still carry the group's common tape — the smallest tape index among them;
-     * a tile's own shortened tape is always allocated later — are paired up; everything else, and
-     * the odd one out, goes to the single-tile list. */
-    uint64_t shared = 0;
-    if (LAST && pairs) {
-        int t = active ? n.tape : 0x7FFFFFFF;
-        for (int off = 32; off > 0; off >>= 1) t = min(t, __shfl_xor(t, off));
-        shared = ballot(active && n.tape == t);
-        if (__popcll(shared) & 1) shared &= ~(1ull << (63 - __builtin_clzll(shared)));   /* keep an even number */
-    }
-    const uint64_t single_mask = mask & ~shared;
-    if (lane == 0) {
-        wave_count[0][wave] = __popcll(mask);
-        wave_count[1][wave] = __popcll(single_mask);
-        wave_count[2][wave] = __popcll(shared) / 2;
-    }
+    if (lane == 0) wave_count[wave] = __popcll(mask);
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const int k = threadIdx.x;
+    if (threadIdx.x == 0) {
         int total = 0;
         const int nw = (blockDim.x + 63) >> 6;
         for (int w = 0; w < nw; ++w) {
-            wave_base[k][w] = total;
-            total += wave_count[k][w];
+            wave_base[w] = total;
+            total += wave_count[w];
         }
-        const int b0 = total ? atomicAdd(num_active + k, total) : 0;
-        for (int w = 0; w < nw; ++w) wave_base[k][w] += b0;
+        const int b0 = total ? atomicAdd(num_active, total) : 0;
+        for (int w = 0; w < nw; ++w) wave_base[w] += b0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -650,13 +617,11 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
          * workgroup of a large grid issues one. */
         if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
             const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int n1 = __hip_atomic_exchange(num_active + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int n2 = __hip_atomic_exchange(num_active + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish_counts(pub, seq, n0, n1, n2, num_active + 4);
+            publish_counts(pub, seq, n0, 0, 0, num_active + 4);
         }
     }
-    const int base = wave_base[0][wave];
+    const int base = wave_base[wave];
     const int next = active ? base + rank_in(mask, lane) : -1;
     if (valid) tiles[gidx].next = LAST ? -1 : next;   /* copy_active_tiles resets next (:650) */
     if (LAST) {
@@ -666,16 +631,6 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
             o.tape = n.tape;
             o.next = -1;
             out[next] = o;
-            if (pairs) {
-                if ((shared >> lane) & 1) {
-                    const int r = rank_in(shared, lane);
-                    int* const item = reinterpret_cast<int*>(&pairs[wave_base[2][wave] + r / 2]);
-                    item[r & 1] = n.position;
-                    if ((r & 1) == 0) { item[2] = n.tape; item[3] = 0; }
-                } else {
-                    singles[wave_base[1][wave] + rank_in(single_mask, lane)] = o;
-                }
-            }
         }
         return;
     }
@@ -1047,7 +1002,7 @@ static CopyFilled copy_filled_args(const int* prev, int* next, int size, int fir
     return cf;
 }
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
-                              const int* image, int* num_active, mpr_tile_node* out, mpr_tile_node* singles, int4* pairs,
+                              const int* image, int* num_active, mpr_tile_node* out,
                               int* pub, int seq, int* next_image, int next_size)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
@@ -1055,11 +1010,11 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb + extra), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, singles, pairs, pub, seq, cf);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }

@@ -20,18 +20,6 @@ enum {
     CNT_COUNT
 };
 
-/* Per sibling group (64 consecutive entries of a tile list = the children of one tile) of the
- * LAST tile stage: what the float pass needs to evaluate any child without its own sub-tape:
- * the tape the group walked and where the group's min/max decisions were stored
- * (choice_masks[mask_off + i] = {lanes that chose lhs, lanes that chose rhs} for the i-th
- * min/max clause of that tape). */
-struct GroupInfo {
-    int tape;
-    int mask_off;
-    int nchoices;
-    int pad;
-};
-
 struct TileStageArgs {
     const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
     uint64_t* tape_wr;         /* same pool, write side (freshly claimed chunks) */
@@ -46,8 +34,6 @@ struct TileStageArgs {
     float z;                   /* 2-D: constant Z */
     float mat[16];             /* column-major 4x4 (3-D) or 3x3 (2-D, first 9) */
     unsigned long long* counters;
-    GroupInfo* groups;         /* last tile stage only (else null): per-group record ...      */
-    ulonglong2* choice_masks;  /* ... and choice masks, choice_cap entries per group          */
     int debug;                 /* development only (MPR_DEBUG_TILES): 1 = skip tape pushing, 2 = skip the arithmetic */
     float* heat;               /* heatmap frames (render*_heatmap): S x S amortised work per pixel, else null */
     int heat_stride;           /* = image size in pixels */
@@ -79,33 +65,6 @@ struct VoxelArgs {
     float* heat;               /* heatmap frames: S x S work per pixel, else null */
 };
 
-/* float pass over pairs of smallest tiles that share a tape (kernels_voxel_pair_asm.hip) */
-struct PairVoxelArgs {
-    const uint64_t* tape_ro;
-    int* image;
-    int tps;                   /* smallest tiles per side */
-    const int4* pairs;         /* {position 0, position 1, tape, -} */
-    int count;
-    int nslots;                /* <= 128 */
-    float mat[16];
-};
-
-/* float pass over sibling groups: K children of one group at a time walk the group's tape */
-struct GroupedVoxelArgs {
-    const uint64_t* tape_ro;
-    int* image;
-    int tps;
-    const mpr_tile_node* tiles;      /* the last tile stage's list (after its evaluation) */
-    int ngroups;
-    int nslots;
-    int choice_cap;
-    float z;
-    float mat[16];
-    const GroupInfo* groups;
-    const ulonglong2* choice_masks;
-    unsigned long long* counters;
-};
-
 struct NormalArgs {
     const uint64_t* tape_ro;
     const int* image;
@@ -134,19 +93,14 @@ bool wide_stage_fits(int nclauses);
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
-                              mpr_tile_node* singles, int4* pairs, int* pub, int seq, int* next_image, int next_size);
-/* num_active points at three counters: survivors, and (last stage with pairing) single tiles and pairs */
+                              int* pub, int seq, int* next_image, int next_size);
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
 /* same pass, interpreter in gfx950 assembly (kernels_voxel_asm.hip); no counters */
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
 
-void launch_eval_voxel_pairs_asm(hipStream_t s, const PairVoxelArgs& a);
-void launch_test_float_pair_asm(hipStream_t s, const uint64_t* tape, int n, const float* a, const float* b, float* out);
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
-size_t grouped_voxel_lds_bytes(int nslots, int k);
-void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a);   /* k = 1, 2 or 4 children per batch */
 size_t normals_lds_bytes(int nslots);
 void launch_eval_normals(hipStream_t s, const NormalArgs& a);
 void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a);   /* kernels_normals_asm.hip; no counters */

@@ -162,235 +162,6 @@ k_eval_voxels(VoxelArgs a)
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* float pass, grouped form.  The smallest tiles that survive are the children of the    */
-/* last tile stage's groups; a child's shortened tape is its group's tape with the       */
-/* child's min/max decisions applied, and clauses the shortening dropped can be          */
-/* evaluated harmlessly (their output slot is dead for that child).  So K = 4 children   */
-/* walk the GROUP's tape together: one clause fetch + decode per 256 voxels, the slot    */
-/* file is float4 per lane (ds_read_b128 / ds_write_b128, conflict-free), and a min/max  */
-/* clause resolves per child from the stored choice masks (wave-uniform per child).      */
-/* Bit-identical to walking each child's own sub-tape (k_eval_voxels).                   */
-/* Clauses are fetched 64 at a time with one coalesced 512-byte load (lane j holds        */
-/* clause j) and handed out with v_readlane.                                             */
-/* ------------------------------------------------------------------------------------ */
-/* K floats per lane as one LDS vector (K = 1, 2, 4 -> ds_read_b32 / b64 / b128) */
-template <int K> struct VecK;
-template <> struct VecK<1> { typedef float type; };
-template <> struct VecK<2> { typedef float2 type; };
-template <> struct VecK<4> { typedef float4 type; };
-template <int K> struct Pack {
-    float v[K];
-    DEV void load(const typename VecK<K>::type* p)
-    {
-        const typename VecK<K>::type t = *p;
-        __builtin_memcpy(v, &t, sizeof(t));
-    }
-    DEV void store(typename VecK<K>::type* p) const
-    {
-        typename VecK<K>::type t;
-        __builtin_memcpy(&t, v, sizeof(t));
-        *p = t;
-    }
-    DEV void splat(float f)
-    {
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = f;
-    }
-};
-
-template <int DIM, int K>
-__global__ void __launch_bounds__(64)
-k_eval_voxels_grouped(GroupedVoxelArgs a)
-{
-    typedef typename VecK<K>::type vec_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    vec_t* const slots = reinterpret_cast<vec_t*>(smem);            /* [nslots][64], K floats per lane */
-    const int lane = threadIdx.x;
-    const int g = blockIdx.x;
-    const mpr_tile_node nd = a.tiles[(size_t)g * 64 + lane];
-    uint64_t amask = ballot(nd.position != -1);
-    if (amask == 0) return;
-
-    const uint64_t* __restrict__ const tro = a.tape_ro;
-    const int tape = __builtin_amdgcn_readfirstlane(a.groups[g].tape);
-    const int nchoices = __builtin_amdgcn_readfirstlane(a.groups[g].nchoices);
-    const ulonglong2* __restrict__ const masks = a.choice_masks + (size_t)g * a.choice_cap;
-    const uint64_t head0 = tro[0];
-    const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
-
-    constexpr int SUB = (DIM == 3) ? 4 : 8;
-    const int S = a.tps * SUB;
-    const int4_ sub = unpack(lane, SUB);
-    const float size_recip = 1.0f / (float)(unsigned)S;
-    vec_t* const myslot = slots + lane;                  /* slot s of this lane: myslot[s * 64] */
-    long long words_total = 0, lane_clauses = 0;
-
-    while (amask) {
-        int c[K];
-        bool valid[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            valid[k] = amask != 0;
-            if (valid[k]) {
-                c[k] = __ffsll((long long)amask) - 1;
-                amask &= amask - 1;
-            } else {
-                c[k] = c[k - 1 < 0 ? 0 : k - 1];
-            }
-        }
-        int px[K], py[K], pz[K];
-        bool skip[K];
-        Pack<K> vx, vy, vz;
-        bool all_skip = true;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int4_ pos = unpack(__builtin_amdgcn_readlane(nd.position, c[k]), a.tps);
-            px[k] = pos.x * SUB + sub.x;
-            py[k] = pos.y * SUB + sub.y;
-            pz[k] = (DIM == 3) ? pos.z * 4 + sub.z : 0;
-            skip[k] = !valid[k];
-            if (DIM == 3) {
-                const int pz_low = pos.z * 4 + (sub.z & 1);      /* reference :852-864 */
-                skip[k] = skip[k] || (a.image[px[k] + py[k] * S] >= pz_low + 2);
-            }
-            all_skip = all_skip && skip[k];
-            const float fx = ((px[k] + 0.5f) * size_recip - 0.5f) * 2.0f;
-            const float fy = ((py[k] + 0.5f) * size_recip - 0.5f) * 2.0f;
-            if (DIM == 3) {
-                const float fz = ((pz[k] + 0.5f) * size_recip - 0.5f) * 2.0f;
-                const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
-                vx.v[k] = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
-                vy.v[k] = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
-                vz.v[k] = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
-            } else {
-                const float fw = a.mat[2] * fx + a.mat[5] * fy + a.mat[8];
-                vx.v[k] = (a.mat[0] * fx + a.mat[3] * fy + a.mat[6]) / fw;
-                vy.v[k] = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
-                vz.v[k] = a.z;
-            }
-        }
-        if (ballot(!all_skip) == 0) continue;
-
-        vx.store(&myslot[sx * 64]);
-        vy.store(&myslot[sy * 64]);
-        vz.store(&myslot[sz * 64]);
-
-        int base = tape + 1;                 /* pool index of the block's first word */
-        uint64_t blk = tro[base + lane];
-        int j = 0, ci = 0, words = 0, ncl = 0;
-        uint32_t dlo = 0, dhi = 0;
-        for (;;) {
-            if (j == 64) {
-                base += 64;
-                blk = tro[base + lane];
-                j = 0;
-            }
-            dlo = rdlane((uint32_t)blk, j);
-            dhi = rdlane((uint32_t)(blk >> 32), j);
-            ++words;
-            const uint32_t op = dlo & 0xFF;
-            if (op < 2) {
-                if (op == 0) break;
-                base = base + j + (int32_t)dhi + 1;      /* JUMP: relative to the JUMP word, then pre-increment */
-                blk = tro[base + lane];
-                j = 0;
-                continue;
-            }
-            ++j;
-            ++ncl;
-            const uint32_t o = (dlo >> 8) & 0xFF, l = (dlo >> 16) & 0xFF, r = dlo >> 24;
-            const float imm = mpr_u2f(dhi);
-            Pack<K> A, B, out;
-            A.load(&myslot[l * 64]);
-            B.load(&myslot[r * 64]);        /* slot 0 when the clause has no rhs: both reads in flight together */
-            if (op >= MPR_OP_ADD_LHS_IMM) {
-                if (r == 0) B.splat(imm);
-                if (op <= MPR_OP_MUL_LHS_RHS) {
-                    if (op <= MPR_OP_ADD_LHS_RHS) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] + B.v[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] * B.v[k];
-                    }
-                } else if (op <= MPR_OP_MAX_LHS_RHS) {
-                    /* min / max: the child's recorded decision replaces the operation */
-                    uint64_t m1 = 0, m2 = 0;
-                    if (ci < nchoices) {
-                        const ulonglong2 m = masks[ci];
-                        m1 = m.x;
-                        m2 = m.y;
-                    }
-                    ++ci;
-                    const bool is_min = op <= MPR_OP_MIN_LHS_RHS;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const float mm = is_min ? mpr_fminf(A.v[k], B.v[k]) : mpr_fmaxf(A.v[k], B.v[k]);
-                        out.v[k] = ((m1 >> c[k]) & 1) ? A.v[k] : (((m2 >> c[k]) & 1) ? B.v[k] : mm);
-                    }
-                } else if (op <= MPR_OP_DIV_LHS_RHS) {
-                    /* SUB / DIV: B is already the immediate in the LHS_IMM form (r == 0) */
-                    if (op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_DIV_IMM_RHS) A.splat(imm);
-                    if (op <= MPR_OP_SUB_LHS_RHS) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] - B.v[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) out.v[k] = A.v[k] / B.v[k];
-                    }
-                } else {
-                    out = (op == MPR_OP_COPY_LHS) ? A : B;     /* COPY_IMM: r == 0, B is the immediate */
-                }
-            } else if (op == MPR_OP_SQUARE_LHS) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) out.v[k] = A.v[k] * A.v[k];
-            } else if (op == MPR_OP_NEG_LHS) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) out.v[k] = -A.v[k];
-            } else if (op == MPR_OP_SQRT_LHS) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) out.v[k] = __builtin_sqrtf(A.v[k]);
-            } else if (op == MPR_OP_ABS_LHS) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) out.v[k] = __builtin_fabsf(A.v[k]);
-            } else {
-#pragma unroll 1
-                for (int k = 0; k < K; ++k) out.v[k] = rare_unary(op, A.v[k]);
-            }
-            out.store(&myslot[o * 64]);
-        }
-        const uint32_t i_out = (dlo >> 8) & 0xFF;
-        Pack<K> res;
-        res.load(&myslot[i_out * 64]);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (DIM == 3) {
-                /* the four lanes lane&15 share an (x, y): keep the tallest filled voxel */
-                int zv = (!skip[k] && res.v[k] < 0.0f) ? pz[k] : -1;
-                zv = max(zv, __shfl_xor(zv, 16));
-                zv = max(zv, __shfl_xor(zv, 32));
-                if (valid[k] && lane < 16 && zv >= 0) {
-                    int* p = &a.image[px[k] + py[k] * S];
-                    if (*p < zv) atomicMax(p, zv);
-                }
-            } else if (!skip[k] && res.v[k] < 0.0f) {
-                a.image[px[k] + py[k] * S] = 1;
-            }
-        }
-        words_total += words;
-        int nvalid = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) nvalid += valid[k] ? 1 : 0;
-        lane_clauses += (long long)ncl * 64 * nvalid;
-    }
-    if (a.counters && lane == 0) {
-        atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
-        atomicAdd((unsigned long long*)&a.counters[CNT_FWD_VOX], (unsigned long long)words_total);
-        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
-    }
-}
-
-/* ------------------------------------------------------------------------------------ */
 /* eval_pixels_d, quad layout.  A Deriv is four floats (dx, dy, dz, v); instead of giving   */
 /* each lane a whole Deriv (16-byte slots, an 8x8 patch per wave, up to a dozen different   */
 /* tapes per patch) a pixel is spread over FOUR lanes, one component each: a wave is the    */
@@ -601,8 +372,6 @@ static void opt_in_once()
     allow_big_lds(k_eval_voxels<2>);
     allow_big_lds(k_eval_voxels<3>);
     allow_big_lds(k_eval_normals_q);
-    allow_big_lds(k_eval_voxels_grouped<2, 4>);
-    allow_big_lds(k_eval_voxels_grouped<3, 4>);
 }
 size_t voxel_lds_bytes(int nslots) { return (size_t)nslots * 256 * 4; }
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a)
@@ -613,23 +382,6 @@ void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a)
     const size_t lds = voxel_lds_bytes(a.nslots);
     if (dim == 3) hipLaunchKernelGGL(k_eval_voxels<3>, g, b, lds, s, a);
     else hipLaunchKernelGGL(k_eval_voxels<2>, g, b, lds, s, a);
-}
-size_t grouped_voxel_lds_bytes(int nslots, int k) { return (size_t)nslots * 256 * k; }
-void launch_eval_voxels_grouped(hipStream_t s, int dim, int k, const GroupedVoxelArgs& a)
-{
-    if (a.ngroups <= 0) return;
-    opt_in_once();
-    const size_t lds = grouped_voxel_lds_bytes(a.nslots, k);
-    const dim3 g(a.ngroups), b(64);
-    if (dim == 3) {
-        if (k == 1) hipLaunchKernelGGL((k_eval_voxels_grouped<3, 1>), g, b, lds, s, a);
-        else if (k == 2) hipLaunchKernelGGL((k_eval_voxels_grouped<3, 2>), g, b, lds, s, a);
-        else hipLaunchKernelGGL((k_eval_voxels_grouped<3, 4>), g, b, lds, s, a);
-    } else {
-        if (k == 1) hipLaunchKernelGGL((k_eval_voxels_grouped<2, 1>), g, b, lds, s, a);
-        else if (k == 2) hipLaunchKernelGGL((k_eval_voxels_grouped<2, 2>), g, b, lds, s, a);
-        else hipLaunchKernelGGL((k_eval_voxels_grouped<2, 4>), g, b, lds, s, a);
-    }
 }
 size_t normals_lds_bytes(int nslots) { return (size_t)nslots * 1024; }   /* 4 waves x nslots x 64 lanes x 4 B */
 void launch_eval_normals(hipStream_t s, const NormalArgs& a)

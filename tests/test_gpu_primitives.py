@@ -89,9 +89,9 @@ def test_float_ops_bit_exact(mpr, orc, opname, kind):
 @pytest.mark.parametrize("opname", INTERVAL_OPS)
 def test_float_ops_assembly_interpreter_bit_exact(mpr, orc, opname, kind, variant):
     """Every opcode through the float pass's assembly interpreter (short tapes): same bits as the
-    oracle, including NaN / inf / subnormal / signed-zero operands, in all three handler tables
-    (operands from the slot file; lhs forwarded; rhs forwarded) of the single-tile interpreter
-    (variants 0..2) and of the two-tiles-per-wave one with packed FP32 arithmetic (3..5)."""
+    oracle, including NaN / inf / subnormal / signed-zero operands, in all six handler tables:
+    operands from the slot file / lhs forwarded / rhs forwarded (variants 0..2), and the same three
+    for a clause whose result dies in the next clause (3..5: neither stored nor addressed)."""
     op = mpr.OP[opname]
     rng = np.random.default_rng(zlib.crc32((opname + kind + "f").encode()))
     a = gen_floats(rng, N, kind)

@@ -226,28 +226,6 @@ def test_planned_gather_through_the_renderer(mpr, tapes):
         c.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 4])
-def test_grouped_float_pass_is_bit_identical(mpr, tapes, k, monkeypatch):
-    """MPR_VOXEL_K: the experimental grouped float pass (K children walk the group's tape with
-    the stored choice masks) must give the same image as the per-tile walk."""
-    for name, dim, S in (("hello_world", 2, 256), ("bear", 3, 256), ("architecture", 3, 128)):
-        tape = tapes(name)
-        monkeypatch.setenv("MPR_VOXEL_K", "0")
-        a = mpr.Context(S)
-        monkeypatch.setenv("MPR_VOXEL_K", str(k))
-        b = mpr.Context(S)
-        for ctx in (a, b):
-            if dim == 2:
-                ctx.render2D(tape, view2())
-            else:
-                ctx.render3D(tape, view3())
-        assert np.array_equal(a.image, b.image)
-        if dim == 3:
-            assert np.array_equal(a.normals, b.normals)
-        a.close()
-        b.close()
-
-
 @pytest.mark.parametrize("name,dim,S", [
     ("hello_world", 2, 256), ("prospero", 2, 512), ("involute_gear_2d", 2, 512),
     ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128),
@@ -316,25 +294,6 @@ def test_assembly_normals_pass_matches_compiled_one(mpr, tapes, name, S, monkeyp
     assert np.array_equal(a.image, b.image)
     bad = np.flatnonzero(a.normals.ravel() != b.normals.ravel())
     assert bad.size == 0, (bad.size, [(hex(a.normals.ravel()[i]), hex(b.normals.ravel()[i])) for i in bad[:5]])
-    a.close()
-    b.close()
-
-
-@pytest.mark.parametrize("name,S", [("bear", 256), ("architecture", 256), ("involute_gear_3d", 128), ("trig", 128)])
-def test_paired_float_pass_matches_single_tile_one(mpr, tapes, name, S, monkeypatch):
-    """Sibling tiles that share a tape go through the float pass two at a time (packed FP32,
-    kernels_voxel_pair_asm.hip); MPR_VOXEL_PAIRS=0 sends every tile through the single-tile
-    interpreter.  Same heightmap and normals."""
-    tape = tapes(name)
-    monkeypatch.setenv("MPR_VOXEL_PAIRS", "0")
-    a = mpr.Context(S)
-    monkeypatch.setenv("MPR_VOXEL_PAIRS", "1")
-    b = mpr.Context(S)
-    for ctx in (a, b):
-        ctx.render3D(tape, view3())
-    assert a.image.any()
-    assert np.array_equal(a.image, b.image)
-    assert np.array_equal(a.normals, b.normals)
     a.close()
     b.close()
 
