@@ -8,6 +8,8 @@
  * memory); results are copied out on request.
  */
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -74,6 +76,12 @@ struct mpr_context {
 
     bool normals_asm = true;           /* normals pass interpreter: gfx950 assembly (default) or compiled (MPR_NORMALS_ASM=0) */
     bool voxel_asm = true;             /* float pass interpreter: gfx950 assembly (default) or the compiled C++ one */
+    bool voxel_jit = true;             /* float pass: tapes translated to machine code on the device (kernels_voxel_jit.hip;
+                                          MPR_VOXEL_JIT=0: the assembly interpreter).  Needs executable device memory. */
+    uint32_t* jit_code = nullptr;      /* executable (HSA), one region per wavefront of the float pass */
+    size_t jit_code_bytes = 0;
+    int cus = 0;                       /* compute units of the device */
+    int jit_grid_cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   /* wavefronts the device holds, per dimension and slot class */
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
@@ -116,6 +124,76 @@ static int ensure_tiles(mpr_context* c, int stage, size_t n)
     c->tiles_cap[stage] = cap;
     return MPR_OK;
 }
+
+/* ---- executable device memory (for the float pass's generated code): HIP has no such allocation, the
+ * HSA runtime underneath it has (hsa_amd_memory_pool_allocate + HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG) ---- */
+namespace {
+struct ExecPoolSearch {
+    uint32_t bdf = 0, domain = 0;
+    int ordinal = 0, seen = 0;
+    bool by_bdf = false, found = false;
+    hsa_agent_t agent{};
+    hsa_amd_memory_pool_t pool{};
+    bool have_pool = false;
+};
+hsa_status_t exec_agent_cb(hsa_agent_t a, void* data)
+{
+    auto* q = static_cast<ExecPoolSearch*>(data);
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, dom = 0;
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
+    const bool match = q->by_bdf ? (bdf == q->bdf && dom == q->domain) : (q->seen == q->ordinal);
+    q->seen++;
+    if (match && !q->found) {
+        q->agent = a;
+        q->found = true;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+hsa_status_t exec_pool_cb(hsa_amd_memory_pool_t p, void* data)
+{
+    auto* q = static_cast<ExecPoolSearch*>(data);
+    hsa_amd_segment_t seg;
+    if (hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL)
+        return HSA_STATUS_SUCCESS;
+    uint32_t flags = 0;
+    bool alloc = false;
+    (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    if (alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !q->have_pool) {
+        q->pool = p;
+        q->have_pool = true;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+/* null when the runtime refuses (the caller then keeps the interpreter) */
+void* alloc_executable(int device, size_t bytes)
+{
+    static bool hsa_up = (hsa_init() == HSA_STATUS_SUCCESS);       /* reference counted: HIP has initialised it already */
+    if (!hsa_up) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+    ExecPoolSearch q;
+    q.by_bdf = true;
+    q.bdf = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
+    q.domain = (uint32_t)prop.pciDomainID;
+    (void)hsa_iterate_agents(exec_agent_cb, &q);
+    if (!q.found) {                      /* no PCI match (virtualised box): HIP ordinals follow the order of the GPU agents */
+        q = ExecPoolSearch();
+        q.ordinal = device;
+        (void)hsa_iterate_agents(exec_agent_cb, &q);
+    }
+    if (!q.found) return nullptr;
+    (void)hsa_amd_agent_iterate_memory_pools(q.agent, exec_pool_cb, &q);
+    if (!q.have_pool) return nullptr;
+    void* p = nullptr;
+    if (hsa_amd_memory_pool_allocate(q.pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &p) != HSA_STATUS_SUCCESS) return nullptr;
+    return p;
+}
+void free_executable(void* p) { if (p) (void)hsa_amd_memory_pool_free(p); }
+}  // namespace
 
 template <typename T>
 static int ensure_buffer(T** ptr, size_t* cap, size_t n)
@@ -177,6 +255,11 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->S = S;
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_JIT")) c->voxel_jit = atoi(e) != 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, opt->device) == hipSuccess) c->cus = prop.multiProcessorCount;
+    }
     if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
@@ -258,6 +341,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->arena) (void)hipFree(c->arena);
     if (c->pool) (void)hipFree(c->pool);
     if (c->tape_index) (void)hipFree(c->tape_index);
+    free_executable(c->jit_code);
     if (c->num_active) (void)hipFree(c->num_active);
     if (c->zs_hist) (void)hipFree(c->zs_hist);
     if (c->zs_cursor) (void)hipFree(c->zs_cursor);
@@ -534,7 +618,33 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         v.heat = heat;
         TimedScope ts(c, "eval_voxels_f");
         /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
-        if (c->voxel_asm && !cnt && !heat) mprk::launch_eval_voxels_asm(s, dim, v);
+        bool jitted = false;
+        if (c->voxel_jit && c->voxel_asm && !cnt && !heat && mprk::jit_slot_class(nslots) != 0 && c->cus > 0) {
+            /* every tape of the frame as machine code: a region per wavefront, sized by the root tape's code */
+            const size_t region = ((mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size()) + 64 + 63) / 64) * 64;
+            const int cls = mprk::jit_slot_class(nslots);
+            int& grid = c->jit_grid_cache[dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];
+            if (grid == 0) grid = mprk::jit_grid(dim, nslots, c->cus);
+            const size_t need = (size_t)grid * region * sizeof(uint32_t);
+            if (need <= ((size_t)4 << 30)) {
+                if (need > c->jit_code_bytes) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    free_executable(c->jit_code);
+                    c->jit_code = nullptr;
+                    c->jit_code_bytes = 0;
+                    const size_t want = std::max(need, (size_t)32 << 20);
+                    c->jit_code = static_cast<uint32_t*>(alloc_executable(c->device, want));
+                    if (c->jit_code) c->jit_code_bytes = want;
+                    else c->voxel_jit = false;          /* no executable memory on this system: the interpreter from now on */
+                }
+                if (c->jit_code) {
+                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, grid);
+                    jitted = true;
+                }
+            }
+        }
+        if (jitted) {}
+        else if (c->voxel_asm && !cnt && !heat) mprk::launch_eval_voxels_asm(s, dim, v);
         else mprk::launch_eval_voxels(s, dim, v);
     }
     if (dim == 3) {
@@ -1053,6 +1163,8 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
     /* variant 1 / 2: a copy in front makes lhs / rhs "the previous clause's result" (operand forwarding:
      * handler tables 1 / 2); 3..5: the same three with two negations of the result behind the clause, so that
      * its result "dies in the next clause" (tables 3..5: no store, no address); -(-x) is x bit for bit */
+    const bool jit = variant >= 6;             /* 6..8: variants 0..2 as generated machine code */
+    if (jit) variant -= 6;
     const bool dies = variant >= 3;
     if (dies) variant -= 3;
     const uint32_t lhs = variant == 1 ? 5 : 1, rhs = b ? (variant == 2 ? 5 : 2) : 0;
@@ -1065,6 +1177,20 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
         tape3[5] = mpr_cl_make(0, 4, 0, 0, 0);
     }
     HIP_TRY(hipMemcpy(dt.p, tape3, sizeof(tape3), hipMemcpyHostToDevice));
+    if (jit) {
+        /* the same tape through the translator and the generated code (kernels_voxel_jit.hip) */
+        const uint32_t region = 256;
+        const size_t blocks = ((size_t)n + 63) / 64;
+        uint32_t* code = static_cast<uint32_t*>(alloc_executable(device, blocks * region * sizeof(uint32_t)));
+        if (!code) return mpr::set_error(MPR_ERR_UNSUPPORTED, "no executable device memory");
+        mprk::launch_test_float_jit(nullptr, (const uint64_t*)dt.p, code, region, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
+        const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+        free_executable(code);
+        HIP_TRY(e1);
+        HIP_TRY(e2);
+        HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+        return MPR_OK;
+    }
     mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

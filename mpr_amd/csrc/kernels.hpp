@@ -101,6 +101,14 @@ void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
 
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
+/* same pass, every tape translated to machine code on the device (kernels_voxel_jit.hip); no counters.
+ * code: executable device memory, `grid` regions of region_dwords each */
+size_t jit_code_dwords(const uint64_t* clauses, int n);
+int jit_slot_class(int nslots);                      /* 24 / 40 / 96 / 192, or 0: too many slots for registers */
+int jit_grid(int dim, int nslots, int cus);
+void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int grid);
+void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
+                           const float* b, float* out);
 size_t normals_lds_bytes(int nslots);
 void launch_eval_normals(hipStream_t s, const NormalArgs& a);
 void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a);   /* kernels_normals_asm.hip; no counters */

@@ -84,14 +84,16 @@ def test_float_ops_bit_exact(mpr, orc, opname, kind):
         assert bad.size == 0, (opname, kind, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:5]])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
 @pytest.mark.parametrize("opname", INTERVAL_OPS)
 def test_float_ops_assembly_interpreter_bit_exact(mpr, orc, opname, kind, variant):
     """Every opcode through the float pass's assembly interpreter (short tapes): same bits as the
     oracle, including NaN / inf / subnormal / signed-zero operands, in all six handler tables:
     operands from the slot file / lhs forwarded / rhs forwarded (variants 0..2), and the same three
-    for a clause whose result dies in the next clause (3..5: neither stored nor addressed)."""
+    for a clause whose result dies in the next clause (3..5: neither stored nor addressed); and as
+    machine code generated on the device (kernels_voxel_jit.hip, 6..8: the clause's operands come
+    from the axis registers / from a copy placed in front of it)."""
     op = mpr.OP[opname]
     rng = np.random.default_rng(zlib.crc32((opname + kind + "f").encode()))
     a = gen_floats(rng, N, kind)

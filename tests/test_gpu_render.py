@@ -256,6 +256,40 @@ def test_assembly_float_pass_matches_compiled_one(mpr, tapes, name, dim, S, monk
     b.close()
 
 
+@pytest.mark.parametrize("name,dim,S", [
+    ("hello_world", 2, 256), ("prospero", 2, 512), ("involute_gear_2d", 2, 512), ("trig", 2, 256), ("many_slots", 2, 128),
+    ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128), ("trig", 3, 128), ("many_slots", 3, 128),
+])
+def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name, dim, S, monkeypatch):
+    """By default the float pass translates every tape into gfx950 machine code on the device and runs
+    that (kernels_voxel_jit.hip); MPR_VOXEL_JIT=0 selects the assembly interpreter (slots in LDS).  Same
+    frame, bit for bit, hierarchical and brute force — the latter runs the whole root tape as one piece
+    of generated code."""
+    tape = tapes(name)
+    monkeypatch.setenv("MPR_VOXEL_JIT", "0")
+    a = mpr.Context(S)
+    monkeypatch.setenv("MPR_VOXEL_JIT", "1")
+    b = mpr.Context(S)
+    for ctx in (a, b):
+        if dim == 2:
+            ctx.render2D(tape, view2())
+        else:
+            ctx.render3D(tape, view3())
+    assert a.image.any()
+    assert np.array_equal(a.image, b.image), int((a.image != b.image).sum())
+    if dim == 3:
+        assert np.array_equal(a.normals, b.normals)
+    if dim == 2:
+        a.render2D_brute(tape, view2())
+        b.render2D_brute(tape, view2())
+        assert np.array_equal(a.image, b.image)
+        b.render2D(tape, view2())          # and again through the hierarchy: regions are rewritten tile after tile
+        a.render2D(tape, view2())
+        assert np.array_equal(a.image, b.image)
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("hello_world", 2, 256),
                                         ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128)])
 def test_serial_first_stage_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):

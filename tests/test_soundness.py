@@ -269,10 +269,11 @@ def test_oracle_float_functions_against_mpmath(mpr, orc, opname):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("opname", list(FLOAT_FNS))
 def test_gpu_float_functions_against_mpmath(mpr, opname, variant):
-    """variant -1: the compiled float interpreter; 0..5: the six handler tables of the assembly one."""
+    """variant -1: the compiled float interpreter; 0..5: the six handler tables of the assembly one;
+    6: machine code generated on the device (kernels_voxel_jit.hip)."""
     fn, gen = FLOAT_FNS[opname]
     rng = np.random.default_rng(11)
     x = gen(rng, 100000).astype(np.float32)
