@@ -81,6 +81,8 @@ struct mpr_context {
     uint32_t* jit_code = nullptr;      /* executable (HSA), one region per wavefront of the float pass */
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
+    unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
+    int jit_debug = 0;                 /* MPR_JIT_DEBUG (development): 1 = translate only, 2 = translate once per wavefront */
     int jit_grid_cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   /* wavefronts the device holds, per dimension and slot class */
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
@@ -256,6 +258,11 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_JIT")) c->voxel_jit = atoi(e) != 0;
+    if (const char* e = getenv("MPR_JIT_DEBUG")) c->jit_debug = atoi(e);
+    if (c->jit_debug & 16) {
+        if (hipMalloc((void**)&c->jit_dbg, 64) == hipSuccess) (void)hipMemset(c->jit_dbg, 0, 64);
+        else c->jit_dbg = nullptr;
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, opt->device) == hipSuccess) c->cus = prop.multiProcessorCount;
@@ -342,6 +349,14 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->pool) (void)hipFree(c->pool);
     if (c->tape_index) (void)hipFree(c->tape_index);
     free_executable(c->jit_code);
+    if (c->jit_dbg) {
+        unsigned long long h[8] = {0};
+        if (hipMemcpy(h, c->jit_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[5])
+            fprintf(stderr, "jit float pass, per wavefront and launch: %.0f cycles, %.0f translating (%.1f tapes, %.0f each), %.0f in generated code (%.1f tiles, %.0f each)\n",
+                    (double)h[2] / h[5], (double)h[0] / h[5], (double)h[3] / h[5], h[3] ? (double)h[0] / h[3] : 0.0, (double)h[1] / h[5], (double)h[4] / h[5],
+                    h[4] ? (double)h[1] / h[4] : 0.0);
+        (void)hipFree(c->jit_dbg);
+    }
     if (c->num_active) (void)hipFree(c->num_active);
     if (c->zs_hist) (void)hipFree(c->zs_hist);
     if (c->zs_cursor) (void)hipFree(c->zs_cursor);
@@ -621,7 +636,15 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         bool jitted = false;
         if (c->voxel_jit && c->voxel_asm && !cnt && !heat && mprk::jit_slot_class(nslots) != 0 && c->cus > 0) {
             /* every tape of the frame as machine code: a region per wavefront, sized by the root tape's code */
-            const size_t region = ((mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size()) + 64 + 63) / 64) * 64;
+            /* per wavefront: one code slot (the root tape's code length — the bound for every tape shortened
+             * from it — plus 64 dwords the instruction prefetch may run into) and 320 dwords the translator dumps
+             * into.  (MPR_JIT_DEBUG & 32, development: a ring of slots with one instruction cache invalidate per
+             * trip; it needs MPR_JIT_GAP >= 256 dwords between slots — how far the instruction prefetch runs ahead is
+             * not documented, so the default stays at one slot and an invalidate per translation.) */
+            const size_t gap_dw = getenv("MPR_JIT_GAP") ? (size_t)atoi(getenv("MPR_JIT_GAP")) : 64;   /* development */
+            const size_t slot_dw = ((mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size()) + gap_dw + 63) / 64) * 64;
+            const size_t nslot = std::min<size_t>(16, std::max<size_t>(1, (size_t)32768 / slot_dw));
+            const size_t region = slot_dw * nslot + 320;
             const int cls = mprk::jit_slot_class(nslots);
             int& grid = c->jit_grid_cache[dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];
             if (grid == 0) grid = mprk::jit_grid(dim, nslots, c->cus);
@@ -638,7 +661,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                     else c->voxel_jit = false;          /* no executable memory on this system: the interpreter from now on */
                 }
                 if (c->jit_code) {
-                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, grid);
+                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, (c->jit_debug & 32) ? (int)nslot : 1, grid, c->jit_debug, (int)tape->clauses.size(), (c->jit_debug & 16) ? c->jit_dbg : nullptr);
                     jitted = true;
                 }
             }
@@ -1179,7 +1202,7 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
     HIP_TRY(hipMemcpy(dt.p, tape3, sizeof(tape3), hipMemcpyHostToDevice));
     if (jit) {
         /* the same tape through the translator and the generated code (kernels_voxel_jit.hip) */
-        const uint32_t region = 256;
+        const uint32_t region = 512;
         const size_t blocks = ((size_t)n + 63) / 64;
         uint32_t* code = static_cast<uint32_t*>(alloc_executable(device, blocks * region * sizeof(uint32_t)));
         if (!code) return mpr::set_error(MPR_ERR_UNSUPPORTED, "no executable device memory");

@@ -106,7 +106,8 @@ void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const fl
 size_t jit_code_dwords(const uint64_t* clauses, int n);
 int jit_slot_class(int nslots);                      /* 24 / 40 / 96 / 192, or 0: too many slots for registers */
 int jit_grid(int dim, int nslots, int cus);
-void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int grid);
+void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
+                            int debug, int tape_len, unsigned long long* dbg);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

@@ -29,6 +29,14 @@ VKERNEL(k_exp,  "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_
 VKERNEL(k_rcp,  "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n")
 VKERNEL(k_sqrt, "v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n")
 VKERNEL(k_cnd,  "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n")
+VKERNEL(k_cnd64, "v_cndmask_b32_e64 %0, %0, %4, s[40:41]\n v_cndmask_b32_e64 %1, %1, %4, s[40:41]\n v_cndmask_b32_e64 %2, %2, %4, s[42:43]\n v_cndmask_b32_e64 %3, %3, %4, s[42:43]\n")
+VKERNEL(k_cndind, "v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %4, %5, vcc\n v_cndmask_b32 %2, %5, %4, vcc\n v_cndmask_b32 %3, %5, %4, vcc\n")
+VKERNEL(k_cmpcnd, "v_cmp_gt_f32 vcc, %0, %4\n s_nop 1\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_gt_f32 vcc, %2, %4\n s_nop 1\n v_cndmask_b32 %3, %3, %4, vcc\n")
+VKERNEL(k_addsgpr, "v_add_f32 %0, s40, %0\n v_add_f32 %1, s41, %1\n v_add_f32 %2, s42, %2\n v_add_f32 %3, s43, %3\n")
+VKERNEL(k_addvcc, "v_addc_co_u32 %0, vcc, %0, %4, vcc\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc\n")
+VKERNEL(k_ldexp, "v_ldexp_f32 %0, %0, %4\n v_ldexp_f32 %1, %1, %4\n v_ldexp_f32 %2, %2, %4\n v_ldexp_f32 %3, %3, %4\n")
+VKERNEL(k_divscale, "v_div_scale_f32 %0, vcc, %0, %4, %0\n v_div_scale_f32 %1, vcc, %1, %4, %1\n v_div_fmas_f32 %2, %2, %4, %5\n v_div_fmas_f32 %3, %3, %4, %5\n")
+VKERNEL(k_cvt, "v_cvt_i32_f32 %0, %0\n v_cvt_f32_i32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_f32_i32 %3, %3\n")
 VKERNEL(k_cmp,  "v_cmp_gt_f32 vcc, %0, %4\n v_cmp_gt_f32 vcc, %1, %4\n v_cmp_gt_f32 vcc, %2, %4\n v_cmp_gt_f32 vcc, %3, %4\n")
 VKERNEL(k_lit,  "v_add_f32 %0, 0x40490fdb, %0\n v_add_f32 %1, 0x40490fdb, %1\n v_add_f32 %2, 0x40490fdb, %2\n v_add_f32 %3, 0x40490fdb, %3\n")
 VKERNEL(k_vop3, "v_fma_f32 %0, %0, %4, %0\n v_fma_f32 %1, %1, %4, %1\n v_div_fixup_f32 %2, %2, %4, %5\n v_div_fixup_f32 %3, %3, %4, %5\n")
@@ -121,13 +129,13 @@ int main() {
     std::vector<T> tests = {
         {"v_add_f32", k_add, 64}, {"v_fma_f32", k_fma, 64}, {"v_add dep.chain", k_dep, 64}, {"v_mov_b32", k_mov, 64},
         {"v_perm_b32", k_perm, 64}, {"v_readlane", k_rdln, 64}, {"v_exp_f32", k_exp, 64}, {"v_rcp_f32", k_rcp, 64},
-        {"v_sqrt_f32", k_sqrt, 64}, {"v_cndmask", k_cnd, 64}, {"v_cmp", k_cmp, 64}, {"v_add literal", k_lit, 64},
+        {"v_sqrt_f32", k_sqrt, 64}, {"v_cndmask", k_cnd, 64}, {"v_cndmask e64 sgpr", k_cnd64, 64}, {"v_cndmask independent", k_cndind, 64}, {"v_cmp+nop+cndmask (instr)", k_cmpcnd, 96}, {"v_add sgpr src", k_addsgpr, 64}, {"v_addc vcc", k_addvcc, 64}, {"v_ldexp", k_ldexp, 64}, {"v_div_scale/fmas", k_divscale, 64}, {"v_cvt", k_cvt, 64}, {"v_cmp", k_cmp, 64}, {"v_add literal", k_lit, 64},
         {"vop3 fma/fixup", k_vop3, 64}, {"v_pk_fma_f32", k_pk, 64}, {"v_fma_f64", k_f64, 64},
         {"s_nop", k_snop, 64}, {"v_add+s_nop (instr)", k_addnop, 64}, {"v_add+s_waitcnt (instr)", k_addwait, 64},
         {"s_add_u32", k_salu, 64}, {"s_and/lshr m0", k_m0, 64},
         {"mix 1v:1s (instr)", k_mix11, 64}, {"mix 1v:3s (instr)", k_mix13, 64}, {"mix 3v:1s (instr)", k_mix31, 64},
     };
-    for (int wpc : {4, 8, 16, 32}) {
+    for (int wpc : {8, 32}) {
         dim3 g(cus * wpc / 4), b(256);
         printf("waves/CU %d\n", wpc);
         for (auto& t : tests) {
