@@ -22,7 +22,27 @@
     "v_div_fmas_f32 v38, v38, v39, v41\n" \
     "v_div_fixup_f32 v37, v38, v36, v35\n"
 
+/* Fast path when every lane's operand is a positive normal number >= 2^-96 (one unsigned compare of the bits): no
+ * scaling of tiny operands, no special values: v_sqrt_f32 is within one ulp, the two residuals say on which side. */
 #define MPR_ASM_SQRT_BODY \
+    "v_add_u32 v38, 0xf0800000, v35\n"                 /* bits - 0x0f800000 */ \
+    "v_cmp_gt_u32 vcc, 0x70000000, v38\n"              /* < 0x7f800000 - 0x0f800000: positive, normal, finite, not tiny */ \
+    "s_cmp_eq_u64 vcc, exec\n" \
+    "s_cbranch_scc0 L_sqrtslow_%=\n" \
+    "v_sqrt_f32 v39, v35\n" \
+    "s_nop 0\n" \
+    "v_add_u32 v40, -1, v39\n" \
+    "v_fma_f32 v41, -v40, v39, v35\n" \
+    "v_cmp_ge_f32 s[92:93], 0, v41\n" \
+    "v_add_u32 v41, 1, v39\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v40, v39, v40, s[92:93]\n" \
+    "v_fma_f32 v39, -v41, v39, v35\n" \
+    "v_cmp_lt_f32 s[92:93], 0, v39\n" \
+    "s_nop 1\n" \
+    "v_cndmask_b32 v37, v40, v41, s[92:93]\n" \
+    "s_branch L_sqrtdone_%=\n" \
+    "L_sqrtslow_%=:\n" \
     "v_mul_f32 v38, 0x4f800000, v35\n" \
     "v_cmp_gt_f32 vcc, 0xf800000, v35\n" \
     "s_nop 1\n" \
@@ -43,7 +63,8 @@
     "v_cndmask_b32 v39, v39, v40, vcc\n" \
     "v_cmp_class_f32 vcc, v38, s90\n" \
     "s_nop 1\n" \
-    "v_cndmask_b32 v37, v39, v38, vcc\n"
+    "v_cndmask_b32 v37, v39, v38, vcc\n" \
+    "L_sqrtdone_%=:\n"
 
 #define MPR_ASM_EXP_BODY \
     "v_mul_f32 v38, 0x3fb8aa3b, v35\n" \

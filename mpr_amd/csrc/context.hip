@@ -82,8 +82,17 @@ struct mpr_context {
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
     unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
+    int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     int jit_debug = 0;                 /* MPR_JIT_DEBUG (development): 1 = translate only, 2 = translate once per wavefront */
-    int jit_grid_cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   /* wavefronts the device holds, per dimension and slot class */
+    int jit_grid_cache[2][2][4] = {};  /* workgroups the device holds, per form (tile / group), dimension and slot class */
+    bool voxel_jit_tiles = false;      /* MPR_VOXEL_JIT=2: generated code per smallest tile where the group form is not possible (development;
+                                          slower than the interpreter for short tapes: a translation per tile).  Brute-force frames always use it:
+                                          every tile runs the root tape, translated once per wavefront. */
+    bool voxel_groups = true;          /* float pass in group form when the last tile stage's tapes allow it (MPR_VOXEL_GROUPS=0: never) */
+    mprk::GroupInfo* groups = nullptr; /* per sibling group of the last tile stage (group form) */
+    size_t groups_cap = 0;
+    ulonglong2* choice_masks = nullptr;
+    size_t masks_cap = 0;
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
@@ -257,8 +266,10 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->S = S;
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
-    if (const char* e = getenv("MPR_VOXEL_JIT")) c->voxel_jit = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; }
+    if (const char* e = getenv("MPR_VOXEL_GROUPS")) c->voxel_groups = atoi(e) != 0;
     if (const char* e = getenv("MPR_JIT_DEBUG")) c->jit_debug = atoi(e);
+    if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
     if (c->jit_debug & 16) {
         if (hipMalloc((void**)&c->jit_dbg, 64) == hipSuccess) (void)hipMemset(c->jit_dbg, 0, 64);
         else c->jit_dbg = nullptr;
@@ -349,6 +360,8 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->pool) (void)hipFree(c->pool);
     if (c->tape_index) (void)hipFree(c->tape_index);
     free_executable(c->jit_code);
+    if (c->groups) (void)hipFree(c->groups);
+    if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->jit_dbg) {
         unsigned long long h[8] = {0};
         if (hipMemcpy(h, c->jit_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[5])
@@ -518,6 +531,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
      * them architecture fits two waves per CU in its last tile stage, with the 58 it needs, three */
     int stage_choice_cap = choice_cap;
     const bool dynamic_choices = c->dynamic_choices;
+    bool group_form = false;
+    int group_stage = 0, group_count = 0, group_cap = 1;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
@@ -547,8 +562,26 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         const int tps = S / tile_size_px;
         c->last.tiles_in[si] = count;
 
+        /* float pass in group form: the last tile stage also writes, per group of 64 siblings, the tape it walked and
+         * the tiles' min / max decisions; possible while a tape records at most 64 of them */
+        const int stage_cap = dynamic_choices ? stage_choice_cap : choice_cap;
+        const bool groups_now = last && count > 0 && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
+                                mprk::jit_slot_class(nslots) != 0 && stage_cap <= 64;
+        if (groups_now) {
+            const size_t ng = ((size_t)count + 63) / 64;
+            rc = ensure_buffer(&c->groups, &c->groups_cap, ng);
+            if (rc) return rc;
+            rc = ensure_buffer(&c->choice_masks, &c->masks_cap, ng * (size_t)std::max(stage_cap, 1));
+            if (rc) return rc;
+            group_form = true;
+            group_stage = i;
+            group_count = count;
+            group_cap = std::max(stage_cap, 1);
+        }
         if (count > 0) {
             mprk::TileStageArgs a;
+            a.groups = groups_now ? c->groups : nullptr;
+            a.choice_masks = groups_now ? c->choice_masks : nullptr;
             a.tape_ro = c->pool;
             a.tape_wr = c->pool;
             a.tape_index = c->tape_index;
@@ -635,19 +668,19 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
         bool jitted = false;
         if (c->voxel_jit && c->voxel_asm && !cnt && !heat && mprk::jit_slot_class(nslots) != 0 && c->cus > 0) {
-            /* every tape of the frame as machine code: a region per wavefront, sized by the root tape's code */
-            /* per wavefront: one code slot (the root tape's code length — the bound for every tape shortened
-             * from it — plus 64 dwords the instruction prefetch may run into) and 320 dwords the translator dumps
-             * into.  (MPR_JIT_DEBUG & 32, development: a ring of slots with one instruction cache invalidate per
-             * trip; it needs MPR_JIT_GAP >= 256 dwords between slots — how far the instruction prefetch runs ahead is
-             * not documented, so the default stays at one slot and an invalidate per translation.) */
-            const size_t gap_dw = getenv("MPR_JIT_GAP") ? (size_t)atoi(getenv("MPR_JIT_GAP")) : 64;   /* development */
-            const size_t slot_dw = ((mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size()) + gap_dw + 63) / 64) * 64;
-            const size_t nslot = std::min<size_t>(16, std::max<size_t>(1, (size_t)32768 / slot_dw));
+            /* every tape as machine code.  Tile form: a region per wavefront; group form: one per workgroup.  A region
+             * holds the root tape's code length (the bound for every tape shortened from it) plus 64 dwords the
+             * instruction prefetch may run into, and 320 dwords the translator dumps into. */
+            const bool gf = group_form && !brute;
+            const size_t code_dw = mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size(), gf);
+            /* group form: a ring of slots 4 KB apart (MPR_JIT_GAP, dwords: development), as many as fit 256 KB, at most 16 */
+            const size_t gap_dw = gf ? (c->jit_gap > 0 ? (size_t)c->jit_gap : 1024) : 64;
+            const size_t slot_dw = ((code_dw + gap_dw + 63) / 64) * 64;
+            const size_t nslot = gf ? std::min<size_t>(16, std::max<size_t>(1, (size_t)65536 / slot_dw)) : 1;
             const size_t region = slot_dw * nslot + 320;
             const int cls = mprk::jit_slot_class(nslots);
-            int& grid = c->jit_grid_cache[dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];
-            if (grid == 0) grid = mprk::jit_grid(dim, nslots, c->cus);
+            int& grid = c->jit_grid_cache[gf ? 1 : 0][dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];
+            if (grid == 0) grid = mprk::jit_grid(dim, nslots, c->cus, gf);
             const size_t need = (size_t)grid * region * sizeof(uint32_t);
             if (need <= ((size_t)4 << 30)) {
                 if (need > c->jit_code_bytes) {
@@ -660,8 +693,16 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                     if (c->jit_code) c->jit_code_bytes = want;
                     else c->voxel_jit = false;          /* no executable memory on this system: the interpreter from now on */
                 }
-                if (c->jit_code) {
-                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, (c->jit_debug & 32) ? (int)nslot : 1, grid, c->jit_debug, (int)tape->clauses.size(), (c->jit_debug & 16) ? c->jit_dbg : nullptr);
+                if (c->jit_code && gf) {
+                    mprk::VoxelArgs gv = v;
+                    gv.tiles = c->tiles[group_stage];
+                    gv.count = group_count;
+                    mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)region, (int)slot_dw, (int)nslot, grid, c->jit_debug, (int)tape->clauses.size(), c->groups,
+                                                 c->choice_masks, group_cap, (c->jit_debug & 16) ? c->jit_dbg : nullptr);
+                    jitted = true;
+                } else if (c->jit_code && !group_form && (brute || c->voxel_jit_tiles)) {
+                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, 1, grid, c->jit_debug, (int)tape->clauses.size(), nullptr,
+                                                 nullptr, 0, (c->jit_debug & 16) ? c->jit_dbg : nullptr);
                     jitted = true;
                 }
             }

@@ -296,6 +296,19 @@ k_eval_tiles(TileStageArgs a)
             ambiguous = true;
         }
     }
+    if (a.groups) {
+        /* last tile stage: keep the group's min / max decisions for the float pass, which runs THIS tape for every
+         * surviving child with the child's decisions applied (kernels_voxel_jit.hip, group form) */
+        const int nrec = ci < a.choice_cap ? ci : a.choice_cap;
+        ulonglong2* const dst = a.choice_masks + (size_t)blockIdx.x * a.choice_cap;
+        for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
+        if (lane == 0) {
+            GroupInfo gi;
+            gi.tape = tape;
+            gi.nchoices = nrec;
+            a.groups[blockIdx.x] = gi;
+        }
+    }
     const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1);
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 

@@ -20,6 +20,15 @@ enum {
     CNT_COUNT
 };
 
+/* Per sibling group (64 consecutive entries of a tile list = the children of one tile) of the LAST tile stage: the
+ * tape the group walked, and how many min / max decisions were recorded for it; choice_masks[g * choice_cap + i] =
+ * {tiles that chose lhs, tiles that chose rhs} at the i-th min / max clause of that tape.  The float pass's group
+ * form evaluates a child with its group's tape and its column of these masks (kernels_voxel_jit.hip). */
+struct GroupInfo {
+    int tape;
+    int nchoices;
+};
+
 struct TileStageArgs {
     const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
     uint64_t* tape_wr;         /* same pool, write side (freshly claimed chunks) */
@@ -34,6 +43,8 @@ struct TileStageArgs {
     float z;                   /* 2-D: constant Z */
     float mat[16];             /* column-major 4x4 (3-D) or 3x3 (2-D, first 9) */
     unsigned long long* counters;
+    GroupInfo* groups;         /* last tile stage, float pass in group form (else null): per-group record ...   */
+    ulonglong2* choice_masks;  /* ... and decision masks, choice_cap entries per group                        */
     int debug;                 /* development only (MPR_DEBUG_TILES): 1 = skip tape pushing, 2 = skip the arithmetic */
     float* heat;               /* heatmap frames (render*_heatmap): S x S amortised work per pixel, else null */
     int heat_stride;           /* = image size in pixels */
@@ -103,11 +114,12 @@ void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
 /* same pass, every tape translated to machine code on the device (kernels_voxel_jit.hip); no counters.
  * code: executable device memory, `grid` regions of region_dwords each */
-size_t jit_code_dwords(const uint64_t* clauses, int n);
+size_t jit_code_dwords(const uint64_t* clauses, int n, bool group);
 int jit_slot_class(int nslots);                      /* 24 / 40 / 96 / 192, or 0: too many slots for registers */
-int jit_grid(int dim, int nslots, int cus);
+int jit_grid(int dim, int nslots, int cus, bool group);
+/* groups != null: the group form over the last tile stage's list (a.tiles / a.count), else one wavefront per smallest tile */
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
-                            int debug, int tape_len, unsigned long long* dbg);
+                            int debug, int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, unsigned long long* dbg);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

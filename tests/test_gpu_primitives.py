@@ -98,7 +98,7 @@ def test_float_ops_assembly_interpreter_bit_exact(mpr, orc, opname, kind, varian
     rng = np.random.default_rng(zlib.crc32((opname + kind + "f").encode()))
     a = gen_floats(rng, N, kind)
     b = gen_floats(rng, N, kind)
-    for imm in (0.75, -1.25):
+    for imm in (0.75, -1.25, 0.5, -4.0):          # the last two: division by a power of two is translated to a multiplication (6..8)
         g = mpr.dev_float_op(op, a, b, imm, asm=True, variant=variant)
         o = orc.float_op(op, a, b, imm)
         bad = np.flatnonzero(~same_bits(g, o))

@@ -260,15 +260,18 @@ def test_assembly_float_pass_matches_compiled_one(mpr, tapes, name, dim, S, monk
     ("hello_world", 2, 256), ("prospero", 2, 512), ("involute_gear_2d", 2, 512), ("trig", 2, 256), ("many_slots", 2, 128),
     ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128), ("trig", 3, 128), ("many_slots", 3, 128),
 ])
-def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name, dim, S, monkeypatch):
-    """By default the float pass translates every tape into gfx950 machine code on the device and runs
-    that (kernels_voxel_jit.hip); MPR_VOXEL_JIT=0 selects the assembly interpreter (slots in LDS).  Same
-    frame, bit for bit, hierarchical and brute force — the latter runs the whole root tape as one piece
-    of generated code."""
+@pytest.mark.parametrize("groups", ["1", "0"])
+def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name, dim, S, groups, monkeypatch):
+    """By default the float pass translates tapes into gfx950 machine code on the device and runs that
+    (kernels_voxel_jit.hip): once per group of 64 sibling tiles with the children's min / max decisions
+    applied by selects (group form; MPR_VOXEL_GROUPS=0: once per smallest tile, each with its own tape).
+    MPR_VOXEL_JIT=0 selects the assembly interpreter (slots in LDS).  Same frame, bit for bit,
+    hierarchical and brute force — the latter runs the whole root tape as one piece of generated code."""
     tape = tapes(name)
+    monkeypatch.setenv("MPR_VOXEL_GROUPS", groups)
     monkeypatch.setenv("MPR_VOXEL_JIT", "0")
     a = mpr.Context(S)
-    monkeypatch.setenv("MPR_VOXEL_JIT", "1")
+    monkeypatch.setenv("MPR_VOXEL_JIT", "2")       # 2: generated code per tile wherever the group form is not possible
     b = mpr.Context(S)
     for ctx in (a, b):
         if dim == 2:
