@@ -82,6 +82,7 @@ struct mpr_context {
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
     unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
+    int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     int jit_debug = 0;                 /* MPR_JIT_DEBUG (development): 1 = translate only, 2 = translate once per wavefront */
     int jit_grid_cache[2][2][4] = {};  /* workgroups the device holds, per form (tile / group), dimension and slot class */
@@ -270,6 +271,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_GROUPS")) c->voxel_groups = atoi(e) != 0;
     if (const char* e = getenv("MPR_JIT_DEBUG")) c->jit_debug = atoi(e);
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
+    if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
     if (c->jit_debug & 16) {
         if (hipMalloc((void**)&c->jit_dbg, 64) == hipSuccess) (void)hipMemset(c->jit_dbg, 0, 64);
         else c->jit_dbg = nullptr;
@@ -676,7 +678,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             /* group form: a ring of slots 4 KB apart (MPR_JIT_GAP, dwords: development), as many as fit 256 KB, at most 16 */
             const size_t gap_dw = gf ? (c->jit_gap > 0 ? (size_t)c->jit_gap : 1024) : 64;
             const size_t slot_dw = ((code_dw + gap_dw + 63) / 64) * 64;
-            const size_t nslot = gf ? std::min<size_t>(16, std::max<size_t>(1, (size_t)65536 / slot_dw)) : 1;
+            const size_t nslot = (gf && c->jit_slots != 1) ? std::min<size_t>(c->jit_slots > 0 ? (size_t)c->jit_slots : 16, std::max<size_t>(1, (size_t)65536 / slot_dw)) : 1;
             const size_t region = slot_dw * nslot + 320;
             const int cls = mprk::jit_slot_class(nslots);
             int& grid = c->jit_grid_cache[gf ? 1 : 0][dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];

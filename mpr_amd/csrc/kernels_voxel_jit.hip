@@ -88,7 +88,7 @@ constexpr uint32_t CALL(uint32_t sgpr) { return 0xBE9E1E00u | sgpr; }        /* 
 constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /* s_bitcmp1_b64 s[76:77] / s[78:79], <index> */
 constexpr uint32_t CSELECT = 0x85EA80C1u;                                      /* s_cselect_b64 vcc, -1, 0 */
 constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21;
-constexpr uint32_t S_DIV = 52, S_SQRT = 54, S_EXP = 56, S_LOG = 58, S_SIN = 60, S_COS = 62, S_ASIN = 64, S_ACOS = 66, S_ATAN = 68;
+constexpr uint32_t S_DIVC = 70, S_DIV = 52, S_SQRT = 54, S_EXP = 56, S_LOG = 58, S_SIN = 60, S_COS = 62, S_ASIN = 64, S_ACOS = 66, S_ATAN = 68;
 constexpr uint32_t FLAG_MINMAX = 1, FLAG_CANON = 2;
 
 struct Builder {
@@ -227,6 +227,20 @@ constexpr JitRow row_of(uint32_t op, bool group)
         case MPR_OP_COPY_IMM: return one(MOV(0, LITERAL), O, NONE, NONE, true);
         case MPR_OP_COPY_LHS: return one(MOV(0, VREG), O, NONE, A);
         case MPR_OP_COPY_RHS: return one(MOV(0, VREG), O, NONE, R);
+        case 30: {
+            /* not an opcode: the translator's own row for DIV_LHS_IMM by a constant that is not a power of two
+             * (2^-30 <= |c| <= 2^30): the constant in v36 and its correctly rounded reciprocal in v38 (dword 4 is
+             * replaced by the translator, which computes 1 / c with an IEEE division), then the short routine */
+            Builder b;
+            b.ins(MOV(35, VREG), NONE, NONE, A);
+            b.fixed(MOV(36, LITERAL));
+            b.lit();
+            b.fixed(MOV(38, LITERAL));
+            b.fixed(0);
+            b.fixed(CALL(S_DIVC));
+            b.ins(MOV(0, VREG + 37), O);
+            return b.r;
+        }
         default: return JitRow{};                                       /* end, JUMP, not an opcode: no code */
     }
 }
@@ -253,7 +267,12 @@ __constant__ JitTable d_jit_table[2] = {jt::make_table(false), jt::make_table(tr
 size_t jit_code_dwords(const uint64_t* clauses, int n, bool group)
 {
     size_t d = 3 + 2;                         /* prologue: three axis moves; epilogue: result move, return */
-    for (int i = 0; i < n; ++i) d += h_jit_table[group ? 1 : 0].w[mpr_cl_op(clauses[i]) & 31][0] & 15u;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t op = mpr_cl_op(clauses[i]) & 31;
+        uint32_t w = h_jit_table[group ? 1 : 0].w[op][0] & 15u;
+        if (op == MPR_OP_DIV_LHS_IMM) w = std::max(w, h_jit_table[0].w[30][0] & 15u);        /* may become the translator's row 30 */
+        d += w;
+    }
     return d;
 }
 
@@ -291,6 +310,21 @@ DEV void jit_load_table(uint32_t* lds, int tid, int nthreads, bool group)
     "v_perm_b32 v45, v57, v56, v45\n v_and_b32 v49, v49, v45\n v_add3_u32 v41, v45, v49, v41\n"                         \
     "v_perm_b32 v46, v57, v56, v46\n v_and_b32 v50, v50, v46\n v_add3_u32 v42, v46, v50, v42\n"                         \
     "v_perm_b32 v47, v57, v56, v47\n v_and_b32 v51, v51, v47\n v_add3_u32 v43, v47, v51, v43\n"                         \
+    "ds_write_b32 v52, v43 offset:(" #k0 "+3)*4\n"                                                                      \
+    "ds_write_b32 v52, v42 offset:(" #k0 "+2)*4\n"                                                                      \
+    "ds_write_b32 v52, v41 offset:(" #k0 "+1)*4\n"                                                                      \
+    "ds_write_b32 v52, v40 offset:(" #k0 ")*4\n"
+/* the same for dwords 4..7, with dword 4 of the row-30 lanes (s[70:71]) replaced by the reciprocal in v55 */
+#define JIT_BATCH_PATCH4(off, k0)                                                                                       \
+    "ds_read_b128 v[40:43], v38 offset:" #off "\n"                                                                      \
+    "ds_read_b128 v[44:47], v38 offset:" #off "+16\n"                                                                   \
+    "ds_read_b128 v[48:51], v38 offset:" #off "+32\n"                                                                   \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+    "v_perm_b32 v44, v57, v56, v44\n v_and_b32 v48, v48, v44\n v_add3_u32 v40, v44, v48, v40\n"                         \
+    "v_perm_b32 v45, v57, v56, v45\n v_and_b32 v49, v49, v45\n v_add3_u32 v41, v45, v49, v41\n"                         \
+    "v_perm_b32 v46, v57, v56, v46\n v_and_b32 v50, v50, v46\n v_add3_u32 v42, v46, v50, v42\n"                         \
+    "v_perm_b32 v47, v57, v56, v47\n v_and_b32 v51, v51, v47\n v_add3_u32 v43, v47, v51, v43\n"                         \
+    "v_cndmask_b32 v40, v40, v55, s[70:71]\n"                                                                          \
     "ds_write_b32 v52, v43 offset:(" #k0 "+3)*4\n"                                                                      \
     "ds_write_b32 v52, v42 offset:(" #k0 "+2)*4\n"                                                                      \
     "ds_write_b32 v52, v41 offset:(" #k0 "+1)*4\n"                                                                      \
@@ -360,6 +394,27 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "v_lshl_or_b32 v39, v40, 23, v39\n"                /* +-2^-k */
         "v_cndmask_b32 v35, v35, v39, vcc\n"
         "v_cndmask_b32 v38, v38, 15, vcc\n"                /* MUL_LHS_IMM */
+        /* DIV_LHS_IMM by any other constant with 2^-30 <= |c| <= 2^30: row 30, with 1 / c (IEEE division: correctly
+         * rounded) as a second literal */
+        "v_and_b32 v39, 0x7fffffff, v35\n"
+        "v_add_u32 v39, 0xcf800000, v39\n"                 /* |c| bits - 0x30800000 */
+        "v_cmp_gt_u32 vcc, 0x1e000001, v39\n"              /* <= 0x4e800000 - 0x30800000 */
+        "v_cmp_eq_u32 s[64:65], 24, v38\n"
+        "s_and_b64 s[70:71], vcc, s[64:65]\n"              /* lanes that get row 30 */
+        "v_mov_b32 v54, 1.0\n"
+        "v_div_scale_f32 v39, s[64:65], v35, v35, v54\n"
+        "v_rcp_f32 v40, v39\n"
+        "v_div_scale_f32 v41, vcc, v54, v35, v54\n"
+        "v_fma_f32 v42, -v39, v40, 1.0\n"
+        "v_fmac_f32 v40, v42, v40\n"
+        "v_mul_f32 v42, v41, v40\n"
+        "v_fma_f32 v43, -v39, v42, v41\n"
+        "v_fmac_f32 v42, v43, v40\n"
+        "v_fma_f32 v39, -v39, v42, v41\n"
+        "s_nop 1\n"
+        "v_div_fmas_f32 v39, v39, v40, v42\n"
+        "v_div_fixup_f32 v55, v39, v35, v54\n"             /* 1 / c */
+        "v_cndmask_b32 v38, v38, 30, s[70:71]\n"
         "v_min_u32 v38, 31, v38\n"                         /* anything that is not an opcode: the empty row 31 */
         "v_mul_u32_u24 v38, 160, v38\n"                    /* 160-byte rows */
         "v_add_u32 v38, %[ltab], v38\n"
@@ -417,7 +472,7 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "L_b1_%=:\n"
         "s_cmp_eq_u64 s[68:69], 0\n"
         "s_cbranch_scc1 L_b0_%=\n"
-        JIT_BATCH(16+48, 4)
+        JIT_BATCH_PATCH4(16+48, 4)
         "L_b0_%=:\n"
         JIT_BATCH(16, 0)
         /* what is complete leaves in 16-byte pieces: lane i carries dwords 4 i .. 4 i + 3, 256 + 4 i ..., 512 + 4 i ... */
@@ -487,11 +542,12 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         : [first] "s"(first), [tlo] "s"(tlo), [thi] "s"(thi), [code] "s"(cbase), [ltab] "s"(ltab), [stage] "s"(lstage), [dump] "s"(ldump),
           [lane] "v"((uint32_t)lane), [lane8] "v"(lane8), [lane16] "v"(lane16), [l3] "v"(l3), [trash] "v"(trash_off)
         : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
-          "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
+          "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
           "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
     return used;
 }
 #undef JIT_BATCH
+#undef JIT_BATCH_PATCH4
 
 /* Ask for the tape of a tile to be brought near (into the L2) long before it is translated: a tape is a linked
  * list of 64-word chunks and following it costs one trip to memory per chunk unless the chunks are already in the
@@ -562,8 +618,7 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     JIT_ROUTINE_ADDR(52, 53, "L_div") JIT_ROUTINE_ADDR(54, 55, "L_sqrt") JIT_ROUTINE_ADDR(56, 57, "L_exp")  \
     JIT_ROUTINE_ADDR(58, 59, "L_log") JIT_ROUTINE_ADDR(60, 61, "L_sin") JIT_ROUTINE_ADDR(62, 63, "L_cos")   \
     JIT_LEAF_ADDR(64, 65, "mpr_fj_asin") JIT_LEAF_ADDR(66, 67, "mpr_fj_acos") JIT_LEAF_ADDR(68, 69, "mpr_fj_atan") \
-    "s_mov_b32 s70, 0x80000000\n"                                                                      \
-    "s_mov_b32 s71, 0x7fffffff\n"                                                                      \
+    JIT_ROUTINE_ADDR(70, 71, "L_divc")                                                                 \
     "s_mov_b32 s90, 0x260\n"                            /* class mask of the square root */           \
     "s_mov_b64 s[76:77], %[cl]\n s_mov_b64 s[78:79], %[cr]\n"   /* group form: the child's min / max decisions */ \
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
@@ -571,6 +626,22 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
     "v_mov_b32 %[res], v37\n"                                                                          \
     "s_branch L_end_%=\n"                                                                              \
+    /* v37 = v35 / v36 with v38 = RN(1 / v36) given: when every lane has 2^-60 <= |v35| <= 2^60 (and the translator  \
+     * made sure of 2^-30 <= |v36| <= 2^30) nothing over- or underflows on the way, and q = x y, two rounds of          \
+     * r = x - c q (exact, fused), q += r y end on the correctly rounded quotient — what the general sequence below      \
+     * computes with its own reciprocal; any other operand: that sequence */                                             \
+    "L_divc_%=:\n"                                                                                     \
+    "v_and_b32 v39, 0x7fffffff, v35\n"                                                                 \
+    "v_add_u32 v39, 0xde800000, v39\n"                 /* |x| bits - 0x21800000 */                     \
+    "v_cmp_gt_u32 vcc, 0x3c000001, v39\n"              /* <= 0x5d800000 - 0x21800000 */                \
+    "s_cmp_eq_u64 vcc, exec\n"                                                                         \
+    "s_cbranch_scc0 L_div_%=\n"                                                                        \
+    "v_mul_f32 v37, v35, v38\n"                                                                        \
+    "v_fma_f32 v39, -v36, v37, v35\n"                                                                  \
+    "v_fma_f32 v37, v39, v38, v37\n"                                                                   \
+    "v_fma_f32 v39, -v36, v37, v35\n"                                                                  \
+    "v_fma_f32 v37, v39, v38, v37\n"                                                                   \
+    "s_setpc_b64 s[30:31]\n"                                                                           \
     "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[30:31]\n"                                            \
     "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[30:31]\n"                                          \
     "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[30:31]\n"                                            \

@@ -116,3 +116,28 @@ def test_deriv_ops_bit_exact(mpr, orc, opname, kind):
     o = orc.deriv_op(op, a, b, 0.75)
     bad = np.flatnonzero(~same_bits(g, o).all(axis=1))
     assert bad.size == 0, (opname, kind, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:3]])
+
+
+@pytest.mark.parametrize("imm", [0.9, 0.3, 11.0, 0.8, 5.612245082855225, 30.55555534362793, 0.6, 0.15, 1.5, 3.0, 7.0, 0.1, -0.7,
+                                 1.0000001, 0.99999994, 1.9999999, 3.4028235e38 / 2 ** 98, 2.0 ** -30 * 1.5, 2.0 ** 30 * 1.25,
+                                 1e-12, 1e12, 1.17549435e-38])
+def test_division_by_a_constant_in_generated_code(mpr, orc, imm):
+    """kernels_voxel_jit.hip turns DIV_LHS_IMM by a constant with 2^-30 <= |c| <= 2^30 into q = x * RN(1/c) and two
+    rounds of r = x - c q, q += r * RN(1/c) when every lane's |x| is in [2^-60, 2^60], and falls back to the general
+    division otherwise: the quotient must be the IEEE one for every operand (variant 6 = generated code; the last
+    three constants are outside the range and take the general route)."""
+    op = mpr.OP["DIV_LHS_IMM"]
+    rng = np.random.default_rng(zlib.crc32(repr(imm).encode()))
+    n = 1 << 20
+    cases = [
+        (rng.standard_normal(n) * np.exp2(rng.uniform(-55, 55, n))).astype(np.float32),       # all lanes in range: the short route
+        rng.uniform(-4, 4, n).astype(np.float32),
+        gen_floats(rng, 1 << 16, "wide"), gen_floats(rng, 1 << 16, "special"), gen_floats(rng, 1 << 16, "bits"),
+        # around powers of two, where quotients sit next to rounding boundaries
+        (np.exp2(rng.integers(-20, 20, n)) * (1 + rng.integers(-3, 4, n) * 2.0 ** -23)).astype(np.float32),
+    ]
+    for a in cases:
+        g = mpr.dev_float_op(op, a, a, imm, asm=True, variant=6)
+        o = orc.float_op(op, a, a, imm)
+        bad = np.flatnonzero(~same_bits(g, o))
+        assert bad.size == 0, (imm, bad.size, [(a[i], g[i], o[i]) for i in bad[:5]])
