@@ -11,8 +11,12 @@ With N > 1 the top-level tile columns of the SAME frame are dealt to the N ranks
 image is all-gathered over RCCL (strong scaling; mpr_amd/multigpu.py).
 
 Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant kernel (eval_voxels_f): algorithmic bytes / HIP-event duration vs 8 TB/s
-  cpu_baseline  the CPU oracle (a port, not the reference) on a bounded sample, all host cores
+  roofline      dominant kernel (eval_voxels_f): algorithmic bytes / HIP-event duration vs 8 TB/s; the
+                kernel's VALU / scalar / LDS issue fractions (its real limiter) from the committed
+                counter passes; the frame-level B_alg of SURVEY.md 8(d)
+  cpu_baseline  the CPU oracle (a port, not the reference): all host cores at 512^3 and one core at
+                256^3, warm-up + 3 frames each, beside the GPU's time at the same size; the oracle's
+                frame must equal the GPU's
   also          the reference's other headline config (prospero render2D 1024^2), for which
                 BASELINE.md holds the only published number (V100, 3.856 ms/frame)
 """
@@ -29,6 +33,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 V100_PROSPERO_1024_MS = 3.85596     # BASELINE.md / reference README.md:111
+# issue rates measured on this chip, wave-instructions per clock per CU at the nominal 2.4 GHz
+# (profiles/r02a_issue_rates.txt, scripts/ubench/issue_rates2.hip): v_fma_f32 / v_add_f32 chains, s_add_u32, ds_read_b32
+VALU_RATE, SALU_RATE, LDS_RATE = 1.75, 0.96, 0.48
+ISSUE_CLOCK_HZ, ISSUE_CUS = 2.4e9, 256
 
 
 def view3():
@@ -189,25 +197,60 @@ def main():
     nframes = max(frames_timed[0], 1)
     avg = {k: v / nframes for k, v in kernel_ms.items()}
     vox_ms = avg.get("eval_voxels_f", 0.0)
-    # algorithmic bytes per launch: one 8-byte clause per wave-group
-    # visit + the 12-byte tile record of every smallest tile
+    kname = ctx.float_kernel()
+    # algorithmic bytes per launch: one 8-byte clause per wave-group visit (group = the 64
+    # voxels of one smallest tile) + the 12-byte tile record of every smallest tile
     b_alg = 8 * work["clauses_fwd_voxels"] + 12 * work["voxel_tiles"]      # N > 1: rank 0's columns, rank 0's kernel time
+    # ... and of the whole frame: B_alg = 8(F + R) + 8W + 12(T_in + T_out) + 4(I_w + I_r), SURVEY.md 8(d)
+    t_in = sum(work["tiles_in"]) + work["voxel_tiles"]
+    t_out = 64 * sum(work["tiles_active"][:2]) + work["tiles_active"][2]
+    levels = sum((S // px) ** 2 for px in (64, 16, 4))
+    i_w = 2 * S * S + levels            # heights + normals + the level images
+    i_r = 2 * S * S                     # copy_filled + the normals pass
+    b_frame = 8 * (work["clauses_fwd"] + work["clauses_bwd"]) + 8 * work["clauses_written"] + 12 * (t_in + t_out) + 4 * (i_w + i_r)
     roofline = None
     if vox_ms > 0 and b_alg:
         achieved = b_alg / (vox_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = issue = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if world == 1 and os.path.exists(pmc):         # the counter passes were collected on the full single-GPU frame
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("eval_voxels_f", {}).get("hbm_bytes_per_launch")
+                    summ = json.load(f)
+                rec = summ.get("eval_voxels_f", {})
+                if rec.get("kernel") == kname:          # counters of another kernel say nothing about this one
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_summary.json: " + summ.get("_source", "?") + " (separate rocprofv3 --pmc passes of this command, not this run)"
+                    sq = rec.get("sq")
+                    if sq:
+                        # fractions of the issue rates measured on this chip (profiles/r02a_issue_rates.txt): wave-instructions
+                        # per second = rate per clock per CU x 2.4 GHz x CUs
+                        dur = vox_ms * 1e-3
+                        peak = lambda r: r * ISSUE_CLOCK_HZ * ISSUE_CUS
+                        issue = {"valu_per_launch": sq.get("SQ_INSTS_VALU"), "salu_per_launch": sq.get("SQ_INSTS_SALU"),
+                                 "lds_per_launch": sq.get("SQ_INSTS_LDS"),
+                                 "valu_frac": round(sq.get("SQ_INSTS_VALU", 0) / dur / peak(VALU_RATE), 4),
+                                 "salu_frac": round(sq.get("SQ_INSTS_SALU", 0) / dur / peak(SALU_RATE), 4),
+                                 "lds_frac": round(sq.get("SQ_INSTS_LDS", 0) / dur / peak(LDS_RATE), 4),
+                                 "rates_per_clk_per_cu": {"valu": VALU_RATE, "salu": SALU_RATE, "lds": LDS_RATE},
+                                 "clock_ghz": ISSUE_CLOCK_HZ / 1e9, "cus": ISSUE_CUS,
+                                 "busy_cu_clock_ghz": round(sq.get("SQ_BUSY_CU_CYCLES", 0) / ISSUE_CUS / dur / 1e9, 3) if sq.get("SQ_BUSY_CU_CYCLES") else None,
+                                 "source": traffic_source}
             except Exception:
-                traffic = None
-        roofline = {"kernel": "k_eval_voxels_asm<3>" + (" (rank 0 of %d)" % world if world > 1 else ""), "bound": "hbm",
+                traffic = traffic_source = issue = None
+        frame_s = ms_per_step * 1e-3
+        roofline = {"kernel": kname + (" (rank 0 of %d)" % world if world > 1 else ""), "bound": "hbm",
                     "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "algorithmic_bytes": int(b_alg), "kernel_ms": round(vox_ms, 4),
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes": int(b_alg), "kernel_ms": round(vox_ms, 4),
+                    "limiter": "valu issue (see issue.valu_frac)" if issue else "valu issue",
+                    "issue": issue,
                     "kernel_ms_all": {k: round(v, 4) for k, v in avg.items()},
+                    "frame": {"algorithmic_bytes": int(b_frame), "achieved": round(b_frame / frame_s / 1e9, 2),
+                              "frac": round(b_frame / frame_s / 1e9 / HBM_PEAK_GBS, 5),
+                              "terms": {"F": int(work["clauses_fwd"]), "R": int(work["clauses_bwd"]), "W": int(work["clauses_written"]),
+                                        "T_in": int(t_in), "T_out": int(t_out), "I_w": int(i_w), "I_r": int(i_r)}},
                     "lane_clauses_per_frame": int(work["lane_clauses"])}
 
     out = None
@@ -248,19 +291,45 @@ def main():
                         "unit": "Mpixel/s", "vs_baseline": round(V100_PROSPERO_1024_MS / pm, 3),
                         "baseline": "3.85596 ms/frame on 1x V100 (reference README.md:111)"}]
 
-    # ---- CPU baseline: the oracle (a port of the algorithm, NOT libfive's renderer) ----
+    # ---- CPU baseline: the oracle (a port of the algorithm, NOT libfive's renderer), as the checker of two
+    #      smaller frames of the same model and as the timed CPU leg: one core, and all cores ----
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import orc
-        cs = 512 if S >= 512 else S
-        cores = os.cpu_count() or 1
         orc.lib()
-        t1 = time.perf_counter()
-        orc.Frame(tape.data, 3, cs, m.colmajor(T, 4), threads=cores, keep_pool=False)
-        cpu_s = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(cs * cs / cpu_s / 1e6, 4), "unit": "Mpixel/s", "cores": cores,
-                               "kind": "port", "ms_per_frame": round(cpu_s * 1e3, 1),
-                               "sample": "%s.frep render3D at %d^3 (1/%d of the voxels of the GPU workload), one frame, "
-                                         "oracle/mpr_oracle.c with OpenMP over tile groups" % (args.model, cs, (S // cs) ** 3)}
+        cores = os.cpu_count() or 1
+        legs = []
+        for cs, threads_list, frames in ((min(S, 256), [1], 3), (min(S, 512), sorted({cores, min(cores, 32)}), 3)):
+            gctx = m.Context(cs, device=local_rank)
+            _, gper = time_frames(lambda: gctx.render3D(tape, T), 5, 20, lambda: None, sync)
+            gpu_ms, _ = stats(gper)
+            gimg, gnrm = gctx.image.copy(), gctx.normals.copy()
+            gctx.close()
+            # warm-up frame per thread count (also picks the better count when there are two), then `frames` timed ones
+            best = None
+            for th in threads_list:
+                t1 = time.perf_counter()
+                fr = orc.Frame(tape.data, 3, cs, m.colmajor(T, 4), threads=th, keep_pool=False)
+                dt = time.perf_counter() - t1
+                if best is None or dt < best[1]:
+                    best = (th, dt)
+            same = bool(np.array_equal(fr.filled[3], gimg) and np.array_equal(fr.normals, gnrm))
+            th = best[0]
+            per_cpu = []
+            for _ in range(frames):
+                t1 = time.perf_counter()
+                orc.Frame(tape.data, 3, cs, m.colmajor(T, 4), threads=th, keep_pool=False)
+                per_cpu.append((time.perf_counter() - t1) * 1e3)
+            cm, csd = stats(per_cpu)
+            legs.append({"value": round(cs * cs / (cm * 1e-3) / 1e6, 4), "unit": "Mpixel/s", "cores": th, "kind": "port",
+                         "ms_per_frame": round(cm, 1), "ms_per_frame_std": round(csd, 1), "frames": frames, "warmup": len(threads_list),
+                         "gpu_ms_per_frame_same_size": round(gpu_ms, 4), "gpu_over_cpu": round(cm / gpu_ms, 1),
+                         "frame_matches_gpu": same,
+                         "sample": "%s.frep render3D at %d^3 (1/%d of the voxels of the GPU workload), oracle/mpr_oracle.c%s" %
+                                   (args.model, cs, (S // cs) ** 3, " with OpenMP over tile groups" if th > 1 else ", one thread")})
+        out["cpu_baseline"] = dict(legs[-1])
+        out["cpu_baseline"]["one_core"] = legs[0]
+        if not all(l["frame_matches_gpu"] for l in legs):
+            raise SystemExit("bench.py: the oracle's frame differs from the GPU's: " + json.dumps(out["cpu_baseline"]))
     ctx.close()
     if rank == 0:
         print(json.dumps(out))

@@ -209,6 +209,12 @@ int mpr_get_counters(mpr_context* ctx, mpr_counters* out);
  * MPR_CTX_TIMING).  names[i] is a static string; returns count in *n (<= cap). */
 int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
 
+/* Name of the kernel the last frame's float pass (eval_voxels_f) ran as, as rocprofv3 prints it without
+ * the namespace: "k_eval_voxels_jit_groups<3, 24>" (generated code, one translation per 64 sibling tiles),
+ * "k_eval_voxels_jit<2, 24>" (generated code per tile), "k_eval_voxels_asm<3>" (assembly interpreter) or
+ * "k_eval_voxels<3>" (C++ interpreter: instrumented frames).  Owned by the context; "" before a frame. */
+const char* mpr_ctx_float_kernel(const mpr_context* ctx);
+
 /* ---- compiled-expression baseline (reference benchmark/dump_tape.cpp + benchmark/brute.cu): the
  *      tape as straight-line HIP source, compiled for the device at run time (hiprtc), evaluated
  *      for every pixel without hierarchy.  Same image as mpr_render2d_brute. ---- */

@@ -158,6 +158,8 @@ def lib():
     L.mpr_ctx_stream.restype = vp
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
+    L.mpr_ctx_float_kernel.argtypes = [vp]
+    L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
     L.mpr_compiled_create.argtypes = [i32, vp, P(vp)]
     L.mpr_compiled_destroy.argtypes = [vp]
@@ -540,6 +542,10 @@ class Context:
         n = ctypes.c_int32()
         _check(lib().mpr_get_timings(self._h, names, ms, cap, ctypes.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def float_kernel(self):
+        """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""
+        return lib().mpr_ctx_float_kernel(self._h).decode()
 
     def dev_filled(self, stage=3):
         return lib().mpr_dev_filled(self._h, stage)

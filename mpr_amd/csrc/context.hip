@@ -82,6 +82,7 @@ struct mpr_context {
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
     unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
+    char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     int jit_debug = 0;                 /* MPR_JIT_DEBUG (development): 1 = translate only, 2 = translate once per wavefront */
@@ -709,9 +710,16 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 }
             }
         }
-        if (jitted) {}
-        else if (c->voxel_asm && !cnt && !heat) mprk::launch_eval_voxels_asm(s, dim, v);
-        else mprk::launch_eval_voxels(s, dim, v);
+        if (jitted) {
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
+                     mprk::jit_slot_class(nslots));
+        } else if (c->voxel_asm && !cnt && !heat) {
+            mprk::launch_eval_voxels_asm(s, dim, v);
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_asm<%d>", dim);
+        } else {
+            mprk::launch_eval_voxels(s, dim, v);
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels<%d>", dim);
+        }
     }
     if (dim == 3) {
         mprk::NormalArgs n;
@@ -1103,6 +1111,8 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
     *out = c->last;
     return MPR_OK;
 }
+
+const char* mpr_ctx_float_kernel(const mpr_context* c) { return c ? c->float_kernel : ""; }
 
 int mpr_get_timings(mpr_context* c, const char** names, float* ms, int32_t cap, int32_t* n)
 {

@@ -2,7 +2,7 @@
 
   profiles/<tag>_bench.json          the bench.py line
   profiles/<tag>_kernel_stats.csv    per-kernel calls / total / average (rocprofv3 --kernel-trace --stats)
-  profiles/pmc_summary.json          HBM bytes per launch of the dominant kernel from the PMC passes
+  profiles/pmc_summary.json          HBM bytes and SQ instruction counts per launch of the frame's kernels from the PMC passes
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE tallies 128-byte
 requests at 64 bytes for wide coalesced reads (MI355X_MICROARCH.md, "HBM"), so both the raw figure
@@ -60,12 +60,27 @@ def per_kernel(sub, counter):
 
 fetch = per_kernel("pmc_fetch", "FETCH_SIZE")
 write = per_kernel("pmc_write", "WRITE_SIZE")
-names = {"eval_voxels_f": "k_eval_voxels_asm<3>", "eval_tiles_i": "k_eval_tiles<3, true>", "eval_tiles_wide": "k_eval_tiles_wide<3>",
-         "eval_pixels_d": "mprk::k_eval_normals_asm"}
+def first(prefixes, table):
+    """the kernel of this run among the forms a pass can take (prefix match on the short name)"""
+    for pre in prefixes:
+        for k in table:
+            if k.startswith(pre):
+                return k
+    return None
+
+
+SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CU_CYCLES", "SQ_WAVES")
+sq = {c: per_kernel("pmc_sq", c) for c in SQ}
+seen = set(fetch) | set(write) | set(sq[SQ[0]])
+names = {"eval_voxels_f": first(("k_eval_voxels_jit_groups<3", "k_eval_voxels_jit<3", "k_eval_voxels_asm<3", "k_eval_voxels<3"), seen),
+         "eval_tiles_i": first(("k_eval_tiles<3, true>",), seen), "eval_tiles_wide": first(("k_eval_tiles_wide<3>",), seen),
+         "eval_pixels_d": first(("mprk::k_eval_normals_asm", "k_eval_normals_asm"), seen)}
 out = {"_note": "KiB counters x1024; read bytes doubled per the gfx950 FETCH_SIZE correction; "
                 "per launch = mean over all launches of that kernel in the run (tile stages: mean over the 3 stages)",
-       "_source": "gpurun_out/%s/pmc_fetch, pmc_write (scripts/profile_round.sh)" % tag}
+       "_source": "scripts/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* of bench.py --steps 20 --warmup 5" % tag}
 for key, kn in names.items():
+    if kn is None:
+        continue
     f = fetch.get(kn)
     w = write.get(kn)
     if not f and not w:
@@ -76,6 +91,9 @@ for key, kn in names.items():
                 "fetch_bytes_raw": fb, "fetch_bytes_corrected": 2 * fb if fb is not None else None,
                 "write_bytes": wb,
                 "hbm_bytes_per_launch": (2 * fb if fb is not None else 0) + (wb or 0)}
+    s = {c: sq[c][kn][0] for c in SQ if kn in sq[c]}
+    if s:
+        out[key]["sq"] = s          # per launch, summed over the chip
 if len(out) > 2:
     with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
