@@ -99,10 +99,17 @@ struct mpr_context {
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
-    size_t sched_recs_cap = 0, sched_levels_cap = 0;
+    uint16_t* sched_prev = nullptr;    /* TapeSchedule::prev_writer */
+    uint32_t* sched_defs = nullptr;    /* TapeSchedule::defs */
+    size_t sched_recs_cap = 0, sched_levels_cap = 0, sched_prev_cap = 0, sched_defs_cap = 0;
     bool sched_ok = false;
     int sched_nlevels = 0, sched_nclauses = 0, sched_root = 0;
     bool wide_stage0 = true;           /* MPR_WIDE_STAGE0=0: first stage with the one-lane-per-tile kernel */
+    int wide_later = -1;               /* MPR_WIDE_LATER: later stages run level-parallel too while they have at most this many
+                                          tiles and the stage before did (0: never; default: two rounds of workgroups on the chip) */
+    int wide_threads = 0;              /* MPR_WIDE_THREADS (development): workgroup size of the level-parallel kernel */
+    uint32_t* wide_bits[2] = {nullptr, nullptr};   /* kernels_wide.hip: inherited-tape tables, ping-pong between stages */
+    size_t wide_bits_cap[2] = {0, 0};
     /* development switches, read once when the context is created (never per frame) */
     bool wide_force = false;           /* MPR_WIDE_FORCE: level-parallel first stage whatever the DAG's shape */
     bool dynamic_choices = true;       /* MPR_DYNAMIC_CHOICES=0: size every stage's choice array by the root tape */
@@ -285,6 +292,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
+    if (const char* e = getenv("MPR_WIDE_LATER")) c->wide_later = atoi(e);
+    if (const char* e = getenv("MPR_WIDE_THREADS")) c->wide_threads = atoi(e);
     if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_TILES")) c->debug_tiles = atoi(e);
     c->debug_choices = getenv("MPR_DEBUG_CHOICES") != nullptr;
@@ -364,6 +373,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->tape_index) (void)hipFree(c->tape_index);
     free_executable(c->jit_code);
     if (c->groups) (void)hipFree(c->groups);
+    for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->jit_dbg) {
         unsigned long long h[8] = {0};
@@ -389,6 +399,8 @@ void mpr_ctx_destroy(mpr_context* c)
     }
     if (c->sched_recs) (void)hipFree(c->sched_recs);
     if (c->sched_levels) (void)hipFree(c->sched_levels);
+    if (c->sched_prev) (void)hipFree(c->sched_prev);
+    if (c->sched_defs) (void)hipFree(c->sched_defs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -436,6 +448,24 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                 HIP_TRY(hipMalloc((void**)&c->sched_levels, lb));
                 c->sched_levels_cap = lb;
             }
+            const size_t pb = sc.prev_writer.size() * sizeof(uint16_t);
+            if (pb > c->sched_prev_cap) {
+                if (c->sched_prev) (void)hipFree(c->sched_prev);
+                c->sched_prev = nullptr;
+                c->sched_prev_cap = 0;
+                HIP_TRY(hipMalloc((void**)&c->sched_prev, pb));
+                c->sched_prev_cap = pb;
+            }
+            HIP_TRY(hipMemcpyAsync(c->sched_prev, sc.prev_writer.data(), pb, hipMemcpyHostToDevice, c->stream));
+            const size_t db = sc.defs.size() * sizeof(uint32_t);
+            if (db > c->sched_defs_cap) {
+                if (c->sched_defs) (void)hipFree(c->sched_defs);
+                c->sched_defs = nullptr;
+                c->sched_defs_cap = 0;
+                HIP_TRY(hipMalloc((void**)&c->sched_defs, db));
+                c->sched_defs_cap = db;
+            }
+            HIP_TRY(hipMemcpyAsync(c->sched_defs, sc.defs.data(), db, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(c->sched_recs, sc.recs.data(), rb, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(c->sched_levels, sc.level_start.data(), lb, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -556,6 +586,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->tiles_n[3] = (size_t)count;
     }
 
+    bool prev_wide = false;
     for (int si = 0; si < nstages; ++si) {
         const int i = stage_list[si];
         const bool last = (si == nstages - 1);
@@ -568,7 +599,19 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         /* float pass in group form: the last tile stage also writes, per group of 64 siblings, the tape it walked and
          * the tiles' min / max decisions; possible while a tape records at most 64 of them */
         const int stage_cap = dynamic_choices ? stage_choice_cap : choice_cap;
-        const bool groups_now = last && count > 0 && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
+        /* level-parallel kernel: the first stage while it has few tiles, later ones while the stage before ran that way */
+        /* ... later ones: a workgroup walks the levels in about the time a wavefront of the serial kernel walks a fifth of the
+         * tape, but only 160 KB / LDS-per-workgroup of them fit a CU: worth it for up to about two rounds of workgroups
+         * (measured: prospero 256^2 0.48 -> 0.20 ms, gears 512^2 0.35 -> 0.11, architecture 256^3 second stage 0.25 -> 0.12;
+         * prospero 512^2 at eight rounds 0.23 -> 0.49) */
+        int wide_limit = c->wide_later;
+        if (wide_limit < 0) {
+            const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, ((size_t)160 << 10) / mprk::wide_stage_lds_bytes(c->sched_nclauses)));
+            wide_limit = 2 * std::max(c->cus, 1) * (int)per_cu;
+        }
+        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 3) &&
+                              (si == 0 ? count <= 8192 : (prev_wide && count <= wide_limit));
+        const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= 64;
         if (groups_now) {
             const size_t ng = ((size_t)count + 63) / 64;
@@ -607,8 +650,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             TimedScope ts(c, "eval_tiles_i");
             /* ... and only while the stage has few tiles (a workgroup per tile is latency-bound at low lane
              * utilisation: with 32768 tiles at 2048^3 the 64-tiles-per-wave walk is 1.5x faster) */
-            if (si == 0 && c->wide_stage0 && c->sched_ok && !heat && !(a.debug & 3) && count <= 8192) {
-                /* first stage: few tiles, all on the root tape -> one workgroup per tile, level by level */
+            if (wide_now) {
+                /* few tiles -> one workgroup per tile, level by level over the root tape's DAG */
                 mprk::WideStageArgs w;
                 w.t = a;
                 w.recs = c->sched_recs;
@@ -616,7 +659,18 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 w.nlevels = c->sched_nlevels;
                 w.nclauses = c->sched_nclauses;
                 w.root_val = c->sched_root;
-                mprk::launch_eval_tiles_wide(s, dim, w);
+                w.root_tape = 0;
+                w.wpt = (c->sched_nclauses + 15) / 16;
+                w.prev_writer = c->sched_prev;
+                w.defs = c->sched_defs;
+                w.bits_in = si == 0 ? nullptr : c->wide_bits[(si - 1) & 1];
+                w.bits_out = nullptr;
+                if (!last && c->wide_later != 0) {          /* the next stage may run this way too */
+                    rc = ensure_buffer(&c->wide_bits[si & 1], &c->wide_bits_cap[si & 1], (size_t)count * (size_t)w.wpt);
+                    if (rc) return rc;
+                    w.bits_out = c->wide_bits[si & 1];
+                }
+                mprk::launch_eval_tiles_wide(s, dim, w, c->wide_threads);
             } else {
                 mprk::launch_eval_tiles(s, dim, a);
             }
@@ -652,6 +706,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->last.tiles_active[si] = active;
         count = last ? active : active * 64;
         c->tiles_n[next] = (size_t)count;
+        prev_wide = wide_now && c->wide_later != 0;
     }
 
     c->last.voxel_tiles = count;

@@ -663,7 +663,9 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
         if (DIM == 3) o.position = (p.x * 4 + sp.x) + (p.y * 4 + sp.y) * sps + (p.z * 4 + sp.z) * sps * sps;
         else o.position = (p.x * 8 + sp.x) + (p.y * 8 + sp.y) * sps;
         o.tape = ptape;
-        o.next = -1;
+        /* until the child's own stage compacts (and overwrites this field with the reference's value): the
+         * parent's index in its list, where kernels_wide.hip finds the table of the tape the child inherits */
+        o.next = gidx - lane + src;
         out[(size_t)pnext * 64 + lane] = o;
     }
 }
@@ -777,7 +779,7 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
         mpr_tile_node o;
         o.position = (p.x * 4 + sp.x) + (p.y * 4 + sp.y) * sps + (p.z * 4 + sp.z) * sps * sps;
         o.tape = ptape;
-        o.next = -1;
+        o.next = gidx - lane + src;             /* see k_compact_subdivide */
         out[(size_t)pnext * 64 + lane] = o;
     }
 }

@@ -61,6 +61,12 @@ struct WideStageArgs {
     int nlevels;
     int nclauses;
     int root_val;              /* value index of the result (0..2 = X, Y, Z; 3 + i = clause i) */
+    int root_tape;             /* pool index of the root tape's head */
+    const uint32_t* bits_in;   /* later stages: two bits per root clause for the tape of every tile of the PREVIOUS stage */
+    uint32_t* bits_out;        /* the same for the tapes this stage leaves (null: nobody will read them) */
+    int wpt;                   /* words per tile in those tables: (nclauses + 15) / 16 */
+    const uint16_t* prev_writer;   /* per clause: the previous clause with the same out slot (0xFFFF: none) */
+    const uint32_t* defs;          /* per clause (tape order): value indices of its operands, pl | pr << 16 */
 };
 
 struct VoxelArgs {
@@ -101,7 +107,8 @@ void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps,
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
 bool wide_stage_fits(int nclauses);
-void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w);
+size_t wide_stage_lds_bytes(int nclauses);
+void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced = 0);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
                               int* pub, int seq, int* next_image, int next_size);

@@ -24,14 +24,35 @@
  *             the copy would be onto itself.
  * The values, choices, tile states and shortened tapes are those of the serial walk; the tests
  * compare both kernels and the oracle (tests/test_gpu_render.py).
+ *
+ * LATER stages (while a stage has few tiles: small images, a rank's share of a multi-GPU frame).  A
+ * shortened tape is a sub-sequence of the root tape with some min / max clauses turned into copies
+ * (:351-458), so a tile of any stage can be evaluated on the ROOT tape's level schedule, given two bits
+ * per root clause for the tape it inherited: 0 not in the tape, 1 in the tape as it is, 2 / 3 decided
+ * for lhs / rhs (a COPY in the tape, or nothing when the copy would be onto itself).  Every ambiguous
+ * tile writes that table for the tape it leaves to its children (bits_out, indexed by the tile) next
+ * to the tape itself in the reference's layout, and its children (which find their parent's index in
+ * the `next` field of their node until their own stage's compaction overwrites it) read it back
+ * (bits_in).  Stage after stage runs like this while the previous stage did; the serial walk, the
+ * float pass and the normals pass read the reference-layout tapes as before.
  */
 #include "kernel_common.hpp"
 
 namespace mprk {
 
-DEV void mark_val(unsigned char* act, uint32_t v)
+/* one byte per clause in LDS: bits 0-1 this tile's own choice, bits 2-3 the inherited state (see the header),
+ * bits 4-5 liveness (1 live, 2 live but not written).  Phases that change different fields are separated by
+ * barriers; concurrent marks of one byte all set the same bit. */
+DEV void mark_val(unsigned char* st, uint32_t v)
 {
-    if (v >= 3) act[v - 3] = 1;
+    if (v >= 3) st[v - 3] |= 0x10;
+}
+DEV int live_of(unsigned char b) { return b >> 4; }
+/* a clause's decision, inherited (bits 2-3: 2 lhs, 3 rhs) or this tile's own (bits 0-1): 0 none, 1 lhs, 2 rhs */
+DEV int total_choice(unsigned char b)
+{
+    const int st = (b >> 2) & 3;
+    return st >= 2 ? st - 1 : (b & 3);
 }
 
 template <int DIM>
@@ -42,9 +63,8 @@ k_eval_tiles_wide(WideStageArgs w)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = w.nclauses;
     float2* const V = reinterpret_cast<float2*>(smem);                                   /* [n + 3] values */
-    unsigned char* const ch = smem + (size_t)(n + 3) * 8;                                /* [n] choice of clause i */
-    unsigned char* const act = ch + n;                                                   /* [n] live flags */
-    int* const sh = reinterpret_cast<int*>(smem + (((size_t)(n + 3) * 8 + 2 * (size_t)n + 15) & ~(size_t)15));   /* [1040] */
+    unsigned char* const ch = smem + (size_t)(n + 3) * 8;                                /* [n] state of clause i (mark_val) */
+    int* const sh = reinterpret_cast<int*>(smem + (((size_t)(n + 3) * 8 + (size_t)n + 15) & ~(size_t)15));   /* [1040] */
     /* sh[0] any choice, sh[1] state (0 dead, 1 ambiguous), sh[2] pool base, sh[3] ok, sh[4] min live-and-dropped i,
      * sh[5] min written i, sh[8..8+1024] scan */
 
@@ -69,15 +89,22 @@ k_eval_tiles_wide(WideStageArgs w)
         sh[1] = alive;
         sh[6] = node.position;
         sh[7] = node.tape;
+        sh[1037] = node.next;                               /* with bits_in: the parent's index in its stage's list */
         sh[4] = 0x7FFFFFFF;
         sh[5] = 0x7FFFFFFF;
         sh[1036] = 0;                                       /* min / max clauses the shortened tape keeps undecided */
     }
-    for (int i = tid; i < n; i += nt) act[i] = 0;
     __syncthreads();
     if (sh[1] == 0) return;
     const int4_ pos = unpack(sh[6], a.tps);
-    const int tape = sh[7];                                 /* the root tape: 0 */
+    const int tape = sh[7];                                 /* the tape the tile inherited (first stage: the root tape) */
+    const int root = w.root_tape;
+    /* ch[i]: bits 0-1 this tile's own choice at clause i, bits 2-3 the inherited state (see the header) */
+    const uint32_t* __restrict__ const inherited = w.bits_in ? w.bits_in + (size_t)sh[1037] * w.wpt : nullptr;
+    for (int i = tid; i < n; i += nt) {
+        const uint32_t st = inherited ? (inherited[i >> 4] >> ((i & 15) * 2)) & 3u : 1u;
+        ch[i] = (unsigned char)(st << 2);
+    }
 
     /* tile corners in round-to-nearest (reference :91-96), then the view transform in round-up mode */
     const float t = (float)a.tps;
@@ -137,15 +164,22 @@ k_eval_tiles_wide(WideStageArgs w)
             const uint32_t op = q.x & 0xFF, r8 = q.x >> 24;
             const uint32_t pl = q.z & 0xFFFF, pr = q.z >> 16, idx = q.w & 0xFFFF, ord = q.w >> 16;
             const float imm = mpr_u2f(q.y);
+            const uint32_t st = (ch[idx] >> 2) & 3;
+            if (st == 0) continue;                                     /* not in this tile's tape */
             const float2 lv2 = V[pl];
             const float2 rv2 = V[pr];
-            int c = 0;
             const ival B = r8 ? iv(rv2.x, rv2.y) : iv(imm, imm);       /* immediate forms carry rhs == 0 */
+            if (st != 1) {                                             /* decided higher up: COPY_LHS / COPY_RHS / COPY_IMM */
+                V[3 + idx] = (st == 2) ? lv2 : make_float2(B.lo, B.hi);
+                continue;
+            }
+            int c = 0;
             const ival out = interval_clause(op, iv(lv2.x, lv2.y), B, imm, c);
             V[3 + idx] = make_float2(out.lo, out.hi);
             /* choices past choice_cap are not recorded by the reference (:257): they still make the
-             * tile push a tape, but the backward pass keeps both sides of such a clause */
-            ch[idx] = (unsigned char)(((int)ord < a.choice_cap) ? c : 0);
+             * tile push a tape, but the backward pass keeps both sides of such a clause.  (A shortened
+             * tape has no more min / max clauses than the stage's cap: context.hip, stage_choice_cap.) */
+            ch[idx] = (unsigned char)((1u << 2) | ((inherited || (int)ord < a.choice_cap) ? c : 0));
             my_choice |= c != 0;
         }
         __syncthreads();
@@ -170,40 +204,99 @@ k_eval_tiles_wide(WideStageArgs w)
             state = 1;
         }
         sh[1] = state;
-        if (a.counters) {
+        if (a.counters && !inherited) {
             atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)n);
             if ((gidx & 63) == 0) atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)(n + 1));
         }
     }
+    if (a.counters && inherited) {                 /* the clauses of the inherited tape (jumps and end not counted) */
+        int mine_in = 0;
+        for (int i = tid; i < n; i += nt) mine_in += ((ch[i] >> 2) & 3) != 0;
+        if (mine_in) {
+            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)mine_in);
+            if ((gidx & 63) == 0) atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)mine_in);
+        }
+    }
     __syncthreads();
+    uint32_t* __restrict__ const leave = w.bits_out ? w.bits_out + (size_t)gidx * w.wpt : nullptr;
     if (!(sh[1] == 1 && sh[0] != 0)) {             /* only ambiguous tiles that chose a side shorten their tape */
-        /* an ambiguous tile that keeps the root tape: the next stage needs room for all of its choices */
+        /* an ambiguous tile that keeps its tape: the next stage needs room for all of its choices */
         if (sh[1] == 1 && tid == 0 && a.next_choices && a.choice_cap > 0) atomicMax(a.next_choices, a.choice_cap);
+        if (sh[1] == 1 && leave) {                 /* ... and its children inherit what it inherited */
+            for (int k = tid; k < w.wpt; k += nt) leave[k] = inherited ? inherited[k] : 0x55555555u;
+        }
         return;
     }
 
-    /* ---- liveness, from the result down the levels (reference :351-458, def-use form) ---- */
-    if (tid == 0) mark_val(act, (uint32_t)w.root_val);
-    __syncthreads();
-    for (int lv = w.nlevels - 1; lv >= 0; --lv) {
-        const int begin = w.level_start[lv], end = w.level_start[lv + 1];
-        for (int k = begin + tid; k < end; k += nt) {
-            const uint4 q = recs[k];
-            const uint32_t idx = q.w & 0xFFFF;
-            if (!act[idx]) continue;
-            const uint32_t op = q.x & 0xFF, l8 = (q.x >> 16) & 0xFF, r8 = q.x >> 24;
-            const uint32_t pl = q.z & 0xFFFF, pr = q.z >> 16;
-            const int c = mpr_op_is_minmax(op) ? ch[idx] : 0;
+    /* ---- liveness (reference :351-458, def-use form): breadth first from the result ----
+     * The reference's walk keeps a flag per SLOT and marks both operand fields of every clause that is not a min / max
+     * with a recorded choice — also of the COPY clauses an earlier stage left, whose unchosen field still names a slot.
+     * Whatever clause of the inherited tape wrote that slot last is kept with them, related or not.  Same here: for such
+     * a field the schedule's chain of earlier writers of the slot is followed to the first one the inherited tape holds.
+     * The queue of clauses to visit lives where the values were (every clause enters it once). */
+    uint16_t* const queue = reinterpret_cast<uint16_t*>(V);
+    uint32_t* const chw = reinterpret_cast<uint32_t*>(ch);          /* ch is 8-byte aligned: live bits are set with word atomics */
+    if (tid == 0) {
+        sh[1038] = 0;
+        if (w.root_val >= 3) {
+            mark_val(ch, (uint32_t)w.root_val);
+            queue[0] = (uint16_t)(w.root_val - 3);
+            sh[1038] = 1;
+        }
+    }
+    auto visit = [&](uint32_t v) {                                  /* value index of an operand */
+        if (v < 3) return;
+        const uint32_t j = v - 3;
+        const uint32_t bit = 0x10u << (8 * (j & 3));
+        if (atomicOr(&chw[j >> 2], bit) & bit) return;
+        queue[atomicAdd(&sh[1038], 1)] = (uint16_t)j;
+    };
+    for (int head = 0;;) {
+        __syncthreads();
+        const int tail = sh[1038];
+        __syncthreads();
+        if (head >= tail) break;
+        for (int e = head + tid; e < tail; e += nt) {
+            const uint32_t i = queue[e];
+            const uint32_t d = (uint32_t)tro[root + 1 + i], pq = w.defs[i];
+            const uint32_t op = d & 0xFF, o8 = (d >> 8) & 0xFF, l8 = (d >> 16) & 0xFF, r8 = d >> 24;
+            const uint32_t pl = pq & 0xFFFF, pr = pq >> 16;
+            const uint32_t b = ch[i], st = (b >> 2) & 3;
+            if (st >= 2) {                                            /* decided by an earlier stage */
+                if (st == 2) visit(pl);
+                else if (r8) visit(pr);
+                const bool absent = (st == 2 && l8 == o8) || (st == 3 && r8 != 0 && r8 == o8);   /* a copy onto itself: never written */
+                const uint32_t field = (st == 2) ? r8 : l8;       /* the slot the COPY clause still names */
+                if (!absent && field) {
+                    const uint32_t v = (st == 2) ? pr : pl;       /* the clause that wrote it in the root tape ... */
+                    int j = v >= 3 ? (int)v - 3 : -1;
+                    while (j >= 0) {                              /* ... or the last one before it that the inherited tape holds */
+                        const uint32_t sj = (ch[j] >> 2) & 3;
+                        bool held = sj == 1;
+                        if (sj >= 2) {
+                            const uint32_t dj = (uint32_t)tro[root + 1 + j];
+                            const uint32_t oj = (dj >> 8) & 0xFF, lj = (dj >> 16) & 0xFF, rj = dj >> 24;
+                            held = !((sj == 2 && lj == oj) || (sj == 3 && rj != 0 && rj == oj));
+                        }
+                        if (held) break;
+                        const uint32_t pj = w.prev_writer[j];
+                        j = pj == 0xFFFF ? -1 : (int)pj;
+                    }
+                    if (j >= 0) visit((uint32_t)j + 3);
+                }
+                continue;
+            }
+            const int c = mpr_op_is_minmax(op) ? (int)(b & 3) : 0;
             if (c == 1) {
-                mark_val(act, pl);
+                visit(pl);
             } else if (c == 2) {
-                if (r8) mark_val(act, pr);
+                if (r8) visit(pr);
             } else {
-                if (l8) mark_val(act, pl);
-                if (r8) mark_val(act, pr);
+                if (l8) visit(pl);
+                if (r8) visit(pr);
             }
         }
-        __syncthreads();
+        head = tail;
     }
 
     /* ---- rank the clauses that get written, in reverse tape order ---- */
@@ -213,16 +306,16 @@ k_eval_tiles_wide(WideStageArgs w)
     int mine = 0, kept = 0;
     int min_drop = 0x7FFFFFFF, min_emit = 0x7FFFFFFF;
     for (int i = hi_i; i > lo_i; --i) {
-        if (!act[i]) continue;
-        const uint64_t d = tro[tape + 1 + i];
+        if (!live_of(ch[i])) continue;
+        const uint64_t d = tro[root + 1 + i];
         const uint32_t op = (uint32_t)d & 0xFF, o = (uint32_t)(d >> 8) & 0xFF, l = (uint32_t)(d >> 16) & 0xFF,
                        r = (uint32_t)(d >> 24) & 0xFF;
-        const int c = mpr_op_is_minmax(op) ? ch[i] : 0;
+        const int c = mpr_op_is_minmax(op) ? total_choice(ch[i]) : 0;
         kept += (mpr_op_is_minmax(op) && c == 0) ? 1 : 0;
         const bool drop = (c == 1 && l == o) || (c == 2 && r != 0 && r == o);
         if (drop) {
             min_drop = i;
-            act[i] = 2;                                   /* live, nothing written */
+            ch[i] = (unsigned char)((ch[i] & 0x0F) | 0x20);       /* live, nothing written */
         } else {
             ++mine;
             min_emit = i;
@@ -266,15 +359,31 @@ k_eval_tiles_wide(WideStageArgs w)
         }
     }
     __syncthreads();
+    if (leave) {
+        /* what the children inherit: the pushed tape's table, or (pool exhausted) the parent's again */
+        for (int k = tid; k < w.wpt; k += nt) {
+            uint32_t word = 0;
+            if (!sh[3]) {
+                word = inherited ? inherited[k] : 0x55555555u;
+            } else {
+                for (int j = 0; j < 16 && k * 16 + j < n; ++j) {
+                    const int i = k * 16 + j;
+                    const int c = total_choice(ch[i]);
+                    word |= (uint32_t)(live_of(ch[i]) ? 1 + c : 0) << (2 * j);
+                }
+            }
+            leave[k] = word;
+        }
+    }
     if (!sh[3]) return;                                   /* pool exhausted: the tile keeps its parent's tape */
     const int base = sh[2];
 
     for (int i = hi_i; i > lo_i; --i) {
-        if (act[i] != 1) continue;
-        uint64_t d = tro[tape + 1 + i];
+        if (live_of(ch[i]) != 1) continue;
+        uint64_t d = tro[root + 1 + i];
         const uint32_t op = (uint32_t)d & 0xFF, r = (uint32_t)(d >> 24) & 0xFF;
         if (mpr_op_is_minmax(op)) {
-            const int c = ch[i];
+            const int c = total_choice(ch[i]);
             if (c == 1) d = (d & ~0xFFull) | MPR_OP_COPY_LHS;
             else if (c == 2) d = (d & ~0xFFull) | (r ? MPR_OP_COPY_RHS : MPR_OP_COPY_IMM);
         }
@@ -282,7 +391,7 @@ k_eval_tiles_wide(WideStageArgs w)
         ++rank;
     }
     if (tid == 0) {
-        twr[base + 63] = tro[tape + 1 + n];                       /* end clause */
+        twr[base + 63] = tro[root + 1 + n];                       /* end clause */
         /* head: copy of the parent's head, after the last clause written */
         const int last_chunk = nchunks - 1;
         const int in_last = total - 62 * last_chunk;       /* 0 when the last chunk was opened for a dropped clause */
@@ -304,10 +413,10 @@ k_eval_tiles_wide(WideStageArgs w)
 
 size_t wide_stage_lds_bytes(int nclauses)
 {
-    return (((size_t)(nclauses + 3) * 8 + 2 * (size_t)nclauses + 15) & ~(size_t)15) + 1040 * sizeof(int);
+    return (((size_t)(nclauses + 3) * 8 + (size_t)nclauses + 15) & ~(size_t)15) + 1040 * sizeof(int);
 }
 bool wide_stage_fits(int nclauses) { return wide_stage_lds_bytes(nclauses) <= 150 * 1024; }
-void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w)
+void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced)
 {
     static bool once = false;
     if (!once) {
@@ -321,7 +430,7 @@ void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w)
     int threads = (width >= 48) ? 256 : 64;
     /* a frame with no more tiles than compute units (256 at 1024^2): sixteen wavefronts per tile shorten
      * both the levels (one clause per thread) and the serial ranking / writing loops */
-    if (const char* e = getenv("MPR_WIDE_THREADS")) threads = atoi(e);
+    if (threads_forced > 0) threads = threads_forced;       /* MPR_WIDE_THREADS (development) */
     else if (width >= 192 && w.t.count <= 256) threads = 1024;
     else if (width >= 192 && w.t.count <= 1024) threads = 512;
     /* ... and with thousands of tiles and levels of moderate width two wavefronts per tile (twice the tiles in

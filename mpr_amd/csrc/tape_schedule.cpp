@@ -22,6 +22,8 @@ TapeSchedule build_schedule(const uint64_t* clauses, int32_t length)
     std::vector<int32_t> level((size_t)n + 3, 0);
     std::vector<SchedRec> recs((size_t)n);
     int32_t ord = 0, depth = 0;
+    s.prev_writer.assign((size_t)n, 0xFFFF);
+    s.defs.assign((size_t)n, 0);
     for (int32_t i = 0; i < n; ++i) {
         const uint64_t c = clauses[1 + i];
         const uint32_t op = mpr_cl_op(c), o = mpr_cl_out(c), l = mpr_cl_lhs(c), r = mpr_cl_rhs(c);
@@ -41,6 +43,8 @@ TapeSchedule build_schedule(const uint64_t* clauses, int32_t length)
         if (r) lv = std::max(lv, level[q.pr]);
         level[(size_t)3 + i] = lv + 1;
         depth = std::max(depth, lv + 1);
+        s.defs[(size_t)i] = (uint32_t)q.pl | ((uint32_t)q.pr << 16);
+        if (lastdef[o] >= 3) s.prev_writer[(size_t)i] = (uint16_t)(lastdef[o] - 3);
         lastdef[o] = 3 + i;
     }
     s.root_val = lastdef[mpr_cl_out(clauses[length - 1])];

@@ -28,6 +28,8 @@ struct TapeSchedule {
     int32_t root_val = 0;               /* value index of the result */
     std::vector<SchedRec> recs;
     std::vector<int32_t> level_start;   /* nlevels + 1 offsets into recs */
+    std::vector<uint16_t> prev_writer;  /* per clause (tape order): the previous clause with the same out slot, 0xFFFF = none */
+    std::vector<uint32_t> defs;         /* per clause (tape order): pl | pr << 16, as in its record */
 };
 
 /* clauses = head, body..., end */

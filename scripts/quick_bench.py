@@ -16,6 +16,15 @@ def run(model, dim, S, n=10):
         for k, v in ctx.timings(): acc[k] = acc.get(k, 0) + v / n
     dt = (time.perf_counter() - t0) / n * 1e3
     print("%s %dD %d: %.3f ms/frame  " % (model, dim, S, dt) + " ".join("%s=%.3f" % kv for kv in acc.items()), flush=True)
+    if os.environ.get("MPR_QB_STAGES") == "1":       # every launch of the last frame, and the frame without events
+        print("   launches: " + " ".join("%s=%.3f" % kv for kv in ctx.timings()), flush=True)
+        ctx.close()
+        ctx = m.Context(S)
+        f = (lambda: ctx.render3D(tape, T)) if dim == 3 else (lambda: ctx.render2D(tape))
+        for _ in range(5): f()
+        t0 = time.perf_counter()
+        for _ in range(50): f()
+        print("   without events: %.3f ms/frame" % ((time.perf_counter() - t0) / 50 * 1e3), flush=True)
     ctx.close()
 
 if __name__ == "__main__":

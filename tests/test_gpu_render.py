@@ -304,6 +304,22 @@ def test_serial_first_stage_matches_oracle(mpr, orc, tapes, name, dim, S, monkey
     compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
 
 
+@pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("prospero", 2, 512), ("involute_gear_2d", 2, 512), ("hello_world", 2, 256),
+                                        ("hello_world", 3, 256), ("bear", 3, 256), ("architecture", 3, 256), ("architecture", 3, 512),
+                                        ("involute_gear_3d", 3, 256), ("trig", 3, 128), ("two_spheres", 2, 256)])
+@pytest.mark.parametrize("later", ["0", "100000000"])
+def test_level_parallel_later_stages_match_oracle(mpr, orc, tapes, name, dim, S, later, monkeypatch):
+    """Stages after the first run level-parallel too (kernels_wide.hip: on the root tape's schedule, with a
+    two-bit table per tile for the tape it inherited) while they have at most MPR_WIDE_LATER tiles
+    (default 16384) and the stage before ran that way.  Here: never, and always (with MPR_WIDE_FORCE, so that
+    tapes with narrow DAGs like bear's take the path as well).  Both must give the oracle's tiles, images
+    and shortened tapes at every stage."""
+    monkeypatch.setenv("MPR_WIDE_LATER", later)
+    if later != "0":
+        monkeypatch.setenv("MPR_WIDE_FORCE", "1")
+    compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
+
+
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("trig", 2, 256),
                                         ("bear", 3, 256), ("architecture", 3, 256)])
 def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):
