@@ -19,10 +19,12 @@
  *     division, square root, exp, log, sin, cos, asin, acos, atan become `v_mov` + `s_swappc_b64` to the
  *     routines the interpreters use (asm_float_bodies.hpp; asin / acos / atan compiled) — the same
  *     instructions in the same order, hence the same bits as k_eval_voxels_asm, k_eval_voxels and the oracle;
- *   - a wavefront translates a tape 64 clauses at a time: lane j decodes clause j into up to 5 dwords
- *     through a 32-entry template table in LDS, a ballot prefix sum places them, five stores write them
- *     to the wavefront's own region of an EXECUTABLE buffer (context.hip: HSA executable pool), JUMP /
- *     chunk links disappear;
+ *   - a wavefront translates a tape 64 clauses at a time: lane j decodes clause j into up to 12 dwords
+ *     through a 32-entry template table in LDS (in three batches of four), a ballot prefix sum places them,
+ *     they are staged in LDS and leave as three 16-byte stores per lane to the wavefront's (group form: the
+ *     workgroup's) own region of an EXECUTABLE buffer (context.hip: HSA executable pool); JUMP / chunk links
+ *     disappear; a division by a constant becomes a multiplication by its reciprocal plus an exact correction
+ *     (L_divc: the reciprocal is computed once, by the translator);
  *   - then `s_waitcnt vmcnt(0)`, `s_icache_inv` (the region is rewritten tile after tile: stale lines
  *     of the previous tape would otherwise execute — scripts/ubench/jit_probe.hip shows exactly that
  *     without the invalidate, and zero stale rounds with it), `s_swappc_b64` into the region.  Code is
