@@ -83,6 +83,7 @@ struct mpr_context {
     int cus = 0;                       /* compute units of the device */
     unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
+    bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     int jit_debug = 0;                 /* MPR_JIT_DEBUG (development): 1 = translate only, 2 = translate once per wavefront */
@@ -276,7 +277,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; }
-    if (const char* e = getenv("MPR_VOXEL_GROUPS")) c->voxel_groups = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_GROUPS")) { c->voxel_groups = atoi(e) != 0; c->groups_always = atoi(e) == 2; }
     if (const char* e = getenv("MPR_JIT_DEBUG")) c->jit_debug = atoi(e);
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
     if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
@@ -597,7 +598,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->last.tiles_in[si] = count;
 
         /* float pass in group form: the last tile stage also writes, per group of 64 siblings, the tape it walked and
-         * the tiles' min / max decisions; possible while a tape records at most 64 of them */
+         * the tiles' min / max decisions; possible while a tape records at most 192 of them (three register pairs per side) */
         const int stage_cap = dynamic_choices ? stage_choice_cap : choice_cap;
         /* level-parallel kernel: the first stage while it has few tiles, later ones while the stage before ran that way */
         /* ... later ones: a workgroup walks the levels in about the time a wavefront of the serial kernel walks a fifth of the
@@ -612,7 +613,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 3) &&
                               (si == 0 ? count <= 8192 : (prev_wide && count <= wide_limit));
         const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
-                                mprk::jit_slot_class(nslots) != 0 && stage_cap <= 64;
+                                mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();
         if (groups_now) {
             const size_t ng = ((size_t)count + 63) / 64;
             rc = ensure_buffer(&c->groups, &c->groups_cap, ng);
@@ -639,6 +640,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.nslots = nslots;
             a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
             a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
+            a.len_stats = groups_now ? c->num_active + 5 : nullptr;
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
@@ -701,6 +703,14 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             if (rc) return rc;
         }
         const int active = act3[0];
+        if (groups_now && act3[2] > 0 && !c->groups_always) {
+            /* a child evaluated on its group's tape walks the clauses the child's own tape dropped as well: worth it while
+             * the tapes walked are less than twice the tapes handed on (measured: bear 1.03x -> float pass 1.63x faster
+             * than the interpreter on per-tile tapes, architecture 1.8x -> 1.39x faster, involute_gear_3d 2.8x -> 1.44x
+             * slower, involute_gear_2d 4.3x -> 5x slower) */
+            if ((double)act3[2] > 2.0 * (double)act3[1]) group_form = false;
+            if (c->debug_choices) fprintf(stderr, "last stage: tapes handed on %d clauses, tapes walked %d (sample)\n", act3[1], act3[2]);
+        }
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
         if (c->debug_choices) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d)\n", si, count, act3[3], choice_cap);
         c->last.tiles_active[si] = active;

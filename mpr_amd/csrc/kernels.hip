@@ -313,6 +313,7 @@ k_eval_tiles(TileStageArgs a)
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 
     long long written = 0;
+    int own_len = nclauses;           /* clauses of the tape this tile hands on: the one it pushes, or the one it walked */
     int bwd_words = 0;
     int kept_minmax = 0;              /* min / max words some lane kept undecided: bounds the choices of the pushed tapes */
     bool overflow = false;
@@ -324,7 +325,7 @@ k_eval_tiles(TileStageArgs a)
             act[lane + 64] = 0;
         }
 
-        int out_index = 0, out_offset = 0;
+        int out_index = 0, out_offset = 0, first_index = 0;
         /* ONE pool claim per wave: every pushing lane reserves the chunks it can need at most (its
          * shortened tape is never longer than the tape just walked), as one contiguous run; a
          * lane that fills a chunk simply moves to the next one of its run.  (The reference claims
@@ -352,6 +353,7 @@ k_eval_tiles(TileStageArgs a)
             const int base = ok ? (int)base64 : 0;
             if (push) {
                 out_index = base + MPR_SUBTAPE_CHUNK * run_chunks * rank_in(live, lane);
+                first_index = out_index;
                 run_end = out_index + MPR_SUBTAPE_CHUNK * run_chunks;
                 out_offset = MPR_SUBTAPE_CHUNK;
                 if (!ok || (long long)out_index + out_offset >= a.pool_cap) overflow = true;
@@ -487,6 +489,17 @@ k_eval_tiles(TileStageArgs a)
             twr[out_index + out_offset] = d;         /* head: copy of the parent's head */
             written++;
             a.tiles[gidx].tape = out_index + out_offset;
+            own_len = ((out_index - first_index) / MPR_SUBTAPE_CHUNK) * 62 + (62 - out_offset);
+        }
+    }
+    if (a.len_stats && (blockIdx.x & 7) == 0) {
+        /* (a sample of the groups: one pair of atomics per wave on two words would be felt) */
+        const uint64_t amb = ballot(ambiguous);
+        int own_sum = ambiguous ? own_len : 0;
+        for (int off = 32; off > 0; off >>= 1) own_sum += __shfl_xor(own_sum, off);
+        if (lane == 0 && amb) {
+            atomicAdd(a.len_stats, own_sum);
+            atomicAdd(a.len_stats + 1, nclauses * __popcll(amb));
         }
     }
 
@@ -563,6 +576,10 @@ DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2, int* need)
     /* the evaluation that just finished left an upper bound on the min / max clauses of the tapes it
      * pushed (TileStageArgs::next_choices): it sizes the next stage's choice array; cleared for the next use */
     const int n3 = __hip_atomic_exchange(need, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* ... and, from the last tile stage, sampled clause totals of the tapes it pushed and of the tapes it walked
+     * (TileStageArgs::len_stats): the host picks the float pass's form with them */
+    n1 = __hip_atomic_exchange(need + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    n2 = __hip_atomic_exchange(need + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     /* every value travels with the sequence number in ONE 8-byte store: no ordering between the words is
      * needed, hence no release fence (which is a write-back of the L2 on this part) */
     unsigned long long* const p = reinterpret_cast<unsigned long long*>(pub);

@@ -50,6 +50,8 @@ struct TileStageArgs {
     int heat_stride;           /* = image size in pixels */
     int* next_choices;         /* device counter (atomicMax): an upper bound on the min / max clauses of any tape this
                                 * stage pushes; sizes the next stage's choice array */
+    int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
+                                * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */
 };
 
 /* first tile stage, one workgroup per tile, level by level over the root tape's DAG
@@ -122,7 +124,8 @@ void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const fl
 /* same pass, every tape translated to machine code on the device (kernels_voxel_jit.hip); no counters.
  * code: executable device memory, `grid` regions of region_dwords each */
 size_t jit_code_dwords(const uint64_t* clauses, int n, bool group);
-int jit_slot_class(int nslots);                      /* 24 / 40 / 96 / 192, or 0: too many slots for registers */
+int jit_slot_class(int nslots);
+int jit_max_choices();        /* recorded min / max decisions per tape the group form of the generated code takes */                      /* 24 / 40 / 96 / 192, or 0: too many slots for registers */
 int jit_grid(int dim, int nslots, int cus, bool group);
 /* groups != null: the group form over the last tile stage's list (a.tiles / a.count), else one wavefront per smallest tile */
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,

@@ -79,7 +79,8 @@ __device__ float jit_atan(float v) { return mpr_atanf(v); }
 constexpr int JIT_WORDS = 12;
 constexpr int JIT_ROW = 4 + 3 * JIT_WORDS;           /* dwords per row: meta, 3 pad, then three batches of {base x4, sel x4, mask x4} */
 struct JitRow { uint32_t n, flags; uint32_t base[JIT_WORDS], sel[JIT_WORDS], mask[JIT_WORDS]; };
-struct JitTable { uint32_t w[32][JIT_ROW]; };
+constexpr int JIT_ROWS = 40;               /* 32 opcodes (30: the translator's constant division), then min / max for decisions 64..127, 128..191 */
+struct JitTable { uint32_t w[JIT_ROWS][JIT_ROW]; };
 namespace jt {
 constexpr uint32_t NONE = 0x0C, CI = 0, O = 1, A = 2, R = 3;                 /* selector bytes */
 constexpr uint32_t VREG = 0x100;                                               /* src0 names a VGPR */
@@ -87,7 +88,8 @@ constexpr uint32_t LITERAL = 255;
 constexpr uint32_t VOP2(uint32_t op, uint32_t vdst, uint32_t vsrc1, uint32_t src0) { return (op << 25) | (vdst << 17) | (vsrc1 << 9) | src0; }
 constexpr uint32_t MOV(uint32_t vdst, uint32_t src0) { return 0x7E000200u | (vdst << 17) | src0; }
 constexpr uint32_t CALL(uint32_t sgpr) { return 0xBE9E1E00u | sgpr; }        /* s_swappc_b64 s[30:31], s[sgpr:sgpr+1] */
-constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /* s_bitcmp1_b64 s[76:77] / s[78:79], <index> */
+constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /* s_bitcmp1_b64 s[76:77] / s[78:79], <index>; decisions 64.. in s[80:83], 128.. in s[84:87] */
+constexpr int JIT_MAX_CHOICES = 192;
 constexpr uint32_t CSELECT = 0x85EA80C1u;                                      /* s_cselect_b64 vcc, -1, 0 */
 constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21;
 constexpr uint32_t S_DIVC = 70, S_DIV = 52, S_SQRT = 54, S_EXP = 56, S_LOG = 58, S_SIN = 60, S_COS = 62, S_ASIN = 64, S_ACOS = 66, S_ATAN = 68;
@@ -132,7 +134,7 @@ constexpr JitRow one(uint32_t base, uint32_t d, uint32_t s1, uint32_t s0, bool i
 /* min / max.  Tile form: the handlers' canonicalising v_max pair, then the operation.  Group form: the result goes
  * to v37 first, then `chose lhs` puts the lhs there instead and `chose rhs` the rhs (raw, as COPY_LHS / COPY_RHS /
  * COPY_IMM of the child's own tape would), and that lands in the out register. */
-constexpr JitRow minmax(uint32_t op, bool imm, bool group)
+constexpr JitRow minmax(uint32_t op, bool imm, bool group, uint32_t q = 0)
 {
     Builder b;
     b.r.flags = FLAG_MINMAX;
@@ -156,10 +158,10 @@ constexpr JitRow minmax(uint32_t op, bool imm, bool group)
         b.ins(VOP2(V_MAX, 36, 0, VREG), NONE, R, R);
     }
     b.fixed(VOP2(op, 37, 36, VREG + 35));
-    b.bitcmp(BITCMP_L);
+    b.bitcmp(BITCMP_L + 4 * q);
     b.fixed(CSELECT);
     b.ins(VOP2(V_CNDMASK, 37, 0, VREG + 37), NONE, A);                 /* v37 = chose lhs ? lhs : v37 */
-    b.bitcmp(BITCMP_R);
+    b.bitcmp(BITCMP_R + 4 * q);
     b.fixed(CSELECT);
     if (imm) b.ins(VOP2(V_CNDMASK, 0, 38, VREG + 37), O);                /* out = chose rhs ? immediate : v37 */
     else b.ins(VOP2(V_CNDMASK, 0, 0, VREG + 37), O, R);
@@ -249,8 +251,12 @@ constexpr JitRow row_of(uint32_t op, bool group)
 constexpr JitTable make_table(bool group)
 {
     JitTable t{};
-    for (uint32_t op = 0; op < 32; ++op) {
-        const JitRow r = row_of(op, group);
+    for (uint32_t op = 0; op < (uint32_t)JIT_ROWS; ++op) {
+        /* rows 32..35 / 36..39: MIN_LHS_IMM .. MAX_LHS_RHS whose decision is one of 64..127 / 128..191 */
+        const uint32_t mm = MPR_OP_MIN_LHS_IMM + (op - 32) % 4, q = 1 + (op - 32) / 4;
+        const JitRow r = op < 32 ? row_of(op, group)
+                                 : minmax(mm == MPR_OP_MIN_LHS_IMM || mm == MPR_OP_MIN_LHS_RHS ? V_MIN : V_MAX,
+                                          mm == MPR_OP_MIN_LHS_IMM || mm == MPR_OP_MAX_LHS_IMM, group, group ? q : 0);
         t.w[op][0] = r.n | (r.flags << 8);
         for (int k = 0; k < JIT_WORDS; ++k) {
             const int at = 4 + 12 * (k / 4) + (k % 4);
@@ -280,12 +286,12 @@ size_t jit_code_dwords(const uint64_t* clauses, int n, bool group)
 
 /* LDS of the translator (dwords): the table, the staging buffer (a block's dwords side by side before they leave in
  * 16-byte pieces: 3 carried + 62 x 12 + slack), a dump for lanes without a dword, a dump for the tape prefetch */
-constexpr int JIT_LDS_STAGE = 32 * JIT_ROW, JIT_STAGE_DWORDS = 784, JIT_LDS_DUMP = JIT_LDS_STAGE + JIT_STAGE_DWORDS;
+constexpr int JIT_LDS_STAGE = JIT_ROWS * JIT_ROW, JIT_STAGE_DWORDS = 784, JIT_LDS_DUMP = JIT_LDS_STAGE + JIT_STAGE_DWORDS;
 constexpr int JIT_LDS_PFDUMP = JIT_LDS_DUMP + 16, JIT_LDS_DWORDS = JIT_LDS_PFDUMP + 256;
 DEV void jit_load_table(uint32_t* lds, int tid, int nthreads, bool group)
 {
     const uint32_t* const src = &d_jit_table[group ? 1 : 0].w[0][0];
-    for (int i = tid; i < 32 * JIT_ROW; i += nthreads) lds[i] = src[i];
+    for (int i = tid; i < JIT_ROWS * JIT_ROW; i += nthreads) lds[i] = src[i];
 }
 
 /* Translate the tape whose first clause is tro[first] into `code`; returns the number of dwords.
@@ -437,6 +443,16 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "v_mbcnt_lo_u32_b32 v53, s64, 0\n"
         "v_mbcnt_hi_u32_b32 v53, s65, v53\n"
         "v_add_u32 v53, s48, v53\n"
+        /* decisions 64..127 / 128..191 (group form): the rows whose compares name the next register pairs */
+        "v_lshrrev_b32 v60, 6, v53\n"
+        "v_min_u32 v60, 2, v60\n"                          /* (tile form: any number of min / max clauses, and rows 32.. are rows 17..20 again) */
+        "v_and_b32 v53, 63, v53\n"
+        "v_cmp_ne_u32 vcc, 0, v60\n"
+        "v_lshl_add_u32 v60, v60, 2, 11\n"                 /* row = opcode + 11 + 4 q */
+        "s_and_b64 vcc, vcc, s[64:65]\n"
+        "v_mul_u32_u24 v60, 160, v60\n"
+        "v_cndmask_b32 v60, 0, v60, vcc\n"
+        "v_add_u32 v38, v38, v60\n"
         "v_add_u32 v53, 128, v53\n"                        /* its index, as the inline constant the scalar compare takes */
         "v_and_b32 v53, 0xff, v53\n"
         "v_or_b32 v56, v56, v53\n"
@@ -589,7 +605,7 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "memory", "vcc", "scc", "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s30", "s31", "s40", "s41", "s42", \
         "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",      \
         "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s90", "s91", "s92",      \
-        "s76", "s77", "s78", "s79", "s93", "s94", "s95", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",       \
+        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s93", "s94", "s95", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",       \
         JIT_V10(4), JIT_V10(5), JIT_V10(6), "v70", "v71"
 #define JIT_CLOBBER_40 "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", JIT_V10(8)
 #define JIT_CLOBBER_96 JIT_CLOBBER_40, JIT_V10(9), JIT_V10(10), JIT_V10(11), JIT_V10(12), JIT_V10(13), "v140", "v141", "v142", "v143"
@@ -622,7 +638,9 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     JIT_LEAF_ADDR(64, 65, "mpr_fj_asin") JIT_LEAF_ADDR(66, 67, "mpr_fj_acos") JIT_LEAF_ADDR(68, 69, "mpr_fj_atan") \
     JIT_ROUTINE_ADDR(70, 71, "L_divc")                                                                 \
     "s_mov_b32 s90, 0x260\n"                            /* class mask of the square root */           \
-    "s_mov_b64 s[76:77], %[cl]\n s_mov_b64 s[78:79], %[cr]\n"   /* group form: the child's min / max decisions */ \
+    "s_mov_b64 s[76:77], %[cl]\n s_mov_b64 s[78:79], %[cr]\n"   /* group form: the child's min / max decisions 0..63 */ \
+    "s_mov_b64 s[80:81], %[cl1]\n s_mov_b64 s[82:83], %[cr1]\n" /* 64..127 */                           \
+    "s_mov_b64 s[84:85], %[cl2]\n s_mov_b64 s[86:87], %[cr2]\n" /* 128..191 */                          \
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
     "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
     "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
@@ -653,14 +671,20 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "L_end_%=:\n"
 
 template <int NS>
-DEV float jit_run(const uint32_t* code, uint32_t fresh, float vx, float vy, float vz, uint64_t cl = 0, uint64_t cr = 0)
+DEV float jit_run(const uint32_t* code, uint32_t fresh, float vx, float vy, float vz, uint64_t cl = 0, uint64_t cr = 0,
+                  uint64_t cl1 = 0, uint64_t cr1 = 0, uint64_t cl2 = 0, uint64_t cr2 = 0)
 {
     const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
     fresh = rdfirst(fresh);
     cl = rfl64(cl);
     cr = rfl64(cr);
+    cl1 = rfl64(cl1);
+    cr1 = rfl64(cr1);
+    cl2 = rfl64(cl2);
+    cr2 = rfl64(cr2);
     float res;
-#define JIT_OPERANDS : [res] "=&v"(res) : [vx] "v"(vx), [vy] "v"(vy), [vz] "v"(vz), [clo] "s"(clo), [chi] "s"(chi), [fresh] "s"(fresh), [cl] "s"(cl), [cr] "s"(cr)
+#define JIT_OPERANDS : [res] "=&v"(res) : [vx] "v"(vx), [vy] "v"(vy), [vz] "v"(vz), [clo] "s"(clo), [chi] "s"(chi), [fresh] "s"(fresh), [cl] "s"(cl), [cr] "s"(cr), \
+                       [cl1] "s"(cl1), [cr1] "s"(cr1), [cl2] "s"(cl2), [cr2] "s"(cr2)
     if constexpr (NS <= 24) {
         asm volatile(JIT_ASM_TEXT JIT_OPERANDS : JIT_CLOBBER_BASE);
     } else if constexpr (NS <= 40) {
@@ -862,8 +886,12 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             else asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
         }
         /* lane i: the decisions of the group's 64 tiles at its i-th min / max */
-        ulonglong2 m = make_ulonglong2(0ull, 0ull);
+        ulonglong2 m = make_ulonglong2(0ull, 0ull), m1 = m, m2 = m;
         if (lane < nch) m = j.choice_masks[(size_t)g * j.choice_cap + lane];
+        if (nch > 64) {
+            if (lane + 64 < nch) m1 = j.choice_masks[(size_t)g * j.choice_cap + 64 + lane];
+            if (lane + 128 < nch) m2 = j.choice_masks[(size_t)g * j.choice_cap + 128 + lane];
+        }
         __syncthreads();
         const unsigned long long t1 = j.dbg ? __builtin_readcyclecounter() : 0ull;
         /* front to back: children with the larger z first (lane = x + 4 y + 16 z); a wavefront takes the next child
@@ -882,8 +910,15 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             JitVoxel<DIM> vox;
             if (!vox.setup(a, cpos, lane)) continue;
             const uint64_t cl = ballot((m.x >> c) & 1ull), cr = ballot((m.y >> c) & 1ull);
+            uint64_t cl1 = 0, cr1 = 0, cl2 = 0, cr2 = 0;
+            if (nch > 64) {
+                cl1 = ballot((m1.x >> c) & 1ull);
+                cr1 = ballot((m1.y >> c) & 1ull);
+                cl2 = ballot((m2.x >> c) & 1ull);
+                cr2 = ballot((m2.y >> c) & 1ull);
+            }
             if (j.debug & 1) continue;
-            const float res = jit_run<NS>(code, 0u, vox.vx, vox.vy, vox.vz, cl, cr);
+            const float res = jit_run<NS>(code, 0u, vox.vx, vox.vy, vox.vz, cl, cr, cl1, cr1, cl2, cr2);
             ++n_run;
             vox.finish(a, res);
         }
@@ -925,6 +960,7 @@ void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code,
     hipLaunchKernelGGL(k_test_float_jit, dim3((n + 63) / 64), dim3(64), 0, s, tape3, code, region_dwords, n, a, b, out);
 }
 
+int jit_max_choices() { return jt::JIT_MAX_CHOICES; }
 int jit_slot_class(int nslots)
 {
     return nslots <= 24 ? 24 : nslots <= 40 ? 40 : nslots <= 96 ? 96 : nslots <= 192 ? 192 : 0;

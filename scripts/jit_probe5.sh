@@ -1,5 +1,5 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-MPR_QB_STAGES=1 timeout 120 python scripts/quick_bench.py prospero:2:256 prospero:2:512 prospero:2:1024 architecture:3:256 architecture:3:512 architecture:3:1024 involute_gear_2d:2:512 involute_gear_2d:2:1024 involute_gear_3d:3:256 hello_world:2:256 bear:3:256 2>&1 | grep -v "amdgpu.ids\|launches"
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for rep in 1 2; do for G in 0 1 2; do echo "== MPR_VOXEL_GROUPS=$G"; MPR_VOXEL_GROUPS=$G MPR_QB_STAGES=1 timeout 120 python scripts/quick_bench.py architecture:3:2048 architecture:3:1024 2>&1 | grep -v "amdgpu.ids\|launches"; done; done
+MPR_DEBUG_CHOICES=1 timeout 60 python scripts/quick_bench.py architecture:3:2048 2>&1 | grep "last stage" | head -3

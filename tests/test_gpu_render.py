@@ -259,15 +259,19 @@ def test_assembly_float_pass_matches_compiled_one(mpr, tapes, name, dim, S, monk
 @pytest.mark.parametrize("name,dim,S", [
     ("hello_world", 2, 256), ("prospero", 2, 512), ("involute_gear_2d", 2, 512), ("trig", 2, 256), ("many_slots", 2, 128),
     ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128), ("trig", 3, 128), ("many_slots", 3, 128),
+    ("architecture", 3, 512), ("involute_gear_3d", 3, 256),
 ])
-@pytest.mark.parametrize("groups", ["1", "0"])
+@pytest.mark.parametrize("groups", ["2", "0"])
 def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name, dim, S, groups, monkeypatch):
     """By default the float pass translates tapes into gfx950 machine code on the device and runs that
     (kernels_voxel_jit.hip): once per group of 64 sibling tiles with the children's min / max decisions
-    applied by selects (group form; MPR_VOXEL_GROUPS=0: once per smallest tile, each with its own tape).
+    applied by selects (group form, up to 192 decisions per tape; by default only while the groups' tapes are
+    not much longer than the children's own, MPR_VOXEL_GROUPS=2: always, =0: once per smallest tile, each with its
+    own tape).
     MPR_VOXEL_JIT=0 selects the assembly interpreter (slots in LDS).  Same frame, bit for bit,
     hierarchical and brute force — the latter runs the whole root tape as one piece of generated code."""
     tape = tapes(name)
+    monkeypatch.setenv("MPR_WIDE_LATER", "0")      # a level-parallel last stage keeps no decision masks: group form off
     monkeypatch.setenv("MPR_VOXEL_GROUPS", groups)
     monkeypatch.setenv("MPR_VOXEL_JIT", "0")
     a = mpr.Context(S)
@@ -278,6 +282,11 @@ def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name
             ctx.render2D(tape, view2())
         else:
             ctx.render3D(tape, view3())
+    assert a.float_kernel().startswith("k_eval_voxels_asm")
+    if name != "many_slots":                       # (more slots than the generated code has registers for)
+        assert b.float_kernel().startswith("k_eval_voxels_jit<" if groups == "0" else "k_eval_voxels_jit"), b.float_kernel()
+        if groups == "2" and (name, S) in (("architecture", 512), ("bear", 256)):
+            assert b.float_kernel().startswith("k_eval_voxels_jit_groups"), b.float_kernel()      # up to 155 / 27 decisions per tape
     assert a.image.any()
     assert np.array_equal(a.image, b.image), int((a.image != b.image).sum())
     if dim == 3:
