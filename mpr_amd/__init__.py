@@ -159,6 +159,8 @@ def lib():
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
     L.mpr_ctx_float_kernel.argtypes = [vp]
+    L.mpr_ctx_last_stage_pushed.argtypes = [vp]
+    L.mpr_ctx_last_stage_pushed.restype = i32
     L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
     L.mpr_compiled_create.argtypes = [i32, vp, P(vp)]
@@ -546,6 +548,10 @@ class Context:
     def float_kernel(self):
         """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""
         return lib().mpr_ctx_float_kernel(self._h).decode()
+
+    def last_stage_pushed(self):
+        """False when the last frame's last tile stage pushed no per-tile tapes (mpr_ctx_last_stage_pushed)."""
+        return bool(lib().mpr_ctx_last_stage_pushed(self._h))
 
     def dev_filled(self, stage=3):
         return lib().mpr_dev_filled(self._h, stage)

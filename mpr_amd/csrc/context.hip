@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/mpr_amd.h"
@@ -83,6 +84,29 @@ struct mpr_context {
     int cus = 0;                       /* compute units of the device */
     unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
+    /* Frames whose last tile stage pushes no tapes (TileStageArgs::no_push): possible when both the float and the normals
+     * pass run on the groups' tapes, decided from what the LAST frame of the same tape and view measured (a push-mode
+     * frame: the first one always is).  What a reader of tiles / tapes needs to get the reference's state back: */
+    bool lean_last_stage = true;       /* MPR_LAST_STAGE_PUSH=1: always push */
+    bool force_push = false;           /* set while a reader re-renders the frame in full */
+    bool last_frame_lean = false;
+    struct FrameKey {
+        uint64_t serial = 0;
+        int dim = 0, rank = 0;
+        unsigned owner_gen = 0;
+        bool parted = false;
+        float mat[16] = {0};
+        float z = 0.0f;
+        bool operator==(const FrameKey& o) const
+        {
+            return serial == o.serial && dim == o.dim && rank == o.rank && owner_gen == o.owner_gen && parted == o.parted &&
+                   z == o.z && std::memcmp(mat, o.mat, sizeof mat) == 0;
+        }
+    };
+    FrameKey learned;                  /* the frame that measured "groups' tapes are short enough" ... */
+    bool learned_ok = false;
+    std::unique_ptr<mpr_tape> last_tape;   /* ... and a copy of its tape (the caller may have freed it by the time a reader asks) */
+    bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
@@ -293,6 +317,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
+    if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->lean_last_stage = atoi(e) == 0;
     if (const char* e = getenv("MPR_WIDE_LATER")) c->wide_later = atoi(e);
     if (const char* e = getenv("MPR_WIDE_THREADS")) c->wide_threads = atoi(e);
     if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
@@ -567,6 +593,18 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     const bool dynamic_choices = c->dynamic_choices;
     bool group_form = false;
     int group_stage = 0, group_count = 0, group_cap = 1;
+    mpr_context::FrameKey key;
+    key.serial = tape->serial;
+    key.dim = dim;
+    key.rank = rank;
+    key.parted = owner != nullptr;
+    key.owner_gen = owner ? (unsigned)c->owner_gen : 0u;
+    key.z = z;
+    std::memcpy(key.mat, mat, (size_t)(dim == 3 ? 16 : 9) * sizeof(float));
+    /* the last frame of this tape and view found the group form worth it: this one's last tile stage pushes no tapes */
+    const bool lean_ok = c->lean_last_stage && !c->force_push && !brute && c->learned_ok && c->learned == key &&
+                         (dim == 2 || c->normals_asm);
+    bool lean_now = false;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
@@ -598,7 +636,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->last.tiles_in[si] = count;
 
         /* float pass in group form: the last tile stage also writes, per group of 64 siblings, the tape it walked and
-         * the tiles' min / max decisions; possible while a tape records at most 192 of them (three register pairs per side) */
+         * the tiles' min / max decisions; possible while a tape records at most 128 of them (two register pairs per side) */
         const int stage_cap = dynamic_choices ? stage_choice_cap : choice_cap;
         /* level-parallel kernel: the first stage while it has few tiles, later ones while the stage before ran that way */
         /* ... later ones: a workgroup walks the levels in about the time a wavefront of the serial kernel walks a fifth of the
@@ -610,10 +648,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, ((size_t)160 << 10) / mprk::wide_stage_lds_bytes(c->sched_nclauses)));
             wide_limit = 2 * std::max(c->cus, 1) * (int)per_cu;
         }
-        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 3) &&
+        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) &&
                               (si == 0 ? count <= 8192 : (prev_wide && count <= wide_limit));
         const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();
+        if (groups_now && lean_ok) lean_now = true;
         if (groups_now) {
             const size_t ng = ((size_t)count + 63) / 64;
             rc = ensure_buffer(&c->groups, &c->groups_cap, ng);
@@ -640,7 +679,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.nslots = nslots;
             a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
             a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
-            a.len_stats = groups_now ? c->num_active + 5 : nullptr;
+            a.len_stats = (groups_now && !lean_now) ? c->num_active + 5 : nullptr;
+            a.no_push = groups_now && lean_now;
+            a.compiled_walk = !c->tiles_asm;
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
@@ -648,6 +689,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.heat_stride = S;
             a.debug = c->debug_tiles;
             if (a.debug & 4) a.debug |= si << 4;
+            if ((c->debug_tiles & 8) && last) a.debug |= 1;          /* 8: skip tape pushing in the last stage only */
             if (heat && dim == 3) mprk::launch_mask_filled(s, c->tiles[i], count, tps, c->filled[i]);
             TimedScope ts(c, "eval_tiles_i");
             /* ... and only while the stage has few tiles (a workgroup per tile is latency-bound at low lane
@@ -703,12 +745,21 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             if (rc) return rc;
         }
         const int active = act3[0];
+        if (groups_now && !lean_now) {
+            /* what the next frame of this tape and view may do (a frame that measured nothing teaches nothing) */
+            c->learned_ok = false;
+        }
         if (groups_now && act3[2] > 0 && !c->groups_always) {
             /* a child evaluated on its group's tape walks the clauses the child's own tape dropped as well: worth it while
              * the tapes walked are less than twice the tapes handed on (measured: bear 1.03x -> float pass 1.63x faster
              * than the interpreter on per-tile tapes, architecture 1.8x -> 1.39x faster, involute_gear_3d 2.8x -> 1.44x
              * slower, involute_gear_2d 4.3x -> 5x slower) */
             if ((double)act3[2] > 2.0 * (double)act3[1]) group_form = false;
+            else if (!cnt && !heat) {
+                c->learned = key;
+                c->learned_ok = true;
+                if (!c->last_tape || c->last_tape->serial != tape->serial) c->last_tape.reset(new mpr_tape(*tape));
+            }
             if (c->debug_choices) fprintf(stderr, "last stage: tapes handed on %d clauses, tapes walked %d (sample)\n", act3[1], act3[2]);
         }
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
@@ -775,6 +826,15 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 }
             }
         }
+        if (lean_now && !(jitted && group_form)) {
+            /* cannot happen while the frame that taught `learned` ran the group form with the same tape; if it does, the
+             * tapes this frame did not push are needed after all: the whole frame again, in full */
+            c->learned_ok = false;
+            c->force_push = true;
+            const int again = render_frame(c, tape, dim, mat, z, owner, rank, brute, blocking);
+            c->force_push = false;
+            return again;
+        }
         if (jitted) {
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
                      mprk::jit_slot_class(nslots));
@@ -800,6 +860,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.counters = cnt;
         n.col_list = nullptr;
         n.ncols = 0;
+        n.groups = lean_now ? c->groups : nullptr;
+        n.choice_masks = lean_now ? c->choice_masks : nullptr;
+        n.choice_cap = group_cap;
         if (owner && c->normals_asm && !cnt) {
             /* owned columns only; the list is rebuilt when the ownership table or the rank changes */
             if (c->my_cols_rank != rank || c->my_cols_gen != c->owner_gen) {
@@ -820,11 +883,27 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     HIP_TRY(hipGetLastError());
     c->frame_pending = true;
     c->pending_dim = dim;
+    c->last_frame_lean = lean_now;
     if (blocking) return mpr_ctx_sync(c);
     return MPR_OK;
 }
 
+/* A reader of tiles or tapes wants the state the reference leaves: if the last frame's last tile stage pushed no tapes, the
+ * frame is rendered again with them (same tape — the context kept a copy —, same view, same partition). */
+static int ensure_full_frame(mpr_context* c)
+{
+    if (!c->last_frame_lean) return MPR_OK;
+    if (!c->last_tape) return mpr::set_error(MPR_ERR_INVALID, "no tape to render the last frame's tapes from");
+    const mpr_context::FrameKey k = c->learned;
+    c->force_push = true;
+    const int rc = render_frame(c, c->last_tape.get(), k.dim, k.mat, k.z, k.parted ? c->owner_host.data() : nullptr, k.rank, false, true);
+    c->force_push = false;
+    return rc;
+}
+
 extern "C" {
+
+int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
 
 int mpr_ctx_sync(mpr_context* c)
 {
@@ -1011,6 +1090,7 @@ int mpr_read_tiles(mpr_context* c, int32_t stage, mpr_tile_node* host, size_t ca
 {
     if (!c || stage < 0 || stage > 3 || !n) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (const int rc = ensure_full_frame(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     *n = c->tiles_n[stage];
     if (host) {
@@ -1023,6 +1103,7 @@ int mpr_read_tape_pool(mpr_context* c, uint64_t* host, size_t cap, int32_t* tape
 {
     if (!c || !tape_index) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (const int rc = ensure_full_frame(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     int ti = 0;
     unsigned long long ti64 = 0;
@@ -1143,6 +1224,7 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
 {
     if (!c || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (const int rc = ensure_full_frame(c)) return rc;        /* tape_index: the pool as the reference leaves it */
     HIP_TRY(hipStreamSynchronize(c->stream));
     int ti = 0;
     unsigned long long tiw[2] = {0, 0};

@@ -302,14 +302,16 @@ k_eval_tiles(TileStageArgs a)
         const int nrec = ci < a.choice_cap ? ci : a.choice_cap;
         ulonglong2* const dst = a.choice_masks + (size_t)blockIdx.x * a.choice_cap;
         for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
+        const uint64_t would_push = ballot(ambiguous && ((any_choice >> lane) & 1));
         if (lane == 0) {
             GroupInfo gi;
             gi.tape = tape;
             gi.nchoices = nrec;
+            gi.pushed = would_push;
             a.groups[blockIdx.x] = gi;
         }
     }
-    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1);
+    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1) && !a.no_push;
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 
     long long written = 0;
@@ -1011,10 +1013,8 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     const int groups = (a.count + 63) / 64;
     const size_t lds = tile_stage_lds_bytes(a.nslots, a.choice_cap);
     /* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers */
-    const char* const env = getenv("MPR_TILES_ASM");      /* development: 0 = compiled forward walk */
-    const bool asm_ok = !(env && atoi(env) == 0);
-    /* ... and the assembly backward walk forms 32-bit byte offsets into the pool */
-    const bool use_asm = asm_ok && a.nslots <= 128 && !(a.debug & 3) && a.pool_cap < (1ll << 29);
+    /* ... and the assembly backward walk forms 32-bit byte offsets into the pool (a.compiled_walk: MPR_TILES_ASM=0) */
+    const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
     if (dim == 3) {
         if (use_asm) hipLaunchKernelGGL((k_eval_tiles<3, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<3, false>), dim3(groups), dim3(64), lds, s, a);

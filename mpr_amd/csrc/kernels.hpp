@@ -27,6 +27,8 @@ enum {
 struct GroupInfo {
     int tape;
     int nchoices;
+    unsigned long long pushed;     /* the tiles whose own tape is this one shortened by their decisions (ambiguous tiles that
+                                      chose a side somewhere): the others' own tape IS this one */
 };
 
 struct TileStageArgs {
@@ -50,6 +52,8 @@ struct TileStageArgs {
     int heat_stride;           /* = image size in pixels */
     int* next_choices;         /* device counter (atomicMax): an upper bound on the min / max clauses of any tape this
                                 * stage pushes; sizes the next stage's choice array */
+    bool no_push;              /* last stage, float AND normals pass on the groups' tapes: write the groups' records only, push no tapes */
+    bool compiled_walk;        /* development (MPR_TILES_ASM=0): the compiled forward / backward walks instead of the assembly ones */
     int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
                                 * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */
 };
@@ -97,6 +101,11 @@ struct NormalArgs {
     unsigned long long* counters;
     const int* col_list;       /* multi-GPU: the 64 x 64 columns this rank owns (null: all) ... */
     int ncols;                 /* ... and how many */
+    /* last tile stage without tape pushing (TileStageArgs::no_push): the smallest tiles carry their group's tape, and a
+     * tile's decisions are applied while that tape is walked (null: every tile carries its own tape) */
+    const GroupInfo* groups;
+    const ulonglong2* choice_masks;
+    int choice_cap;
 };
 
 void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,

@@ -13,6 +13,13 @@
  * with division, square root, exp and log in line through the shared routines of
  * asm_float_bodies.hpp; the inverse trigonometric functions and sin / cos leave the block.
  * One wave per workgroup (LDS base 0 for the v_perm_b32 address trick).
+ *
+ * Decisions.  When the last tile stage pushed no tapes (TileStageArgs::no_push) a smallest tile carries its
+ * GROUP's tape, and its own tape — the one the reference walks here — is that tape with the tile's recorded
+ * min / max decisions applied (clauses the shortening dropped are walked for nothing).  The kernel then keeps
+ * the decisions of every pixel's tile as bit sets in LDS ({chose lhs, chose rhs} x 192 bits behind the slot
+ * file) and the min / max handlers go through L_dec, which overrides the comparison's outcome for the lanes
+ * whose tile decided that clause: the partials then come from the operand the tile's own tape would copy.
  */
 #include "asm_float_bodies.hpp"
 #include "kernel_common.hpp"
@@ -73,6 +80,7 @@ __device__ float nq_atan(float a, int isv)
  *   s[80:81] handler address  s[82:83] table base  s[84:85] block address  s86 clause word  s87 immediate
  *   s88 clause counter  s89 block base  s90 0x260  s96 0xff00  s[98:99] lanes holding the value (comp 3)
  *   s[70:71] return address of the shared routines, s[72:79] their entry points (div, sqrt, exp, log)
+ *   s64 decisions present  s65 min / max clauses met so far  s[66:67] L_dec  s[46:47] its return address
  *   v32 aA  v33 aB  v34 aO  v35 A  v36 B  v37 result (and previous result)  v38..v47 temporaries      */
 #define NQ_Q3 " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n"
 #define NQ_DISPATCH                                    \
@@ -148,15 +156,19 @@ __device__ float nq_atan(float a, int isv)
     "v_mul_f32 v40, v35, v36\n v_add_f32 v38, v38, v39\n v_cndmask_b32 v37, v38, v40, s[98:99]\n" NQ_END     \
     NQ_H(v, 17) NQ_IMM LDL NQ_AO WL                          /* MIN_IMM: b = (0, 0, 0, imm); av < imm ? a : b */ \
     "v_mov_b32 v39, s87\n v_cndmask_b32 v36, 0, v39, s[98:99]\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"        \
+    "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
     NQ_H(v, 18) LDL LDR NQ_AO WLR                            /* MIN: av < bv ? a : b */                      \
     "v_mov_b32_dpp v39, v36" NQ_Q3 "s_nop 1\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"                          \
+    "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
     NQ_H(v, 19) NQ_IMM LDL NQ_AO WL                          /* MAX_IMM: av >= imm ? a : b */                \
     "v_mov_b32 v39, s87\n v_cndmask_b32 v36, 0, v39, s[98:99]\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_ge_f32 vcc, v46, v39\n"        \
+    "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
     NQ_H(v, 20) LDL LDR NQ_AO WLR                                                                            \
     "v_mov_b32_dpp v39, v36" NQ_Q3 "s_nop 1\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_ge_f32 vcc, v46, v39\n"                          \
+    "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
     NQ_H(v, 21) NQ_IMM LDL NQ_AO WL                          /* a - imm: only the value */                   \
     "s_nop 0\n v_subrev_f32 v38, s87, v35\n v_cndmask_b32 v37, v35, v38, s[98:99]\n" NQ_END                  \
@@ -179,7 +191,8 @@ __device__ float nq_atan(float a, int isv)
     NQ_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"
 
 /* Walks the tape at tro[first] over the slot file at LDS offset 0; returns the result slot. */
-DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane, bool isv)
+DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane, bool isv,
+                                uint32_t decisions, uint32_t decb)
 {
     unsigned char* const myslot = smem + lane * 4;
     uint32_t blo = 0, bhi = 0;
@@ -190,14 +203,19 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
     const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
     float prev = 0.0f;
     uint32_t mode = 0;
+    uint32_t mmc = 0;                  /* min / max clauses met so far */
+    decisions = rdfirst(decisions);
 
     for (;;) {
         base = rdfirst(base);
         sj = rdfirst(sj);
         mode = rdfirst(mode);
+        mmc = rdfirst(mmc);
         asm volatile(
             "s_mov_b32 s89, %[base]\n"
             "s_mov_b32 s88, %[sj]\n"
+            "s_mov_b32 s64, %[dec]\n"
+            "s_mov_b32 s65, %[mmc]\n"
             "s_mov_b32 s90, 0x260\n"
             "s_mov_b32 s96, 0xff00\n"
             "s_mov_b32 s98, 0x88888888\n"
@@ -210,6 +228,7 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             "s_add_u32 s76, s82, L_exp_%=-L_pc_%=\n s_addc_u32 s77, s83, 0\n"
             "s_add_u32 s78, s82, L_log_%=-L_pc_%=\n s_addc_u32 s79, s83, 0\n"
             "s_add_u32 s68, s82, L_sincos_%=-L_pc_%=\n s_addc_u32 s69, s83, 0\n"
+            "s_add_u32 s66, s82, L_dec_%=-L_pc_%=\n s_addc_u32 s67, s83, 0\n"
             "s_add_u32 s82, s82, L_n0_0_%=-L_pc_%=\n"
             "s_addc_u32 s83, s83, 0\n"
             "s_cmp_eq_u32 %[mode], 0\n"
@@ -259,6 +278,32 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n"
             "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n"
             "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n"
+            /* a min / max clause: count it; when decisions are present, the lanes whose tile decided it take the chosen
+             * operand whatever the comparison said (vcc set: lhs).  Bits beyond the 192 kept per lane: undecided. */
+            "L_dec_%=:\n"
+            "s_add_u32 s65, s65, 1\n"
+            "s_cmp_eq_u32 s64, 0\n"
+            "s_cbranch_scc1 L_decret_%=\n"
+            "s_sub_u32 s40, s65, 1\n"
+            "s_lshr_b32 s41, s40, 6\n"
+            "s_cmp_ge_u32 s41, 3\n"
+            "s_cbranch_scc1 L_decret_%=\n"
+            "s_and_b32 s40, s40, 63\n"
+            "s_lshl_b32 s41, s41, 7\n"
+            "v_add_u32 v42, s41, %[decb]\n"
+            "ds_read_b64 v[38:39], v42\n"
+            "ds_read_b64 v[40:41], v42 offset:384\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_lshrrev_b64 v[38:39], s40, v[38:39]\n"
+            "v_lshrrev_b64 v[40:41], s40, v[40:41]\n"
+            "v_and_b32 v38, 1, v38\n"
+            "v_and_b32 v40, 1, v40\n"
+            "v_cmp_ne_u32 s[42:43], 0, v38\n"
+            "v_cmp_ne_u32 s[44:45], 0, v40\n"
+            "s_or_b64 vcc, vcc, s[42:43]\n"
+            "s_andn2_b64 vcc, vcc, s[44:45]\n"
+            "L_decret_%=:\n"
+            "s_setpc_b64 s[46:47]\n"
             "L_casin_%=:\n" NQ_CALLC("mpr_nq_asin")
             "L_cacos_%=:\n" NQ_CALLC("mpr_nq_acos")
             "L_catan_%=:\n" NQ_CALLC("mpr_nq_atan")
@@ -268,11 +313,12 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
             "s_mov_b32 %[dhi], s87\n"
             "s_mov_b32 %[base], s89\n"
             "s_mov_b32 %[sj], s88\n"
-            : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi)
+            "s_mov_b32 %[mmc], s65\n"
+            : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi), [mmc] "+&s"(mmc)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
-              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev)
+              [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev), [dec] "s"(decisions), [decb] "v"(decb)
             : "memory", "vcc", "scc",
-              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
               "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s98", "s99",
               "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
               /* what the called routines may use on top (NQ_CALLC) */
@@ -329,7 +375,7 @@ k_eval_normals_asm(NormalArgs a)
     const float vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
 
     /* deepest tile's tape (:1034-1066) */
-    int my_tape = 0;
+    int my_tape = 0, my_micro = -1;
     if (filled) {
         const int t64 = S / 64;
         const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
@@ -344,9 +390,52 @@ k_eval_normals_asm(NormalArgs a)
             } else {
                 const int micro = sn.next * 64 + (px % 16) / 4 + ((py % 16) / 4) * 4 + ((pz % 16) / 4) * 16;
                 my_tape = a.microtiles[micro].tape;
+                my_micro = micro;
             }
         }
     }
+    /* the last tile stage pushed no tapes: this smallest tile's own tape is its group's (my_tape) with these decisions */
+    unsigned long long dl0 = 0, dl1 = 0, dl2 = 0, dr0 = 0, dr1 = 0, dr2 = 0;
+    if (a.groups) {
+        /* one (group, tile) at a time — a footprint meets a handful: lane i fetches the group's i-th pair of masks, and
+         * the tile's bit of every mask is a ballot away (the float pass gets its decisions the same way) */
+        uint64_t pending = ballot(my_micro >= 0);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int micro = __builtin_amdgcn_readlane(my_micro, leader);
+            pending &= ~ballot(my_micro == micro);
+            const int g = micro >> 6, child = micro & 63;
+            const GroupInfo gi = a.groups[g];
+            if (!((gi.pushed >> child) & 1ull)) continue;
+            const ulonglong2* const m = a.choice_masks + (size_t)g * a.choice_cap;
+            const int n = gi.nchoices < 192 ? gi.nchoices : 192;
+            ulonglong2 w0 = make_ulonglong2(0ull, 0ull), w1 = w0, w2 = w0;
+            if (lane < n) w0 = m[lane];
+            if (n > 64) {
+                if (lane + 64 < n) w1 = m[lane + 64];
+                if (lane + 128 < n) w2 = m[lane + 128];
+            }
+            const uint64_t l0 = ballot((w0.x >> child) & 1ull), r0 = ballot((w0.y >> child) & 1ull);
+            uint64_t l1 = 0, r1 = 0, l2 = 0, r2 = 0;
+            if (n > 64) {
+                l1 = ballot((w1.x >> child) & 1ull);
+                r1 = ballot((w1.y >> child) & 1ull);
+                l2 = ballot((w2.x >> child) & 1ull);
+                r2 = ballot((w2.y >> child) & 1ull);
+            }
+            if (my_micro == micro) {
+                dl0 = l0; dr0 = r0; dl1 = l1; dr1 = r1; dl2 = l2; dr2 = r2;
+            }
+        }
+    }
+    unsigned char* const dec = smem + (size_t)a.nslots * 256;          /* [2][3][16 pixels] 64-bit words behind the slot file */
+    if (a.groups) {
+        unsigned long long* const pl = reinterpret_cast<unsigned long long*>(dec) + pix;
+        unsigned long long* const pr = reinterpret_cast<unsigned long long*>(dec + 384) + pix;
+        pl[0] = dl0; pl[16] = dl1; pl[32] = dl2;
+        pr[0] = dr0; pr[16] = dr1; pr[32] = dr2;
+    }
+    const uint32_t decb = (uint32_t)(uintptr_t)dec + (uint32_t)pix * 8u;
 
     const uint64_t* __restrict__ const tro = a.tape_ro;
     const uint64_t head0 = tro[0];
@@ -367,7 +456,7 @@ k_eval_normals_asm(NormalArgs a)
         if (comp == 1) *reinterpret_cast<float*>(myslot + sy * 256) = 1.0f;
         if (comp == 2) *reinterpret_cast<float*>(myslot + sz * 256) = 1.0f;
 
-        const uint32_t rslot = interp_normals_asm(tro, (uint32_t)(tape + 1), smem, lane, isv);
+        const uint32_t rslot = interp_normals_asm(tro, (uint32_t)(tape + 1), smem, lane, isv, a.groups ? 1u : 0u, decb);
         const float rr = *reinterpret_cast<const float*>(myslot + rslot * 256);
         if (mine) result = rr;
     }
@@ -386,7 +475,7 @@ void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
     const int fside = a.size / 4;
     const int groups = a.col_list ? a.ncols * 256 : fside * fside;
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_eval_normals_asm, dim3(groups), dim3(64), (size_t)a.nslots * 256, s, a);
+    hipLaunchKernelGGL(k_eval_normals_asm, dim3(groups), dim3(64), (size_t)a.nslots * 256 + (a.groups ? 768 : 0), s, a);
 }
 
 }  // namespace mprk

@@ -79,7 +79,7 @@ __device__ float jit_atan(float v) { return mpr_atanf(v); }
 constexpr int JIT_WORDS = 12;
 constexpr int JIT_ROW = 4 + 3 * JIT_WORDS;           /* dwords per row: meta, 3 pad, then three batches of {base x4, sel x4, mask x4} */
 struct JitRow { uint32_t n, flags; uint32_t base[JIT_WORDS], sel[JIT_WORDS], mask[JIT_WORDS]; };
-constexpr int JIT_ROWS = 40;               /* 32 opcodes (30: the translator's constant division), then min / max for decisions 64..127, 128..191 */
+constexpr int JIT_ROWS = 36;               /* 32 opcodes (30: the translator's constant division), then min / max for decisions 64..127 */
 struct JitTable { uint32_t w[JIT_ROWS][JIT_ROW]; };
 namespace jt {
 constexpr uint32_t NONE = 0x0C, CI = 0, O = 1, A = 2, R = 3;                 /* selector bytes */
@@ -88,8 +88,9 @@ constexpr uint32_t LITERAL = 255;
 constexpr uint32_t VOP2(uint32_t op, uint32_t vdst, uint32_t vsrc1, uint32_t src0) { return (op << 25) | (vdst << 17) | (vsrc1 << 9) | src0; }
 constexpr uint32_t MOV(uint32_t vdst, uint32_t src0) { return 0x7E000200u | (vdst << 17) | src0; }
 constexpr uint32_t CALL(uint32_t sgpr) { return 0xBE9E1E00u | sgpr; }        /* s_swappc_b64 s[30:31], s[sgpr:sgpr+1] */
-constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /* s_bitcmp1_b64 s[76:77] / s[78:79], <index>; decisions 64.. in s[80:83], 128.. in s[84:87] */
-constexpr int JIT_MAX_CHOICES = 192;
+constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /* s_bitcmp1_b64 s[76:77] / s[78:79], <index>; decisions 64..127 in s[48:49] / s[50:51] */
+constexpr uint32_t BITCMP_L1 = 0xBF0F0030u, BITCMP_R1 = 0xBF0F0032u;
+constexpr int JIT_MAX_CHOICES = 128;
 constexpr uint32_t CSELECT = 0x85EA80C1u;                                      /* s_cselect_b64 vcc, -1, 0 */
 constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21;
 constexpr uint32_t S_DIVC = 70, S_DIV = 52, S_SQRT = 54, S_EXP = 56, S_LOG = 58, S_SIN = 60, S_COS = 62, S_ASIN = 64, S_ACOS = 66, S_ATAN = 68;
@@ -158,10 +159,10 @@ constexpr JitRow minmax(uint32_t op, bool imm, bool group, uint32_t q = 0)
         b.ins(VOP2(V_MAX, 36, 0, VREG), NONE, R, R);
     }
     b.fixed(VOP2(op, 37, 36, VREG + 35));
-    b.bitcmp(BITCMP_L + 4 * q);
+    b.bitcmp(q ? BITCMP_L1 : BITCMP_L);
     b.fixed(CSELECT);
     b.ins(VOP2(V_CNDMASK, 37, 0, VREG + 37), NONE, A);                 /* v37 = chose lhs ? lhs : v37 */
-    b.bitcmp(BITCMP_R + 4 * q);
+    b.bitcmp(q ? BITCMP_R1 : BITCMP_R);
     b.fixed(CSELECT);
     if (imm) b.ins(VOP2(V_CNDMASK, 0, 38, VREG + 37), O);                /* out = chose rhs ? immediate : v37 */
     else b.ins(VOP2(V_CNDMASK, 0, 0, VREG + 37), O, R);
@@ -252,7 +253,7 @@ constexpr JitTable make_table(bool group)
 {
     JitTable t{};
     for (uint32_t op = 0; op < (uint32_t)JIT_ROWS; ++op) {
-        /* rows 32..35 / 36..39: MIN_LHS_IMM .. MAX_LHS_RHS whose decision is one of 64..127 / 128..191 */
+        /* rows 32..35: MIN_LHS_IMM .. MAX_LHS_RHS whose decision is one of 64..127 */
         const uint32_t mm = MPR_OP_MIN_LHS_IMM + (op - 32) % 4, q = 1 + (op - 32) / 4;
         const JitRow r = op < 32 ? row_of(op, group)
                                  : minmax(mm == MPR_OP_MIN_LHS_IMM || mm == MPR_OP_MIN_LHS_RHS ? V_MIN : V_MAX,
@@ -443,9 +444,9 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "v_mbcnt_lo_u32_b32 v53, s64, 0\n"
         "v_mbcnt_hi_u32_b32 v53, s65, v53\n"
         "v_add_u32 v53, s48, v53\n"
-        /* decisions 64..127 / 128..191 (group form): the rows whose compares name the next register pairs */
+        /* decisions 64..127 (group form): the rows whose compares name the second pair of registers */
         "v_lshrrev_b32 v60, 6, v53\n"
-        "v_min_u32 v60, 2, v60\n"                          /* (tile form: any number of min / max clauses, and rows 32.. are rows 17..20 again) */
+        "v_min_u32 v60, 1, v60\n"                          /* (tile form: any number of min / max clauses, and rows 32.. are rows 17..20 again) */
         "v_and_b32 v53, 63, v53\n"
         "v_cmp_ne_u32 vcc, 0, v60\n"
         "v_lshl_add_u32 v60, v60, 2, 11\n"                 /* row = opcode + 11 + 4 q */
@@ -597,15 +598,15 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
 }
 
 /* Run the code at `code` on (vx, vy, vz).  fresh bit 0: the region was just rewritten by this wavefront (invalidate the
- * instruction cache), bit 1: three prefetch loads are in flight behind the code's stores.  cl / cr: group form, the
- * child's `chose lhs` / `chose rhs` bits over the tape's min / max clauses.  NS: slots the kernel provides registers
+ * instruction cache), bit 1: three prefetch loads are in flight behind the code's stores.  decisions: group form, lane i
+ * holds the child's `chose lhs` / `chose rhs` bits at the tape's i-th and (64 + i)-th min / max clause.  NS: slots the kernel provides registers
  * for.  The register lists are what the generated code, the routines and the compiled leaf routines may touch. */
 #define JIT_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
 #define JIT_CLOBBER_BASE                                                                                                   \
     "memory", "vcc", "scc", "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s30", "s31", "s40", "s41", "s42", \
         "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",      \
         "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s90", "s91", "s92",      \
-        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s93", "s94", "s95", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",       \
+        "s76", "s77", "s78", "s79", "s93", "s94", "s95", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",       \
         JIT_V10(4), JIT_V10(5), JIT_V10(6), "v70", "v71"
 #define JIT_CLOBBER_40 "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", JIT_V10(8)
 #define JIT_CLOBBER_96 JIT_CLOBBER_40, JIT_V10(9), JIT_V10(10), JIT_V10(11), JIT_V10(12), JIT_V10(13), "v140", "v141", "v142", "v143"
@@ -638,9 +639,11 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     JIT_LEAF_ADDR(64, 65, "mpr_fj_asin") JIT_LEAF_ADDR(66, 67, "mpr_fj_acos") JIT_LEAF_ADDR(68, 69, "mpr_fj_atan") \
     JIT_ROUTINE_ADDR(70, 71, "L_divc")                                                                 \
     "s_mov_b32 s90, 0x260\n"                            /* class mask of the square root */           \
-    "s_mov_b64 s[76:77], %[cl]\n s_mov_b64 s[78:79], %[cr]\n"   /* group form: the child's min / max decisions 0..63 */ \
-    "s_mov_b64 s[80:81], %[cl1]\n s_mov_b64 s[82:83], %[cr1]\n" /* 64..127 */                           \
-    "s_mov_b64 s[84:85], %[cl2]\n s_mov_b64 s[86:87], %[cr2]\n" /* 128..191 */                          \
+    /* group form: the child's min / max decisions; lane i brings those of the tape's i-th and (64 + i)-th min / max:  \
+     * bit 0 chose lhs, bit 1 chose rhs, bits 2 / 3 the same for 64 + i (s[50:51] was the base of the addresses above) */ \
+    "v_and_b32 v35, 1, %[dec]\n v_and_b32 v36, 2, %[dec]\n v_and_b32 v37, 4, %[dec]\n v_and_b32 v38, 8, %[dec]\n"     \
+    "v_cmp_ne_u32 s[76:77], 0, v35\n v_cmp_ne_u32 s[78:79], 0, v36\n"                                   \
+    "v_cmp_ne_u32 s[48:49], 0, v37\n v_cmp_ne_u32 s[50:51], 0, v38\n"                                   \
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
     "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
     "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
@@ -671,20 +674,12 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "L_end_%=:\n"
 
 template <int NS>
-DEV float jit_run(const uint32_t* code, uint32_t fresh, float vx, float vy, float vz, uint64_t cl = 0, uint64_t cr = 0,
-                  uint64_t cl1 = 0, uint64_t cr1 = 0, uint64_t cl2 = 0, uint64_t cr2 = 0)
+DEV float jit_run(const uint32_t* code, uint32_t fresh, float vx, float vy, float vz, uint32_t decisions = 0)
 {
     const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
     fresh = rdfirst(fresh);
-    cl = rfl64(cl);
-    cr = rfl64(cr);
-    cl1 = rfl64(cl1);
-    cr1 = rfl64(cr1);
-    cl2 = rfl64(cl2);
-    cr2 = rfl64(cr2);
     float res;
-#define JIT_OPERANDS : [res] "=&v"(res) : [vx] "v"(vx), [vy] "v"(vy), [vz] "v"(vz), [clo] "s"(clo), [chi] "s"(chi), [fresh] "s"(fresh), [cl] "s"(cl), [cr] "s"(cr), \
-                       [cl1] "s"(cl1), [cr1] "s"(cr1), [cl2] "s"(cl2), [cr2] "s"(cr2)
+#define JIT_OPERANDS : [res] "=&v"(res) : [vx] "v"(vx), [vy] "v"(vy), [vz] "v"(vz), [clo] "s"(clo), [chi] "s"(chi), [fresh] "s"(fresh), [dec] "v"(decisions)
     if constexpr (NS <= 24) {
         asm volatile(JIT_ASM_TEXT JIT_OPERANDS : JIT_CLOBBER_BASE);
     } else if constexpr (NS <= 40) {
@@ -836,7 +831,8 @@ k_eval_voxels_jit(JitVoxelArgs j)
 /* ---- group form: a workgroup per group of 64 sibling tiles, one translation, every surviving child runs it ---- */
 constexpr int JIT_GROUP_WAVES = 4;
 template <int DIM, int NS>
-__global__ void __launch_bounds__(64 * JIT_GROUP_WAVES)
+/* registers: slots + 48; the bound keeps the compiler's own values from costing a wavefront of occupancy */
+__global__ void __launch_bounds__(64 * JIT_GROUP_WAVES, NS <= 24 ? 6 : NS <= 40 ? 5 : NS <= 96 ? 3 : 2)
 k_eval_voxels_jit_groups(JitVoxelArgs j)
 {
     __shared__ __attribute__((aligned(64))) uint32_t lds[JIT_LDS_DWORDS];
@@ -854,6 +850,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
      * 1 KB was). */
     uint32_t* const region = j.code + (size_t)blockIdx.x * j.region_dwords;
     __shared__ int next_child_lds;
+    __shared__ ulonglong2 more_masks[64];
     int* const next_child = &next_child_lds;
     uint32_t slot = 0;
     bool first_group = true;
@@ -886,11 +883,12 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             else asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
         }
         /* lane i: the decisions of the group's 64 tiles at its i-th min / max */
-        ulonglong2 m = make_ulonglong2(0ull, 0ull), m1 = m, m2 = m;
+        ulonglong2 m = make_ulonglong2(0ull, 0ull);
         if (lane < nch) m = j.choice_masks[(size_t)g * j.choice_cap + lane];
-        if (nch > 64) {
-            if (lane + 64 < nch) m1 = j.choice_masks[(size_t)g * j.choice_cap + 64 + lane];
-            if (lane + 128 < nch) m2 = j.choice_masks[(size_t)g * j.choice_cap + 128 + lane];
+        if (nch > 64 && threadIdx.x < 64) {
+            /* decisions 64..127 wait in LDS (registers held across the children's loop would cost a wave of occupancy) */
+            const int i = 64 + (int)threadIdx.x;
+            more_masks[threadIdx.x] = i < nch ? j.choice_masks[(size_t)g * j.choice_cap + i] : make_ulonglong2(0ull, 0ull);
         }
         __syncthreads();
         const unsigned long long t1 = j.dbg ? __builtin_readcyclecounter() : 0ull;
@@ -909,16 +907,13 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             const int cpos = (int)rdlane((uint32_t)position, (uint32_t)c);
             JitVoxel<DIM> vox;
             if (!vox.setup(a, cpos, lane)) continue;
-            const uint64_t cl = ballot((m.x >> c) & 1ull), cr = ballot((m.y >> c) & 1ull);
-            uint64_t cl1 = 0, cr1 = 0, cl2 = 0, cr2 = 0;
+            uint32_t decisions = (uint32_t)((m.x >> c) & 1ull) | ((uint32_t)((m.y >> c) & 1ull) << 1);
             if (nch > 64) {
-                cl1 = ballot((m1.x >> c) & 1ull);
-                cr1 = ballot((m1.y >> c) & 1ull);
-                cl2 = ballot((m2.x >> c) & 1ull);
-                cr2 = ballot((m2.y >> c) & 1ull);
+                const ulonglong2 m1 = more_masks[lane];
+                decisions |= ((uint32_t)((m1.x >> c) & 1ull) << 2) | ((uint32_t)((m1.y >> c) & 1ull) << 3);
             }
             if (j.debug & 1) continue;
-            const float res = jit_run<NS>(code, 0u, vox.vx, vox.vy, vox.vz, cl, cr, cl1, cr1, cl2, cr2);
+            const float res = jit_run<NS>(code, 0u, vox.vx, vox.vy, vox.vz, decisions);
             ++n_run;
             vox.finish(a, res);
         }

@@ -1,38 +1,69 @@
 /*
  * tape_builder.cpp — expression DAG -> flat tape of 64-bit clauses (host side of mpr::Tape).
  *
- * Follows the behaviour of the reference's Tape::Tape(const libfive::Tree&),
- * src/tape.cpp:21-228:
- *   - walk the DAG in orderedDfs() order (:25); constants never get a slot, X/Y/Z are
- *     remembered (:31-40); every supported operation records "last use" of its operands
- *     (:42-66)
- *   - slot 0 is reserved; output slots come LIFO from a free list, else a fresh slot, and at
- *     255 slots the builder reports "ran out of slots" and uses slot 0 (:68-87)
- *   - the head clause (op 0) carries the slots bound to X, Y, Z in bytes 1..3 (:89-99)
- *   - opcode variants: commutative ops keep the non-constant operand in lhs (:134-155);
- *     non-commutative ops have IMM_RHS / LHS_IMM / LHS_RHS forms (:157-176)
- *   - operand slots are released at their last use BEFORE the output slot is chosen, so
- *     in-place clauses (out == lhs) occur (:198-212)
- *   - the end clause (op 0) carries the root's slot in byte 1 (:214-221)
- * Unlike the reference this returns error information instead of printing to stderr.
+ * Produces the tape the reference's Tape::Tape(const libfive::Tree&) produces for the same DAG
+ * (src/tape.cpp:21-228) — the slot numbers are part of that, so the allocation ORDER is the
+ * reference's: slot 0 reserved; X, Y, Z (those that occur) take the first slots (:89-99, the head
+ * clause names them); operations are emitted in dependency order (:25); an operand's slot goes
+ * back on a LIFO free list at its last reader and BEFORE the reader's own output slot is taken,
+ * so in-place clauses occur (:198-212); a fresh slot only when the list is empty; at 255 slots
+ * the tape is marked "out of slots" and slot 0 is handed out (:68-87); constants never get a slot
+ * but become the immediate of the IMM form of their reader (:134-176); the end clause names the
+ * root's slot (:214-221).
+ *
+ * Shape: the DAG is numbered in dependency order once, and everything else is arrays over those
+ * numbers (operand numbers, last reader, slot) plus one table that maps a tree operation to its
+ * clause opcodes.  Errors come back in TapeBuild instead of going to stderr.
  */
 #include "tape_builder.hpp"
 
 #include <cstring>
-#include <map>
 #include <unordered_map>
 
 #include "../../include/mpr_clause.h"
 
 namespace mpr {
 namespace front {
+namespace {
 
-static uint32_t fbits(float f)
+/* how a tree operation is spelt in clauses */
+enum Shape : uint8_t { NOT_EMITTED, UNARY, COMMUTATIVE, ORDERED };
+struct Spelling {
+    Shape shape = NOT_EMITTED;
+    uint8_t plain = 0;        /* UNARY: the opcode; binary: both operands in slots */
+    uint8_t const_right = 0;  /* binary: lhs in a slot, rhs constant */
+    uint8_t const_left = 0;   /* ORDERED only: lhs constant, rhs in a slot */
+};
+struct SpellingTable {
+    Spelling of[LAST_OP];
+    constexpr SpellingTable() : of{}
+    {
+        constexpr struct { Op op; uint8_t code; } unary[] = {
+            {OP_SQUARE, MPR_OP_SQUARE_LHS}, {OP_SQRT, MPR_OP_SQRT_LHS}, {OP_NEG, MPR_OP_NEG_LHS}, {OP_SIN, MPR_OP_SIN_LHS},
+            {OP_COS, MPR_OP_COS_LHS}, {OP_ASIN, MPR_OP_ASIN_LHS}, {OP_ACOS, MPR_OP_ACOS_LHS}, {OP_ATAN, MPR_OP_ATAN_LHS},
+            {OP_EXP, MPR_OP_EXP_LHS}, {OP_ABS, MPR_OP_ABS_LHS}, {OP_LOG, MPR_OP_LOG_LHS}};
+        for (const auto& u : unary) of[u.op] = Spelling{UNARY, u.code, 0, 0};
+        /* a commutative operation with a constant keeps the other operand in lhs whichever side it was on */
+        of[OP_ADD] = Spelling{COMMUTATIVE, MPR_OP_ADD_LHS_RHS, MPR_OP_ADD_LHS_IMM, MPR_OP_ADD_LHS_IMM};
+        of[OP_MUL] = Spelling{COMMUTATIVE, MPR_OP_MUL_LHS_RHS, MPR_OP_MUL_LHS_IMM, MPR_OP_MUL_LHS_IMM};
+        of[OP_MIN] = Spelling{COMMUTATIVE, MPR_OP_MIN_LHS_RHS, MPR_OP_MIN_LHS_IMM, MPR_OP_MIN_LHS_IMM};
+        of[OP_MAX] = Spelling{COMMUTATIVE, MPR_OP_MAX_LHS_RHS, MPR_OP_MAX_LHS_IMM, MPR_OP_MAX_LHS_IMM};
+        of[OP_SUB] = Spelling{ORDERED, MPR_OP_SUB_LHS_RHS, MPR_OP_SUB_LHS_IMM, MPR_OP_SUB_IMM_RHS};
+        of[OP_DIV] = Spelling{ORDERED, MPR_OP_DIV_LHS_RHS, MPR_OP_DIV_LHS_IMM, MPR_OP_DIV_IMM_RHS};
+    }
+};
+constexpr SpellingTable SPELL;
+
+uint32_t bits_of(float f)
 {
     uint32_t u;
     std::memcpy(&u, &f, 4);
     return u;
 }
+
+constexpr int NONE = -1;
+
+}  // namespace
 
 TapeBuild build_tape(const Tree& tree)
 {
@@ -41,128 +72,111 @@ TapeBuild build_tape(const Tree& tree)
         tb.error = "empty tree";
         return tb;
     }
-    const std::vector<Tree> ordered = tree.orderedDfs();
 
-    std::vector<const Node*> ordered_fast;
-    ordered_fast.reserve(ordered.size());
-    std::unordered_map<const Node*, const Node*> last_used;
-    const Node* axes_used[3] = {nullptr, nullptr, nullptr};
-
-    for (auto& c : ordered) {
-        switch (c->op) {
-            case CONSTANT: continue;
-            case VAR_X: axes_used[0] = c.id(); break;
-            case VAR_Y: axes_used[1] = c.id(); break;
-            case VAR_Z: axes_used[2] = c.id(); break;
-            case OP_ADD: case OP_MUL: case OP_MIN: case OP_MAX: case OP_SUB: case OP_DIV:
-                last_used[c->rhs.get()] = c.id();
-                /* FALLTHROUGH */
-            case OP_SQUARE: case OP_SQRT: case OP_NEG: case OP_SIN: case OP_COS: case OP_ASIN:
-            case OP_ACOS: case OP_ATAN: case OP_EXP: case OP_ABS: case OP_LOG:
-                last_used[c->lhs.get()] = c.id();
-                ordered_fast.push_back(c.id());
-                break;
-            default:
-                tb.warnings += "unsupported opcode " + std::to_string((int)c->op) + "; ";
-                tb.unsupported++;
-                break;
+    /* ---- number the DAG in dependency order ---- */
+    const std::vector<Tree> order = tree.orderedDfs();
+    const int n = (int)order.size();
+    std::unordered_map<const Node*, int> number;
+    number.reserve((size_t)n * 2);
+    for (int i = 0; i < n; ++i) number.emplace(order[(size_t)i].id(), i);
+    auto number_of = [&](const NodePtr& p) {
+        if (!p) return NONE;
+        const auto it = number.find(p.get());
+        return it == number.end() ? NONE : it->second;
+    };
+    std::vector<int> left((size_t)n, NONE), right((size_t)n, NONE);
+    std::vector<int> last_reader((size_t)n, NONE);      /* the last emitted operation that reads this node */
+    std::vector<int> emitted;
+    int axis_node[3] = {NONE, NONE, NONE};
+    for (int i = 0; i < n; ++i) {
+        const Node* const node = order[(size_t)i].id();
+        if (node->op == CONSTANT) continue;
+        if (node->op >= VAR_X && node->op <= VAR_Z) {
+            axis_node[node->op - VAR_X] = i;
+            continue;
         }
+        const Shape shape = node->op < LAST_OP ? SPELL.of[node->op].shape : NOT_EMITTED;
+        if (shape == NOT_EMITTED) {
+            tb.warnings += "unsupported opcode " + std::to_string((int)node->op) + "; ";
+            tb.unsupported++;
+            continue;
+        }
+        left[(size_t)i] = number_of(node->lhs);
+        right[(size_t)i] = shape == UNARY ? NONE : number_of(node->rhs);
+        /* (the rhs is recorded first: when both operands are one node the result is the same either way) */
+        if (right[(size_t)i] != NONE) last_reader[(size_t)right[(size_t)i]] = i;
+        if (left[(size_t)i] != NONE) last_reader[(size_t)left[(size_t)i]] = i;
+        emitted.push_back(i);
     }
 
-    std::vector<uint8_t> free_slots;
-    std::unordered_map<const Node*, uint8_t> bound_slots;
-    unsigned num_slots = 1;
-
-    auto get_slot = [&](const Node* id) -> uint8_t {
-        uint8_t out = 0;
-        if (!free_slots.empty()) {
-            out = free_slots.back();
-            free_slots.pop_back();
-        } else if (num_slots == 255) {
+    /* ---- slots ---- */
+    std::vector<int> slot_of((size_t)n, NONE);
+    std::vector<uint8_t> returned;                     /* LIFO */
+    unsigned slots_made = 1;                           /* slot 0 is nobody's */
+    auto take_slot = [&](int node) {
+        unsigned s = 0;
+        if (!returned.empty()) {
+            s = returned.back();
+            returned.pop_back();
+        } else if (slots_made == 255) {
             tb.slots_exhausted = true;
         } else {
-            out = (uint8_t)num_slots++;
+            s = slots_made++;
         }
-        bound_slots[id] = out;
-        return out;
+        slot_of[(size_t)node] = (int)s;
+        return s;
     };
-    auto get_reg = [&](const Node* n) -> uint8_t {
-        auto it = bound_slots.find(n);
-        if (it != bound_slots.end()) return it->second;
+    auto slot_read = [&](int node) -> uint32_t {
+        if (node != NONE && slot_of[(size_t)node] != NONE) return (uint32_t)slot_of[(size_t)node];
         tb.warnings += "unbound operand; ";
         return 0;
     };
+    auto is_constant = [&](int node) { return node != NONE && order[(size_t)node]->op == CONSTANT; };
+    auto constant_bits = [&](int node) { return bits_of(order[(size_t)node]->value); };
 
     uint32_t axis_slot[3] = {0, 0, 0};
-    for (unsigned i = 0; i < 3; ++i)
-        if (axes_used[i] != nullptr) axis_slot[i] = get_slot(axes_used[i]);
-    tb.clauses.reserve(ordered_fast.size() + 2);
+    for (int k = 0; k < 3; ++k)
+        if (axis_node[k] != NONE) axis_slot[k] = take_slot(axis_node[k]);
+    tb.clauses.reserve(emitted.size() + 2);
     tb.clauses.push_back(mpr_cl_make(0, axis_slot[0], axis_slot[1], axis_slot[2], 0));
 
-    for (const Node* c : ordered_fast) {
-        uint32_t op = 0, lhs = 0, rhs = 0, imm = 0;
-        const bool lc = c->lhs && c->lhs->op == CONSTANT;
-        const bool rc = c->rhs && c->rhs->op == CONSTANT;
-        auto unary = [&](uint32_t o) { op = o; lhs = get_reg(c->lhs.get()); };
-        auto commutative = [&](uint32_t o_imm, uint32_t o_rhs) {
-            if (lc) { op = o_imm; lhs = get_reg(c->rhs.get()); imm = fbits(c->lhs->value); }
-            else if (rc) { op = o_imm; lhs = get_reg(c->lhs.get()); imm = fbits(c->rhs->value); }
-            else { op = o_rhs; lhs = get_reg(c->lhs.get()); rhs = get_reg(c->rhs.get()); }
-        };
-        auto noncommutative = [&](uint32_t o_lhs_imm, uint32_t o_imm_rhs, uint32_t o_lhs_rhs) {
-            if (lc) { op = o_imm_rhs; rhs = get_reg(c->rhs.get()); imm = fbits(c->lhs->value); }
-            else if (rc) { op = o_lhs_imm; lhs = get_reg(c->lhs.get()); imm = fbits(c->rhs->value); }
-            else { op = o_lhs_rhs; lhs = get_reg(c->lhs.get()); rhs = get_reg(c->rhs.get()); }
-        };
-        switch (c->op) {
-            case OP_SQUARE: unary(MPR_OP_SQUARE_LHS); break;
-            case OP_SQRT: unary(MPR_OP_SQRT_LHS); break;
-            case OP_NEG: unary(MPR_OP_NEG_LHS); break;
-            case OP_SIN: unary(MPR_OP_SIN_LHS); break;
-            case OP_COS: unary(MPR_OP_COS_LHS); break;
-            case OP_ASIN: unary(MPR_OP_ASIN_LHS); break;
-            case OP_ACOS: unary(MPR_OP_ACOS_LHS); break;
-            case OP_ATAN: unary(MPR_OP_ATAN_LHS); break;
-            case OP_EXP: unary(MPR_OP_EXP_LHS); break;
-            case OP_ABS: unary(MPR_OP_ABS_LHS); break;
-            case OP_LOG: unary(MPR_OP_LOG_LHS); break;
-            case OP_ADD: commutative(MPR_OP_ADD_LHS_IMM, MPR_OP_ADD_LHS_RHS); break;
-            case OP_MUL: commutative(MPR_OP_MUL_LHS_IMM, MPR_OP_MUL_LHS_RHS); break;
-            case OP_MIN: commutative(MPR_OP_MIN_LHS_IMM, MPR_OP_MIN_LHS_RHS); break;
-            case OP_MAX: commutative(MPR_OP_MAX_LHS_IMM, MPR_OP_MAX_LHS_RHS); break;
-            case OP_SUB:
-                noncommutative(MPR_OP_SUB_LHS_IMM, MPR_OP_SUB_IMM_RHS, MPR_OP_SUB_LHS_RHS);
-                break;
-            case OP_DIV:
-                noncommutative(MPR_OP_DIV_LHS_IMM, MPR_OP_DIV_IMM_RHS, MPR_OP_DIV_LHS_RHS);
-                break;
-            default: break;
+    /* ---- one clause per emitted operation ---- */
+    for (const int i : emitted) {
+        const Spelling& sp = SPELL.of[order[(size_t)i]->op];
+        const int a = left[(size_t)i], b = right[(size_t)i];
+        uint32_t opcode = sp.plain, lhs = 0, rhs = 0, imm = 0;
+        if (sp.shape == UNARY) {
+            lhs = slot_read(a);
+        } else if (is_constant(a)) {
+            opcode = sp.const_left;
+            imm = constant_bits(a);
+            if (sp.shape == COMMUTATIVE) lhs = slot_read(b);
+            else rhs = slot_read(b);
+        } else if (is_constant(b)) {
+            opcode = sp.const_right;
+            imm = constant_bits(b);
+            lhs = slot_read(a);
+        } else {
+            lhs = slot_read(a);
+            rhs = slot_read(b);
         }
-
-        /* release operand slots at their last use, before choosing the output slot */
-        for (const Node* h : {c->lhs.get(), c->rhs.get()}) {
-            if (h != nullptr && h->op != CONSTANT) {
-                auto lu = last_used.find(h);
-                if (lu != last_used.end() && lu->second == c) {
-                    auto it = bound_slots.find(h);
-                    if (it != bound_slots.end()) {
-                        free_slots.push_back(it->second);
-                        bound_slots.erase(it);
-                    }
-                }
+        /* operands read here for the last time give their slots back first: the output may take one of them */
+        for (const int operand : {a, b}) {
+            if (operand == NONE || is_constant(operand)) continue;
+            if (last_reader[(size_t)operand] == i && slot_of[(size_t)operand] != NONE) {
+                returned.push_back((uint8_t)slot_of[(size_t)operand]);
+                slot_of[(size_t)operand] = NONE;
             }
         }
-        const uint32_t out = get_slot(c);
-        tb.clauses.push_back(mpr_cl_make(op, out, lhs, rhs, imm));
+        const uint32_t out = take_slot(i);
+        tb.clauses.push_back(mpr_cl_make(opcode, out, lhs, rhs, imm));
     }
 
-    /* end clause: result slot of the root.  A root that is a bare constant or axis has no
-     * clause of its own; an axis reads its bound slot, a constant has none (slot 0). */
-    const Node* root = ordered.back().id();
-    uint32_t root_slot = 0;
-    if (root->op != CONSTANT) root_slot = get_reg(root);
+    /* end clause: the root's slot.  A root that is a bare axis reads the axis' slot; a bare constant has none (0). */
+    const int root = n - 1;
+    const uint32_t root_slot = is_constant(root) ? 0u : slot_read(root);
     tb.clauses.push_back(mpr_cl_make(0, root_slot, 0, 0, 0));
-    tb.num_slots = (int)num_slots;
+    tb.num_slots = (int)slots_made;
     return tb;
 }
 
