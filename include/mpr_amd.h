@@ -99,7 +99,10 @@ typedef struct mpr_ctx_options {
     int32_t device;            /* HIP device ordinal */
     int32_t image_size_px;     /* S; must be a multiple of 64 */
     int64_t pool_clauses;      /* tape pool capacity in clauses; 0 = MPR_NUM_SUBTAPES_BIG*64
-                                  (inc/parameters.hpp:18-22, BIG_SERVER build) */
+                                  (inc/parameters.hpp:18-22, BIG_SERVER build): 3.28 GB of device
+                                  memory per context.  A pool that runs out is not an error: the tiles
+                                  concerned keep their parents' tapes (src/context.cu:336-347) and
+                                  mpr_counters::pool_overflowed is set */
     int32_t flags;             /* MPR_CTX_* */
 } mpr_ctx_options;
 #define MPR_CTX_TIMING 1       /* record HIP events around every kernel (mpr_get_timings) */
