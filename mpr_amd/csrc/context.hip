@@ -82,7 +82,6 @@ struct mpr_context {
     uint32_t* jit_code = nullptr;      /* executable (HSA), one region per wavefront of the float pass */
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
-    unsigned long long* jit_dbg = nullptr;   /* MPR_JIT_DEBUG & 16: cycle counts of the float pass, printed when the context goes */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
     /* Frames whose last tile stage pushes no tapes (TileStageArgs::no_push): possible when both the float and the normals
      * pass run on the groups' tapes, decided from what the LAST frame of the same tape and view measured (a push-mode
@@ -110,7 +109,6 @@ struct mpr_context {
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
-    int jit_debug = 0;                 /* MPR_JIT_DEBUG (development): 1 = translate only, 2 = translate once per wavefront */
     int jit_grid_cache[2][2][4] = {};  /* workgroups the device holds, per form (tile / group), dimension and slot class */
     bool voxel_jit_tiles = false;      /* MPR_VOXEL_JIT=2: generated code per smallest tile where the group form is not possible (development;
                                           slower than the interpreter for short tapes: a translation per tile).  Brute-force frames always use it:
@@ -302,13 +300,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; }
     if (const char* e = getenv("MPR_VOXEL_GROUPS")) { c->voxel_groups = atoi(e) != 0; c->groups_always = atoi(e) == 2; }
-    if (const char* e = getenv("MPR_JIT_DEBUG")) c->jit_debug = atoi(e);
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
     if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
-    if (c->jit_debug & 16) {
-        if (hipMalloc((void**)&c->jit_dbg, 64) == hipSuccess) (void)hipMemset(c->jit_dbg, 0, 64);
-        else c->jit_dbg = nullptr;
-    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, opt->device) == hipSuccess) c->cus = prop.multiProcessorCount;
@@ -402,14 +395,6 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->groups) (void)hipFree(c->groups);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
-    if (c->jit_dbg) {
-        unsigned long long h[8] = {0};
-        if (hipMemcpy(h, c->jit_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[5])
-            fprintf(stderr, "jit float pass, per wavefront and launch: %.0f cycles, %.0f translating (%.1f tapes, %.0f each), %.0f in generated code (%.1f tiles, %.0f each)\n",
-                    (double)h[2] / h[5], (double)h[0] / h[5], (double)h[3] / h[5], h[3] ? (double)h[0] / h[3] : 0.0, (double)h[1] / h[5], (double)h[4] / h[5],
-                    h[4] ? (double)h[1] / h[4] : 0.0);
-        (void)hipFree(c->jit_dbg);
-    }
     if (c->num_active) (void)hipFree(c->num_active);
     if (c->zs_hist) (void)hipFree(c->zs_hist);
     if (c->zs_cursor) (void)hipFree(c->zs_cursor);
@@ -816,12 +801,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                     mprk::VoxelArgs gv = v;
                     gv.tiles = c->tiles[group_stage];
                     gv.count = group_count;
-                    mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)region, (int)slot_dw, (int)nslot, grid, c->jit_debug, (int)tape->clauses.size(), c->groups,
-                                                 c->choice_masks, group_cap, (c->jit_debug & 16) ? c->jit_dbg : nullptr);
+                    mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)region, (int)slot_dw, (int)nslot, grid, (int)tape->clauses.size(), c->groups,
+                                                 c->choice_masks, group_cap);
                     jitted = true;
                 } else if (c->jit_code && !group_form && (brute || c->voxel_jit_tiles)) {
-                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, 1, grid, c->jit_debug, (int)tape->clauses.size(), nullptr,
-                                                 nullptr, 0, (c->jit_debug & 16) ? c->jit_dbg : nullptr);
+                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, 1, grid, (int)tape->clauses.size(), nullptr,
+                                                 nullptr, 0);
                     jitted = true;
                 }
             }

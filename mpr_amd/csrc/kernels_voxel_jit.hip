@@ -754,12 +754,10 @@ struct JitVoxelArgs {
     uint32_t* code;            /* executable; one region per wavefront (tile form) / workgroup (group form) */
     uint32_t region_dwords;    /* code (group form: `slots` pieces of slot_dwords), then 320 dwords the translator dumps into */
     uint32_t slot_dwords, slots;
-    int debug;                 /* development (MPR_JIT_DEBUG): 1 = translate only, 2 = translate each wavefront's first tape only, 8 = no prefetch */
     int tape_len;              /* words of the root tape at pool[0] */
     const GroupInfo* groups;   /* group form: the tape each group of 64 siblings walked, and their min / max decisions */
     const ulonglong2* choice_masks;
     int choice_cap;
-    unsigned long long* dbg;   /* development (MPR_JIT_DEBUG & 16): cycles in translation / generated code / all, counts */
 };
 
 /* ---- tile form: a wavefront per smallest tile, each with its own tape ------------------------------------------ */
@@ -778,8 +776,6 @@ k_eval_voxels_jit(JitVoxelArgs j)
     const uint64_t* __restrict__ const tro = a.tape_ro;
     const uint64_t head0 = tro[0];
     int cached_tape = -1;
-    unsigned long long c_tr = 0, c_run = 0, n_tr = 0, n_run = 0;
-    const unsigned long long t_begin = j.dbg ? __builtin_readcyclecounter() : 0ull;
 
     for (int run = blockIdx.x; run * JIT_RUN < a.count; run += gridDim.x) {
         for (int k = 0; k < JIT_RUN; ++k) {
@@ -790,15 +786,12 @@ k_eval_voxels_jit(JitVoxelArgs j)
             JitVoxel<DIM> vox;
             if (!vox.setup(a, position, lane)) continue;
             uint32_t fresh = 0;
-            const unsigned long long t0 = j.dbg ? __builtin_readcyclecounter() : 0ull;
-            if (tape != cached_tape && !((j.debug & 2) && cached_tape != -1)) {
-                ++n_tr;
+            if (tape != cached_tape) {
                 (void)jit_translate(tro, (uint32_t)(tape + 1), head0, code, trash_off, lds, lane);
                 cached_tape = tape;
                 fresh = 1;
             }
-            if (j.debug & 1) continue;
-            if (!(j.debug & 8)) {
+            {
                 /* the next tile's tape travels while this one runs */
                 int nt = tile_index + 1;
                 if (k + 1 == JIT_RUN) nt = (run + (int)gridDim.x) * JIT_RUN;
@@ -807,24 +800,9 @@ k_eval_voxels_jit(JitVoxelArgs j)
                 jit_prefetch_tape(tro, ntape, j.tape_len, (uint32_t)(uintptr_t)(lds + JIT_LDS_PFDUMP), lane);
                 fresh |= 2u;                              /* three loads are in flight behind the code's stores */
             }
-            const unsigned long long t1 = j.dbg ? __builtin_readcyclecounter() : 0ull;
             const float res = jit_run<NS>(code, fresh, vox.vx, vox.vy, vox.vz);
-            if (j.dbg) {
-                const unsigned long long t2 = __builtin_readcyclecounter();
-                c_tr += t1 - t0;
-                c_run += t2 - t1;
-                ++n_run;
-            }
             vox.finish(a, res);
         }
-    }
-    if (j.dbg && lane == 0) {
-        atomicAdd(&j.dbg[0], c_tr);
-        atomicAdd(&j.dbg[1], c_run);
-        atomicAdd(&j.dbg[2], (unsigned long long)__builtin_readcyclecounter() - t_begin);
-        atomicAdd(&j.dbg[3], n_tr);
-        atomicAdd(&j.dbg[4], n_run);
-        atomicAdd(&j.dbg[5], 1ull);
     }
 }
 
@@ -857,8 +835,6 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
     const uint64_t* __restrict__ const tro = a.tape_ro;
     const uint64_t head0 = tro[0];
     const int ngroups = (a.count + 63) / 64;
-    unsigned long long c_tr = 0, c_run = 0, n_tr = 0, n_run = 0;
-    const unsigned long long t_begin = j.dbg ? __builtin_readcyclecounter() : 0ull;
 
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
         /* the 64 siblings as the last compaction left them: position -1 = empty, filled or hidden */
@@ -870,12 +846,10 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
         const GroupInfo gi = j.groups[g];
         const int gtape = __builtin_amdgcn_readfirstlane(gi.tape);
         const int nch = __builtin_amdgcn_readfirstlane(gi.nchoices);
-        const unsigned long long t0 = j.dbg ? __builtin_readcyclecounter() : 0ull;
         if (!first_group) slot = slot + 1 == j.slots ? 0 : slot + 1;
         first_group = false;
         uint32_t* const code = region + (size_t)slot * j.slot_dwords;
         if (wave == 0) {
-            ++n_tr;
             if (lane == 0) *next_child = 0;
             const uint32_t trash_off = (uint32_t)((j.region_dwords - 320 - slot * j.slot_dwords) * 4u) + (uint32_t)lane * 16u;
             (void)jit_translate(tro, (uint32_t)(gtape + 1), head0, code, trash_off, lds, lane);
@@ -891,7 +865,6 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             more_masks[threadIdx.x] = i < nch ? j.choice_masks[(size_t)g * j.choice_cap + i] : make_ulonglong2(0ull, 0ull);
         }
         __syncthreads();
-        const unsigned long long t1 = j.dbg ? __builtin_readcyclecounter() : 0ull;
         /* front to back: children with the larger z first (lane = x + 4 y + 16 z); a wavefront takes the next child
          * when it is done with its last one (hidden children cost nothing, the others differ little) */
         const int nalive = __popcll(alive);
@@ -912,25 +885,10 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
                 const ulonglong2 m1 = more_masks[lane];
                 decisions |= ((uint32_t)((m1.x >> c) & 1ull) << 2) | ((uint32_t)((m1.y >> c) & 1ull) << 3);
             }
-            if (j.debug & 1) continue;
             const float res = jit_run<NS>(code, 0u, vox.vx, vox.vy, vox.vz, decisions);
-            ++n_run;
             vox.finish(a, res);
         }
-        if (j.dbg) {
-            const unsigned long long t2 = __builtin_readcyclecounter();
-            c_tr += t1 - t0;
-            c_run += t2 - t1;
-        }
         __syncthreads();                                  /* the region is rewritten for the next group */
-    }
-    if (j.dbg && lane == 0) {
-        atomicAdd(&j.dbg[0], c_tr);
-        atomicAdd(&j.dbg[1], c_run);
-        atomicAdd(&j.dbg[2], (unsigned long long)__builtin_readcyclecounter() - t_begin);
-        atomicAdd(&j.dbg[3], n_tr);
-        atomicAdd(&j.dbg[4], n_run);
-        atomicAdd(&j.dbg[5], 1ull);
     }
 }
 
@@ -981,7 +939,7 @@ int jit_grid(int dim, int nslots, int cus, bool group)
                                                                                                              : jit_grid_of<2, 192>(cus, group);
 }
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
-                            int debug, int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, unsigned long long* dbg)
+                            int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap)
 {
     if (a.count <= 0) return;
     JitVoxelArgs j;
@@ -990,12 +948,10 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
     j.region_dwords = region_dwords;
     j.slot_dwords = (uint32_t)slot_dwords;
     j.slots = (uint32_t)slots;
-    j.debug = debug;
     j.tape_len = tape_len;
     j.groups = groups;
     j.choice_masks = choice_masks;
     j.choice_cap = choice_cap;
-    j.dbg = dbg;
     const int ns = jit_slot_class(a.nslots);
     if (groups) {
         const dim3 g(std::min(grid, (a.count + 63) / 64)), b(64 * JIT_GROUP_WAVES);

@@ -209,19 +209,22 @@ def test_planned_gather_through_the_renderer(mpr, tapes):
         tpr.plan(tape, T)
         rs.append(tpr)
     assert all(np.array_equal(rs[0].owner, t.owner) for t in rs) and rs[0].planned
-    # frame, by hand in the order render() uses, with the collective emulated after all packs exist
-    for r, t in enumerate(rs):
-        ctxs[r].render3D_part(tape, T, t.owner, r, blocking=False)
-        ctxs[r].pack_planned(t.send_ptr)
-    for r, t in enumerate(rs):
-        for o, u in enumerate(rs):
-            ctxs[o].sync()
-            with torch.cuda.stream(torch.cuda.ExternalStream(ctxs[r].stream)):
-                t.recv[o * t.per_rank:(o + 1) * t.per_rank].copy_(u.send)
-        ctxs[r].unpack_planned(t.recv_ptr)
-        ctxs[r].sync()
-        assert np.array_equal(ctxs[r].image, want_h)
-        assert np.array_equal(ctxs[r].normals, want_n)
+    # frames, by hand in the order render() uses, with the collective emulated after all packs exist; from the second
+    # frame of a rank's share on, the last tile stage pushes no tapes (same tape, view and partition as the frame before)
+    for frame in range(3):
+        for r, t in enumerate(rs):
+            ctxs[r].render3D_part(tape, T, t.owner, r, blocking=False)
+            ctxs[r].pack_planned(t.send_ptr)
+        for r, t in enumerate(rs):
+            for o, u in enumerate(rs):
+                ctxs[o].sync()
+                with torch.cuda.stream(torch.cuda.ExternalStream(ctxs[r].stream)):
+                    t.recv[o * t.per_rank:(o + 1) * t.per_rank].copy_(u.send)
+            ctxs[r].unpack_planned(t.recv_ptr)
+            ctxs[r].sync()
+            assert np.array_equal(ctxs[r].image, want_h)
+            assert np.array_equal(ctxs[r].normals, want_n)
+    assert not any(c.last_stage_pushed() for c in ctxs)
     for c in ctxs:
         c.close()
 
