@@ -118,6 +118,9 @@ struct mpr_context {
     size_t groups_cap = 0;
     ulonglong2* choice_masks = nullptr;
     size_t masks_cap = 0;
+    unsigned char* group_alive = nullptr;  /* per group: a tile left for the float pass (written by the last compaction) */
+    int* group_list = nullptr;             /* those groups in list order, then their number (k_list_alive_groups) */
+    size_t group_alive_cap = 0, group_list_cap = 0;
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
@@ -350,7 +353,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     }
     CT(hipMalloc((void**)&c->pool, ((size_t)c->pool_cap + 128) * sizeof(uint64_t)));   /* + slack: walkers fetch 64-word blocks */
     CT(hipMalloc((void**)&c->tape_index, 2 * sizeof(unsigned long long)));   /* [0] index, [1] sticky overflow flag of the frame */
-    CT(hipMalloc((void**)&c->num_active, 8 * sizeof(int)));      /* [0..2] counts, [3] workgroups done, [4] choices the next stage needs */
+    CT(hipMalloc((void**)&c->num_active, 8 * sizeof(int)));      /* [0..2] counts, [3] workgroups done, [4] choices the next stage needs, [5..6] tape lengths of the last stage, [7] the float pass's next group */
     CT(hipMalloc((void**)&c->zs_hist, 1024 * sizeof(int)));
     CT(hipMalloc((void**)&c->zs_cursor, 1024 * sizeof(int)));
     CT(hipMemsetAsync(c->zs_hist, 0, 1024 * sizeof(int), c->stream));
@@ -393,6 +396,8 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->tape_index) (void)hipFree(c->tape_index);
     free_executable(c->jit_code);
     if (c->groups) (void)hipFree(c->groups);
+    if (c->group_alive) (void)hipFree(c->group_alive);
+    if (c->group_list) (void)hipFree(c->group_list);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->num_active) (void)hipFree(c->num_active);
@@ -644,6 +649,10 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             if (rc) return rc;
             rc = ensure_buffer(&c->choice_masks, &c->masks_cap, ng * (size_t)std::max(stage_cap, 1));
             if (rc) return rc;
+            rc = ensure_buffer(&c->group_alive, &c->group_alive_cap, ng);
+            if (rc) return rc;
+            rc = ensure_buffer(&c->group_list, &c->group_list_cap, ng + 1);
+            if (rc) return rc;
             group_form = true;
             group_stage = i;
             group_count = count;
@@ -713,12 +722,13 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
                                          c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub),
-                                         c->num_active + 4);
+                                         c->num_active + 4, groups_now ? c->group_alive : nullptr);
         } else if (count > 0) {
             TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
             mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                           c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub));
+                                           c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub), groups_now ? c->group_alive : nullptr);
         }
+        if (groups_now && count > 0) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
         if (count == 0) {
             /* copy_filled rides in the compaction's launch; no compaction, a launch of its own */
             TimedScope ts(c, "copy_filled");
@@ -802,11 +812,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                     gv.tiles = c->tiles[group_stage];
                     gv.count = group_count;
                     mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)region, (int)slot_dw, (int)nslot, grid, (int)tape->clauses.size(), c->groups,
-                                                 c->choice_masks, group_cap);
+                                                 c->choice_masks, group_cap, c->num_active + 7, c->group_list);
                     jitted = true;
                 } else if (c->jit_code && !group_form && (brute || c->voxel_jit_tiles)) {
                     mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, 1, grid, (int)tape->clauses.size(), nullptr,
-                                                 nullptr, 0);
+                                                 nullptr, 0, nullptr, nullptr);
                     jitted = true;
                 }
             }

@@ -600,7 +600,8 @@ template <int DIM, bool LAST>
 __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
-                    mpr_tile_node* __restrict__ out, int* __restrict__ pub, int seq, CopyFilled cf)
+                    mpr_tile_node* __restrict__ out, int* __restrict__ pub, int seq, CopyFilled cf,
+                    unsigned char* __restrict__ group_alive)
 {
     if ((int)blockIdx.x >= cf.first_block) {
         copy_filled_block<DIM>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
@@ -623,6 +624,7 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
         }
     }
     const uint64_t mask = ballot(active);
+    if (LAST && group_alive && lane == 0 && valid) group_alive[gidx >> 6] = mask != 0;      /* float pass, group form: groups worth a visit */
     /* one atomic per 1024 tiles: same-address atomics serialise at ~12 ns each on this part, and the
      * last stage of a 1024^3 frame has 1.3 M tiles.  Waves keep their order inside the block, so
      * the survivors of one sibling group (= one wave) stay contiguous. */
@@ -749,7 +751,8 @@ k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __rest
 
 template <bool LAST>
 __global__ void __launch_bounds__(1024)
-k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restrict__ cursor, mpr_tile_node* __restrict__ out)
+k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restrict__ cursor, mpr_tile_node* __restrict__ out,
+             unsigned char* __restrict__ group_alive)
 {
     __shared__ int lh[ZS_MAX_BINS], gb[ZS_MAX_BINS];
     for (int i = threadIdx.x; i < tps; i += blockDim.x) lh[i] = 0;
@@ -763,6 +766,10 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
     n.next = -1;
     if (valid) n = tiles[gidx];
     const bool active = valid && n.position != -1;
+    if (LAST && group_alive) {
+        const uint64_t any = ballot(active);
+        if (lane == 0 && valid) group_alive[gidx >> 6] = any != 0;
+    }
     int z = 0, r = 0;
     if (active) {
         z = unpack(n.position, tps).z;
@@ -1033,26 +1040,56 @@ static CopyFilled copy_filled_args(const int* prev, int* next, int size, int fir
     *extra = (unsigned)(((long long)size * size + 1023) / 1024);
     return cf;
 }
+/* The groups of the last tile stage that still have a tile for the float pass, in list order (front to back): the float
+ * pass's workgroups take them one at a time with one atomic each, and an atomic per EMPTY group — most of a large frame's
+ * groups — would be what bounds the kernel (same-address atomics: ~12 ns each).  One workgroup; list[ngroups] = how many. */
+__global__ void __launch_bounds__(1024)
+k_list_alive_groups(const unsigned char* __restrict__ alive, int ngroups, int* __restrict__ list)
+{
+    __shared__ int sc[1024];
+    const int t = threadIdx.x;
+    const int per = (ngroups + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, ngroups);
+    int mine = 0;
+    for (int g = lo; g < hi; ++g) mine += alive[g] != 0;
+    sc[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? sc[t - off] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    int at = sc[t] - mine;
+    for (int g = lo; g < hi; ++g)
+        if (alive[g]) list[at++] = g;
+    if (t == 1023) list[ngroups] = sc[t];
+}
+void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngroups, int* list)
+{
+    hipLaunchKernelGGL(k_list_alive_groups, dim3(1), dim3(1024), 0, s, alive, ngroups, list);
+}
+
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
-                              int* pub, int seq, int* next_image, int next_size)
+                              int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb + extra), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need)
+                            int* need, unsigned char* group_alive)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
@@ -1060,8 +1097,8 @@ void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int 
     const dim3 g(nb), b(1024);
     hipLaunchKernelGGL(k_zs_hist, dim3(nb + extra), b, 0, s, tiles, count, tps, image, hist, cf);
     hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need);
-    if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out);
-    else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out);
+    if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out, group_alive);
+    else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out, nullptr);
 }
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size)
 {

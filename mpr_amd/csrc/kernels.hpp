@@ -113,7 +113,8 @@ void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsign
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need);
+                            int* need, unsigned char* group_alive = nullptr);
+void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngroups, int* list);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
@@ -122,7 +123,7 @@ size_t wide_stage_lds_bytes(int nclauses);
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced = 0);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
-                              int* pub, int seq, int* next_image, int next_size);
+                              int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive = nullptr);
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
@@ -138,7 +139,8 @@ int jit_max_choices();        /* recorded min / max decisions per tape the group
 int jit_grid(int dim, int nslots, int cus, bool group);
 /* groups != null: the group form over the last tile stage's list (a.tiles / a.count), else one wavefront per smallest tile */
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
-                            int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap);
+                            int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
+                            const int* group_list);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

@@ -758,6 +758,8 @@ struct JitVoxelArgs {
     const GroupInfo* groups;   /* group form: the tape each group of 64 siblings walked, and their min / max decisions */
     const ulonglong2* choice_masks;
     int choice_cap;
+    int* group_counter;        /* group form: the next entry of group_list to hand out (zero at the start of the frame) */
+    const int* group_list;     /* group form: the groups with a surviving tile, in list order; [number of groups] = how many */
 };
 
 /* ---- tile form: a wavefront per smallest tile, each with its own tape ------------------------------------------ */
@@ -836,7 +838,19 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
     const uint64_t head0 = tro[0];
     const int ngroups = (a.count + 63) / 64;
 
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    __shared__ int next_group;
+    /* the groups that still have a tile (j.group_list, in list order: front to back) are handed out one at a time as
+     * workgroups come free: their cost varies with the number of surviving children — a fixed stride left a third of the
+     * kernel's duration to a tail of long workgroups — and the order is what lets the groups behind a surface find it
+     * already drawn (handing out four at a time cost bear 30 %) */
+    const int nlisted = j.group_list[ngroups];
+    for (;;) {
+        if (threadIdx.x == 0) next_group = atomicAdd(j.group_counter, 1);
+        __syncthreads();
+        const int r = next_group;
+        __syncthreads();
+        if (r >= nlisted) break;
+        const int g = j.group_list[r];
         /* the 64 siblings as the last compaction left them: position -1 = empty, filled or hidden */
         const int idx = g * 64 + lane;
         int position = -1;
@@ -939,7 +953,8 @@ int jit_grid(int dim, int nslots, int cus, bool group)
                                                                                                              : jit_grid_of<2, 192>(cus, group);
 }
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
-                            int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap)
+                            int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
+                            const int* group_list)
 {
     if (a.count <= 0) return;
     JitVoxelArgs j;
@@ -952,6 +967,8 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
     j.groups = groups;
     j.choice_masks = choice_masks;
     j.choice_cap = choice_cap;
+    j.group_counter = group_counter;
+    j.group_list = group_list;
     const int ns = jit_slot_class(a.nslots);
     if (groups) {
         const dim3 g(std::min(grid, (a.count + 63) / 64)), b(64 * JIT_GROUP_WAVES);
