@@ -54,3 +54,23 @@ def compare_frame(mpr, orc, tape, dim, S, mat, z=0.0, check_tapes=True):
     assert cnt["voxel_tiles"] == ref.counters["voxel_tiles"]
     ctx.close()
     return cnt, ref
+
+
+def check_default_path(mpr, ref, tape, dim, S, mat, z=0.0, frames=3):
+    """compare_frame runs instrumented frames (work counters on: compiled interpreters, every tape pushed).  This is the
+    path a caller gets — generated code in the float pass, and from the second frame of the same tape and view on no
+    tapes from the last tile stage where that pays — against the same oracle frame: heights / occupancy and normals."""
+    ctx = mpr.Context(S)
+    kinds = []
+    for _ in range(frames):
+        if dim == 2:
+            ctx.render2D(tape, mat, z)
+        else:
+            ctx.render3D(tape, mat)
+        kinds.append((ctx.float_kernel(), ctx.last_stage_pushed()))
+        assert np.array_equal(ctx.image, ref.filled[3]), "image of the default path differs (%d cells)" % int((ctx.image != ref.filled[3]).sum())
+        if dim == 3:
+            bad = int((ctx.normals != ref.normals).sum())
+            assert bad == 0, "normals of the default path differ at %d pixels (%s)" % (bad, kinds[-1])
+    ctx.close()
+    return kinds

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import view2, view3
-from helpers import compare_frame
+from helpers import check_default_path, compare_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -20,22 +20,29 @@ pytestmark = pytest.mark.gpu
 def test_prospero_1024_full_frame(mpr, orc, tapes):
     cnt, ref = compare_frame(mpr, orc, tapes("prospero"), 2, 1024, view2())
     assert 0 < ref.image.sum() < ref.image.size
+    check_default_path(mpr, ref, tapes("prospero"), 2, 1024, view2())
 
 
 def test_gears_4096_full_frame(mpr, orc, tapes):
     cnt, ref = compare_frame(mpr, orc, tapes("involute_gear_2d"), 2, 4096, view2())
     assert 0 < ref.image.sum() < ref.image.size
+    check_default_path(mpr, ref, tapes("involute_gear_2d"), 2, 4096, view2())
 
 
 def test_bear_1024_full_frame(mpr, orc, tapes):
     cnt, ref = compare_frame(mpr, orc, tapes("bear"), 3, 1024, view3())
     assert (ref.image > 0).sum() > 300000
     assert cnt["voxel_tiles"] > 500000
+    kinds = check_default_path(mpr, ref, tapes("bear"), 3, 1024, view3())
+    # generated code, one translation per group of 64 tiles; from the second frame on no tapes from the last tile stage
+    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [True, False, False], kinds
 
 
 def test_architecture_2048_full_frame(mpr, orc, tapes):
     cnt, ref = compare_frame(mpr, orc, tapes("architecture"), 3, 2048, view3())
     assert (ref.image > 0).sum() > 1000000
+    kinds = check_default_path(mpr, ref, tapes("architecture"), 3, 2048, view3())
+    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [True, False, False], kinds
 
 
 def test_architecture_2048_sharded_over_three_contexts(mpr, orc, tapes):
