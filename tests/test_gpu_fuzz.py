@@ -6,12 +6,14 @@ The benchmark models each use a handful of opcodes in fixed patterns; these tree
 domains (sqrt / log / asin / acos of values that leave them), long chains on one slot and wide fans —
 so that the interpreters' handler tables (operands from the slot file / forwarded, results stored /
 dropped, compiled routines called from inside the loops) meet in combinations the models never
-produce."""
+produce.  Every expression is rendered twice over: instrumented frames (compiled interpreters, every tape
+pushed) for the full comparison, and the default path (generated code in the float pass, level-parallel
+tile stages, repeated frames without last-stage tapes) for heights / occupancy and normals."""
 import numpy as np
 import pytest
 
 from conftest import view2, view3
-from helpers import compare_frame
+from helpers import check_default_path, compare_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -82,13 +84,16 @@ def random_tree(m, seed, depth=4):
 def test_random_expression_2d(mpr, orc, seed):
     tape = mpr.Tape(random_tree(mpr, 1000 + seed))
     assert tape.length > 20
-    compare_frame(mpr, orc, tape, 2, 256, view2(), z=float(np.float32(0.05 * (seed % 5) - 0.1)))
+    z = float(np.float32(0.05 * (seed % 5) - 0.1))
+    cnt, ref = compare_frame(mpr, orc, tape, 2, 256, view2(), z=z)
+    check_default_path(mpr, ref, tape, 2, 256, view2(), z=z)     # generated code, repeated frames
 
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_expression_3d(mpr, orc, seed):
     tape = mpr.Tape(random_tree(mpr, 2000 + seed))
-    compare_frame(mpr, orc, tape, 3, 128, view3())
+    cnt, ref = compare_frame(mpr, orc, tape, 3, 128, view3())
+    check_default_path(mpr, ref, tape, 3, 128, view3())
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -99,4 +104,19 @@ def test_random_expression_3d_general_view(mpr, orc, seed):
     T[:3, 3] = rng.uniform(-0.1, 0.1, 3).astype(np.float32)
     T[3, 2] = 0.25
     tape = mpr.Tape(random_tree(mpr, 3000 + seed, depth=3))
-    compare_frame(mpr, orc, tape, 3, 128, T)
+    cnt, ref = compare_frame(mpr, orc, tape, 3, 128, T)
+    check_default_path(mpr, ref, tape, 3, 128, T)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_expression_3d_on_group_tapes(mpr, orc, seed, monkeypatch):
+    """At this size the last tile stage would run level-parallel (few tiles) and the float pass on per-tile tapes; with
+    the serial last stage the float pass takes the group form where the tapes allow it and repeated frames push no
+    tapes in the last stage: the decisions of every tile applied in generated code (float pass) and by the normals
+    interpreter, on expressions with min / max of everything."""
+    monkeypatch.setenv("MPR_WIDE_LATER", "0")
+    tape = mpr.Tape(random_tree(mpr, 2000 + seed))
+    ref = orc.Frame(tape.data, 3, 128, mpr.colmajor(view3(), 4), threads=0)
+    check_default_path(mpr, ref, tape, 3, 128, view3(), frames=3)
+    monkeypatch.setenv("MPR_VOXEL_GROUPS", "2")          # ... and whatever the tapes' lengths
+    check_default_path(mpr, ref, tape, 3, 128, view3(), frames=2)
