@@ -36,14 +36,16 @@
  * Generated code is fetched through the instruction caches (64 KB per CU pair, about 5 bytes per clock each when
  * it misses: profiles/r02a_jit_probe.txt), and code that is written per tile never hits: measured, the same
  * instructions run 4x faster from a warm instruction cache.  Hence the GROUP form (k_eval_voxels_jit_groups),
- * used whenever the tapes of the last tile stage record at most 64 min / max decisions: the 64 children of a tile
+ * used when the tapes of the last tile stage record at most 128 min / max decisions and are not much longer than the
+ * tapes that stage hands on (context.hip: the stage samples both lengths): the 64 children of a tile
  * walked ONE tape in the last interval stage, and a child's own shortened tape is that tape with the child's
  * min / max decisions applied and dead clauses dropped.  So the group's tape is translated once, by one wavefront
  * of a workgroup, with every min / max followed by two selects steered by the child's decisions (bit i of two
  * scalar registers: `chose lhs`, `chose rhs`; the last tile stage stores the decision masks per group), and the
  * workgroup's wavefronts run that one piece of code — a few KB that stay in the instruction cache — for every
  * surviving child.  Dropped clauses are evaluated for nothing (3 % more clauses for bear); the values of all
- * others are the ones the child's own tape gives, bit for bit.
+ * others are the ones the child's own tape gives, bit for bit.  Workgroups are persistent and take the groups that
+ * still have a tile one at a time, in list order (front to back), as they come free.
  *
  * The region of a wavefront holds the longest code any tape of the frame can have: shortening only
  * replaces min / max by copies and drops clauses, so the root tape's code length is the bound (host:
