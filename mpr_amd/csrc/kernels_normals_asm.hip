@@ -83,13 +83,16 @@ __device__ float nq_atan(float a, int isv)
  *   s64 decisions present  s65 min / max clauses met so far  s[66:67] L_dec  s[46:47] its return address
  *   v32 aA  v33 aB  v34 aO  v35 A  v36 B  v37 result (and previous result)  v38..v47 temporaries      */
 #define NQ_Q3 " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n"
-#define NQ_DISPATCH                                    \
+/* next clause: word, handler address ... */
+#define NQ_PREP                                        \
     "s_add_u32 s88, s88, 1\n"                          \
     "v_readlane_b32 s86, %[blo], s88\n"                \
     "s_and_b32 s80, s86, s96\n"                        \
     "s_add_u32 s80, s80, s82\n"                        \
-    "s_addc_u32 s81, s83, 0\n"                         \
-    "s_setpc_b64 s[80:81]\n"
+    "s_addc_u32 s81, s83, 0\n"
+/* ... and go.  Handlers run NQ_PREP right after forming their addresses (the last use of the clause word) and issuing
+ * their LDS reads, under the reads' latency: a wavefront's walk is a dependent chain, and this link need not be on it */
+#define NQ_DISPATCH NQ_PREP "s_setpc_b64 s[80:81]\n"
 #define NQ_IMM "v_readlane_b32 s87, %[bhi], s88\n"
 #define NQ_AL "v_perm_b32 v32, s86, %[lb], %[selL]\n ds_read_b32 v35, v32\n"
 #define NQ_AR "v_perm_b32 v33, s86, %[lb], %[selR]\n ds_read_b32 v36, v33\n"
@@ -97,7 +100,7 @@ __device__ float nq_atan(float a, int isv)
 #define NQ_FR "v_mov_b32 v36, v37\n"
 #define NQ_AO "v_perm_b32 v34, s86, %[lb], %[selO]\n"
 #define NQ_W "s_waitcnt lgkmcnt(0)\n"
-#define NQ_END "ds_write_b32 v34, v37\n" NQ_DISPATCH
+#define NQ_END "ds_write_b32 v34, v37\n s_setpc_b64 s[80:81]\n"
 #define NQ_H(v, n) ".p2align 8\nL_n" #v "_" #n "_%=:\n"
 #define NQ_EXIT NQ_IMM "s_branch L_exit_%=\n"
 #define NQ_CALL(pair) "s_swappc_b64 s[70:71], " pair "\n"
@@ -120,73 +123,73 @@ __device__ float nq_atan(float a, int isv)
 #define NQ_TABLE(v, LDL, LDR, WL, WR, WLR)                                                                   \
     NQ_H(v, 0) "s_branch L_exit_%=\n"                                                     /* end of tape */  \
     NQ_H(v, 1) NQ_IMM "s_add_u32 s89, s89, s88\n s_add_u32 s89, s89, s87\n s_add_u32 s89, s89, 1\n s_branch L_load_%=\n" \
-    NQ_H(v, 2) LDL NQ_AO WL                                  /* SQUARE: isv ? a*a : a*av + a*av */           \
+    NQ_H(v, 2) LDL NQ_AO NQ_PREP WL                                  /* SQUARE: isv ? a*a : a*av + a*av */           \
     "v_mul_f32_dpp v38, v35, v35" NQ_Q3 "v_mul_f32 v39, v35, v35\n v_add_f32 v38, v38, v38\n"               \
     "v_cndmask_b32 v37, v38, v39, s[98:99]\n" NQ_END                                                         \
-    NQ_H(v, 3) LDL NQ_AO WL                                  /* SQRT: s = sqrt(av); isv ? s : a / (2 s) */   \
+    NQ_H(v, 3) LDL NQ_AO NQ_PREP WL                                  /* SQRT: s = sqrt(av); isv ? s : a / (2 s) */   \
     "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_SQRT                                              \
     "v_mov_b32 v44, v37\n v_mul_f32 v36, 2.0, v37\n v_mov_b32 v35, v43\n" NQ_DIV                             \
     "v_cndmask_b32 v37, v37, v44, s[98:99]\n" NQ_END                                                         \
-    NQ_H(v, 4) LDL NQ_AO WL "v_xor_b32 v37, 0x80000000, v35\n" NQ_END                                        \
-    NQ_H(v, 5) LDL NQ_AO WL                                  /* SIN: isv ? sin(av) : cos(av) * a */          \
+    NQ_H(v, 4) LDL NQ_AO NQ_PREP WL "v_xor_b32 v37, 0x80000000, v35\n" NQ_END                                        \
+    NQ_H(v, 5) LDL NQ_AO NQ_PREP WL                                  /* SIN: isv ? sin(av) : cos(av) * a */          \
     "v_mov_b32 v48, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_CALL("s[68:69]")                                  \
     "v_mul_f32 v38, v36, v48\n v_cndmask_b32 v37, v38, v37, s[98:99]\n" NQ_END                              \
-    NQ_H(v, 6) LDL NQ_AO WL                                  /* COS: isv ? cos(av) : -sin(av) * a */         \
+    NQ_H(v, 6) LDL NQ_AO NQ_PREP WL                                  /* COS: isv ? cos(av) : -sin(av) * a */         \
     "v_mov_b32 v48, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_CALL("s[68:69]")                                  \
     "v_mul_f32_e64 v38, -v37, v48\n v_cndmask_b32 v37, v38, v36, s[98:99]\n" NQ_END                         \
-    NQ_H(v, 7) LDL NQ_AO WL "s_branch L_casin_%=\n"                                                         \
-    NQ_H(v, 8) LDL NQ_AO WL "s_branch L_cacos_%=\n"                                                         \
-    NQ_H(v, 9) LDL NQ_AO WL "s_branch L_catan_%=\n"                                                         \
-    NQ_H(v, 10) LDL NQ_AO WL                                 /* EXP: e = exp(av); isv ? e : e * a */         \
+    NQ_H(v, 7) LDL NQ_AO NQ_PREP WL "s_branch L_casin_%=\n"                                                         \
+    NQ_H(v, 8) LDL NQ_AO NQ_PREP WL "s_branch L_cacos_%=\n"                                                         \
+    NQ_H(v, 9) LDL NQ_AO NQ_PREP WL "s_branch L_catan_%=\n"                                                         \
+    NQ_H(v, 10) LDL NQ_AO NQ_PREP WL                                 /* EXP: e = exp(av); isv ? e : e * a */         \
     "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 NQ_EXP                                               \
     "v_mul_f32 v38, v37, v43\n v_cndmask_b32 v37, v38, v37, s[98:99]\n" NQ_END                               \
-    NQ_H(v, 11) LDL NQ_AO WL                                 /* ABS: av < 0 ? -a : a */                      \
+    NQ_H(v, 11) LDL NQ_AO NQ_PREP WL                                 /* ABS: av < 0 ? -a : a */                      \
     "v_mov_b32 v39, 0\n v_xor_b32 v38, 0x80000000, v35\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"               \
     "s_nop 1\n v_cndmask_b32 v37, v35, v38, vcc\n" NQ_END                                                    \
-    NQ_H(v, 12) LDL NQ_AO WL                                 /* LOG: isv ? log(av) : a / av */               \
+    NQ_H(v, 12) LDL NQ_AO NQ_PREP WL                                 /* LOG: isv ? log(av) : a / av */               \
     "v_mov_b32 v43, v35\n v_mov_b32_dpp v35, v35" NQ_Q3 "s_nop 0\n v_mov_b32 v45, v35\n" NQ_LOG              \
     "v_mov_b32 v44, v37\n v_mov_b32 v35, v43\n v_mov_b32 v36, v45\n" NQ_DIV                                  \
     "v_cndmask_b32 v37, v37, v44, s[98:99]\n" NQ_END                                                         \
-    NQ_H(v, 13) NQ_IMM LDL NQ_AO WL                          /* a + imm: only the value */                   \
+    NQ_H(v, 13) NQ_IMM LDL NQ_AO NQ_PREP WL                          /* a + imm: only the value */                   \
     "s_nop 0\n v_add_f32 v38, s87, v35\n v_cndmask_b32 v37, v35, v38, s[98:99]\n" NQ_END                     \
-    NQ_H(v, 14) LDL LDR NQ_AO WLR "v_add_f32 v37, v35, v36\n" NQ_END                                         \
-    NQ_H(v, 15) NQ_IMM LDL NQ_AO WL "s_nop 0\n v_mul_f32 v37, s87, v35\n" NQ_END                             \
-    NQ_H(v, 16) LDL LDR NQ_AO WLR                            /* MUL: isv ? a*b : a*bv + b*av */              \
+    NQ_H(v, 14) LDL LDR NQ_AO NQ_PREP WLR "v_add_f32 v37, v35, v36\n" NQ_END                                         \
+    NQ_H(v, 15) NQ_IMM LDL NQ_AO NQ_PREP WL "s_nop 0\n v_mul_f32 v37, s87, v35\n" NQ_END                             \
+    NQ_H(v, 16) LDL LDR NQ_AO NQ_PREP WLR                            /* MUL: isv ? a*b : a*bv + b*av */              \
     "v_mul_f32_dpp v38, v36, v35" NQ_Q3 "v_mul_f32_dpp v39, v35, v36" NQ_Q3                                  \
     "v_mul_f32 v40, v35, v36\n v_add_f32 v38, v38, v39\n v_cndmask_b32 v37, v38, v40, s[98:99]\n" NQ_END     \
-    NQ_H(v, 17) NQ_IMM LDL NQ_AO WL                          /* MIN_IMM: b = (0, 0, 0, imm); av < imm ? a : b */ \
+    NQ_H(v, 17) NQ_IMM LDL NQ_AO NQ_PREP WL                          /* MIN_IMM: b = (0, 0, 0, imm); av < imm ? a : b */ \
     "v_mov_b32 v39, s87\n v_cndmask_b32 v36, 0, v39, s[98:99]\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"        \
     "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
-    NQ_H(v, 18) LDL LDR NQ_AO WLR                            /* MIN: av < bv ? a : b */                      \
+    NQ_H(v, 18) LDL LDR NQ_AO NQ_PREP WLR                            /* MIN: av < bv ? a : b */                      \
     "v_mov_b32_dpp v39, v36" NQ_Q3 "s_nop 1\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_lt_f32 vcc, v46, v39\n"                          \
     "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
-    NQ_H(v, 19) NQ_IMM LDL NQ_AO WL                          /* MAX_IMM: av >= imm ? a : b */                \
+    NQ_H(v, 19) NQ_IMM LDL NQ_AO NQ_PREP WL                          /* MAX_IMM: av >= imm ? a : b */                \
     "v_mov_b32 v39, s87\n v_cndmask_b32 v36, 0, v39, s[98:99]\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_ge_f32 vcc, v46, v39\n"        \
     "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
-    NQ_H(v, 20) LDL LDR NQ_AO WLR                                                                            \
+    NQ_H(v, 20) LDL LDR NQ_AO NQ_PREP WLR                                                                            \
     "v_mov_b32_dpp v39, v36" NQ_Q3 "s_nop 1\n v_mov_b32_dpp v46, v35" NQ_Q3 "v_cmp_ge_f32 vcc, v46, v39\n"                          \
     "s_swappc_b64 s[46:47], s[66:67]\n"                                                                       \
     "s_nop 1\n v_cndmask_b32 v37, v36, v35, vcc\n" NQ_END                                                    \
-    NQ_H(v, 21) NQ_IMM LDL NQ_AO WL                          /* a - imm: only the value */                   \
+    NQ_H(v, 21) NQ_IMM LDL NQ_AO NQ_PREP WL                          /* a - imm: only the value */                   \
     "s_nop 0\n v_subrev_f32 v38, s87, v35\n v_cndmask_b32 v37, v35, v38, s[98:99]\n" NQ_END                  \
-    NQ_H(v, 22) NQ_IMM LDR NQ_AO WR                          /* imm - b: isv ? imm - b : -b */               \
+    NQ_H(v, 22) NQ_IMM LDR NQ_AO NQ_PREP WR                          /* imm - b: isv ? imm - b : -b */               \
     "s_nop 0\n v_sub_f32 v38, s87, v36\n v_xor_b32 v39, 0x80000000, v36\n v_cndmask_b32 v37, v39, v38, s[98:99]\n" NQ_END \
-    NQ_H(v, 23) LDL LDR NQ_AO WLR "v_sub_f32 v37, v35, v36\n" NQ_END                                         \
-    NQ_H(v, 24) NQ_IMM LDL NQ_AO WL "s_nop 0\n v_mov_b32 v36, s87\n" NQ_DIV NQ_END      /* a / imm, all components */ \
-    NQ_H(v, 25) NQ_IMM LDR NQ_AO WR                          /* imm / b: isv ? imm / b : (-imm * b) / (bv * bv) */ \
+    NQ_H(v, 23) LDL LDR NQ_AO NQ_PREP WLR "v_sub_f32 v37, v35, v36\n" NQ_END                                         \
+    NQ_H(v, 24) NQ_IMM LDL NQ_AO NQ_PREP WL "s_nop 0\n v_mov_b32 v36, s87\n" NQ_DIV NQ_END      /* a / imm, all components */ \
+    NQ_H(v, 25) NQ_IMM LDR NQ_AO NQ_PREP WR                          /* imm / b: isv ? imm / b : (-imm * b) / (bv * bv) */ \
     "v_mov_b32_dpp v41, v36" NQ_Q3 "v_mul_f32_e64 v39, -s87, v36\n v_mov_b32 v40, s87\n v_mul_f32 v38, v41, v41\n" \
     "v_cndmask_b32 v35, v39, v40, s[98:99]\n v_cndmask_b32 v36, v38, v36, s[98:99]\n" NQ_DIV NQ_END          \
-    NQ_H(v, 26) LDL LDR NQ_AO WLR                            /* a / b: isv ? a / b : (bv*a - av*b) / (bv*bv) */ \
+    NQ_H(v, 26) LDL LDR NQ_AO NQ_PREP WLR                            /* a / b: isv ? a / b : (bv*a - av*b) / (bv*bv) */ \
     "v_mul_f32_dpp v38, v36, v35" NQ_Q3 "v_mul_f32_dpp v39, v35, v36" NQ_Q3 "v_mov_b32_dpp v41, v36" NQ_Q3      \
     "v_sub_f32 v38, v38, v39\n s_nop 0\n v_mul_f32 v40, v41, v41\n"                                           \
     "v_cndmask_b32 v35, v38, v35, s[98:99]\n v_cndmask_b32 v36, v40, v36, s[98:99]\n"                         \
     NQ_DIV NQ_END                                                                                            \
-    NQ_H(v, 27) NQ_IMM NQ_AO "s_nop 0\n v_mov_b32 v39, s87\n v_cndmask_b32 v37, 0, v39, s[98:99]\n" NQ_END   \
-    NQ_H(v, 28) LDL NQ_AO WL "v_mov_b32 v37, v35\n" NQ_END                                                   \
-    NQ_H(v, 29) LDR NQ_AO WR "v_mov_b32 v37, v36\n" NQ_END                                                   \
+    NQ_H(v, 27) NQ_IMM NQ_AO NQ_PREP "s_nop 0\n v_mov_b32 v39, s87\n v_cndmask_b32 v37, 0, v39, s[98:99]\n" NQ_END   \
+    NQ_H(v, 28) LDL NQ_AO NQ_PREP WL "v_mov_b32 v37, v35\n" NQ_END                                                   \
+    NQ_H(v, 29) LDR NQ_AO NQ_PREP WR "v_mov_b32 v37, v36\n" NQ_END                                                   \
     NQ_H(v, 30) NQ_EXIT                                                                                      \
     NQ_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"
 
