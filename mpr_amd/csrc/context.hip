@@ -105,6 +105,7 @@ struct mpr_context {
     FrameKey learned;                  /* the frame that measured "groups' tapes are short enough" ... */
     bool learned_ok = false;
     std::unique_ptr<mpr_tape> last_tape;   /* ... and a copy of its tape (the caller may have freed it by the time a reader asks) */
+    bool tiles_vgpr = true;            /* MPR_TILES_VGPR=0 (development): tile stages keep every slot file in LDS */
     bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
@@ -314,6 +315,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILES_VGPR")) c->tiles_vgpr = atoi(e) != 0;
     if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->lean_last_stage = atoi(e) == 0;
     if (const char* e = getenv("MPR_WIDE_LATER")) c->wide_later = atoi(e);
     if (const char* e = getenv("MPR_WIDE_THREADS")) c->wide_threads = atoi(e);
@@ -676,6 +678,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.len_stats = (groups_now && !lean_now) ? c->num_active + 5 : nullptr;
             a.no_push = groups_now && lean_now;
             a.compiled_walk = !c->tiles_asm;
+            a.vgpr_slots = c->tiles_vgpr;
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;

@@ -103,15 +103,18 @@ __device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, fl
 
 /* ASM: forward walk by the assembly interpreter (tile_interp_asm.hpp; slot file as lo / hi planes,
  * nslots <= 128), else the compiled loop below (slot file float2 per lane) */
-template <int DIM, bool ASM>
-__global__ void __launch_bounds__(64)
+/* VS (with ASM): the slot file in vector registers instead (tile_interp_asm_vgpr: tapes with 40 to 93 slots, whose LDS
+ * planes would leave room for fewer than 8 wavefronts per CU); LDS then holds the choices and 2 KB of scratch */
+template <int DIM, bool ASM, bool VS = false>
+__global__ void __launch_bounds__(64, VS ? 2 : 0)
 k_eval_tiles(TileStageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const size_t planes_bytes = VS ? 0 : (size_t)a.nslots * 512;
     float2* const slots = reinterpret_cast<float2*>(smem);                       /* [nslots][64] */
     float* const plane = reinterpret_cast<float*>(smem);                         /* ASM: slot s = plane[s * 128 + lane], + 64 */
-    ulonglong2* const choices = reinterpret_cast<ulonglong2*>(smem + (size_t)a.nslots * 512);       /* [choice_cap] */
-    uint64_t* const act = reinterpret_cast<uint64_t*>(smem + (size_t)a.nslots * 512 + (size_t)a.choice_cap * 16);   /* [128], nslots > 128 only */
+    ulonglong2* const choices = reinterpret_cast<ulonglong2*>(smem + planes_bytes);       /* [choice_cap] */
+    uint64_t* const act = reinterpret_cast<uint64_t*>(smem + planes_bytes + (size_t)a.choice_cap * 16);   /* [128], nslots > 128 only */
 
     const uint64_t* __restrict__ const tro = a.tape_ro;
     uint64_t* __restrict__ const twr = a.tape_wr;
@@ -184,12 +187,12 @@ k_eval_tiles(TileStageArgs a)
     long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define MPR_PHASE(k) do { if (prof) { const long long tn = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&pc[k], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     const uint64_t head0 = tro[0];
-    if (ASM) {
+    if (ASM && !VS) {
         const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
         plane[sx * 128 + lane] = vx.lo; plane[sx * 128 + 64 + lane] = vx.hi;
         plane[sy * 128 + lane] = vy.lo; plane[sy * 128 + 64 + lane] = vy.hi;
         plane[sz * 128 + lane] = vz.lo; plane[sz * 128 + 64 + lane] = vz.hi;
-    } else {
+    } else if (!ASM) {
         slots[((head0 >> 8) & 0xFF) * 64 + lane] = make_float2(vx.lo, vx.hi);
         slots[((head0 >> 16) & 0xFF) * 64 + lane] = make_float2(vy.lo, vy.hi);
         slots[((head0 >> 24) & 0xFF) * 64 + lane] = make_float2(vz.lo, vz.hi);
@@ -203,9 +206,14 @@ k_eval_tiles(TileStageArgs a)
     int fwd_words = 0, nclauses = 0;
     int end_index = 0;                 /* pool index of the end clause */
     uint64_t d = 0;
+    float2 res_vs = make_float2(0.0f, 0.0f);
     if (ASM) {
-        const TileInterpResult ir = tile_interp_asm(tro, (uint32_t)(tape + 1), smem, lane, alive_mask,
-                                                    (uint32_t)a.nslots * 512u, a.choice_cap, &first_block);
+        const TileInterpResult ir =
+            VS ? tile_interp_asm_vgpr(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, a.choice_cap, &first_block,
+                                      2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                                      2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                                      make_float2(vz.lo, vz.hi), &res_vs)
+               : tile_interp_asm(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, (uint32_t)a.nslots * 512u, a.choice_cap, &first_block);
         ci = ir.nchoices;
         any_choice = ir.any_choice;
         fwd_words = ir.words;
@@ -279,7 +287,7 @@ k_eval_tiles(TileStageArgs a)
     const int nchoices_fwd = ci;       /* min / max clauses of the tape just walked */
     const uint64_t end_clause = d;
     const uint32_t i_out = (uint32_t)(end_clause >> 8) & 0xFF;
-    const float2 res = ASM ? make_float2(plane[i_out * 128 + lane], plane[i_out * 128 + 64 + lane]) : slots[i_out * 64 + lane];
+    const float2 res = VS ? res_vs : ASM ? make_float2(plane[i_out * 128 + lane], plane[i_out * 128 + 64 + lane]) : slots[i_out * 64 + lane];
 
     /* ---- classification (reference :293-321) ---- */
     bool ambiguous = false;
@@ -380,7 +388,7 @@ k_eval_tiles(TileStageArgs a)
             st.overflow = overflow ? 1u : 0u;
             st.live = live;
             const long long lim = a.pool_cap - 65;
-            tile_push_asm(tro, end_index - 1, smem, lane, st, (uint32_t)run_end, ci, (uint32_t)a.nslots * 512u, a.choice_cap,
+            tile_push_asm(tro, end_index - 1, smem, lane, st, (uint32_t)run_end, ci, (uint32_t)planes_bytes, a.choice_cap,
                           (uint32_t)(lim < 0 ? 0 : (lim > 0x7FFFFF00ll ? 0x7FFFFF00ll : lim)));
             out_index = (int)st.out_index;
             out_offset = (int)st.out_offset;
@@ -1014,6 +1022,12 @@ void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsign
                        tape_index, tape_len, num_active, tiles, count, cols, owner, rank);
 }
 size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + (size_t)choice_cap * 16 + (nslots > 128 ? 1024 : 0); }
+/* slots in registers (k_eval_tiles<.., .., true>) when the LDS planes would hold a CU under the 8 wavefronts that 256
+ * registers per lane allow, and the slots fit the registers */
+bool tile_stage_vgpr_slots(int nslots, int choice_cap)
+{
+    return nslots <= TI_VS_MAX_SLOTS && tile_stage_lds_bytes(nslots, choice_cap) > (size_t)160 * 1024 / 8;
+}
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
 {
     opt_in_once();
@@ -1022,11 +1036,15 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     /* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers */
     /* ... and the assembly backward walk forms 32-bit byte offsets into the pool (a.compiled_walk: MPR_TILES_ASM=0) */
     const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
+    const bool vs = use_asm && a.vgpr_slots && !(a.debug & 4) && tile_stage_vgpr_slots(a.nslots, a.choice_cap);
+    const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
     if (dim == 3) {
-        if (use_asm) hipLaunchKernelGGL((k_eval_tiles<3, true>), dim3(groups), dim3(64), lds, s, a);
+        if (vs) hipLaunchKernelGGL((k_eval_tiles<3, true, true>), dim3(groups), dim3(64), lds_vs, s, a);
+        else if (use_asm) hipLaunchKernelGGL((k_eval_tiles<3, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<3, false>), dim3(groups), dim3(64), lds, s, a);
     } else {
-        if (use_asm) hipLaunchKernelGGL((k_eval_tiles<2, true>), dim3(groups), dim3(64), lds, s, a);
+        if (vs) hipLaunchKernelGGL((k_eval_tiles<2, true, true>), dim3(groups), dim3(64), lds_vs, s, a);
+        else if (use_asm) hipLaunchKernelGGL((k_eval_tiles<2, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, false>), dim3(groups), dim3(64), lds, s, a);
     }
 }

@@ -53,6 +53,7 @@ struct TileStageArgs {
     int* next_choices;         /* device counter (atomicMax): an upper bound on the min / max clauses of any tape this
                                 * stage pushes; sizes the next stage's choice array */
     bool no_push;              /* last stage, float AND normals pass on the groups' tapes: write the groups' records only, push no tapes */
+    bool vgpr_slots;           /* tapes with many slots: the assembly walk with the slot file in registers (MPR_TILES_VGPR=0: never) */
     bool compiled_walk;        /* development (MPR_TILES_ASM=0): the compiled forward / backward walks instead of the assembly ones */
     int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
                                 * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */

@@ -114,6 +114,9 @@ static __device__ float2 ti_named_sqrtx(float a, float b)
 #define TI_ST "ds_write2st64_b32 v34, v40, v41 offset1:1\n"
 #define TI_H(v, n) ".p2align 8\nL_t" #v "_" #n "_%=:\n"
 #define TI_EXIT TI_IMM "s_branch L_exit_%=\n"
+#define TI_H30 TI_EXIT                /* a word that is not an opcode: evaluated (to NaN) outside the block */
+#define TI_VS_ENTER
+#define TI_VS_LEAVE
 #define TI_END TI_ST TI_GO
 #define TI_NEGLO "v_xor_b32 v40, 0x80000000, v40\n"
 /* call a compiled routine on v[36:37]; v34 (address of the out slot) survives in v42 */
@@ -176,9 +179,385 @@ static __device__ float2 ti_named_sqrtx(float a, float b)
     TI_H(v, 27) TI_IMM TI_AO TI_PREP "s_nop 0\n v_mov_b32 v40, s87\n v_mov_b32 v41, s87\n" TI_END                  \
     TI_H(v, 28) LDL TI_AO TI_PREP WL "v_mov_b32 v40, v36\n v_mov_b32 v41, v37\n" TI_END                            \
     TI_H(v, 29) LDR TI_AO TI_PREP WR "v_mov_b32 v40, v38\n v_mov_b32 v41, v39\n" TI_END                            \
-    TI_H(v, 30) TI_EXIT                                                                                     \
+    TI_H(v, 30) TI_H30                                                                                      \
     TI_H(v, 31) "s_add_u32 s79, s79, 63\n s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"   /* lane 63: next block */
 
+
+/* The walk itself, as text: expanded in tile_interp_asm (slots in LDS) and in tile_interp_asm_vgpr (slots in VGPRs),
+ * each time with that variant's definitions of TI_AL / TI_AR / TI_AO / TI_ST / TI_H30 / TI_VS_ENTER / TI_VS_LEAVE. */
+#define TI_ASM_TEXT \
+    TI_VS_ENTER \
+    "s_mov_b32 s89, %[base]\n" \
+    "s_mov_b32 s88, %[sj]\n" \
+    "s_mov_b32 s96, 0xff00\n" \
+    "s_mov_b32 s72, %[alo]\n" \
+    "s_mov_b32 s73, %[ahi]\n" \
+    "s_mov_b32 s74, %[caddr]\n" \
+    "s_mov_b32 s75, %[cend]\n" \
+    "s_mov_b32 s76, %[anylo]\n" \
+    "s_mov_b32 s77, %[anyhi]\n" \
+    "s_mov_b32 s78, %[ci]\n" \
+    "s_mov_b32 s79, %[words]\n" \
+    "v_mov_b32 v40, %[plo]\n" \
+    "v_mov_b32 v41, %[phi]\n" \
+    "s_getpc_b64 s[82:83]\n" \
+    "L_pc_%=:\n" \
+    "s_add_u32 s82, s82, L_t0_0_%=-L_pc_%=\n" \
+    "s_addc_u32 s83, s83, 0\n" \
+    "s_cmp_eq_u32 %[mode], 0\n" \
+    "s_cbranch_scc1 L_load_%=\n" \
+    "s_cmp_eq_u32 %[mode], 2\n" \
+    "s_cbranch_scc1 L_loaded_%=\n" \
+    TI_DISPATCH \
+    /* ---- fetch 63 clauses at s89, rewrite the clause words ---- */ \
+    "L_load_%=:\n" \
+    "s_mov_b32 s84, s89\n" \
+    "s_mov_b32 s85, 0\n" \
+    "s_lshl_b64 s[84:85], s[84:85], 3\n" \
+    "s_add_u32 s84, s84, %[tlo]\n" \
+    "s_addc_u32 s85, s85, %[thi]\n" \
+    "global_load_dword %[blo], %[lane8], s[84:85]\n" \
+    "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n" \
+    "L_loaded_%=:\n" \
+    "s_mov_b32 s88, -1\n" \
+    "v_mov_b32 v45, 0\n" \
+    "v_mov_b32 v47, 32\n" \
+    "v_mov_b32 v48, 64\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    "v_bfe_u32 v44, %[blo], 8, 8\n"                 /* out slot */ \
+    "v_and_b32 v42, 0xff, %[blo]\n" \
+    "v_min_u32 v42, 30, v42\n"                       /* opcode; unknown ones -> handler 30 */ \
+    "v_mov_b32_dpp v45, v44 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */ \
+    "v_bfe_u32 v46, %[blo], 16, 8\n"                /* lhs slot */ \
+    "v_lshrrev_b32 v43, 24, %[blo]\n"               /* rhs slot */ \
+    "v_cmp_eq_u32 s[92:93], v43, v45\n" \
+    "v_cmp_eq_u32 vcc, v46, v45\n" \
+    "v_cmp_ne_u32 s[94:95], 0, v45\n" \
+    "v_cndmask_b32 v46, 0, v48, s[92:93]\n"          /* rhs forwarded: table 2 */ \
+    "v_cndmask_b32 v46, v46, v47, vcc\n"             /* lhs forwarded: table 1 */ \
+    "v_cndmask_b32 v46, 0, v46, s[94:95]\n" \
+    "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */ \
+    "v_mov_b32 v43, 31\n" \
+    "v_add_u32 v42, v42, v46\n" \
+    "v_cndmask_b32 v42, v42, v43, vcc\n"             /* handler index = table * 32 + opcode */ \
+    /* clause word as the handlers see it: byte 0 = 2 * out slot, byte 1 = handler index, \
+    * bytes 2, 3 = 2 * lhs, 2 * rhs (slots < 128) */ \
+    "v_lshlrev_b32 v44, 1, v44\n" \
+    "v_lshl_or_b32 v42, v42, 8, v44\n" \
+    "v_and_b32 %[blo], 0xffff0000, %[blo]\n" \
+    "v_lshlrev_b32 %[blo], 1, %[blo]\n" \
+    "v_or_b32 %[blo], %[blo], v42\n" \
+    "s_nop 0\n" \
+    TI_DISPATCH \
+    /* ---- handlers: three tables of 32 x 256 bytes ---- */ \
+    TI_TABLE(0, TI_AL, TI_AR, TI_W, TI_W, TI_W) \
+    TI_TABLE(1, TI_FL, TI_AR, "", TI_W, TI_W) \
+    TI_TABLE(2, TI_AL, TI_FR, TI_W, "", TI_W) \
+    /* ---- i_square(v[36:37]) (device_math.hpp) ---- */ \
+    ".p2align 8\n" \
+    "L_square_%=:\n" \
+    "v_cmp_lt_f32 s[92:93], v37, -v36\n"             /* big: -lo > hi */ \
+    "v_mul_f32 v42, v36, v36\n"                      /* a = RU(lo * lo) */ \
+    "v_mul_f32 v43, v37, v37\n"                      /* b = RU(hi * hi) */ \
+    "v_mul_f32_e64 v44, -v36, v36\n"                 /* -c, c = RD(lo * lo) */ \
+    "v_cmp_lt_f32 vcc, 0, v36\n"                     /* pos */ \
+    "v_cmp_gt_f32 s[94:95], 0, v37\n"                /* neg */ \
+    "v_cndmask_b32 v45, v43, v42, s[92:93]\n" \
+    "v_cndmask_b32 v40, 0, -v44, vcc\n" \
+    "v_cndmask_b32 v45, v45, v43, vcc\n" \
+    "v_mul_f32_e64 v46, -v37, v37\n"                 /* -d, d = RD(hi * hi) */ \
+    "v_cndmask_b32 v41, v45, v42, s[94:95]\n" \
+    "v_cndmask_b32 v40, v40, -v46, s[94:95]\n" \
+    TI_END \
+    /* ---- i_abs(v[36:37]) ---- */ \
+    "L_abs_%=:\n" \
+    "v_max_f32 v42, v37, v37\n" \
+    "v_max_f32_e64 v43, -v36, -v36\n" \
+    "v_max_f32 v43, v43, v42\n"                      /* m = fmax(-lo, hi) */ \
+    "v_cmp_gt_f32 vcc, 0, v37\n"                     /* neg: hi < 0 */ \
+    "v_cmp_le_f32 s[92:93], 0, v36\n"                /* nonneg: lo >= 0 */ \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v42, 0, -v37, vcc\n" \
+    "v_cndmask_b32 v43, v43, -v36, vcc\n" \
+    "v_cndmask_b32 v40, v42, v36, s[92:93]\n" \
+    "v_cndmask_b32 v41, v43, v37, s[92:93]\n" \
+    TI_END \
+    /* ---- i_mul(v[36:37], v[38:39]): sign-case table without branches ---- */ \
+    "L_mul_%=:\n" \
+    "v_cmp_gt_f32 s[40:41], 0, v36\n"                /* xn */ \
+    "v_cmp_nlt_f32 s[42:43], 0, v37\n"               /* !xp */ \
+    "v_cmp_ngt_f32 s[46:47], 0, v38\n"               /* !yn */ \
+    "v_cmp_lt_f32 s[50:51], 0, v39\n"                /* yp */ \
+    "v_cmp_lt_f32 s[44:45], 0, v37\n"                /* xp */ \
+    "s_and_b64 s[42:43], s[40:41], s[42:43]\n"       /* xN */ \
+    "s_and_b64 s[58:59], s[46:47], s[50:51]\n"       /* yP */ \
+    "s_or_b64 s[46:47], s[46:47], s[50:51]\n"        /* !yN */ \
+    "v_cmp_ngt_f32 vcc, 0, v36\n"                    /* !xn */ \
+    "v_cmp_gt_f32 s[48:49], 0, v38\n"                /* yn */ \
+    "s_and_b64 s[52:53], s[40:41], s[44:45]\n"       /* xM */ \
+    "s_and_b64 s[46:47], s[46:47], s[42:43]\n"       /* !yN & xN */ \
+    "s_and_b64 s[54:55], vcc, s[44:45]\n"            /* xP */ \
+    "s_and_b64 s[56:57], s[48:49], s[50:51]\n"       /* yM */ \
+    "s_or_b64 vcc, s[58:59], s[46:47]\n"             /* p is x.lo */ \
+    "s_and_b64 s[46:47], s[52:53], s[58:59]\n"       /* xM & yP */ \
+    "v_cndmask_b32 v42, v37, v36, vcc\n"             /* p */ \
+    "s_or_b64 vcc, s[42:43], s[46:47]\n"             /* q is y.hi */ \
+    "s_and_b64 s[42:43], s[54:55], s[56:57]\n"       /* xP & yM */ \
+    "v_cndmask_b32 v43, v38, v39, vcc\n"             /* q */ \
+    "s_or_b64 vcc, s[58:59], s[42:43]\n"             /* r is x.hi */ \
+    "v_cndmask_b32 v44, v36, v37, vcc\n"             /* r */ \
+    "s_or_b64 vcc, s[54:55], s[46:47]\n"             /* s is y.hi */ \
+    "v_cndmask_b32 v45, v38, v39, vcc\n"             /* s */ \
+    "v_mul_f32_e64 v42, -v42, v43\n"                 /* -lo = RU(-p * q) */ \
+    "v_mul_f32 v43, v44, v45\n"                      /* hi = RU(r * s) */ \
+    "v_mul_f32_e64 v44, -v36, v39\n"                 /* -lo2 = RU(-x.lo * y.hi) */ \
+    "v_mul_f32 v45, v37, v39\n"                      /* hi2 = RU(x.hi * y.hi) */ \
+    "s_and_b64 vcc, s[52:53], s[56:57]\n"            /* M * M */ \
+    "v_max_f32 v46, v42, v42\n" \
+    "v_max_f32 v44, v44, v44\n" \
+    "v_max_f32 v44, v44, v46\n"                      /* -min(lo2, lo) */ \
+    "v_cndmask_b32 v40, v42, v44, vcc\n" \
+    "v_max_f32 v44, v43, v43\n" \
+    "v_max_f32 v45, v45, v45\n" \
+    "v_max_f32 v45, v44, v45\n"                      /* max(hi, hi2) */ \
+    "s_or_b64 s[40:41], s[40:41], s[44:45]\n"        /* xn | xp */ \
+    "s_or_b64 s[42:43], s[48:49], s[50:51]\n"        /* yn | yp */ \
+    "v_xor_b32 v40, 0x80000000, v40\n" \
+    "v_cndmask_b32 v41, v43, v45, vcc\n" \
+    "s_and_b64 vcc, s[40:41], s[42:43]\n"            /* neither operand is the zero class */ \
+    "v_cndmask_b32 v40, 0, v40, vcc\n" \
+    "v_cndmask_b32 v41, 0, v41, vcc\n" \
+    TI_END \
+    /* ---- i_min(v[36:37], v[38:39]) + choice ---- */ \
+    "L_min_%=:\n" \
+    "v_max_f32 v42, v38, v38\n" \
+    "v_max_f32 v43, v36, v36\n" \
+    "v_max_f32 v44, v39, v39\n" \
+    "v_cmp_nlt_f32 vcc, v37, v38\n"                  /* !c1, c1: x.hi < y.lo */ \
+    "v_cmp_gt_f32 s[92:93], v36, v39\n"              /* y.hi < x.lo */ \
+    "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */ \
+    "v_min_f32 v42, v43, v42\n" \
+    "v_max_f32 v43, v37, v37\n" \
+    "v_min_f32 v43, v43, v44\n" \
+    "s_branch L_choice_%=\n" \
+    /* ---- i_max ---- */ \
+    "L_max_%=:\n" \
+    "v_max_f32 v42, v38, v38\n" \
+    "v_max_f32 v43, v36, v36\n" \
+    "v_max_f32 v44, v39, v39\n" \
+    "v_cmp_ngt_f32 vcc, v36, v39\n"                  /* !c1, c1: x.lo > y.hi */ \
+    "v_cmp_lt_f32 s[92:93], v37, v38\n"              /* y.lo > x.hi */ \
+    "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */ \
+    "v_max_f32 v42, v43, v42\n" \
+    "v_max_f32 v43, v37, v37\n" \
+    "v_max_f32 v43, v43, v44\n" \
+    /* result = c1 ? x : c2 ? y : (v42, v43); record {lanes that chose lhs, lanes that chose rhs} */ \
+    "L_choice_%=:\n" \
+    "v_cndmask_b32 v40, v42, v38, s[92:93]\n" \
+    "v_cndmask_b32 v41, v43, v39, s[92:93]\n" \
+    "v_cndmask_b32 v40, v36, v40, vcc\n" \
+    "v_cndmask_b32 v41, v37, v41, vcc\n" \
+    "s_andn2_b64 s[94:95], s[72:73], vcc\n"          /* chose lhs */ \
+    "s_and_b64 s[92:93], s[92:93], s[72:73]\n"       /* chose rhs */ \
+    "s_or_b64 s[76:77], s[76:77], s[94:95]\n" \
+    "s_or_b64 s[76:77], s[76:77], s[92:93]\n" \
+    "s_cmp_lt_u32 s74, s75\n" \
+    "s_cbranch_scc0 L_nochoice_%=\n" \
+    "s_mov_b64 exec, 1\n" \
+    "v_mov_b32 v42, s94\n" \
+    "v_mov_b32 v43, s95\n" \
+    "v_mov_b32 v44, s92\n" \
+    "v_mov_b32 v45, s93\n" \
+    "v_mov_b32 v46, s74\n" \
+    "ds_write_b128 v46, v[42:45]\n" \
+    "s_mov_b64 exec, -1\n" \
+    "L_nochoice_%=:\n" \
+    "s_add_u32 s74, s74, 16\n" \
+    "s_add_u32 s78, s78, 1\n" \
+    TI_END \
+    /* ---- i_div(v[36:37], v[38:39]) (device_math.hpp: operands of the two directed quotients by \
+    *      selects, quotients in a round-to-nearest sandwich, moved one ulp by the residual's sign); \
+    *      s[58:59]: lanes whose divisor contains zero ---- */ \
+    "L_idiv_%=:\n" \
+    "s_movk_i32 s56, 0x1f8\n" \
+    "s_movk_i32 s57, 0x198\n" \
+    "v_cmp_gt_f32 s[40:41], 0, v37\n"                /* xn: x.hi < 0 */ \
+    "v_cmp_gt_f32 s[42:43], 0, v36\n"                /* x.lo < 0 */ \
+    "v_cmp_gt_f32 vcc, 0, v39\n"                     /* yn: y.hi < 0 */ \
+    "s_andn2_b64 s[42:43], s[42:43], s[40:41]\n"     /* xm */ \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v42, v36, v37, vcc\n"             /* a1 = yn ? x.hi : x.lo */ \
+    "v_cndmask_b32 v43, v37, v36, vcc\n"             /* a2 = yn ? x.lo : x.hi */ \
+    "v_cndmask_b32 v44, v38, v39, vcc\n"             /* ym = yn ? y.hi : y.lo */ \
+    "v_cndmask_b32 v45, v39, v44, s[42:43]\n" \
+    "v_cndmask_b32 v45, v45, v38, s[40:41]\n"        /* b1 = xn ? y.lo : xm ? ym : y.hi */ \
+    "v_cndmask_b32 v46, v38, v44, s[42:43]\n" \
+    "v_cndmask_b32 v46, v46, v39, s[40:41]\n"        /* b2 = xn ? y.hi : xm ? ym : y.lo */ \
+    /* Fast path, taken when every lane is away from the edges of the format — numerators zero or \
+    * 2^-60 <= |a| <= 2^60, divisors 2^-30 <= |b| <= 2^30, so that quotients and residuals stay normal: \
+    * reciprocal by v_rcp + one Newton step, quotient by one correction (rounded up for the lower bound, \
+    * down for the upper one), then the EXACT residual r = a - q b says on which side of q the true \
+    * quotient lies, and the directed result is q or its neighbour.  No switch to \
+    * round-to-nearest, a third of the instructions of the general sequence below. */ \
+    "v_and_b32 v51, 0x7fffffff, v45\n"               /* |b1| */ \
+    "v_and_b32 v52, 0x7fffffff, v46\n"               /* |b2| */ \
+    "v_and_b32 v53, 0x7fffffff, v42\n"               /* |a1| */ \
+    "v_and_b32 v54, 0x7fffffff, v43\n"               /* |a2| */ \
+    "v_min_u32 v55, v51, v52\n" \
+    "v_max_u32 v51, v51, v52\n" \
+    "s_mov_b32 s44, 0x30800000\n"                    /* 2^-30 */ \
+    "s_mov_b32 s45, 0x4e800000\n"                    /* 2^30 */ \
+    "v_cmp_le_u32 s[46:47], s44, v55\n" \
+    "v_cmp_ge_u32 vcc, s45, v51\n" \
+    "s_and_b64 s[46:47], s[46:47], vcc\n" \
+    "s_mov_b32 s44, 0x21800000\n"                    /* 2^-60 */ \
+    "s_mov_b32 s45, 0x5d800000\n"                    /* 2^60 */ \
+    "v_max_u32 v51, v53, v54\n" \
+    "v_cmp_ge_u32 vcc, s45, v51\n" \
+    "s_and_b64 s[46:47], s[46:47], vcc\n" \
+    "v_cmp_le_u32 s[48:49], s44, v53\n" \
+    "v_cmp_eq_u32 s[50:51], 0, v53\n"               /* a1 is a zero */ \
+    "s_or_b64 s[48:49], s[48:49], s[50:51]\n" \
+    "s_and_b64 s[46:47], s[46:47], s[48:49]\n" \
+    "v_cmp_le_u32 s[48:49], s44, v54\n" \
+    "v_cmp_eq_u32 s[52:53], 0, v54\n"               /* a2 is a zero */ \
+    "s_or_b64 s[48:49], s[48:49], s[52:53]\n" \
+    "s_and_b64 s[46:47], s[46:47], s[48:49]\n" \
+    "s_cmp_eq_u64 s[46:47], exec\n" \
+    "s_cbranch_scc0 L_idiv_slow_%=\n" \
+    "v_rcp_f32 v51, v45\n" \
+    "v_rcp_f32 v52, v46\n" \
+    "s_nop 0\n" \
+    "v_fma_f32 v53, -v45, v51, 1.0\n" \
+    "v_fma_f32 v54, -v46, v52, 1.0\n" \
+    "v_fmac_f32 v51, v53, v51\n"                     /* 1 / b1 */ \
+    "v_fmac_f32 v52, v54, v52\n"                     /* 1 / b2 */ \
+    "v_mul_f32 v47, v42, v51\n" \
+    "v_mul_f32 v49, v43, v52\n" \
+    "v_fma_f32 v48, -v47, v45, v42\n" \
+    "v_fma_f32 v50, -v49, v46, v43\n" \
+    "v_fma_f32 v53, v48, v51, v47\n"                 /* q1 = RU(S1), S1 = a1 / b1 up to a fraction of an ulp */ \
+    "v_fma_f32 v54, -v50, v52, -v49\n"               /* -q2 = RU(-S2): q2 = RD(S2) — each quotient errs to */ \
+    "v_xor_b32 v54, 0x80000000, v54\n"               /* the side its single correction step can undo */ \
+    "v_cndmask_b32 v47, v53, v47, s[50:51]\n"        /* a zero numerator: the product already is the */ \
+    "v_cndmask_b32 v49, v54, v49, s[52:53]\n"        /* signed zero (the sum above would lose its sign) */ \
+    "v_fma_f32 v48, -v47, v45, v42\n"                /* exact residuals */ \
+    "v_fma_f32 v50, -v49, v46, v43\n" \
+    /* lower bound: one ulp down when the true quotient is below q1 (r1 and b1 of opposite sign) */ \
+    "v_xor_b32 v51, v48, v45\n" \
+    "v_ashrrev_i32 v52, 31, v47\n" \
+    "v_cmp_gt_i32 vcc, 0, v51\n" \
+    "v_cmp_neq_f32 s[44:45], 0, v48\n" \
+    "v_or_b32 v52, 1, v52\n"                         /* -1 for a negative q1, else 1 */ \
+    "s_and_b64 vcc, vcc, s[44:45]\n" \
+    "v_sub_u32 v52, v47, v52\n"                      /* next_down(q1) */ \
+    "v_cndmask_b32 v40, v47, v52, vcc\n" \
+    /* upper bound: one ulp up when the true quotient is above q2 (r2 and b2 of the same sign) */ \
+    "v_xor_b32 v51, v50, v46\n" \
+    "v_ashrrev_i32 v52, 31, v49\n" \
+    "v_cmp_lt_i32 vcc, -1, v51\n" \
+    "v_cmp_neq_f32 s[44:45], 0, v50\n" \
+    "v_or_b32 v52, 1, v52\n" \
+    "s_and_b64 vcc, vcc, s[44:45]\n" \
+    "v_add_u32 v52, v49, v52\n"                      /* next_up(q2) */ \
+    "v_cndmask_b32 v41, v49, v52, vcc\n" \
+    "s_branch L_idiv_tail_%=\n" \
+    "L_idiv_slow_%=:\n"                              /* some lane at the edges of the format: compiled routine */ \
+    "v_mov_b32 v47, v34\n" \
+    "v_mov_b32 v0, v42\n v_mov_b32 v1, v45\n v_mov_b32 v2, v43\n v_mov_b32 v3, v46\n" \
+    "s_getpc_b64 s[40:41]\n" \
+    "s_add_u32 s40, s40, mpr_ti_divx@rel32@lo+4\n" \
+    "s_addc_u32 s41, s41, mpr_ti_divx@rel32@hi+12\n" \
+    "s_swappc_b64 s[30:31], s[40:41]\n" \
+    "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v47\n" \
+    "L_idiv_tail_%=:\n" \
+    "v_mov_b32 v51, 0xff800000\n" \
+    "v_mov_b32 v52, 0x7f800000\n" \
+    "v_cndmask_b32 v40, v40, v51, s[58:59]\n" \
+    "v_cndmask_b32 v41, v41, v52, s[58:59]\n" \
+    TI_END \
+    /* ---- i_sqrt(v[36:37]): x.hi < 0: NaN; lower bound 0 when x.lo <= 0 ---- */ \
+    "L_isqrt_%=:\n" \
+    "s_movk_i32 s55, 0x260\n" \
+    "s_movk_i32 s56, 0x1f8\n" \
+    "v_cmp_ge_f32 vcc, 0, v36\n"                     /* x.lo <= 0 */ \
+    "v_cmp_gt_f32 s[58:59], 0, v37\n"                /* x.hi < 0 */ \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v42, v36, 0, vcc\n"               /* a */ \
+    /* Fast path when every lane's operands are zero or 2^-60 <= x <= 2^60 (negative upper ends pass: \
+    * their lanes are overwritten with NaN below): v_sqrt_f32 is within one ulp, so the directed \
+    * roots are among y - 1 ulp, y, y + 1 ulp, told apart by the signs of x - c^2 (fma).  No switch \
+    * to round-to-nearest, half the instructions of the general sequence. */ \
+    "v_and_b32 v52, 0x7fffffff, v37\n" \
+    "s_mov_b32 s44, 0x21800000\n"                    /* 2^-60 */ \
+    "s_mov_b32 s45, 0x5d800000\n"                    /* 2^60 */ \
+    "v_cmp_le_u32 s[46:47], s44, v42\n" \
+    "v_cmp_eq_u32 s[50:51], 0, v42\n"               /* a is zero */ \
+    "v_cmp_ge_u32 vcc, s45, v42\n" \
+    "s_or_b64 s[46:47], s[46:47], s[50:51]\n" \
+    "s_and_b64 s[46:47], s[46:47], vcc\n" \
+    "v_cmp_le_u32 s[48:49], s44, v52\n" \
+    "v_cmp_eq_u32 s[52:53], 0, v52\n"               /* x.hi is a zero */ \
+    "v_cmp_ge_u32 vcc, s45, v52\n" \
+    "s_or_b64 s[48:49], s[48:49], s[52:53]\n" \
+    "s_and_b64 s[48:49], s[48:49], vcc\n" \
+    "s_and_b64 s[46:47], s[46:47], s[48:49]\n" \
+    "s_cmp_eq_u64 s[46:47], exec\n" \
+    "s_cbranch_scc0 L_isqrt_slow_%=\n" \
+    "v_sqrt_f32 v47, v42\n" \
+    "v_sqrt_f32 v49, v37\n" \
+    "s_nop 0\n" \
+    "v_add_u32 v51, 1, v47\n"                        /* lower: y + 1 ulp, y - 1 ulp */ \
+    "v_add_u32 v52, -1, v47\n" \
+    "v_add_u32 v54, 1, v49\n"                        /* upper */ \
+    "v_add_u32 v55, -1, v49\n" \
+    "v_fma_f32 v48, -v47, v47, v42\n"                /* x - y^2 */ \
+    "v_fma_f32 v53, -v51, v51, v42\n"                /* x - (y + 1)^2 */ \
+    "v_fma_f32 v50, -v49, v49, v37\n" \
+    "v_fma_f32 v43, -v55, v55, v37\n"                /* x - (y - 1)^2 */ \
+    "v_cmp_le_f32 s[44:45], 0, v53\n"               /* y + 1 still not above the root */ \
+    "v_cmp_gt_f32 s[46:47], 0, v48\n"               /* y above the root */ \
+    "v_cmp_ge_f32 s[48:49], 0, v43\n"               /* y - 1 still not below the root */ \
+    "v_cmp_lt_f32 vcc, 0, v50\n"                    /* y below the root */ \
+    "v_cndmask_b32 v51, v47, v51, s[44:45]\n" \
+    "v_cndmask_b32 v55, v49, v55, s[48:49]\n" \
+    "v_cndmask_b32 v40, v51, v52, s[46:47]\n"        /* largest c with c^2 <= x */ \
+    "v_cndmask_b32 v41, v55, v54, vcc\n"             /* smallest c with c^2 >= x */ \
+    "v_cndmask_b32 v40, v40, v42, s[50:51]\n"        /* the root of a zero is that zero */ \
+    "v_cndmask_b32 v41, v41, v37, s[52:53]\n" \
+    "s_branch L_isqrt_tail_%=\n" \
+    "L_isqrt_slow_%=:\n" \
+    "v_mov_b32 v47, v34\n" \
+    "v_mov_b32 v0, v42\n v_mov_b32 v1, v37\n" \
+    "s_getpc_b64 s[40:41]\n" \
+    "s_add_u32 s40, s40, mpr_ti_sqrtx@rel32@lo+4\n" \
+    "s_addc_u32 s41, s41, mpr_ti_sqrtx@rel32@hi+12\n" \
+    "s_swappc_b64 s[30:31], s[40:41]\n" \
+    "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v47\n" \
+    "L_isqrt_tail_%=:\n" \
+    "v_mov_b32 v51, 0x7fc00000\n" \
+    "v_cndmask_b32 v40, v40, v51, s[58:59]\n" \
+    "v_cndmask_b32 v41, v41, v51, s[58:59]\n" \
+    TI_END \
+    /* ---- compiled routines (double precision inside): called, not left for ---- */ \
+    "L_casin_%=:\n" TI_CALL("mpr_ti_asin") \
+    "L_cacos_%=:\n" TI_CALL("mpr_ti_acos") \
+    "L_catan_%=:\n" TI_CALL("mpr_ti_atan") \
+    "L_cexp_%=:\n" TI_CALL("mpr_ti_exp") \
+    "L_clog_%=:\n" TI_CALL("mpr_ti_log") \
+    /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */ \
+    "L_exit_%=:\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    TI_VS_LEAVE \
+    "s_mov_b32 %[dlo], s86\n" \
+    "s_mov_b32 %[dhi], s87\n" \
+    "s_mov_b32 %[base], s89\n" \
+    "s_mov_b32 %[sj], s88\n" \
+    "s_mov_b32 %[caddr], s74\n" \
+    "s_mov_b32 %[anylo], s76\n" \
+    "s_mov_b32 %[anyhi], s77\n" \
+    "s_mov_b32 %[ci], s78\n" \
+    "s_mov_b32 %[words], s79\n"
 
 struct TileInterpResult {
     uint32_t result_slot;     /* slot named by the end clause */
@@ -223,376 +602,7 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
         anylo = rdfirst(anylo);
         anyhi = rdfirst(anyhi);
         asm volatile(
-            "s_mov_b32 s89, %[base]\n"
-            "s_mov_b32 s88, %[sj]\n"
-            "s_mov_b32 s96, 0xff00\n"
-            "s_mov_b32 s72, %[alo]\n"
-            "s_mov_b32 s73, %[ahi]\n"
-            "s_mov_b32 s74, %[caddr]\n"
-            "s_mov_b32 s75, %[cend]\n"
-            "s_mov_b32 s76, %[anylo]\n"
-            "s_mov_b32 s77, %[anyhi]\n"
-            "s_mov_b32 s78, %[ci]\n"
-            "s_mov_b32 s79, %[words]\n"
-            "v_mov_b32 v40, %[plo]\n"
-            "v_mov_b32 v41, %[phi]\n"
-            "s_getpc_b64 s[82:83]\n"
-            "L_pc_%=:\n"
-            "s_add_u32 s82, s82, L_t0_0_%=-L_pc_%=\n"
-            "s_addc_u32 s83, s83, 0\n"
-            "s_cmp_eq_u32 %[mode], 0\n"
-            "s_cbranch_scc1 L_load_%=\n"
-            "s_cmp_eq_u32 %[mode], 2\n"
-            "s_cbranch_scc1 L_loaded_%=\n"
-            TI_DISPATCH
-            /* ---- fetch 63 clauses at s89, rewrite the clause words ---- */
-            "L_load_%=:\n"
-            "s_mov_b32 s84, s89\n"
-            "s_mov_b32 s85, 0\n"
-            "s_lshl_b64 s[84:85], s[84:85], 3\n"
-            "s_add_u32 s84, s84, %[tlo]\n"
-            "s_addc_u32 s85, s85, %[thi]\n"
-            "global_load_dword %[blo], %[lane8], s[84:85]\n"
-            "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
-            "L_loaded_%=:\n"
-            "s_mov_b32 s88, -1\n"
-            "v_mov_b32 v45, 0\n"
-            "v_mov_b32 v47, 32\n"
-            "v_mov_b32 v48, 64\n"
-            "s_waitcnt vmcnt(0)\n"
-            "v_bfe_u32 v44, %[blo], 8, 8\n"                 /* out slot */
-            "v_and_b32 v42, 0xff, %[blo]\n"
-            "v_min_u32 v42, 30, v42\n"                       /* opcode; unknown ones -> handler 30 */
-            "v_mov_b32_dpp v45, v44 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */
-            "v_bfe_u32 v46, %[blo], 16, 8\n"                /* lhs slot */
-            "v_lshrrev_b32 v43, 24, %[blo]\n"               /* rhs slot */
-            "v_cmp_eq_u32 s[92:93], v43, v45\n"
-            "v_cmp_eq_u32 vcc, v46, v45\n"
-            "v_cmp_ne_u32 s[94:95], 0, v45\n"
-            "v_cndmask_b32 v46, 0, v48, s[92:93]\n"          /* rhs forwarded: table 2 */
-            "v_cndmask_b32 v46, v46, v47, vcc\n"             /* lhs forwarded: table 1 */
-            "v_cndmask_b32 v46, 0, v46, s[94:95]\n"
-            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */
-            "v_mov_b32 v43, 31\n"
-            "v_add_u32 v42, v42, v46\n"
-            "v_cndmask_b32 v42, v42, v43, vcc\n"             /* handler index = table * 32 + opcode */
-            /* clause word as the handlers see it: byte 0 = 2 * out slot, byte 1 = handler index,
-             * bytes 2, 3 = 2 * lhs, 2 * rhs (slots < 128) */
-            "v_lshlrev_b32 v44, 1, v44\n"
-            "v_lshl_or_b32 v42, v42, 8, v44\n"
-            "v_and_b32 %[blo], 0xffff0000, %[blo]\n"
-            "v_lshlrev_b32 %[blo], 1, %[blo]\n"
-            "v_or_b32 %[blo], %[blo], v42\n"
-            "s_nop 0\n"
-            TI_DISPATCH
-            /* ---- handlers: three tables of 32 x 256 bytes ---- */
-            TI_TABLE(0, TI_AL, TI_AR, TI_W, TI_W, TI_W)
-            TI_TABLE(1, TI_FL, TI_AR, "", TI_W, TI_W)
-            TI_TABLE(2, TI_AL, TI_FR, TI_W, "", TI_W)
-            /* ---- i_square(v[36:37]) (device_math.hpp) ---- */
-            ".p2align 8\n"
-            "L_square_%=:\n"
-            "v_cmp_lt_f32 s[92:93], v37, -v36\n"             /* big: -lo > hi */
-            "v_mul_f32 v42, v36, v36\n"                      /* a = RU(lo * lo) */
-            "v_mul_f32 v43, v37, v37\n"                      /* b = RU(hi * hi) */
-            "v_mul_f32_e64 v44, -v36, v36\n"                 /* -c, c = RD(lo * lo) */
-            "v_cmp_lt_f32 vcc, 0, v36\n"                     /* pos */
-            "v_cmp_gt_f32 s[94:95], 0, v37\n"                /* neg */
-            "v_cndmask_b32 v45, v43, v42, s[92:93]\n"
-            "v_cndmask_b32 v40, 0, -v44, vcc\n"
-            "v_cndmask_b32 v45, v45, v43, vcc\n"
-            "v_mul_f32_e64 v46, -v37, v37\n"                 /* -d, d = RD(hi * hi) */
-            "v_cndmask_b32 v41, v45, v42, s[94:95]\n"
-            "v_cndmask_b32 v40, v40, -v46, s[94:95]\n"
-            TI_END
-            /* ---- i_abs(v[36:37]) ---- */
-            "L_abs_%=:\n"
-            "v_max_f32 v42, v37, v37\n"
-            "v_max_f32_e64 v43, -v36, -v36\n"
-            "v_max_f32 v43, v43, v42\n"                      /* m = fmax(-lo, hi) */
-            "v_cmp_gt_f32 vcc, 0, v37\n"                     /* neg: hi < 0 */
-            "v_cmp_le_f32 s[92:93], 0, v36\n"                /* nonneg: lo >= 0 */
-            "s_nop 0\n"
-            "v_cndmask_b32 v42, 0, -v37, vcc\n"
-            "v_cndmask_b32 v43, v43, -v36, vcc\n"
-            "v_cndmask_b32 v40, v42, v36, s[92:93]\n"
-            "v_cndmask_b32 v41, v43, v37, s[92:93]\n"
-            TI_END
-            /* ---- i_mul(v[36:37], v[38:39]): sign-case table without branches ---- */
-            "L_mul_%=:\n"
-            "v_cmp_gt_f32 s[40:41], 0, v36\n"                /* xn */
-            "v_cmp_nlt_f32 s[42:43], 0, v37\n"               /* !xp */
-            "v_cmp_ngt_f32 s[46:47], 0, v38\n"               /* !yn */
-            "v_cmp_lt_f32 s[50:51], 0, v39\n"                /* yp */
-            "v_cmp_lt_f32 s[44:45], 0, v37\n"                /* xp */
-            "s_and_b64 s[42:43], s[40:41], s[42:43]\n"       /* xN */
-            "s_and_b64 s[58:59], s[46:47], s[50:51]\n"       /* yP */
-            "s_or_b64 s[46:47], s[46:47], s[50:51]\n"        /* !yN */
-            "v_cmp_ngt_f32 vcc, 0, v36\n"                    /* !xn */
-            "v_cmp_gt_f32 s[48:49], 0, v38\n"                /* yn */
-            "s_and_b64 s[52:53], s[40:41], s[44:45]\n"       /* xM */
-            "s_and_b64 s[46:47], s[46:47], s[42:43]\n"       /* !yN & xN */
-            "s_and_b64 s[54:55], vcc, s[44:45]\n"            /* xP */
-            "s_and_b64 s[56:57], s[48:49], s[50:51]\n"       /* yM */
-            "s_or_b64 vcc, s[58:59], s[46:47]\n"             /* p is x.lo */
-            "s_and_b64 s[46:47], s[52:53], s[58:59]\n"       /* xM & yP */
-            "v_cndmask_b32 v42, v37, v36, vcc\n"             /* p */
-            "s_or_b64 vcc, s[42:43], s[46:47]\n"             /* q is y.hi */
-            "s_and_b64 s[42:43], s[54:55], s[56:57]\n"       /* xP & yM */
-            "v_cndmask_b32 v43, v38, v39, vcc\n"             /* q */
-            "s_or_b64 vcc, s[58:59], s[42:43]\n"             /* r is x.hi */
-            "v_cndmask_b32 v44, v36, v37, vcc\n"             /* r */
-            "s_or_b64 vcc, s[54:55], s[46:47]\n"             /* s is y.hi */
-            "v_cndmask_b32 v45, v38, v39, vcc\n"             /* s */
-            "v_mul_f32_e64 v42, -v42, v43\n"                 /* -lo = RU(-p * q) */
-            "v_mul_f32 v43, v44, v45\n"                      /* hi = RU(r * s) */
-            "v_mul_f32_e64 v44, -v36, v39\n"                 /* -lo2 = RU(-x.lo * y.hi) */
-            "v_mul_f32 v45, v37, v39\n"                      /* hi2 = RU(x.hi * y.hi) */
-            "s_and_b64 vcc, s[52:53], s[56:57]\n"            /* M * M */
-            "v_max_f32 v46, v42, v42\n"
-            "v_max_f32 v44, v44, v44\n"
-            "v_max_f32 v44, v44, v46\n"                      /* -min(lo2, lo) */
-            "v_cndmask_b32 v40, v42, v44, vcc\n"
-            "v_max_f32 v44, v43, v43\n"
-            "v_max_f32 v45, v45, v45\n"
-            "v_max_f32 v45, v44, v45\n"                      /* max(hi, hi2) */
-            "s_or_b64 s[40:41], s[40:41], s[44:45]\n"        /* xn | xp */
-            "s_or_b64 s[42:43], s[48:49], s[50:51]\n"        /* yn | yp */
-            "v_xor_b32 v40, 0x80000000, v40\n"
-            "v_cndmask_b32 v41, v43, v45, vcc\n"
-            "s_and_b64 vcc, s[40:41], s[42:43]\n"            /* neither operand is the zero class */
-            "v_cndmask_b32 v40, 0, v40, vcc\n"
-            "v_cndmask_b32 v41, 0, v41, vcc\n"
-            TI_END
-            /* ---- i_min(v[36:37], v[38:39]) + choice ---- */
-            "L_min_%=:\n"
-            "v_max_f32 v42, v38, v38\n"
-            "v_max_f32 v43, v36, v36\n"
-            "v_max_f32 v44, v39, v39\n"
-            "v_cmp_nlt_f32 vcc, v37, v38\n"                  /* !c1, c1: x.hi < y.lo */
-            "v_cmp_gt_f32 s[92:93], v36, v39\n"              /* y.hi < x.lo */
-            "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
-            "v_min_f32 v42, v43, v42\n"
-            "v_max_f32 v43, v37, v37\n"
-            "v_min_f32 v43, v43, v44\n"
-            "s_branch L_choice_%=\n"
-            /* ---- i_max ---- */
-            "L_max_%=:\n"
-            "v_max_f32 v42, v38, v38\n"
-            "v_max_f32 v43, v36, v36\n"
-            "v_max_f32 v44, v39, v39\n"
-            "v_cmp_ngt_f32 vcc, v36, v39\n"                  /* !c1, c1: x.lo > y.hi */
-            "v_cmp_lt_f32 s[92:93], v37, v38\n"              /* y.lo > x.hi */
-            "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
-            "v_max_f32 v42, v43, v42\n"
-            "v_max_f32 v43, v37, v37\n"
-            "v_max_f32 v43, v43, v44\n"
-            /* result = c1 ? x : c2 ? y : (v42, v43); record {lanes that chose lhs, lanes that chose rhs} */
-            "L_choice_%=:\n"
-            "v_cndmask_b32 v40, v42, v38, s[92:93]\n"
-            "v_cndmask_b32 v41, v43, v39, s[92:93]\n"
-            "v_cndmask_b32 v40, v36, v40, vcc\n"
-            "v_cndmask_b32 v41, v37, v41, vcc\n"
-            "s_andn2_b64 s[94:95], s[72:73], vcc\n"          /* chose lhs */
-            "s_and_b64 s[92:93], s[92:93], s[72:73]\n"       /* chose rhs */
-            "s_or_b64 s[76:77], s[76:77], s[94:95]\n"
-            "s_or_b64 s[76:77], s[76:77], s[92:93]\n"
-            "s_cmp_lt_u32 s74, s75\n"
-            "s_cbranch_scc0 L_nochoice_%=\n"
-            "s_mov_b64 exec, 1\n"
-            "v_mov_b32 v42, s94\n"
-            "v_mov_b32 v43, s95\n"
-            "v_mov_b32 v44, s92\n"
-            "v_mov_b32 v45, s93\n"
-            "v_mov_b32 v46, s74\n"
-            "ds_write_b128 v46, v[42:45]\n"
-            "s_mov_b64 exec, -1\n"
-            "L_nochoice_%=:\n"
-            "s_add_u32 s74, s74, 16\n"
-            "s_add_u32 s78, s78, 1\n"
-            TI_END
-            /* ---- i_div(v[36:37], v[38:39]) (device_math.hpp: operands of the two directed quotients by
-             *      selects, quotients in a round-to-nearest sandwich, moved one ulp by the residual's sign);
-             *      s[58:59]: lanes whose divisor contains zero ---- */
-            "L_idiv_%=:\n"
-            "s_movk_i32 s56, 0x1f8\n"
-            "s_movk_i32 s57, 0x198\n"
-            "v_cmp_gt_f32 s[40:41], 0, v37\n"                /* xn: x.hi < 0 */
-            "v_cmp_gt_f32 s[42:43], 0, v36\n"                /* x.lo < 0 */
-            "v_cmp_gt_f32 vcc, 0, v39\n"                     /* yn: y.hi < 0 */
-            "s_andn2_b64 s[42:43], s[42:43], s[40:41]\n"     /* xm */
-            "s_nop 0\n"
-            "v_cndmask_b32 v42, v36, v37, vcc\n"             /* a1 = yn ? x.hi : x.lo */
-            "v_cndmask_b32 v43, v37, v36, vcc\n"             /* a2 = yn ? x.lo : x.hi */
-            "v_cndmask_b32 v44, v38, v39, vcc\n"             /* ym = yn ? y.hi : y.lo */
-            "v_cndmask_b32 v45, v39, v44, s[42:43]\n"
-            "v_cndmask_b32 v45, v45, v38, s[40:41]\n"        /* b1 = xn ? y.lo : xm ? ym : y.hi */
-            "v_cndmask_b32 v46, v38, v44, s[42:43]\n"
-            "v_cndmask_b32 v46, v46, v39, s[40:41]\n"        /* b2 = xn ? y.hi : xm ? ym : y.lo */
-            /* Fast path, taken when every lane is away from the edges of the format — numerators zero or
-             * 2^-60 <= |a| <= 2^60, divisors 2^-30 <= |b| <= 2^30, so that quotients and residuals stay normal:
-             * reciprocal by v_rcp + one Newton step, quotient by one correction (rounded up for the lower bound,
-             * down for the upper one), then the EXACT residual r = a - q b says on which side of q the true
-             * quotient lies, and the directed result is q or its neighbour.  No switch to
-             * round-to-nearest, a third of the instructions of the general sequence below. */
-            "v_and_b32 v51, 0x7fffffff, v45\n"               /* |b1| */
-            "v_and_b32 v52, 0x7fffffff, v46\n"               /* |b2| */
-            "v_and_b32 v53, 0x7fffffff, v42\n"               /* |a1| */
-            "v_and_b32 v54, 0x7fffffff, v43\n"               /* |a2| */
-            "v_min_u32 v55, v51, v52\n"
-            "v_max_u32 v51, v51, v52\n"
-            "s_mov_b32 s44, 0x30800000\n"                    /* 2^-30 */
-            "s_mov_b32 s45, 0x4e800000\n"                    /* 2^30 */
-            "v_cmp_le_u32 s[46:47], s44, v55\n"
-            "v_cmp_ge_u32 vcc, s45, v51\n"
-            "s_and_b64 s[46:47], s[46:47], vcc\n"
-            "s_mov_b32 s44, 0x21800000\n"                    /* 2^-60 */
-            "s_mov_b32 s45, 0x5d800000\n"                    /* 2^60 */
-            "v_max_u32 v51, v53, v54\n"
-            "v_cmp_ge_u32 vcc, s45, v51\n"
-            "s_and_b64 s[46:47], s[46:47], vcc\n"
-            "v_cmp_le_u32 s[48:49], s44, v53\n"
-            "v_cmp_eq_u32 s[50:51], 0, v53\n"               /* a1 is a zero */
-            "s_or_b64 s[48:49], s[48:49], s[50:51]\n"
-            "s_and_b64 s[46:47], s[46:47], s[48:49]\n"
-            "v_cmp_le_u32 s[48:49], s44, v54\n"
-            "v_cmp_eq_u32 s[52:53], 0, v54\n"               /* a2 is a zero */
-            "s_or_b64 s[48:49], s[48:49], s[52:53]\n"
-            "s_and_b64 s[46:47], s[46:47], s[48:49]\n"
-            "s_cmp_eq_u64 s[46:47], exec\n"
-            "s_cbranch_scc0 L_idiv_slow_%=\n"
-            "v_rcp_f32 v51, v45\n"
-            "v_rcp_f32 v52, v46\n"
-            "s_nop 0\n"
-            "v_fma_f32 v53, -v45, v51, 1.0\n"
-            "v_fma_f32 v54, -v46, v52, 1.0\n"
-            "v_fmac_f32 v51, v53, v51\n"                     /* 1 / b1 */
-            "v_fmac_f32 v52, v54, v52\n"                     /* 1 / b2 */
-            "v_mul_f32 v47, v42, v51\n"
-            "v_mul_f32 v49, v43, v52\n"
-            "v_fma_f32 v48, -v47, v45, v42\n"
-            "v_fma_f32 v50, -v49, v46, v43\n"
-            "v_fma_f32 v53, v48, v51, v47\n"                 /* q1 = RU(S1), S1 = a1 / b1 up to a fraction of an ulp */
-            "v_fma_f32 v54, -v50, v52, -v49\n"               /* -q2 = RU(-S2): q2 = RD(S2) — each quotient errs to */
-            "v_xor_b32 v54, 0x80000000, v54\n"               /* the side its single correction step can undo */
-            "v_cndmask_b32 v47, v53, v47, s[50:51]\n"        /* a zero numerator: the product already is the */
-            "v_cndmask_b32 v49, v54, v49, s[52:53]\n"        /* signed zero (the sum above would lose its sign) */
-            "v_fma_f32 v48, -v47, v45, v42\n"                /* exact residuals */
-            "v_fma_f32 v50, -v49, v46, v43\n"
-            /* lower bound: one ulp down when the true quotient is below q1 (r1 and b1 of opposite sign) */
-            "v_xor_b32 v51, v48, v45\n"
-            "v_ashrrev_i32 v52, 31, v47\n"
-            "v_cmp_gt_i32 vcc, 0, v51\n"
-            "v_cmp_neq_f32 s[44:45], 0, v48\n"
-            "v_or_b32 v52, 1, v52\n"                         /* -1 for a negative q1, else 1 */
-            "s_and_b64 vcc, vcc, s[44:45]\n"
-            "v_sub_u32 v52, v47, v52\n"                      /* next_down(q1) */
-            "v_cndmask_b32 v40, v47, v52, vcc\n"
-            /* upper bound: one ulp up when the true quotient is above q2 (r2 and b2 of the same sign) */
-            "v_xor_b32 v51, v50, v46\n"
-            "v_ashrrev_i32 v52, 31, v49\n"
-            "v_cmp_lt_i32 vcc, -1, v51\n"
-            "v_cmp_neq_f32 s[44:45], 0, v50\n"
-            "v_or_b32 v52, 1, v52\n"
-            "s_and_b64 vcc, vcc, s[44:45]\n"
-            "v_add_u32 v52, v49, v52\n"                      /* next_up(q2) */
-            "v_cndmask_b32 v41, v49, v52, vcc\n"
-            "s_branch L_idiv_tail_%=\n"
-            "L_idiv_slow_%=:\n"                              /* some lane at the edges of the format: compiled routine */
-            "v_mov_b32 v47, v34\n"
-            "v_mov_b32 v0, v42\n v_mov_b32 v1, v45\n v_mov_b32 v2, v43\n v_mov_b32 v3, v46\n"
-            "s_getpc_b64 s[40:41]\n"
-            "s_add_u32 s40, s40, mpr_ti_divx@rel32@lo+4\n"
-            "s_addc_u32 s41, s41, mpr_ti_divx@rel32@hi+12\n"
-            "s_swappc_b64 s[30:31], s[40:41]\n"
-            "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v47\n"
-            "L_idiv_tail_%=:\n"
-            "v_mov_b32 v51, 0xff800000\n"
-            "v_mov_b32 v52, 0x7f800000\n"
-            "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
-            "v_cndmask_b32 v41, v41, v52, s[58:59]\n"
-            TI_END
-            /* ---- i_sqrt(v[36:37]): x.hi < 0: NaN; lower bound 0 when x.lo <= 0 ---- */
-            "L_isqrt_%=:\n"
-            "s_movk_i32 s55, 0x260\n"
-            "s_movk_i32 s56, 0x1f8\n"
-            "v_cmp_ge_f32 vcc, 0, v36\n"                     /* x.lo <= 0 */
-            "v_cmp_gt_f32 s[58:59], 0, v37\n"                /* x.hi < 0 */
-            "s_nop 0\n"
-            "v_cndmask_b32 v42, v36, 0, vcc\n"               /* a */
-            /* Fast path when every lane's operands are zero or 2^-60 <= x <= 2^60 (negative upper ends pass:
-             * their lanes are overwritten with NaN below): v_sqrt_f32 is within one ulp, so the directed
-             * roots are among y - 1 ulp, y, y + 1 ulp, told apart by the signs of x - c^2 (fma).  No switch
-             * to round-to-nearest, half the instructions of the general sequence. */
-            "v_and_b32 v52, 0x7fffffff, v37\n"
-            "s_mov_b32 s44, 0x21800000\n"                    /* 2^-60 */
-            "s_mov_b32 s45, 0x5d800000\n"                    /* 2^60 */
-            "v_cmp_le_u32 s[46:47], s44, v42\n"
-            "v_cmp_eq_u32 s[50:51], 0, v42\n"               /* a is zero */
-            "v_cmp_ge_u32 vcc, s45, v42\n"
-            "s_or_b64 s[46:47], s[46:47], s[50:51]\n"
-            "s_and_b64 s[46:47], s[46:47], vcc\n"
-            "v_cmp_le_u32 s[48:49], s44, v52\n"
-            "v_cmp_eq_u32 s[52:53], 0, v52\n"               /* x.hi is a zero */
-            "v_cmp_ge_u32 vcc, s45, v52\n"
-            "s_or_b64 s[48:49], s[48:49], s[52:53]\n"
-            "s_and_b64 s[48:49], s[48:49], vcc\n"
-            "s_and_b64 s[46:47], s[46:47], s[48:49]\n"
-            "s_cmp_eq_u64 s[46:47], exec\n"
-            "s_cbranch_scc0 L_isqrt_slow_%=\n"
-            "v_sqrt_f32 v47, v42\n"
-            "v_sqrt_f32 v49, v37\n"
-            "s_nop 0\n"
-            "v_add_u32 v51, 1, v47\n"                        /* lower: y + 1 ulp, y - 1 ulp */
-            "v_add_u32 v52, -1, v47\n"
-            "v_add_u32 v54, 1, v49\n"                        /* upper */
-            "v_add_u32 v55, -1, v49\n"
-            "v_fma_f32 v48, -v47, v47, v42\n"                /* x - y^2 */
-            "v_fma_f32 v53, -v51, v51, v42\n"                /* x - (y + 1)^2 */
-            "v_fma_f32 v50, -v49, v49, v37\n"
-            "v_fma_f32 v43, -v55, v55, v37\n"                /* x - (y - 1)^2 */
-            "v_cmp_le_f32 s[44:45], 0, v53\n"               /* y + 1 still not above the root */
-            "v_cmp_gt_f32 s[46:47], 0, v48\n"               /* y above the root */
-            "v_cmp_ge_f32 s[48:49], 0, v43\n"               /* y - 1 still not below the root */
-            "v_cmp_lt_f32 vcc, 0, v50\n"                    /* y below the root */
-            "v_cndmask_b32 v51, v47, v51, s[44:45]\n"
-            "v_cndmask_b32 v55, v49, v55, s[48:49]\n"
-            "v_cndmask_b32 v40, v51, v52, s[46:47]\n"        /* largest c with c^2 <= x */
-            "v_cndmask_b32 v41, v55, v54, vcc\n"             /* smallest c with c^2 >= x */
-            "v_cndmask_b32 v40, v40, v42, s[50:51]\n"        /* the root of a zero is that zero */
-            "v_cndmask_b32 v41, v41, v37, s[52:53]\n"
-            "s_branch L_isqrt_tail_%=\n"
-            "L_isqrt_slow_%=:\n"
-            "v_mov_b32 v47, v34\n"
-            "v_mov_b32 v0, v42\n v_mov_b32 v1, v37\n"
-            "s_getpc_b64 s[40:41]\n"
-            "s_add_u32 s40, s40, mpr_ti_sqrtx@rel32@lo+4\n"
-            "s_addc_u32 s41, s41, mpr_ti_sqrtx@rel32@hi+12\n"
-            "s_swappc_b64 s[30:31], s[40:41]\n"
-            "v_mov_b32 v40, v0\n v_mov_b32 v41, v1\n v_mov_b32 v34, v47\n"
-            "L_isqrt_tail_%=:\n"
-            "v_mov_b32 v51, 0x7fc00000\n"
-            "v_cndmask_b32 v40, v40, v51, s[58:59]\n"
-            "v_cndmask_b32 v41, v41, v51, s[58:59]\n"
-            TI_END
-            /* ---- compiled routines (double precision inside): called, not left for ---- */
-            "L_casin_%=:\n" TI_CALL("mpr_ti_asin")
-            "L_cacos_%=:\n" TI_CALL("mpr_ti_acos")
-            "L_catan_%=:\n" TI_CALL("mpr_ti_atan")
-            "L_cexp_%=:\n" TI_CALL("mpr_ti_exp")
-            "L_clog_%=:\n" TI_CALL("mpr_ti_log")
-            /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
-            "L_exit_%=:\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "s_mov_b32 %[dlo], s86\n"
-            "s_mov_b32 %[dhi], s87\n"
-            "s_mov_b32 %[base], s89\n"
-            "s_mov_b32 %[sj], s88\n"
-            "s_mov_b32 %[caddr], s74\n"
-            "s_mov_b32 %[anylo], s76\n"
-            "s_mov_b32 %[anyhi], s77\n"
-            "s_mov_b32 %[ci], s78\n"
-            "s_mov_b32 %[words], s79\n"
+            TI_ASM_TEXT
             : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),
               [caddr] "+&s"(caddr), [anylo] "+&s"(anylo), [anyhi] "+&s"(anyhi), [ci] "+&s"(ci), [words] "+&s"(words)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
@@ -634,6 +644,110 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     return r;
 }
 
+
+/* ====================================================================================== */
+/* The same walk with the slot file in VECTOR REGISTERS, for tapes with many slots.           */
+/*                                                                                          */
+/* The LDS planes cost 512 bytes per slot and wavefront: a tape with 84 slots (the involute   */
+/* gears, prospero) leaves room for 3 wavefronts per CU, and a walk that is a dependent chain */
+/* needs many more to keep a CU busy.  Here slot s (1..92: slot 0 is nobody's) is the register */
+/* pair v[68 + 2 s], v[69 + 2 s] — v70..v253 —, addressed through the scalar GPR index          */
+/* (s_set_gpr_idx_on: scripts/ubench/gpr_idx_probe.hip — gfx950 has no v_movrel): the           */
+/* pre-doubled slot byte of the rewritten clause word IS the index.  256 registers per lane are */
+/* 2 wavefronts per SIMD, 8 per CU, and an operand arrives in ~15 cycles instead of an LDS      */
+/* round trip.  Everything else — handlers, arithmetic, choices, the compiled routines (which   */
+/* stay below v70) — is the text above.  The registers have to survive from the axis intervals' */
+/* arrival to the result's departure, so both happen inside the one asm statement (TI_VS_ENTER / */
+/* TI_VS_LEAVE, through a little LDS: the statement names all but ten VGPRs, and its operands    */
+/* have to live in those), and a word that is not an opcode gets its NaN inside the block too   */
+/* (TI_H30): nothing re-enters.                                                                */
+/* ====================================================================================== */
+#undef TI_AL
+#undef TI_AR
+#undef TI_AO
+#undef TI_ST
+#undef TI_H30
+#undef TI_VS_ENTER
+#undef TI_VS_LEAVE
+#define TI_VS_BASE "v68"
+#define TI_VS_BASE1 "v69"
+#define TI_AL "s_bfe_u32 s60, s86, 0x80010\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v36, " TI_VS_BASE "\n v_mov_b32 v37, " TI_VS_BASE1 "\n s_set_gpr_idx_off\n"
+#define TI_AR "s_lshr_b32 s60, s86, 24\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v38, " TI_VS_BASE "\n v_mov_b32 v39, " TI_VS_BASE1 "\n s_set_gpr_idx_off\n"
+#define TI_AO "s_and_b32 s61, s86, 0xff\n"                       /* 2 * out slot, kept for TI_ST (TI_PREP replaces s86) */
+#define TI_ST "s_set_gpr_idx_on s61, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v40\n v_mov_b32 " TI_VS_BASE1 ", v41\n s_set_gpr_idx_off\n"
+#define TI_H30 TI_AO TI_PREP "v_mov_b32 v40, 0x7fc00000\n v_mov_b32 v41, 0x7fc00000\n" TI_END
+/* the axis intervals arrive, and the result leaves, through 2 KB of LDS behind the choices ([8][64] floats at %[io]):
+ * every VGPR operand of this statement has to live in the ten registers it does not name */
+#define TI_VS_ENTER                                                                                          \
+    "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"                                           \
+    "ds_read_b32 v36, v32\n ds_read_b32 v37, v32 offset:256\n ds_read_b32 v38, v32 offset:512\n"            \
+    "ds_read_b32 v39, v32 offset:768\n ds_read_b32 v42, v32 offset:1024\n ds_read_b32 v43, v32 offset:1280\n" \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                 \
+    "s_set_gpr_idx_on %[ax], gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v36\n v_mov_b32 " TI_VS_BASE1 ", v37\n s_set_gpr_idx_off\n" \
+    "s_set_gpr_idx_on %[ay], gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v38\n v_mov_b32 " TI_VS_BASE1 ", v39\n s_set_gpr_idx_off\n" \
+    "s_set_gpr_idx_on %[az], gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v42\n v_mov_b32 " TI_VS_BASE1 ", v43\n s_set_gpr_idx_off\n"
+/* at the end clause: byte 0 of the rewritten word = 2 * the result's slot */
+#define TI_VS_LEAVE                                                                                          \
+    "s_and_b32 s60, s86, 0xff\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v36, " TI_VS_BASE "\n v_mov_b32 v37, " TI_VS_BASE1 "\n s_set_gpr_idx_off\n" \
+    "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"                                           \
+    "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n s_waitcnt lgkmcnt(0)\n"
+#define TI_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+constexpr int TI_VS_MAX_SLOTS = 93;
+
+/* smem: ulonglong2[choice_cap] at LDS offset 0, then [8][64] floats of scratch.  ax / ay / az: 2 * the slots of the axes
+ * (head clause); x / y / z: their intervals; res: the result interval. */
+DEV TileInterpResult tile_interp_asm_vgpr(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane,
+                                          uint64_t alive_mask, int choice_cap, const uint64_t* first_block,
+                                          uint32_t ax, uint32_t ay, uint32_t az, float2 x, float2 y, float2 z, float2* res)
+{
+    uint32_t blo = (uint32_t)*first_block, bhi = (uint32_t)(*first_block >> 32);
+    uint32_t base = rdfirst(first), sj = 0, dlo = 0, dhi = 0;
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    const uint32_t alo = (uint32_t)alive_mask, ahi = (uint32_t)(alive_mask >> 32);
+    uint32_t caddr = rdfirst((uint32_t)(uintptr_t)smem);
+    const uint32_t cend = caddr + (uint32_t)choice_cap * 16u;
+    uint32_t ci = 0, words = 0, anylo = 0, anyhi = 0;
+    const uint32_t mode = 2;                                   /* the caller fetched the first block */
+    const uint32_t zero = 0;
+    float* const io = reinterpret_cast<float*>(smem + (size_t)choice_cap * 16);
+    io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
+    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
+    ax = rdfirst(ax);
+    ay = rdfirst(ay);
+    az = rdfirst(az);
+    asm volatile(
+        TI_ASM_TEXT
+        : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),
+          [caddr] "+&s"(caddr), [anylo] "+&s"(anylo), [anyhi] "+&s"(anyhi), [ci] "+&s"(ci), [words] "+&s"(words)
+        : [lane8] "v"(lane8), [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [plo] "s"(zero), [phi] "s"(zero),
+          [alo] "s"(alo), [ahi] "s"(ahi), [cend] "s"(cend), [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [io] "s"(ioaddr)
+        : "memory", "vcc", "scc",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
+          "s55", "s56", "s57", "s58", "s59", "s60", "s61",
+          "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
+          "s87", "s88", "s89", "s92", "s93", "s94", "s95", "s96",
+          "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
+          "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
+          /* the slot file */
+          "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", TI_V10(8), TI_V10(9), TI_V10(10), TI_V10(11), TI_V10(12), TI_V10(13), TI_V10(14), TI_V10(15),
+          TI_V10(16), TI_V10(17), TI_V10(18), TI_V10(19), TI_V10(20), TI_V10(21), TI_V10(22), TI_V10(23), TI_V10(24),
+          "v250", "v251", "v252", "v253");
+    res->x = io[384 + lane];
+    res->y = io[448 + lane];
+    TileInterpResult r;
+    r.result_slot = (dlo & 0xFF) >> 1;
+    r.nchoices = (int)ci;
+    r.any_choice = ((uint64_t)anyhi << 32) | anylo;
+    r.words = (int)words;
+    r.end_index = (int)(base + sj);
+    return r;
+}
 
 /* ====================================================================================== */
 /* Backward walk of tape pushing (reference src/context.cu:351-458) in assembly.            */

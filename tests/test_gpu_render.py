@@ -397,6 +397,18 @@ def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, mon
     compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
 
 
+@pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("prospero", 2, 1024), ("involute_gear_2d", 2, 512), ("architecture", 3, 256),
+                                        ("involute_gear_3d", 3, 256), ("involute_gear_3d", 3, 512)])
+@pytest.mark.parametrize("vgpr", ["0", "1"])
+def test_slot_file_in_registers_matches_oracle(mpr, orc, tapes, name, dim, S, vgpr, monkeypatch):
+    """Tapes with 40 to 93 slots walk the tile stages with the slot file in vector registers (tile_interp_asm.hpp:
+    8 wavefronts per CU instead of the 3 their LDS planes leave room for); MPR_TILES_VGPR=0 keeps it in LDS.  Both give
+    the oracle's frame at every stage (level-parallel later stages off, so that the walk in question runs them)."""
+    monkeypatch.setenv("MPR_TILES_VGPR", vgpr)
+    monkeypatch.setenv("MPR_WIDE_LATER", "0")
+    compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
+
+
 @pytest.mark.parametrize("name,S", [("bear", 256), ("architecture", 256), ("involute_gear_3d", 256), ("trig", 128), ("sphere", 128),
                                     ("two_spheres", 128)])
 def test_assembly_normals_pass_matches_compiled_one(mpr, tapes, name, S, monkeypatch):
