@@ -105,8 +105,8 @@ __device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, fl
  * nslots <= 128), else the compiled loop below (slot file float2 per lane) */
 /* VS (with ASM): the slot file in vector registers instead (tile_interp_asm_vgpr: tapes with 40 to 93 slots, whose LDS
  * planes would leave room for fewer than 8 wavefronts per CU); LDS then holds the choices and 2 KB of scratch */
-template <int DIM, bool ASM, bool VS = false>
-__global__ void __launch_bounds__(64, VS ? 2 : 0)
+template <int DIM, bool ASM, int VS = 0>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
+__global__ void __launch_bounds__(64, VS == TI_VS_SMALL_SLOTS ? 4 : VS ? 2 : 0)
 k_eval_tiles(TileStageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -209,7 +209,7 @@ k_eval_tiles(TileStageArgs a)
     float2 res_vs = make_float2(0.0f, 0.0f);
     if (ASM) {
         const TileInterpResult ir =
-            VS ? tile_interp_asm_vgpr(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, a.choice_cap, &first_block,
+            VS ? tile_interp_asm_vgpr<(VS ? VS : TI_VS_MAX_SLOTS)>(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, a.choice_cap, &first_block,
                                       2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
                                       2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
                                       make_float2(vz.lo, vz.hi), &res_vs)
@@ -1022,11 +1022,14 @@ void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsign
                        tape_index, tape_len, num_active, tiles, count, cols, owner, rank);
 }
 size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + (size_t)choice_cap * 16 + (nslots > 128 ? 1024 : 0); }
-/* slots in registers (k_eval_tiles<.., .., true>) when the LDS planes would hold a CU under the 8 wavefronts that 256
- * registers per lane allow, and the slots fit the registers */
-bool tile_stage_vgpr_slots(int nslots, int choice_cap)
+/* Slots in registers (k_eval_tiles<.., .., VS>) when that puts more wavefronts on a CU than the LDS planes do: up to 24
+ * slots cost 118 registers per lane (4 waves per SIMD, 16 per CU), up to 93 slots all 256 (2 and 8). */
+int tile_stage_vgpr_class(int nslots, int choice_cap)
 {
-    return nslots <= TI_VS_MAX_SLOTS && tile_stage_lds_bytes(nslots, choice_cap) > (size_t)160 * 1024 / 8;
+    const size_t waves_by_lds = ((size_t)160 * 1024) / tile_stage_lds_bytes(nslots, choice_cap);
+    if (nslots <= TI_VS_SMALL_SLOTS && waves_by_lds < 16) return TI_VS_SMALL_SLOTS;
+    if (nslots > TI_VS_SMALL_SLOTS && nslots <= TI_VS_MAX_SLOTS && waves_by_lds < 8) return TI_VS_MAX_SLOTS;
+    return 0;
 }
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
 {
@@ -1036,14 +1039,16 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     /* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers */
     /* ... and the assembly backward walk forms 32-bit byte offsets into the pool (a.compiled_walk: MPR_TILES_ASM=0) */
     const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
-    const bool vs = use_asm && a.vgpr_slots && !(a.debug & 4) && tile_stage_vgpr_slots(a.nslots, a.choice_cap);
+    const int vs = (use_asm && a.vgpr_slots && !(a.debug & 4)) ? tile_stage_vgpr_class(a.nslots, a.choice_cap) : 0;
     const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
     if (dim == 3) {
-        if (vs) hipLaunchKernelGGL((k_eval_tiles<3, true, true>), dim3(groups), dim3(64), lds_vs, s, a);
+        if (vs == TI_VS_SMALL_SLOTS) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
+        else if (vs) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_MAX_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
         else if (use_asm) hipLaunchKernelGGL((k_eval_tiles<3, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<3, false>), dim3(groups), dim3(64), lds, s, a);
     } else {
-        if (vs) hipLaunchKernelGGL((k_eval_tiles<2, true, true>), dim3(groups), dim3(64), lds_vs, s, a);
+        if (vs == TI_VS_SMALL_SLOTS) hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
+        else if (vs) hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_MAX_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
         else if (use_asm) hipLaunchKernelGGL((k_eval_tiles<2, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, false>), dim3(groups), dim3(64), lds, s, a);
     }

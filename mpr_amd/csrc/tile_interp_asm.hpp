@@ -692,10 +692,11 @@ DEV TileInterpResult tile_interp_asm(const uint64_t* __restrict__ tro, uint32_t 
     "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"                                           \
     "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n s_waitcnt lgkmcnt(0)\n"
 #define TI_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
-constexpr int TI_VS_MAX_SLOTS = 93;
+constexpr int TI_VS_MAX_SLOTS = 93, TI_VS_SMALL_SLOTS = 24;
 
 /* smem: ulonglong2[choice_cap] at LDS offset 0, then [8][64] floats of scratch.  ax / ay / az: 2 * the slots of the axes
  * (head clause); x / y / z: their intervals; res: the result interval. */
+template <int NS>          /* registers for this many slots: 24 (v70..v117) or TI_VS_MAX_SLOTS (v70..v253) */
 DEV TileInterpResult tile_interp_asm_vgpr(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane,
                                           uint64_t alive_mask, int choice_cap, const uint64_t* first_block,
                                           uint32_t ax, uint32_t ay, uint32_t az, float2 x, float2 y, float2 z, float2* res)
@@ -716,28 +717,36 @@ DEV TileInterpResult tile_interp_asm_vgpr(const uint64_t* __restrict__ tro, uint
     ax = rdfirst(ax);
     ay = rdfirst(ay);
     az = rdfirst(az);
-    asm volatile(
-        TI_ASM_TEXT
-        : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),
-          [caddr] "+&s"(caddr), [anylo] "+&s"(anylo), [anyhi] "+&s"(anyhi), [ci] "+&s"(ci), [words] "+&s"(words)
-        : [lane8] "v"(lane8), [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [plo] "s"(zero), [phi] "s"(zero),
+#define TI_VS_OPERANDS \
+        : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi),\
+          [caddr] "+&s"(caddr), [anylo] "+&s"(anylo), [anyhi] "+&s"(anyhi), [ci] "+&s"(ci), [words] "+&s"(words)\
+        : [lane8] "v"(lane8), [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [plo] "s"(zero), [phi] "s"(zero),\
           [alo] "s"(alo), [ahi] "s"(ahi), [cend] "s"(cend), [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [io] "s"(ioaddr)
-        : "memory", "vcc", "scc",
-          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
-          "s55", "s56", "s57", "s58", "s59", "s60", "s61",
-          "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
-          "s87", "s88", "s89", "s92", "s93", "s94", "s95", "s96",
-          "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
-          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
-          "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
-          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
-          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
-          /* the slot file */
-          "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", TI_V10(8), TI_V10(9), TI_V10(10), TI_V10(11), TI_V10(12), TI_V10(13), TI_V10(14), TI_V10(15),
-          TI_V10(16), TI_V10(17), TI_V10(18), TI_V10(19), TI_V10(20), TI_V10(21), TI_V10(22), TI_V10(23), TI_V10(24),
-          "v250", "v251", "v252", "v253");
+#define TI_VS_CLOBBERS \
+        : "memory", "vcc", "scc",\
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",\
+          "s55", "s56", "s57", "s58", "s59", "s60", "s61",\
+          "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",\
+          "s87", "s88", "s89", "s92", "s93", "s94", "s95", "s96",\
+          "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",\
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",\
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",\
+          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",\
+          "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",\
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",\
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31"
+    if constexpr (NS <= 24) {
+        asm volatile(TI_ASM_TEXT TI_VS_OPERANDS TI_VS_CLOBBERS,
+                     "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", TI_V10(8), TI_V10(9), TI_V10(10),
+                     "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117");
+    } else {
+        asm volatile(TI_ASM_TEXT TI_VS_OPERANDS TI_VS_CLOBBERS,
+                     "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", TI_V10(8), TI_V10(9), TI_V10(10), TI_V10(11),
+                     TI_V10(12), TI_V10(13), TI_V10(14), TI_V10(15), TI_V10(16), TI_V10(17), TI_V10(18), TI_V10(19), TI_V10(20),
+                     TI_V10(21), TI_V10(22), TI_V10(23), TI_V10(24), "v250", "v251", "v252", "v253");
+    }
+#undef TI_VS_OPERANDS
+#undef TI_VS_CLOBBERS
     res->x = io[384 + lane];
     res->y = io[448 + lane];
     TileInterpResult r;

@@ -398,11 +398,12 @@ def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, mon
 
 
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("prospero", 2, 1024), ("involute_gear_2d", 2, 512), ("architecture", 3, 256),
-                                        ("involute_gear_3d", 3, 256), ("involute_gear_3d", 3, 512)])
+                                        ("involute_gear_3d", 3, 256), ("involute_gear_3d", 3, 512), ("bear", 3, 256), ("bear", 3, 512)])
 @pytest.mark.parametrize("vgpr", ["0", "1"])
 def test_slot_file_in_registers_matches_oracle(mpr, orc, tapes, name, dim, S, vgpr, monkeypatch):
     """Tapes with 40 to 93 slots walk the tile stages with the slot file in vector registers (tile_interp_asm.hpp:
-    8 wavefronts per CU instead of the 3 their LDS planes leave room for); MPR_TILES_VGPR=0 keeps it in LDS.  Both give
+    8 wavefronts per CU instead of the 3 their LDS planes leave room for), and so do tapes with 20 to 24 slots (16
+    instead of 13); MPR_TILES_VGPR=0 keeps it in LDS.  Both give
     the oracle's frame at every stage (level-parallel later stages off, so that the walk in question runs them)."""
     monkeypatch.setenv("MPR_TILES_VGPR", vgpr)
     monkeypatch.setenv("MPR_WIDE_LATER", "0")
