@@ -861,6 +861,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.groups = lean_now ? c->groups : nullptr;
         n.choice_masks = lean_now ? c->choice_masks : nullptr;
         n.choice_cap = group_cap;
+        n.vgpr_slots = c->tiles_vgpr;
         if (owner && c->normals_asm && !cnt) {
             /* owned columns only; the list is rebuilt when the ownership table or the rank changes */
             if (c->my_cols_rank != rank || c->my_cols_gen != c->owner_gen) {

@@ -107,6 +107,7 @@ struct NormalArgs {
     const GroupInfo* groups;
     const ulonglong2* choice_masks;
     int choice_cap;
+    bool vgpr_slots;           /* tapes with many slots: the slot file in registers (MPR_TILES_VGPR=0: never) */
 };
 
 void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,

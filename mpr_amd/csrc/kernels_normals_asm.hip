@@ -100,9 +100,13 @@ __device__ float nq_atan(float a, int isv)
 #define NQ_FR "v_mov_b32 v36, v37\n"
 #define NQ_AO "v_perm_b32 v34, s86, %[lb], %[selO]\n"
 #define NQ_W "s_waitcnt lgkmcnt(0)\n"
-#define NQ_END "ds_write_b32 v34, v37\n s_setpc_b64 s[80:81]\n"
+#define NQ_ST "ds_write_b32 v34, v37\n"
+#define NQ_END NQ_ST "s_setpc_b64 s[80:81]\n"
 #define NQ_H(v, n) ".p2align 8\nL_n" #v "_" #n "_%=:\n"
 #define NQ_EXIT NQ_IMM "s_branch L_exit_%=\n"
+#define NQ_H30 NQ_EXIT               /* a word that is not an opcode: evaluated (to NaN) outside the block */
+#define NQ_VS_ENTER
+#define NQ_VS_LEAVE
 #define NQ_CALL(pair) "s_swappc_b64 s[70:71], " pair "\n"
 /* v37 = sym(v35) by a compiled routine; v34 (address of the out slot) survives in v44 */
 #define NQ_CALLC(sym)                                                                            \
@@ -190,8 +194,116 @@ __device__ float nq_atan(float a, int isv)
     NQ_H(v, 27) NQ_IMM NQ_AO NQ_PREP "s_nop 0\n v_mov_b32 v39, s87\n v_cndmask_b32 v37, 0, v39, s[98:99]\n" NQ_END   \
     NQ_H(v, 28) LDL NQ_AO NQ_PREP WL "v_mov_b32 v37, v35\n" NQ_END                                                   \
     NQ_H(v, 29) LDR NQ_AO NQ_PREP WR "v_mov_b32 v37, v36\n" NQ_END                                                   \
-    NQ_H(v, 30) NQ_EXIT                                                                                      \
+    NQ_H(v, 30) NQ_H30                                                                                       \
     NQ_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"
+
+/* The walk itself, as text: expanded in interp_normals_asm (slots in LDS) and in interp_normals_asm_vgpr (slots in
+ * VGPRs), each time with that variant's NQ_AL / NQ_AR / NQ_AO / NQ_ST / NQ_H30 / NQ_VS_ENTER / NQ_VS_LEAVE. */
+#define NQ_ASM_TEXT \
+    NQ_VS_ENTER \
+    "s_mov_b32 s89, %[base]\n" \
+    "s_mov_b32 s88, %[sj]\n" \
+    "s_mov_b32 s64, %[dec]\n" \
+    "s_mov_b32 s65, %[mmc]\n" \
+    "s_mov_b32 s90, 0x260\n" \
+    "s_mov_b32 s96, 0xff00\n" \
+    "s_mov_b32 s98, 0x88888888\n" \
+    "s_mov_b32 s99, 0x88888888\n" \
+    "v_mov_b32 v37, %[prev]\n" \
+    "s_getpc_b64 s[82:83]\n" \
+    "L_pc_%=:\n" \
+    "s_add_u32 s72, s82, L_div_%=-L_pc_%=\n s_addc_u32 s73, s83, 0\n" \
+    "s_add_u32 s74, s82, L_sqrt_%=-L_pc_%=\n s_addc_u32 s75, s83, 0\n" \
+    "s_add_u32 s76, s82, L_exp_%=-L_pc_%=\n s_addc_u32 s77, s83, 0\n" \
+    "s_add_u32 s78, s82, L_log_%=-L_pc_%=\n s_addc_u32 s79, s83, 0\n" \
+    "s_add_u32 s68, s82, L_sincos_%=-L_pc_%=\n s_addc_u32 s69, s83, 0\n" \
+    "s_add_u32 s66, s82, L_dec_%=-L_pc_%=\n s_addc_u32 s67, s83, 0\n" \
+    "s_add_u32 s82, s82, L_n0_0_%=-L_pc_%=\n" \
+    "s_addc_u32 s83, s83, 0\n" \
+    "s_cmp_eq_u32 %[mode], 0\n" \
+    "s_cbranch_scc1 L_load_%=\n" \
+    NQ_DISPATCH \
+    "L_load_%=:\n" \
+    "s_mov_b32 s84, s89\n" \
+    "s_mov_b32 s85, 0\n" \
+    "s_lshl_b64 s[84:85], s[84:85], 3\n" \
+    "s_add_u32 s84, s84, %[tlo]\n" \
+    "s_addc_u32 s85, s85, %[thi]\n" \
+    "global_load_dword %[blo], %[lane8], s[84:85]\n" \
+    "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n" \
+    "s_mov_b32 s88, -1\n" \
+    "v_mov_b32 v41, 0\n" \
+    "v_mov_b32 v43, 32\n" \
+    "v_mov_b32 v44, 64\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    "v_bfe_u32 v40, %[blo], 8, 8\n" \
+    "v_and_b32 v38, 0xff, %[blo]\n" \
+    "v_min_u32 v38, 30, v38\n" \
+    "v_mov_b32_dpp v41, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_bfe_u32 v42, %[blo], 16, 8\n" \
+    "v_lshrrev_b32 v39, 24, %[blo]\n" \
+    "v_cmp_eq_u32 s[92:93], v39, v41\n" \
+    "v_cmp_eq_u32 vcc, v42, v41\n" \
+    "v_cmp_ne_u32 s[94:95], 0, v41\n" \
+    "v_cndmask_b32 v42, 0, v44, s[92:93]\n" \
+    "v_cndmask_b32 v42, v42, v43, vcc\n" \
+    "v_cndmask_b32 v42, 0, v42, s[94:95]\n" \
+    "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n" \
+    "v_mov_b32 v39, 31\n" \
+    "v_add_u32 v38, v38, v42\n" \
+    "v_cndmask_b32 v38, v38, v39, vcc\n" \
+    "v_lshl_or_b32 v38, v38, 8, v40\n" \
+    "v_and_b32 %[blo], 0xffff0000, %[blo]\n" \
+    "v_or_b32 %[blo], %[blo], v38\n" \
+    "s_nop 0\n" \
+    NQ_DISPATCH \
+    NQ_TABLE(0, NQ_AL, NQ_AR, NQ_W, NQ_W, NQ_W) \
+    NQ_TABLE(1, NQ_FL, NQ_AR, "", NQ_W, NQ_W) \
+    NQ_TABLE(2, NQ_AL, NQ_FR, NQ_W, "", NQ_W) \
+    /* shared routines: argument v35 (and v36), result v37, return to s[70:71] */ \
+    ".p2align 8\n" \
+    "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[70:71]\n" \
+    "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n" \
+    "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n" \
+    "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n" \
+    "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n" \
+    /* a min / max clause: count it; when decisions are present, the lanes whose tile decided it take the chosen \
+    * operand whatever the comparison said (vcc set: lhs).  Bits beyond the 192 kept per lane: undecided. */ \
+    "L_dec_%=:\n" \
+    "s_add_u32 s65, s65, 1\n" \
+    "s_cmp_eq_u32 s64, 0\n" \
+    "s_cbranch_scc1 L_decret_%=\n" \
+    "s_sub_u32 s40, s65, 1\n" \
+    "s_lshr_b32 s41, s40, 6\n" \
+    "s_cmp_ge_u32 s41, 3\n" \
+    "s_cbranch_scc1 L_decret_%=\n" \
+    "s_and_b32 s40, s40, 63\n" \
+    "s_lshl_b32 s41, s41, 7\n" \
+    "v_add_u32 v42, s41, %[decb]\n" \
+    "ds_read_b64 v[38:39], v42\n" \
+    "ds_read_b64 v[40:41], v42 offset:384\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_lshrrev_b64 v[38:39], s40, v[38:39]\n" \
+    "v_lshrrev_b64 v[40:41], s40, v[40:41]\n" \
+    "v_and_b32 v38, 1, v38\n" \
+    "v_and_b32 v40, 1, v40\n" \
+    "v_cmp_ne_u32 s[42:43], 0, v38\n" \
+    "v_cmp_ne_u32 s[44:45], 0, v40\n" \
+    "s_or_b64 vcc, vcc, s[42:43]\n" \
+    "s_andn2_b64 vcc, vcc, s[44:45]\n" \
+    "L_decret_%=:\n" \
+    "s_setpc_b64 s[46:47]\n" \
+    "L_casin_%=:\n" NQ_CALLC("mpr_nq_asin") \
+    "L_cacos_%=:\n" NQ_CALLC("mpr_nq_acos") \
+    "L_catan_%=:\n" NQ_CALLC("mpr_nq_atan") \
+    "L_exit_%=:\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    NQ_VS_LEAVE \
+    "s_mov_b32 %[dlo], s86\n" \
+    "s_mov_b32 %[dhi], s87\n" \
+    "s_mov_b32 %[base], s89\n" \
+    "s_mov_b32 %[sj], s88\n" \
+    "s_mov_b32 %[mmc], s65\n"
 
 /* Walks the tape at tro[first] over the slot file at LDS offset 0; returns the result slot. */
 DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first, unsigned char* smem, int lane, bool isv,
@@ -215,108 +327,7 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
         mode = rdfirst(mode);
         mmc = rdfirst(mmc);
         asm volatile(
-            "s_mov_b32 s89, %[base]\n"
-            "s_mov_b32 s88, %[sj]\n"
-            "s_mov_b32 s64, %[dec]\n"
-            "s_mov_b32 s65, %[mmc]\n"
-            "s_mov_b32 s90, 0x260\n"
-            "s_mov_b32 s96, 0xff00\n"
-            "s_mov_b32 s98, 0x88888888\n"
-            "s_mov_b32 s99, 0x88888888\n"
-            "v_mov_b32 v37, %[prev]\n"
-            "s_getpc_b64 s[82:83]\n"
-            "L_pc_%=:\n"
-            "s_add_u32 s72, s82, L_div_%=-L_pc_%=\n s_addc_u32 s73, s83, 0\n"
-            "s_add_u32 s74, s82, L_sqrt_%=-L_pc_%=\n s_addc_u32 s75, s83, 0\n"
-            "s_add_u32 s76, s82, L_exp_%=-L_pc_%=\n s_addc_u32 s77, s83, 0\n"
-            "s_add_u32 s78, s82, L_log_%=-L_pc_%=\n s_addc_u32 s79, s83, 0\n"
-            "s_add_u32 s68, s82, L_sincos_%=-L_pc_%=\n s_addc_u32 s69, s83, 0\n"
-            "s_add_u32 s66, s82, L_dec_%=-L_pc_%=\n s_addc_u32 s67, s83, 0\n"
-            "s_add_u32 s82, s82, L_n0_0_%=-L_pc_%=\n"
-            "s_addc_u32 s83, s83, 0\n"
-            "s_cmp_eq_u32 %[mode], 0\n"
-            "s_cbranch_scc1 L_load_%=\n"
-            NQ_DISPATCH
-            "L_load_%=:\n"
-            "s_mov_b32 s84, s89\n"
-            "s_mov_b32 s85, 0\n"
-            "s_lshl_b64 s[84:85], s[84:85], 3\n"
-            "s_add_u32 s84, s84, %[tlo]\n"
-            "s_addc_u32 s85, s85, %[thi]\n"
-            "global_load_dword %[blo], %[lane8], s[84:85]\n"
-            "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
-            "s_mov_b32 s88, -1\n"
-            "v_mov_b32 v41, 0\n"
-            "v_mov_b32 v43, 32\n"
-            "v_mov_b32 v44, 64\n"
-            "s_waitcnt vmcnt(0)\n"
-            "v_bfe_u32 v40, %[blo], 8, 8\n"
-            "v_and_b32 v38, 0xff, %[blo]\n"
-            "v_min_u32 v38, 30, v38\n"
-            "v_mov_b32_dpp v41, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
-            "v_bfe_u32 v42, %[blo], 16, 8\n"
-            "v_lshrrev_b32 v39, 24, %[blo]\n"
-            "v_cmp_eq_u32 s[92:93], v39, v41\n"
-            "v_cmp_eq_u32 vcc, v42, v41\n"
-            "v_cmp_ne_u32 s[94:95], 0, v41\n"
-            "v_cndmask_b32 v42, 0, v44, s[92:93]\n"
-            "v_cndmask_b32 v42, v42, v43, vcc\n"
-            "v_cndmask_b32 v42, 0, v42, s[94:95]\n"
-            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"
-            "v_mov_b32 v39, 31\n"
-            "v_add_u32 v38, v38, v42\n"
-            "v_cndmask_b32 v38, v38, v39, vcc\n"
-            "v_lshl_or_b32 v38, v38, 8, v40\n"
-            "v_and_b32 %[blo], 0xffff0000, %[blo]\n"
-            "v_or_b32 %[blo], %[blo], v38\n"
-            "s_nop 0\n"
-            NQ_DISPATCH
-            NQ_TABLE(0, NQ_AL, NQ_AR, NQ_W, NQ_W, NQ_W)
-            NQ_TABLE(1, NQ_FL, NQ_AR, "", NQ_W, NQ_W)
-            NQ_TABLE(2, NQ_AL, NQ_FR, NQ_W, "", NQ_W)
-            /* shared routines: argument v35 (and v36), result v37, return to s[70:71] */
-            ".p2align 8\n"
-            "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[70:71]\n"
-            "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n"
-            "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n"
-            "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n"
-            "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n"
-            /* a min / max clause: count it; when decisions are present, the lanes whose tile decided it take the chosen
-             * operand whatever the comparison said (vcc set: lhs).  Bits beyond the 192 kept per lane: undecided. */
-            "L_dec_%=:\n"
-            "s_add_u32 s65, s65, 1\n"
-            "s_cmp_eq_u32 s64, 0\n"
-            "s_cbranch_scc1 L_decret_%=\n"
-            "s_sub_u32 s40, s65, 1\n"
-            "s_lshr_b32 s41, s40, 6\n"
-            "s_cmp_ge_u32 s41, 3\n"
-            "s_cbranch_scc1 L_decret_%=\n"
-            "s_and_b32 s40, s40, 63\n"
-            "s_lshl_b32 s41, s41, 7\n"
-            "v_add_u32 v42, s41, %[decb]\n"
-            "ds_read_b64 v[38:39], v42\n"
-            "ds_read_b64 v[40:41], v42 offset:384\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "v_lshrrev_b64 v[38:39], s40, v[38:39]\n"
-            "v_lshrrev_b64 v[40:41], s40, v[40:41]\n"
-            "v_and_b32 v38, 1, v38\n"
-            "v_and_b32 v40, 1, v40\n"
-            "v_cmp_ne_u32 s[42:43], 0, v38\n"
-            "v_cmp_ne_u32 s[44:45], 0, v40\n"
-            "s_or_b64 vcc, vcc, s[42:43]\n"
-            "s_andn2_b64 vcc, vcc, s[44:45]\n"
-            "L_decret_%=:\n"
-            "s_setpc_b64 s[46:47]\n"
-            "L_casin_%=:\n" NQ_CALLC("mpr_nq_asin")
-            "L_cacos_%=:\n" NQ_CALLC("mpr_nq_acos")
-            "L_catan_%=:\n" NQ_CALLC("mpr_nq_atan")
-            "L_exit_%=:\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "s_mov_b32 %[dlo], s86\n"
-            "s_mov_b32 %[dhi], s87\n"
-            "s_mov_b32 %[base], s89\n"
-            "s_mov_b32 %[sj], s88\n"
-            "s_mov_b32 %[mmc], s65\n"
+            NQ_ASM_TEXT
             : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi), [mmc] "+&s"(mmc)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
               [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "v"(prev), [dec] "s"(decisions), [decb] "v"(decb)
@@ -340,7 +351,70 @@ DEV uint32_t interp_normals_asm(const uint64_t* __restrict__ tro, uint32_t first
     return dlo & 0xFF;
 }
 
-__global__ void __launch_bounds__(64)
+/* The same walk with the slot file in VECTOR REGISTERS (slot s = v[50 + s], addressed through the scalar GPR index:
+ * see tile_interp_asm.hpp), for tapes with many slots: 256 bytes of LDS per slot and wavefront leave a tape with 93 slots
+ * 6 wavefronts per CU; 93 registers on top of the walk's own are 3 per SIMD, 12 per CU.  The axes' values arrive and the
+ * result leaves inside the one asm statement, and a word that is not an opcode gets its NaN inside the block: nothing
+ * re-enters. */
+#undef NQ_AL
+#undef NQ_AR
+#undef NQ_AO
+#undef NQ_ST
+#undef NQ_H30
+#undef NQ_VS_ENTER
+#undef NQ_VS_LEAVE
+#define NQ_AL "s_bfe_u32 s60, s86, 0x80010\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v35, v50\n s_set_gpr_idx_off\n"
+#define NQ_AR "s_lshr_b32 s60, s86, 24\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v36, v50\n s_set_gpr_idx_off\n"
+#define NQ_AO "s_and_b32 s61, s86, 0xff\n"                        /* the out slot, kept for NQ_ST (NQ_PREP replaces s86) */
+#define NQ_ST "s_set_gpr_idx_on s61, gpr_idx(DST)\n v_mov_b32 v50, v37\n s_set_gpr_idx_off\n"
+#define NQ_H30 NQ_AO NQ_PREP "v_mov_b32 v37, 0x7fc00000\n" NQ_END
+#define NQ_VS_ENTER                                                                                                   \
+    "s_set_gpr_idx_on %[ax], gpr_idx(DST)\n v_mov_b32 v50, %[xin]\n s_set_gpr_idx_off\n"                              \
+    "s_set_gpr_idx_on %[ay], gpr_idx(DST)\n v_mov_b32 v50, %[yin]\n s_set_gpr_idx_off\n"                              \
+    "s_set_gpr_idx_on %[az], gpr_idx(DST)\n v_mov_b32 v50, %[zin]\n s_set_gpr_idx_off\n"
+/* at the end clause: byte 0 of the rewritten word = the result's slot */
+#define NQ_VS_LEAVE "s_and_b32 s60, s86, 0xff\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 %[res], v50\n s_set_gpr_idx_off\n"
+#define NQ_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+constexpr int NQ_VS_MAX_SLOTS = 93;
+
+/* ax / ay / az: the axes' slots (head clause); xin / yin / zin: this lane's component of their Derivs; returns the result's */
+DEV float interp_normals_asm_vgpr(const uint64_t* __restrict__ tro, uint32_t first, int lane, uint32_t decisions, uint32_t decb,
+                                  uint32_t ax, uint32_t ay, uint32_t az, float xin, float yin, float zin)
+{
+    uint32_t blo = 0, bhi = 0;
+    uint32_t base = rdfirst(first), sj = 0, dlo = 0, dhi = 0, mmc = 0;
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    const uint32_t mode = 0;
+    const uint32_t zero = 0;
+    float res = 0.0f;
+    decisions = rdfirst(decisions);
+    ax = rdfirst(ax);
+    ay = rdfirst(ay);
+    az = rdfirst(az);
+#define NQ_VS_OPERANDS \
+        : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi), [mmc] "+&s"(mmc),\
+          [res] "=&v"(res)\
+        : [lane8] "v"(lane8), [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "s"(zero), [dec] "s"(decisions), [decb] "v"(decb),\
+          [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [xin] "v"(xin), [yin] "v"(yin), [zin] "v"(zin)
+#define NQ_VS_CLOBBERS \
+        : "memory", "vcc", "scc",\
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s60", "s61", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",\
+          "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s98", "s99",\
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",\
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",\
+          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",\
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",\
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31"
+    asm volatile(NQ_ASM_TEXT NQ_VS_OPERANDS NQ_VS_CLOBBERS, NQ_V10(5), NQ_V10(6), NQ_V10(7), NQ_V10(8), NQ_V10(9), NQ_V10(10), NQ_V10(11),
+                 NQ_V10(12), NQ_V10(13), "v140", "v141", "v142");
+#undef NQ_VS_OPERANDS
+#undef NQ_VS_CLOBBERS
+    return res;
+}
+
+template <int VS>          /* 0, or the slots the register file is built for */
+__global__ void __launch_bounds__(64, VS ? 3 : 0)
 k_eval_normals_asm(NormalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -431,7 +505,7 @@ k_eval_normals_asm(NormalArgs a)
             }
         }
     }
-    unsigned char* const dec = smem + (size_t)a.nslots * 256;          /* [2][3][16 pixels] 64-bit words behind the slot file */
+    unsigned char* const dec = smem + (VS ? 0 : (size_t)a.nslots * 256);          /* [2][3][16 pixels] 64-bit words behind the slot file */
     if (a.groups) {
         unsigned long long* const pl = reinterpret_cast<unsigned long long*>(dec) + pix;
         unsigned long long* const pr = reinterpret_cast<unsigned long long*>(dec + 384) + pix;
@@ -452,15 +526,21 @@ k_eval_normals_asm(NormalArgs a)
         todo &= ~grp;
 
         /* :1021-1031 — value first, then the unit partials (unused axes alias slot 0) */
-        *reinterpret_cast<float*>(myslot + sx * 256) = isv ? vx : 0.0f;
-        *reinterpret_cast<float*>(myslot + sy * 256) = isv ? vy : 0.0f;
-        *reinterpret_cast<float*>(myslot + sz * 256) = isv ? vz : 0.0f;
-        if (comp == 0) *reinterpret_cast<float*>(myslot + sx * 256) = 1.0f;
-        if (comp == 1) *reinterpret_cast<float*>(myslot + sy * 256) = 1.0f;
-        if (comp == 2) *reinterpret_cast<float*>(myslot + sz * 256) = 1.0f;
-
-        const uint32_t rslot = interp_normals_asm(tro, (uint32_t)(tape + 1), smem, lane, isv, a.groups ? 1u : 0u, decb);
-        const float rr = *reinterpret_cast<const float*>(myslot + rslot * 256);
+        float rr;
+        if (VS) {
+            rr = interp_normals_asm_vgpr(tro, (uint32_t)(tape + 1), lane, a.groups ? 1u : 0u, decb, sx, sy, sz,
+                                         isv ? vx : (comp == 0 ? 1.0f : 0.0f), isv ? vy : (comp == 1 ? 1.0f : 0.0f),
+                                         isv ? vz : (comp == 2 ? 1.0f : 0.0f));
+        } else {
+            *reinterpret_cast<float*>(myslot + sx * 256) = isv ? vx : 0.0f;
+            *reinterpret_cast<float*>(myslot + sy * 256) = isv ? vy : 0.0f;
+            *reinterpret_cast<float*>(myslot + sz * 256) = isv ? vz : 0.0f;
+            if (comp == 0) *reinterpret_cast<float*>(myslot + sx * 256) = 1.0f;
+            if (comp == 1) *reinterpret_cast<float*>(myslot + sy * 256) = 1.0f;
+            if (comp == 2) *reinterpret_cast<float*>(myslot + sz * 256) = 1.0f;
+            const uint32_t rslot = interp_normals_asm(tro, (uint32_t)(tape + 1), smem, lane, isv, a.groups ? 1u : 0u, decb);
+            rr = *reinterpret_cast<const float*>(myslot + rslot * 256);
+        }
         if (mine) result = rr;
     }
 
@@ -478,7 +558,13 @@ void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
     const int fside = a.size / 4;
     const int groups = a.col_list ? a.ncols * 256 : fside * fside;
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_eval_normals_asm, dim3(groups), dim3(64), (size_t)a.nslots * 256 + (a.groups ? 768 : 0), s, a);
+    /* slots in registers when the LDS slot file would hold a CU under the 12 wavefronts those registers allow (tried for
+     * small slot files too: bear, 23 slots, 0.378 -> 0.420 ms — one wavefront per SIMD fewer, and the index switching) */
+    const size_t lds = (size_t)a.nslots * 256 + (a.groups ? 768 : 0);
+    if (a.vgpr_slots && a.nslots <= NQ_VS_MAX_SLOTS && lds > (size_t)160 * 1024 / 12)
+        hipLaunchKernelGGL(k_eval_normals_asm<NQ_VS_MAX_SLOTS>, dim3(groups), dim3(64), (size_t)(a.groups ? 768 : 16), s, a);
+    else
+        hipLaunchKernelGGL(k_eval_normals_asm<0>, dim3(groups), dim3(64), lds, s, a);
 }
 
 }  // namespace mprk
