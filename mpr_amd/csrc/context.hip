@@ -781,6 +781,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         fill_mat(v.mat, mat, dim == 3 ? 16 : 9);
         v.counters = cnt;
         v.heat = heat;
+        v.vgpr_slots = c->tiles_vgpr;
         TimedScope ts(c, "eval_voxels_f");
         /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
         bool jitted = false;

@@ -87,6 +87,7 @@ struct VoxelArgs {
     float mat[16];
     unsigned long long* counters;
     float* heat;               /* heatmap frames: S x S work per pixel, else null */
+    bool vgpr_slots;           /* assembly interpreter, tapes with many slots: the slot file in registers (MPR_TILES_VGPR=0: never) */
 };
 
 struct NormalArgs {

@@ -82,6 +82,9 @@ DEV float rare_unary_a(uint32_t op, float v)
 #define MPR_ST "ds_write_b32 v34, v37\n"
 #define MPR_H(v, n) ".p2align 8\nL_h" #v "_" #n "_%=:\n"
 #define MPR_EXIT "s_branch L_exit_%=\n"
+#define MPR_H30(LDL, WL, MVA) MPR_EXIT      /* a word that is not an opcode: evaluated (as a logarithm, like k_eval_voxels) outside the block */
+#define MPR_VS_ENTER
+#define MPR_VS_LEAVE
 #define MPR_END MPR_ST MPR_DISPATCH
 /* v37 = sym(v35) by a compiled routine; v34 (address of the out slot) survives in v44.  The routines
  * keep v40..v47 and every SGPR from s34 up (calling convention), where the interpreter's state is. */
@@ -142,11 +145,147 @@ DEV float rare_unary_a(uint32_t op, float v)
     MPR_H(v, 27) MPR_IMM AO "s_nop 0\n v_mov_b32 v37, s87\n" END                 /* COPY_IMM */          \
     MPR_H(v, 28) LDL AO WL "v_mov_b32 v37, " A "\n" END                  /* COPY_LHS */          \
     MPR_H(v, 29) LDR AO WR "v_mov_b32 v37, " B "\n" END                  /* COPY_RHS */          \
-    MPR_H(v, 30) MPR_EXIT                                                         /* not an opcode */     \
+    MPR_H(v, 30) MPR_H30(LDL, WL, MVA)                                            /* not an opcode */     \
     MPR_H(v, 31) "s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"                  /* lane 63: next block */
 
 /* Walks the tape whose first clause is tro[first] over the slot file at LDS offset 0 (slot s of
  * lane l at s * 256 + l * 4) and returns the result slot named by the end clause. */
+/* The walk itself, as text: expanded in interp_asm (slots in LDS) and in interp_asm_vgpr (slots in VGPRs), each time
+ * with that variant's MPR_AL / MPR_AR / MPR_AO / MPR_ST / MPR_H30 / MPR_VS_ENTER / MPR_VS_LEAVE. */
+#define MPR_ASM_TEXT \
+    MPR_VS_ENTER \
+    "s_mov_b32 s89, %[base]\n" \
+    "s_mov_b32 s88, %[sj]\n" \
+    "s_mov_b32 s90, 0x260\n" \
+    "s_mov_b32 s96, 0xff00\n" \
+    "s_mov_b32 s91, 0\n"                            /* no heightmap value in flight */ \
+    "s_mov_b32 %[ab], 0\n" \
+    "v_mov_b32 v37, %[prev]\n" \
+    "s_getpc_b64 s[82:83]\n" \
+    "L_pc_%=:\n" \
+    "s_add_u32 s82, s82, L_h0_0_%=-L_pc_%=\n" \
+    "s_addc_u32 s83, s83, 0\n" \
+    "s_cmp_eq_u32 %[mode], 0\n" \
+    "s_cbranch_scc1 L_load_%=\n" \
+    "s_cmp_eq_u32 %[mode], 2\n" \
+    "s_cbranch_scc1 L_loaded_%=\n" \
+    MPR_DISPATCH \
+    /* ---- fetch 63 clauses at s89, build the handler addresses ---- */ \
+    "L_load_%=:\n" \
+    "s_mov_b32 s84, s89\n" \
+    "s_mov_b32 s85, 0\n" \
+    "s_lshl_b64 s[84:85], s[84:85], 3\n" \
+    "s_add_u32 s84, s84, %[tlo]\n" \
+    "s_addc_u32 s85, s85, %[thi]\n" \
+    "global_load_dword %[blo], %[lane8], s[84:85]\n" \
+    "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n" \
+    "s_mov_b32 s91, %[rck]\n" \
+    "s_cmp_eq_u32 s91, 0\n" \
+    "s_cbranch_scc1 L_loaded_%=\n" \
+    "s_mov_b32 s84, %[ilo]\n"                       /* the lane's heightmap entry, past the L1 */ \
+    "s_mov_b32 s85, %[ihi]\n" \
+    "global_load_dword v45, %[ioff], s[84:85] sc1\n" \
+    "L_loaded_%=:\n" \
+    "s_mov_b32 s88, -1\n" \
+    "v_mov_b32 v41, 0\n" \
+    "v_mov_b32 v43, 32\n" \
+    "v_mov_b32 v44, 64\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    "s_cmp_eq_u32 s91, 0\n" \
+    "s_cbranch_scc1 L_nocheck_%=\n" \
+    "v_cmp_ge_i32 vcc, v45, %[thr]\n"               /* hidden by now? */ \
+    "s_mov_b32 s91, 0\n" \
+    "s_cmp_eq_u64 vcc, exec\n" \
+    "s_cbranch_scc1 L_abort_%=\n" \
+    "L_nocheck_%=:\n" \
+    "v_bfe_u32 v40, %[blo], 8, 8\n"                 /* out slot */ \
+    "v_and_b32 v38, 0xff, %[blo]\n" \
+    "v_min_u32 v38, 30, v38\n"                       /* opcode; unknown ones -> handler 30 */ \
+    "v_mov_b32_dpp v41, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */ \
+    "v_bfe_u32 v42, %[blo], 16, 8\n"                /* lhs slot */ \
+    "v_lshrrev_b32 v39, 24, %[blo]\n"               /* rhs slot */ \
+    "v_cmp_eq_u32 s[92:93], v39, v41\n" \
+    "v_cmp_eq_u32 vcc, v42, v41\n" \
+    "v_cmp_ne_u32 s[94:95], 0, v41\n" \
+    "v_cndmask_b32 v42, 0, v44, s[92:93]\n"          /* rhs forwarded: table 2 */ \
+    "v_cndmask_b32 v42, v42, v43, vcc\n"             /* lhs forwarded: table 1 */ \
+    "v_cndmask_b32 v42, 0, v42, s[94:95]\n" \
+    /* this clause takes the previous result from v37 (exactly one operand), writes the same slot \
+    * and is an ordinary opcode: the previous clause need not store (tables 3-5 = +96) */ \
+    "s_xor_b64 s[40:41], s[92:93], vcc\n" \
+    "s_and_b64 s[40:41], s[40:41], s[94:95]\n" \
+    "v_cmp_eq_u32 s[42:43], v40, v41\n" \
+    "v_add_u32 v45, -2, v38\n" \
+    "v_cmp_gt_u32 s[44:45], 28, v45\n" \
+    "v_cmp_ne_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63's clause runs as lane 0 of the next block: from LDS */ \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n" \
+    "s_and_b64 s[44:45], s[44:45], vcc\n" \
+    "s_and_b64 s[40:41], s[40:41], s[44:45]\n" \
+    "v_mov_b32 v46, 0\n" \
+    "v_mov_b32 v47, 0x60\n" \
+    "v_cndmask_b32 v45, 0, v47, s[40:41]\n" \
+    "v_add_u32 v38, v38, v42\n" \
+    "s_nop 0\n" \
+    "v_mov_b32_dpp v46, v45 wave_shl:1 row_mask:0xf bank_mask:0xf\n"   /* lane j <- lane j + 1 (lane 63: 0) */ \
+    "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */ \
+    "v_mov_b32 v39, 31\n" \
+    "v_add_u32 v38, v38, v46\n" \
+    "v_cndmask_b32 v38, v38, v39, vcc\n"             /* handler index = table * 32 + opcode */ \
+    /* clause word as the handlers see it: byte 0 out slot, byte 1 handler index, bytes 2, 3 lhs, rhs */ \
+    "v_lshl_or_b32 v38, v38, 8, v40\n" \
+    "v_and_b32 %[blo], 0xffff0000, %[blo]\n" \
+    "v_or_b32 %[blo], %[blo], v38\n" \
+    "s_nop 0\n" \
+    MPR_DISPATCH \
+    /* ---- handlers: three tables of 32 x 128 bytes ---- */ \
+    MPR_TABLE(0, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "", MPR_AO, MPR_END) \
+    MPR_TABLE(1, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "", MPR_AO, MPR_END) \
+    MPR_TABLE(2, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n", MPR_AO, MPR_END) \
+    MPR_TABLE(3, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "", "s_nop 0\n", MPR_DISPATCH) \
+    MPR_TABLE(4, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "", "s_nop 0\n", MPR_DISPATCH) \
+    MPR_TABLE(5, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n", "s_nop 0\n", MPR_DISPATCH) \
+    /* ---- v37 = v35 / v36, correctly rounded ---- */ \
+    ".p2align 7\n" \
+    "L_div_%=:\n" \
+    MPR_ASM_DIV_BODY \
+    MPR_ST MPR_DISPATCH \
+    /* ---- v37 = sqrt(v35), correctly rounded ---- */ \
+    "L_sqrt_%=:\n" \
+    MPR_ASM_SQRT_BODY \
+    MPR_ST MPR_DISPATCH \
+    /* ---- v37 = mpr_expf(v35) (include/mpr_fmath.h), same operations in the same order ---- */ \
+    "L_exp_%=:\n" \
+    MPR_ASM_EXP_BODY \
+    MPR_ST MPR_DISPATCH \
+    /* ---- v37 = mpr_logf(v35) ---- */ \
+    "L_log_%=:\n" \
+    MPR_ASM_LOG_BODY \
+    MPR_ST MPR_DISPATCH \
+    /* ---- v37 = mpr_sinf(v35) / mpr_cosf(v35) ---- */ \
+    "L_sin_%=:\n" \
+    MPR_ASM_SINCOS_BODY \
+    MPR_ST MPR_DISPATCH \
+    "L_cos_%=:\n" \
+    MPR_ASM_SINCOS_BODY \
+    "v_mov_b32 v37, v36\n" \
+    MPR_ST MPR_DISPATCH \
+    /* ---- v37 = mpr_asinf / mpr_acosf / mpr_atanf(v35): compiled routines, called ---- */ \
+    "L_casin_%=:\n" MPR_CALL("mpr_fa_asin") \
+    "L_cacos_%=:\n" MPR_CALL("mpr_fa_acos") \
+    "L_catan_%=:\n" MPR_CALL("mpr_fa_atan") \
+    /* ---- every lane is hidden: give up ---- */ \
+    "L_abort_%=:\n" \
+    "s_mov_b32 %[ab], 1\n" \
+    "s_mov_b32 s86, 0\n" \
+    /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */ \
+    "L_exit_%=:\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    MPR_VS_LEAVE \
+    "s_mov_b32 %[dlo], s86\n" \
+    "s_mov_b32 %[dhi], s87\n" \
+    "s_mov_b32 %[base], s89\n" \
+    "s_mov_b32 %[sj], s88\n"
+
 /* first_block: the 64 words at tro[first + lane], when the caller has already fetched them (under
  * other latencies of its prologue), else null */
 /* image / img_off / hidden_at (3-D frames): whenever a further block of the tape is fetched, the lane's
@@ -186,136 +325,7 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
         sj = rdfirst(sj);
         mode = rdfirst(mode);
         asm volatile(
-            "s_mov_b32 s89, %[base]\n"
-            "s_mov_b32 s88, %[sj]\n"
-            "s_mov_b32 s90, 0x260\n"
-            "s_mov_b32 s96, 0xff00\n"
-            "s_mov_b32 s91, 0\n"                            /* no heightmap value in flight */
-            "s_mov_b32 %[ab], 0\n"
-            "v_mov_b32 v37, %[prev]\n"
-            "s_getpc_b64 s[82:83]\n"
-            "L_pc_%=:\n"
-            "s_add_u32 s82, s82, L_h0_0_%=-L_pc_%=\n"
-            "s_addc_u32 s83, s83, 0\n"
-            "s_cmp_eq_u32 %[mode], 0\n"
-            "s_cbranch_scc1 L_load_%=\n"
-            "s_cmp_eq_u32 %[mode], 2\n"
-            "s_cbranch_scc1 L_loaded_%=\n"
-            MPR_DISPATCH
-            /* ---- fetch 63 clauses at s89, build the handler addresses ---- */
-            "L_load_%=:\n"
-            "s_mov_b32 s84, s89\n"
-            "s_mov_b32 s85, 0\n"
-            "s_lshl_b64 s[84:85], s[84:85], 3\n"
-            "s_add_u32 s84, s84, %[tlo]\n"
-            "s_addc_u32 s85, s85, %[thi]\n"
-            "global_load_dword %[blo], %[lane8], s[84:85]\n"
-            "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n"
-            "s_mov_b32 s91, %[rck]\n"
-            "s_cmp_eq_u32 s91, 0\n"
-            "s_cbranch_scc1 L_loaded_%=\n"
-            "s_mov_b32 s84, %[ilo]\n"                       /* the lane's heightmap entry, past the L1 */
-            "s_mov_b32 s85, %[ihi]\n"
-            "global_load_dword v45, %[ioff], s[84:85] sc1\n"
-            "L_loaded_%=:\n"
-            "s_mov_b32 s88, -1\n"
-            "v_mov_b32 v41, 0\n"
-            "v_mov_b32 v43, 32\n"
-            "v_mov_b32 v44, 64\n"
-            "s_waitcnt vmcnt(0)\n"
-            "s_cmp_eq_u32 s91, 0\n"
-            "s_cbranch_scc1 L_nocheck_%=\n"
-            "v_cmp_ge_i32 vcc, v45, %[thr]\n"               /* hidden by now? */
-            "s_mov_b32 s91, 0\n"
-            "s_cmp_eq_u64 vcc, exec\n"
-            "s_cbranch_scc1 L_abort_%=\n"
-            "L_nocheck_%=:\n"
-            "v_bfe_u32 v40, %[blo], 8, 8\n"                 /* out slot */
-            "v_and_b32 v38, 0xff, %[blo]\n"
-            "v_min_u32 v38, 30, v38\n"                       /* opcode; unknown ones -> handler 30 */
-            "v_mov_b32_dpp v41, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */
-            "v_bfe_u32 v42, %[blo], 16, 8\n"                /* lhs slot */
-            "v_lshrrev_b32 v39, 24, %[blo]\n"               /* rhs slot */
-            "v_cmp_eq_u32 s[92:93], v39, v41\n"
-            "v_cmp_eq_u32 vcc, v42, v41\n"
-            "v_cmp_ne_u32 s[94:95], 0, v41\n"
-            "v_cndmask_b32 v42, 0, v44, s[92:93]\n"          /* rhs forwarded: table 2 */
-            "v_cndmask_b32 v42, v42, v43, vcc\n"             /* lhs forwarded: table 1 */
-            "v_cndmask_b32 v42, 0, v42, s[94:95]\n"
-            /* this clause takes the previous result from v37 (exactly one operand), writes the same slot
-             * and is an ordinary opcode: the previous clause need not store (tables 3-5 = +96) */
-            "s_xor_b64 s[40:41], s[92:93], vcc\n"
-            "s_and_b64 s[40:41], s[40:41], s[94:95]\n"
-            "v_cmp_eq_u32 s[42:43], v40, v41\n"
-            "v_add_u32 v45, -2, v38\n"
-            "v_cmp_gt_u32 s[44:45], 28, v45\n"
-            "v_cmp_ne_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63's clause runs as lane 0 of the next block: from LDS */
-            "s_and_b64 s[40:41], s[40:41], s[42:43]\n"
-            "s_and_b64 s[44:45], s[44:45], vcc\n"
-            "s_and_b64 s[40:41], s[40:41], s[44:45]\n"
-            "v_mov_b32 v46, 0\n"
-            "v_mov_b32 v47, 0x60\n"
-            "v_cndmask_b32 v45, 0, v47, s[40:41]\n"
-            "v_add_u32 v38, v38, v42\n"
-            "s_nop 0\n"
-            "v_mov_b32_dpp v46, v45 wave_shl:1 row_mask:0xf bank_mask:0xf\n"   /* lane j <- lane j + 1 (lane 63: 0) */
-            "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */
-            "v_mov_b32 v39, 31\n"
-            "v_add_u32 v38, v38, v46\n"
-            "v_cndmask_b32 v38, v38, v39, vcc\n"             /* handler index = table * 32 + opcode */
-            /* clause word as the handlers see it: byte 0 out slot, byte 1 handler index, bytes 2, 3 lhs, rhs */
-            "v_lshl_or_b32 v38, v38, 8, v40\n"
-            "v_and_b32 %[blo], 0xffff0000, %[blo]\n"
-            "v_or_b32 %[blo], %[blo], v38\n"
-            "s_nop 0\n"
-            MPR_DISPATCH
-            /* ---- handlers: three tables of 32 x 128 bytes ---- */
-            MPR_TABLE(0, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "", MPR_AO, MPR_END)
-            MPR_TABLE(1, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "", MPR_AO, MPR_END)
-            MPR_TABLE(2, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n", MPR_AO, MPR_END)
-            MPR_TABLE(3, MPR_AL, "v35", MPR_AR, "v36", MPR_W, MPR_W, MPR_W, "", "", "", "", "s_nop 0\n", MPR_DISPATCH)
-            MPR_TABLE(4, "", "v37", MPR_AR, "v36", "", MPR_W, MPR_W, "v_mov_b32 v35, v37\n", "", "s_nop 0\n", "", "s_nop 0\n", MPR_DISPATCH)
-            MPR_TABLE(5, MPR_AL, "v35", "", "v37", MPR_W, "", MPR_W, "", "v_mov_b32 v36, v37\n", "", "s_nop 0\n", "s_nop 0\n", MPR_DISPATCH)
-            /* ---- v37 = v35 / v36, correctly rounded ---- */
-            ".p2align 7\n"
-            "L_div_%=:\n"
-            MPR_ASM_DIV_BODY
-            MPR_ST MPR_DISPATCH
-            /* ---- v37 = sqrt(v35), correctly rounded ---- */
-            "L_sqrt_%=:\n"
-            MPR_ASM_SQRT_BODY
-            MPR_ST MPR_DISPATCH
-            /* ---- v37 = mpr_expf(v35) (include/mpr_fmath.h), same operations in the same order ---- */
-            "L_exp_%=:\n"
-            MPR_ASM_EXP_BODY
-            MPR_ST MPR_DISPATCH
-            /* ---- v37 = mpr_logf(v35) ---- */
-            "L_log_%=:\n"
-            MPR_ASM_LOG_BODY
-            MPR_ST MPR_DISPATCH
-            /* ---- v37 = mpr_sinf(v35) / mpr_cosf(v35) ---- */
-            "L_sin_%=:\n"
-            MPR_ASM_SINCOS_BODY
-            MPR_ST MPR_DISPATCH
-            "L_cos_%=:\n"
-            MPR_ASM_SINCOS_BODY
-            "v_mov_b32 v37, v36\n"
-            MPR_ST MPR_DISPATCH
-            /* ---- v37 = mpr_asinf / mpr_acosf / mpr_atanf(v35): compiled routines, called ---- */
-            "L_casin_%=:\n" MPR_CALL("mpr_fa_asin")
-            "L_cacos_%=:\n" MPR_CALL("mpr_fa_acos")
-            "L_catan_%=:\n" MPR_CALL("mpr_fa_atan")
-            /* ---- every lane is hidden: give up ---- */
-            "L_abort_%=:\n"
-            "s_mov_b32 %[ab], 1\n"
-            "s_mov_b32 s86, 0\n"
-            /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */
-            "L_exit_%=:\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "s_mov_b32 %[dlo], s86\n"
-            "s_mov_b32 %[dhi], s87\n"
-            "s_mov_b32 %[base], s89\n"
-            "s_mov_b32 %[sj], s88\n"
+            MPR_ASM_TEXT
             : [blo] "+&v"(blo), [bhi] "+&v"(bhi),          /* early clobber: an input of equal value must not share them */
               [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi), [ab] "=&s"(aborted)
             : [lb] "v"(lb), [selL] "v"(selL), [selR] "v"(selR), [selO] "v"(selO), [lane8] "v"(lane8),
@@ -343,8 +353,70 @@ DEV uint32_t interp_asm(const uint64_t* __restrict__ tro, uint32_t first, unsign
     return dlo & 0xFF;
 }
 
-template <int DIM>
-__global__ void __launch_bounds__(64)
+/* The same walk with the slot file in VECTOR REGISTERS (slot s = v[48 + s], addressed through the scalar GPR index: see
+ * tile_interp_asm.hpp), for tapes with many slots: 256 bytes of LDS per slot and wavefront leave a tape with 84 slots
+ * 7 wavefronts per CU; 93 registers on top of the walk's own are 3 per SIMD, 12 per CU.  The axes' values arrive and the
+ * result leaves inside the one asm statement; a word that is not an opcode is the logarithm it is outside (MPR_H30). */
+#undef MPR_AL
+#undef MPR_AR
+#undef MPR_AO
+#undef MPR_ST
+#undef MPR_H30
+#undef MPR_VS_ENTER
+#undef MPR_VS_LEAVE
+#define MPR_AL "s_bfe_u32 s60, s86, 0x80010\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v35, v48\n s_set_gpr_idx_off\n"
+#define MPR_AR "s_lshr_b32 s60, s86, 24\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 v36, v48\n s_set_gpr_idx_off\n"
+#define MPR_AO "s_and_b32 s61, s86, 0xff\n"                       /* the out slot, kept for MPR_ST */
+#define MPR_ST "s_set_gpr_idx_on s61, gpr_idx(DST)\n v_mov_b32 v48, v37\n s_set_gpr_idx_off\n"
+#define MPR_H30(LDL, WL, MVA) LDL MPR_AO WL MVA "s_branch L_log_%=\n"
+#define MPR_VS_ENTER                                                                                                   \
+    "s_set_gpr_idx_on %[ax], gpr_idx(DST)\n v_mov_b32 v48, %[xin]\n s_set_gpr_idx_off\n"                              \
+    "s_set_gpr_idx_on %[ay], gpr_idx(DST)\n v_mov_b32 v48, %[yin]\n s_set_gpr_idx_off\n"                              \
+    "s_set_gpr_idx_on %[az], gpr_idx(DST)\n v_mov_b32 v48, %[zin]\n s_set_gpr_idx_off\n"
+#define MPR_VS_LEAVE "s_and_b32 s60, s86, 0xff\n s_set_gpr_idx_on s60, gpr_idx(SRC0)\n v_mov_b32 %[res], v48\n s_set_gpr_idx_off\n"
+#define MPR_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+constexpr int MPR_VS_MAX_SLOTS = 93;
+
+/* ax / ay / az: the axes' slots (head clause); xin / yin / zin: their values; *res: the result; returns INTERP_ABORTED or 0 */
+DEV uint32_t interp_asm_vgpr(const uint64_t* __restrict__ tro, uint32_t first, int lane, const uint64_t* first_block,
+                             const int* image, uint32_t img_off, int hidden_at, uint32_t ax, uint32_t ay, uint32_t az,
+                             float xin, float yin, float zin, float* res)
+{
+    uint32_t blo = (uint32_t)*first_block, bhi = (uint32_t)(*first_block >> 32);
+    uint32_t base = rdfirst(first), sj = 0, dlo = 0, dhi = 0;
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t tlo = (uint32_t)(uintptr_t)tro, thi = (uint32_t)((uintptr_t)tro >> 32);
+    const uint32_t ilo = rdfirst((uint32_t)(uintptr_t)image), ihi = rdfirst((uint32_t)((uintptr_t)image >> 32));
+    const uint32_t recheck = rdfirst(image ? 1u : 0u);
+    uint32_t aborted = 0;
+    const uint32_t mode = 2, zero = 0;
+    float r = 0.0f;
+    ax = rdfirst(ax);
+    ay = rdfirst(ay);
+    az = rdfirst(az);
+    asm volatile(
+        MPR_ASM_TEXT
+        : [blo] "+&v"(blo), [bhi] "+&v"(bhi), [base] "+&s"(base), [sj] "+&s"(sj), [dlo] "=&s"(dlo), [dhi] "=&s"(dhi), [ab] "=&s"(aborted),
+          [res] "=&v"(r)
+        : [lane8] "v"(lane8), [tlo] "s"(tlo), [thi] "s"(thi), [mode] "s"(mode), [prev] "s"(zero),
+          [ilo] "s"(ilo), [ihi] "s"(ihi), [rck] "s"(recheck), [ioff] "v"(img_off), [thr] "v"(hidden_at),
+          [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [xin] "v"(xin), [yin] "v"(yin), [zin] "v"(zin)
+        : "memory", "vcc", "scc",
+          "s60", "s61", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
+          /* the slot file */
+          "v48", "v49", MPR_V10(5), MPR_V10(6), MPR_V10(7), MPR_V10(8), MPR_V10(9), MPR_V10(10), MPR_V10(11), MPR_V10(12), MPR_V10(13), "v140");
+    *res = r;
+    return aborted ? INTERP_ABORTED : 0u;
+}
+
+template <int DIM, bool VS>
+__global__ void __launch_bounds__(64, VS ? 3 : 0)
 k_eval_voxels_asm(VoxelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -399,15 +471,22 @@ k_eval_voxels_asm(VoxelArgs a)
         vy = (a.mat[1] * fx + a.mat[4] * fy + a.mat[7]) / fw;
         vz = a.z;
     }
-    *reinterpret_cast<float*>(myslot + ((head0 >> 8) & 0xFF) * 256) = vx;
-    *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
-    *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
-
     const int pz_low2 = (DIM == 3) ? pos.z * 4 + (sub.z & 1) + 2 : 0;
-    const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane, &first_block, DIM == 3 ? a.image : nullptr,
-                                      (uint32_t)(px + py * S) * 4u, pz_low2);
-    if (rslot == INTERP_ABORTED) return;
-    const float res = *reinterpret_cast<const float*>(myslot + rslot * 256);
+    float res;
+    if (VS) {
+        if (interp_asm_vgpr(tro, (uint32_t)(tape + 1), lane, &first_block, DIM == 3 ? a.image : nullptr, (uint32_t)(px + py * S) * 4u, pz_low2,
+                            (uint32_t)(head0 >> 8) & 0xFFu, (uint32_t)(head0 >> 16) & 0xFFu, (uint32_t)(head0 >> 24) & 0xFFu, vx, vy, vz,
+                            &res) == INTERP_ABORTED)
+            return;
+    } else {
+        *reinterpret_cast<float*>(myslot + ((head0 >> 8) & 0xFF) * 256) = vx;
+        *reinterpret_cast<float*>(myslot + ((head0 >> 16) & 0xFF) * 256) = vy;
+        *reinterpret_cast<float*>(myslot + ((head0 >> 24) & 0xFF) * 256) = vz;
+        const uint32_t rslot = interp_asm(tro, (uint32_t)(tape + 1), smem, lane, &first_block, DIM == 3 ? a.image : nullptr,
+                                          (uint32_t)(px + py * S) * 4u, pz_low2);
+        if (rslot == INTERP_ABORTED) return;
+        res = *reinterpret_cast<const float*>(myslot + rslot * 256);
+    }
     if (!skip && res < 0.0f) {
         if (DIM == 3) {
             int* p = &a.image[px + py * S];
@@ -445,8 +524,15 @@ void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a)
     if (a.count <= 0) return;
     const dim3 g((a.count + 63) & ~63), b(64);           /* whole windows of 64: the tile map permutes inside them */
     const size_t lds = voxel_asm_lds_bytes(a.nslots);
-    if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_asm<3>, g, b, lds, s, a);
-    else hipLaunchKernelGGL(k_eval_voxels_asm<2>, g, b, lds, s, a);
+    /* slots in registers when the LDS slot file would hold a CU under the 12 wavefronts those registers allow */
+    const bool vs = a.vgpr_slots && a.nslots <= MPR_VS_MAX_SLOTS && lds > (size_t)160 * 1024 / 12;
+    if (dim == 3) {
+        if (vs) hipLaunchKernelGGL((k_eval_voxels_asm<3, true>), g, b, 16, s, a);
+        else hipLaunchKernelGGL((k_eval_voxels_asm<3, false>), g, b, lds, s, a);
+    } else {
+        if (vs) hipLaunchKernelGGL((k_eval_voxels_asm<2, true>), g, b, 16, s, a);
+        else hipLaunchKernelGGL((k_eval_voxels_asm<2, false>), g, b, lds, s, a);
+    }
 }
 
 }  // namespace mprk
