@@ -17,6 +17,8 @@ Rank 0 prints ONE JSON line.  Extra objects on that line:
   cpu_baseline  the CPU oracle (a port, not the reference): all host cores at 512^3 and one core at
                 256^3, warm-up + 3 frames each, beside the GPU's time at the same size; the oracle's
                 frame must equal the GPU's
+  full_frames   the same frame when every frame pushes the last tile stage's tapes (the first frame of a
+                tape or view; the timed frames repeat one view and do not need them)
   also          the reference's other headline config (prospero render2D 1024^2), for which
                 BASELINE.md holds the only published number (V100, 3.856 ms/frame)
 """
@@ -278,6 +280,21 @@ def main():
         }
         if verified is not None:
             out["verified_against_single_gpu"] = verified
+
+    # ---- the same frame when every frame pushes the last tile stage's tapes (what the FIRST frame of a tape / view costs:
+    #      repeated frames do not need those tapes, DESIGN.md 3 "Frames whose last tile stage pushes no tapes") ----
+    if rank == 0 and world == 1:
+        os.environ["MPR_LAST_STAGE_PUSH"] = "1"
+        fctx = m.Context(S, device=local_rank)
+        del os.environ["MPR_LAST_STAGE_PUSH"]
+        _, fper = time_frames(lambda: fctx.render3D(tape, T), min(args.warmup, 5), min(args.steps, 30), lambda: None, sync)
+        fm, fs = stats(fper)
+        same = bool(np.array_equal(fctx.image, ctx.image) and np.array_equal(fctx.normals, ctx.normals))
+        fctx.close()
+        out["full_frames"] = {"ms_per_frame_mean": round(fm, 4), "ms_per_frame_std": round(fs, 4),
+                              "value": round(S * S / (fm * 1e-3) / 1e6, 3), "unit": "Mpixel/s", "same_images": same,
+                              "note": "every frame pushes the last tile stage's tapes (MPR_LAST_STAGE_PUSH=1): the cost of the first "
+                                      "frame of a tape or view; the timed frames above repeat one view, as benchmark/stats.cpp does"}
 
     # ---- side measurement: prospero render2D 1024^2 (the published V100 number's config) ----
     if rank == 0 and world == 1 and not args.no_also:
