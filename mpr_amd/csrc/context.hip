@@ -676,6 +676,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
             a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
             a.len_stats = (groups_now && !lean_now) ? c->num_active + 5 : nullptr;
+            if (c->debug_choices && si == nstages - 2) a.len_stats = c->num_active + 5;
             a.no_push = groups_now && lean_now;
             a.compiled_walk = !c->tiles_asm;
             a.vgpr_slots = c->tiles_vgpr;
@@ -761,7 +762,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             if (c->debug_choices) fprintf(stderr, "last stage: tapes handed on %d clauses, tapes walked %d (sample)\n", act3[1], act3[2]);
         }
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
-        if (c->debug_choices) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d)\n", si, count, act3[3], choice_cap);
+        if (c->debug_choices) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d); tapes handed on %d, walked %d\n", si, count, act3[3], choice_cap, act3[1], act3[2]);
         c->last.tiles_active[si] = active;
         count = last ? active : active * 64;
         c->tiles_n[next] = (size_t)count;
