@@ -860,8 +860,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.counters = cnt;
         n.col_list = nullptr;
         n.ncols = 0;
-        n.groups = lean_now ? c->groups : nullptr;
-        n.choice_masks = lean_now ? c->choice_masks : nullptr;
+        /* the groups' tapes and decisions whenever the last stage recorded them and the float pass took them (a frame without
+         * last-stage tapes has nothing else; one with them gets the shared walks) */
+        const bool normals_on_groups = (lean_now || group_form) && c->normals_asm && !cnt;
+        n.groups = normals_on_groups ? c->groups : nullptr;
+        n.choice_masks = normals_on_groups ? c->choice_masks : nullptr;
         n.choice_cap = group_cap;
         n.vgpr_slots = c->tiles_vgpr;
         if (owner && c->normals_asm && !cnt) {

@@ -472,6 +472,9 @@ k_eval_normals_asm(NormalArgs a)
         }
     }
     /* the last tile stage pushed no tapes: this smallest tile's own tape is its group's (my_tape) with these decisions */
+    /* with the groups' records at hand every smallest tile is walked on its group's tape (in a frame whose last stage pushed
+     * tapes the node names the tile's own: same values either way, but tiles of a group then share one walk) */
+    if (a.groups && my_micro >= 0) my_tape = a.groups[my_micro >> 6].tape;
     unsigned long long dl0 = 0, dl1 = 0, dl2 = 0, dr0 = 0, dr1 = 0, dr2 = 0;
     if (a.groups) {
         /* one (group, tile) at a time — a footprint meets a handful: lane i fetches the group's i-th pair of masks, and
