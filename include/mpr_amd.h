@@ -219,7 +219,7 @@ int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap
 const char* mpr_ctx_float_kernel(const mpr_context* ctx);
 
 /* 1 when the last frame's last tile stage pushed per-tile tapes (the reference's state), 0 when it did not need to:
- * a frame that repeats the tape and view of the one before it, with float and normals pass on the groups' tapes
+ * a frame of a tape whose last measuring frame found float and normals pass on the groups' tapes worth it
  * (DESIGN.md 3).  mpr_read_tiles / mpr_read_tape_pool render such a frame again in full before they read, so what
  * they return is always the reference's state. */
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* ctx);

@@ -84,8 +84,9 @@ struct mpr_context {
     int cus = 0;                       /* compute units of the device */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
     /* Frames whose last tile stage pushes no tapes (TileStageArgs::no_push): possible when both the float and the normals
-     * pass run on the groups' tapes, decided from what the LAST frame of the same tape and view measured (a push-mode
-     * frame: the first one always is).  What a reader of tiles / tapes needs to get the reference's state back: */
+     * pass run on the groups' tapes, decided from what the last MEASURING frame of the same tape and partition found (a
+     * push-mode frame: the first one always is, and one after every 64 without).  What a reader of tiles / tapes needs to get the
+     * reference's state back: */
     bool lean_last_stage = true;       /* MPR_LAST_STAGE_PUSH=1: always push */
     bool force_push = false;           /* set while a reader re-renders the frame in full */
     bool last_frame_lean = false;
@@ -96,14 +97,18 @@ struct mpr_context {
         bool parted = false;
         float mat[16] = {0};
         float z = 0.0f;
-        bool operator==(const FrameKey& o) const
+        /* same tape and partition: the view may differ (how much the last stage shortens its tapes is a property of the
+         * model and the resolution far more than of the view, and a frame that guesses wrong is slower, not different) */
+        bool same_model(const FrameKey& o) const
         {
-            return serial == o.serial && dim == o.dim && rank == o.rank && owner_gen == o.owner_gen && parted == o.parted &&
-                   z == o.z && std::memcmp(mat, o.mat, sizeof mat) == 0;
+            return serial == o.serial && dim == o.dim && rank == o.rank && owner_gen == o.owner_gen && parted == o.parted;
         }
     };
     FrameKey learned;                  /* the frame that measured "groups' tapes are short enough" ... */
+    FrameKey last_key;                 /* ... and the last frame rendered (what a reader's full frame repeats) */
     bool learned_ok = false;
+    int frames_since_measured = 0;
+    int lean_period = 64;              /* a full (measuring) frame after this many frames without: views drift (MPR_LEAN_PERIOD) */
     std::unique_ptr<mpr_tape> last_tape;   /* ... and a copy of its tape (the caller may have freed it by the time a reader asks) */
     bool tiles_vgpr = true;            /* MPR_TILES_VGPR=0 (development): tile stages keep every slot file in LDS */
     bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
@@ -317,6 +322,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILES_VGPR")) c->tiles_vgpr = atoi(e) != 0;
     if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->lean_last_stage = atoi(e) == 0;
+    if (const char* e = getenv("MPR_LEAN_PERIOD")) c->lean_period = std::max(atoi(e), 1);
     if (const char* e = getenv("MPR_WIDE_LATER")) c->wide_later = atoi(e);
     if (const char* e = getenv("MPR_WIDE_THREADS")) c->wide_threads = atoi(e);
     if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
@@ -594,8 +600,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     key.z = z;
     std::memcpy(key.mat, mat, (size_t)(dim == 3 ? 16 : 9) * sizeof(float));
     /* the last frame of this tape and view found the group form worth it: this one's last tile stage pushes no tapes */
-    const bool lean_ok = c->lean_last_stage && !c->force_push && !brute && c->learned_ok && c->learned == key &&
-                         (dim == 2 || c->normals_asm);
+    const bool lean_ok = c->lean_last_stage && !c->force_push && !brute && c->learned_ok && c->learned.same_model(key) &&
+                         c->frames_since_measured < c->lean_period && (dim == 2 || c->normals_asm);
     bool lean_now = false;
     if (!brute) {
         const int t0 = S / 64;
@@ -757,6 +763,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             else if (!cnt && !heat) {
                 c->learned = key;
                 c->learned_ok = true;
+                c->frames_since_measured = 0;
                 if (!c->last_tape || c->last_tape->serial != tape->serial) c->last_tape.reset(new mpr_tape(*tape));
             }
             if (c->debug_choices) fprintf(stderr, "last stage: tapes handed on %d clauses, tapes walked %d (sample)\n", act3[1], act3[2]);
@@ -888,6 +895,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     c->frame_pending = true;
     c->pending_dim = dim;
     c->last_frame_lean = lean_now;
+    c->last_key = key;
+    if (lean_now) c->frames_since_measured++;
     if (blocking) return mpr_ctx_sync(c);
     return MPR_OK;
 }
@@ -898,7 +907,7 @@ static int ensure_full_frame(mpr_context* c)
 {
     if (!c->last_frame_lean) return MPR_OK;
     if (!c->last_tape) return mpr::set_error(MPR_ERR_INVALID, "no tape to render the last frame's tapes from");
-    const mpr_context::FrameKey k = c->learned;
+    const mpr_context::FrameKey k = c->last_key;
     c->force_push = true;
     const int rc = render_frame(c, c->last_tape.get(), k.dim, k.mat, k.z, k.parted ? c->owner_host.data() : nullptr, k.rank, false, true);
     c->force_push = false;
