@@ -78,8 +78,8 @@ __device__ float jit_atan(float v) { return mpr_atanf(v); }
  * For a VOP1 / VOP2 word T holds {src0, vsrc1, vdst, 0} and mask = 0xFFFFFF00 doubles bytes 1..2 into bit positions 9
  * and 17; for a literal T is the literal and mask = base = 0; for s_bitcmp1_b64 T holds the decision index in byte 1
  * (ssrc1 as an inline integer constant) and mask = 0. */
-constexpr int JIT_WORDS = 12;
-constexpr int JIT_ROW = 4 + 3 * JIT_WORDS;           /* dwords per row: meta, 3 pad, then three batches of {base x4, sel x4, mask x4} */
+constexpr int JIT_WORDS = 16;               /* a row holds up to 15 dwords (four batches of four) */
+constexpr int JIT_ROW = 4 + 3 * JIT_WORDS;           /* dwords per row: meta, 3 pad, then four batches of {base x4, sel x4, mask x4} */
 struct JitRow { uint32_t n, flags; uint32_t base[JIT_WORDS], sel[JIT_WORDS], mask[JIT_WORDS]; };
 constexpr int JIT_ROWS = 36;               /* 32 opcodes (30: the translator's constant division), then min / max for decisions 64..127 */
 struct JitTable { uint32_t w[JIT_ROWS][JIT_ROW]; };
@@ -94,7 +94,10 @@ constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /*
 constexpr uint32_t BITCMP_L1 = 0xBF0F0030u, BITCMP_R1 = 0xBF0F0032u;
 constexpr int JIT_MAX_CHOICES = 128;
 constexpr uint32_t CSELECT = 0x85EA80C1u;                                      /* s_cselect_b64 vcc, -1, 0 */
-constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21;
+constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21, V_FMAMK = 23;
+constexpr uint32_t CLASS_V39_V7 = 0x7C200F27u;                                 /* v_cmp_class_f32 vcc, v39, v7 */
+constexpr uint32_t BRANCH_VCCZ_2 = 0xBF860002u;                                /* s_cbranch_vccz +2 dwords */
+constexpr uint32_t CLASS_NOT_POSITIVE_NORMAL = 0x2FFu;                         /* what v7 holds while generated code runs */
 constexpr uint32_t S_DIVC = 70, S_DIV = 52, S_SQRT = 54, S_EXP = 56, S_LOG = 58, S_SIN = 60, S_COS = 62, S_ASIN = 64, S_ACOS = 66, S_ATAN = 68;
 constexpr uint32_t FLAG_MINMAX = 1, FLAG_CANON = 2;
 
@@ -108,6 +111,7 @@ struct Builder {
         ++r.n;
     }
     constexpr void lit() { r.base[r.n] = 0; r.sel[r.n] = 0x07060504u; r.mask[r.n] = 0; ++r.n; }      /* the literal */
+    constexpr void neglit() { r.base[r.n] = 0x80000000u; r.sel[r.n] = 0x07060504u; r.mask[r.n] = 0; ++r.n; }   /* the literal with its sign flipped */
     constexpr void bitcmp(uint32_t base) { r.base[r.n] = base; r.sel[r.n] = NONE | (CI << 8) | (NONE << 16) | (NONE << 24); r.mask[r.n] = 0; ++r.n; }
     constexpr void fixed(uint32_t w) { r.base[r.n] = w; r.sel[r.n] = NONE | (NONE << 8) | (NONE << 16) | (NONE << 24); r.mask[r.n] = 0; ++r.n; }
 };
@@ -125,6 +129,8 @@ constexpr JitRow leaf_call(uint32_t s)
     b.ins(MOV(0, VREG), NONE, NONE, A);
     b.fixed(CALL(s));
     b.ins(MOV(0, VREG + 0), O);
+    b.fixed(MOV(7, LITERAL));                           /* the compiled leaves may use v0..v7 */
+    b.fixed(CLASS_NOT_POSITIVE_NORMAL);
     return b.r;
 }
 constexpr JitRow one(uint32_t base, uint32_t d, uint32_t s1, uint32_t s0, bool imm = false)
@@ -235,17 +241,28 @@ constexpr JitRow row_of(uint32_t op, bool group)
         case MPR_OP_COPY_LHS: return one(MOV(0, VREG), O, NONE, A);
         case MPR_OP_COPY_RHS: return one(MOV(0, VREG), O, NONE, R);
         case 30: {
-            /* not an opcode: the translator's own row for DIV_LHS_IMM by a constant that is not a power of two
-             * (2^-30 <= |c| <= 2^30): the constant in v36 and its correctly rounded reciprocal in v38 (dword 4 is
-             * replaced by the translator, which computes 1 / c with an IEEE division), then the short routine */
+            /* not an opcode: the translator's own row for DIV_LHS_IMM by a constant c that is not a power of two
+             * (2^-30 <= |c| <= 2^30), with y = RN(1 / c) (the translator computes it with an IEEE division and puts it
+             * in dwords 6, 10 and 14).  Inline when x * x is a positive normal number in every lane (2^-63 <= |x| < 2^64:
+             * nothing over- or underflows on the way): q = x y, then two rounds of r = x - c q (exact, fused),
+             * q += r y end on the correctly rounded quotient.  Any other operand: L_divc divides in general, and comes
+             * back to the last instruction with v39 = a zero and v37 = the quotient. */
             Builder b;
+            b.ins(VOP2(V_MUL, 39, 0, VREG), NONE, A, A);                 /* v39 = x * x */
+            b.fixed(CLASS_V39_V7);                                       /* vcc = lanes where that is anything but a positive normal */
+            b.fixed(BRANCH_VCCZ_2);
             b.ins(MOV(35, VREG), NONE, NONE, A);
-            b.fixed(MOV(36, LITERAL));
-            b.lit();
-            b.fixed(MOV(38, LITERAL));
-            b.fixed(0);
             b.fixed(CALL(S_DIVC));
-            b.ins(MOV(0, VREG + 37), O);
+            b.ins(VOP2(V_MUL, 37, 0, LITERAL), NONE, A, NONE);           /* v37 = y * x */
+            b.fixed(0);
+            b.ins(VOP2(V_FMAMK, 39, 0, VREG + 37), NONE, A, NONE);       /* v39 = v37 * (-c) + x */
+            b.neglit();
+            b.fixed(VOP2(V_FMAMK, 37, 37, VREG + 39));                   /* v37 = v39 * y + v37 */
+            b.fixed(0);
+            b.ins(VOP2(V_FMAMK, 39, 0, VREG + 37), NONE, A, NONE);
+            b.neglit();
+            b.ins(VOP2(V_FMAMK, 0, 37, VREG + 39), O);                   /* out = v39 * y + v37 */
+            b.fixed(0);
             return b.r;
         }
         default: return JitRow{};                                       /* end, JUMP, not an opcode: no code */
@@ -288,8 +305,8 @@ size_t jit_code_dwords(const uint64_t* clauses, int n, bool group)
 }
 
 /* LDS of the translator (dwords): the table, the staging buffer (a block's dwords side by side before they leave in
- * 16-byte pieces: 3 carried + 62 x 12 + slack), a dump for lanes without a dword, a dump for the tape prefetch */
-constexpr int JIT_LDS_STAGE = JIT_ROWS * JIT_ROW, JIT_STAGE_DWORDS = 784, JIT_LDS_DUMP = JIT_LDS_STAGE + JIT_STAGE_DWORDS;
+ * 16-byte pieces: 3 carried + 62 x 15 + slack), a dump for lanes without a dword, a dump for the tape prefetch */
+constexpr int JIT_LDS_STAGE = JIT_ROWS * JIT_ROW, JIT_STAGE_DWORDS = 1056, JIT_LDS_DUMP = JIT_LDS_STAGE + JIT_STAGE_DWORDS;
 constexpr int JIT_LDS_PFDUMP = JIT_LDS_DUMP + 16, JIT_LDS_DWORDS = JIT_LDS_PFDUMP + 256;
 DEV void jit_load_table(uint32_t* lds, int tid, int nthreads, bool group)
 {
@@ -304,8 +321,8 @@ DEV void jit_load_table(uint32_t* lds, int tid, int nthreads, bool group)
  * Written in assembly because two things decide its cost.  (1) Latency: a tape is a linked list of 64-word chunks, so
  * the next block's address is known only once the current block has arrived; the next block is requested the moment
  * the current one is in registers, before any of the work on it, and no memory operation of that work is conditional
- * — the dwords of a block are put side by side in LDS and leave in exactly three 16-byte stores per lane (the ones
- * beyond the end go to the dump) — so the wait for the next block is the exact `s_waitcnt vmcnt(3)`.  (2) Instruction
+ * — the dwords of a block are put side by side in LDS and leave in exactly four 16-byte stores per lane (the ones
+ * beyond the end go to the dump) — so the wait for the next block is the exact `s_waitcnt vmcnt(4)`.  (2) Instruction
  * count: a template dword gets the clause's registers with one v_perm_b32, one v_and_b32 and one v_add3_u32.
  *   s42 block base (clause index)   s43 dwords that have left   s44 dwords waiting in the staging buffer
  *   s46 first terminator lane (64: none)   s48 min / max clauses so far   s52 / s53 terminator lo / hi
@@ -325,8 +342,9 @@ DEV void jit_load_table(uint32_t* lds, int tid, int nthreads, bool group)
     "ds_write_b32 v52, v42 offset:(" #k0 "+2)*4\n"                                                                      \
     "ds_write_b32 v52, v41 offset:(" #k0 "+1)*4\n"                                                                      \
     "ds_write_b32 v52, v40 offset:(" #k0 ")*4\n"
-/* the same for dwords 4..7, with dword 4 of the row-30 lanes (s[70:71]) replaced by the reciprocal in v55 */
-#define JIT_BATCH_PATCH4(off, k0)                                                                                       \
+/* the same for dwords 4.., with the batch's third dword (6, 10, 14) of the row-30 lanes (s[70:71]) replaced by the
+ * reciprocal in v55 */
+#define JIT_BATCH_PATCH(off, k0)                                                                                       \
     "ds_read_b128 v[40:43], v38 offset:" #off "\n"                                                                      \
     "ds_read_b128 v[44:47], v38 offset:" #off "+16\n"                                                                   \
     "ds_read_b128 v[48:51], v38 offset:" #off "+32\n"                                                                   \
@@ -335,7 +353,7 @@ DEV void jit_load_table(uint32_t* lds, int tid, int nthreads, bool group)
     "v_perm_b32 v45, v57, v56, v45\n v_and_b32 v49, v49, v45\n v_add3_u32 v41, v45, v49, v41\n"                         \
     "v_perm_b32 v46, v57, v56, v46\n v_and_b32 v50, v50, v46\n v_add3_u32 v42, v46, v50, v42\n"                         \
     "v_perm_b32 v47, v57, v56, v47\n v_and_b32 v51, v51, v47\n v_add3_u32 v43, v47, v51, v43\n"                         \
-    "v_cndmask_b32 v40, v40, v55, s[70:71]\n"                                                                          \
+    "v_cndmask_b32 v42, v42, v55, s[70:71]\n"                                                                          \
     "ds_write_b32 v52, v43 offset:(" #k0 "+3)*4\n"                                                                      \
     "ds_write_b32 v52, v42 offset:(" #k0 "+2)*4\n"                                                                      \
     "ds_write_b32 v52, v41 offset:(" #k0 "+1)*4\n"                                                                      \
@@ -367,7 +385,7 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_branch L_body_%=\n"
         "L_next_%=:\n"
-        "s_waitcnt vmcnt(3)\n"                             /* the prefetched block; the three stores behind it stay in flight */
+        "s_waitcnt vmcnt(4)\n"                             /* the prefetched block; the four stores behind it stay in flight */
         "v_mov_b32 v34, v36\n v_mov_b32 v35, v37\n"
         "L_body_%=:\n"
         "v_and_b32 v38, 0xff, v34\n"                       /* opcode */
@@ -427,7 +445,7 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "v_div_fixup_f32 v55, v39, v35, v54\n"             /* 1 / c */
         "v_cndmask_b32 v38, v38, 30, s[70:71]\n"
         "v_min_u32 v38, 31, v38\n"                         /* anything that is not an opcode: the empty row 31 */
-        "v_mul_u32_u24 v38, 160, v38\n"                    /* 160-byte rows */
+        "v_mul_u32_u24 v38, 208, v38\n"                    /* 208-byte rows */
         "v_add_u32 v38, %[ltab], v38\n"
         "ds_read_b32 v39, v38\n"                           /* meta: dwords | flags << 8 */
         "v_and_b32 v56, 0xffffff00, v34\n"
@@ -453,7 +471,7 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "v_cmp_ne_u32 vcc, 0, v60\n"
         "v_lshl_add_u32 v60, v60, 2, 11\n"                 /* row = opcode + 11 + 4 q */
         "s_and_b64 vcc, vcc, s[64:65]\n"
-        "v_mul_u32_u24 v60, 160, v60\n"
+        "v_mul_u32_u24 v60, 208, v60\n"
         "v_cndmask_b32 v60, 0, v60, vcc\n"
         "v_add_u32 v38, v38, v60\n"
         "v_add_u32 v53, 128, v53\n"                        /* its index, as the inline constant the scalar compare takes */
@@ -487,16 +505,22 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
          * that lane's own dword for the place — always one with a smaller number — is written after it (LDS
          * operations of a wavefront happen in order).  Lanes without any write to the dump, so that within one
          * instruction no two lanes share an address. */
+        "v_cmp_lt_u32 s[56:57], 12, v59\n"                /* lanes with dwords 12..14 (the scan is done with s[56:63]) */
+        "s_nop 0\n"
+        "s_cmp_eq_u64 s[56:57], 0\n"
+        "s_cbranch_scc1 L_b2_%=\n"
+        JIT_BATCH_PATCH(16+144, 12)
+        "L_b2_%=:\n"
         "s_cmp_eq_u64 s[66:67], 0\n"
         "s_cbranch_scc1 L_b1_%=\n"
-        JIT_BATCH(16+96, 8)
+        JIT_BATCH_PATCH(16+96, 8)
         "L_b1_%=:\n"
         "s_cmp_eq_u64 s[68:69], 0\n"
         "s_cbranch_scc1 L_b0_%=\n"
-        JIT_BATCH_PATCH4(16+48, 4)
+        JIT_BATCH_PATCH(16+48, 4)
         "L_b0_%=:\n"
         JIT_BATCH(16, 0)
-        /* what is complete leaves in 16-byte pieces: lane i carries dwords 4 i .. 4 i + 3, 256 + 4 i ..., 512 + 4 i ... */
+        /* what is complete leaves in 16-byte pieces: lane i carries dwords 4 i .. 4 i + 3, 256 + 4 i ..., 512 + 4 i ..., 768 + 4 i ... */
         "s_and_b32 s45, s44, -4\n"                         /* dwords that leave now */
         "v_add_u32 v53, %[stage], %[lane16]\n"
         "s_lshl_b32 s47, s43, 2\n"
@@ -507,6 +531,7 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "ds_read_b128 v[40:43], v53\n"
         "ds_read_b128 v[44:47], v53 offset:1024\n"
         "ds_read_b128 v[48:51], v53 offset:2048\n"
+        "ds_read_b128 v[64:67], v53 offset:3072\n"
         "v_cndmask_b32 v60, %[trash], v54, vcc\n"
         "v_add_u32 v58, 0x100, v58\n"
         "v_cmp_gt_u32 vcc, s45, v58\n"
@@ -515,17 +540,23 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "v_cndmask_b32 v61, %[trash], v54, vcc\n"
         "v_cmp_gt_u32 vcc, s45, v58\n"
         "v_add_u32 v54, 0x400, v54\n"
-        "s_lshl_b32 s47, s45, 2\n"
+        "v_add_u32 v58, 0x100, v58\n"
         "v_cndmask_b32 v62, %[trash], v54, vcc\n"
+        "v_cmp_gt_u32 vcc, s45, v58\n"
+        "v_add_u32 v54, 0x400, v54\n"
+        "s_lshl_b32 s47, s45, 2\n"
+        "v_cndmask_b32 v63, %[trash], v54, vcc\n"
         /* the 0..3 dwords that stay move to the front */
         "v_add_u32 v58, s47, %[l3]\n"
         "ds_read_b32 v58, v58\n"
-        "s_waitcnt lgkmcnt(3)\n"
+        "s_waitcnt lgkmcnt(4)\n"
         "global_store_dwordx4 v60, v[40:43], %[code]\n"
-        "s_waitcnt lgkmcnt(2)\n"
+        "s_waitcnt lgkmcnt(3)\n"
         "global_store_dwordx4 v61, v[44:47], %[code]\n"
-        "s_waitcnt lgkmcnt(1)\n"
+        "s_waitcnt lgkmcnt(2)\n"
         "global_store_dwordx4 v62, v[48:51], %[code]\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "global_store_dwordx4 v63, v[64:67], %[code]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "ds_write_b32 %[l3], v58\n"
         "s_add_u32 s43, s43, s45\n"
@@ -564,11 +595,11 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
           [lane] "v"((uint32_t)lane), [lane8] "v"(lane8), [lane16] "v"(lane16), [l3] "v"(l3), [trash] "v"(trash_off)
         : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
           "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
-          "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
+          "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67");
     return used;
 }
 #undef JIT_BATCH
-#undef JIT_BATCH_PATCH4
+#undef JIT_BATCH_PATCH
 
 /* Ask for the tape of a tile to be brought near (into the L2) long before it is translated: a tape is a linked
  * list of 64-word chunks and following it costs one trip to memory per chunk unless the chunks are already in the
@@ -647,25 +678,28 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "v_cmp_ne_u32 s[76:77], 0, v35\n v_cmp_ne_u32 s[78:79], 0, v36\n"                                   \
     "v_cmp_ne_u32 s[48:49], 0, v37\n v_cmp_ne_u32 s[50:51], 0, v38\n"                                   \
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
+    "v_mov_b32 v7, 0x2ff\n"                           /* class mask of the inline constant division */  \
     "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
     "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
     "v_mov_b32 %[res], v37\n"                                                                          \
     "s_branch L_end_%=\n"                                                                              \
-    /* v37 = v35 / v36 with v38 = RN(1 / v36) given: when every lane has 2^-60 <= |v35| <= 2^60 (and the translator  \
-     * made sure of 2^-30 <= |v36| <= 2^30) nothing over- or underflows on the way, and q = x y, two rounds of          \
-     * r = x - c q (exact, fused), q += r y end on the correctly rounded quotient — what the general sequence below      \
-     * computes with its own reciprocal; any other operand: that sequence */                                             \
+    /* The general case of a division by a constant (row 30 of the table: some lane's x * x is not a positive normal   \
+     * number).  x is in v35; the return address is that of the row's sixth dword, and the constant — negated — is the   \
+     * literal three dwords on.  v37 = x / c by the general sequence; back to the row's last instruction                   \
+     * (out = v39 * y + v37) with v39 = a zero whose sign times y's is the quotient's, so that a quotient of -0 stays -0.  \
+     * (The code was written a moment ago by this workgroup's translator: the scalar cache may hold the region's           \
+     * previous contents.) */                                                                                              \
     "L_divc_%=:\n"                                                                                     \
-    "v_and_b32 v39, 0x7fffffff, v35\n"                                                                 \
-    "v_add_u32 v39, 0xde800000, v39\n"                 /* |x| bits - 0x21800000 */                     \
-    "v_cmp_gt_u32 vcc, 0x3c000001, v39\n"              /* <= 0x5d800000 - 0x21800000 */                \
-    "s_cmp_eq_u64 vcc, exec\n"                                                                         \
-    "s_cbranch_scc0 L_div_%=\n"                                                                        \
-    "v_mul_f32 v37, v35, v38\n"                                                                        \
-    "v_fma_f32 v39, -v36, v37, v35\n"                                                                  \
-    "v_fma_f32 v37, v39, v38, v37\n"                                                                   \
-    "v_fma_f32 v39, -v36, v37, v35\n"                                                                  \
-    "v_fma_f32 v37, v39, v38, v37\n"                                                                   \
+    "s_dcache_inv\n"                                                                                   \
+    "s_load_dword s40, s[30:31], 0xc\n"                                                                \
+    "s_waitcnt lgkmcnt(0)\n"                                                                           \
+    "s_xor_b32 s40, s40, 0x80000000\n"                                                                 \
+    "v_mov_b32 v36, s40\n"                                                                             \
+    MPR_ASM_DIV_BODY                                                                                   \
+    "v_xor_b32 v39, v37, v36\n"                                                                        \
+    "v_and_b32 v39, 0x80000000, v39\n"                                                                 \
+    "s_add_u32 s30, s30, 32\n"                                                                         \
+    "s_addc_u32 s31, s31, 0\n"                                                                         \
     "s_setpc_b64 s[30:31]\n"                                                                           \
     "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[30:31]\n"                                            \
     "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[30:31]\n"                                          \

@@ -123,14 +123,16 @@ def test_deriv_ops_bit_exact(mpr, orc, opname, kind):
                                  1e-12, 1e12, 1.17549435e-38])
 def test_division_by_a_constant_in_generated_code(mpr, orc, imm):
     """kernels_voxel_jit.hip turns DIV_LHS_IMM by a constant with 2^-30 <= |c| <= 2^30 into q = x * RN(1/c) and two
-    rounds of r = x - c q, q += r * RN(1/c) when every lane's |x| is in [2^-60, 2^60], and falls back to the general
-    division otherwise: the quotient must be the IEEE one for every operand (variant 6 = generated code; the last
-    three constants are outside the range and take the general route)."""
+    rounds of r = x - c q, q += r * RN(1/c), inline, when every lane's x * x is a positive normal number
+    (2^-63 <= |x| < 2^64), and into the general division otherwise: the quotient must be the IEEE one for every operand
+    (variant 6 = generated code; the last three constants are outside the range and take the general route)."""
     op = mpr.OP["DIV_LHS_IMM"]
     rng = np.random.default_rng(zlib.crc32(repr(imm).encode()))
     n = 1 << 20
     cases = [
         (rng.standard_normal(n) * np.exp2(rng.uniform(-55, 55, n))).astype(np.float32),       # all lanes in range: the short route
+        (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.integers(-63, 63, n))).astype(np.float32),   # ... up to its edges
+        (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.choice([-63.0, -62.0, 62.0, 63.0], n))).astype(np.float32),
         rng.uniform(-4, 4, n).astype(np.float32),
         gen_floats(rng, 1 << 16, "wide"), gen_floats(rng, 1 << 16, "special"), gen_floats(rng, 1 << 16, "bits"),
         # around powers of two, where quotients sit next to rounding boundaries
