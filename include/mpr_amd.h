@@ -273,6 +273,11 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
                       float imm, float* out4);
 
+/* the dwords the device-side translator of the generated-code float pass makes of one clause (a host restatement of
+ * its template arithmetic; returns their number, -1 for a bad argument): table 0 / 1 = tile / group form; row = the
+ * opcode, 30 (division by a constant; its reciprocal literals are left zero) or 32.. (decisions 64..127) */
+int mpr_test_jit_row(int32_t table, int32_t row, uint32_t clause_lo, uint32_t imm_bits, int32_t choice, uint32_t* out, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,6 +184,7 @@ def lib():
     L.mpr_test_float_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
+    L.mpr_test_jit_row.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_uint32, i32, vp, i32]
     _LIB = L
     return L
 

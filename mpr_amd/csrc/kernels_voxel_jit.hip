@@ -1029,3 +1029,29 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
 }
 
 }  // namespace mprk
+
+/* What the translator makes of one clause (host restatement of its `dword = T + (T & mask) + base`, for the test that
+ * disassembles the rows): table 0 tile form, 1 group form; row = the opcode, 30 (division by a constant), or 32.. */
+extern "C" int mpr_test_jit_row(int32_t table, int32_t row, uint32_t clause_lo, uint32_t imm_bits, int32_t choice, uint32_t* out, int32_t cap)
+{
+    if (table < 0 || table > 1 || row < 0 || row >= mprk::JIT_ROWS || !out) return -1;
+    const uint32_t* const w = mprk::h_jit_table[table].w[row];
+    const int n = (int)(w[0] & 15u);
+    if (n > cap) return -1;
+    const uint32_t regs = ((clause_lo & 0xFFFFFF00u) + 0x30303000u) | ((128u + (uint32_t)choice) & 0xFFu);
+    for (int k = 0; k < n; ++k) {
+        const int at = 4 + 12 * (k / 4) + (k % 4);
+        const uint32_t base = w[at], sel = w[at + 4], mask = w[at + 8];
+        uint32_t T = 0;
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t s = (sel >> (8 * b)) & 0xFFu;
+            uint32_t byte = 0;
+            if (s < 4) byte = (regs >> (8 * s)) & 0xFFu;
+            else if (s < 8) byte = (imm_bits >> (8 * (s - 4))) & 0xFFu;
+            T |= byte << (8 * b);
+        }
+        out[k] = T + (T & mask) + base;
+    }
+    return n;
+}
+
