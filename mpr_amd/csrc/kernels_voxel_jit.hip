@@ -99,7 +99,7 @@ constexpr uint32_t CLASS_V39_V7 = 0x7C200F27u;                                 /
 constexpr uint32_t BRANCH_VCCZ_2 = 0xBF860002u;                                /* s_cbranch_vccz +2 dwords */
 constexpr uint32_t CLASS_NOT_POSITIVE_NORMAL = 0x2FFu;                         /* what v7 holds while generated code runs */
 constexpr uint32_t S_DIVC = 70, S_DIV = 52, S_SQRT = 54, S_EXP = 56, S_LOG = 58, S_SIN = 60, S_COS = 62, S_ASIN = 64, S_ACOS = 66, S_ATAN = 68;
-constexpr uint32_t FLAG_MINMAX = 1, FLAG_CANON = 2;
+constexpr uint32_t FLAG_MINMAX = 1;
 
 struct Builder {
     JitRow r{};
@@ -140,33 +140,31 @@ constexpr JitRow one(uint32_t base, uint32_t d, uint32_t s1, uint32_t s0, bool i
     if (imm) b.lit();
     return b.r;
 }
-/* min / max.  Tile form: the handlers' canonicalising v_max pair, then the operation.  Group form: the result goes
- * to v37 first, then `chose lhs` puts the lhs there instead and `chose rhs` the rhs (raw, as COPY_LHS / COPY_RHS /
- * COPY_IMM of the child's own tape would), and that lands in the out register. */
+/* min / max.  Generated code runs with MODE.IEEE off (jit_run), where v_min_f32 / v_max_f32 return the other operand for
+ * ANY NaN — fminf's rule, which the interpreters get by canonicalising both operands first (with IEEE on, a signalling
+ * NaN would win as a quiet one).  Tile form: the operation.  Group form: the result goes to v37 first, then `chose lhs`
+ * puts the lhs there instead and `chose rhs` the rhs (raw, as COPY_LHS / COPY_RHS / COPY_IMM of the child's own tape
+ * would), and that lands in the out register. */
 constexpr JitRow minmax(uint32_t op, bool imm, bool group, uint32_t q = 0)
 {
     Builder b;
     b.r.flags = FLAG_MINMAX;
-    b.ins(VOP2(V_MAX, 35, 0, VREG), NONE, A, A);
     if (!group) {
         if (imm) {
-            b.r.flags |= FLAG_CANON;
-            b.fixed(MOV(36, LITERAL));
+            b.ins(VOP2(op, 0, 0, LITERAL), O, A, NONE);
             b.lit();
         } else {
-            b.ins(VOP2(V_MAX, 36, 0, VREG), NONE, R, R);
+            b.ins(VOP2(op, 0, 0, VREG), O, R, A);
         }
-        b.ins(VOP2(op, 0, 36, VREG + 35), O);
         return b.r;
     }
     if (imm) {
         b.fixed(MOV(38, LITERAL));
         b.lit();
-        b.fixed(VOP2(V_MAX, 36, 38, VREG + 38));
+        b.ins(VOP2(op, 37, 38, VREG), NONE, NONE, A);
     } else {
-        b.ins(VOP2(V_MAX, 36, 0, VREG), NONE, R, R);
+        b.ins(VOP2(op, 37, 0, VREG), NONE, R, A);
     }
-    b.fixed(VOP2(op, 37, 36, VREG + 35));
     b.bitcmp(q ? BITCMP_L1 : BITCMP_L);
     b.fixed(CSELECT);
     b.ins(VOP2(V_CNDMASK, 37, 0, VREG + 37), NONE, A);                 /* v37 = chose lhs ? lhs : v37 */
@@ -450,13 +448,10 @@ DEV uint32_t jit_translate(const uint64_t* __restrict__ tro, uint32_t first, uin
         "ds_read_b32 v39, v38\n"                           /* meta: dwords | flags << 8 */
         "v_and_b32 v56, 0xffffff00, v34\n"
         "v_add_u32 v56, 0x30303000, v56\n"                 /* registers: 48 + out / lhs / rhs in bytes 1..3 */
-        "v_max_f32 v57, v35, v35\n"                        /* the immediate as the min / max handlers see it */
+        "v_mov_b32 v57, v35\n"                             /* the literal of this clause */
         "s_waitcnt lgkmcnt(0)\n"
-        "v_and_b32 v58, 0x200, v39\n"
-        "v_cmp_ne_u32 vcc, 0, v58\n"
         "v_and_b32 v59, 15, v39\n"
         "v_and_b32 v58, 0x100, v39\n"
-        "v_cndmask_b32 v57, v35, v57, vcc\n"               /* the literal of this clause */
         "v_cmp_gt_u32 vcc, s46, %[lane]\n"                 /* clauses in front of the terminator */
         "v_cmp_ne_u32 s[64:65], 0, v58\n"                  /* min / max clauses */
         "s_and_b64 s[64:65], s[64:65], vcc\n"
@@ -680,7 +675,9 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
     "v_mov_b32 v7, 0x2ff\n"                           /* class mask of the inline constant division */  \
     "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
+    "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0\n" /* MODE.IEEE off while generated code runs (see jt::minmax) */ \
     "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
+    "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 1\n"                                                 \
     "v_mov_b32 %[res], v37\n"                                                                          \
     "s_branch L_end_%=\n"                                                                              \
     /* The general case of a division by a constant (row 30 of the table: some lane's x * x is not a positive normal   \
