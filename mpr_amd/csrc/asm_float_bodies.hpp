@@ -68,8 +68,9 @@
 
 #define MPR_ASM_EXP_BODY \
     "v_mul_f32 v38, 0x3fb8aa3b, v35\n" \
-    "v_add_f32 v38, 0x4b400000, v38\n" \
-    "v_add_f32 v38, 0xcb400000, v38\n"              /* kf = round(x / ln 2) */ \
+    /* kf = (t + 1.5 * 2^23) - 1.5 * 2^23 in the C++ definition: t rounded to the nearest integer, ties to even, as long as \
+     * |t| < 2^22 — and a larger |t| is an |x| whose result the special cases below replace */ \
+    "v_rndne_f32 v38, v38\n" \
     "v_fmamk_f32 v39, v38, 0xbf318000, v35\n" \
     "v_fmamk_f32 v39, v38, 0x395e8083, v39\n"       /* r */ \
     "v_mov_b32 v40, 0x3ab743ce\n" \
