@@ -11,16 +11,21 @@ With N > 1 the top-level tile columns of the SAME frame are dealt to the N ranks
 image is all-gathered over RCCL (strong scaling; mpr_amd/multigpu.py).
 
 Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant kernel (eval_voxels_f): algorithmic bytes / HIP-event duration vs 8 TB/s; the
-                kernel's VALU / scalar / LDS issue fractions (its real limiter) from the committed
-                counter passes; the frame-level B_alg of SURVEY.md 8(d)
-  cpu_baseline  the CPU oracle (a port, not the reference): all host cores at 512^3 and one core at
-                256^3, warm-up + 3 frames each, beside the GPU's time at the same size; the oracle's
-                frame must equal the GPU's
-  full_frames   the same frame when every frame pushes the last tile stage's tapes (the first frame of a
-                tape or view; the timed frames repeat one view and do not need them)
+  roofline      dominant kernel (eval_voxels_f).  The kernel is VALU-issue-bound, so the primary figure is
+                bound = "valu": VALU wave-instructions per launch (SQ counters, committed passes of this command) over the
+                HIP-event duration, against 2.0 wave-instr/clk/CU x 2.4 GHz x 256 CUs (MI355X_MICROARCH.md) and against
+                the rate measured on this chip (profiles/r03a_issue_rates3.txt: it sustains ~2.1-2.2 GHz under VALU load),
+                plus a rate-weighted fraction (half- and quarter-rate instructions at their own ceilings).  The HBM figure
+                north_star asks for rides in roofline.hbm (algorithmic bytes / duration vs 8 TB/s) with `traffic`; the
+                frame-level B_alg of SURVEY.md 8(d) in roofline.frame
+  cpu_baseline  the CPU oracle (a port, not the reference) AT THE BENCH CONFIGURATION: all host cores, 1 warm-up + 3 frames,
+                and one core on the columns a 16-way deal of the same frame gives rank 0; the oracle's frame must equal the GPU's
+  full_frames   the same frame rendered the reference's way throughout (every tile stage evaluated and pushed; what a reader
+                of tiles / tapes makes the context do), and first_frames: the first frame of a tape the context has not seen
   also          the reference's other headline config (prospero render2D 1024^2), for which
                 BASELINE.md holds the only published number (V100, 3.856 ms/frame)
+
+    python bench.py --all [--out profiles/r03_records.jsonl]     one JSON record per model x size
 """
 import argparse
 import json
@@ -35,11 +40,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 V100_PROSPERO_1024_MS = 3.85596     # BASELINE.md / reference README.md:111
-# issue rates measured on this chip, wave-instructions per clock per CU at the nominal 2.4 GHz
-# (profiles/r02a_issue_rates.txt, scripts/ubench/issue_rates2.hip): v_fma_f32 / v_add_f32 chains, s_add_u32, ds_read_b32
-VALU_RATE, SALU_RATE, LDS_RATE = 1.75, 0.96, 0.48
+# VALU issue ceilings, wave-instructions per second for the chip:
+#  guide: a wave64 VALU op is two passes of a 32-lane SIMD, 4 SIMDs per CU -> 2.0 / clk / CU at the nominal 2.4 GHz (MI355X_MICROARCH.md)
+#  measured (scripts/ubench/issue_rates3.hip -> profiles/r03a_issue_rates3.txt, 8 waves/SIMD, independent chains, s_setprio):
+#  v_add / v_mul 4.18-4.27, v_fma 3.69, v_mov 4.51 wave-instr/ns/CU — the same 2.0 / clk at the 2.1-2.2 GHz the chip sustains
+#  under VALU load (round 2's "1.75 / clk" was this rate divided by the nominal clock); half-rate classes ~half of it, v_exp /
+#  v_rcp / v_sqrt 0.49 / clk at nominal = 1.18 / ns / CU
 ISSUE_CLOCK_HZ, ISSUE_CUS = 2.4e9, 256
-
+VALU_GUIDE_PER_CLK = 2.0
+VALU_MEASURED_PER_NS, VALU_HALF_PER_NS, VALU_QUARTER_PER_NS = 4.2, 2.1, 1.18
+SALU_PER_NS, LDS_PER_NS = 0.96 * 2.4, 0.48 * 2.4        # profiles/r02a_issue_rates.txt (per nominal clock)
 
 def view3():
     T = np.eye(4, dtype=np.float32)
@@ -69,6 +79,203 @@ def time_frames(fn, warmup, steps, barrier, sync):
     return total, per
 
 
+def frame_b_alg(work, S, dim=3):
+    """B_alg = 8(F + R) + 8W + 12(T_in + T_out) + 4(I_w + I_r); returns (bytes, terms)"""
+    nst = 3 if dim == 3 else 2
+    t_in = sum(work["tiles_in"][:nst]) + work["voxel_tiles"]
+    t_out = 64 * sum(work["tiles_active"][:nst - 1]) + work["tiles_active"][nst - 1]
+    levels = sum((S // px) ** 2 for px in ((64, 16, 4) if dim == 3 else (64, 8)))
+    i_w = (2 if dim == 3 else 1) * S * S + levels        # heights (+ normals) + the level images
+    i_r = (2 if dim == 3 else 1) * S * S                 # copy_filled (+ the normals pass)
+    b = 8 * (work["clauses_fwd"] + work["clauses_bwd"]) + 8 * work["clauses_written"] + 12 * (t_in + t_out) + 4 * (i_w + i_r)
+    return b, {"F": int(work["clauses_fwd"]), "R": int(work["clauses_bwd"]), "W": int(work["clauses_written"]),
+               "T_in": int(t_in), "T_out": int(t_out), "I_w": int(i_w), "I_r": int(i_r)}
+
+
+def roofline_of(work, S, vox_ms, kname, avg, ms_per_step, world, model):
+    if not (vox_ms > 0 and work["clauses_fwd_voxels"]):
+        return None
+    # algorithmic bytes per launch (DESIGN.md 5): one 8-byte clause per wave-group visit (group = the 64 voxels of one
+    # smallest tile, SURVEY.md 8(d)) + the 12-byte tile record of every smallest tile.  N > 1: rank 0's columns and kernel time
+    b_alg = 8 * work["clauses_fwd_voxels"] + 12 * work["voxel_tiles"]
+    b_frame, terms = frame_b_alg(work, S)
+    dur = vox_ms * 1e-3
+    hbm_achieved = b_alg / dur / 1e9
+    traffic = traffic_source = sq = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if world == 1 and os.path.exists(pmc):         # the counter passes were collected on the full single-GPU frame
+        try:
+            with open(pmc) as f:
+                summ = json.load(f)
+            rec = summ.get("eval_voxels_f", {})
+            if rec.get("kernel") == kname:          # counters of another kernel say nothing about this one
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_summary.json: " + summ.get("_source", "?") + " (separate rocprofv3 --pmc passes of this command, not this run)"
+                sq = rec.get("sq")
+        except Exception:
+            traffic = traffic_source = sq = None
+    hbm = {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(b_alg),
+           "note": "the framing north_star asks for; the kernel reads one tape per 64 tiles and keeps slots in registers, so its "
+                   "real traffic (`traffic`) is a fraction of the algorithmic bytes and HBM is not what bounds it"}
+    frame_s = ms_per_step * 1e-3
+    common = {"traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(vox_ms, 4),
+              "kernel_ms_all": {k: round(v, 4) for k, v in avg.items()},
+              "frame": {"algorithmic_bytes": int(b_frame), "achieved": round(b_frame / frame_s / 1e9, 2),
+                        "frac": round(b_frame / frame_s / 1e9 / HBM_PEAK_GBS, 5), "terms": terms},
+              "lane_clauses_per_frame": int(work["lane_clauses"])}
+    name = kname + (" (rank 0 of %d)" % world if world > 1 else "")
+    if not sq or not sq.get("SQ_INSTS_VALU"):
+        out = {"kernel": name}
+        out.update({k: hbm[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes")})
+        out["limiter"] = "valu issue (no committed SQ counters for this kernel: profiles/pmc_summary.json)"
+        out.update(common)
+        return out
+    valu = float(sq["SQ_INSTS_VALU"])
+    guide_peak = VALU_GUIDE_PER_CLK * ISSUE_CLOCK_HZ * ISSUE_CUS / 1e9            # G wave-instr / s
+    measured_peak = VALU_MEASURED_PER_NS * ISSUE_CUS
+    achieved = valu / dur / 1e9
+    out = {"kernel": name, "bound": "valu", "achieved": round(achieved, 2), "peak": round(guide_peak, 1), "unit": "Gwave-instr/s",
+           "frac": round(achieved / guide_peak, 4),
+           "peak_source": "MI355X_MICROARCH.md: wave64 VALU op = 2 passes of a SIMD-32, 4 SIMDs/CU -> 2.0 wave-instr/clk/CU x 2.4 GHz x 256 CUs",
+           "valu_per_launch": valu,
+           "measured_ceiling": {"peak": round(measured_peak, 1), "frac": round(achieved / measured_peak, 4),
+                                "source": "profiles/r03a_issue_rates3.txt: v_add/v_mul 4.2 wave-instr/ns/CU at 8 waves/SIMD = 2.0/clk at the "
+                                          "2.1-2.2 GHz the chip sustains under VALU load"}}
+    mixp = os.path.join(ROOT, "profiles", "valu_mix.json")
+    if os.path.exists(mixp):
+        try:
+            with open(mixp) as f:
+                mix = json.load(f)
+            m = mix.get(kname.split("<")[0], {}).get(model)
+            if m:
+                # the instruction stream's classes (scripts/valu_mix.py: generated-code templates + routines x the tape's opcode
+                # histogram) scaled to the measured total; each class against its own measured ceiling
+                t_issue = valu * (m["full"] / VALU_MEASURED_PER_NS + m["half"] / VALU_HALF_PER_NS + m["quarter"] / VALU_QUARTER_PER_NS) / ISSUE_CUS * 1e-9
+                out["rate_weighted"] = {"frac": round(t_issue / dur, 4), "mix": m,
+                                        "ceilings_per_ns_per_cu": {"full": VALU_MEASURED_PER_NS, "half": VALU_HALF_PER_NS, "quarter": VALU_QUARTER_PER_NS},
+                                        "source": "profiles/valu_mix.json (scripts/valu_mix.py)"}
+        except Exception:
+            pass
+    out["other_units"] = {"salu_frac": round(sq.get("SQ_INSTS_SALU", 0) / dur / (SALU_PER_NS * ISSUE_CUS * 1e9), 4),
+                          "lds_frac": round(sq.get("SQ_INSTS_LDS", 0) / dur / (LDS_PER_NS * ISSUE_CUS * 1e9), 4),
+                          "busy_cu_clock_ghz": round(sq.get("SQ_BUSY_CU_CYCLES", 0) / ISSUE_CUS / dur / 1e9, 3) if sq.get("SQ_BUSY_CU_CYCLES") else None}
+    out["hbm"] = hbm
+    out.update(common)
+    return out
+
+
+def cpu_baseline(m, tape, model, S, T, ctx, frames=3, dim=3, one_core_parts=16):
+    """Times oracle/mpr_oracle.c on the GPU's own workload.  ctx holds the GPU's frame of (tape, T) at S."""
+    from oracle import orc
+    from mpr_amd.multigpu import column_weights
+    orc.lib()
+    cores = os.cpu_count() or 1
+    mat = m.colmajor(T, dim + 1)
+    gimg = ctx.image.copy()
+    gnrm = ctx.normals.copy() if dim == 3 else None
+    t1 = time.perf_counter()
+    fr = orc.Frame(tape.data, dim, S, mat, threads=cores, keep_pool=False)          # warm-up, and the checker
+    warm_s = time.perf_counter() - t1
+    same = bool(np.array_equal(fr.filled[3], gimg) and (dim == 2 or np.array_equal(fr.normals, gnrm)))
+    del fr
+    per_cpu = []
+    for _ in range(frames if warm_s < 30 else 1):
+        t1 = time.perf_counter()
+        orc.Frame(tape.data, dim, S, mat, threads=cores, keep_pool=False, skip_normals=False)
+        per_cpu.append((time.perf_counter() - t1) * 1e3)
+    cm, csd = stats(per_cpu)
+    rec = {"value": round(S * S / (cm * 1e-3) / 1e6, 4), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+           "ms_per_frame": round(cm, 1), "ms_per_frame_std": round(csd, 1), "frames": len(per_cpu), "warmup": 1,
+           "frame_matches_gpu": same,
+           "sample": "%s.frep render%dD at %d^%d — the bench configuration itself, whole frame — oracle/mpr_oracle.c, OpenMP over tile groups, %d threads"
+                     % (model, dim, S, dim, cores)}
+    # one core: the columns rank 0 gets when the frame's 64x64 columns are dealt 16 ways by measured work (the multi-GPU deal)
+    w = column_weights(ctx.stages[3].tiles, S, dim)
+    owner = m.partition_columns((S // 64) ** 2, one_core_parts, w)
+    share = float(w[owner == 0].sum() / max(w.sum(), 1.0))
+    t1 = time.perf_counter()
+    orc.Frame(tape.data, dim, S, mat, threads=1, owner=owner, rank=0, keep_pool=False)
+    one_ms = (time.perf_counter() - t1) * 1e3
+    rec["one_core"] = {"cores": 1, "kind": "port", "ms_sample": round(one_ms, 1), "share_of_frame": round(share, 4),
+                       "ms_per_frame_extrapolated": round(one_ms / max(share, 1e-9), 1),
+                       "value": round(S * S / (one_ms / max(share, 1e-9) * 1e-3) / 1e6, 4), "unit": "Mpixel/s", "frames": 1, "warmup": 0,
+                       "sample": "%s.frep render%dD at %d^%d, the %d of %d top-level columns that a %d-way longest-processing-time deal gives "
+                                 "rank 0 (%.1f %% of the frame's smallest tiles), one thread, one frame"
+                                 % (model, dim, S, dim, int((owner == 0).sum()), owner.size, one_core_parts, 100 * share)}
+    return rec
+
+
+ALL_CONFIGS = [  # (model, dim, size, cpu legs?)   BASELINE.json configs first, then the reference's table sizes
+    ("prospero", 2, 1024, True), ("involute_gear_2d", 2, 4096, True), ("bear", 3, 1024, True), ("architecture", 3, 2048, True),
+    ("prospero", 2, 256, True), ("prospero", 2, 512, True), ("prospero", 2, 2048, False), ("prospero", 2, 4096, False),
+    ("involute_gear_2d", 2, 1024, False), ("hello_world", 2, 1024, False),
+    ("bear", 3, 256, True), ("bear", 3, 512, True), ("bear", 3, 2048, False),
+    ("architecture", 3, 512, False), ("architecture", 3, 1024, False), ("involute_gear_3d", 3, 1024, False),
+]
+
+
+def run_all(args):
+    """One JSON record per model x size with the fields of BASELINE.md 4 (benchmark/render_2d_table.cpp:50-62 prints
+    `size mean stdev`; so does this, on stderr)."""
+    import torch
+    import mpr_amd as m
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X")
+    m.build()
+    records = []
+    for model, dim, S, with_cpu in ALL_CONFIGS:
+        tape = m.Tape(m.model(model))
+        T = view3() if dim == 3 else np.eye(3, dtype=np.float32)
+        render = (lambda c: c.render3D(tape, T)) if dim == 3 else (lambda c: c.render2D(tape, T))
+        cctx = m.Context(S, flags=m.CTX_COUNTERS | m.CTX_SERIAL_STAGES)
+        render(cctx)
+        work = cctx.counters()
+        cctx.close()
+        ctx = m.Context(S, flags=m.CTX_TIMING)
+        render(ctx)
+        kname = ctx.float_kernel()
+        t1 = time.perf_counter()
+        render(ctx)
+        one = time.perf_counter() - t1
+        steps = 100 if one < 0.05 else 20
+        kernel_ms = {}
+        per = []
+        for _ in range(20 if one < 0.05 else 3):
+            render(ctx)
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            render(ctx)
+            per.append((time.perf_counter() - t1) * 1e3)
+            for name, ms in ctx.timings():
+                kernel_ms[name] = kernel_ms.get(name, 0.0) + ms / steps
+        mean, std = stats(per)
+        b_frame, terms = frame_b_alg(work, S, dim)
+        rec = {"model": model, "dim": dim, "size": S, "gpus": 1, "ms_mean": round(mean, 4), "ms_std": round(std, 4),
+               "mpixel_per_s": round(S * S / (mean * 1e-3) / 1e6, 2), "B_alg_bytes": int(b_frame), "B_alg_terms": terms,
+               "roofline_hbm": round(b_frame / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+               "roofline_lds": None, "roofline_valu": None,
+               "roofline_note": "roofline_hbm = B_alg / frame time / 8 TB/s (SURVEY.md 8(d)); VALU / LDS fractions need the SQ counter passes, "
+                                "collected for the bench configuration only (bench line: roofline)",
+               "float_kernel": kname, "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+               "voxel_tiles": int(work["voxel_tiles"]), "lane_clauses": int(work["lane_clauses"]),
+               "cpu_ms_allcores": None, "cpu_cores": os.cpu_count() or 1, "cpu_ms_1core": None}
+        if with_cpu and not args.no_cpu:
+            cb = cpu_baseline(m, tape, model, S, T, ctx, frames=3, dim=dim)
+            rec["cpu_ms_allcores"] = cb["ms_per_frame"]
+            rec["cpu_ms_1core"] = cb["one_core"]["ms_per_frame_extrapolated"]
+            rec["cpu_1core_sample"] = cb["one_core"]["sample"]
+            rec["cpu_frame_matches_gpu"] = cb["frame_matches_gpu"]
+        ctx.close()
+        sys.stderr.write("%s %dD: %d %.4f %.4f\n" % (model, dim, S, mean, std))
+        print(json.dumps(rec), flush=True)
+        records.append(rec)
+    if args.out:
+        with open(args.out, "w") as f:
+            for r in records:
+                f.write(json.dumps(r) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,7 +285,11 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the prospero 2-D side measurement")
+    ap.add_argument("--all", action="store_true", help="one JSON record per model x size (BASELINE.md 4) instead of the bench line")
+    ap.add_argument("--out", default=None, help="--all: also write the records to this file")
     args = ap.parse_args()
+    if args.all:
+        return run_all(args)
 
     import torch
     import mpr_amd as m
@@ -118,7 +329,7 @@ def main():
     T = view3()
 
     # ---- instrumented frame (counters on): algorithmic work of the dominant kernel ----
-    cctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS)
+    cctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS | m.CTX_SERIAL_STAGES)
     cctx.render3D(tape, T)
     work = cctx.counters()
     cctx.close()
@@ -146,7 +357,7 @@ def main():
         tpr = TileParallelRenderer(ctx, m, rank, world, make_buffer, all_gather, dim=3)
         tpr.plan(tape, T)
         # this rank's share of the dominant kernel's algorithmic work: an instrumented frame of its columns
-        pctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS)
+        pctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS | m.CTX_SERIAL_STAGES)
         pctx.render3D_part(tape, T, tpr.owner, rank)
         work = pctx.counters()
         pctx.close()
@@ -200,60 +411,7 @@ def main():
     avg = {k: v / nframes for k, v in kernel_ms.items()}
     vox_ms = avg.get("eval_voxels_f", 0.0)
     kname = ctx.float_kernel()
-    # algorithmic bytes per launch: one 8-byte clause per wave-group visit (group = the 64
-    # voxels of one smallest tile) + the 12-byte tile record of every smallest tile
-    b_alg = 8 * work["clauses_fwd_voxels"] + 12 * work["voxel_tiles"]      # N > 1: rank 0's columns, rank 0's kernel time
-    # ... and of the whole frame: B_alg = 8(F + R) + 8W + 12(T_in + T_out) + 4(I_w + I_r), SURVEY.md 8(d)
-    t_in = sum(work["tiles_in"]) + work["voxel_tiles"]
-    t_out = 64 * sum(work["tiles_active"][:2]) + work["tiles_active"][2]
-    levels = sum((S // px) ** 2 for px in (64, 16, 4))
-    i_w = 2 * S * S + levels            # heights + normals + the level images
-    i_r = 2 * S * S                     # copy_filled + the normals pass
-    b_frame = 8 * (work["clauses_fwd"] + work["clauses_bwd"]) + 8 * work["clauses_written"] + 12 * (t_in + t_out) + 4 * (i_w + i_r)
-    roofline = None
-    if vox_ms > 0 and b_alg:
-        achieved = b_alg / (vox_ms * 1e-3) / 1e9
-        traffic = traffic_source = issue = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if world == 1 and os.path.exists(pmc):         # the counter passes were collected on the full single-GPU frame
-            try:
-                with open(pmc) as f:
-                    summ = json.load(f)
-                rec = summ.get("eval_voxels_f", {})
-                if rec.get("kernel") == kname:          # counters of another kernel say nothing about this one
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/pmc_summary.json: " + summ.get("_source", "?") + " (separate rocprofv3 --pmc passes of this command, not this run)"
-                    sq = rec.get("sq")
-                    if sq:
-                        # fractions of the issue rates measured on this chip (profiles/r02a_issue_rates.txt): wave-instructions
-                        # per second = rate per clock per CU x 2.4 GHz x CUs
-                        dur = vox_ms * 1e-3
-                        peak = lambda r: r * ISSUE_CLOCK_HZ * ISSUE_CUS
-                        issue = {"valu_per_launch": sq.get("SQ_INSTS_VALU"), "salu_per_launch": sq.get("SQ_INSTS_SALU"),
-                                 "lds_per_launch": sq.get("SQ_INSTS_LDS"),
-                                 "valu_frac": round(sq.get("SQ_INSTS_VALU", 0) / dur / peak(VALU_RATE), 4),
-                                 "salu_frac": round(sq.get("SQ_INSTS_SALU", 0) / dur / peak(SALU_RATE), 4),
-                                 "lds_frac": round(sq.get("SQ_INSTS_LDS", 0) / dur / peak(LDS_RATE), 4),
-                                 "rates_per_clk_per_cu": {"valu": VALU_RATE, "salu": SALU_RATE, "lds": LDS_RATE},
-                                 "clock_ghz": ISSUE_CLOCK_HZ / 1e9, "cus": ISSUE_CUS,
-                                 "busy_cu_clock_ghz": round(sq.get("SQ_BUSY_CU_CYCLES", 0) / ISSUE_CUS / dur / 1e9, 3) if sq.get("SQ_BUSY_CU_CYCLES") else None,
-                                 "source": traffic_source}
-            except Exception:
-                traffic = traffic_source = issue = None
-        frame_s = ms_per_step * 1e-3
-        roofline = {"kernel": kname + (" (rank 0 of %d)" % world if world > 1 else ""), "bound": "hbm",
-                    "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "algorithmic_bytes": int(b_alg), "kernel_ms": round(vox_ms, 4),
-                    "limiter": "valu issue (see issue.valu_frac)" if issue else "valu issue",
-                    "issue": issue,
-                    "kernel_ms_all": {k: round(v, 4) for k, v in avg.items()},
-                    "frame": {"algorithmic_bytes": int(b_frame), "achieved": round(b_frame / frame_s / 1e9, 2),
-                              "frac": round(b_frame / frame_s / 1e9 / HBM_PEAK_GBS, 5),
-                              "terms": {"F": int(work["clauses_fwd"]), "R": int(work["clauses_bwd"]), "W": int(work["clauses_written"]),
-                                        "T_in": int(t_in), "T_out": int(t_out), "I_w": int(i_w), "I_r": int(i_r)}},
-                    "lane_clauses_per_frame": int(work["lane_clauses"])}
+    roofline = roofline_of(work, S, vox_ms, kname, avg, ms_per_step, world, args.model)
 
     out = None
     if rank == 0:
@@ -281,8 +439,8 @@ def main():
         if verified is not None:
             out["verified_against_single_gpu"] = verified
 
-    # ---- the same frame when every frame pushes the last tile stage's tapes (what the FIRST frame of a tape / view costs:
-    #      repeated frames do not need those tapes, DESIGN.md 3 "Frames whose last tile stage pushes no tapes") ----
+    # ---- the same frame the reference's way throughout (every tile stage evaluated from the 64^3 tiles down, every tape pushed:
+    #      the state a reader of tiles / tapes asks for), and the FIRST frame of a tape the context has not seen ----
     if rank == 0 and world == 1:
         os.environ["MPR_LAST_STAGE_PUSH"] = "1"
         fctx = m.Context(S, device=local_rank)
@@ -293,8 +451,18 @@ def main():
         fctx.close()
         out["full_frames"] = {"ms_per_frame_mean": round(fm, 4), "ms_per_frame_std": round(fs, 4),
                               "value": round(S * S / (fm * 1e-3) / 1e6, 3), "unit": "Mpixel/s", "same_images": same,
-                              "note": "every frame pushes the last tile stage's tapes (MPR_LAST_STAGE_PUSH=1): the cost of the first "
-                                      "frame of a tape or view; the timed frames above repeat one view, as benchmark/stats.cpp does"}
+                              "note": "MPR_LAST_STAGE_PUSH=1: every frame leaves the reference's tiles and tapes behind (what a frame costs "
+                                      "when they are read back); images identical to the timed frames"}
+        fresh = [m.Tape(m.model(args.model)) for _ in range(min(args.steps, 12))]      # new tapes: nothing the context has learned applies
+        first = []
+        for ft in fresh:
+            sync()
+            t1 = time.perf_counter()
+            ctx.render3D(ft, T)
+            first.append((time.perf_counter() - t1) * 1e3)
+        f1, f1s = stats(first[2:] if len(first) > 4 else first)
+        out["first_frames"] = {"ms_per_frame_mean": round(f1, 4), "ms_per_frame_std": round(f1s, 4), "frames": len(first),
+                               "note": "render3D of a tape object the context sees for the first time (includes the tape's upload)"}
 
     # ---- side measurement: prospero render2D 1024^2 (the published V100 number's config) ----
     if rank == 0 and world == 1 and not args.no_also:
@@ -308,44 +476,12 @@ def main():
                         "unit": "Mpixel/s", "vs_baseline": round(V100_PROSPERO_1024_MS / pm, 3),
                         "baseline": "3.85596 ms/frame on 1x V100 (reference README.md:111)"}]
 
-    # ---- CPU baseline: the oracle (a port of the algorithm, NOT libfive's renderer), as the checker of two
-    #      smaller frames of the same model and as the timed CPU leg: one core, and all cores ----
+    # ---- CPU baseline: the oracle (a port of the algorithm, NOT libfive's renderer) at the bench configuration itself: all host
+    #      cores on the whole frame (1 warm-up + 3 timed, the 750 ms rule of benchmark/render_3d_table.cpp:71 in spirit), one core on
+    #      the columns a 16-way deal of the same frame gives rank 0.  The oracle's frame must equal the GPU's. ----
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import orc
-        orc.lib()
-        cores = os.cpu_count() or 1
-        legs = []
-        for cs, threads_list, frames in ((min(S, 256), [1], 3), (min(S, 512), sorted({cores, min(cores, 32)}), 3)):
-            gctx = m.Context(cs, device=local_rank)
-            _, gper = time_frames(lambda: gctx.render3D(tape, T), 5, 20, lambda: None, sync)
-            gpu_ms, _ = stats(gper)
-            gimg, gnrm = gctx.image.copy(), gctx.normals.copy()
-            gctx.close()
-            # warm-up frame per thread count (also picks the better count when there are two), then `frames` timed ones
-            best = None
-            for th in threads_list:
-                t1 = time.perf_counter()
-                fr = orc.Frame(tape.data, 3, cs, m.colmajor(T, 4), threads=th, keep_pool=False)
-                dt = time.perf_counter() - t1
-                if best is None or dt < best[1]:
-                    best = (th, dt)
-            same = bool(np.array_equal(fr.filled[3], gimg) and np.array_equal(fr.normals, gnrm))
-            th = best[0]
-            per_cpu = []
-            for _ in range(frames):
-                t1 = time.perf_counter()
-                orc.Frame(tape.data, 3, cs, m.colmajor(T, 4), threads=th, keep_pool=False)
-                per_cpu.append((time.perf_counter() - t1) * 1e3)
-            cm, csd = stats(per_cpu)
-            legs.append({"value": round(cs * cs / (cm * 1e-3) / 1e6, 4), "unit": "Mpixel/s", "cores": th, "kind": "port",
-                         "ms_per_frame": round(cm, 1), "ms_per_frame_std": round(csd, 1), "frames": frames, "warmup": len(threads_list),
-                         "gpu_ms_per_frame_same_size": round(gpu_ms, 4), "gpu_over_cpu": round(cm / gpu_ms, 1),
-                         "frame_matches_gpu": same,
-                         "sample": "%s.frep render3D at %d^3 (1/%d of the voxels of the GPU workload), oracle/mpr_oracle.c%s" %
-                                   (args.model, cs, (S // cs) ** 3, " with OpenMP over tile groups" if th > 1 else ", one thread")})
-        out["cpu_baseline"] = dict(legs[-1])
-        out["cpu_baseline"]["one_core"] = legs[0]
-        if not all(l["frame_matches_gpu"] for l in legs):
+        out["cpu_baseline"] = cpu_baseline(m, tape, args.model, S, T, ctx, frames=3)
+        if not out["cpu_baseline"]["frame_matches_gpu"]:
             raise SystemExit("bench.py: the oracle's frame differs from the GPU's: " + json.dumps(out["cpu_baseline"]))
     ctx.close()
     if rank == 0:

@@ -158,6 +158,9 @@ private:
 };
 
 struct Tape {
+    /* Unlike the reference's constructor (src/tape.cpp:79-81, :106, :195: a warning on stderr, then a tape that evaluates
+     * something else), this one THROWS std::runtime_error for an expression that needs more than 254 live values at once
+     * or names an opcode the evaluators lack: a main written against the reference may want a try block. */
     explicit Tape(const libfive::Tree& tree)
     {
         mpr_tape* t = nullptr;

@@ -90,8 +90,9 @@ int32_t mpr_tape_length(const mpr_tape* t);            /* mpr::Tape::length */
 const uint64_t* mpr_tape_data(const mpr_tape* t);      /* mpr::Tape::data (host copy) */
 int32_t mpr_tape_num_slots(const mpr_tape* t);         /* highest slot index + 1 */
 int32_t mpr_tape_num_choices(const mpr_tape* t);       /* number of min/max clauses */
-int32_t mpr_tape_flags(const mpr_tape* t);             /* bit0: slots exhausted (src/tape.cpp:79-81),
-                                                          bit1: unsupported opcodes (:182-196) */
+int32_t mpr_tape_flags(const mpr_tape* t);             /* bit1: unsupported opcodes (src/tape.cpp:182-196).  Bit0 is never set:
+                                                          where the reference prints "Ran out of slots!" and renders with slot 0
+                                                          (:79-81), mpr_tape_from_tree fails with MPR_ERR_UNSUPPORTED */
 void mpr_tape_free(mpr_tape* t);
 
 /* ---- context (mpr::Context, inc/context.hpp:38-73, src/context.cpp:17-49) ---- */
@@ -108,6 +109,10 @@ typedef struct mpr_ctx_options {
 #define MPR_CTX_TIMING 1       /* record HIP events around every kernel (mpr_get_timings) */
 #define MPR_CTX_COUNTERS 2     /* accumulate the work counters of mpr_get_counters on the device
                                   (costs a few atomics per wave: keep off when timing) */
+#define MPR_CTX_SERIAL_STAGES 4 /* tile stages always by the 64-tiles-per-wavefront kernels, never level-parallel: with
+                                  MPR_CTX_COUNTERS the clause counters are then the implementation-independent figures of
+                                  SURVEY.md 8(d) (F / R per group of 64 list entries; the level-parallel kernel has no such
+                                  groups and reports its own clause counts) */
 
 int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out);
 int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out);
@@ -199,7 +204,7 @@ typedef struct mpr_counters {
     int64_t clauses_written;    /* W: words written to the pool by tape pushes */
     int64_t clauses_fwd_voxels; /*    part of F spent in the float voxel/pixel pass */
     int64_t clauses_fwd_normals;/*    part of F spent in the normals pass */
-    int64_t lane_clauses;       /* lane-granular clause evaluations */
+    int64_t lane_clauses;       /* words visited forward, terminator excluded, per tile / visible voxel / pixel */
     int64_t normal_pixels;      /* pixels evaluated by the normals pass */
     int32_t tape_index;         /* pool words in use after the frame */
     int32_t pool_overflowed;    /* a push ran out of pool and fell back (src/context.cu:336-347) */

@@ -1,7 +1,8 @@
 /*
  * mpr_effects_math.h — per-pixel arithmetic of mpr::Effects (reference src/effects.cu:17-209:
- * draw_ssao, blur_ssao, draw_shaded), one definition compiled (without FMA contraction) into the
- * HIP kernels of libmpr_amd and into the oracle, like mpr_fmath.h.
+ * draw_ssao, blur_ssao, draw_shaded), compiled (without FMA contraction) into the HIP kernels of
+ * libmpr_amd.  Product code only: the oracle checks it with a restatement of its own
+ * (oracle/orc_effects.h).
  *
  * Restated behaviour, including what looks accidental in the reference:
  *   - Eigen unrolls fixed-size reductions (dot, squaredNorm, matrix * vector) as first half + second

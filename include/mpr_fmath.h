@@ -14,9 +14,10 @@
  * precision Cody-Waite reduction.  Measured error vs. a double reference: <= 2 ulp
  * (tests/test_fmath.py).  Rounding mode must be round-to-nearest when these are called.
  *
- * This header is product code; the oracle includes it so that both sides share the
- * definition (the oracle checks everything *around* these functions; their accuracy is
- * checked separately against glibc's double routines).
+ * This header is product code only.  The oracle has its own, separately written implementation of the
+ * same definition (oracle/orc_fmath.h: necessarily the same operation sequence, since the bits must
+ * agree); the independent evidence for these functions is the ulp test of the GPU's outputs against
+ * mpmath (tests/test_soundness.py::test_gpu_float_functions_against_mpmath).
  */
 #ifndef MPR_FMATH_H
 #define MPR_FMATH_H

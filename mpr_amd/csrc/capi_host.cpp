@@ -142,7 +142,7 @@ int mpr_tape_from_tree(const mpr_tree* tr, mpr_tape** out)
             return mpr::set_error(MPR_ERR_UNSUPPORTED, "expression needs more than 254 live values at once (src/tape.cpp:79: \"Ran out of slots!\")");
         auto* t = new mpr_tape();
         t->clauses = std::move(tb.clauses);
-        t->flags = (tb.slots_exhausted ? 1 : 0) | (tb.unsupported ? 2 : 0);
+        t->flags = tb.unsupported ? 2 : 0;          /* bit 0 (slots exhausted) is never set: such an expression is refused above */
         finish_tape(t);
         *out = t;
         return MPR_OK;)

@@ -115,6 +115,8 @@ struct mpr_context {
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
+    bool jit_always_invalidate = false;/* MPR_VOXEL_JIT=3 (development): the group form invalidates the instruction cache after every translation */
+    bool jit_validated_arch = false;   /* gfx950: the ring's one-invalidate-per-trip was validated there and nowhere else */
     int jit_grid_cache[2][2][4] = {};  /* workgroups the device holds, per form (tile / group), dimension and slot class */
     bool voxel_jit_tiles = false;      /* MPR_VOXEL_JIT=2: generated code per smallest tile where the group form is not possible (development;
                                           slower than the interpreter for short tapes: a translation per tile).  Brute-force frames always use it:
@@ -307,13 +309,17 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->S = S;
     c->flags = opt->flags;
     if (const char* e = getenv("MPR_VOXEL_ASM")) c->voxel_asm = atoi(e) != 0;
-    if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; }
+    if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; c->jit_always_invalidate = atoi(e) == 3; }
     if (const char* e = getenv("MPR_VOXEL_GROUPS")) { c->voxel_groups = atoi(e) != 0; c->groups_always = atoi(e) == 2; }
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
     if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, opt->device) == hipSuccess) c->cus = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, opt->device) == hipSuccess) {
+            c->cus = prop.multiProcessorCount;
+            /* the ring of code slots that is invalidated once per trip was validated on gfx950 (scripts/ubench/jit_probe.hip) */
+            c->jit_validated_arch = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        }
     }
     if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
@@ -646,7 +652,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, ((size_t)160 << 10) / mprk::wide_stage_lds_bytes(c->sched_nclauses)));
             wide_limit = 2 * std::max(c->cus, 1) * (int)per_cu;
         }
-        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) &&
+        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) && !(c->flags & MPR_CTX_SERIAL_STAGES) &&
                               (si == 0 ? count <= 8192 : (prev_wide && count <= wide_limit));
         const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();
@@ -823,8 +829,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                     mprk::VoxelArgs gv = v;
                     gv.tiles = c->tiles[group_stage];
                     gv.count = group_count;
+                    /* A slot's code must not be reached by the sequential instruction prefetch of its neighbour before it is
+                     * written: 256 B between slots executed stale code, 1 KB did not, 4 KB (1024 dwords) is the validated
+                     * margin.  Anything closer, or another device, pays the invalidate per group. */
+                    const bool always_inv = c->jit_always_invalidate || gap_dw < 1024 || !c->jit_validated_arch;
                     mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)region, (int)slot_dw, (int)nslot, grid, (int)tape->clauses.size(), c->groups,
-                                                 c->choice_masks, group_cap, c->num_active + 7, c->group_list);
+                                                 c->choice_masks, group_cap, c->num_active + 7, c->group_list, always_inv);
                     jitted = true;
                 } else if (c->jit_code && !group_form && (brute || c->voxel_jit_tiles)) {
                     mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, 1, grid, (int)tape->clauses.size(), nullptr,

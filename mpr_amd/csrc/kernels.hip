@@ -374,7 +374,6 @@ k_eval_tiles(TileStageArgs a)
         if (writing) {
             out_offset--;
             twr[out_index + out_offset] = end_clause;
-            written++;
         }
         lm_set(lm, i_out, live);
 
@@ -452,7 +451,6 @@ k_eval_tiles(TileStageArgs a)
                             const int delta = prev_index - (out_index + out_offset);
                             twr[out_index + out_offset] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)delta << 32);
                             twr[prev_index] = (uint64_t)MPR_OP_JUMP | ((uint64_t)(uint32_t)(-delta) << 32);
-                            written += 2;
                             --out_offset;
                         }
                     }
@@ -486,10 +484,7 @@ k_eval_tiles(TileStageArgs a)
                             w = (d & ~0xFFull) | MPR_OP_COPY_IMM;
                         }
                     }
-                    if (emit) {
-                        twr[out_index + out_offset] = w;
-                        written++;
-                    }
+                    if (emit) twr[out_index + out_offset] = w;
                 }
             }
         }
@@ -497,9 +492,12 @@ k_eval_tiles(TileStageArgs a)
         if (writing) {
             out_offset--;
             twr[out_index + out_offset] = d;         /* head: copy of the parent's head */
-            written++;
             a.tiles[gidx].tape = out_index + out_offset;
             own_len = ((out_index - first_index) / MPR_SUBTAPE_CHUNK) * 62 + (62 - out_offset);
+            /* W of SURVEY.md 8(d): every word of the chunks behind this one (end marker or link, 62 clauses, link) and this
+             * chunk's words from the head up — what the reference's walk stores one by one (:352, :402-409, :450, :457).
+             * Counted from where the walk ended, so that the assembly walk (which keeps no count) reports it too. */
+            written = (long long)(out_index - first_index) + (MPR_SUBTAPE_CHUNK - out_offset);
         }
     }
     if (a.len_stats && (blockIdx.x & 7) == 0) {
@@ -550,9 +548,11 @@ k_eval_tiles(TileStageArgs a)
         if (lane == 0) {
             atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)fwd_words);
             atomicAdd((unsigned long long*)&a.counters[CNT_BWD], (unsigned long long)bwd_words);
-            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)nclauses * __popcll(alive_mask));
+            atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)(fwd_words - 1) * __popcll(alive_mask));
         }
-        if (written) atomicAdd((unsigned long long*)&a.counters[CNT_WRITTEN], (unsigned long long)written);
+        long long wsum = written;
+        for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
+        if (lane == 0 && wsum) atomicAdd((unsigned long long*)&a.counters[CNT_WRITTEN], (unsigned long long)wsum);
         if (overflow) a.counters[CNT_OVERFLOW] = 1;
     }
     if (overflow) a.tape_index[1] = 1;        /* sticky per frame; read back by mpr_get_counters */

@@ -143,7 +143,7 @@ int jit_grid(int dim, int nslots, int cus, bool group);
 /* groups != null: the group form over the last tile stage's list (a.tiles / a.count), else one wavefront per smallest tile */
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
                             int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
-                            const int* group_list);
+                            const int* group_list, bool always_invalidate = false);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

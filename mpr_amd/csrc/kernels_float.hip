@@ -142,10 +142,11 @@ k_eval_voxels(VoxelArgs a)
             a.image[px + py * S] = 1;
         }
     }
+    const unsigned long long visible = (unsigned long long)__popcll(ballot(!skip));
     if (a.counters && lane == 0) {
         atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words);
         atomicAdd((unsigned long long*)&a.counters[CNT_FWD_VOX], (unsigned long long)words);
-        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)(words - 1) * 64ull);
+        atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)(words - 1) * visible);
     }
     if (a.heat) {
         /* heatmap frames (reference eval_voxels_f_heatmap, src/context.cu:1960-1980).  The reference

@@ -793,6 +793,8 @@ struct JitVoxelArgs {
     int choice_cap;
     int* group_counter;        /* group form: the next entry of group_list to hand out (zero at the start of the frame) */
     const int* group_list;     /* group form: the groups with a surviving tile, in list order; [number of groups] = how many */
+    int always_invalidate;     /* group form: s_icache_inv after every translation, not once per trip round the ring of code slots
+                                * (context.hip: slots closer than the validated 4 KB, a device other than gfx950, MPR_VOXEL_JIT=3) */
 };
 
 /* ---- tile form: a wavefront per smallest tile, each with its own tape ------------------------------------------ */
@@ -900,7 +902,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             if (lane == 0) *next_child = 0;
             const uint32_t trash_off = (uint32_t)((j.region_dwords - 320 - slot * j.slot_dwords) * 4u) + (uint32_t)lane * 16u;
             (void)jit_translate(tro, (uint32_t)(gtape + 1), head0, code, trash_off, lds, lane);
-            if (slot == 0) asm volatile("s_waitcnt vmcnt(0)\n s_icache_inv\n s_nop 7\n s_nop 7\n" ::: "memory");
+            if (slot == 0 || j.always_invalidate) asm volatile("s_waitcnt vmcnt(0)\n s_icache_inv\n s_nop 7\n s_nop 7\n" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
         }
         /* lane i: the decisions of the group's 64 tiles at its i-th min / max */
@@ -987,7 +989,7 @@ int jit_grid(int dim, int nslots, int cus, bool group)
 }
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
                             int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
-                            const int* group_list)
+                            const int* group_list, bool always_invalidate)
 {
     if (a.count <= 0) return;
     JitVoxelArgs j;
@@ -1002,6 +1004,7 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
     j.choice_cap = choice_cap;
     j.group_counter = group_counter;
     j.group_list = group_list;
+    j.always_invalidate = always_invalidate ? 1 : 0;
     const int ns = jit_slot_class(a.nslots);
     if (groups) {
         const dim3 g(std::min(grid, (a.count + 63) / 64)), b(64 * JIT_GROUP_WAVES);

@@ -791,7 +791,7 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
     f->normals = (uint32_t*)calloc((size_t)S * S, sizeof(uint32_t));
     if (want_heat) f->heat = (float*)calloc((size_t)S * S, sizeof(float));
 
-    int64_t F_tiles = 0, F_vox = 0, F_norm = 0, R = 0, W = 0, LC = 0;
+    int64_t F_tiles = 0, F_vox = 0, F_norm = 0, R = 0, W = 0, LC = 0, W_surv = 0, F_vox_min = 0, F_vox_max = 0;
     int slots_exceeded = 0, overflowed = 0;
 
     /* which stages run: 3-D 0,1,2 (64/16/4 px, x4); 2-D 0,2 (64/8 px, x8) — :1164-1165, :1310 */
@@ -847,6 +847,7 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
 
         /* heatmap lower bound: backward work only of tiles that also survive the stage */
         int32_t* pushed_words = (heat_mode == 2) ? (int32_t*)calloc(count ? count : 1, sizeof(int32_t)) : NULL;
+        int32_t* wr_words = (int32_t*)calloc(count ? count : 1, sizeof(int32_t));      /* words each tile's push wrote */
 
         /* eval_tiles_i — :1185 / :1342.  Groups of 64 consecutive tiles share a tape. */
         int64_t n_empty = 0, n_filled = 0, n_pushed = 0, n_ambig = 0;
@@ -876,8 +877,9 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                     }
                 }
                 slots_exceeded |= se;
-                LC += nc;
+                LC += fwd - 1;          /* every word but the terminator, per tile */
                 W += wr;
+                if (r == T_PUSHED) wr_words[t] = (int32_t)wr;
                 if (fwd > gfwd) gfwd = fwd;
                 if (bwd > gbwd) gbwd = bwd;
                 switch (r) {
@@ -902,6 +904,9 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
             }
         }
 
+        for (size_t t = 0; t < count; ++t)
+            if (tiles[t].position != -1) W_surv += wr_words[t];
+        free(wr_words);
         if (pushed_words) {
             for (size_t t = 0; t < count; ++t) {
                 if (pushed_words[t] && tiles[t].position != -1)
@@ -979,14 +984,16 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
         const float size_recip = 1.0f / (float)(tps * sub);
         /* heatmap bounds (3-D): the walk of every smallest tile, for the second pass below */
         int32_t* tile_words = (dim == 3 && heat_mode >= 2) ? (int32_t*)calloc(count ? count : 1, sizeof(int32_t)) : NULL;
+        int32_t* walk_words = (dim == 3) ? (int32_t*)calloc(count ? count : 1, sizeof(int32_t)) : NULL;   /* F bounds */
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : F_vox, LC)
         for (size_t t = 0; t < count; ++t) {
             const int4_ pos = unpack(vt[t].position, tps);
             int64_t words_max = 0;
-            if (tile_words) {
+            if (tile_words || walk_words) {
                 int64_t w = 0;
                 (void)eval_point_f(f->pool, vt[t].tape, 0.0f, 0.0f, 0.0f, &w);
-                tile_words[t] = (int32_t)(w - 1);
+                if (tile_words) tile_words[t] = (int32_t)(w - 1);
+                if (walk_words) walk_words[t] = (int32_t)w;
             }
             for (int s = 0; s < 64; ++s) {
                 const int4_ sp = unpack(s, sub);
@@ -1025,10 +1032,29 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                     /* :1977-1980: half of the thread's walk to each of its two pixels */
                     if (f->heat) f->heat[px + (size_t)py * S] += (float)(uint32_t)(words - 1) / 2.0f;
                 }
-                LC += words;
+                LC += words - 1;
                 if (words > words_max) words_max = words;
             }
             F_vox += words_max;
+        }
+        if (walk_words) {
+            /* the float pass's F over all execution orders: a tile is walked unless all 32 voxel pairs are skipped, and a pair
+             * that the FINAL heightmap leaves visible is visible whenever the tile runs */
+            for (size_t t = 0; t < count; ++t) {
+                const int4_ pos = unpack(vt[t].position, tps);
+                int visible = 0;
+                for (int s = 0; s < 32 && !visible; ++s) {
+                    const int4_ sp = unpack(s, sub);
+                    const int32_t px = pos.x * 4 + sp.x, py = pos.y * 4 + sp.y;
+                    const int32_t pz_low = pos.z * 4 + (sp.z & 1);
+                    if (image[px + py * S] < pz_low + 2) visible = 1;
+                }
+                F_vox_max += walk_words[t];
+                if (visible) F_vox_min += walk_words[t];
+            }
+            free(walk_words);
+        } else {
+            F_vox_min = F_vox_max = F_vox;
         }
         if (tile_words) {
             /* lower bound: only the voxel pairs that no order of execution can skip (the final
@@ -1093,7 +1119,7 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                 }
                 int64_t words = 0;
                 const deriv r = eval_point_d(f->pool, tape_at, v[0], v[1], v[2], &words);
-                LC += words;
+                LC += words - 1;
                 npix++;
                 int k;
                 for (k = 0; k < nseen; ++k) if (seen_tape[k] == tape_at) break;
@@ -1116,6 +1142,9 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
     f->c.clauses_fwd = F_tiles + F_vox + F_norm;
     f->c.clauses_bwd = R;
     f->c.clauses_written = W;
+    f->c.clauses_written_survivors = W_surv;
+    f->c.clauses_fwd_voxels_min = F_vox_min;
+    f->c.clauses_fwd_voxels_max = F_vox_max;
     f->c.lane_clauses = LC;
     f->c.tape_index = f->tape_index;
     f->c.pool_overflowed = overflowed;

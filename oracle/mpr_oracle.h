@@ -31,12 +31,19 @@ typedef struct orc_counters {
     int64_t clauses_fwd_normals; /*    of which normals pass */
     int64_t clauses_bwd;         /* R */
     int64_t clauses_written;     /* W */
-    int64_t lane_clauses;        /* clause evaluations per tile / voxel / pixel */
+    int64_t lane_clauses;        /* words visited forward, terminator excluded, per tile / voxel / pixel */
     int64_t normal_pixels;
     int32_t tape_index;
     int32_t pool_overflowed;
     int32_t slots_exceeded;
     int32_t threads;
+    /* 3-D: the float pass's F over all execution orders lies between these (the skip test of src/context.cu:852-864
+     * reads a heightmap other tiles are still writing): the walks of the smallest tiles with a voxel pair the FINAL
+     * heightmap still leaves visible, and the walks of all of them; 2-D: both equal clauses_fwd_voxels */
+    int64_t clauses_fwd_voxels_min, clauses_fwd_voxels_max;
+    /* W restricted to the tiles that survive their stage (3-D: whether a tile that is culled later pushed first is
+     * timing dependent, src/context.cu:299-305 vs :312) */
+    int64_t clauses_written_survivors;
 } orc_counters;
 
 /* Render a frame.  dim = 2 or 3.  mat: column-major 3x3 (dim 2) or 4x4 (dim 3).

@@ -34,6 +34,9 @@ class Counters(ctypes.Structure):
         ("pool_overflowed", ctypes.c_int32),
         ("slots_exceeded", ctypes.c_int32),
         ("threads", ctypes.c_int32),
+        ("clauses_fwd_voxels_min", ctypes.c_int64),
+        ("clauses_fwd_voxels_max", ctypes.c_int64),
+        ("clauses_written_survivors", ctypes.c_int64),
     ]
 
     def as_dict(self):

@@ -11,7 +11,7 @@
  * from, or generated out of, the product's sources.  Where the two disagree in a single bit the
  * GPU-vs-oracle tests fail; how close the definition is to the true functions — the only thing that
  * can be said about CUDA's libm — is tested on the GPU's OUTPUTS against mpmath
- * (tests/test_transcendentals.py).
+ * (tests/test_soundness.py::test_gpu_float_functions_against_mpmath; tests/test_fmath.py for this file).
  *
  * Written as coefficient tables + Horner loops over explicit fmaf(); round-to-nearest must be in
  * effect; compile with -ffp-contract=off.

@@ -4,6 +4,7 @@
 // tests/test_host_api.py (syntax only without a GPU; run by the gpu test).
 #include <cmath>
 #include <cstdio>
+#include <vector>
 
 #include "mpr.hpp"
 
@@ -27,30 +28,24 @@ int main(int argc, char** argv)
         decided64++;
     }
 
+    // every surviving 64^2 tile was given a compacted id (`next`) and its 64 children sit at [64 * id, 64 * id + 64) of the
+    // next stage's list: one table from id to the parent's position, built once
+    std::vector<int> parent_of(ctx.stages[2].tile_array_size / 64 + 1, -1);
+    for (unsigned j = 0; j < std::pow(size / 64, 2); ++j) {
+        const auto top = ctx.stages[0].tiles[j];
+        if (top.next >= 0 && (size_t)top.next < parent_of.size()) {
+            parent_of[top.next] = top.position;
+        }
+    }
     unsigned decided8 = 0, filled8 = 0;
     for (unsigned i = 0; i < ctx.stages[2].tile_array_size; ++i) {
-        const auto tile = ctx.stages[2].tiles[i];
-        if (tile.position != -1) {
+        if (ctx.stages[2].tiles[i].position != -1) {
             continue;
         }
-        // walk back to the parent: the q-th surviving 64^2 tile
-        int q = -1;
-        unsigned parent = -1;
-        for (unsigned j = 0; j < std::pow(size / 64, 2); ++j) {
-            if (ctx.stages[0].tiles[j].position != -1) {
-                q++;
-            }
-            if (q == (int)i / 64) {
-                parent = ctx.stages[0].tiles[j].position;
-                break;
-            }
-        }
-        const auto px = parent % (size / 64), py = parent / (size / 64);
-        const auto x = (px * 8) + ((i % 64) % 8), y = (py * 8) + ((i % 64) / 8);
+        const unsigned parent = parent_of[i / 64], child = i % 64, per_side = size / 64;
+        const unsigned x = (parent % per_side) * 8 + child % 8, y = (parent / per_side) * 8 + child / 8;
         decided8++;
-        if (ctx.stages[3].filled[x * 8 + y * 8 * size]) {
-            filled8++;
-        }
+        filled8 += ctx.stages[3].filled[x * 8 + y * 8 * size] != 0;
     }
 
     unsigned inside = 0;

@@ -305,6 +305,35 @@ def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name
     b.close()
 
 
+@pytest.mark.parametrize("name,dim,S", [("bear", 3, 512), ("architecture", 3, 1024), ("hello_world", 2, 256)])
+def test_code_ring_against_an_invalidate_per_group(mpr, tapes, name, dim, S, monkeypatch):
+    """The group form writes a group's code into the next slot of a ring and invalidates the instruction cache only when
+    it re-enters slot 0; that rests on the slots lying 4 KB apart (beyond the sequential instruction prefetch).
+    MPR_VOXEL_JIT=3 invalidates after every translation — no such assumption — and a gap below the validated one
+    (MPR_JIT_GAP) falls back to it by itself: all three give the same frame, repeatedly."""
+    tape = tapes(name)
+    monkeypatch.setenv("MPR_VOXEL_GROUPS", "2")
+    ring = mpr.Context(S)
+    monkeypatch.setenv("MPR_VOXEL_JIT", "3")
+    every = mpr.Context(S)
+    monkeypatch.setenv("MPR_VOXEL_JIT", "1")
+    monkeypatch.setenv("MPR_JIT_GAP", "16")           # 64 bytes between slots: far inside the prefetch's reach
+    tight = mpr.Context(S)
+    for rep in range(3):
+        for ctx in (ring, every, tight):
+            if dim == 2:
+                ctx.render2D(tape, view2())
+            else:
+                ctx.render3D(tape, view3())
+            assert ctx.float_kernel().startswith("k_eval_voxels_jit_groups"), ctx.float_kernel()
+        assert ring.image.any()
+        assert np.array_equal(ring.image, every.image) and np.array_equal(ring.image, tight.image)
+        if dim == 3:
+            assert np.array_equal(ring.normals, every.normals) and np.array_equal(ring.normals, tight.normals)
+    for ctx in (ring, every, tight):
+        ctx.close()
+
+
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("hello_world", 2, 256),
                                         ("bear", 3, 256), ("architecture", 3, 256), ("involute_gear_3d", 3, 128)])
 def test_serial_first_stage_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):
