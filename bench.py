@@ -170,15 +170,26 @@ def cpu_baseline(m, tape, model, S, T, ctx, frames=3, dim=3, one_core_parts=16):
     from oracle import orc
     from mpr_amd.multigpu import column_weights
     orc.lib()
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     mat = m.colmajor(T, dim + 1)
     gimg = ctx.image.copy()
     gnrm = ctx.normals.copy() if dim == 3 else None
-    t1 = time.perf_counter()
-    fr = orc.Frame(tape.data, dim, S, mat, threads=cores, keep_pool=False)          # warm-up, and the checker
-    warm_s = time.perf_counter() - t1
-    same = bool(np.array_equal(fr.filled[3], gimg) and (dim == 2 or np.array_equal(fr.normals, gnrm)))
-    del fr
+    # warm-up frames, one per candidate thread count (the oracle's OpenMP loop stops scaling well before 256 hardware threads:
+    # one atomic pool index, one heightmap); the better one is timed.  The last one is also the checker.
+    best = None
+    same = True
+    for th in sorted({avail, min(avail, 32)}, reverse=True):
+        t1 = time.perf_counter()
+        fr = orc.Frame(tape.data, dim, S, mat, threads=th, keep_pool=False)
+        dt = time.perf_counter() - t1
+        same = same and bool(np.array_equal(fr.filled[3], gimg) and (dim == 2 or np.array_equal(fr.normals, gnrm)))
+        del fr
+        if best is None or dt < best[1]:
+            best = (th, dt)
+    cores, warm_s = best
     per_cpu = []
     for _ in range(frames if warm_s < 30 else 1):
         t1 = time.perf_counter()
@@ -187,7 +198,7 @@ def cpu_baseline(m, tape, model, S, T, ctx, frames=3, dim=3, one_core_parts=16):
     cm, csd = stats(per_cpu)
     rec = {"value": round(S * S / (cm * 1e-3) / 1e6, 4), "unit": "Mpixel/s", "cores": cores, "kind": "port",
            "ms_per_frame": round(cm, 1), "ms_per_frame_std": round(csd, 1), "frames": len(per_cpu), "warmup": 1,
-           "frame_matches_gpu": same,
+           "host_threads_available": avail, "frame_matches_gpu": same,
            "sample": "%s.frep render%dD at %d^%d — the bench configuration itself, whole frame — oracle/mpr_oracle.c, OpenMP over tile groups, %d threads"
                      % (model, dim, S, dim, cores)}
     # one core: the columns rank 0 gets when the frame's 64x64 columns are dealt 16 ways by measured work (the multi-GPU deal)

@@ -83,33 +83,31 @@ struct mpr_context {
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
-    /* Frames whose last tile stage pushes no tapes (TileStageArgs::no_push): possible when both the float and the normals
-     * pass run on the groups' tapes, decided from what the last MEASURING frame of the same tape and partition found (a
-     * push-mode frame: the first one always is, and one after every 64 without).  What a reader of tiles / tapes needs to get the
-     * reference's state back: */
-    bool lean_last_stage = true;       /* MPR_LAST_STAGE_PUSH=1: always push */
-    bool force_push = false;           /* set while a reader re-renders the frame in full */
-    bool last_frame_lean = false;
+    /* Frames that do not leave the reference's tiles and tapes behind ("fast" frames: what render* does by default; the
+     * images are the reference's bit for bit):
+     *  - the last tile stage pushes no tapes (TileStageArgs::no_push) when both the float and the normals pass run on the
+     *    groups' tapes.  Whether that pays is measured by the stage itself, every frame, on a sixteenth of its groups; a
+     *    tape whose last stage shortens too much for it (the involute gears, prospero) gets its per-tile tapes from a second
+     *    run of that stage, once — from then on `hint` makes the stage push straight away;
+     *  - a 3-D frame starts at the 16^3 tiles when the 64^3 stage would be a handful of wavefronts (skip_stage0).
+     * What a reader of tiles / tapes / counters needs to get the reference's state back: */
+    bool reference_frames = false;     /* MPR_LAST_STAGE_PUSH=1: every frame the reference's way (all stages, all tapes) */
+    bool force_reference = false;      /* set while a reader re-renders the frame the reference's way */
+    bool last_frame_fast = false;      /* the last frame took one of the shortcuts above ... */
+    bool last_frame_lean = false;      /* ... this one: no tapes from its last tile stage */
+    bool skip_stage0 = true;           /* MPR_SKIP_STAGE0=0: never start at the 16^3 tiles */
+    int measure_len_forced = -1;       /* MPR_MEASURE_LEN (development): groups per run of the last stage's sample */
     struct FrameKey {
-        uint64_t serial = 0;
         int dim = 0, rank = 0;
-        unsigned owner_gen = 0;
         bool parted = false;
         float mat[16] = {0};
         float z = 0.0f;
-        /* same tape and partition: the view may differ (how much the last stage shortens its tapes is a property of the
-         * model and the resolution far more than of the view, and a frame that guesses wrong is slower, not different) */
-        bool same_model(const FrameKey& o) const
-        {
-            return serial == o.serial && dim == o.dim && rank == o.rank && owner_gen == o.owner_gen && parted == o.parted;
-        }
     };
-    FrameKey learned;                  /* the frame that measured "groups' tapes are short enough" ... */
-    FrameKey last_key;                 /* ... and the last frame rendered (what a reader's full frame repeats) */
-    bool learned_ok = false;
-    int frames_since_measured = 0;
-    int lean_period = 64;              /* a full (measuring) frame after this many frames without: views drift (MPR_LEAN_PERIOD) */
+    FrameKey last_key;                 /* the last frame rendered (what a reader's reference frame repeats) ... */
     std::unique_ptr<mpr_tape> last_tape;   /* ... and a copy of its tape (the caller may have freed it by the time a reader asks) */
+    enum { HINT_UNKNOWN = 0, HINT_GROUPS = 1, HINT_TAPES = 2 };
+    uint64_t hint_serial = 0;          /* what the last measuring frame of this tape and dimension found: the groups' tapes are ... */
+    int hint_dim = 0, hint_mode = HINT_UNKNOWN;   /* ... short enough for float and normals pass (GROUPS), or per-tile tapes pay (TAPES) */
     bool tiles_vgpr = true;            /* MPR_TILES_VGPR=0 (development): tile stages keep every slot file in LDS */
     bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
@@ -327,8 +325,9 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILES_VGPR")) c->tiles_vgpr = atoi(e) != 0;
-    if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->lean_last_stage = atoi(e) == 0;
-    if (const char* e = getenv("MPR_LEAN_PERIOD")) c->lean_period = std::max(atoi(e), 1);
+    if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->reference_frames = atoi(e) != 0;
+    if (const char* e = getenv("MPR_SKIP_STAGE0")) c->skip_stage0 = atoi(e) != 0;
+    if (const char* e = getenv("MPR_MEASURE_LEN")) c->measure_len_forced = atoi(e);
     if (const char* e = getenv("MPR_WIDE_LATER")) c->wide_later = atoi(e);
     if (const char* e = getenv("MPR_WIDE_THREADS")) c->wide_threads = atoi(e);
     if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
@@ -598,39 +597,60 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     bool group_form = false;
     int group_stage = 0, group_count = 0, group_cap = 1;
     mpr_context::FrameKey key;
-    key.serial = tape->serial;
     key.dim = dim;
     key.rank = rank;
     key.parted = owner != nullptr;
-    key.owner_gen = owner ? (unsigned)c->owner_gen : 0u;
     key.z = z;
     std::memcpy(key.mat, mat, (size_t)(dim == 3 ? 16 : 9) * sizeof(float));
-    /* the last frame of this tape and view found the group form worth it: this one's last tile stage pushes no tapes */
-    const bool lean_ok = c->lean_last_stage && !c->force_push && !brute && c->learned_ok && c->learned.same_model(key) &&
-                         c->frames_since_measured < c->lean_period && (dim == 2 || c->normals_asm);
+    /* the reference's way (every stage from the 64 px tiles down, every tape pushed): asked for, or a frame that is inspected */
+    const bool reference = c->reference_frames || c->force_reference || brute || cnt || heat;
+    int hint = (c->hint_serial == tape->serial && c->hint_dim == dim) ? c->hint_mode : (int)mpr_context::HINT_UNKNOWN;
     bool lean_now = false;
+    /* 3-D: the 64^3 stage of a frame up to 1024^3 is 64 wavefronts walking the whole tape one clause after the other — 0.15 ms
+     * of latency on an idle chip — while ALL of its 16^3 tiles are one round of wavefronts for the next stage.  A
+     * frame nobody inspects starts there: every 64^3 tile counts as ambiguous.  The hierarchy is conservative at every level, so
+     * the heights and normals are the same; tile lists and tapes of the first two stages are not the reference's, and a reader gets
+     * the frame again the reference's way (ensure_reference_frame).  Tapes with wide DAGs keep the level-parallel first stage. */
+    const int t16 = S / 16;
+    const bool skip0 = !reference && c->skip_stage0 && dim == 3 && !(c->wide_stage0 && c->sched_ok) && c->cus > 0 &&
+                       (long long)t16 * t16 * t16 / 64 <= 16ll * c->cus && c->normals_asm && c->tiles_asm;
+    /* a reader's reference frame of a partitioned context keeps the columns other ranks sent (mpr_unpack_*): only this rank's
+     * columns are cleared */
+    const bool keep_foreign = c->force_reference && owner != nullptr;
+    if (keep_foreign) mprk::launch_zero_owned(s, c->arena, dim == 3, S, c->owner_dev, rank);
+    const size_t zero_now = keep_foreign ? 0 : zero_words;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
         rc = ensure_tiles(c, 0, (size_t)count);
         if (rc) return rc;
+        if (skip0) {
+            rc = ensure_tiles(c, 1, (size_t)count * 64);
+            if (rc) return rc;
+        }
         TimedScope ts(c, "preload_tiles");
-        mprk::launch_begin_frame(s, c->arena, zero_words, c->tape_index, (int)tape->clauses.size(), c->num_active,
-                                 c->tiles[0], count, t0 * t0, owner ? c->owner_dev : nullptr, rank);
+        mprk::launch_begin_frame(s, c->arena, zero_now, c->tape_index, (int)tape->clauses.size(), c->num_active,
+                                 c->tiles[0], count, t0 * t0, owner ? c->owner_dev : nullptr, rank, skip0 ? c->tiles[1] : nullptr, t0);
         c->tiles_n[0] = (size_t)count;
+        if (skip0) {
+            c->last.tiles_in[0] = count;
+            c->last.tiles_active[0] = count;
+            count *= 64;
+            c->tiles_n[1] = (size_t)count;
+        }
     } else {
         const int t8 = S / 8;
         count = t8 * t8;
         rc = ensure_tiles(c, 3, (size_t)count);
         if (rc) return rc;
         TimedScope ts(c, "preload_tiles");
-        mprk::launch_begin_frame(s, c->arena, zero_words, c->tape_index, (int)tape->clauses.size(), c->num_active,
+        mprk::launch_begin_frame(s, c->arena, zero_now, c->tape_index, (int)tape->clauses.size(), c->num_active,
                                  c->tiles[3], count, count, nullptr, 0);
         c->tiles_n[3] = (size_t)count;
     }
 
     bool prev_wide = false;
-    for (int si = 0; si < nstages; ++si) {
+    for (int si = skip0 ? 1 : 0; si < nstages; ++si) {
         const int i = stage_list[si];
         const bool last = (si == nstages - 1);
         const int next = (dim == 3) ? i + 1 : (i ? 3 : 2);
@@ -656,7 +676,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                               (si == 0 ? count <= 8192 : (prev_wide && count <= wide_limit));
         const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();
-        if (groups_now && lean_ok) lean_now = true;
+        /* no tapes from this stage unless the frame is inspected or this tape's last measurement said they pay */
+        const bool try_lean = groups_now && !reference && hint != mpr_context::HINT_TAPES && (dim == 2 || c->normals_asm);
         if (groups_now) {
             const size_t ng = ((size_t)count + 63) / 64;
             rc = ensure_buffer(&c->groups, &c->groups_cap, ng);
@@ -672,8 +693,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             group_count = count;
             group_cap = std::max(stage_cap, 1);
         }
+        mprk::TileStageArgs a;
         if (count > 0) {
-            mprk::TileStageArgs a;
             a.groups = groups_now ? c->groups : nullptr;
             a.choice_masks = groups_now ? c->choice_masks : nullptr;
             a.tape_ro = c->pool;
@@ -687,9 +708,21 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.nslots = nslots;
             a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
             a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
-            a.len_stats = (groups_now && !lean_now) ? c->num_active + 5 : nullptr;
+            a.len_stats = groups_now ? c->num_active + 5 : nullptr;
             if (c->debug_choices && si == nstages - 2) a.len_stats = c->num_active + 5;
-            a.no_push = groups_now && lean_now;
+            a.no_push = try_lean;
+            {
+                /* the sample the stage measures its tapes on (a.len_stats): about a sixteenth of the groups while nothing is known
+                 * about this tape; a sixty-fourth afterwards, and only where the launch is long enough to hide the sample's longer
+                 * waves (a wrong hint costs time, never a pixel); everything in frames that push anyway */
+                const int ng = (count + 63) / 64;
+                a.measure_at[0] = ng / 4;
+                a.measure_at[1] = ng / 2;
+                if (!try_lean || hint == mpr_context::HINT_UNKNOWN) a.measure_len = std::max(ng / 32, std::min(ng, 4));
+                else a.measure_len = ng >= 32 * std::max(c->cus, 1) ? ng / 128 : 0;
+                if (c->measure_len_forced >= 0) a.measure_len = c->measure_len_forced;
+                if (a.measure_len == 0 && groups_now) a.len_stats = nullptr;
+            }
             a.compiled_walk = !c->tiles_asm;
             a.vgpr_slots = c->tiles_vgpr;
             a.z = z;
@@ -732,48 +765,66 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
         if (rc) return rc;
-        const int seq = ++c->pub_seq;
         const bool zs = dim == 3 && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
-        if (count > 0 && zs) {
-            TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
-            mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
-                                         c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub),
-                                         c->num_active + 4, groups_now ? c->group_alive : nullptr);
-        } else if (count > 0) {
-            TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
-            mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                           c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub), groups_now ? c->group_alive : nullptr);
-        }
-        if (groups_now && count > 0) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
-        if (count == 0) {
+        int act3[4] = {0, 0, 0, 0};
+        /* second mask_filled_tiles + assign_next_nodes + subdivide / copy_active_tiles + copy_filled, then the survivor count */
+        auto compact = [&](bool mark_groups) -> int {
+            const int seq = ++c->pub_seq;
+            if (zs) {
+                TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
+                mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
+                                             c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub),
+                                             c->num_active + 4, mark_groups ? c->group_alive : nullptr);
+            } else {
+                TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
+                mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
+                                               c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub), mark_groups ? c->group_alive : nullptr);
+            }
+            if (mark_groups) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
+            return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
+        };
+        if (count > 0) {
+            rc = compact(groups_now);
+            if (rc) return rc;
+        } else {
             /* copy_filled rides in the compaction's launch; no compaction, a launch of its own */
             TimedScope ts(c, "copy_filled");
             mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
-        }
-        int act3[4] = {0, 0, 0, 0};
-        if (count > 0) {
-            rc = read_active(c, seq, act3);         /* the reference's blocking read-back (:1209, :1375) */
-            if (rc) return rc;
-        }
-        const int active = act3[0];
-        if (groups_now && !lean_now) {
-            /* what the next frame of this tape and view may do (a frame that measured nothing teaches nothing) */
-            c->learned_ok = false;
         }
         if (groups_now && act3[2] > 0 && !c->groups_always) {
             /* a child evaluated on its group's tape walks the clauses the child's own tape dropped as well: worth it while
              * the tapes walked are less than twice the tapes handed on (measured: bear 1.03x -> float pass 1.63x faster
              * than the interpreter on per-tile tapes, architecture 1.8x -> 1.39x faster, involute_gear_3d 2.8x -> 1.44x
              * slower, involute_gear_2d 4.3x -> 5x slower) */
-            if ((double)act3[2] > 2.0 * (double)act3[1]) group_form = false;
-            else if (!cnt && !heat) {
-                c->learned = key;
-                c->learned_ok = true;
-                c->frames_since_measured = 0;
-                if (!c->last_tape || c->last_tape->serial != tape->serial) c->last_tape.reset(new mpr_tape(*tape));
+            /* (which groups fall into the sample varies from frame to frame — list order is the compaction's — so a tape near the
+             * threshold is kept where it is: leaving a form takes 15 % more than staying out of it) */
+            const double limit = hint == mpr_context::HINT_GROUPS ? 2.3 : hint == mpr_context::HINT_TAPES ? 1.7 : 2.0;
+            const bool pays = (double)act3[2] <= limit * (double)act3[1];
+            if (!pays) group_form = false;
+            if (!reference) {
+                c->hint_serial = tape->serial;
+                c->hint_dim = dim;
+                c->hint_mode = hint = pays ? mpr_context::HINT_GROUPS : mpr_context::HINT_TAPES;
             }
             if (c->debug_choices) fprintf(stderr, "last stage: tapes handed on %d clauses, tapes walked %d (sample)\n", act3[1], act3[2]);
         }
+        lean_now = try_lean && group_form;
+        if (try_lean && !group_form && count > 0) {
+            /* the stage pushed nothing and the float pass wants per-tile tapes after all (first frame of such a tape: from now on
+             * `hint` says so): the stage again, pushing.  Dead tiles stay dead, fills are idempotent, and no tile's tape field was
+             * touched by the measuring run, so the second run sees what the first saw minus the tiles the second mask took. */
+            a.no_push = false;
+            a.len_stats = nullptr;
+            a.groups = nullptr;
+            a.choice_masks = nullptr;
+            {
+                TimedScope ts(c, "eval_tiles_i");
+                mprk::launch_eval_tiles(s, dim, a);
+            }
+            rc = compact(false);
+            if (rc) return rc;
+        }
+        const int active = act3[0];
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
         if (c->debug_choices) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d); tapes handed on %d, walked %d\n", si, count, act3[3], choice_cap, act3[1], act3[2]);
         c->last.tiles_active[si] = active;
@@ -781,7 +832,6 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->tiles_n[next] = (size_t)count;
         prev_wide = wide_now && c->wide_later != 0;
     }
-
     c->last.voxel_tiles = count;
     if (count > 0) {
         mprk::VoxelArgs v;
@@ -844,12 +894,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             }
         }
         if (lean_now && !(jitted && group_form)) {
-            /* cannot happen while the frame that taught `learned` ran the group form with the same tape; if it does, the
-             * tapes this frame did not push are needed after all: the whole frame again, in full */
-            c->learned_ok = false;
-            c->force_push = true;
+            /* no executable memory after all (the allocation above failed): the tapes this frame did not push are needed — the
+             * whole frame again, the reference's way */
+            c->force_reference = true;
             const int again = render_frame(c, tape, dim, mat, z, owner, rank, brute, blocking);
-            c->force_push = false;
+            c->force_reference = false;
             return again;
         }
         if (jitted) {
@@ -905,22 +954,25 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     c->frame_pending = true;
     c->pending_dim = dim;
     c->last_frame_lean = lean_now;
+    c->last_frame_fast = lean_now || skip0;
     c->last_key = key;
-    if (lean_now) c->frames_since_measured++;
+    if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != tape->serial)) c->last_tape.reset(new mpr_tape(*tape));
     if (blocking) return mpr_ctx_sync(c);
     return MPR_OK;
 }
 
-/* A reader of tiles or tapes wants the state the reference leaves: if the last frame's last tile stage pushed no tapes, the
- * frame is rendered again with them (same tape — the context kept a copy —, same view, same partition). */
+/* A reader of tiles, tapes or counters wants the state the reference leaves: if the last frame took a shortcut (no tapes from
+ * its last tile stage, or no 64^3 stage) the frame is rendered again the reference's way — same tape (the context kept a copy),
+ * same view, same partition.  The images come out the same bit for bit; in a partitioned context the columns other ranks
+ * sent stay where mpr_unpack_* put them. */
 static int ensure_full_frame(mpr_context* c)
 {
-    if (!c->last_frame_lean) return MPR_OK;
+    if (!c->last_frame_fast) return MPR_OK;
     if (!c->last_tape) return mpr::set_error(MPR_ERR_INVALID, "no tape to render the last frame's tapes from");
     const mpr_context::FrameKey k = c->last_key;
-    c->force_push = true;
+    c->force_reference = true;
     const int rc = render_frame(c, c->last_tape.get(), k.dim, k.mat, k.z, k.parted ? c->owner_host.data() : nullptr, k.rank, false, true);
-    c->force_push = false;
+    c->force_reference = false;
     return rc;
 }
 

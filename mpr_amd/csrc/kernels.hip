@@ -42,7 +42,7 @@ namespace mprk {
 __global__ void __launch_bounds__(256)
 k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, unsigned long long* __restrict__ tape_index, int tape_len,
                 int* __restrict__ num_active, mpr_tile_node* __restrict__ tiles, int count, int cols,
-                const int* __restrict__ owner, int rank)
+                const int* __restrict__ owner, int rank, mpr_tile_node* __restrict__ children, int t0)
 {
     /* frame start in one launch: reset the filled images (+ normals), *tape_index, the compaction's
      * counters (they also clear themselves after use), and write the first tile list */
@@ -57,7 +57,49 @@ k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, unsigned long long
         n.tape = 0;
         n.next = -1;
         if (owner && owner[k % cols] != rank) n.position = -1;
+        if (children) {
+            /* frames that start at the 16^3 tiles (context.hip: skip0): every 64^3 tile counts as ambiguous and gets its
+             * compacted id the way the front-to-back compaction would hand them out — nearest z layer first */
+            const int z = (int)(k / (size_t)cols);
+            n.next = (int)(k % (size_t)cols) + (t0 - 1 - z) * cols;
+        }
         tiles[k] = n;
+    }
+    if (children) {
+        /* ... and its 64 children (subdivide_active_tiles_3d, reference :564-590), dead where the parent is another rank's */
+        const int sps = t0 * 4;
+        for (size_t c = i; c < (size_t)count * 64; c += stride) {
+            const int j = (int)(c >> 6), sub = (int)(c & 63);
+            const int z = t0 - 1 - j / cols, xy = j % cols;
+            const int px = xy % t0, py = xy / t0;
+            mpr_tile_node o;
+            o.position = (px * 4 + (sub & 3)) + (py * 4 + ((sub >> 2) & 3)) * sps + (z * 4 + (sub >> 4)) * sps * sps;
+            if (owner && owner[xy] != rank) o.position = -1;
+            o.tape = 0;
+            o.next = xy + z * cols;                 /* the parent's index in its list (see k_compact_subdivide) */
+            children[c] = o;
+        }
+    }
+}
+
+/* a reader's reference frame of a partitioned context (context.hip: keep_foreign): clear this rank's 64 x 64 columns of the
+ * four filled images (and the normals), leave the others as mpr_unpack_* filled them.  arena = the images in order, each
+ * padded to 64 words */
+__global__ void __launch_bounds__(256)
+k_zero_owned(int* __restrict__ arena, int with_normals, int S, const int* __restrict__ owner, int rank)
+{
+    const int cols = S / 64;
+    size_t off = 0;
+    for (int level = 0; level < 5; ++level) {
+        if (level == 4 && !with_normals) break;
+        const int side = level < 4 ? S / (64 >> (2 * level)) : S;
+        const int per_col = side / cols;             /* pixels of this image per column side */
+        const size_t n = (size_t)side * side;
+        for (size_t k = threadIdx.x + (size_t)blockIdx.x * blockDim.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+            const int x = (int)(k % side), y = (int)(k / side);
+            if (owner[x / per_col + (y / per_col) * cols] == rank) arena[off + k] = 0;
+        }
+        off += (n + 63) & ~(size_t)63;
     }
 }
 
@@ -319,7 +361,15 @@ k_eval_tiles(TileStageArgs a)
             a.groups[blockIdx.x] = gi;
         }
     }
-    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1) && !a.no_push;
+    /* a.no_push with a.len_stats: the groups of the sample still walk backward and write their tapes — into chunks nobody will
+     * read: the tiles keep the group's tape — so that the frame knows what pushing would have bought (context.hip).  The
+     * sample is two runs of consecutive groups well before the end of the list: a pushing wavefront takes nearly twice as
+     * long, and sprinkled over the launch (every 16th group) such waves cost the stage 40 % — a long tail, and two bodies
+     * of code competing for the instruction cache throughout. */
+    const bool sampled = a.len_stats && ((unsigned)((int)blockIdx.x - a.measure_at[0]) < (unsigned)a.measure_len ||
+                                         (unsigned)((int)blockIdx.x - a.measure_at[1]) < (unsigned)a.measure_len);
+    const bool measure_only = a.no_push && sampled;
+    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1) && (!a.no_push || measure_only);
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 
     long long written = 0;
@@ -492,7 +542,7 @@ k_eval_tiles(TileStageArgs a)
         if (writing) {
             out_offset--;
             twr[out_index + out_offset] = d;         /* head: copy of the parent's head */
-            a.tiles[gidx].tape = out_index + out_offset;
+            if (!measure_only) a.tiles[gidx].tape = out_index + out_offset;
             own_len = ((out_index - first_index) / MPR_SUBTAPE_CHUNK) * 62 + (62 - out_offset);
             /* W of SURVEY.md 8(d): every word of the chunks behind this one (end marker or link, 62 clauses, link) and this
              * chunk's words from the head up — what the reference's walk stores one by one (:352, :402-409, :450, :457).
@@ -500,7 +550,7 @@ k_eval_tiles(TileStageArgs a)
             written = (long long)(out_index - first_index) + (MPR_SUBTAPE_CHUNK - out_offset);
         }
     }
-    if (a.len_stats && (blockIdx.x & 7) == 0) {
+    if (sampled) {
         /* (a sample of the groups: one pair of atomics per wave on two words would be felt) */
         const uint64_t amb = ballot(ambiguous);
         int own_sum = ambiguous ? own_len : 0;
@@ -1013,13 +1063,17 @@ void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps,
     hipLaunchKernelGGL(k_mask_filled_tiles, dim3((count + 255) / 256), dim3(256), 0, s, tiles, count, tps, image);
 }
 void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,
-                        mpr_tile_node* tiles, int count, int cols, const int* owner, int rank)
+                        mpr_tile_node* tiles, int count, int cols, const int* owner, int rank, mpr_tile_node* children, int t0)
 {
     const size_t n4 = zero_words / 4;             /* the arena's parts are padded to 64 words */
-    const size_t want = std::max(n4, (size_t)count);
+    const size_t want = std::max(n4, (size_t)count * (children ? 64 : 1));
     const int blocks = (int)std::min<size_t>((want + 255) / 256, 4096);
     hipLaunchKernelGGL(k_preload_tiles, dim3(std::max(blocks, 1)), dim3(256), 0, s, reinterpret_cast<int4*>(zero_base), n4,
-                       tape_index, tape_len, num_active, tiles, count, cols, owner, rank);
+                       tape_index, tape_len, num_active, tiles, count, cols, owner, rank, children, t0);
+}
+void launch_zero_owned(hipStream_t s, int* arena, bool with_normals, int S, const int* owner, int rank)
+{
+    hipLaunchKernelGGL(k_zero_owned, dim3(1024), dim3(256), 0, s, arena, with_normals ? 1 : 0, S, owner, rank);
 }
 size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + (size_t)choice_cap * 16 + (nslots > 128 ? 1024 : 0); }
 /* Slots in registers (k_eval_tiles<.., .., VS>) when that puts more wavefronts on a CU than the LDS planes do: up to 24

@@ -52,9 +52,11 @@ struct TileStageArgs {
     int heat_stride;           /* = image size in pixels */
     int* next_choices;         /* device counter (atomicMax): an upper bound on the min / max clauses of any tape this
                                 * stage pushes; sizes the next stage's choice array */
-    bool no_push;              /* last stage, float AND normals pass on the groups' tapes: write the groups' records only, push no tapes */
+    bool no_push;              /* last stage, float AND normals pass on the groups' tapes: write the groups' records only, push no tapes
+                                * (with len_stats: a sixteenth of the groups still pushes, into chunks nobody reads, to measure) */
     bool vgpr_slots;           /* tapes with many slots: the assembly walk with the slot file in registers (MPR_TILES_VGPR=0: never) */
     bool compiled_walk;        /* development (MPR_TILES_ASM=0): the compiled forward / backward walks instead of the assembly ones */
+    int measure_at[2], measure_len;   /* the sample len_stats is taken over: groups [measure_at[k], measure_at[k] + measure_len) */
     int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
                                 * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */
 };
@@ -111,8 +113,10 @@ struct NormalArgs {
     bool vgpr_slots;           /* tapes with many slots: the slot file in registers (MPR_TILES_VGPR=0: never) */
 };
 
+/* children != null (3-D frames that start at the 16^3 tiles): also the 64 children of every first-stage tile, t0 = S / 64 */
 void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,
-                        mpr_tile_node* tiles, int count, int cols, const int* owner, int rank);
+                        mpr_tile_node* tiles, int count, int cols, const int* owner, int rank, mpr_tile_node* children = nullptr, int t0 = 0);
+void launch_zero_owned(hipStream_t s, int* arena, bool with_normals, int S, const int* owner, int rank);
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,

@@ -350,11 +350,12 @@ k_eval_normals_q(NormalArgs a)
     const uint32_t ux = mpr_f2u(quad_bcast(mpr_u2f(u), 0)), uy = mpr_f2u(quad_bcast(mpr_u2f(u), 1)),
                    uz = mpr_f2u(quad_bcast(mpr_u2f(u), 2));
     if (filled && comp == 0) a.output[pxy] = (0xFFu << 24) | (uz << 16) | (uy << 8) | ux;
+    const unsigned long long npx = (unsigned long long)(__popcll(ballot(filled)) / 4);
     if (a.counters && lane == 0) {
         atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)words_total);
         atomicAdd((unsigned long long*)&a.counters[CNT_FWD_NORM], (unsigned long long)words_total);
         atomicAdd((unsigned long long*)&a.counters[CNT_LANE], (unsigned long long)lane_clauses);
-        atomicAdd((unsigned long long*)&a.counters[CNT_NORMAL_PX], (unsigned long long)(__popcll(ballot(filled)) / 4));
+        atomicAdd((unsigned long long*)&a.counters[CNT_NORMAL_PX], npx);
     }
 }
 

@@ -58,8 +58,8 @@ def compare_frame(mpr, orc, tape, dim, S, mat, z=0.0, check_tapes=True):
 
 def check_default_path(mpr, ref, tape, dim, S, mat, z=0.0, frames=3):
     """compare_frame runs instrumented frames (work counters on: compiled interpreters, every tape pushed).  This is the
-    path a caller gets — generated code in the float pass, and from the second frame of the same tape and view on no
-    tapes from the last tile stage where that pays — against the same oracle frame: heights / occupancy and normals."""
+    path a caller gets — generated code in the float pass, no tapes from the last tile stage where that pays, 3-D frames up to
+    1024^3 of narrow DAGs from the 16^3 tiles down — against the same oracle frame: heights / occupancy and normals."""
     ctx = mpr.Context(S)
     kinds = []
     for _ in range(frames):

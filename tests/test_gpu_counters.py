@@ -48,9 +48,10 @@ def test_counters_3d_inside_the_oracles_bounds(mpr, orc, tapes, name, S):
     assert ref["clauses_written_survivors"] <= got["clauses_written"]
     slack = ref["clauses_written"] - ref["clauses_written_survivors"]        # what the oracle's own order wrote for tiles culled later
     assert got["clauses_written"] <= ref["clauses_written_survivors"] + 4 * slack + evaluated // 100 + 64
-    # forward / backward words of the tile stages: groups that lose all their tiles to a neighbour's fill before they start
-    # are not walked at all, so only loose agreement is asserted (2 %)
+    # forward / backward words of the tile stages: a group is walked when one of its tiles is still visible as its wave starts.
+    # The oracle culls before a stage with the fills of EARLIER stages only (mask_filled_tiles as its own pass, :1335); here that
+    # test is fused into the evaluation and also sees fills of waves of the same launch, so fewer groups may be walked, never more
     ft = got["clauses_fwd"] - got["clauses_fwd_voxels"] - got["clauses_fwd_normals"]
-    assert abs(ft - ref["clauses_fwd_tiles"]) <= 0.02 * ref["clauses_fwd_tiles"] + 64
-    assert abs(got["clauses_bwd"] - ref["clauses_bwd"]) <= 0.02 * ref["clauses_bwd"] + 64
+    assert 0.8 * ref["clauses_fwd_tiles"] <= ft <= ref["clauses_fwd_tiles"]
+    assert 0.8 * ref["clauses_bwd"] - 64 <= got["clauses_bwd"] <= ref["clauses_bwd"] + 64
     assert got["normal_pixels"] == ref["normal_pixels"]

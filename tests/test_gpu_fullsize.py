@@ -35,14 +35,14 @@ def test_bear_1024_full_frame(mpr, orc, tapes):
     assert cnt["voxel_tiles"] > 500000
     kinds = check_default_path(mpr, ref, tapes("bear"), 3, 1024, view3())
     # generated code, one translation per group of 64 tiles; from the second frame on no tapes from the last tile stage
-    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [True, False, False], kinds
+    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [False, False, False], kinds
 
 
 def test_architecture_2048_full_frame(mpr, orc, tapes):
     cnt, ref = compare_frame(mpr, orc, tapes("architecture"), 3, 2048, view3())
     assert (ref.image > 0).sum() > 1000000
     kinds = check_default_path(mpr, ref, tapes("architecture"), 3, 2048, view3())
-    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [True, False, False], kinds
+    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [False, False, False], kinds
 
 
 def test_architecture_2048_sharded_over_three_contexts(mpr, orc, tapes):

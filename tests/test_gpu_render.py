@@ -225,6 +225,12 @@ def test_planned_gather_through_the_renderer(mpr, tapes):
             assert np.array_equal(ctxs[r].image, want_h)
             assert np.array_equal(ctxs[r].normals, want_n)
     assert not any(c.last_stage_pushed() for c in ctxs)
+    # a reader of counters / tiles makes a rank render its columns again the reference's way: the columns the other ranks sent
+    # stay in place (the re-render used to clear the whole image)
+    for r, c in enumerate(ctxs):
+        cnt = c.counters()
+        assert c.last_stage_pushed() and cnt["tape_index"] > 0
+        assert np.array_equal(c.image, want_h) and np.array_equal(c.normals, want_n)
     for c in ctxs:
         c.close()
 
@@ -313,6 +319,7 @@ def test_code_ring_against_an_invalidate_per_group(mpr, tapes, name, dim, S, mon
     (MPR_JIT_GAP) falls back to it by itself: all three give the same frame, repeatedly."""
     tape = tapes(name)
     monkeypatch.setenv("MPR_VOXEL_GROUPS", "2")
+    monkeypatch.setenv("MPR_WIDE_LATER", "0")      # a level-parallel last stage keeps no decision masks: group form off
     ring = mpr.Context(S)
     monkeypatch.setenv("MPR_VOXEL_JIT", "3")
     every = mpr.Context(S)
@@ -364,63 +371,80 @@ def test_level_parallel_later_stages_match_oracle(mpr, orc, tapes, name, dim, S,
 @pytest.mark.parametrize("name,S", [("bear", 256), ("architecture", 512), ("hello_world", 256), ("involute_gear_3d", 256), ("trig", 128),
                                     ("two_spheres", 128)])
 def test_frames_without_last_stage_tapes(mpr, orc, tapes, name, S, monkeypatch):
-    """A frame that repeats the tape and view of the frame before it, where that frame found the float pass's group
-    form worth it, pushes no tapes in its last tile stage: float and normals pass walk the groups' tapes with every
-    tile's decisions applied.  Heights and normals are those of the first (full) frame and of the oracle; reading tiles or
-    tapes afterwards gives the full frame's (the context renders it again); a new view starts with a full frame."""
+    """By default a frame's last tile stage pushes no tapes when the float and the normals pass can walk the groups' tapes with
+    every tile's decisions applied — decided by the stage's own measurement, every frame, the first one of a tape included — and
+    a 3-D frame of this size starts at the 16^3 tiles (bear: narrow DAG; the others keep the level-parallel first stage).
+    Heights and normals are the oracle's; reading tiles or tapes afterwards gives the reference's state (the context renders
+    the frame again the reference's way); a tape whose last stage shortens too much gets its tapes from a second run of that
+    stage once and pushes straight away from then on."""
     monkeypatch.setenv("MPR_WIDE_LATER", "0")
-    monkeypatch.setenv("MPR_LEAN_PERIOD", "2")
     tape = tapes(name)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
     ctx = mpr.Context(S)
-    ctx.render3D(tape, view3())
-    assert ctx.last_stage_pushed()
-    first_h, first_n = ctx.image.copy(), ctx.normals.copy()
-    assert np.array_equal(first_h, ref.filled[3]) and np.array_equal(first_n, ref.normals)
-    lean = 0
-    for _ in range(3):                                 # without, without, measuring
+    kinds = []
+    for _ in range(4):
         ctx.render3D(tape, view3())
-        lean += not ctx.last_stage_pushed()
-        assert np.array_equal(ctx.image, first_h)
-        bad = np.flatnonzero(ctx.normals.ravel() != first_n.ravel())
-        assert bad.size == 0, (bad.size, [(hex(ctx.normals.ravel()[i]), hex(first_n.ravel()[i])) for i in bad[:5]])
+        kinds.append((ctx.last_stage_pushed(), ctx.float_kernel().split("<")[0]))
+        assert np.array_equal(ctx.image, ref.filled[3])
+        bad = np.flatnonzero(ctx.normals.ravel() != ref.normals.ravel())
+        assert bad.size == 0, (bad.size, kinds, [(hex(ctx.normals.ravel()[i]), hex(ref.normals.ravel()[i])) for i in bad[:5]])
     if name == "bear":
-        assert lean == 2, ctx.float_kernel()           # (the last stage of the others shortens its tapes too much at this size)
-    # the reference's state on request: tiles and tapes as a full frame leaves them
-    full = mpr.Context(S, flags=0)
+        assert kinds == [(False, "k_eval_voxels_jit_groups")] * 4, kinds           # no tapes from the very first frame
+    if name == "involute_gear_3d":
+        assert all(k == (True, "k_eval_voxels_asm") for k in kinds), kinds         # per-tile tapes: measured by the first frame, known after
+    # the reference's state on request: tiles and tapes as a frame rendered the reference's way leaves them
     monkeypatch.setenv("MPR_LAST_STAGE_PUSH", "1")
     always = mpr.Context(S)
+    monkeypatch.delenv("MPR_LAST_STAGE_PUSH")
     for _ in range(2):
         always.render3D(tape, view3())
-    assert always.last_stage_pushed()
+        assert always.last_stage_pushed()
+        assert np.array_equal(always.image, ref.filled[3]) and np.array_equal(always.normals, ref.normals)
     ctx.render3D(tape, view3())
-    if name == "bear":
-        assert not ctx.last_stage_pushed()             # a frame without tapes again
     pool, apool = ctx.tape_data, always.tape_data
-    assert ctx.last_stage_pushed()                     # reading rendered the frame again, with tapes
-    for s in (2, 3):
+    assert ctx.last_stage_pushed()                     # reading rendered the frame again, the reference's way
+    for s in (0, 1, 2, 3):
         g, a = ctx.stages[s].tiles, always.stages[s].tiles
+        assert g.size == a.size == ref.tiles[s].size
         g, a = g[g["position"] != -1], a[a["position"] != -1]
         g, a = g[np.argsort(g["position"])], a[np.argsort(a["position"])]
         assert np.array_equal(g["position"], a["position"])
         glen, gh = orc.tiles_digest(pool, g)
         alen, ah = orc.tiles_digest(apool, a)
         assert np.array_equal(glen, alen) and np.array_equal(gh, ah)
-    assert np.array_equal(ctx.image, first_h) and np.array_equal(ctx.normals, first_n)
-    # another view of the same tape: the oracle's image again, without tapes from the start (what the last measuring
-    # frame found holds for the model), with a measuring frame after every MPR_LEAN_PERIOD frames without
+    assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals)
+    # another view of the same tape: the oracle's image again
     T = view3().copy()
     T[0, 3] = 0.125
     ref2 = orc.Frame(tape.data, 3, S, mpr.colmajor(T, 4), threads=0)
-    kinds = []
-    for k in range(5):
+    for k in range(3):
         ctx.render3D(tape, T)
-        kinds.append(ctx.last_stage_pushed())
         assert np.array_equal(ctx.image, ref2.filled[3]) and np.array_equal(ctx.normals, ref2.normals)
     if name == "bear":
-        assert kinds == [False, False, True, False, False], kinds      # (the reader above rendered a full frame: the count restarted)
-    for c in (ctx, full, always):
+        assert not ctx.last_stage_pushed()
+    for c in (ctx, always):
         c.close()
+
+
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 1024), ("hello_world", 256), ("trig", 128), ("many_slots", 128)])
+def test_frames_that_start_at_the_16px_tiles(mpr, orc, tapes, name, S, monkeypatch):
+    """3-D frames nobody inspects start at the 16^3 tiles when the 64^3 stage would be a handful of wavefronts walking the whole
+    tape (context.hip: skip0).  Same heights and normals as with the first stage (MPR_SKIP_STAGE0=0) and as the oracle."""
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    fast = mpr.Context(S)
+    monkeypatch.setenv("MPR_SKIP_STAGE0", "0")
+    slow = mpr.Context(S)
+    for ctx in (fast, slow):
+        for _ in range(2):
+            ctx.render3D(tape, view3())
+            assert np.array_equal(ctx.image, ref.filled[3]), int((ctx.image != ref.filled[3]).sum())
+            assert np.array_equal(ctx.normals, ref.normals), int((ctx.normals != ref.normals).sum())
+    # a reader gets the reference's first stage back
+    t0 = fast.stages[0].tiles
+    assert np.array_equal(np.sort(t0["position"][t0["next"] != -1]), np.sort(ref.tiles[0]["position"][ref.tiles[0]["next"] != -1]))
+    fast.close()
+    slow.close()
 
 
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("trig", 2, 256),
