@@ -274,6 +274,9 @@ int mpr_test_float_op(int32_t device, int32_t op, int32_t n, const float* a, con
  * variant 0: operands from the slot file, 1 / 2: lhs / rhs forwarded from the previous clause */
 int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n, const float* a,
                           const float* b, float imm, float* out);
+/* the square-root routine of the float interpreters and of the generated code on the bit patterns [first, first + count): the
+ * number of results that are not the correctly rounded root (NaN for NaN counts as equal), and one such input */
+int mpr_test_sqrt_all(int32_t device, uint64_t first, uint64_t count, uint64_t* mismatches, uint32_t* example);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
                       float imm, float* out4);

@@ -185,6 +185,7 @@ def lib():
     L.mpr_test_float_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
+    L.mpr_test_sqrt_all.argtypes = [i32, ctypes.c_uint64, ctypes.c_uint64, vp, vp]
     L.mpr_test_jit_row.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_uint32, i32, vp, i32]
     _LIB = L
     return L
@@ -680,6 +681,15 @@ def dev_float_op(op, a, b=None, imm=0.0, device=0, asm=False, variant=0):
     else:
         _check(lib().mpr_test_float_op(device, op, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
     return out
+
+
+def dev_sqrt_all(first=0, count=1 << 32, device=0):
+    """The float pass's square-root routine on the bit patterns [first, first + count): (mismatches against the correctly
+    rounded root, one offending bit pattern)."""
+    bad = ctypes.c_uint64(0)
+    ex = ctypes.c_uint32(0)
+    _check(lib().mpr_test_sqrt_all(device, first, count, ctypes.byref(bad), ctypes.byref(ex)))
+    return int(bad.value), int(ex.value)
 
 
 def dev_deriv_op(op, a4, b4=None, imm=0.0, device=0):

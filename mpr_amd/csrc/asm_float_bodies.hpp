@@ -4,8 +4,13 @@
  * inline-asm text.  Register convention: argument v35 (division: v35 / v36), result v37,
  * temporaries v38..v42, s91, s[92:95], vcc; s90 must hold 0x260 (class mask of the square root).
  * Each is, instruction for instruction, what the compiler makes of the C++ definition
- * (IEEE division and square root expansions; mpr_expf / mpr_logf of include/mpr_fmath.h), so the
+ * (IEEE division; mpr_expf / mpr_logf of include/mpr_fmath.h; the square root see below), so the
  * results are bit-identical to the compiled interpreters and to the oracle.
+ *
+ * Square root, exp and log come in two pieces: MPR_ASM_x_BODY is the path every lane of an ordinary frame takes, straight
+ * through, without a taken branch (a taken branch costs a wavefront about 20 cycles, as much as five dependent VALU
+ * instructions: scripts/ubench/branch_cost.hip); MPR_ASM_x_TAIL holds the rare cases (tiny or special operands), entered by
+ * a branch from the body and left by a branch back to its end.  Put the tail behind the jump that ends the routine.
  */
 #pragma once
 
@@ -22,26 +27,30 @@
     "v_div_fmas_f32 v38, v38, v39, v41\n" \
     "v_div_fixup_f32 v37, v38, v36, v35\n"
 
-/* Fast path when every lane's operand is a positive normal number >= 2^-96 (one unsigned compare of the bits): no
- * scaling of tiny operands, no special values: v_sqrt_f32 is within one ulp, the two residuals say on which side. */
+/* Fast path when every lane's operand is a positive normal number >= 2^-96 (one unsigned compare of the bits): no scaling of
+ * tiny operands, no special values.  y = v_rsq_f32(x) is 1 / sqrt(x) to about an ulp; g = x y and h = y / 2 get one coupled
+ * Newton step (r = 1/2 - h g; g += g r; h += h r), and the last step adds the exact residual of g times h: g + (x - g g) h.
+ * That sum, before its one rounding, is within 2^-50 (relative) of sqrt(x), and no square root of a float lies that close to the
+ * middle between two floats (the closest miss it by more than 2^-49): the rounded sum IS the correctly rounded root — the value
+ * sqrtf / __builtin_sqrtf return and the oracle computes.  Checked on the device for every float (mpr_test_sqrt_all:
+ * tests/test_gpu_primitives.py).  7 full-rate instructions and the quarter-rate v_rsq_f32, where v_sqrt_f32 + two residual
+ * tests + selects took 5 full-rate, 5 half-rate and the quarter-rate one: a fifth of the float pass's issue time for bear. */
 #define MPR_ASM_SQRT_BODY \
     "v_add_u32 v38, 0xf0800000, v35\n"                 /* bits - 0x0f800000 */ \
     "v_cmp_gt_u32 vcc, 0x70000000, v38\n"              /* < 0x7f800000 - 0x0f800000: positive, normal, finite, not tiny */ \
     "s_cmp_eq_u64 vcc, exec\n" \
     "s_cbranch_scc0 L_sqrtslow_%=\n" \
-    "v_sqrt_f32 v39, v35\n" \
+    "v_rsq_f32 v39, v35\n" \
     "s_nop 0\n" \
-    "v_add_u32 v40, -1, v39\n" \
-    "v_fma_f32 v41, -v40, v39, v35\n" \
-    "v_cmp_ge_f32 s[92:93], 0, v41\n" \
-    "v_add_u32 v41, 1, v39\n" \
-    "s_nop 0\n" \
-    "v_cndmask_b32 v40, v39, v40, s[92:93]\n" \
-    "v_fma_f32 v39, -v41, v39, v35\n" \
-    "v_cmp_lt_f32 s[92:93], 0, v39\n" \
-    "s_nop 1\n" \
-    "v_cndmask_b32 v37, v40, v41, s[92:93]\n" \
-    "s_branch L_sqrtdone_%=\n" \
+    "v_mul_f32 v40, v35, v39\n"                        /* g */ \
+    "v_mul_f32 v39, 0.5, v39\n"                        /* h */ \
+    "v_fma_f32 v41, -v39, v40, 0.5\n"                  /* r */ \
+    "v_fmac_f32 v40, v40, v41\n" \
+    "v_fmac_f32 v39, v39, v41\n" \
+    "v_fma_f32 v41, -v40, v40, v35\n"                  /* x - g g, exactly */ \
+    "v_fma_f32 v37, v41, v39, v40\n" \
+    "L_sqrtdone_%=:\n"
+#define MPR_ASM_SQRT_TAIL \
     "L_sqrtslow_%=:\n" \
     "v_mul_f32 v38, 0x4f800000, v35\n" \
     "v_cmp_gt_f32 vcc, 0xf800000, v35\n" \
@@ -64,7 +73,7 @@
     "v_cmp_class_f32 vcc, v38, s90\n" \
     "s_nop 1\n" \
     "v_cndmask_b32 v37, v39, v38, vcc\n" \
-    "L_sqrtdone_%=:\n"
+    "s_branch L_sqrtdone_%=\n"
 
 #define MPR_ASM_EXP_BODY \
     "v_mul_f32 v38, 0x3fb8aa3b, v35\n" \
@@ -89,7 +98,10 @@
     /* |x| <= 87 in every lane (NaN counts as not): none of the three special cases applies */ \
     "s_mov_b32 s91, 0x42ae0000\n" \
     "v_cmp_nle_f32 vcc, |v35|, s91\n" \
-    "s_cbranch_vccz L_expdone_%=\n" \
+    "s_cbranch_vccnz L_expspecial_%=\n" \
+    "L_expdone_%=:\n"
+#define MPR_ASM_EXP_TAIL \
+    "L_expspecial_%=:\n" \
     "s_mov_b32 s91, 0x42b17218\n" \
     "v_cmp_ngt_f32 vcc, 0xc2cff5c3, v35\n"          /* !(x < -103.98) */ \
     "v_cmp_nlt_f32 s[92:93], s91, v35\n"            /* !(x > 88.72284) */ \
@@ -98,7 +110,7 @@
     "v_cndmask_b32 v37, 0, v37, vcc\n" \
     "v_cndmask_b32 v37, v40, v37, s[92:93]\n" \
     "v_cndmask_b32 v37, v35, v37, s[94:95]\n" \
-    "L_expdone_%=:\n"
+    "s_branch L_expdone_%=\n"
 
 #define MPR_ASM_LOG_BODY \
     /* every lane a positive normal number: no subnormal scaling, none of the special results */ \
@@ -108,13 +120,7 @@
     "v_mov_b32 v38, v35\n" \
     "s_cmp_eq_u64 vcc, exec\n" \
     "s_cselect_b32 s91, 1, 0\n" \
-    "s_cbranch_scc1 L_logmain_%=\n" \
-    "v_mul_f32 v38, 0x4b000000, v35\n" \
-    "v_cmp_gt_u32 vcc, 0x800000, v35\n"             /* subnormal: scale by 2^23 */ \
-    "v_mov_b32 v41, 0xffffff6b\n" \
-    "s_nop 0\n" \
-    "v_cndmask_b32 v38, v35, v38, vcc\n" \
-    "v_cndmask_b32 v40, v40, v41, vcc\n" \
+    "s_cbranch_scc0 L_logscale_%=\n" \
     "L_logmain_%=:\n" \
     "v_lshrrev_b32 v39, 23, v38\n" \
     "v_add_u32 v39, v39, v40\n"                     /* e */ \
@@ -145,7 +151,18 @@
     "v_add_f32 v40, v38, v40\n" \
     "v_fmamk_f32 v37, v39, 0x3f318000, v40\n" \
     "s_cmp_eq_u32 s91, 1\n" \
-    "s_cbranch_scc1 L_logdone_%=\n" \
+    "s_cbranch_scc0 L_logspecial_%=\n" \
+    "L_logdone_%=:\n"
+#define MPR_ASM_LOG_TAIL \
+    "L_logscale_%=:\n" \
+    "v_mul_f32 v38, 0x4b000000, v35\n" \
+    "v_cmp_gt_u32 vcc, 0x800000, v35\n"             /* subnormal: scale by 2^23 */ \
+    "v_mov_b32 v41, 0xffffff6b\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v38, v35, v38, vcc\n" \
+    "v_cndmask_b32 v40, v40, v41, vcc\n" \
+    "s_branch L_logmain_%=\n" \
+    "L_logspecial_%=:\n" \
     "v_cmp_ne_u32 vcc, 0x7f800000, v35\n"           /* log(+inf) = +inf */ \
     "v_mov_b32 v40, 0xff800000\n" \
     "v_mov_b32 v41, 0x7fc00000\n" \
@@ -159,7 +176,7 @@
     "v_cmp_u_f32 vcc, v35, v35\n"                   /* NaN in, the same NaN out */ \
     "s_nop 1\n" \
     "v_cndmask_b32 v37, v37, v35, vcc\n" \
-    "L_logdone_%=:\n"
+    "s_branch L_logdone_%=\n"
 
 /* v37 = mpr_sinf(v35), v36 = mpr_cosf(v35) (include/mpr_fmath.h): double-precision Cody-Waite
  * reduction by pi/2, the two Cephes polynomials, quadrant by selects instead of the switch.

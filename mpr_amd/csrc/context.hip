@@ -112,6 +112,20 @@ struct mpr_context {
     bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
+    /* pipelined tail of a 3-D frame: last tile stage on `stream`, float pass beside it on `stream2` (kernels.hpp: PIPE_*) */
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int* pipe_slots = nullptr;
+    size_t pipe_slots_cap = 0;
+    int* pipe_ctl = nullptr;
+    bool pipeline = false;             /* MPR_PIPELINE=1 (off by default: measured, no gain — the two kernels take as long side by side as
+                                          one after the other, both being bound by the time their vector instructions take to issue;
+                                          DESIGN.md 8) */
+    int pipe_wgs = 4;                  /* MPR_PIPE_WGS: workgroups per CU of the float pass while the tile stage runs (the rest follow behind it) */
+    bool pipe_vs = false;              /* MPR_PIPE_VS=1: the tile stage keeps its slots in registers while pipelined (fewer waves beside the float pass) */
+    bool last_frame_piped = false;
+    int piped_since_measure = 0;
+    int jit_wgs_per_cu = 0;            /* MPR_JIT_WGS (development): workgroups per CU of the group form's persistent grid */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     bool jit_always_invalidate = false;/* MPR_VOXEL_JIT=3 (development): the group form invalidates the instruction cache after every translation */
     bool jit_validated_arch = false;   /* gfx950: the ring's one-invalidate-per-trip was validated there and nowhere else */
@@ -264,7 +278,9 @@ struct TimedScope {
     mpr_context* c;
     bool on;
     size_t idx = 0;
-    TimedScope(mpr_context* ctx, const char* name) : c(ctx), on((ctx->flags & MPR_CTX_TIMING) != 0)
+    hipStream_t st;
+    TimedScope(mpr_context* ctx, const char* name, hipStream_t on_stream = nullptr)
+        : c(ctx), on((ctx->flags & MPR_CTX_TIMING) != 0), st(on_stream ? on_stream : ctx->stream)
     {
         if (!on) return;
         if (c->timings_used == c->timings.size()) {
@@ -278,11 +294,11 @@ struct TimedScope {
         }
         idx = c->timings_used++;
         c->timings[idx].name = name;
-        (void)hipEventRecord(c->timings[idx].start, c->stream);
+        (void)hipEventRecord(c->timings[idx].start, st);
     }
     ~TimedScope()
     {
-        if (on) (void)hipEventRecord(c->timings[idx].stop, c->stream);
+        if (on) (void)hipEventRecord(c->timings[idx].stop, st);
     }
 };
 
@@ -310,6 +326,10 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; c->jit_always_invalidate = atoi(e) == 3; }
     if (const char* e = getenv("MPR_VOXEL_GROUPS")) { c->voxel_groups = atoi(e) != 0; c->groups_always = atoi(e) == 2; }
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
+    if (const char* e = getenv("MPR_JIT_WGS")) c->jit_wgs_per_cu = atoi(e);
+    if (const char* e = getenv("MPR_PIPELINE")) c->pipeline = atoi(e) != 0;
+    if (const char* e = getenv("MPR_PIPE_WGS")) c->pipe_wgs = std::max(atoi(e), 1);
+    if (const char* e = getenv("MPR_PIPE_VS")) c->pipe_vs = atoi(e) != 0;
     if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
     {
         hipDeviceProp_t prop;
@@ -346,6 +366,10 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
         }                                                            \
     } while (0)
     CT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CT(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    CT(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CT(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    CT(hipMalloc((void**)&c->pipe_ctl, mprk::PIPE_CTL_WORDS * sizeof(int)));
     {
         /* the four filled images and the normals (src/context.cpp:21-27) live in one allocation, in this
          * order, so that one kernel resets them at the start of a frame (mprk::launch_begin_frame) */
@@ -431,6 +455,11 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->sched_levels) (void)hipFree(c->sched_levels);
     if (c->sched_prev) (void)hipFree(c->sched_prev);
     if (c->sched_defs) (void)hipFree(c->sched_defs);
+    if (c->pipe_slots) (void)hipFree(c->pipe_slots);
+    if (c->pipe_ctl) (void)hipFree(c->pipe_ctl);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -556,6 +585,51 @@ static void fill_mat(float dst[16], const float* src, int n)
     std::memcpy(dst, src, (size_t)n * sizeof(float));
 }
 
+/* Generated code for the float pass: sizes of a code region, the persistent grid, and the executable buffer itself.
+ * Tile form: a region per wavefront; group form: one per workgroup.  A region holds the root tape's code length (the bound
+ * for every tape shortened from it) plus 64 dwords the instruction prefetch may run into, and 320 dwords the translator
+ * dumps into.  ok = false: no generated code for this tape (too many slots) or on this system (no executable memory). */
+struct JitPlan {
+    bool ok = false;
+    size_t region = 0, slot_dw = 0, nslot = 1;
+    int grid = 0;
+    bool always_inv = false;
+};
+static int jit_prepare(mpr_context* c, const mpr_tape* tape, int dim, int nslots, bool gf, JitPlan* out)
+{
+    *out = JitPlan();
+    if (!(c->voxel_jit && c->voxel_asm && mprk::jit_slot_class(nslots) != 0 && c->cus > 0)) return MPR_OK;
+    const size_t code_dw = mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size(), gf);
+    /* group form: a ring of slots 4 KB apart (MPR_JIT_GAP, dwords: development), as many as fit 256 KB, at most 16 */
+    const size_t gap_dw = gf ? (c->jit_gap > 0 ? (size_t)c->jit_gap : 1024) : 64;
+    out->slot_dw = ((code_dw + gap_dw + 63) / 64) * 64;
+    out->nslot = (gf && c->jit_slots != 1) ? std::min<size_t>(c->jit_slots > 0 ? (size_t)c->jit_slots : 16, std::max<size_t>(1, (size_t)65536 / out->slot_dw)) : 1;
+    out->region = out->slot_dw * out->nslot + 320;
+    const int cls = mprk::jit_slot_class(nslots);
+    int& grid = c->jit_grid_cache[gf ? 1 : 0][dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];
+    if (grid == 0) grid = mprk::jit_grid(dim, nslots, c->cus, gf);
+    out->grid = grid;
+    if (gf && c->jit_wgs_per_cu > 0) out->grid = std::min(grid, c->jit_wgs_per_cu * c->cus);      /* development */
+    /* A slot's code must not be reached by the sequential instruction prefetch of its neighbour before it is written: 256 B
+     * between slots executed stale code, 1 KB did not, 4 KB (1024 dwords) is the validated margin.  Anything closer, or
+     * another device, pays the invalidate per group. */
+    out->always_inv = c->jit_always_invalidate || gap_dw < 1024 || !c->jit_validated_arch;
+    const size_t need = (size_t)grid * out->region * sizeof(uint32_t);
+    if (need > ((size_t)4 << 30)) return MPR_OK;
+    if (need > c->jit_code_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        free_executable(c->jit_code);
+        c->jit_code = nullptr;
+        c->jit_code_bytes = 0;
+        const size_t want = std::max(need, (size_t)32 << 20);
+        c->jit_code = static_cast<uint32_t*>(alloc_executable(c->device, want));
+        if (c->jit_code) c->jit_code_bytes = want;
+        else c->voxel_jit = false;          /* no executable memory on this system: the interpreter from now on */
+    }
+    out->ok = c->jit_code != nullptr;
+    return MPR_OK;
+}
+
 static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const float* mat, float z,
                         const int32_t* owner, int rank, bool brute, bool blocking)
 {
@@ -605,7 +679,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     /* the reference's way (every stage from the 64 px tiles down, every tape pushed): asked for, or a frame that is inspected */
     const bool reference = c->reference_frames || c->force_reference || brute || cnt || heat;
     int hint = (c->hint_serial == tape->serial && c->hint_dim == dim) ? c->hint_mode : (int)mpr_context::HINT_UNKNOWN;
-    bool lean_now = false;
+    bool lean_now = false, piped = false;
     /* 3-D: the 64^3 stage of a frame up to 1024^3 is 64 wavefronts walking the whole tape one clause after the other — 0.15 ms
      * of latency on an idle chip — while ALL of its 16^3 tiles are one round of wavefronts for the next stage.  A
      * frame nobody inspects starts there: every 64^3 tile counts as ambiguous.  The hierarchy is conservative at every level, so
@@ -694,6 +768,35 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             group_cap = std::max(stage_cap, 1);
         }
         mprk::TileStageArgs a;
+        a.pipe_slots = nullptr;
+        a.pipe_ctl = nullptr;
+        /* Pipelined tail (3-D, a tape known to take the group form, a launch of several rounds of wavefronts): the last tile
+         * stage and the float pass at the same time, as producer and consumer of a queue of groups (kernels.hpp: PIPE_*).  The
+         * stage's wavefronts are dependent chains that leave the vector units half idle, the float pass is bound by their issue
+         * rate: side by side they take about as long as the float pass alone.  No compaction in between: the float pass gets
+         * every tile that was ambiguous when its wavefront finished and leaves the hidden ones at its skip test. */
+        JitPlan pipe_plan;
+        bool pipe_now = last && dim == 3 && try_lean && hint == mpr_context::HINT_GROUPS && c->pipeline && !wide_now &&
+                        count >= 128 * std::max(c->cus, 1) && (c->zsort & 2) && c->piped_since_measure < 63;
+        /* (a pipelined frame measures nothing — nobody could read the sample in time —, so every 64th frame of a tape is not
+         * pipelined and looks at how much its last stage shortens, in case the view has drifted) */
+        if (last && groups_now) c->piped_since_measure = pipe_now ? c->piped_since_measure + 1 : 0;
+        if (pipe_now) {
+            rc = jit_prepare(c, tape, dim, nslots, true, &pipe_plan);
+            if (rc) return rc;
+            pipe_now = pipe_plan.ok && pipe_plan.grid > c->cus;
+        }
+        if (pipe_now) {
+            const int ng = (count + 63) / 64;
+            rc = ensure_buffer(&c->pipe_slots, &c->pipe_slots_cap, (size_t)ng);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(c->pipe_slots, 0, (size_t)ng * sizeof(int), s));
+            HIP_TRY(hipMemsetAsync(c->pipe_ctl, 0, mprk::PIPE_CTL_WORDS * sizeof(int), s));
+            HIP_TRY(hipEventRecord(c->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            a.pipe_slots = c->pipe_slots;
+            a.pipe_ctl = c->pipe_ctl;
+        }
         if (count > 0) {
             a.groups = groups_now ? c->groups : nullptr;
             a.choice_masks = groups_now ? c->choice_masks : nullptr;
@@ -721,10 +824,10 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 if (!try_lean || hint == mpr_context::HINT_UNKNOWN) a.measure_len = std::max(ng / 32, std::min(ng, 4));
                 else a.measure_len = ng >= 32 * std::max(c->cus, 1) ? ng / 128 : 0;
                 if (c->measure_len_forced >= 0) a.measure_len = c->measure_len_forced;
-                if (a.measure_len == 0 && groups_now) a.len_stats = nullptr;
+                if ((a.measure_len == 0 && groups_now) || pipe_now) a.len_stats = nullptr;      /* (a pipelined frame has nobody to read the sample in time) */
             }
             a.compiled_walk = !c->tiles_asm;
-            a.vgpr_slots = c->tiles_vgpr;
+            a.vgpr_slots = pipe_now ? (c->tiles_vgpr && c->pipe_vs) : c->tiles_vgpr;
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
@@ -761,6 +864,54 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             } else {
                 mprk::launch_eval_tiles(s, dim, a);
             }
+        }
+        if (pipe_now) {
+            /* behind the stage on its stream: the flag that says the queue is complete, then the rest of the float pass's
+             * workgroups (the chip has room for them once the stage's wavefronts are gone); beside it on the second stream: the
+             * float pass itself */
+            mprk::launch_pipe_done(s, c->pipe_ctl);
+            mprk::VoxelArgs v;
+            v.tape_ro = c->pool;
+            v.image = c->filled[3];
+            v.tps = S / 4;
+            v.tiles = c->tiles[i];
+            v.count = count;
+            v.nslots = nslots;
+            v.z = z;
+            fill_mat(v.mat, mat, 16);
+            v.counters = nullptr;
+            v.heat = nullptr;
+            v.vgpr_slots = c->tiles_vgpr;
+            const int g1 = std::min(pipe_plan.grid, c->pipe_wgs * c->cus), g2 = pipe_plan.grid - g1;
+            group_cap = std::max(stage_cap, 1);
+            {
+                TimedScope ts(c, "eval_voxels_f", c->stream2);
+                mprk::launch_eval_voxels_jit_pipe(c->stream2, v, c->jit_code, (uint32_t)pipe_plan.region, (int)pipe_plan.slot_dw, (int)pipe_plan.nslot, g1, 0,
+                                                  (int)tape->clauses.size(), c->groups, c->choice_masks, group_cap, c->pipe_slots, c->pipe_ctl,
+                                                  c->filled[2], pipe_plan.always_inv, c->pub_dev + 15);
+            }
+            if (g2 > 0) {
+                TimedScope ts(c, "eval_voxels_f_behind");
+                mprk::launch_eval_voxels_jit_pipe(s, v, c->jit_code, (uint32_t)pipe_plan.region, (int)pipe_plan.slot_dw, (int)pipe_plan.nslot, g2, g1,
+                                                  (int)tape->clauses.size(), c->groups, c->choice_masks, group_cap, c->pipe_slots, c->pipe_ctl,
+                                                  c->filled[2], pipe_plan.always_inv, c->pub_dev + 15);
+            }
+            HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            {
+                TimedScope ts(c, "copy_filled");
+                mprk::launch_merge_filled(s, c->filled[2], c->filled[3], S);
+            }
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit_groups<3, %d, true>", mprk::jit_slot_class(nslots));
+            group_form = true;
+            group_stage = i;
+            group_count = count;
+            lean_now = true;
+            piped = true;
+            c->last.tiles_active[si] = -1;            /* nobody counted: a reader gets the frame again the reference's way */
+            count = 0;
+            c->tiles_n[next] = 0;
+            break;
         }
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
@@ -832,7 +983,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->tiles_n[next] = (size_t)count;
         prev_wide = wide_now && c->wide_later != 0;
     }
-    c->last.voxel_tiles = count;
+    c->last.voxel_tiles = piped ? -1 : count;
     if (count > 0) {
         mprk::VoxelArgs v;
         v.tape_ro = c->pool;
@@ -849,48 +1000,23 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         TimedScope ts(c, "eval_voxels_f");
         /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
         bool jitted = false;
-        if (c->voxel_jit && c->voxel_asm && !cnt && !heat && mprk::jit_slot_class(nslots) != 0 && c->cus > 0) {
-            /* every tape as machine code.  Tile form: a region per wavefront; group form: one per workgroup.  A region
-             * holds the root tape's code length (the bound for every tape shortened from it) plus 64 dwords the
-             * instruction prefetch may run into, and 320 dwords the translator dumps into. */
+        if (!cnt && !heat) {
+            /* every tape as machine code */
             const bool gf = group_form && !brute;
-            const size_t code_dw = mprk::jit_code_dwords(tape->clauses.data(), (int)tape->clauses.size(), gf);
-            /* group form: a ring of slots 4 KB apart (MPR_JIT_GAP, dwords: development), as many as fit 256 KB, at most 16 */
-            const size_t gap_dw = gf ? (c->jit_gap > 0 ? (size_t)c->jit_gap : 1024) : 64;
-            const size_t slot_dw = ((code_dw + gap_dw + 63) / 64) * 64;
-            const size_t nslot = (gf && c->jit_slots != 1) ? std::min<size_t>(c->jit_slots > 0 ? (size_t)c->jit_slots : 16, std::max<size_t>(1, (size_t)65536 / slot_dw)) : 1;
-            const size_t region = slot_dw * nslot + 320;
-            const int cls = mprk::jit_slot_class(nslots);
-            int& grid = c->jit_grid_cache[gf ? 1 : 0][dim - 2][cls == 24 ? 0 : cls == 40 ? 1 : cls == 96 ? 2 : 3];
-            if (grid == 0) grid = mprk::jit_grid(dim, nslots, c->cus, gf);
-            const size_t need = (size_t)grid * region * sizeof(uint32_t);
-            if (need <= ((size_t)4 << 30)) {
-                if (need > c->jit_code_bytes) {
-                    HIP_TRY(hipStreamSynchronize(s));
-                    free_executable(c->jit_code);
-                    c->jit_code = nullptr;
-                    c->jit_code_bytes = 0;
-                    const size_t want = std::max(need, (size_t)32 << 20);
-                    c->jit_code = static_cast<uint32_t*>(alloc_executable(c->device, want));
-                    if (c->jit_code) c->jit_code_bytes = want;
-                    else c->voxel_jit = false;          /* no executable memory on this system: the interpreter from now on */
-                }
-                if (c->jit_code && gf) {
-                    mprk::VoxelArgs gv = v;
-                    gv.tiles = c->tiles[group_stage];
-                    gv.count = group_count;
-                    /* A slot's code must not be reached by the sequential instruction prefetch of its neighbour before it is
-                     * written: 256 B between slots executed stale code, 1 KB did not, 4 KB (1024 dwords) is the validated
-                     * margin.  Anything closer, or another device, pays the invalidate per group. */
-                    const bool always_inv = c->jit_always_invalidate || gap_dw < 1024 || !c->jit_validated_arch;
-                    mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)region, (int)slot_dw, (int)nslot, grid, (int)tape->clauses.size(), c->groups,
-                                                 c->choice_masks, group_cap, c->num_active + 7, c->group_list, always_inv);
-                    jitted = true;
-                } else if (c->jit_code && !group_form && (brute || c->voxel_jit_tiles)) {
-                    mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)region, (int)slot_dw, 1, grid, (int)tape->clauses.size(), nullptr,
-                                                 nullptr, 0, nullptr, nullptr);
-                    jitted = true;
-                }
+            JitPlan jp;
+            rc = jit_prepare(c, tape, dim, nslots, gf, &jp);
+            if (rc) return rc;
+            if (jp.ok && gf) {
+                mprk::VoxelArgs gv = v;
+                gv.tiles = c->tiles[group_stage];
+                gv.count = group_count;
+                mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)jp.region, (int)jp.slot_dw, (int)jp.nslot, jp.grid, (int)tape->clauses.size(), c->groups,
+                                             c->choice_masks, group_cap, c->num_active + 7, c->group_list, jp.always_inv);
+                jitted = true;
+            } else if (jp.ok && !group_form && (brute || c->voxel_jit_tiles)) {
+                mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)jp.region, (int)jp.slot_dw, 1, jp.grid, (int)tape->clauses.size(), nullptr,
+                                             nullptr, 0, nullptr, nullptr);
+                jitted = true;
             }
         }
         if (lean_now && !(jitted && group_form)) {
@@ -955,6 +1081,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     c->pending_dim = dim;
     c->last_frame_lean = lean_now;
     c->last_frame_fast = lean_now || skip0;
+    c->last_frame_piped = piped;
     c->last_key = key;
     if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != tape->serial)) c->last_tape.reset(new mpr_tape(*tape));
     if (blocking) return mpr_ctx_sync(c);
@@ -986,6 +1113,11 @@ int mpr_ctx_sync(mpr_context* c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_pending = false;
+    if (c->pub_host[15] != 0) {
+        c->pub_host[15] = 0;
+        c->pipeline = false;
+        return mpr::set_error(MPR_ERR_NO_DEVICE, "pipelined frame: a float-pass workgroup waited 0.2 s for the last tile stage (pipelining is off from now on)");
+    }
     return MPR_OK;
 }
 
@@ -1493,6 +1625,24 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+/* the square-root routine of the float interpreters / generated code on the bit patterns [first, first + count): number of results
+ * that differ from the correctly rounded root, and one such input */
+int mpr_test_sqrt_all(int32_t device, uint64_t first, uint64_t count, uint64_t* mismatches, uint32_t* example)
+{
+    if (!mismatches) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf d;
+    HIP_TRY(d.alloc(16));
+    HIP_TRY(hipMemset(d.p, 0, 16));
+    mprk::launch_test_sqrt_all(nullptr, first, count, (unsigned long long*)d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost));
+    *mismatches = h[0];
+    if (example) *example = (uint32_t)h[1];
     return MPR_OK;
 }
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4, float imm, float* out4)

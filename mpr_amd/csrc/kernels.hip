@@ -351,14 +351,47 @@ k_eval_tiles(TileStageArgs a)
          * surviving child with the child's decisions applied (kernels_voxel_jit.hip, group form) */
         const int nrec = ci < a.choice_cap ? ci : a.choice_cap;
         ulonglong2* const dst = a.choice_masks + (size_t)blockIdx.x * a.choice_cap;
-        for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
         const uint64_t would_push = ballot(ambiguous && ((any_choice >> lane) & 1));
-        if (lane == 0) {
-            GroupInfo gi;
-            gi.tape = tape;
-            gi.nchoices = nrec;
-            gi.pushed = would_push;
-            a.groups[blockIdx.x] = gi;
+        if (!a.pipe_slots) {
+            for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
+            if (lane == 0) {
+                GroupInfo gi;
+                gi.tape = tape;
+                gi.nchoices = nrec;
+                gi.pushed = would_push;
+                gi.alive = 0;
+                gi.base_position = 0;
+                gi.reserved = 0;
+                a.groups[blockIdx.x] = gi;
+            }
+        } else {
+            /* pipelined frame: a workgroup of the float pass — on another XCD as likely as not, behind another L2 — reads this
+             * record as soon as the slot below says so.  Device-scope stores go through to memory; once they have been
+             * acknowledged (vmcnt) the slot is published.  (No release fence: that is a write-back of the whole L2 here.) */
+            unsigned long long* const d64 = reinterpret_cast<unsigned long long*>(dst);
+            for (int i = lane; i < nrec; i += 64) {
+                __hip_atomic_store(d64 + 2 * i, choices[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d64 + 2 * i + 1, choices[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const uint64_t amb = ballot(ambiguous);
+            /* child 0's position from any live tile: lane = x + 4 y + 16 z inside the parent (subdivide_active_tiles_3d) */
+            const int sps = a.tps;
+            const int my_base = node.position - ((lane & 3) + ((lane >> 2) & 3) * sps + (lane >> 4) * sps * sps);
+            const int base_position = __builtin_amdgcn_readlane(my_base, leader);
+            if (lane == 0) {
+                unsigned long long* const g64 = reinterpret_cast<unsigned long long*>(a.groups + blockIdx.x);
+                __hip_atomic_store(g64 + 0, (unsigned long long)(unsigned)tape | ((unsigned long long)(unsigned)nrec << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g64 + 1, would_push, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g64 + 2, amb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g64 + 3, (unsigned long long)(unsigned)base_position, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (amb != 0) {
+                __builtin_amdgcn_s_waitcnt(0);                      /* every store above has been acknowledged */
+                if (lane == 0) {
+                    const int r = __hip_atomic_fetch_add(a.pipe_ctl + PIPE_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.pipe_slots + r, (int)blockIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
     /* a.no_push with a.len_stats: the groups of the sample still walk backward and write their tapes — into chunks nobody will
@@ -868,6 +901,25 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
     }
 }
 
+/* pipelined frames: the float pass ran beside the last tile stage, before that stage's fills could be copied down
+ * (copy_filled_3d, :664-692, writes 4 t + 3 and the voxel pass then raises it: the maximum of the two either way) */
+__global__ void k_merge_filled(const int* __restrict__ prev, int* __restrict__ image, int size)
+{
+    const int x = threadIdx.x + blockIdx.x * blockDim.x;
+    const int y = threadIdx.y + blockIdx.y * blockDim.y;
+    if (x < size && y < size) {
+        const int t = prev[x / 4 + (y / 4) * (size / 4)];
+        if (t) {
+            const int h = t * 4 + 3;
+            if (image[x + y * size] < h) image[x + y * size] = h;
+        }
+    }
+}
+__global__ void k_pipe_done(int* ctl)
+{
+    __hip_atomic_store(ctl + PIPE_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* copy_filled — reference :664-692 */
 template <int DIM>
 __global__ void k_copy_filled(const int* __restrict__ prev, int* __restrict__ image, int size)
@@ -1183,6 +1235,12 @@ void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int
     if (dim == 3) hipLaunchKernelGGL(k_copy_filled<3>, g, b, 0, s, prev, image, size);
     else hipLaunchKernelGGL(k_copy_filled<2>, g, b, 0, s, prev, image, size);
 }
+void launch_merge_filled(hipStream_t s, const int* prev, int* image, int size)
+{
+    const dim3 b(32, 8), g((size + 31) / 32, (size + 7) / 8);
+    hipLaunchKernelGGL(k_merge_filled, g, b, 0, s, prev, image, size);
+}
+void launch_pipe_done(hipStream_t s, int* pipe_ctl) { hipLaunchKernelGGL(k_pipe_done, dim3(1), dim3(1), 0, s, pipe_ctl); }
 void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
                  int ncols, int capacity, int with_normals, int* out)
 {

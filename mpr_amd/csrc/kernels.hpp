@@ -29,7 +29,19 @@ struct GroupInfo {
     int nchoices;
     unsigned long long pushed;     /* the tiles whose own tape is this one shortened by their decisions (ambiguous tiles that
                                       chose a side somewhere): the others' own tape IS this one */
+    unsigned long long alive;      /* pipelined frames: the tiles still ambiguous when their wavefront finished (the float pass's
+                                      children, before any later fill hides them) ... */
+    int base_position;             /* ... and the position of the group's child 0 (child c: + its x, y, z offsets) */
+    int reserved;
 };
+
+/* Pipelined tail of a 3-D frame (context.hip: pipe): the last tile stage and the float pass run at the same time, on two
+ * streams, as producer and consumer of a queue of groups.  A wavefront of the last stage that leaves ambiguous tiles writes
+ * its group's record and masks with device-scope stores, waits for them, takes the next slot (an atomic on ctl[PIPE_TAIL])
+ * and stores group + 1 there; a workgroup of the float pass takes the next slot number (ctl[PIPE_HEAD]) and waits for it to
+ * fill.  ctl[PIPE_DONE] is set by a kernel behind the stage on its stream: from then on ctl[PIPE_TAIL] is final.  Counters
+ * sit 128 bytes apart. */
+enum { PIPE_TAIL = 0, PIPE_HEAD = 32, PIPE_DONE = 64, PIPE_ERROR = 96, PIPE_CTL_WORDS = 128 };
 
 struct TileStageArgs {
     const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
@@ -56,6 +68,8 @@ struct TileStageArgs {
                                 * (with len_stats: a sixteenth of the groups still pushes, into chunks nobody reads, to measure) */
     bool vgpr_slots;           /* tapes with many slots: the assembly walk with the slot file in registers (MPR_TILES_VGPR=0: never) */
     bool compiled_walk;        /* development (MPR_TILES_ASM=0): the compiled forward / backward walks instead of the assembly ones */
+    int* pipe_slots;           /* pipelined frames (see PIPE_*): the queue, one word per group, zero = not yet; else null */
+    int* pipe_ctl;
     int measure_at[2], measure_len;   /* the sample len_stats is taken over: groups [measure_at[k], measure_at[k] + measure_len) */
     int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
                                 * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */
@@ -137,6 +151,7 @@ void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
 /* same pass, interpreter in gfx950 assembly (kernels_voxel_asm.hip); no counters */
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a);
 
+void launch_test_sqrt_all(hipStream_t s, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out);
 /* same pass, every tape translated to machine code on the device (kernels_voxel_jit.hip); no counters.
  * code: executable device memory, `grid` regions of region_dwords each */
@@ -148,6 +163,14 @@ int jit_grid(int dim, int nslots, int cus, bool group);
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
                             int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
                             const int* group_list, bool always_invalidate = false);
+/* pipelined frames: the consumer side.  region_first: index of this launch's first code region (two launches share the
+ * queue: one beside the tile stage, one behind it); image2 / tps2: the last tile stage's filled image, whose fills have not
+ * been copied down yet while the float pass runs */
+void launch_eval_voxels_jit_pipe(hipStream_t s, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
+                                 int region_first, int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap,
+                                 const int* pipe_slots, int* pipe_ctl, const int* image2, bool always_invalidate, int* host_error);
+void launch_pipe_done(hipStream_t s, int* pipe_ctl);
+void launch_merge_filled(hipStream_t s, const int* prev, int* image, int size);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

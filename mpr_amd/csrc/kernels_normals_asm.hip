@@ -263,9 +263,9 @@ __device__ float nq_atan(float a, int isv)
     /* shared routines: argument v35 (and v36), result v37, return to s[70:71] */ \
     ".p2align 8\n" \
     "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[70:71]\n" \
-    "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n" \
-    "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n" \
-    "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n" \
+    "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n" MPR_ASM_SQRT_TAIL \
+    "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n" MPR_ASM_EXP_TAIL \
+    "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n" MPR_ASM_LOG_TAIL \
     "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n" \
     /* a min / max clause: count it; when decisions are present, the lanes whose tile decided it take the chosen \
     * operand whatever the comparison said (vcc set: lhs).  Bits beyond the 192 kept per lane: undecided. */ \

@@ -253,14 +253,17 @@ DEV float rare_unary_a(uint32_t op, float v)
     "L_sqrt_%=:\n" \
     MPR_ASM_SQRT_BODY \
     MPR_ST MPR_DISPATCH \
+    MPR_ASM_SQRT_TAIL \
     /* ---- v37 = mpr_expf(v35) (include/mpr_fmath.h), same operations in the same order ---- */ \
     "L_exp_%=:\n" \
     MPR_ASM_EXP_BODY \
     MPR_ST MPR_DISPATCH \
+    MPR_ASM_EXP_TAIL \
     /* ---- v37 = mpr_logf(v35) ---- */ \
     "L_log_%=:\n" \
     MPR_ASM_LOG_BODY \
     MPR_ST MPR_DISPATCH \
+    MPR_ASM_LOG_TAIL \
     /* ---- v37 = mpr_sinf(v35) / mpr_cosf(v35) ---- */ \
     "L_sin_%=:\n" \
     MPR_ASM_SINCOS_BODY \
@@ -516,6 +519,39 @@ k_test_float_asm(const uint64_t* tape3, int n, const float* a, const float* b, f
 void launch_test_float_asm(hipStream_t s, const uint64_t* tape3, int n, const float* a, const float* b, float* out)
 {
     hipLaunchKernelGGL(k_test_float_asm, dim3((n + 63) / 64), dim3(64), 8 * 256, s, tape3, n, a, b, out);
+}
+
+/* The square-root routine of the assembly interpreters and of the generated code (MPR_ASM_SQRT_BODY) on EVERY float: bit
+ * patterns first .. first + count - 1, 64 consecutive ones per wavefront (the routine picks its fast path per wavefront),
+ * against the compiler's correctly rounded sqrtf.  out[0] += mismatches; out[1] = one offending bit pattern. */
+__global__ void __launch_bounds__(256)
+k_test_sqrt_all(unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    const unsigned long long per = 1ull << 16;                 /* values per workgroup */
+    unsigned long long bad = 0;
+    uint32_t bad_bits = 0;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * per; base < count; base += (unsigned long long)gridDim.x * per) {
+        for (unsigned long long k = threadIdx.x; k < per && base + k < count; k += blockDim.x) {
+            const uint32_t bits = (uint32_t)(first + base + k);
+            const float x = mpr_u2f(bits);
+            float r;
+            asm volatile("v_mov_b32 v35, %1\n s_mov_b32 s90, 0x260\n" MPR_ASM_SQRT_BODY "v_mov_b32 %0, v37\n s_branch L_sqrtover_%=\n" MPR_ASM_SQRT_TAIL "L_sqrtover_%=:\n"
+                         : "=v"(r) : "v"(x)
+                         : "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42");
+            const float want = __builtin_sqrtf(x);
+            const uint32_t rb = mpr_f2u(r), wb = mpr_f2u(want);
+            const bool both_nan = (rb & 0x7fffffffu) > 0x7f800000u && (wb & 0x7fffffffu) > 0x7f800000u;
+            if (rb != wb && !both_nan) { ++bad; bad_bits = bits; }
+        }
+    }
+    if (bad) {
+        atomicAdd(out, bad);
+        out[1] = bad_bits;
+    }
+}
+void launch_test_sqrt_all(hipStream_t s, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_test_sqrt_all, dim3(4096), dim3(256), 0, s, first, count, out);
 }
 
 size_t voxel_asm_lds_bytes(int nslots) { return (size_t)nslots * 256; }

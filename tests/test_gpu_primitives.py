@@ -143,3 +143,11 @@ def test_division_by_a_constant_in_generated_code(mpr, orc, imm):
         o = orc.float_op(op, a, a, imm)
         bad = np.flatnonzero(~same_bits(g, o))
         assert bad.size == 0, (imm, bad.size, [(a[i], g[i], o[i]) for i in bad[:5]])
+
+
+def test_square_root_routine_on_every_float(mpr):
+    """The float pass's square root (asm_float_bodies.hpp: v_rsq_f32, one coupled Newton step, the exact residual) must be the
+    correctly rounded root — what sqrtf gives the oracle — for all 2^32 bit patterns: fast path (positive normal numbers from
+    2^-96 up), scaled path (tiny and subnormal), zeros, infinities, negative numbers, NaNs."""
+    bad, example = mpr.dev_sqrt_all(0, 1 << 32)
+    assert bad == 0, "sqrt differs from the correctly rounded root for %d inputs, e.g. bits 0x%08x" % (bad, example)

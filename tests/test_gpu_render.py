@@ -426,6 +426,29 @@ def test_frames_without_last_stage_tapes(mpr, orc, tapes, name, S, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("name,S", [("bear", 1024), ("architecture", 2048)])
+def test_pipelined_tail_gives_the_same_frame(mpr, orc, tapes, name, S, monkeypatch):
+    """MPR_PIPELINE=1 (an experiment that is kept but off: DESIGN.md 8) runs the last tile stage and the float pass at the same
+    time on two streams, the stage's wavefronts publishing their groups through a queue in device memory; no compaction in
+    between, the stage's fills merged into the heightmap afterwards.  Same heights and normals as the default frames and the
+    oracle, frame after frame (the first frame of a tape is never pipelined: nothing is known about its tapes yet)."""
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    monkeypatch.setenv("MPR_PIPELINE", "1")
+    ctx = mpr.Context(S)
+    kernels = []
+    for _ in range(6):
+        ctx.render3D(tape, view3())
+        kernels.append(ctx.float_kernel())
+        assert np.array_equal(ctx.image, ref.filled[3]), int((ctx.image != ref.filled[3]).sum())
+        assert np.array_equal(ctx.normals, ref.normals), int((ctx.normals != ref.normals).sum())
+    assert kernels[0].endswith(">") and not kernels[0].endswith("true>") and all(k.endswith("true>") for k in kernels[1:]), kernels
+    # a reader gets the reference's state back (and the same images)
+    assert ctx.counters()["voxel_tiles"] == ref.counters["voxel_tiles"]
+    assert np.array_equal(ctx.image, ref.filled[3])
+    ctx.close()
+
+
 @pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 1024), ("hello_world", 256), ("trig", 128), ("many_slots", 128)])
 def test_frames_that_start_at_the_16px_tiles(mpr, orc, tapes, name, S, monkeypatch):
     """3-D frames nobody inspects start at the 16^3 tiles when the 64^3 stage would be a handful of wavefronts walking the whole
