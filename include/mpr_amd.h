@@ -99,11 +99,12 @@ void mpr_tape_free(mpr_tape* t);
 typedef struct mpr_ctx_options {
     int32_t device;            /* HIP device ordinal */
     int32_t image_size_px;     /* S; must be a multiple of 64 */
-    int64_t pool_clauses;      /* tape pool capacity in clauses; 0 = MPR_NUM_SUBTAPES_BIG*64
-                                  (inc/parameters.hpp:18-22, BIG_SERVER build): 3.28 GB of device
-                                  memory per context.  A pool that runs out is not an error: the tiles
+    int64_t pool_clauses;      /* tape pool capacity in clauses (the reference's NUM_SUBTAPES * 64,
+                                  inc/parameters.hpp:14-22).  A pool that runs out is not an error: the tiles
                                   concerned keep their parents' tapes (src/context.cu:336-347) and
-                                  mpr_counters::pool_overflowed is set */
+                                  mpr_counters::pool_overflowed is set.  0 = sized by the context: a few M clauses
+                                  to begin with, doubled — and the frame rendered again — whenever a frame's
+                                  pushes do not fit, up to the BIG_SERVER size (3.28 GB) */
     int32_t flags;             /* MPR_CTX_* */
 } mpr_ctx_options;
 #define MPR_CTX_TIMING 1       /* record HIP events around every kernel (mpr_get_timings) */
@@ -118,6 +119,9 @@ int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out);
 int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out);
 void mpr_ctx_destroy(mpr_context* ctx);
 int32_t mpr_ctx_image_size(const mpr_context* ctx);    /* Context::image_size_px */
+/* device memory the context holds right now: images, tile lists, the tape pool (which starts small and doubles when a frame's
+ * pushes do not fit, unless mpr_ctx_options::pool_clauses names a capacity), the float pass's code regions and records */
+int64_t mpr_ctx_resident_bytes(const mpr_context* ctx);
 
 /* Context::render2D (src/context.cu:1136-1280).  Blocking: returns after the device has
  * finished, like the reference's cudaDeviceSynchronize at :1279. */

@@ -161,6 +161,8 @@ def lib():
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
     L.mpr_ctx_float_kernel.argtypes = [vp]
     L.mpr_ctx_last_stage_pushed.argtypes = [vp]
+    L.mpr_ctx_resident_bytes.argtypes = [vp]
+    L.mpr_ctx_resident_bytes.restype = ctypes.c_int64
     L.mpr_ctx_last_stage_pushed.restype = i32
     L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
@@ -551,6 +553,10 @@ class Context:
     def float_kernel(self):
         """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""
         return lib().mpr_ctx_float_kernel(self._h).decode()
+
+    def resident_bytes(self):
+        """Device memory the context holds right now (mpr_ctx_resident_bytes)."""
+        return int(lib().mpr_ctx_resident_bytes(self._h))
 
     def last_stage_pushed(self):
         """False when the last frame's last tile stage pushed no per-tile tapes (mpr_ctx_last_stage_pushed)."""

@@ -45,6 +45,9 @@ struct mpr_context {
 
     uint64_t* pool = nullptr;          /* Context::tape_data */
     long long pool_cap = 0;
+    bool pool_auto = false;            /* the caller named no capacity: the pool starts small and doubles (up to the reference's BIG_SERVER
+                                          size) whenever a frame's pushes do not fit — that frame is rendered again, so what a reader
+                                          sees never depends on where the pool happened to stand */
     unsigned long long* tape_index = nullptr;   /* Context::tape_index; 64 bits on the device so that failed claims of
                                                  * concurrent waves can never wrap it (reported clamped to int32) */
     int* num_active = nullptr;         /* Context::num_active_tiles */
@@ -353,7 +356,17 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_TILES")) c->debug_tiles = atoi(e);
     c->debug_choices = getenv("MPR_DEBUG_CHOICES") != nullptr;
-    c->pool_cap = opt->pool_clauses > 0 ? opt->pool_clauses : (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK;
+    /* Tape pool.  The reference allocates NUM_SUBTAPES * 64 clauses whatever the frame (inc/parameters.hpp:14-22: 328 MB, 3.28 GB
+     * with BIG_SERVER); a frame of bear 1024^3 that leaves the reference's tapes behind fills 1.1 GB of it, an ordinary frame
+     * (no tapes from its last tile stage) under 0.2 GB, prospero 1024^2 a few MB.  A capacity the caller names is kept, with
+     * the reference's behaviour when it runs out (tiles keep their parents' tapes, src/context.cu:336-347).  Otherwise: 2 M
+     * clauses (16 MB) per 256 px of image side to begin with, at least 4 M, doubled on demand. */
+    c->pool_auto = opt->pool_clauses <= 0;
+    if (const char* e = getenv("MPR_POOL_CLAUSES")) {                  /* development: a fixed capacity without touching the caller */
+        if (atoll(e) > 0) { c->pool_cap = atoll(e); c->pool_auto = false; }
+    }
+    if (c->pool_auto) c->pool_cap = std::max<long long>(4ll << 20, (long long)(S / 256) * (2ll << 20));
+    else if (c->pool_cap == 0) c->pool_cap = opt->pool_clauses;
     if (c->pool_cap > 0x7FFFFFFFll) c->pool_cap = 0x7FFFFFFFll;   /* tape indices are int32 (inc/context.hpp:25) */
     *out = nullptr;
 #define CT(expr)                                                     \
@@ -466,6 +479,19 @@ void mpr_ctx_destroy(mpr_context* c)
 
 int32_t mpr_ctx_image_size(const mpr_context* c) { return c ? c->S : 0; }
 
+/* device memory the context holds right now (every allocation that grows with the frame; the fixed few KB of counters apart) */
+int64_t mpr_ctx_resident_bytes(const mpr_context* c)
+{
+    if (!c) return 0;
+    size_t b = c->arena_words * sizeof(int) + ((size_t)c->pool_cap + 128) * sizeof(uint64_t) + c->jit_code_bytes;
+    for (int i = 0; i < 4; ++i) b += c->tiles_cap[i] * sizeof(mpr_tile_node);
+    b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + c->group_list_cap * sizeof(int);
+    b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t) + c->pipe_slots_cap * sizeof(int);
+    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap;
+    b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
+    return (int64_t)b;
+}
+
 }  // extern "C"
 
 /* ---- the frame ------------------------------------------------------------------------- */
@@ -553,12 +579,12 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
 /* The compaction publishes the counts into host-coherent memory, each tagged with the sequence number
  * `seq` (kernels.hip: publish_counts); spin until they show up.  The stream is polled now
  * and then so that a failed launch cannot hang the caller. */
-static int read_active(mpr_context* c, int seq, int out[4])
+static int read_active(mpr_context* c, int seq, int out[5])
 {
     /* four 8-byte words, each {sequence number, value} written by one store (kernels.hip: publish_counts) */
     const unsigned long long* const p = reinterpret_cast<const unsigned long long*>(c->pub_host);
     auto arrived = [&]() {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 5; ++k) {
             const unsigned long long w = __atomic_load_n(&p[k], __ATOMIC_ACQUIRE);
             if ((unsigned)(w >> 32) != (unsigned)seq) return false;
             out[k] = (int)(unsigned)w;
@@ -917,7 +943,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
         if (rc) return rc;
         const bool zs = dim == 3 && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
-        int act3[4] = {0, 0, 0, 0};
+        int act3[5] = {0, 0, 0, 0, 0};
         /* second mask_filled_tiles + assign_next_nodes + subdivide / copy_active_tiles + copy_filled, then the survivor count */
         auto compact = [&](bool mark_groups) -> int {
             const int seq = ++c->pub_seq;
@@ -925,11 +951,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
                                              c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub),
-                                             c->num_active + 4, mark_groups ? c->group_alive : nullptr);
+                                             c->num_active + 4, mark_groups ? c->group_alive : nullptr, c->tape_index);
             } else {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                               c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub), mark_groups ? c->group_alive : nullptr);
+                                               c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub), mark_groups ? c->group_alive : nullptr, c->tape_index);
             }
             if (mark_groups) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
             return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
@@ -974,6 +1000,22 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             }
             rc = compact(false);
             if (rc) return rc;
+        }
+        if (count > 0 && (act3[4] & 0x80000000) && c->pool_auto && c->pool_cap < (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) {
+            /* a push of this stage found the pool full and its tile kept the parent's tape (the reference's silent fallback):
+             * correct images, but not the tapes a larger pool gives.  A pool this context sized itself grows and the frame
+             * starts over. */
+            HIP_TRY(hipStreamSynchronize(s));
+            const long long bigger = std::min<long long>(c->pool_cap * 2, (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK);
+            uint64_t* fresh = nullptr;
+            if (hipMalloc((void**)&fresh, ((size_t)bigger + 128) * sizeof(uint64_t)) == hipSuccess) {
+                (void)hipFree(c->pool);
+                c->pool = fresh;
+                c->pool_cap = bigger;
+                c->tape_serial = 0;                  /* the root tape has to be copied in again */
+                return render_frame(c, tape, dim, mat, z, owner, rank, brute, blocking);
+            }
+            (void)hipGetLastError();                 /* no memory for a larger pool: carry on with the fallback, as the reference would */
         }
         const int active = act3[0];
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));

@@ -664,7 +664,7 @@ DEV void copy_filled_block(const CopyFilled& cf, int block, int nthreads, int ti
  * cudaMemcpy of num_active_tiles, src/context.cu:1209, :1375).  Here the kernel that knows the
  * count stores it straight into host-coherent pinned memory, tagged with a sequence number; the
  * host spins on those words — no copy kernel, no stream synchronisation. */
-DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2, int* need)
+DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2, int* need, const unsigned long long* tape_index)
 {
     /* the evaluation that just finished left an upper bound on the min / max clauses of the tapes it
      * pushed (TileStageArgs::next_choices): it sizes the next stage's choice array; cleared for the next use */
@@ -681,6 +681,15 @@ DEV void publish_counts(int* pub, int seq, int n0, int n1, int n2, int* need)
     __hip_atomic_store(p + 1, tag | (unsigned)n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(p + 2, tag | (unsigned)n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(p + 3, tag | (unsigned)n3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    /* ... and how far the evaluation's pushes have filled the tape pool (bit 31: one of them did not fit): the host grows a pool
+     * it sized itself and renders the frame again (context.hip) */
+    unsigned n4 = 0;
+    if (tape_index) {
+        const unsigned long long ti = __hip_atomic_load(tape_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ov = __hip_atomic_load(tape_index + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n4 = (unsigned)(ti < 0x7FFFFFFFull ? ti : 0x7FFFFFFFull) | (ov ? 0x80000000u : 0u);
+    }
+    __hip_atomic_store(p + 4, tag | n4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -692,7 +701,7 @@ __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
                     mpr_tile_node* __restrict__ out, int* __restrict__ pub, int seq, CopyFilled cf,
-                    unsigned char* __restrict__ group_alive)
+                    unsigned char* __restrict__ group_alive, const unsigned long long* __restrict__ tape_index)
 {
     if ((int)blockIdx.x >= cf.first_block) {
         copy_filled_block<DIM>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
@@ -743,7 +752,7 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
         if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
             const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish_counts(pub, seq, n0, 0, 0, num_active + 4);
+            publish_counts(pub, seq, n0, 0, 0, num_active + 4, tape_index);
         }
     }
     const int base = wave_base[wave];
@@ -821,7 +830,8 @@ k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __re
 
 /* one workgroup: cursor[z] = number of survivors in front of layer z; hist is cleared for the next use */
 __global__ void __launch_bounds__(ZS_MAX_BINS)
-k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ pub, int seq, int* __restrict__ need)
+k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ pub, int seq, int* __restrict__ need,
+          const unsigned long long* __restrict__ tape_index)
 {
     __shared__ int sc[ZS_MAX_BINS];
     const int t = threadIdx.x;
@@ -837,7 +847,7 @@ k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __rest
         __syncthreads();
     }
     if (t < tps) cursor[z] = sc[t] - mine;
-    if (t == ZS_MAX_BINS - 1) publish_counts(pub, seq, sc[t], 0, 0, need);      /* the scatter is still to come: the host can already size the next launch */
+    if (t == ZS_MAX_BINS - 1) publish_counts(pub, seq, sc[t], 0, 0, need, tape_index);      /* the scatter is still to come: the host can already size the next launch */
 }
 
 template <bool LAST>
@@ -1201,31 +1211,32 @@ void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngr
 
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
-                              int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive)
+                              int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive,
+                              const unsigned long long* tape_index)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb + extra), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need, unsigned char* group_alive)
+                            int* need, unsigned char* group_alive, const unsigned long long* tape_index)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb), b(1024);
     hipLaunchKernelGGL(k_zs_hist, dim3(nb + extra), b, 0, s, tiles, count, tps, image, hist, cf);
-    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need);
+    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need, tape_index);
     if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out, group_alive);
     else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out, nullptr);
 }

@@ -134,7 +134,7 @@ void launch_zero_owned(hipStream_t s, int* arena, bool with_normals, int S, cons
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need, unsigned char* group_alive = nullptr);
+                            int* need, unsigned char* group_alive = nullptr, const unsigned long long* tape_index = nullptr);
 void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngroups, int* list);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
@@ -144,7 +144,8 @@ size_t wide_stage_lds_bytes(int nclauses);
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced = 0);
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
-                              int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive = nullptr);
+                              int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive = nullptr,
+                              const unsigned long long* tape_index = nullptr);
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);

@@ -539,3 +539,35 @@ def test_compiled_expression_baseline_equals_brute_force(mpr, tapes, name, S):
     assert want.any() and np.array_equal(got, want), int((got != want).sum())
     k.close()
     ctx.close()
+
+
+def test_tape_pool_sized_by_the_frames(mpr, orc, tapes):
+    """The reference allocates its tape pool for the worst case (3.28 GB with BIG_SERVER, inc/parameters.hpp:18-22).  Here a
+    pool the caller did not size starts at a few M clauses and doubles whenever a frame's pushes do not fit, the frame being
+    rendered again — so tiles and tapes read back are what the big pool gives.  Three contexts at 2048^3 (one GPU playing three
+    ranks) stay far below one reference pool."""
+    tape = tapes("architecture")
+    S = 2048
+    ctxs = [mpr.Context(S) for _ in range(3)]
+    before = sum(c.resident_bytes() for c in ctxs)
+    for c in ctxs:
+        for _ in range(2):
+            c.render3D(tape, view3())
+    after = sum(c.resident_bytes() for c in ctxs)
+    print("three contexts at 2048^3: %.2f GB at creation, %.2f GB after frames of architecture" % (before / 2**30, after / 2**30))
+    assert after < 3 * 2**30, after                      # (round 2: 3 x 3.28 GB for the pools alone)
+    assert np.array_equal(ctxs[0].image, ctxs[2].image)
+    # reading tiles / tapes makes a frame the reference's way: the pool grows as far as that needs, and the tapes are complete
+    cnt = ctxs[0].counters()
+    assert cnt["pool_overflowed"] == 0 and cnt["tape_index"] > tape.length
+    for c in ctxs:
+        c.close()
+    # bear 1024^3 the reference's way needs over a GB of tapes: grown in steps, no overflow, the oracle's survivors
+    tape = tapes("bear")
+    ctx = mpr.Context(1024)
+    ctx.render3D(tape, view3())
+    small = ctx.resident_bytes()
+    cnt = ctx.counters()
+    assert cnt["pool_overflowed"] == 0
+    assert ctx.resident_bytes() > small and cnt["tape_index"] > 100e6
+    ctx.close()
