@@ -366,7 +366,7 @@ def main():
                 dist.all_gather_into_tensor(out, inp)
 
         tpr = TileParallelRenderer(ctx, m, rank, world, make_buffer, all_gather, dim=3)
-        tpr.plan(tape, T)
+        tpr.plan(tape, T, feedback=os.environ.get("MPR_BENCH_FEEDBACK") == "1")     # default: the stage-0 proxy deal, no frame in advance
         # this rank's share of the dominant kernel's algorithmic work: an instrumented frame of its columns
         pctx = m.Context(S, device=local_rank, flags=m.CTX_COUNTERS | m.CTX_SERIAL_STAGES)
         pctx.render3D_part(tape, T, tpr.owner, rank)
@@ -444,6 +444,8 @@ def main():
             "config": {"workload": "%s.frep render3D heightmap+normals at %d^3" % (args.model, S),
                        "image_size_px": S, "tape_clauses": tape.length - 2, "tape_slots": tape.num_slots,
                        "parallelism": "tile-columns x%d" % world,
+                       "column_deal": ("previous frame's smallest tiles per column" if os.environ.get("MPR_BENCH_FEEDBACK") == "1"
+                                       else "first tile stage's ambiguous tiles per column (no frame in advance)") if world > 1 else None,
                        "voxel_tiles": int(work["voxel_tiles"])},
             "roofline": roofline,
         }

@@ -162,6 +162,7 @@ def lib():
     L.mpr_ctx_float_kernel.argtypes = [vp]
     L.mpr_ctx_last_stage_pushed.argtypes = [vp]
     L.mpr_ctx_resident_bytes.argtypes = [vp]
+    L.mpr_column_weights.argtypes = [vp, vp, i32, vp, f32, vp]
     L.mpr_ctx_resident_bytes.restype = ctypes.c_int64
     L.mpr_ctx_last_stage_pushed.restype = i32
     L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
@@ -469,6 +470,13 @@ class Context:
         heat = np.empty((self.image_size_px, self.image_size_px), dtype=np.float32)
         _check(lib().mpr_render3d_heatmap(self._h, tape._h, _ptr(m), _ptr(heat)))
         return heat
+
+    def column_weights(self, tape, mat, z=0.0, dim=3):
+        """Ambiguous first-stage tiles per 64 x 64 column (mpr_column_weights): the work proxy of the column deal."""
+        m = colmajor(mat, dim + 1)
+        w = np.zeros((self.image_size_px // 64) ** 2, dtype=np.float32)
+        _check(lib().mpr_column_weights(self._h, tape._h, dim, _ptr(m), z, _ptr(w)))
+        return w
 
     def render3D_part(self, tape, mat, owner, rank, blocking=True):
         m = colmajor(mat, 4)

@@ -96,6 +96,7 @@ struct mpr_context {
      * What a reader of tiles / tapes / counters needs to get the reference's state back: */
     bool reference_frames = false;     /* MPR_LAST_STAGE_PUSH=1: every frame the reference's way (all stages, all tapes) */
     bool force_reference = false;      /* set while a reader re-renders the frame the reference's way */
+    bool stage0_only = false;          /* set by mpr_column_weights: the frame stops behind its first tile stage's evaluation */
     bool last_frame_fast = false;      /* the last frame took one of the shortcuts above ... */
     bool last_frame_lean = false;      /* ... this one: no tapes from its last tile stage */
     bool skip_stage0 = true;           /* MPR_SKIP_STAGE0=0: never start at the 16^3 tiles */
@@ -796,6 +797,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         mprk::TileStageArgs a;
         a.pipe_slots = nullptr;
         a.pipe_ctl = nullptr;
+        a.no_mask = c->stage0_only;
         /* Pipelined tail (3-D, a tape known to take the group form, a launch of several rounds of wavefronts): the last tile
          * stage and the float pass at the same time, as producer and consumer of a queue of groups (kernels.hpp: PIPE_*).  The
          * stage's wavefronts are dependent chains that leave the vector units half idle, the float pass is bound by their issue
@@ -890,6 +892,10 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             } else {
                 mprk::launch_eval_tiles(s, dim, a);
             }
+        }
+        if (c->stage0_only) {
+            HIP_TRY(hipStreamSynchronize(s));
+            return MPR_OK;
         }
         if (pipe_now) {
             /* behind the stage on its stream: the flag that says the queue is complete, then the rest of the float pass's
@@ -1211,6 +1217,28 @@ int mpr_render2d_async(mpr_context* c, const mpr_tape* t, const float m[9], floa
 int mpr_render3d_async(mpr_context* c, const mpr_tape* t, const float m[16])
 {
     return render_frame(c, t, 3, m, 0.0f, nullptr, 0, false, false);
+}
+/* Per 64 x 64 column the number of first-stage tiles the interval evaluation leaves ambiguous: the work proxy the column deal of
+ * SURVEY.md 8(e) uses (every rank runs the cheap 64 px stage over the whole frame, identically, and deals the columns by
+ * longest-processing-time-first on these counts: no communication, no frame rendered in advance). */
+int mpr_column_weights(mpr_context* c, const mpr_tape* t, int32_t dim, const float* mat, float z, float* weights)
+{
+    if (!c || !t || !mat || !weights || (dim != 2 && dim != 3)) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    c->force_reference = true;
+    c->stage0_only = true;
+    const int rc = render_frame(c, t, dim, mat, z, nullptr, 0, false, true);
+    c->force_reference = false;
+    c->stage0_only = false;
+    c->last_frame_fast = false;
+    if (rc) return rc;
+    const int t0 = c->S / 64, cols = t0 * t0;
+    const size_t n = (size_t)cols * (dim == 3 ? t0 : 1);
+    std::vector<mpr_tile_node> tiles(n);
+    HIP_TRY(hipMemcpy(tiles.data(), c->tiles[0], n * sizeof(mpr_tile_node), hipMemcpyDeviceToHost));
+    for (int i = 0; i < cols; ++i) weights[i] = 0.0f;
+    for (size_t k = 0; k < n; ++k)
+        if (tiles[k].position != -1) weights[k % (size_t)cols] += 1.0f;
+    return MPR_OK;
 }
 int mpr_render3d_part(mpr_context* c, const mpr_tape* t, const float m[16], const int32_t* owner, int32_t rank)
 {

@@ -175,7 +175,7 @@ k_eval_tiles(TileStageArgs a)
     /* mask_filled_tiles before evaluation (3-D).  Fused here it also sees fills of waves of this very
      * launch (same image, less work); heatmap frames count work, so they run the reference's separate
      * pass (k_mask_filled_tiles) instead and get the reference's deterministic set of evaluated tiles */
-    if (DIM == 3 && alive && !a.heat) {
+    if (DIM == 3 && alive && !a.heat && !a.no_mask) {
         if (a.image[pos.w] > pos.z) {
             alive = false;
             a.tiles[gidx].position = -1;
@@ -336,7 +336,7 @@ k_eval_tiles(TileStageArgs a)
     if (alive) {
         if (res.x > 0.0f) {                                   /* empty */
             a.tiles[gidx].position = -1;
-        } else if (DIM == 3 && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
+        } else if (DIM == 3 && !a.no_mask && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
             a.tiles[gidx].position = -1;                      /* masked */
         } else if (res.y < 0.0f) {                            /* filled */
             a.tiles[gidx].position = -1;

@@ -68,6 +68,8 @@ struct TileStageArgs {
                                 * (with len_stats: a sixteenth of the groups still pushes, into chunks nobody reads, to measure) */
     bool vgpr_slots;           /* tapes with many slots: the assembly walk with the slot file in registers (MPR_TILES_VGPR=0: never) */
     bool compiled_walk;        /* development (MPR_TILES_ASM=0): the compiled forward / backward walks instead of the assembly ones */
+    bool no_mask;              /* mpr_column_weights: no tile is culled by a fill (src/context.cu:299-305) — which tiles a stage leaves
+                                * ambiguous then depends on the tape and the view alone, not on the order its wavefronts finish in */
     int* pipe_slots;           /* pipelined frames (see PIPE_*): the queue, one word per group, zero = not yet; else null */
     int* pipe_ctl;
     int measure_at[2], measure_len;   /* the sample len_stats is taken over: groups [measure_at[k], measure_at[k] + measure_len) */

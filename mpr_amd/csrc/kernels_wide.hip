@@ -78,7 +78,7 @@ k_eval_tiles_wide(WideStageArgs w)
     if (tid == 0) {
         const mpr_tile_node node = a.tiles[gidx];
         int alive = node.position != -1;
-        if (DIM == 3 && alive) {
+        if (DIM == 3 && alive && !a.no_mask) {
             const int4_ p = unpack(node.position, a.tps);
             if (a.image[p.w] > p.z) {                       /* mask_filled_tiles before evaluation */
                 alive = 0;
@@ -194,7 +194,7 @@ k_eval_tiles_wide(WideStageArgs w)
         int state = 0;
         if (res.x > 0.0f) {                                   /* empty */
             a.tiles[gidx].position = -1;
-        } else if (DIM == 3 && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
+        } else if (DIM == 3 && !a.no_mask && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
             a.tiles[gidx].position = -1;                      /* masked */
         } else if (res.y < 0.0f) {                            /* filled */
             a.tiles[gidx].position = -1;

@@ -10,10 +10,11 @@ only its columns produces exactly the pixels the single-GPU frame has there.  Pe
 
 No reduction is involved, so the result is bit-identical to the single-GPU frame.
 
-The column -> rank deal is the longest-processing-time-first heuristic on per-column work
-measured on a previous frame (every rank renders one full frame during warm-up and counts the
-smallest tiles per column; the counts are deterministic, hence the deal is identical on all
-ranks without communication).
+The column -> rank deal is the longest-processing-time-first heuristic on a per-column work proxy
+every rank computes for itself, identically, without communication: by default the number of
+first-stage (64 px) tiles of a column that the interval evaluation leaves ambiguous (one cheap
+stage over the whole frame); optionally (plan(feedback=True)) the smallest tiles
+per column of a full frame rendered beforehand.
 
 The class is written against a small "context" protocol (render3D / render3D_part /
 pack_columns / unpack_columns / stages[3].tiles) so that the world-size-2 gloo test in
@@ -50,13 +51,19 @@ class TileParallelRenderer:
         self.capacity = 0
         self.with_normals = dim == 3
 
-    def plan(self, tape, mat, z=0.0):
-        """Measure per-column work on one full frame and deal the columns (identical on all ranks)."""
-        if self.dim == 3:
-            self.ctx.render3D(tape, mat)
+    def plan(self, tape, mat, z=0.0, feedback=False):
+        """Deal the columns (identical on all ranks, no communication).  Default: by the first tile stage's own verdict — every
+        rank runs the 64 px stage over the whole frame (a fraction of a millisecond) and weighs a column by the tiles it leaves
+        ambiguous (the stage-0 proxy).  feedback=True: by the smallest tiles per column of one full frame
+        rendered first — a better balance for a view that repeats (what a benchmark does; say so when you use it)."""
+        if not feedback and hasattr(self.ctx, "column_weights"):
+            w = self.ctx.column_weights(tape, mat, z, self.dim)
         else:
-            self.ctx.render2D(tape, mat, z)
-        w = column_weights(self.ctx.stages[3].tiles, self.size, self.dim)
+            if self.dim == 3:
+                self.ctx.render3D(tape, mat)
+            else:
+                self.ctx.render2D(tape, mat, z)
+            w = column_weights(self.ctx.stages[3].tiles, self.size, self.dim)
         self.set_owner(self.mpr.partition_columns(self.cols, self.world, w))
         return self.owner
 

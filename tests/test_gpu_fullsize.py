@@ -93,3 +93,48 @@ def test_architecture_2048_sharded_over_three_contexts(mpr, orc, tapes):
         assert np.array_equal(ctxs[r].normals, want_n)
     for c in ctxs:
         c.close()
+
+
+def test_bear_1024_dealt_to_eight_ranks_on_one_device(mpr, orc, tapes):
+    """BASELINE's headline frame in its sharded form, eight ranks played by eight contexts on one device: the default column deal
+    (first tile stage's ambiguous tiles per column — no frame rendered in advance), every rank's partial frame packed, the
+    all-gather emulated by device copies, unpacked: every rank ends up with the single-device frame, bit for bit, and the deal
+    leaves no rank more than 1.6 x its fair share of the smallest tiles."""
+    torch = pytest.importorskip("torch")
+    from mpr_amd.multigpu import TileParallelRenderer, column_weights
+    tape, S, T, world = tapes("bear"), 1024, view3(), 8
+    full = mpr.Context(S)
+    full.render3D(tape, T)
+    want_h, want_n = full.image.copy(), full.normals.copy()
+    true_w = column_weights(full.stages[3].tiles, S, 3)
+    full.close()
+    ctxs = [mpr.Context(S) for _ in range(world)]
+
+    def make_buffer(n):
+        t = torch.zeros(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        return t, t.data_ptr()
+
+    rs = []
+    for r in range(world):
+        tpr = TileParallelRenderer(ctxs[r], mpr, r, world, make_buffer, lambda o, i: None, dim=3)
+        tpr.plan(tape, T)
+        rs.append(tpr)
+    assert all(np.array_equal(rs[0].owner, t.owner) for t in rs)
+    share = np.array([true_w[rs[0].owner == r].sum() for r in range(world)]) / true_w.sum()
+    assert share.max() < 1.6 / world, share
+    for frame in range(2):
+        for r, t in enumerate(rs):
+            ctxs[r].render3D_part(tape, T, t.owner, r, blocking=False)
+            ctxs[r].pack_planned(t.send_ptr)
+        for r, t in enumerate(rs):
+            for o, u in enumerate(rs):
+                ctxs[o].sync()
+                with torch.cuda.stream(torch.cuda.ExternalStream(ctxs[r].stream)):
+                    t.recv[o * t.per_rank:(o + 1) * t.per_rank].copy_(u.send)
+            ctxs[r].unpack_planned(t.recv_ptr)
+            ctxs[r].sync()
+            assert np.array_equal(ctxs[r].image, want_h)
+            assert np.array_equal(ctxs[r].normals, want_n)
+    for c in ctxs:
+        c.close()
