@@ -93,7 +93,12 @@ constexpr uint32_t CALL(uint32_t sgpr) { return 0xBE9E1E00u | sgpr; }        /* 
 constexpr uint32_t BITCMP_L = 0xBF0F004Cu, BITCMP_R = 0xBF0F004Eu;            /* s_bitcmp1_b64 s[76:77] / s[78:79], <index>; decisions 64..127 in s[48:49] / s[50:51] */
 constexpr uint32_t BITCMP_L1 = 0xBF0F0030u, BITCMP_R1 = 0xBF0F0032u;
 constexpr int JIT_MAX_CHOICES = 128;
-constexpr uint32_t CSELECT = 0x85EA80C1u;                                      /* s_cselect_b64 vcc, -1, 0 */
+constexpr uint32_t CSELECT = 0x85DE80C1u;                                      /* s_cselect_b64 s[94:95], -1, 0 */
+/* v_cndmask_b32_e64 vdst, src0, vsrc1, s[94:95] (VOP3: two dwords).  NOT the VOP2 form with vcc: a v_cndmask that reads a vcc
+ * the SCALAR unit wrote issues at a tenth of the VALU rate (0.175 wave-instr/clk/CU at any occupancy, scripts/ubench/
+ * issue_rates2.hip: "v_cndmask"), the VOP3 form with an SGPR pair at half rate (0.82-0.90: "v_cndmask e64 sgpr") */
+constexpr uint32_t CND64_LO = 0xD1000000u;                                     /* | vdst */
+constexpr uint32_t CND64_HI = (94u << 18) | (1u << 17);                        /* | src0 (9 bits) | vsrc1 << 9; src1 is a VGPR */
 constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21, V_FMAMK = 23;
 constexpr uint32_t CLASS_V39_V7 = 0x7C200F27u;                                 /* v_cmp_class_f32 vcc, v39, v7 */
 constexpr uint32_t BRANCH_VCCZ_2 = 0xBF860002u;                                /* s_cbranch_vccz +2 dwords */
@@ -114,6 +119,18 @@ struct Builder {
     constexpr void neglit() { r.base[r.n] = 0x80000000u; r.sel[r.n] = 0x07060504u; r.mask[r.n] = 0; ++r.n; }   /* the literal with its sign flipped */
     constexpr void bitcmp(uint32_t base) { r.base[r.n] = base; r.sel[r.n] = NONE | (CI << 8) | (NONE << 16) | (NONE << 24); r.mask[r.n] = 0; ++r.n; }
     constexpr void fixed(uint32_t w) { r.base[r.n] = w; r.sel[r.n] = NONE | (NONE << 8) | (NONE << 16) | (NONE << 24); r.mask[r.n] = 0; ++r.n; }
+    /* vdst = s[94:95] ? vsrc1 : v37.  d: selector of vdst (NONE: v37); s1: selector of vsrc1 (NONE: v38) */
+    constexpr void cnd64(uint32_t d, uint32_t s1)
+    {
+        r.base[r.n] = CND64_LO | (d == NONE ? 37u : 0u);
+        r.sel[r.n] = d | (NONE << 8) | (NONE << 16) | (NONE << 24);
+        r.mask[r.n] = 0;
+        ++r.n;
+        r.base[r.n] = CND64_HI | (VREG + 37) | (s1 == NONE ? (38u << 9) : 0u);
+        r.sel[r.n] = NONE | (s1 << 8) | (NONE << 16) | (NONE << 24);
+        r.mask[r.n] = 0xFFFFFF00u;
+        ++r.n;
+    }
 };
 constexpr JitRow unary_call(uint32_t s)
 {
@@ -167,11 +184,11 @@ constexpr JitRow minmax(uint32_t op, bool imm, bool group, uint32_t q = 0)
     }
     b.bitcmp(q ? BITCMP_L1 : BITCMP_L);
     b.fixed(CSELECT);
-    b.ins(VOP2(V_CNDMASK, 37, 0, VREG + 37), NONE, A);                 /* v37 = chose lhs ? lhs : v37 */
+    b.cnd64(NONE, A);                                                    /* v37 = chose lhs ? lhs : v37 */
     b.bitcmp(q ? BITCMP_R1 : BITCMP_R);
     b.fixed(CSELECT);
-    if (imm) b.ins(VOP2(V_CNDMASK, 0, 38, VREG + 37), O);                /* out = chose rhs ? immediate : v37 */
-    else b.ins(VOP2(V_CNDMASK, 0, 0, VREG + 37), O, R);
+    if (imm) b.cnd64(O, NONE);                                           /* out = chose rhs ? immediate (v38) : v37 */
+    else b.cnd64(O, R);
     return b.r;
 }
 constexpr JitRow row_of(uint32_t op, bool group)

@@ -442,7 +442,9 @@ def test_pipelined_tail_gives_the_same_frame(mpr, orc, tapes, name, S, monkeypat
         kernels.append(ctx.float_kernel())
         assert np.array_equal(ctx.image, ref.filled[3]), int((ctx.image != ref.filled[3]).sum())
         assert np.array_equal(ctx.normals, ref.normals), int((ctx.normals != ref.normals).sum())
-    assert kernels[0].endswith(">") and not kernels[0].endswith("true>") and all(k.endswith("true>") for k in kernels[1:]), kernels
+    # (the very first attempt at a frame of a new tape is never pipelined — nothing is known about its tapes yet —, but it may have
+    # been rendered again because the tape pool had to grow)
+    assert all(k.endswith("true>") for k in kernels[1:]), kernels
     # a reader gets the reference's state back (and the same images)
     assert ctx.counters()["voxel_tiles"] == ref.counters["voxel_tiles"]
     assert np.array_equal(ctx.image, ref.filled[3])

@@ -37,12 +37,16 @@ def test_rows_disassemble_to_the_intended_instructions(mpr):
     assert row(mpr, 1, OP["SUB_IMM_RHS"]) == ["v_sub_f32_e32 v53, 0x40490fdb, v51"]
     assert row(mpr, 1, OP["NEG_LHS"]) == ["v_xor_b32_e32 v53, 0x80000000, v50"]
     assert row(mpr, 1, OP["SQRT_LHS"]) == ["v_mov_b32_e32 v35, v50", "s_swappc_b64 s[30:31], s[54:55]", "v_mov_b32_e32 v53, v37"]
-    # group form: min with the decisions of choice 7 in s[76:79] (no canonicalising v_max pair: the code runs with MODE.IEEE off)
+    # group form: min with the decisions of choice 7 in s[76:79] (no canonicalising v_max pair: the code runs with MODE.IEEE off);
+    # the selects take their mask from an SGPR pair (VOP3): the VOP2 form on a vcc the scalar unit wrote runs at a tenth of the rate
     assert row(mpr, 1, OP["MIN_LHS_RHS"]) == [
         "v_min_f32_e32 v37, v50, v51",
-        "s_bitcmp1_b64 s[76:77], 7", "s_cselect_b64 vcc, -1, 0", "v_cndmask_b32_e32 v37, v37, v50, vcc",
-        "s_bitcmp1_b64 s[78:79], 7", "s_cselect_b64 vcc, -1, 0", "v_cndmask_b32_e32 v53, v37, v51, vcc"]
-    assert row(mpr, 1, OP["MAX_LHS_IMM"])[:2] == ["v_mov_b32_e32 v38, 0x40490fdb", "v_max_f32_e32 v37, v50, v38"]
+        "s_bitcmp1_b64 s[76:77], 7", "s_cselect_b64 s[94:95], -1, 0", "v_cndmask_b32_e64 v37, v37, v50, s[94:95]",
+        "s_bitcmp1_b64 s[78:79], 7", "s_cselect_b64 s[94:95], -1, 0", "v_cndmask_b32_e64 v53, v37, v51, s[94:95]"]
+    assert row(mpr, 1, OP["MAX_LHS_IMM"]) == [
+        "v_mov_b32_e32 v38, 0x40490fdb", "v_max_f32_e32 v37, v50, v38",
+        "s_bitcmp1_b64 s[76:77], 7", "s_cselect_b64 s[94:95], -1, 0", "v_cndmask_b32_e64 v37, v37, v50, s[94:95]",
+        "s_bitcmp1_b64 s[78:79], 7", "s_cselect_b64 s[94:95], -1, 0", "v_cndmask_b32_e64 v53, v37, v38, s[94:95]"]
     # ... and of choice 64 + 7 in s[48:51] (row 33 = MIN_LHS_RHS for decisions 64..127)
     assert row(mpr, 1, 33, opcode=OP["MIN_LHS_RHS"])[1] == "s_bitcmp1_b64 s[48:49], 7"
     # tile form: no decisions
