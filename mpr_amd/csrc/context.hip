@@ -1076,8 +1076,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             return again;
         }
         if (jitted) {
-            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
-                     mprk::jit_slot_class(nslots));
+            /* (as rocprofv3 prints it: the group form's kernel has a third template argument, `pipelined`) */
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d%s>", group_form && !brute ? "_groups" : "", dim,
+                     mprk::jit_slot_class(nslots), group_form && !brute ? ", false" : "");
         } else if (c->voxel_asm && !cnt && !heat) {
             mprk::launch_eval_voxels_asm(s, dim, v);
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_asm<%d>", dim);
