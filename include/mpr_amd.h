@@ -110,6 +110,8 @@ typedef struct mpr_ctx_options {
 #define MPR_CTX_TIMING 1       /* record HIP events around every kernel (mpr_get_timings) */
 #define MPR_CTX_COUNTERS 2     /* accumulate the work counters of mpr_get_counters on the device
                                   (costs a few atomics per wave: keep off when timing) */
+#define MPR_CTX_TIMING_FLOAT 8  /* HIP events around the float pass only (eval_voxels_f: the dominant kernel): two events per frame
+                                  instead of sixteen, so that a timed loop can carry them at no measurable cost */
 #define MPR_CTX_SERIAL_STAGES 4 /* tile stages always by the 64-tiles-per-wavefront kernels, never level-parallel: with
                                   MPR_CTX_COUNTERS the clause counters are then the implementation-independent figures of
                                   SURVEY.md 8(d) (F / R per group of 64 list entries; the level-parallel kernel has no such

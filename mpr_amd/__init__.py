@@ -26,6 +26,7 @@ TILE_DTYPE = np.dtype([("position", "<i4"), ("tape", "<i4"), ("next", "<i4")])
 CTX_TIMING = 1
 CTX_COUNTERS = 2
 CTX_SERIAL_STAGES = 4
+CTX_TIMING_FLOAT = 8
 
 # libfive packed opcode numbers understood by the front end (include/mpr_amd.h mpr_tree_op)
 T_SQUARE, T_SQRT, T_NEG, T_SIN, T_COS, T_ASIN, T_ACOS, T_ATAN, T_EXP, T_ABS, T_LOG = 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18

@@ -284,7 +284,8 @@ struct TimedScope {
     size_t idx = 0;
     hipStream_t st;
     TimedScope(mpr_context* ctx, const char* name, hipStream_t on_stream = nullptr)
-        : c(ctx), on((ctx->flags & MPR_CTX_TIMING) != 0), st(on_stream ? on_stream : ctx->stream)
+        : c(ctx), on((ctx->flags & MPR_CTX_TIMING) != 0 || ((ctx->flags & MPR_CTX_TIMING_FLOAT) != 0 && std::strcmp(name, "eval_voxels_f") == 0)),
+          st(on_stream ? on_stream : ctx->stream)
     {
         if (!on) return;
         if (c->timings_used == c->timings.size()) {
