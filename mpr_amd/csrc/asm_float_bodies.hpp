@@ -75,34 +75,39 @@
     "v_cndmask_b32 v37, v39, v38, vcc\n" \
     "s_branch L_sqrtdone_%=\n"
 
+/* mpr_expf: t = x log2(e); kf = (t + 1.5 * 2^23) - 1.5 * 2^23 (t rounded to the nearest integer, ties to even: the C++
+ * definition word for word); r = x - kf ln2 in two steps; p = the polynomial; p * 2^k.  For |x| <= 87 the result is a normal number,
+ * so 2^k is an addition to p's exponent field — and k sits in the low bits of t + 1.5 * 2^23 (0x4b400000 + k), whose upper bits a
+ * shift by 23 pushes out: one v_lshl_add_u32 where v_cvt_i32_f32 + v_ldexp_f32 (both half rate) stood.  The tail redoes it by the
+ * book for everything else. */
 #define MPR_ASM_EXP_BODY \
     "v_mul_f32 v38, 0x3fb8aa3b, v35\n" \
-    /* kf = (t + 1.5 * 2^23) - 1.5 * 2^23 in the C++ definition: t rounded to the nearest integer, ties to even, as long as \
-     * |t| < 2^22 — and a larger |t| is an |x| whose result the special cases below replace */ \
-    "v_rndne_f32 v38, v38\n" \
+    "v_add_f32 v42, 0x4b400000, v38\n"              /* t + 1.5 * 2^23 */ \
+    "v_add_f32 v38, 0xcb400000, v42\n"              /* kf */ \
     "v_fmamk_f32 v39, v38, 0xbf318000, v35\n" \
     "v_fmamk_f32 v39, v38, 0x395e8083, v39\n"       /* r */ \
     "v_mov_b32 v40, 0x3ab743ce\n" \
     "v_fmac_f32 v40, 0x39506967, v39\n" \
     "v_fmaak_f32 v40, v40, v39, 0x3c088908\n" \
-    "v_cvt_i32_f32 v38, v38\n"                      /* k */ \
     "v_fmaak_f32 v40, v40, v39, 0x3d2aa9c1\n" \
     "v_fmaak_f32 v40, v40, v39, 0x3e2aaaaa\n" \
     "v_mul_f32 v41, v39, v39\n" \
     "v_fma_f32 v40, v40, v39, 0.5\n" \
     "v_fmac_f32 v39, v40, v41\n" \
-    "v_add_f32 v39, 1.0, v39\n" \
-    /* p * 2^k: the C++ definition multiplies by 2^(k/2) and 2^(k - k/2), the first product exact, \
-     * i.e. one rounding of p * 2^k — which is what v_ldexp_f32 does in one instruction */ \
-    "v_ldexp_f32 v37, v39, v38\n" \
-    /* |x| <= 87 in every lane (NaN counts as not): none of the three special cases applies */ \
+    "v_add_f32 v39, 1.0, v39\n"                     /* p */ \
+    "v_lshl_add_u32 v37, v42, 23, v39\n"            /* p * 2^k for a normal result */ \
+    /* |x| <= 87 in every lane (NaN counts as not): none of the special cases applies */ \
     "s_mov_b32 s91, 0x42ae0000\n" \
     "v_cmp_nle_f32 vcc, |v35|, s91\n" \
     "s_cbranch_vccnz L_expspecial_%=\n" \
     "L_expdone_%=:\n"
 #define MPR_ASM_EXP_TAIL \
     "L_expspecial_%=:\n" \
+    "v_cvt_i32_f32 v38, v38\n"                      /* k */ \
     "s_mov_b32 s91, 0x42b17218\n" \
+    /* p * 2^k: the C++ definition multiplies by 2^(k/2) and 2^(k - k/2), the first product exact, \
+     * i.e. one rounding of p * 2^k — which is what v_ldexp_f32 does in one instruction */ \
+    "v_ldexp_f32 v37, v39, v38\n" \
     "v_cmp_ngt_f32 vcc, 0xc2cff5c3, v35\n"          /* !(x < -103.98) */ \
     "v_cmp_nlt_f32 s[92:93], s91, v35\n"            /* !(x > 88.72284) */ \
     "v_cmp_o_f32 s[94:95], v35, v35\n" \

@@ -691,6 +691,7 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "v_cmp_ne_u32 s[48:49], 0, v37\n v_cmp_ne_u32 s[50:51], 0, v38\n"                                   \
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
     "v_mov_b32 v7, 0x2ff\n"                           /* class mask of the inline constant division */  \
+    "v_mov_b32 v46, 0\n v_mov_b32 v47, 1.0\n"          /* L_sin / L_cos: (argument, cosine) seen last: cos(+0) = 1 */ \
     "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0\n" /* MODE.IEEE off while generated code runs (see jt::minmax) */ \
     "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
@@ -719,8 +720,17 @@ DEV void jit_prefetch_tape(const uint64_t* __restrict__ tro, int tape, int tape_
     "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[30:31]\n" MPR_ASM_SQRT_TAIL                        \
     "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[30:31]\n" MPR_ASM_EXP_TAIL                           \
     "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[30:31]\n" MPR_ASM_LOG_TAIL                           \
-    "L_sin_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[30:31]\n"                                         \
-    "L_cos_%=:\n" MPR_ASM_SINCOS_BODY "v_mov_b32 v37, v36\n s_setpc_b64 s[30:31]\n"                    \
+    /* sin and cos: one routine computes both (MPR_ASM_SINCOS_BODY: v37 = sin, v36 = cos), and models ask for both of the same  \
+     * argument a few clauses apart (bear: three times).  v46 / v47 — temporaries of this routine alone — keep (argument,      \
+     * its cosine) between calls: a cosine of the bits just seen is a compare and a move instead of 61 issue units.  The pair is \
+     * always a true one (set with the routine's own results; (0, 1) at the start of a run), so a hit is the routine's value. */ \
+    "L_sin_%=:\n" MPR_ASM_SINCOS_BODY "v_mov_b32 v46, v35\n v_mov_b32 v47, v36\n s_setpc_b64 s[30:31]\n"     \
+    "L_cos_%=:\n"                                                                                      \
+    "v_cmp_ne_u32 vcc, v35, v46\n"                                                                      \
+    "s_cbranch_vccnz L_cosmiss_%=\n"                                                                    \
+    "v_mov_b32 v37, v47\n"                                                                              \
+    "s_setpc_b64 s[30:31]\n"                                                                            \
+    "L_cosmiss_%=:\n" MPR_ASM_SINCOS_BODY "v_mov_b32 v37, v36\n v_mov_b32 v46, v35\n v_mov_b32 v47, v36\n s_setpc_b64 s[30:31]\n" \
     "L_end_%=:\n"
 
 template <int NS>
