@@ -74,6 +74,7 @@ def main():
         imm = (d >> np.uint64(32)).astype(np.uint32).view(np.float32)
         total = np.zeros(3)
         by = collections.OrderedDict()
+        last_sin = None
         for k in range(1, len(d) - 1):
             op = names.get(int(d[k]) & 0xFF, "?")
             if op in ("SQRT_LHS",):
@@ -83,7 +84,12 @@ def main():
             elif op == "LOG_LHS":
                 c = R["LOG"] + mov2
             elif op in ("SIN_LHS", "COS_LHS"):
-                c = R["SINCOS"] + mov2
+                c = R["SINCOS"] + mov2 + (np.array([2.0, 0, 0]) if op == "SIN_LHS" else np.array([3.0, 1, 0]))
+                if op == "SIN_LHS":
+                    last_sin = ((int(d[k]) >> 16) & 0xFF, k)            # the slot whose cosine the routine keeps
+                elif last_sin is not None and last_sin[0] == ((int(d[k]) >> 16) & 0xFF) and \
+                        all(((int(d[j]) >> 8) & 0xFF) != last_sin[0] for j in range(last_sin[1], k)):
+                    c = mov2 + np.array([1.0, 1, 0])                   # the cosine of the argument just seen: a compare and a move
             elif op in ("ASIN_LHS", "ACOS_LHS", "ATAN_LHS"):
                 c = np.array([40.0, 8, 1])            # compiled leaves: an estimate, none of the benchmark's 3-D models but the gears use them
             elif op.startswith("MIN") or op.startswith("MAX"):
