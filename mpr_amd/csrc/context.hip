@@ -238,22 +238,42 @@ hsa_status_t exec_pool_cb(hsa_amd_memory_pool_t p, void* data)
     }
     return HSA_STATUS_SUCCESS;
 }
-/* null when the runtime refuses (the caller then keeps the interpreter) */
+/* null when the runtime refuses (the caller then keeps the interpreter).  The HSA agent is the one that owns a piece of memory
+ * hipMalloc'ed on `device` (hsa_amd_pointer_info): no guessing from PCI addresses or ordinals, which HIP_VISIBLE_DEVICES reorders.
+ * The PCI / ordinal match remains as the fallback for a runtime that does not answer. */
 void* alloc_executable(int device, size_t bytes)
 {
     static bool hsa_up = (hsa_init() == HSA_STATUS_SUCCESS);       /* reference counted: HIP has initialised it already */
     if (!hsa_up) return nullptr;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
     ExecPoolSearch q;
-    q.by_bdf = true;
-    q.bdf = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
-    q.domain = (uint32_t)prop.pciDomainID;
-    (void)hsa_iterate_agents(exec_agent_cb, &q);
-    if (!q.found) {                      /* no PCI match (virtualised box): HIP ordinals follow the order of the GPU agents */
-        q = ExecPoolSearch();
-        q.ordinal = device;
+    {
+        int current = -1;
+        (void)hipGetDevice(&current);
+        void* probe = nullptr;
+        if (hipSetDevice(device) == hipSuccess && hipMalloc(&probe, 256) == hipSuccess) {
+            hsa_amd_pointer_info_t info;
+            std::memset(&info, 0, sizeof(info));
+            info.size = sizeof(info);
+            if (hsa_amd_pointer_info(probe, &info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS && info.agentOwner.handle != 0) {
+                q.agent = info.agentOwner;
+                q.found = true;
+            }
+            (void)hipFree(probe);
+        }
+        if (current >= 0 && current != device) (void)hipSetDevice(current);
+    }
+    if (!q.found) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+        q.by_bdf = true;
+        q.bdf = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
+        q.domain = (uint32_t)prop.pciDomainID;
         (void)hsa_iterate_agents(exec_agent_cb, &q);
+        if (!q.found) {                      /* no PCI match (virtualised box): HIP ordinals follow the order of the GPU agents */
+            q = ExecPoolSearch();
+            q.ordinal = device;
+            (void)hsa_iterate_agents(exec_agent_cb, &q);
+        }
     }
     if (!q.found) return nullptr;
     (void)hsa_amd_agent_iterate_memory_pools(q.agent, exec_pool_cb, &q);
