@@ -193,7 +193,8 @@ int mpr_read_filled(mpr_context* ctx, int32_t stage, int32_t* host);
 /* normals -> host; S*S uint32 0xFF<<24 | nz<<16 | ny<<8 | nx */
 int mpr_read_normals(mpr_context* ctx, uint32_t* host);
 /* stages[stage].tiles -> host; *n = number of valid entries from the last render
- * (stage 0: all top-level tiles).  cap in entries. */
+ * (stage 0: all top-level tiles).  cap in entries.  (Renders the last frame again the reference's way first when it was an
+ * ordinary one: see mpr_ctx_last_stage_pushed.  So do mpr_read_tape_pool and mpr_get_counters.) */
 int mpr_read_tiles(mpr_context* ctx, int32_t stage, mpr_tile_node* host, size_t cap, size_t* n);
 /* tape_data / *tape_index -> host; copies min(cap, *tape_index) clauses */
 int mpr_read_tape_pool(mpr_context* ctx, uint64_t* host, size_t cap, int32_t* tape_index);
@@ -232,10 +233,16 @@ int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap
  * "k_eval_voxels<3>" (C++ interpreter: instrumented frames).  Owned by the context; "" before a frame. */
 const char* mpr_ctx_float_kernel(const mpr_context* ctx);
 
-/* 1 when the last frame's last tile stage pushed per-tile tapes (the reference's state), 0 when it did not need to:
- * a frame of a tape whose last measuring frame found float and normals pass on the groups' tapes worth it
- * (DESIGN.md 3).  mpr_read_tiles / mpr_read_tape_pool render such a frame again in full before they read, so what
- * they return is always the reference's state. */
+/* 1 when the last frame's last tile stage pushed per-tile tapes (the reference's state), 0 when it did not need to (its own
+ * sample of the tapes it would push said that float and normals pass do as well on the tapes it walked: DESIGN.md 3).
+ *
+ * render* leaves the reference's IMAGES — heights / occupancy, normals — always.  The reference's tile lists, tapes and
+ * tape_index it leaves only when they are asked for: ordinary frames skip what only a reader needs (the last stage's per-tile
+ * tapes; the 64^3 stage of 3-D frames up to 1024^3 whose tapes have narrow DAGs).  mpr_read_tiles, mpr_read_tape_pool AND
+ * mpr_get_counters therefore first render the last frame again the reference's way (same tape — the context keeps a copy —,
+ * view and partition): the images come out identical, the columns other ranks sent into a partitioned context stay in place,
+ * mpr_get_timings afterwards describes that extra frame.  MPR_LAST_STAGE_PUSH=1 in the environment when the context is created
+ * makes every frame the reference's way. */
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* ctx);
 
 /* ---- compiled-expression baseline (reference benchmark/dump_tape.cpp + benchmark/brute.cu): the
