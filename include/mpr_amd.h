@@ -301,6 +301,10 @@ int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, co
  * its template arithmetic; returns their number, -1 for a bad argument): table 0 / 1 = tile / group form; row = the
  * opcode, 30 (division by a constant; its reciprocal literals are left zero) or 32.. (decisions 64..127) */
 int mpr_test_jit_row(int32_t table, int32_t row, uint32_t clause_lo, uint32_t imm_bits, int32_t choice, uint32_t* out, int32_t cap);
+/* the interval walks of a tape (head, operations, end: `len` clause words) as the machine code the first tile stage runs
+ * (csrc/tile_gen.hpp): which = 0 forward, 1 backward.  Returns the number of dwords (copied to `out` when they fit `cap`),
+ * -1 for a tape the generator does not take (a slot beyond 23, more than 64 min / max clauses, a jump, an unknown opcode) */
+int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -191,6 +191,8 @@ def lib():
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_sqrt_all.argtypes = [i32, ctypes.c_uint64, ctypes.c_uint64, vp, vp]
     L.mpr_test_jit_row.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_uint32, i32, vp, i32]
+    L.mpr_test_tile_gen.argtypes = [vp, i32, i32, vp, i32]
+    L.mpr_test_tile_gen.restype = ctypes.c_int
     _LIB = L
     return L
 

@@ -23,6 +23,7 @@
 #include "../../include/mpr_effects_tables.h"
 #include "internal.hpp"
 #include "kernels.hpp"
+#include "tile_gen.hpp"
 
 namespace {
 
@@ -147,6 +148,14 @@ struct mpr_context {
     size_t group_alive_cap = 0, group_list_cap = 0;
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
+    /* the resident tape's interval walks as generated code (tile_gen.hpp), for the frame's first tile stage; MPR_TILE_GEN=0: never,
+     * 2: the forward walk only */
+    int tile_gen = 1;
+    uint32_t* gen_code = nullptr;      /* executable memory: forward code, then backward code */
+    uint32_t* gen_stage = nullptr;     /* what the host hands over (device memory; copied into gen_code by a kernel) */
+    size_t gen_cap_dw = 0;
+    bool gen_ok = false;
+    int gen_fwd_dw = 0, gen_words = 0, gen_nchoices = 0;
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
     uint16_t* sched_prev = nullptr;    /* TapeSchedule::prev_writer */
@@ -366,6 +375,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     }
     if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
@@ -467,6 +477,8 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->pool) (void)hipFree(c->pool);
     if (c->tape_index) (void)hipFree(c->tape_index);
     free_executable(c->jit_code);
+    free_executable(c->gen_code);
+    if (c->gen_stage) (void)hipFree(c->gen_stage);
     if (c->groups) (void)hipFree(c->groups);
     if (c->group_alive) (void)hipFree(c->group_alive);
     if (c->group_list) (void)hipFree(c->group_list);
@@ -532,6 +544,35 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         HIP_TRY(hipStreamSynchronize(c->stream));   /* pageable source must stay valid */
         c->tape_serial = tape->serial;
         c->tape_len = len;
+        /* the tape's interval walks as machine code, for the stage whose tiles all walk this very tape */
+        c->gen_ok = false;
+        if (c->tile_gen && c->tiles_asm && c->tiles_vgpr && tape->num_slots <= mpr::TILE_GEN_MAX_SLOTS) {
+            const mpr::TileGen g = mpr::tile_gen_build(tape->clauses.data(), len);
+            const size_t ndw = g.fwd.size() + g.bwd.size();
+            if (g.ok && ndw > 0) {
+                if (ndw > c->gen_cap_dw) {
+                    free_executable(c->gen_code);
+                    if (c->gen_stage) (void)hipFree(c->gen_stage);
+                    c->gen_code = nullptr;
+                    c->gen_stage = nullptr;
+                    c->gen_cap_dw = 0;
+                    const size_t want = (ndw + 1023) & ~(size_t)1023;
+                    c->gen_code = static_cast<uint32_t*>(alloc_executable(c->device, want * sizeof(uint32_t)));
+                    if (c->gen_code && hipMalloc((void**)&c->gen_stage, want * sizeof(uint32_t)) == hipSuccess) c->gen_cap_dw = want;
+                }
+                if (c->gen_cap_dw >= ndw) {
+                    std::vector<uint32_t> both(g.fwd);
+                    both.insert(both.end(), g.bwd.begin(), g.bwd.end());
+                    HIP_TRY(hipMemcpyAsync(c->gen_stage, both.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                    mprk::launch_install_code(c->stream, c->gen_code, c->gen_stage, ndw, std::max(c->cus, 1));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    c->gen_ok = true;
+                    c->gen_fwd_dw = (int)g.fwd.size();
+                    c->gen_words = g.words;
+                    c->gen_nchoices = g.nchoices;
+                }
+            }
+        }
         /* the tape's level schedule for the wide first-stage kernel */
         const mpr::TapeSchedule& sc = tape->schedule;
         /* level-parallel first stage only for DAGs that are wide enough to feed a wavefront: with a
@@ -816,6 +857,13 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             group_cap = std::max(stage_cap, 1);
         }
         mprk::TileStageArgs a;
+        if (c->gen_ok && si == (skip0 ? 1 : 0) && !last && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0) {
+            /* every tile of the frame's first stage walks the root tape */
+            a.gen_fwd = c->gen_code;
+            a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
+        }
         a.pipe_slots = nullptr;
         a.pipe_ctl = nullptr;
         a.no_mask = c->stage0_only;

@@ -33,6 +33,7 @@
 
 #include "kernel_common.hpp"
 #include "tile_interp_asm.hpp"
+#include "tile_gen_asm.hpp"
 
 namespace mprk {
 
@@ -147,10 +148,13 @@ __device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, fl
  * nslots <= 128), else the compiled loop below (slot file float2 per lane) */
 /* VS (with ASM): the slot file in vector registers instead (tile_interp_asm_vgpr: tapes with 40 to 93 slots, whose LDS
  * planes would leave room for fewer than 8 wavefronts per CU); LDS then holds the choices and 2 KB of scratch */
-template <int DIM, bool ASM, int VS = 0>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
+/* GEN (with VS = 24): every tile of the launch walks the ROOT tape, whose walks exist as generated code (tile_gen.hpp,
+ * TileStageArgs::gen_fwd / gen_bwd): a frame's first stage */
+template <int DIM, bool ASM, int VS = 0, bool GEN = false>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
 __global__ void __launch_bounds__(64, VS == TI_VS_SMALL_SLOTS ? 4 : VS ? 2 : 0)
 k_eval_tiles(TileStageArgs a)
 {
+    static_assert(!GEN || (ASM && VS == TI_VS_SMALL_SLOTS), "generated code runs on the small register slot file");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const size_t planes_bytes = VS ? 0 : (size_t)a.nslots * 512;
     float2* const slots = reinterpret_cast<float2*>(smem);                       /* [nslots][64] */
@@ -187,7 +191,7 @@ k_eval_tiles(TileStageArgs a)
     const int tape = __builtin_amdgcn_readlane(node.tape, leader);
     /* the tape's first 64 words travel under the interval arithmetic of the prologue */
     uint64_t first_block = 0;
-    if (ASM) first_block = a.tape_ro[tape + 1 + lane];
+    if (ASM && !GEN) first_block = a.tape_ro[tape + 1 + lane];
 
     /* tile corners in round-to-nearest (reference :91-96) */
     const float t = (float)a.tps;
@@ -249,7 +253,27 @@ k_eval_tiles(TileStageArgs a)
     int end_index = 0;                 /* pool index of the end clause */
     uint64_t d = 0;
     float2 res_vs = make_float2(0.0f, 0.0f);
-    if (ASM) {
+    uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};      /* GEN: this lane's decisions (bit k: chose lhs / rhs at min / max clause k) */
+    unsigned char* const gen_io = smem + (size_t)a.choice_cap * 16;
+    if constexpr (GEN) {
+        tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                         2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                         make_float2(vz.lo, vz.hi), &res_vs, chl, chr);
+        ci = a.gen_nchoices;
+        fwd_words = a.gen_words;
+        nclauses = fwd_words - 1;
+        end_index = tape + a.gen_words;
+        d = tro[end_index];
+        any_choice = ballot((chl[0] | chl[1] | chr[0] | chr[1]) != 0) & alive_mask;
+        if (!a.gen_bwd) {
+            /* the assembly backward walk reads the decisions as masks over the lanes */
+            for (int k = 0; k < ci && k < a.choice_cap; ++k) {
+                const uint64_t m1 = ballot((chl[k >> 5] >> (k & 31)) & 1u) & alive_mask;
+                const uint64_t m2 = ballot((chr[k >> 5] >> (k & 31)) & 1u) & alive_mask;
+                if (lane == 0) choices[k] = make_ulonglong2(m1, m2);
+            }
+        }
+    } else if (ASM) {
         const TileInterpResult ir =
             VS ? tile_interp_asm_vgpr<(VS ? VS : TI_VS_MAX_SLOTS)>(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, a.choice_cap, &first_block,
                                       2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
@@ -461,7 +485,28 @@ k_eval_tiles(TileStageArgs a)
         lm_set(lm, i_out, live);
 
         MPR_PHASE(2);
-        if (ASM) {
+        if (GEN && a.gen_bwd) {
+            /* backward walk by the root tape's generated code (tile_gen_asm.hpp) */
+            TileGenPush gp;
+            gp.active = writing ? (1u << i_out) : 0u;
+            gp.pos = (uint32_t)(out_index + out_offset);
+            gp.first = (uint32_t)out_index;
+            gp.run_end = (uint32_t)run_end;
+            const long long lim = a.pool_cap - 65;
+            tile_gen_backward(a.gen_bwd, tro, gen_io, lane, gp, chl, chr, (uint32_t)(lim < 0 ? 0 : (lim > 0x7FFFFF00ll ? 0x7FFFFF00ll : lim)));
+            if (writing) {
+                out_index = (int)gp.first;
+                out_offset = (int)(gp.pos - gp.first);
+                overflow = gp.overflow != 0;
+            }
+            writing = push && !overflow;
+            live = ballot(writing);
+            bwd_words = a.gen_words;
+            int kept = writing ? (int)gp.kept : 0;
+            for (int off = 32; off > 0; off >>= 1) kept = max(kept, __shfl_xor(kept, off));
+            kept_minmax = kept;
+            d = tro[tape];
+        } else if (ASM) {
             /* backward walk by the assembly interpreter (tile_interp_asm.hpp) */
             TilePushState st;
             st.a0l = lm.lo0; st.a0h = lm.hi0; st.a1l = lm.lo1; st.a1h = lm.hi1;
@@ -1157,6 +1202,12 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
     const int vs = (use_asm && a.vgpr_slots && !(a.debug & 4)) ? tile_stage_vgpr_class(a.nslots, a.choice_cap) : 0;
     const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
+    if (a.gen_fwd && use_asm && a.vgpr_slots && a.nslots <= TI_VS_SMALL_SLOTS && !a.groups) {
+        const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
+        if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
+        else hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
+        return;
+    }
     if (dim == 3) {
         if (vs == TI_VS_SMALL_SLOTS) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
         else if (vs) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_MAX_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
@@ -1168,6 +1219,21 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
         else if (use_asm) hipLaunchKernelGGL((k_eval_tiles<2, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, false>), dim3(groups), dim3(64), lds, s, a);
     }
+}
+__global__ void k_copy_code(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n)
+{
+    const size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    if (i < n) dst[i] = src[i];
+}
+__global__ void k_icache_inv()
+{
+    asm volatile("s_icache_inv\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0" ::: "memory");
+}
+void launch_install_code(hipStream_t s, uint32_t* exec_dst, const uint32_t* src, size_t dwords, int cus)
+{
+    hipLaunchKernelGGL(k_copy_code, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, s, exec_dst, src, dwords);
+    /* (a kernel boundary writes the copy back to memory; the instruction caches are not part of that) */
+    hipLaunchKernelGGL(k_icache_inv, dim3((unsigned)cus * 32u), dim3(64), 0, s);
 }
 static CopyFilled copy_filled_args(const int* prev, int* next, int size, int first_block, unsigned* extra)
 {

@@ -75,6 +75,10 @@ struct TileStageArgs {
     int measure_at[2], measure_len;   /* the sample len_stats is taken over: groups [measure_at[k], measure_at[k] + measure_len) */
     int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
                                 * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */
+    const uint32_t* gen_fwd = nullptr;   /* a launch whose tiles all walk the ROOT tape (a frame's first stage), tape of at most 24 slots and
+                                          * 64 min / max clauses: its walks as generated code (tile_gen.hpp) — else null */
+    const uint32_t* gen_bwd = nullptr;   /* (null with gen_fwd set: the assembly interpreter walks backward; development) */
+    int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
 };
 
 /* first tile stage, one workgroup per tile, level by level over the root tape's DAG
@@ -141,6 +145,8 @@ void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngr
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
+/* host-generated code (tile_gen.hpp) into executable memory: copied by a kernel, then every CU drops its instruction cache */
+void launch_install_code(hipStream_t s, uint32_t* exec_dst, const uint32_t* src, size_t dwords, int cus);
 bool wide_stage_fits(int nclauses);
 size_t wide_stage_lds_bytes(int nclauses);
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced = 0);

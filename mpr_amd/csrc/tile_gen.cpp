@@ -1,0 +1,313 @@
+/* tile_gen.cpp — see tile_gen.hpp.  Instruction encodings: GFX9 family (gfx950); tests/test_tile_gen.py disassembles what
+ * this file emits with the ROCm assembler and compares it with the instructions it is meant to be. */
+#include "tile_gen.hpp"
+
+#include "../../include/mpr_clause.h"
+
+namespace mpr {
+namespace {
+
+constexpr uint32_t SIGN = 0x80000000u;
+/* VOP2 opcodes */
+constexpr int V_CNDMASK = 0, V_ADD_F32 = 1, V_SUB_F32 = 2, V_SUBREV_F32 = 3, V_MUL_F32 = 5, V_LSHLREV = 18, V_AND = 19, V_OR = 20,
+              V_XOR = 21, V_ADD_U32 = 52, V_SUB_U32 = 53;
+/* VOP3 opcodes */
+constexpr int V3_CNDMASK = 0x100, V3_ADD_F32 = 0x101, V3_MUL_F32 = 0x105, V3_BFE_U32 = 0x1C8, V3_LSHL_OR = 0x200;
+/* VOPC opcodes */
+constexpr int VC_EQ_U32 = 0xCA, VC_NE_U32 = 0xCD;
+constexpr uint32_t VCC = 106, EXEC = 126, LIT = 255;
+
+struct Emit {
+    std::vector<uint32_t>& c;
+    static uint32_t V(int r) { return 256u + (uint32_t)r; }
+    static uint32_t I(int k) { return 128u + (uint32_t)k; }                     /* inline integer 0..64 */
+    void d(uint32_t x) { c.push_back(x); }
+    void vop2(int op, int vdst, uint32_t src0, int vsrc1) { d((uint32_t)op << 25 | (uint32_t)vdst << 17 | (uint32_t)vsrc1 << 9 | src0); }
+    void vop2_lit(int op, int vdst, uint32_t lit, int vsrc1) { vop2(op, vdst, LIT, vsrc1); d(lit); }
+    void mov(int vdst, uint32_t src0) { d(0x7E000200u | (uint32_t)vdst << 17 | src0); }
+    void mov_lit(int vdst, uint32_t lit) { mov(vdst, LIT); d(lit); }
+    void vop3(int op, uint32_t dst, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t neg = 0)
+    {
+        d(0xD0000000u | (uint32_t)op << 16 | dst);
+        d(s0 | s1 << 9 | s2 << 18 | neg << 29);
+    }
+    void vopc(int op, uint32_t src0, int vsrc1) { d(0x7C000000u | (uint32_t)op << 17 | (uint32_t)vsrc1 << 9 | src0); }
+    void swappc(int ret, int target) { d(0xBE801E00u | (uint32_t)ret << 16 | (uint32_t)target); }
+    void setpc(int target) { d(0xBE801D00u | (uint32_t)target); }
+    void mov_exec(uint32_t src) { d(0xBE800100u | EXEC << 16 | src); }
+    void cbranch_vccz(int dwords) { d(0xBF860000u | (uint32_t)(dwords & 0xFFFF)); }
+    void nop(int n) { d(0xBF800000u | (uint32_t)n); }
+    void store_x2(int vaddr, int vdata, int saddr) { d(0xDC748000u); d((uint32_t)vaddr | (uint32_t)vdata << 8 | (uint32_t)saddr << 16); }
+};
+
+inline int lo(int s) { return 68 + 2 * s; }
+inline int hi(int s) { return 69 + 2 * s; }
+
+/* ---- forward ---- */
+void call1(Emit& e, int target, int o, int l)
+{
+    e.mov(36, Emit::V(lo(l)));
+    e.mov(37, Emit::V(hi(l)));
+    e.swappc(TG_RET_ROUTINE, target);
+    e.mov(lo(o), Emit::V(40));
+    e.mov(hi(o), Emit::V(41));
+}
+/* lhs (slot, or the immediate when l < 0) and rhs likewise */
+void call2(Emit& e, int target, int o, int l, int r, uint32_t imm)
+{
+    if (l >= 0) {
+        e.mov(36, Emit::V(lo(l)));
+        e.mov(37, Emit::V(hi(l)));
+    } else {
+        e.mov_lit(36, imm);
+        e.mov(37, Emit::V(36));
+    }
+    if (r >= 0) {
+        e.mov(38, Emit::V(lo(r)));
+        e.mov(39, Emit::V(hi(r)));
+    } else {
+        e.mov_lit(38, imm);
+        e.mov(39, Emit::V(38));
+    }
+    e.swappc(TG_RET_ROUTINE, target);
+    e.mov(lo(o), Emit::V(40));
+    e.mov(hi(o), Emit::V(41));
+}
+
+bool forward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t K, int choice)
+{
+    const int Ol = lo(o), Oh = hi(o), Al = lo(l), Ah = hi(l), Bl = lo(r), Bh = hi(r);
+    switch (op) {
+        case MPR_OP_SQUARE_LHS: call1(e, TG_RT_SQUARE, o, l); break;
+        case MPR_OP_SQRT_LHS: call1(e, TG_RT_SQRT, o, l); break;
+        case MPR_OP_NEG_LHS:                                 /* [-hi, -lo] */
+            e.vop2_lit(V_XOR, 40, SIGN, Ah);
+            e.vop2_lit(V_XOR, Oh, SIGN, Al);
+            e.mov(Ol, Emit::V(40));
+            break;
+        case MPR_OP_SIN_LHS:
+        case MPR_OP_COS_LHS:                                 /* the constant interval [-1, 1] (inc/gpu_interval.hpp:346-380) */
+            e.mov(Ol, 243);
+            e.mov(Oh, 242);
+            break;
+        case MPR_OP_ASIN_LHS: call1(e, TG_RT_ASIN, o, l); break;
+        case MPR_OP_ACOS_LHS: call1(e, TG_RT_ACOS, o, l); break;
+        case MPR_OP_ATAN_LHS: call1(e, TG_RT_ATAN, o, l); break;
+        case MPR_OP_EXP_LHS: call1(e, TG_RT_EXP, o, l); break;
+        case MPR_OP_ABS_LHS: call1(e, TG_RT_ABS, o, l); break;
+        case MPR_OP_LOG_LHS: call1(e, TG_RT_LOG, o, l); break;
+        /* sums and differences in round-up mode: the lower bound as minus the rounded-up negation.  The lower ends are
+         * consumed first, so that out may be one of the operands */
+        case MPR_OP_ADD_LHS_IMM:
+            e.vop2_lit(V_SUB_F32, 40, K ^ SIGN, Al);                          /* -(lo + K) = (-K) - lo */
+            e.vop2_lit(V_ADD_F32, Oh, K, Ah);
+            e.vop2_lit(V_XOR, Ol, SIGN, 40);
+            break;
+        case MPR_OP_ADD_LHS_RHS:
+            e.vop3(V3_ADD_F32, 40, Emit::V(Al), Emit::V(Bl), 0, 3);            /* (-a.lo) + (-b.lo) */
+            e.vop2(V_ADD_F32, Oh, Emit::V(Ah), Bh);
+            e.vop2_lit(V_XOR, Ol, SIGN, 40);
+            break;
+        case MPR_OP_MUL_LHS_IMM: {
+            /* K < 0 swaps the ends (the comparison the interpreter makes at run time: false for -0 and NaN) */
+            union { uint32_t u; float f; } k;
+            k.u = K;
+            const bool neg = k.f < 0.0f;
+            e.mov_lit(42, K);
+            e.vop3(V3_MUL_F32, 40, Emit::V(neg ? Ah : Al), Emit::V(42), 0, 1);  /* -lo = RU((-p) K) */
+            e.vop2(V_MUL_F32, Oh, Emit::V(neg ? Al : Ah), 42);                 /* hi = RU(q K) */
+            e.vop2_lit(V_XOR, Ol, SIGN, 40);
+            break;
+        }
+        case MPR_OP_MUL_LHS_RHS: call2(e, TG_RT_MUL, o, l, r, K); break;
+        case MPR_OP_MIN_LHS_IMM:
+        case MPR_OP_MIN_LHS_RHS:
+        case MPR_OP_MAX_LHS_IMM:
+        case MPR_OP_MAX_LHS_RHS: {
+            const bool is_min = op <= MPR_OP_MIN_LHS_RHS;
+            const bool has_rhs = op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS;
+            call2(e, is_min ? TG_RT_MIN : TG_RT_MAX, o, l, has_rhs ? r : -1, K);
+            /* the routine leaves vcc = lanes that did NOT choose the lhs, s[92:93] = lanes that chose the rhs */
+            e.mov_lit(42, 1u << (choice & 31));
+            e.vop3(V3_CNDMASK, 43, Emit::V(42), Emit::I(0), VCC);
+            e.vop2(V_OR, 56 + (choice >> 5), Emit::V(56 + (choice >> 5)), 43);
+            e.vop3(V3_CNDMASK, 43, Emit::I(0), Emit::V(42), 92);
+            e.vop2(V_OR, 58 + (choice >> 5), Emit::V(58 + (choice >> 5)), 43);
+            break;
+        }
+        case MPR_OP_SUB_LHS_IMM:
+            e.vop2_lit(V_SUB_F32, 40, K, Al);                                  /* K - lo */
+            e.vop2_lit(V_SUBREV_F32, Oh, K, Ah);                               /* hi - K */
+            e.vop2_lit(V_XOR, Ol, SIGN, 40);
+            break;
+        case MPR_OP_SUB_IMM_RHS:
+            e.vop2_lit(V_SUBREV_F32, 40, K, Bh);                               /* hi - K */
+            e.vop2_lit(V_SUB_F32, Oh, K, Bl);                                  /* K - lo */
+            e.vop2_lit(V_XOR, Ol, SIGN, 40);
+            break;
+        case MPR_OP_SUB_LHS_RHS:
+            e.vop2(V_SUB_F32, 40, Emit::V(Bh), Al);                            /* b.hi - a.lo */
+            e.vop2(V_SUB_F32, Oh, Emit::V(Ah), Bl);                            /* a.hi - b.lo */
+            e.vop2_lit(V_XOR, Ol, SIGN, 40);
+            break;
+        case MPR_OP_DIV_LHS_IMM: call2(e, TG_RT_DIVI, o, l, -1, K); break;
+        case MPR_OP_DIV_IMM_RHS: call2(e, TG_RT_DIV, o, -1, r, K); break;
+        case MPR_OP_DIV_LHS_RHS: call2(e, TG_RT_DIV, o, l, r, K); break;
+        case MPR_OP_COPY_IMM:
+            e.mov_lit(Ol, K);
+            e.mov(Oh, Emit::V(Ol));
+            break;
+        case MPR_OP_COPY_LHS:
+            if (o != l) {
+                e.mov(Ol, Emit::V(Al));
+                e.mov(Oh, Emit::V(Ah));
+            }
+            break;
+        case MPR_OP_COPY_RHS:
+            if (o != r) {
+                e.mov(Ol, Emit::V(Bl));
+                e.mov(Oh, Emit::V(Bh));
+            }
+            break;
+        default: return false;
+    }
+    return true;
+}
+
+/* ---- backward (reference :351-458; the compiled restatement: kernels.hip, "backward walk") ---- */
+/* pos -= the lanes' emit flag (VGPR ef); lanes whose chunk is full move to the next one of their run */
+void take_word(Emit& e, int ef)
+{
+    e.vop2(V_SUB_U32, 61, Emit::V(61), ef);
+    e.vopc(VC_EQ_U32, Emit::V(61), 62);
+    e.cbranch_vccz(1);
+    e.swappc(TG_RET_ROUTINE, TG_RT_CHUNK);                   /* clears v32 / v35 of a lane that ran out of chunks */
+}
+void store_word(Emit& e, int ef, uint32_t W1, uint32_t& cur_hi)
+{
+    if (W1 != cur_hi) {
+        e.mov_lit(47, W1);
+        cur_hi = W1;
+    }
+    e.vopc(VC_NE_U32, Emit::I(0), ef);
+    e.vop2(V_LSHLREV, 44, Emit::I(3), 61);
+    e.mov_exec(VCC);
+    e.store_x2(44, 46, 76);
+    e.mov_exec(193);                                          /* -1 */
+}
+
+void backward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uint32_t W1, int choice, uint32_t& cur_hi)
+{
+    e.vop3(V3_BFE_U32, 32, Emit::V(60), Emit::I(o), Emit::I(1));                 /* is the out slot active for this lane? */
+    if (!mpr_op_is_minmax(op)) {
+        take_word(e, 32);
+        /* active[o] = 0, active[l] = active[r] = 1 for those lanes (an operand that is the out slot: bit unchanged) */
+        if (l != o && r != o) e.vop2_lit(V_AND, 60, ~(1u << o), 60);
+        if (l != 0 && l != o) e.vop3(V3_LSHL_OR, 60, Emit::V(32), Emit::I(l), Emit::V(60));
+        if (r != 0 && r != o && r != l) e.vop3(V3_LSHL_OR, 60, Emit::V(32), Emit::I(r), Emit::V(60));
+        e.mov_lit(46, W0);
+        store_word(e, 32, W1, cur_hi);
+        return;
+    }
+    /* min / max: lanes that chose a side keep that operand only and get a COPY — or nothing, when it would copy a slot
+     * onto itself */
+    e.vop3(V3_BFE_U32, 33, Emit::V(56 + (choice >> 5)), Emit::I(choice & 31), Emit::I(1));   /* chose lhs */
+    e.vop3(V3_BFE_U32, 34, Emit::V(58 + (choice >> 5)), Emit::I(choice & 31), Emit::I(1));   /* chose rhs */
+    e.vop2(V_OR, 36, Emit::V(33), 34);
+    e.vop2(V_XOR, 36, Emit::I(1), 36);
+    e.vop2(V_AND, 36, Emit::V(36), 32);                                          /* undecided and active: keeps the min / max */
+    e.vop2(V_ADD_U32, 54, Emit::V(54), 36);
+    const bool dropL = l == o, dropR = r != 0 && r == o;
+    if (!dropL && !dropR) {
+        e.mov(35, Emit::V(32));
+    } else if (dropL && dropR) {
+        e.mov(35, Emit::V(36));
+    } else {
+        e.vop2(V_XOR, 35, Emit::I(1), dropL ? 33 : 34);
+        e.vop2(V_AND, 35, Emit::V(35), 32);
+    }
+    take_word(e, 35);
+    e.vop2(V_XOR, 37, Emit::I(1), 34);
+    e.vop2(V_AND, 37, Emit::V(37), 32);                                          /* lhs stays live: active, did not choose rhs */
+    if (r != 0) {
+        e.vop2(V_XOR, 38, Emit::I(1), 33);
+        e.vop2(V_AND, 38, Emit::V(38), 32);
+    }
+    e.vop2_lit(V_AND, 60, ~(1u << o), 60);
+    if (l != 0) e.vop3(V3_LSHL_OR, 60, Emit::V(37), Emit::I(l), Emit::V(60));
+    if (r != 0) e.vop3(V3_LSHL_OR, 60, Emit::V(38), Emit::I(r), Emit::V(60));
+    e.vopc(VC_NE_U32, Emit::I(0), 33);
+    e.mov_lit(46, W0);
+    e.mov_lit(39, (W0 & ~0xFFu) | MPR_OP_COPY_LHS);
+    e.vop2(V_CNDMASK, 46, Emit::V(46), 39);
+    e.vopc(VC_NE_U32, Emit::I(0), 34);
+    e.mov_lit(40, (W0 & ~0xFFu) | (r != 0 ? MPR_OP_COPY_RHS : MPR_OP_COPY_IMM));
+    e.nop(0);
+    e.vop2(V_CNDMASK, 46, Emit::V(46), 40);
+    store_word(e, 35, W1, cur_hi);
+}
+
+}  // namespace
+
+TileGen tile_gen_build(const uint64_t* clauses, int len)
+{
+    TileGen g;
+    if (!clauses || len < 2) return g;
+    int end = -1, nch = 0;
+    for (int i = 1; i < len; ++i) {
+        const uint32_t op = (uint32_t)clauses[i] & 0xFF;
+        const int o = (int)(clauses[i] >> 8) & 0xFF, l = (int)(clauses[i] >> 16) & 0xFF, r = (int)(clauses[i] >> 24) & 0xFF;
+        if (o >= TILE_GEN_MAX_SLOTS || l >= TILE_GEN_MAX_SLOTS || r >= TILE_GEN_MAX_SLOTS) return g;
+        if (op == MPR_OP_INVALID) {
+            end = i;
+            break;
+        }
+        if (op == MPR_OP_JUMP || op >= MPR_OP_COUNT || o == 0) return g;
+        if (mpr_op_is_minmax(op)) ++nch;
+    }
+    if (end < 0 || nch > TILE_GEN_MAX_CHOICES) return g;
+    {
+        const int hx = (int)(clauses[0] >> 8) & 0xFF, hy = (int)(clauses[0] >> 16) & 0xFF, hz = (int)(clauses[0] >> 24) & 0xFF;
+        if (hx >= TILE_GEN_MAX_SLOTS || hy >= TILE_GEN_MAX_SLOTS || hz >= TILE_GEN_MAX_SLOTS) return g;
+    }
+    Emit f{g.fwd}, b{g.bwd};
+    int choice = 0;
+    for (int i = 1; i < end; ++i) {
+        const uint64_t w = clauses[i];
+        const uint32_t op = (uint32_t)w & 0xFF;
+        if (!forward_clause(f, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), choice)) {
+            g.fwd.clear();
+            return g;
+        }
+        if (mpr_op_is_minmax(op)) ++choice;
+    }
+    g.result_slot = (int)(clauses[end] >> 8) & 0xFF;
+    f.mov(36, Emit::V(lo(g.result_slot)));
+    f.mov(37, Emit::V(hi(g.result_slot)));
+    f.setpc(TG_RET_CODE);
+
+    uint32_t cur_hi = 0;                                      /* the harness enters with v47 = 0 */
+    for (int i = end - 1; i >= 1; --i) {
+        const uint64_t w = clauses[i];
+        const uint32_t op = (uint32_t)w & 0xFF;
+        if (mpr_op_is_minmax(op)) --choice;
+        backward_clause(b, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)w, (uint32_t)(w >> 32), choice, cur_hi);
+    }
+    b.setpc(TG_RET_CODE);
+    g.words = end;
+    g.nchoices = nch;
+    g.ok = true;
+    return g;
+}
+
+}  // namespace mpr
+
+extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
+{
+    const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
+    if (!g.ok || which < 0 || which > 1) return -1;
+    const std::vector<uint32_t>& c = which ? g.bwd : g.fwd;
+    if (out && (int)c.size() <= cap)
+        for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
+    return (int)c.size();
+}

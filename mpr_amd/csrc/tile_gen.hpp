@@ -1,0 +1,49 @@
+/*
+ * tile_gen.hpp — the ROOT tape's interval walks as gfx950 machine code, generated on the host when a tape is made resident.
+ *
+ * Every tile of a frame's first stage walks the same tape (reference src/context.cu:188-321 forward, :323-458 backward), so
+ * unlike the tapes pushed later this one is worth compiling: a clause becomes the handful of instructions its opcode needs,
+ * with the slot registers and the immediate in the instruction words — no fetch, no decode, no dispatch, no operand moves
+ * through a register index.  The arithmetic is the interpreter's own (tile_interp_asm.hpp): simple clauses are emitted in
+ * line, the others call the interpreter's routine bodies.  Counterpart on the device: tile_gen_asm.hpp.
+ *
+ * Register conventions of the generated code (fixed: the harness and the routine bodies are written against them)
+ *   slot s                  v[68 + 2 s] (lower bound), v[69 + 2 s] (upper bound)           s <= 24
+ *   routine operands        v[36:37] lhs, v[38:39] rhs; result v[40:41]
+ *   decisions               v56 / v57: bit k set = this lane's tile chose the LHS at min / max clause k (k < 32 / k >= 32),
+ *                           v58 / v59: the same for the RHS
+ *   routine entry points    SGPR pairs (TileGenReg), return address s[36:37]; the code itself returns through s[38:39]
+ * backward walk
+ *   v60 active slots (bit s), v61 pool index of the last word written, v62 first index of the current chunk,
+ *   v[46:47] the clause word being stored (v47 keeps the last upper half), s[76:77] pool, s[62:63] "chunk full" routine
+ */
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mpr {
+
+constexpr int TILE_GEN_MAX_SLOTS = 24;      /* slots 0..23 */
+constexpr int TILE_GEN_MAX_CHOICES = 64;
+
+enum TileGenReg : int {
+    TG_RT_SQUARE = 62, TG_RT_ABS = 64, TG_RT_MUL = 66, TG_RT_SQRT = 68, TG_RT_MIN = 70, TG_RT_MAX = 80, TG_RT_DIV = 82,
+    TG_RT_DIVI = 84, TG_RT_ASIN = 86, TG_RT_ACOS = 88, TG_RT_ATAN = 90, TG_RT_EXP = 98, TG_RT_LOG = 96,
+    TG_RET_ROUTINE = 36, TG_RET_CODE = 38,
+    TG_RT_CHUNK = 62,
+};
+
+struct TileGen {
+    bool ok = false;
+    std::vector<uint32_t> fwd;      /* forward walk: axes in their slots -> result in v[36:37], decisions in v56..v59 */
+    std::vector<uint32_t> bwd;      /* backward walk of tape pushing */
+    int words = 0;                  /* clause words a walk visits: the operations and the end clause (or the head) */
+    int nchoices = 0;               /* min / max clauses */
+    int result_slot = 0;
+};
+
+/* clauses: head, operations, end (the host copy of a root tape).  ok == false: the tape does not fit the conventions
+ * above (a slot beyond 23, more than 64 min / max clauses, a jump or an unknown opcode) — the interpreter walks it. */
+TileGen tile_gen_build(const uint64_t* clauses, int len);
+
+}  // namespace mpr

@@ -1,0 +1,195 @@
+/*
+ * tile_gen_asm.hpp — device side of tile_gen.hpp: the harnesses that run the ROOT tape's generated interval code for the 64
+ * tiles of a wavefront (k_eval_tiles<.., GEN>), forward (reference src/context.cu:236-279) and backward (tape pushing,
+ * :351-458).  The generated code is a straight line of instructions per clause; what a clause cannot do in three or four
+ * instructions it calls here: the interpreter's own interval routines (TI_BODIES_TEXT, ending in a return instead of a
+ * dispatch), min / max variants that leave the lanes' decisions to the caller, and the "chunk full" step of the backward walk.
+ * Registers: tile_gen.hpp.  The wave must be in round-up mode with all 64 lanes enabled.
+ */
+#pragma once
+#include "tile_interp_asm.hpp"
+
+namespace mprk {
+
+#undef TI_ST
+#undef TI_GO
+#define TI_ST ""
+#define TI_GO "s_setpc_b64 s[36:37]\n"
+/* entry point of a routine, relative to L_pc (s[40:41]) */
+#define TG_ADDR(lo, hi, label) "s_add_u32 s" #lo ", s40, " label "_%=-L_pc_%=\n s_addc_u32 s" #hi ", s41, 0\n"
+
+/* smem_io: 4 KB of LDS ([16][64] words) the register state travels through: the statement below names all but ten vector
+ * registers.  ax / ay / az: 2 * the axes' slots; x / y / z: their intervals.  Out: the end clause's interval, and the lanes'
+ * decisions at the tape's min / max clauses (bit k of chl / chr: chose lhs / rhs at clause k; two words each). */
+DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane, uint32_t ax, uint32_t ay, uint32_t az,
+                          float2 x, float2 y, float2 z, float2* res, uint32_t* chl, uint32_t* chr)
+{
+    float* const io = reinterpret_cast<float*>(smem_io);
+    io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
+    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    ax = rdfirst(ax);
+    ay = rdfirst(ay);
+    az = rdfirst(az);
+    asm volatile(
+        TI_VS_ENTER
+        "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
+        "s_getpc_b64 s[40:41]\n"
+        "L_pc_%=:\n"
+        TG_ADDR(62, 63, "L_square") TG_ADDR(64, 65, "L_abs") TG_ADDR(66, 67, "L_mul") TG_ADDR(68, 69, "L_isqrt")
+        TG_ADDR(70, 71, "L_gmin") TG_ADDR(80, 81, "L_gmax") TG_ADDR(82, 83, "L_gdiv") TG_ADDR(84, 85, "L_gdivi")
+        TG_ADDR(86, 87, "L_casin") TG_ADDR(88, 89, "L_cacos") TG_ADDR(90, 91, "L_catan") TG_ADDR(98, 99, "L_cexp")
+        TG_ADDR(96, 97, "L_clog")
+        "s_mov_b32 s34, %[clo]\n"
+        "s_mov_b32 s35, %[chi]\n"
+        "s_swappc_b64 s[38:39], s[34:35]\n"
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
+        "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
+        "ds_write_b32 v32, v56 offset:2048\n ds_write_b32 v32, v57 offset:2304\n"
+        "ds_write_b32 v32, v58 offset:2560\n ds_write_b32 v32, v59 offset:2816\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_branch L_end_%=\n"
+        TI_BODIES_TEXT
+        /* min / max of v[36:37], v[38:39] -> v[40:41] (device_math.hpp i_min / i_max); the decisions stay with the lanes:
+         * vcc = did NOT choose the lhs, s[92:93] = chose the rhs (the caller records them) */
+        "L_gmin_%=:\n"
+        "v_max_f32 v42, v38, v38\n"
+        "v_max_f32 v43, v36, v36\n"
+        "v_max_f32 v44, v39, v39\n"
+        "v_cmp_nlt_f32 vcc, v37, v38\n"                  /* !c1, c1: x.hi < y.lo */
+        "v_cmp_gt_f32 s[92:93], v36, v39\n"              /* y.hi < x.lo */
+        "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
+        "v_min_f32 v42, v43, v42\n"
+        "v_max_f32 v43, v37, v37\n"
+        "v_min_f32 v43, v43, v44\n"
+        "s_branch L_gsel_%=\n"
+        "L_gmax_%=:\n"
+        "v_max_f32 v42, v38, v38\n"
+        "v_max_f32 v43, v36, v36\n"
+        "v_max_f32 v44, v39, v39\n"
+        "v_cmp_ngt_f32 vcc, v36, v39\n"                  /* !c1, c1: x.lo > y.hi */
+        "v_cmp_lt_f32 s[92:93], v37, v38\n"              /* y.lo > x.hi */
+        "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
+        "v_max_f32 v42, v43, v42\n"
+        "v_max_f32 v43, v37, v37\n"
+        "v_max_f32 v43, v43, v44\n"
+        "L_gsel_%=:\n"
+        "v_cndmask_b32 v40, v42, v38, s[92:93]\n"
+        "v_cndmask_b32 v41, v43, v39, s[92:93]\n"
+        "v_cndmask_b32 v40, v36, v40, vcc\n"
+        "v_cndmask_b32 v41, v37, v41, vcc\n"
+        "s_setpc_b64 s[36:37]\n"
+        /* division: s[58:59] = lanes whose divisor v[38:39] contains zero (the handlers' tests, tile_interp_asm.hpp) */
+        "L_gdiv_%=:\n"
+        "v_cmp_ge_f32 s[58:59], 0, v38\n v_cmp_le_f32 vcc, 0, v39\n"
+        "s_and_b64 s[58:59], s[58:59], vcc\n s_branch L_idiv_%=\n"
+        "L_gdivi_%=:\n"                                  /* a constant divisor */
+        "v_cmp_lg_f32 s[58:59], 0, v38\n s_nop 0\n"
+        "s_not_b64 s[58:59], s[58:59]\n s_branch L_idiv_%=\n"
+        "L_end_%=:\n"
+        :
+        : [lane8] "v"(lane8), [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi)
+        : "memory", "vcc", "scc",
+          "s34", "s35", "s36", "s37", "s38", "s39",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
+          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
+          "s97", "s98", "s99",
+          "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
+          "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
+          "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", TI_V10(8), TI_V10(9), TI_V10(10),
+          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117");
+    res->x = io[384 + lane];
+    res->y = io[448 + lane];
+    const uint32_t* const iw = reinterpret_cast<const uint32_t*>(io);
+    chl[0] = iw[512 + lane];
+    chl[1] = iw[576 + lane];
+    chr[0] = iw[640 + lane];
+    chr[1] = iw[704 + lane];
+}
+
+/* The backward walk.  Per lane in: active (bit = slot: the end clause's out slot for a pushing lane, 0 otherwise), pos = pool
+ * index of the last word written (the end clause), first = first index of its chunk, run_end = first index past its run of
+ * chunks; the decisions.  Out: pos and first where the walk stopped (the head goes to pos - 1), overflow (ran out of chunks),
+ * kept = min / max clauses the lane's tape keeps.  pool_limit: last index a chunk may start at. */
+struct TileGenPush {
+    uint32_t active, pos, first, run_end;
+    uint32_t overflow, kept;
+};
+DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned char* smem_io, int lane, TileGenPush& st,
+                           const uint32_t* chl, const uint32_t* chr, uint32_t pool_limit)
+{
+    uint32_t* const io = reinterpret_cast<uint32_t*>(smem_io);
+    io[lane] = st.active; io[64 + lane] = st.pos; io[128 + lane] = st.first; io[192 + lane] = st.run_end;
+    io[256 + lane] = chl[0]; io[320 + lane] = chl[1]; io[384 + lane] = chr[0]; io[448 + lane] = chr[1];
+    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    const uint32_t plo = rdfirst((uint32_t)(uintptr_t)pool), phi = rdfirst((uint32_t)((uintptr_t)pool >> 32));
+    const uint32_t plim = rdfirst(pool_limit);
+    asm volatile(
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
+        "ds_read_b32 v60, v32\n ds_read_b32 v61, v32 offset:256\n ds_read_b32 v62, v32 offset:512\n ds_read_b32 v63, v32 offset:768\n"
+        "ds_read_b32 v56, v32 offset:1024\n ds_read_b32 v57, v32 offset:1280\n ds_read_b32 v58, v32 offset:1536\n ds_read_b32 v59, v32 offset:1792\n"
+        "v_mov_b32 v47, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n"
+        "s_mov_b32 s76, %[plo]\n s_mov_b32 s77, %[phi]\n s_mov_b32 s98, %[plim]\n"
+        "s_getpc_b64 s[40:41]\n"
+        "L_pc_%=:\n"
+        TG_ADDR(62, 63, "L_chunk")
+        "s_mov_b32 s34, %[clo]\n"
+        "s_mov_b32 s35, %[chi]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_swappc_b64 s[38:39], s[34:35]\n"
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
+        "ds_write_b32 v32, v61 offset:2048\n ds_write_b32 v32, v62 offset:2304\n"
+        "ds_write_b32 v32, v55 offset:2560\n ds_write_b32 v32, v54 offset:2816\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_branch L_end_%=\n"
+        /* some lane's chunk is full (pos == first: word 0 is the link's): it moves to the next chunk of its run and writes the
+         * two links (reference :384-413) or, out of room, stops pushing (its flags v32 / v35 of the clause under way are
+         * cleared, so that the clause does nothing for it) */
+        "L_chunk_%=:\n"
+        "v_cmp_eq_u32 vcc, v61, v62\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_mov_b32 v52, v62\n"
+        "v_add_u32 v62, 64, v62\n"
+        "v_cmp_ge_u32 vcc, v62, v63\n"
+        "v_cmp_gt_u32 s[92:93], v62, s98\n"
+        "s_or_b64 vcc, vcc, s[92:93]\n"
+        "v_cndmask_b32 v60, v60, 0, vcc\n"
+        "v_cndmask_b32 v32, v32, 0, vcc\n"
+        "v_cndmask_b32 v35, v35, 0, vcc\n"
+        "v_cndmask_b32 v55, v55, 1, vcc\n"
+        "s_andn2_b64 exec, exec, vcc\n"
+        "v_add_lshl_u32 v44, v62, 63, 3\n"
+        "v_lshlrev_b32 v45, 3, v52\n"
+        "v_mov_b32 v48, 1\n"                              /* word 63 of the new chunk: JUMP back to the previous one (-127) */
+        "v_mov_b32 v49, 0xffffff81\n"
+        "v_mov_b32 v50, 1\n"                              /* word 0 of the previous chunk: JUMP forward (+127) */
+        "v_mov_b32 v51, 127\n"
+        "global_store_dwordx2 v44, v[48:49], s[76:77]\n"
+        "global_store_dwordx2 v45, v[50:51], s[76:77]\n"
+        "v_add_u32 v61, 62, v62\n"
+        "s_mov_b64 exec, -1\n"
+        "s_setpc_b64 s[36:37]\n"
+        "L_end_%=:\n"
+        :
+        : [lane8] "v"(lane8), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi), [plo] "s"(plo), [phi] "s"(phi), [plim] "s"(plim)
+        : "memory", "vcc", "scc", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s62", "s63", "s76", "s77", "s92", "s93", "s98",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
+          "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    st.pos = io[512 + lane];
+    st.first = io[576 + lane];
+    st.overflow = io[640 + lane];
+    st.kept = io[704 + lane];
+}
+
+#undef TG_ADDR
+
+}  // namespace mprk

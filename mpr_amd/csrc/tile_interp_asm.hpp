@@ -183,76 +183,9 @@ static __device__ float2 ti_named_sqrtx(float a, float b)
     TI_H(v, 31) "s_add_u32 s79, s79, 63\n s_add_u32 s89, s89, 63\n s_branch L_load_%=\n"   /* lane 63: next block */
 
 
-/* The walk itself, as text: expanded in tile_interp_asm (slots in LDS) and in tile_interp_asm_vgpr (slots in VGPRs),
- * each time with that variant's definitions of TI_AL / TI_AR / TI_AO / TI_ST / TI_H30 / TI_VS_ENTER / TI_VS_LEAVE. */
-#define TI_ASM_TEXT \
-    TI_VS_ENTER \
-    "s_mov_b32 s89, %[base]\n" \
-    "s_mov_b32 s88, %[sj]\n" \
-    "s_mov_b32 s96, 0xff00\n" \
-    "s_mov_b32 s72, %[alo]\n" \
-    "s_mov_b32 s73, %[ahi]\n" \
-    "s_mov_b32 s74, %[caddr]\n" \
-    "s_mov_b32 s75, %[cend]\n" \
-    "s_mov_b32 s76, %[anylo]\n" \
-    "s_mov_b32 s77, %[anyhi]\n" \
-    "s_mov_b32 s78, %[ci]\n" \
-    "s_mov_b32 s79, %[words]\n" \
-    "v_mov_b32 v40, %[plo]\n" \
-    "v_mov_b32 v41, %[phi]\n" \
-    "s_getpc_b64 s[82:83]\n" \
-    "L_pc_%=:\n" \
-    "s_add_u32 s82, s82, L_t0_0_%=-L_pc_%=\n" \
-    "s_addc_u32 s83, s83, 0\n" \
-    "s_cmp_eq_u32 %[mode], 0\n" \
-    "s_cbranch_scc1 L_load_%=\n" \
-    "s_cmp_eq_u32 %[mode], 2\n" \
-    "s_cbranch_scc1 L_loaded_%=\n" \
-    TI_DISPATCH \
-    /* ---- fetch 63 clauses at s89, rewrite the clause words ---- */ \
-    "L_load_%=:\n" \
-    "s_mov_b32 s84, s89\n" \
-    "s_mov_b32 s85, 0\n" \
-    "s_lshl_b64 s[84:85], s[84:85], 3\n" \
-    "s_add_u32 s84, s84, %[tlo]\n" \
-    "s_addc_u32 s85, s85, %[thi]\n" \
-    "global_load_dword %[blo], %[lane8], s[84:85]\n" \
-    "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n" \
-    "L_loaded_%=:\n" \
-    "s_mov_b32 s88, -1\n" \
-    "v_mov_b32 v45, 0\n" \
-    "v_mov_b32 v47, 32\n" \
-    "v_mov_b32 v48, 64\n" \
-    "s_waitcnt vmcnt(0)\n" \
-    "v_bfe_u32 v44, %[blo], 8, 8\n"                 /* out slot */ \
-    "v_and_b32 v42, 0xff, %[blo]\n" \
-    "v_min_u32 v42, 30, v42\n"                       /* opcode; unknown ones -> handler 30 */ \
-    "v_mov_b32_dpp v45, v44 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */ \
-    "v_bfe_u32 v46, %[blo], 16, 8\n"                /* lhs slot */ \
-    "v_lshrrev_b32 v43, 24, %[blo]\n"               /* rhs slot */ \
-    "v_cmp_eq_u32 s[92:93], v43, v45\n" \
-    "v_cmp_eq_u32 vcc, v46, v45\n" \
-    "v_cmp_ne_u32 s[94:95], 0, v45\n" \
-    "v_cndmask_b32 v46, 0, v48, s[92:93]\n"          /* rhs forwarded: table 2 */ \
-    "v_cndmask_b32 v46, v46, v47, vcc\n"             /* lhs forwarded: table 1 */ \
-    "v_cndmask_b32 v46, 0, v46, s[94:95]\n" \
-    "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */ \
-    "v_mov_b32 v43, 31\n" \
-    "v_add_u32 v42, v42, v46\n" \
-    "v_cndmask_b32 v42, v42, v43, vcc\n"             /* handler index = table * 32 + opcode */ \
-    /* clause word as the handlers see it: byte 0 = 2 * out slot, byte 1 = handler index, \
-    * bytes 2, 3 = 2 * lhs, 2 * rhs (slots < 128) */ \
-    "v_lshlrev_b32 v44, 1, v44\n" \
-    "v_lshl_or_b32 v42, v42, 8, v44\n" \
-    "v_and_b32 %[blo], 0xffff0000, %[blo]\n" \
-    "v_lshlrev_b32 %[blo], 1, %[blo]\n" \
-    "v_or_b32 %[blo], %[blo], v42\n" \
-    "s_nop 0\n" \
-    TI_DISPATCH \
-    /* ---- handlers: three tables of 32 x 256 bytes ---- */ \
-    TI_TABLE(0, TI_AL, TI_AR, TI_W, TI_W, TI_W) \
-    TI_TABLE(1, TI_FL, TI_AR, "", TI_W, TI_W) \
-    TI_TABLE(2, TI_AL, TI_FR, TI_W, "", TI_W) \
+/* The interval routines the handlers branch to (operands v[36:37], v[38:39], result v[40:41], ending in TI_END): shared by the two
+ * interpreters below and, as subroutines of generated code, by tile_gen_asm.hpp (TI_END = a return there). */
+#define TI_BODIES_TEXT \
     /* ---- i_square(v[36:37]) (device_math.hpp) ---- */ \
     ".p2align 8\n" \
     "L_square_%=:\n" \
@@ -544,7 +477,79 @@ static __device__ float2 ti_named_sqrtx(float a, float b)
     "L_cacos_%=:\n" TI_CALL("mpr_ti_acos") \
     "L_catan_%=:\n" TI_CALL("mpr_ti_atan") \
     "L_cexp_%=:\n" TI_CALL("mpr_ti_exp") \
-    "L_clog_%=:\n" TI_CALL("mpr_ti_log") \
+    "L_clog_%=:\n" TI_CALL("mpr_ti_log")
+
+/* The walk itself, as text: expanded in tile_interp_asm (slots in LDS) and in tile_interp_asm_vgpr (slots in VGPRs),
+ * each time with that variant's definitions of TI_AL / TI_AR / TI_AO / TI_ST / TI_H30 / TI_VS_ENTER / TI_VS_LEAVE. */
+#define TI_ASM_TEXT \
+    TI_VS_ENTER \
+    "s_mov_b32 s89, %[base]\n" \
+    "s_mov_b32 s88, %[sj]\n" \
+    "s_mov_b32 s96, 0xff00\n" \
+    "s_mov_b32 s72, %[alo]\n" \
+    "s_mov_b32 s73, %[ahi]\n" \
+    "s_mov_b32 s74, %[caddr]\n" \
+    "s_mov_b32 s75, %[cend]\n" \
+    "s_mov_b32 s76, %[anylo]\n" \
+    "s_mov_b32 s77, %[anyhi]\n" \
+    "s_mov_b32 s78, %[ci]\n" \
+    "s_mov_b32 s79, %[words]\n" \
+    "v_mov_b32 v40, %[plo]\n" \
+    "v_mov_b32 v41, %[phi]\n" \
+    "s_getpc_b64 s[82:83]\n" \
+    "L_pc_%=:\n" \
+    "s_add_u32 s82, s82, L_t0_0_%=-L_pc_%=\n" \
+    "s_addc_u32 s83, s83, 0\n" \
+    "s_cmp_eq_u32 %[mode], 0\n" \
+    "s_cbranch_scc1 L_load_%=\n" \
+    "s_cmp_eq_u32 %[mode], 2\n" \
+    "s_cbranch_scc1 L_loaded_%=\n" \
+    TI_DISPATCH \
+    /* ---- fetch 63 clauses at s89, rewrite the clause words ---- */ \
+    "L_load_%=:\n" \
+    "s_mov_b32 s84, s89\n" \
+    "s_mov_b32 s85, 0\n" \
+    "s_lshl_b64 s[84:85], s[84:85], 3\n" \
+    "s_add_u32 s84, s84, %[tlo]\n" \
+    "s_addc_u32 s85, s85, %[thi]\n" \
+    "global_load_dword %[blo], %[lane8], s[84:85]\n" \
+    "global_load_dword %[bhi], %[lane8], s[84:85] offset:4\n" \
+    "L_loaded_%=:\n" \
+    "s_mov_b32 s88, -1\n" \
+    "v_mov_b32 v45, 0\n" \
+    "v_mov_b32 v47, 32\n" \
+    "v_mov_b32 v48, 64\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    "v_bfe_u32 v44, %[blo], 8, 8\n"                 /* out slot */ \
+    "v_and_b32 v42, 0xff, %[blo]\n" \
+    "v_min_u32 v42, 30, v42\n"                       /* opcode; unknown ones -> handler 30 */ \
+    "v_mov_b32_dpp v45, v44 wave_shr:1 row_mask:0xf bank_mask:0xf\n"   /* out slot of the previous clause (lane 0: none) */ \
+    "v_bfe_u32 v46, %[blo], 16, 8\n"                /* lhs slot */ \
+    "v_lshrrev_b32 v43, 24, %[blo]\n"               /* rhs slot */ \
+    "v_cmp_eq_u32 s[92:93], v43, v45\n" \
+    "v_cmp_eq_u32 vcc, v46, v45\n" \
+    "v_cmp_ne_u32 s[94:95], 0, v45\n" \
+    "v_cndmask_b32 v46, 0, v48, s[92:93]\n"          /* rhs forwarded: table 2 */ \
+    "v_cndmask_b32 v46, v46, v47, vcc\n"             /* lhs forwarded: table 1 */ \
+    "v_cndmask_b32 v46, 0, v46, s[94:95]\n" \
+    "v_cmp_eq_u32 vcc, 0x1f8, %[lane8]\n"           /* lane 63 -> handler 31 of table 0 */ \
+    "v_mov_b32 v43, 31\n" \
+    "v_add_u32 v42, v42, v46\n" \
+    "v_cndmask_b32 v42, v42, v43, vcc\n"             /* handler index = table * 32 + opcode */ \
+    /* clause word as the handlers see it: byte 0 = 2 * out slot, byte 1 = handler index, \
+    * bytes 2, 3 = 2 * lhs, 2 * rhs (slots < 128) */ \
+    "v_lshlrev_b32 v44, 1, v44\n" \
+    "v_lshl_or_b32 v42, v42, 8, v44\n" \
+    "v_and_b32 %[blo], 0xffff0000, %[blo]\n" \
+    "v_lshlrev_b32 %[blo], 1, %[blo]\n" \
+    "v_or_b32 %[blo], %[blo], v42\n" \
+    "s_nop 0\n" \
+    TI_DISPATCH \
+    /* ---- handlers: three tables of 32 x 256 bytes ---- */ \
+    TI_TABLE(0, TI_AL, TI_AR, TI_W, TI_W, TI_W) \
+    TI_TABLE(1, TI_FL, TI_AR, "", TI_W, TI_W) \
+    TI_TABLE(2, TI_AL, TI_FR, TI_W, "", TI_W) \
+    TI_BODIES_TEXT \
     /* ---- leave: end of tape, or an opcode evaluated in C++ ---- */ \
     "L_exit_%=:\n" \
     "s_waitcnt lgkmcnt(0)\n" \

@@ -472,6 +472,17 @@ def test_frames_that_start_at_the_16px_tiles(mpr, orc, tapes, name, S, monkeypat
     slow.close()
 
 
+@pytest.mark.parametrize("name,dim,S", [("bear", 3, 256), ("bear", 2, 512), ("trig", 3, 128), ("trig", 2, 256), ("two_spheres", 3, 128), ("ring", 2, 256)])
+@pytest.mark.parametrize("gen", ["0", "2"])
+def test_first_stage_without_generated_code(mpr, orc, tapes, name, dim, S, gen, monkeypatch):
+    """A frame's first tile stage — all of its tiles walk the root tape — runs that tape's interval walks as machine code
+    generated on the host (csrc/tile_gen.cpp) when the tape has at most 24 slots and 64 min / max clauses: every other test
+    of this file.  MPR_TILE_GEN=0: the interpreter walks it instead; 2: generated code forward, the interpreter backward.
+    The oracle's frame either way, shortened tapes included."""
+    monkeypatch.setenv("MPR_TILE_GEN", gen)
+    compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
+
+
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("trig", 2, 256),
                                         ("bear", 3, 256), ("architecture", 3, 256)])
 def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):

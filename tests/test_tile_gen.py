@@ -1,0 +1,120 @@
+"""The first tile stage runs the ROOT tape's interval walks as machine code generated on the host (csrc/tile_gen.cpp:
+one short instruction sequence per clause, slots and immediates in the instruction words).  Here that code is
+disassembled with the ROCm assembler's llvm-mc and compared with the instructions it is meant to be — no GPU needed;
+tests/test_gpu_render.py runs it against the interpreter and the oracle."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+LLVM_MC = "/opt/rocm/lib/llvm/bin/llvm-mc"
+PI, MINUS_PI = 0x40490FDB, 0xC0490FDB
+pytestmark = pytest.mark.skipif(not os.path.exists(LLVM_MC), reason="llvm-mc not found")
+
+
+def clause(op, out=0, lhs=0, rhs=0, imm=0):
+    return op | out << 8 | lhs << 16 | rhs << 24 | imm << 32
+
+
+def generated(mpr, words, which):
+    arr = np.array(words, dtype=np.uint64)
+    buf = (ctypes.c_uint32 * 65536)()
+    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), which, buf, 65536)
+    if n < 0:
+        return None
+    text = ",".join("0x%02x" % b for d in buf[:n] for b in struct.pack("<I", d))
+    r = subprocess.run([LLVM_MC, "-arch=amdgcn", "-mcpu=gfx950", "-disassemble"], input=text.encode(), capture_output=True, check=True)
+    assert not r.stderr.strip(), r.stderr.decode()
+    return [" ".join(l.split()) for l in r.stdout.decode().splitlines() if l.strip() and not l.strip().startswith(".")]
+
+
+def one(mpr, c, which=0):
+    """the code of a tape with the single clause c (x, y, z in slots 1, 2, 3), without the epilogue"""
+    code = generated(mpr, [clause(0, 1, 2, 3), c, clause(0, (c >> 8) & 0xFF)], which)
+    assert code[-1] == "s_setpc_b64 s[38:39]"
+    return code[:-3] if which == 0 else code[:-1]
+
+
+def test_forward_rows(mpr):
+    OP = mpr.OP
+    # slot s is v[68 + 2 s] (lower end), v[69 + 2 s] (upper end); round-up mode: lower ends as minus the rounded-up negation
+    assert one(mpr, clause(OP["ADD_LHS_RHS"], 4, 1, 2)) == [
+        "v_add_f32_e64 v40, -v70, -v72", "v_add_f32_e32 v77, v71, v73", "v_xor_b32_e32 v76, 0x80000000, v40"]
+    assert one(mpr, clause(OP["ADD_LHS_IMM"], 4, 4, 0, PI)) == [
+        "v_sub_f32_e32 v40, 0xc0490fdb, v76", "v_add_f32_e32 v77, 0x40490fdb, v77", "v_xor_b32_e32 v76, 0x80000000, v40"]
+    assert one(mpr, clause(OP["SUB_LHS_IMM"], 4, 1, 0, PI)) == [
+        "v_sub_f32_e32 v40, 0x40490fdb, v70", "v_subrev_f32_e32 v77, 0x40490fdb, v71", "v_xor_b32_e32 v76, 0x80000000, v40"]
+    assert one(mpr, clause(OP["SUB_IMM_RHS"], 4, 0, 2, PI)) == [
+        "v_subrev_f32_e32 v40, 0x40490fdb, v73", "v_sub_f32_e32 v77, 0x40490fdb, v72", "v_xor_b32_e32 v76, 0x80000000, v40"]
+    assert one(mpr, clause(OP["SUB_LHS_RHS"], 4, 1, 2)) == [
+        "v_sub_f32_e32 v40, v73, v70", "v_sub_f32_e32 v77, v71, v72", "v_xor_b32_e32 v76, 0x80000000, v40"]
+    # a negative factor swaps the ends, decided when the code is made
+    assert one(mpr, clause(OP["MUL_LHS_IMM"], 4, 1, 0, PI))[1:3] == ["v_mul_f32_e64 v40, -v70, v42", "v_mul_f32_e32 v77, v71, v42"]
+    assert one(mpr, clause(OP["MUL_LHS_IMM"], 4, 1, 0, MINUS_PI))[1:3] == ["v_mul_f32_e64 v40, -v71, v42", "v_mul_f32_e32 v77, v70, v42"]
+    assert one(mpr, clause(OP["NEG_LHS"], 4, 4)) == [
+        "v_xor_b32_e32 v40, 0x80000000, v77", "v_xor_b32_e32 v77, 0x80000000, v76", "v_mov_b32_e32 v76, v40"]
+    assert one(mpr, clause(OP["SIN_LHS"], 4, 1)) == ["v_mov_b32_e32 v76, -1.0", "v_mov_b32_e32 v77, 1.0"]
+    assert one(mpr, clause(OP["COPY_LHS"], 4, 4)) == []
+    # the interpreter's routines, called: operands v[36:39], result v[40:41], entry points in SGPR pairs
+    assert one(mpr, clause(OP["MUL_LHS_RHS"], 4, 1, 2)) == [
+        "v_mov_b32_e32 v36, v70", "v_mov_b32_e32 v37, v71", "v_mov_b32_e32 v38, v72", "v_mov_b32_e32 v39, v73",
+        "s_swappc_b64 s[36:37], s[66:67]", "v_mov_b32_e32 v76, v40", "v_mov_b32_e32 v77, v41"]
+    assert one(mpr, clause(OP["SQRT_LHS"], 4, 1))[2] == "s_swappc_b64 s[36:37], s[68:69]"
+    assert one(mpr, clause(OP["DIV_IMM_RHS"], 4, 0, 2, PI))[:5] == [
+        "v_mov_b32_e32 v36, 0x40490fdb", "v_mov_b32_e32 v37, v36", "v_mov_b32_e32 v38, v72", "v_mov_b32_e32 v39, v73",
+        "s_swappc_b64 s[36:37], s[82:83]"]
+    # min / max: the routine leaves the lanes' decisions in vcc (did not choose the lhs) and s[92:93] (chose the rhs); bit k
+    # of v56 / v58 keeps them for the backward walk
+    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[4:] == [
+        "s_swappc_b64 s[36:37], s[80:81]", "v_mov_b32_e32 v76, v40", "v_mov_b32_e32 v77, v41", "v_mov_b32_e32 v42, 1",
+        "v_cndmask_b32_e64 v43, v42, 0, vcc", "v_or_b32_e32 v56, v56, v43", "v_cndmask_b32_e64 v43, 0, v42, s[92:93]",
+        "v_or_b32_e32 v58, v58, v43"]
+
+
+def test_backward_rows(mpr):
+    OP = mpr.OP
+    take = ["v_cmp_eq_u32_e32 vcc, v61, v62", "s_cbranch_vccz 1", "s_swappc_b64 s[36:37], s[62:63]"]
+    store = ["v_lshlrev_b32_e32 v44, 3, v61", "s_mov_b64 exec, vcc", "global_store_dwordx2 v44, v[46:47], s[76:77]", "s_mov_b64 exec, -1"]
+    # v60: active slots, v61: pool index of the last word written, v62: first index of the chunk
+    assert one(mpr, clause(OP["ADD_LHS_RHS"], 4, 1, 2), 1) == [
+        "v_bfe_u32 v32, v60, 4, 1", "v_sub_u32_e32 v61, v61, v32"] + take + [
+        "v_and_b32_e32 v60, 0xffffffef, v60", "v_lshl_or_b32 v60, v32, 1, v60", "v_lshl_or_b32 v60, v32, 2, v60",
+        "v_mov_b32_e32 v46, 0x201040e", "v_cmp_ne_u32_e32 vcc, 0, v32"] + store
+    # an operand that is the out slot leaves its bit as it is; an immediate goes into the upper half of the word
+    assert one(mpr, clause(OP["SUB_LHS_IMM"], 4, 4, 0, PI), 1) == [
+        "v_bfe_u32 v32, v60, 4, 1", "v_sub_u32_e32 v61, v61, v32"] + take + [
+        "v_mov_b32_e32 v46, 0x40415", "v_mov_b32_e32 v47, 0x40490fdb", "v_cmp_ne_u32_e32 vcc, 0, v32"] + store
+    # min: a lane that chose a side keeps that operand and stores a COPY
+    code = one(mpr, clause(OP["MIN_LHS_RHS"], 4, 1, 2), 1)
+    assert code[:3] == ["v_bfe_u32 v32, v60, 4, 1", "v_bfe_u32 v33, v56, 0, 1", "v_bfe_u32 v34, v58, 0, 1"]
+    assert "v_mov_b32_e32 v39, 0x201041c" in code and "v_mov_b32_e32 v40, 0x201041d" in code
+    assert code[-4:] == store
+    # ... or nothing, when the copy would be of a slot onto itself
+    code = one(mpr, clause(OP["MAX_LHS_IMM"], 4, 4, 0, PI), 1)
+    assert code[7:10] == ["v_xor_b32_e32 v35, 1, v33", "v_and_b32_e32 v35, v35, v32", "v_sub_u32_e32 v61, v61, v35"]
+    assert "v_mov_b32_e32 v40, 0x4041b" in code                     # COPY_IMM
+
+
+def test_whole_tapes(mpr):
+    allowed = {"v_mov_b32_e32", "v_add_f32_e64", "v_add_f32_e32", "v_sub_f32_e32", "v_subrev_f32_e32", "v_xor_b32_e32", "v_mul_f32_e64",
+               "v_mul_f32_e32", "s_swappc_b64", "s_setpc_b64", "v_cndmask_b32_e64", "v_cndmask_b32_e32", "v_or_b32_e32", "v_and_b32_e32",
+               "v_bfe_u32", "v_lshl_or_b32", "v_sub_u32_e32", "v_add_u32_e32", "v_cmp_eq_u32_e32", "v_cmp_ne_u32_e32", "s_cbranch_vccz",
+               "v_lshlrev_b32_e32", "s_mov_b64", "global_store_dwordx2", "s_nop"}
+    tape = mpr.Tape(mpr.model("bear"))
+    words = [int(w) for w in np.asarray(tape.data)]
+    for which in (0, 1):
+        code = generated(mpr, words, which)
+        assert code is not None and code[-1] == "s_setpc_b64 s[38:39]"
+        assert {l.split()[0] for l in code} <= allowed
+        # one store per clause in the backward code, one decision record per min / max clause in the forward code
+        if which == 1:
+            assert sum(l.startswith("global_store") for l in code) == len(words) - 2
+        else:
+            assert sum(l.startswith("v_or_b32_e32 v56") or l.startswith("v_or_b32_e32 v57") for l in code) == tape.num_choices
+    # tapes the conventions do not fit are left to the interpreter
+    for name in ("architecture", "prospero"):
+        t = mpr.Tape(mpr.model(name))
+        assert generated(mpr, [int(w) for w in np.asarray(t.data)], 0) is None
