@@ -521,7 +521,7 @@ int64_t mpr_ctx_resident_bytes(const mpr_context* c)
     for (int i = 0; i < 4; ++i) b += c->tiles_cap[i] * sizeof(mpr_tile_node);
     b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + c->group_list_cap * sizeof(int);
     b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t) + c->pipe_slots_cap * sizeof(int);
-    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap;
+    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t);
     b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
     return (int64_t)b;
 }
