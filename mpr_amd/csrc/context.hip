@@ -155,7 +155,12 @@ struct mpr_context {
     uint32_t* gen_stage = nullptr;     /* what the host hands over (device memory; copied into gen_code by a kernel) */
     size_t gen_cap_dw = 0;
     bool gen_ok = false;
-    int gen_fwd_dw = 0, gen_words = 0, gen_nchoices = 0;
+    int gen_fwd_dw = 0, gen_bwd_dw = 0, gen_words = 0, gen_nchoices = 0;
+    /* ... and the normals pass on that tape's generated Deriv code, for frames whose first stage recorded its tiles' decisions
+     * (MPR_NORMALS_GEN=0: never) */
+    bool normals_gen = true;
+    unsigned long long* gen_dec = nullptr;      /* four words per 16^3 tile of such a frame (TileStageArgs::gen_decisions) */
+    size_t gen_dec_cap = 0;
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
     uint16_t* sched_prev = nullptr;    /* TapeSchedule::prev_writer */
@@ -376,6 +381,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
+    if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
@@ -479,6 +485,7 @@ void mpr_ctx_destroy(mpr_context* c)
     free_executable(c->jit_code);
     free_executable(c->gen_code);
     if (c->gen_stage) (void)hipFree(c->gen_stage);
+    if (c->gen_dec) (void)hipFree(c->gen_dec);
     if (c->groups) (void)hipFree(c->groups);
     if (c->group_alive) (void)hipFree(c->group_alive);
     if (c->group_list) (void)hipFree(c->group_list);
@@ -521,7 +528,7 @@ int64_t mpr_ctx_resident_bytes(const mpr_context* c)
     for (int i = 0; i < 4; ++i) b += c->tiles_cap[i] * sizeof(mpr_tile_node);
     b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + c->group_list_cap * sizeof(int);
     b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t) + c->pipe_slots_cap * sizeof(int);
-    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t);
+    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t) + c->gen_dec_cap * sizeof(unsigned long long);
     b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
     return (int64_t)b;
 }
@@ -548,7 +555,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         c->gen_ok = false;
         if (c->tile_gen && c->tiles_asm && c->tiles_vgpr && tape->num_slots <= mpr::TILE_GEN_MAX_SLOTS) {
             const mpr::TileGen g = mpr::tile_gen_build(tape->clauses.data(), len);
-            const size_t ndw = g.fwd.size() + g.bwd.size();
+            const size_t ndw = g.fwd.size() + g.bwd.size() + g.deriv.size();
             if (g.ok && ndw > 0) {
                 if (ndw > c->gen_cap_dw) {
                     free_executable(c->gen_code);
@@ -563,11 +570,13 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                 if (c->gen_cap_dw >= ndw) {
                     std::vector<uint32_t> both(g.fwd);
                     both.insert(both.end(), g.bwd.begin(), g.bwd.end());
+                    both.insert(both.end(), g.deriv.begin(), g.deriv.end());
                     HIP_TRY(hipMemcpyAsync(c->gen_stage, both.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                     mprk::launch_install_code(c->stream, c->gen_code, c->gen_stage, ndw, std::max(c->cus, 1));
                     HIP_TRY(hipStreamSynchronize(c->stream));
                     c->gen_ok = true;
                     c->gen_fwd_dw = (int)g.fwd.size();
+                    c->gen_bwd_dw = (int)g.bwd.size();
                     c->gen_words = g.words;
                     c->gen_nchoices = g.nchoices;
                 }
@@ -813,6 +822,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     }
 
     bool prev_wide = false;
+    bool decisions_recorded = false;       /* the first stage ran over the 16^3 tiles on generated code and kept its tiles' decisions */
     for (int si = skip0 ? 1 : 0; si < nstages; ++si) {
         const int i = stage_list[si];
         const bool last = (si == nstages - 1);
@@ -863,6 +873,13 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
             a.gen_words = c->gen_words;
             a.gen_nchoices = c->gen_nchoices;
+            if (skip0 && dim == 3 && a.gen_bwd && c->normals_gen && c->normals_asm && nstages == 3) {
+                /* the tiles' decisions on the root tape's min / max clauses, for the normals pass */
+                rc = ensure_buffer(&c->gen_dec, &c->gen_dec_cap, (size_t)count * 4);
+                if (rc) return rc;
+                a.gen_decisions = c->gen_dec;
+                decisions_recorded = true;
+            }
         }
         a.pipe_slots = nullptr;
         a.pipe_ctl = nullptr;
@@ -1177,6 +1194,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.choice_masks = normals_on_groups ? c->choice_masks : nullptr;
         n.choice_cap = group_cap;
         n.vgpr_slots = c->tiles_vgpr;
+        if (decisions_recorded && normals_on_groups && group_stage == 2) {
+            n.gen_code = c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw;
+            n.gen_decisions = c->gen_dec;
+            n.gen_nchoices = c->gen_nchoices;
+        }
         if (owner && c->normals_asm && !cnt) {
             /* owned columns only; the list is rebuilt when the ownership table or the rank changes */
             if (c->my_cols_rank != rank || c->my_cols_gen != c->owner_gen) {

@@ -501,6 +501,13 @@ k_eval_tiles(TileStageArgs a)
             }
             writing = push && !overflow;
             live = ballot(writing);
+            if (a.gen_decisions && writing) {
+                unsigned long long* const rec = a.gen_decisions + (size_t)gidx * 4;
+                rec[0] = (unsigned long long)chl[0] | ((unsigned long long)chl[1] << 32);
+                rec[1] = (unsigned long long)chr[0] | ((unsigned long long)chr[1] << 32);
+                rec[2] = (unsigned long long)gp.kept_lo | ((unsigned long long)gp.kept_hi << 32);
+                rec[3] = 0;
+            }
             bwd_words = a.gen_words;
             int kept = writing ? (int)gp.kept : 0;
             for (int off = 32; off > 0; off >>= 1) kept = max(kept, __shfl_xor(kept, off));

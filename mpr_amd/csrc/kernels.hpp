@@ -79,6 +79,9 @@ struct TileStageArgs {
                                           * 64 min / max clauses: its walks as generated code (tile_gen.hpp) — else null */
     const uint32_t* gen_bwd = nullptr;   /* (null with gen_fwd set: the assembly interpreter walks backward; development) */
     int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
+    unsigned long long* gen_decisions = nullptr;   /* with gen_bwd, optional: per tile that pushes a tape, four words — the root tape's min / max
+                                                    * clauses it decided for the lhs, for the rhs, those its tape keeps, 0 (the normals pass on
+                                                    * the root tape's generated code applies them, kernels_normals_gen.hip) */
 };
 
 /* first tile stage, one workgroup per tile, level by level over the root tape's DAG
@@ -131,6 +134,12 @@ struct NormalArgs {
     const ulonglong2* choice_masks;
     int choice_cap;
     bool vgpr_slots;           /* tapes with many slots: the slot file in registers (MPR_TILES_VGPR=0: never) */
+    /* frames whose first stage ran the root tape's generated code over the 16^3 tiles and recorded its decisions
+     * (TileStageArgs::gen_decisions), group form: every pixel on the ROOT tape's generated Deriv code (tile_gen.hpp) with the
+     * decisions of its 16^3 and 4^3 tiles applied — one walk per footprint whatever tapes its pixels carry (else null) */
+    const uint32_t* gen_code = nullptr;
+    const unsigned long long* gen_decisions = nullptr;
+    int gen_nchoices = 0;
 };
 
 /* children != null (3-D frames that start at the 16^3 tiles): also the 64 children of every first-stage tile, t0 = S / 64 */

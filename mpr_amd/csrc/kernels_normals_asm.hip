@@ -556,6 +556,186 @@ k_eval_normals_asm(NormalArgs a)
     if (filled && comp == 0) a.output[pxy] = (0xFFu << 24) | (uz << 16) | (uy << 8) | ux;
 }
 
+/* ---- the pass on the ROOT tape's generated code (tile_gen.hpp: TileGen::deriv) ----
+ * A pixel's own tape — what the reference walks here — is the root tape with the decisions of its 16^3 tile (which shortened
+ * the tape it pushed) and of its 4^3 tile (recorded by the last stage, in that shortened tape's numbering) applied.  With both
+ * sets of decisions at hand as bits over the ROOT tape's min / max clauses, every pixel can run the one piece of code that
+ * exists once per tape: no interpreter, and one walk per footprint whatever tiles its 16 pixels belong to. */
+#define NG_ADDR(lo, hi, label) "s_add_u32 s" #lo ", s40, " label "_%=-L_pc_%=\n s_addc_u32 s" #hi ", s41, 0\n"
+#define NG_CALLC(sym)                                                                            \
+    "s_getpc_b64 s[40:41]\n"                                                                     \
+    "s_add_u32 s40, s40, " sym "@rel32@lo+4\n"                                                   \
+    "s_addc_u32 s41, s41, " sym "@rel32@hi+12\n"                                                 \
+    "s_swappc_b64 s[30:31], s[40:41]\n"                                                          \
+    "v_mov_b32 v37, v0\n s_setpc_b64 s[70:71]\n"
+DEV float normals_gen_walk(const uint32_t* code, uint32_t ax, uint32_t ay, uint32_t az, float xin, float yin, float zin,
+                           uint32_t dl0, uint32_t dl1, uint32_t dr0, uint32_t dr1)
+{
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    ax = rdfirst(ax);
+    ay = rdfirst(ay);
+    az = rdfirst(az);
+    float res;
+    asm volatile(
+        "s_mov_b32 s90, 0x260\n"
+        "s_mov_b32 s98, 0x88888888\n"
+        "s_mov_b32 s99, 0x88888888\n"
+        "s_set_gpr_idx_on %[ax], gpr_idx(DST)\n v_mov_b32 v50, %[xin]\n s_set_gpr_idx_off\n"
+        "s_set_gpr_idx_on %[ay], gpr_idx(DST)\n v_mov_b32 v50, %[yin]\n s_set_gpr_idx_off\n"
+        "s_set_gpr_idx_on %[az], gpr_idx(DST)\n v_mov_b32 v50, %[zin]\n s_set_gpr_idx_off\n"
+        "v_mov_b32 v74, %[dl0]\n v_mov_b32 v75, %[dl1]\n v_mov_b32 v76, %[dr0]\n v_mov_b32 v77, %[dr1]\n"
+        "s_getpc_b64 s[40:41]\n"
+        "L_pc_%=:\n"
+        NG_ADDR(72, 73, "L_div") NG_ADDR(74, 75, "L_sqrt") NG_ADDR(76, 77, "L_exp") NG_ADDR(78, 79, "L_log") NG_ADDR(68, 69, "L_sincos")
+        NG_ADDR(80, 81, "L_gasin") NG_ADDR(82, 83, "L_gacos") NG_ADDR(84, 85, "L_gatan")
+        "s_mov_b32 s34, %[clo]\n"
+        "s_mov_b32 s35, %[chi]\n"
+        "s_swappc_b64 s[38:39], s[34:35]\n"
+        "v_mov_b32 %[res], v37\n"
+        "s_branch L_end_%=\n"
+        /* shared routines: argument v35 (and v36), result v37, return to s[70:71] */
+        ".p2align 8\n"
+        "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[70:71]\n"
+        "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[70:71]\n" MPR_ASM_SQRT_TAIL
+        "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[70:71]\n" MPR_ASM_EXP_TAIL
+        "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[70:71]\n" MPR_ASM_LOG_TAIL
+        "L_sincos_%=:\n" MPR_ASM_SINCOS_BODY "s_setpc_b64 s[70:71]\n"
+        "L_gasin_%=:\n" NG_CALLC("mpr_nq_asin")
+        "L_gacos_%=:\n" NG_CALLC("mpr_nq_acos")
+        "L_gatan_%=:\n" NG_CALLC("mpr_nq_atan")
+        "L_end_%=:\n"
+        : [res] "=&v"(res)
+        : [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [xin] "v"(xin), [yin] "v"(yin), [zin] "v"(zin), [dl0] "v"(dl0), [dl1] "v"(dl1),
+          [dr0] "v"(dr0), [dr1] "v"(dr1), [clo] "s"(clo), [chi] "s"(chi)
+        : "memory", "vcc", "scc",
+          "s34", "s35", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+          "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
+          "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s98", "s99",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
+          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
+          NQ_V10(5), NQ_V10(6), "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77");
+    return res;
+}
+#undef NG_ADDR
+#undef NG_CALLC
+
+__global__ void __launch_bounds__(64)
+k_eval_normals_gen(NormalArgs a)
+{
+    const int lane = threadIdx.x;
+    const int S = a.size;
+    const int fside = S / 4;                                  /* footprints per side */
+    int fxi, fyi;
+    if (a.col_list) {
+        const int col = a.col_list[blockIdx.x >> 8], f = blockIdx.x & 255, cols = S / 64;
+        fxi = (col % cols) * 16 + (f & 15);
+        fyi = (col / cols) * 16 + (f >> 4);
+    } else {
+        fxi = blockIdx.x % fside;
+        fyi = blockIdx.x / fside;
+    }
+    const int pix = lane >> 2, comp = lane & 3;
+    const bool isv = comp == 3;
+    const int px = fxi * 4 + (pix & 3), py = fyi * 4 + (pix >> 2);
+    const int pxy = px + py * S;
+    int pz = a.image[pxy];
+    const bool filled = pz != 0;
+    if (ballot(filled) == 0) return;
+    if (pz < S - 1) pz += 1;                                   /* :1003-1005 */
+
+    const float size_recip = 1.0f / (float)(unsigned)S;
+    const float fx = ((px + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fy = ((py + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fz = ((pz + 0.5f) * size_recip - 0.5f) * 2.0f;
+    const float fw = a.mat[3] * fx + a.mat[7] * fy + a.mat[11] * fz + a.mat[15];
+    const float vx = (a.mat[0] * fx + a.mat[4] * fy + a.mat[8] * fz + a.mat[12]) / fw;
+    const float vy = (a.mat[1] * fx + a.mat[5] * fy + a.mat[9] * fz + a.mat[13]) / fw;
+    const float vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
+
+    /* the pixel's 16^3 tile (index in its stage's list, and the tape that tile pushed: 0 = none) and 4^3 tile (:1034-1066) */
+    int my_sub = -1, sub_tape = 0, my_micro = -1;
+    if (filled) {
+        const int t64 = S / 64;
+        const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
+        const mpr_tile_node tn = a.tiles[tile];
+        if (tn.next != -1) {
+            my_sub = tn.next * 64 + (px % 64) / 16 + ((py % 64) / 16) * 4 + ((pz % 64) / 16) * 16;
+            const mpr_tile_node sn = a.subtiles[my_sub];
+            sub_tape = sn.tape;
+            if (sn.next != -1) my_micro = sn.next * 64 + (px % 16) / 4 + ((py % 16) / 4) * 4 + ((pz % 16) / 4) * 16;
+        }
+    }
+    const unsigned long long all = a.gen_nchoices >= 64 ? ~0ull : ((1ull << a.gen_nchoices) - 1ull);
+    unsigned long long dl = 0, dr = 0;
+    /* pixels with a 4^3 tile: the 16^3 tile's decisions, then the 4^3 tile's, renumbered from the clauses its tape keeps to the
+     * root tape's; one (16^3 tile, 4^3 tile) at a time — a footprint meets a handful */
+    uint64_t pending = ballot(my_micro >= 0);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int micro = __builtin_amdgcn_readlane(my_micro, leader);
+        const int sub = __builtin_amdgcn_readlane(my_sub, leader);
+        const int stape = __builtin_amdgcn_readlane(sub_tape, leader);
+        pending &= ~ballot(my_micro == micro);
+        const int g = micro >> 6, child = micro & 63;
+        unsigned long long L = 0, R = 0, K = all;
+        if (stape != 0) {
+            const unsigned long long* const rec = a.gen_decisions + (size_t)sub * 4;
+            L = rec[0];
+            R = rec[1];
+            K = rec[2];
+        }
+        const GroupInfo gi = a.groups[g];
+        uint64_t l0 = 0, r0 = 0;
+        if ((gi.pushed >> child) & 1ull) {
+            const ulonglong2* const m = a.choice_masks + (size_t)g * a.choice_cap;
+            const int n = gi.nchoices < 64 ? gi.nchoices : 64;
+            ulonglong2 w0 = make_ulonglong2(0ull, 0ull);
+            if (lane < n) w0 = m[lane];
+            l0 = ballot((w0.x >> child) & 1ull);
+            r0 = ballot((w0.y >> child) & 1ull);
+        }
+        /* lane k: root clause k is the j-th the 16^3 tile's tape keeps */
+        const bool kept = (K >> lane) & 1ull;
+        const int j = __popcll(K & ((1ull << lane) - 1ull));
+        const uint64_t DL = L | ballot(kept && ((l0 >> j) & 1ull));
+        const uint64_t DR = R | ballot(kept && ((r0 >> j) & 1ull));
+        if (my_micro == micro) {
+            dl = DL;
+            dr = DR;
+        }
+    }
+    /* pixels whose 16^3 tile was not subdivided but pushed a tape before it was decided: that tape's decisions */
+    pending = ballot(my_micro < 0 && my_sub >= 0 && sub_tape != 0);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int sub = __builtin_amdgcn_readlane(my_sub, leader);
+        const bool mine = my_micro < 0 && my_sub == sub;
+        pending &= ~ballot(mine);
+        const unsigned long long* const rec = a.gen_decisions + (size_t)sub * 4;
+        if (mine) {
+            dl = rec[0];
+            dr = rec[1];
+        }
+    }
+
+    const uint64_t head0 = a.tape_ro[0];
+    const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
+    /* :1021-1031 — value first, then the unit partials */
+    const float result = normals_gen_walk(a.gen_code, sx, sy, sz, isv ? vx : (comp == 0 ? 1.0f : 0.0f), isv ? vy : (comp == 1 ? 1.0f : 0.0f),
+                                          isv ? vz : (comp == 2 ? 1.0f : 0.0f), (uint32_t)dl, (uint32_t)(dl >> 32), (uint32_t)dr, (uint32_t)(dr >> 32));
+
+    /* :1123-1131 */
+    const float gx = quad_bcast_a(result, 0), gy = quad_bcast_a(result, 1), gz = quad_bcast_a(result, 2);
+    const float norm = __builtin_sqrtf(gx * gx + gy * gy + gz * gz);
+    const uint32_t u = f2u8((result / norm) * 127 + 128);
+    const uint32_t ux = mpr_f2u(quad_bcast_a(mpr_u2f(u), 0)), uy = mpr_f2u(quad_bcast_a(mpr_u2f(u), 1)),
+                   uz = mpr_f2u(quad_bcast_a(mpr_u2f(u), 2));
+    if (filled && comp == 0) a.output[pxy] = (0xFFu << 24) | (uz << 16) | (uy << 8) | ux;
+}
+
 void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
 {
     const int fside = a.size / 4;
@@ -563,6 +743,10 @@ void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
     if (groups <= 0) return;
     /* slots in registers when the LDS slot file would hold a CU under the 12 wavefronts those registers allow (tried for
      * small slot files too: bear, 23 slots, 0.378 -> 0.420 ms — one wavefront per SIMD fewer, and the index switching) */
+    if (a.gen_code && a.gen_decisions && a.groups) {
+        hipLaunchKernelGGL(k_eval_normals_gen, dim3(groups), dim3(64), 0, s, a);
+        return;
+    }
     const size_t lds = (size_t)a.nslots * 256 + (a.groups ? 768 : 0);
     if (a.vgpr_slots && a.nslots <= NQ_VS_MAX_SLOTS && lds > (size_t)160 * 1024 / 12)
         hipLaunchKernelGGL(k_eval_normals_asm<NQ_VS_MAX_SLOTS>, dim3(groups), dim3(64), (size_t)(a.groups ? 768 : 16), s, a);

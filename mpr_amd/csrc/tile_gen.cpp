@@ -14,7 +14,7 @@ constexpr int V_CNDMASK = 0, V_ADD_F32 = 1, V_SUB_F32 = 2, V_SUBREV_F32 = 3, V_M
 /* VOP3 opcodes */
 constexpr int V3_CNDMASK = 0x100, V3_ADD_F32 = 0x101, V3_MUL_F32 = 0x105, V3_BFE_U32 = 0x1C8, V3_LSHL_OR = 0x200;
 /* VOPC opcodes */
-constexpr int VC_EQ_U32 = 0xCA, VC_NE_U32 = 0xCD;
+constexpr int VC_EQ_U32 = 0xCA, VC_NE_U32 = 0xCD, VC_LT_F32 = 0x41, VC_GE_F32 = 0x46;
 constexpr uint32_t VCC = 106, EXEC = 126, LIT = 255;
 
 struct Emit {
@@ -38,6 +38,30 @@ struct Emit {
     void cbranch_vccz(int dwords) { d(0xBF860000u | (uint32_t)(dwords & 0xFFFF)); }
     void nop(int n) { d(0xBF800000u | (uint32_t)n); }
     void store_x2(int vaddr, int vdata, int saddr) { d(0xDC748000u); d((uint32_t)vaddr | (uint32_t)vdata << 8 | (uint32_t)saddr << 16); }
+    /* quad_perm:[3,3,3,3] on src0 (the value component of a Deriv to its quad).  A register a VALU instruction wrote needs two
+     * wait states before a DPP operand reads it: `w1` / `w2` = what the last / the one before last instruction wrote */
+    int w1 = -1, w2 = -1;
+    void wrote(int v) { w2 = w1; w1 = v; }
+    void dpp_wait(int src)
+    {
+        if (src == w1) { nop(1); w1 = w2 = -1; }
+        else if (src == w2) { nop(0); w1 = w2 = -1; }
+    }
+    void vop2_q3(int op, int vdst, int src0, int vsrc1)
+    {
+        dpp_wait(src0);
+        vop2(op, vdst, 250, vsrc1);
+        d(0xFF00FF00u | (uint32_t)src0);
+        wrote(vdst);
+    }
+    void mov_q3(int vdst, int src0)
+    {
+        dpp_wait(src0);
+        mov(vdst, 250);
+        d(0xFF00FF00u | (uint32_t)src0);
+        wrote(vdst);
+    }
+    void sop2_vcc(int op, int ssrc1) { d(0x80000000u | (uint32_t)op << 23 | VCC << 16 | (uint32_t)ssrc1 << 8 | VCC); }   /* vcc = vcc op s[ssrc1:+1] */
 };
 
 inline int lo(int s) { return 68 + 2 * s; }
@@ -217,6 +241,7 @@ void backward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uin
     e.vop2(V_XOR, 36, Emit::I(1), 36);
     e.vop2(V_AND, 36, Emit::V(36), 32);                                          /* undecided and active: keeps the min / max */
     e.vop2(V_ADD_U32, 54, Emit::V(54), 36);
+    e.vop3(V3_LSHL_OR, 41 + (choice >> 5), Emit::V(36), Emit::I(choice & 31), Emit::V(41 + (choice >> 5)));   /* ... and says so in v41 / v42 */
     const bool dropL = l == o, dropR = r != 0 && r == o;
     if (!dropL && !dropR) {
         e.mov(35, Emit::V(32));
@@ -245,6 +270,188 @@ void backward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uin
     e.nop(0);
     e.vop2(V_CNDMASK, 46, Emit::V(46), 40);
     store_word(e, 35, W1, cur_hi);
+}
+
+/* ---- the Deriv walk of the normals pass (reference :1067-1121; the interpreter's handlers: kernels_normals_asm.hip) ---- */
+/* Lane = pixel * 4 + component (dx, dy, dz, value); slot s = v[50 + s]; s[98:99] = the value lanes; the shared float routines
+ * take v35 (, v36) and return v37 through s[70:71] (entry points: TileGenReg TD_*).  Every row computes exactly the handler's
+ * expression.  v74 / v75 (v76 / v77): bit k set = the pixel's tile decided min / max clause k for the lhs (rhs). */
+struct DerivEmit {
+    Emit& e;
+    static int slot(int s) { return 50 + s; }
+    void v2(int op, int vdst, uint32_t src0, int vsrc1) { e.vop2(op, vdst, src0, vsrc1); e.wrote(vdst); }
+    void v2l(int op, int vdst, uint32_t lit, int vsrc1) { e.vop2_lit(op, vdst, lit, vsrc1); e.wrote(vdst); }
+    void mv(int vdst, uint32_t src0) { e.mov(vdst, src0); e.wrote(vdst); }
+    void mvl(int vdst, uint32_t lit) { e.mov_lit(vdst, lit); e.wrote(vdst); }
+    void v3(int op, uint32_t dst, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t neg = 0) { e.vop3(op, dst, s0, s1, s2, neg); e.wrote((int)dst); }
+    void sel_value(int vdst, int other, int value) { v3(V3_CNDMASK, vdst, Emit::V(other), Emit::V(value), 98); }    /* value lanes: `value` */
+    void call(int pair) { e.swappc(70, pair); e.wrote(-1); e.wrote(-1); }
+    void nop(int n) { e.nop(n); e.wrote(-1); }
+};
+bool deriv_clause(DerivEmit& g, uint32_t op, int o, int l, int r, uint32_t K, int choice)
+{
+    const int O = DerivEmit::slot(o), A = DerivEmit::slot(l), B = DerivEmit::slot(r);
+    Emit& e = g.e;
+    switch (op) {
+        case MPR_OP_SQUARE_LHS:                               /* isv ? a a : a av + a av */
+            e.vop2_q3(V_MUL_F32, 38, A, A);
+            g.v2(V_MUL_F32, 39, Emit::V(A), A);
+            g.v2(V_ADD_F32, 38, Emit::V(38), 38);
+            g.sel_value(O, 38, 39);
+            break;
+        case MPR_OP_SQRT_LHS:                                 /* s = sqrt(av); isv ? s : a / (2 s) */
+            g.mv(43, Emit::V(A));
+            e.mov_q3(35, A);
+            g.call(TD_RT_SQRT);
+            g.mv(44, Emit::V(37));
+            g.v2(V_MUL_F32, 36, 244, 37);                     /* 2.0 */
+            g.mv(35, Emit::V(43));
+            g.call(TD_RT_DIV);
+            g.sel_value(O, 37, 44);
+            break;
+        case MPR_OP_NEG_LHS: g.v2l(V_XOR, O, SIGN, A); break;
+        case MPR_OP_SIN_LHS:                                  /* isv ? sin(av) : cos(av) a */
+            g.mv(48, Emit::V(A));
+            e.mov_q3(35, A);
+            g.call(TD_RT_SINCOS);
+            g.v2(V_MUL_F32, 38, Emit::V(36), 48);
+            g.sel_value(O, 38, 37);
+            break;
+        case MPR_OP_COS_LHS:                                  /* isv ? cos(av) : -sin(av) a */
+            g.mv(48, Emit::V(A));
+            e.mov_q3(35, A);
+            g.call(TD_RT_SINCOS);
+            g.v3(V3_MUL_F32, 38, Emit::V(37), Emit::V(48), 0, 1);
+            g.sel_value(O, 38, 36);
+            break;
+        case MPR_OP_ASIN_LHS:
+        case MPR_OP_ACOS_LHS:
+        case MPR_OP_ATAN_LHS:                                 /* compiled routines: a in v0, "value lane" in v1, result v37 */
+            g.mv(0, Emit::V(A));
+            g.v3(V3_CNDMASK, 1, Emit::I(0), Emit::I(1), 98);
+            g.call(op == MPR_OP_ASIN_LHS ? TD_RT_ASIN : op == MPR_OP_ACOS_LHS ? TD_RT_ACOS : TD_RT_ATAN);
+            g.mv(O, Emit::V(37));
+            break;
+        case MPR_OP_EXP_LHS:                                  /* e = exp(av); isv ? e : e a */
+            g.mv(43, Emit::V(A));
+            e.mov_q3(35, A);
+            g.call(TD_RT_EXP);
+            g.v2(V_MUL_F32, 38, Emit::V(37), 43);
+            g.sel_value(O, 38, 37);
+            break;
+        case MPR_OP_ABS_LHS:                                  /* av < 0 ? -a : a */
+            g.mv(39, Emit::I(0));
+            g.v2l(V_XOR, 38, SIGN, A);
+            e.mov_q3(46, A);
+            e.vopc(VC_LT_F32, Emit::V(46), 39);
+            e.wrote(-1);
+            g.nop(1);
+            g.v2(V_CNDMASK, O, Emit::V(A), 38);
+            break;
+        case MPR_OP_LOG_LHS:                                  /* isv ? log(av) : a / av */
+            g.mv(43, Emit::V(A));
+            e.mov_q3(35, A);
+            g.nop(0);
+            g.mv(45, Emit::V(35));
+            g.call(TD_RT_LOG);
+            g.mv(44, Emit::V(37));
+            g.mv(35, Emit::V(43));
+            g.mv(36, Emit::V(45));
+            g.call(TD_RT_DIV);
+            g.sel_value(O, 37, 44);
+            break;
+        case MPR_OP_ADD_LHS_IMM:                              /* only the value */
+            g.v2l(V_ADD_F32, 38, K, A);
+            g.sel_value(O, A, 38);
+            break;
+        case MPR_OP_ADD_LHS_RHS: g.v2(V_ADD_F32, O, Emit::V(A), B); break;
+        case MPR_OP_MUL_LHS_IMM: g.v2l(V_MUL_F32, O, K, A); break;
+        case MPR_OP_MUL_LHS_RHS:                              /* isv ? a b : a bv + b av */
+            e.vop2_q3(V_MUL_F32, 38, B, A);
+            e.vop2_q3(V_MUL_F32, 39, A, B);
+            g.v2(V_MUL_F32, 40, Emit::V(A), B);
+            g.v2(V_ADD_F32, 38, Emit::V(38), 39);
+            g.sel_value(O, 38, 40);
+            break;
+        case MPR_OP_MIN_LHS_IMM:
+        case MPR_OP_MIN_LHS_RHS:
+        case MPR_OP_MAX_LHS_IMM:
+        case MPR_OP_MAX_LHS_RHS: {
+            const bool is_min = op <= MPR_OP_MIN_LHS_RHS;
+            const bool has_rhs = op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS;
+            int Bv = B;
+            if (has_rhs) {
+                e.mov_q3(39, B);                              /* bv */
+            } else {
+                g.mvl(39, K);                                 /* b = (0, 0, 0, imm) */
+                g.v3(V3_CNDMASK, 36, Emit::I(0), Emit::V(39), 98);
+                Bv = 36;
+            }
+            e.mov_q3(46, A);                                  /* av */
+            e.vopc(is_min ? VC_LT_F32 : VC_GE_F32, Emit::V(46), 39);          /* vcc: take a */
+            e.wrote(-1);
+            /* the tile's decision overrides the comparison */
+            g.v3(V3_BFE_U32, 40, Emit::V(74 + (choice >> 5)), Emit::I(choice & 31), Emit::I(1));
+            g.v3(V3_BFE_U32, 41, Emit::V(76 + (choice >> 5)), Emit::I(choice & 31), Emit::I(1));
+            e.vop3(0xCD, 42, Emit::I(0), Emit::V(40), 0);     /* v_cmp_ne_u32 s[42:43], 0, v40 */
+            e.vop3(0xCD, 44, Emit::I(0), Emit::V(41), 0);
+            e.wrote(-1);
+            e.wrote(-1);
+            g.nop(0);
+            e.sop2_vcc(15, 42);                               /* vcc |= decided lhs */
+            e.sop2_vcc(19, 44);                               /* vcc &= ~decided rhs */
+            e.wrote(-1);
+            e.wrote(-1);
+            g.v2(V_CNDMASK, O, Emit::V(Bv), A);
+            break;
+        }
+        case MPR_OP_SUB_LHS_IMM:                              /* only the value */
+            g.v2l(V_SUBREV_F32, 38, K, A);
+            g.sel_value(O, A, 38);
+            break;
+        case MPR_OP_SUB_IMM_RHS:                              /* isv ? imm - b : -b */
+            g.v2l(V_SUB_F32, 38, K, B);
+            g.v2l(V_XOR, 39, SIGN, B);
+            g.sel_value(O, 39, 38);
+            break;
+        case MPR_OP_SUB_LHS_RHS: g.v2(V_SUB_F32, O, Emit::V(A), B); break;
+        case MPR_OP_DIV_LHS_IMM:                              /* every component by imm */
+            g.mv(35, Emit::V(A));
+            g.mvl(36, K);
+            g.call(TD_RT_DIV);
+            g.mv(O, Emit::V(37));
+            break;
+        case MPR_OP_DIV_IMM_RHS:                              /* isv ? imm / b : (-imm b) / (bv bv) */
+            e.mov_q3(41, B);
+            g.mvl(40, K);
+            g.v3(V3_MUL_F32, 39, Emit::V(40), Emit::V(B), 0, 1);
+            g.v2(V_MUL_F32, 38, Emit::V(41), 41);
+            g.v3(V3_CNDMASK, 35, Emit::V(39), Emit::V(40), 98);
+            g.v3(V3_CNDMASK, 36, Emit::V(38), Emit::V(B), 98);
+            g.call(TD_RT_DIV);
+            g.mv(O, Emit::V(37));
+            break;
+        case MPR_OP_DIV_LHS_RHS:                              /* isv ? a / b : (bv a - av b) / (bv bv) */
+            e.vop2_q3(V_MUL_F32, 38, B, A);
+            e.vop2_q3(V_MUL_F32, 39, A, B);
+            e.mov_q3(41, B);
+            g.v2(V_SUB_F32, 38, Emit::V(38), 39);
+            g.nop(0);
+            g.v2(V_MUL_F32, 40, Emit::V(41), 41);
+            g.v3(V3_CNDMASK, 35, Emit::V(38), Emit::V(A), 98);
+            g.v3(V3_CNDMASK, 36, Emit::V(40), Emit::V(B), 98);
+            g.call(TD_RT_DIV);
+            g.mv(O, Emit::V(37));
+            break;
+        case MPR_OP_COPY_IMM:
+            g.mvl(39, K);
+            g.v3(V3_CNDMASK, O, Emit::I(0), Emit::V(39), 98);
+            break;
+        case MPR_OP_COPY_LHS: if (o != l) g.mv(O, Emit::V(A)); break;
+        case MPR_OP_COPY_RHS: if (o != r) g.mv(O, Emit::V(B)); break;
+        default: return false;
+    }
+    return true;
 }
 
 }  // namespace
@@ -286,6 +493,24 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
     f.mov(37, Emit::V(hi(g.result_slot)));
     f.setpc(TG_RET_CODE);
 
+    {
+        Emit de{g.deriv};
+        DerivEmit dg{de};
+        int ch = 0;
+        for (int i = 1; i < end; ++i) {
+            const uint64_t w = clauses[i];
+            const uint32_t op = (uint32_t)w & 0xFF;
+            if (!deriv_clause(dg, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), ch)) {
+                g.fwd.clear();
+                g.deriv.clear();
+                return g;
+            }
+            if (mpr_op_is_minmax(op)) ++ch;
+        }
+        de.mov(37, Emit::V(DerivEmit::slot(g.result_slot)));
+        de.setpc(TG_RET_CODE);
+    }
+
     uint32_t cur_hi = 0;                                      /* the harness enters with v47 = 0 */
     for (int i = end - 1; i >= 1; --i) {
         const uint64_t w = clauses[i];
@@ -305,8 +530,8 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
     const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
-    if (!g.ok || which < 0 || which > 1) return -1;
-    const std::vector<uint32_t>& c = which ? g.bwd : g.fwd;
+    if (!g.ok || which < 0 || which > 2) return -1;
+    const std::vector<uint32_t>& c = which == 2 ? g.deriv : which ? g.bwd : g.fwd;
     if (out && (int)c.size() <= cap)
         for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
     return (int)c.size();

@@ -15,7 +15,8 @@
  *   routine entry points    SGPR pairs (TileGenReg), return address s[36:37]; the code itself returns through s[38:39]
  * backward walk
  *   v60 active slots (bit s), v61 pool index of the last word written, v62 first index of the current chunk,
- *   v[46:47] the clause word being stored (v47 keeps the last upper half), s[76:77] pool, s[62:63] "chunk full" routine
+ *   v[46:47] the clause word being stored (v47 keeps the last upper half), s[76:77] pool, s[62:63] "chunk full" routine,
+ *   v54 number of min / max clauses the lane's tape keeps, v41 / v42 which ones (bit k: clause k)
  */
 #pragma once
 #include <cstdint>
@@ -31,12 +32,15 @@ enum TileGenReg : int {
     TG_RT_DIVI = 84, TG_RT_ASIN = 86, TG_RT_ACOS = 88, TG_RT_ATAN = 90, TG_RT_EXP = 98, TG_RT_LOG = 96,
     TG_RET_ROUTINE = 36, TG_RET_CODE = 38,
     TG_RT_CHUNK = 62,
+    /* the normals pass's Deriv walk: routines return through s[70:71] */
+    TD_RT_DIV = 72, TD_RT_SQRT = 74, TD_RT_EXP = 76, TD_RT_LOG = 78, TD_RT_SINCOS = 68, TD_RT_ASIN = 80, TD_RT_ACOS = 82, TD_RT_ATAN = 84,
 };
 
 struct TileGen {
     bool ok = false;
     std::vector<uint32_t> fwd;      /* forward walk: axes in their slots -> result in v[36:37], decisions in v56..v59 */
     std::vector<uint32_t> bwd;      /* backward walk of tape pushing */
+    std::vector<uint32_t> deriv;    /* the normals pass's walk (value + three partials per pixel: four lanes), decisions in v74..v77 */
     int words = 0;                  /* clause words a walk visits: the operations and the end clause (or the head) */
     int nchoices = 0;               /* min / max clauses */
     int result_slot = 0;

@@ -121,6 +121,7 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
 struct TileGenPush {
     uint32_t active, pos, first, run_end;
     uint32_t overflow, kept;
+    uint32_t kept_lo, kept_hi;     /* out: which min / max clauses the lane's tape keeps (bit k: the root tape's k-th) */
 };
 DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned char* smem_io, int lane, TileGenPush& st,
                            const uint32_t* chl, const uint32_t* chr, uint32_t pool_limit)
@@ -137,7 +138,7 @@ DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned 
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_read_b32 v60, v32\n ds_read_b32 v61, v32 offset:256\n ds_read_b32 v62, v32 offset:512\n ds_read_b32 v63, v32 offset:768\n"
         "ds_read_b32 v56, v32 offset:1024\n ds_read_b32 v57, v32 offset:1280\n ds_read_b32 v58, v32 offset:1536\n ds_read_b32 v59, v32 offset:1792\n"
-        "v_mov_b32 v47, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n"
+        "v_mov_b32 v47, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n"
         "s_mov_b32 s76, %[plo]\n s_mov_b32 s77, %[phi]\n s_mov_b32 s98, %[plim]\n"
         "s_getpc_b64 s[40:41]\n"
         "L_pc_%=:\n"
@@ -149,6 +150,7 @@ DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned 
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_write_b32 v32, v61 offset:2048\n ds_write_b32 v32, v62 offset:2304\n"
         "ds_write_b32 v32, v55 offset:2560\n ds_write_b32 v32, v54 offset:2816\n"
+        "ds_write_b32 v32, v41 offset:3072\n ds_write_b32 v32, v42 offset:3328\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_branch L_end_%=\n"
         /* some lane's chunk is full (pos == first: word 0 is the link's): it moves to the next chunk of its run and writes the
@@ -182,12 +184,14 @@ DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned 
         :
         : [lane8] "v"(lane8), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi), [plo] "s"(plo), [phi] "s"(phi), [plim] "s"(plim)
         : "memory", "vcc", "scc", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s62", "s63", "s76", "s77", "s92", "s93", "s98",
-          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
           "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
     st.pos = io[512 + lane];
     st.first = io[576 + lane];
     st.overflow = io[640 + lane];
     st.kept = io[704 + lane];
+    st.kept_lo = io[768 + lane];
+    st.kept_hi = io[832 + lane];
 }
 
 #undef TG_ADDR

@@ -94,7 +94,8 @@ def test_backward_rows(mpr):
     assert code[-4:] == store
     # ... or nothing, when the copy would be of a slot onto itself
     code = one(mpr, clause(OP["MAX_LHS_IMM"], 4, 4, 0, PI), 1)
-    assert code[7:10] == ["v_xor_b32_e32 v35, 1, v33", "v_and_b32_e32 v35, v35, v32", "v_sub_u32_e32 v61, v61, v35"]
+    assert code[7] == "v_lshl_or_b32 v41, v36, 0, v41"          # this lane's tape keeps min / max clause 0
+    assert code[8:11] == ["v_xor_b32_e32 v35, 1, v33", "v_and_b32_e32 v35, v35, v32", "v_sub_u32_e32 v61, v61, v35"]
     assert "v_mov_b32_e32 v40, 0x4041b" in code                     # COPY_IMM
 
 
