@@ -99,6 +99,42 @@ def test_backward_rows(mpr):
     assert "v_mov_b32_e32 v40, 0x4041b" in code                     # COPY_IMM
 
 
+def test_deriv_rows(mpr):
+    """The normals pass's walk: lane = pixel * 4 + component (dx, dy, dz, value), slot s = v[50 + s], s[98:99] = the value lanes,
+    the value of an operand reaches its quad through DPP quad_perm:[3,3,3,3]; routines return through s[70:71]."""
+    OP = mpr.OP
+    q3 = " quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+
+    def d(c):
+        code = generated(mpr, [clause(0, 1, 2, 3), c, clause(0, (c >> 8) & 0xFF)], 2)
+        assert code[-2:] == ["v_mov_b32_e32 v37, v%d" % (50 + ((c >> 8) & 0xFF)), "s_setpc_b64 s[38:39]"]
+        return code[:-2]
+
+    assert d(clause(OP["ADD_LHS_RHS"], 4, 1, 2)) == ["v_add_f32_e32 v54, v51, v52"]
+    assert d(clause(OP["MUL_LHS_IMM"], 4, 1, 0, PI)) == ["v_mul_f32_e32 v54, 0x40490fdb, v51"]
+    # a + imm, a - imm: only the value lane
+    assert d(clause(OP["SUB_LHS_IMM"], 4, 1, 0, PI)) == ["v_subrev_f32_e32 v38, 0x40490fdb, v51", "v_cndmask_b32_e64 v54, v51, v38, s[98:99]"]
+    # product rule: isv ? a b : a bv + b av
+    assert d(clause(OP["MUL_LHS_RHS"], 4, 1, 2)) == [
+        "v_mul_f32_dpp v38, v52, v51" + q3, "v_mul_f32_dpp v39, v51, v52" + q3, "v_mul_f32_e32 v40, v51, v52",
+        "v_add_f32_e32 v38, v38, v39", "v_cndmask_b32_e64 v54, v38, v40, s[98:99]"]
+    assert d(clause(OP["SQUARE_LHS"], 4, 1)) == [
+        "v_mul_f32_dpp v38, v51, v51" + q3, "v_mul_f32_e32 v39, v51, v51", "v_add_f32_e32 v38, v38, v38",
+        "v_cndmask_b32_e64 v54, v38, v39, s[98:99]"]
+    # max: the comparison of the values, overridden by the decisions of the pixel's tiles (bit 0 of v74: lhs, of v76: rhs)
+    assert d(clause(OP["MAX_LHS_RHS"], 4, 1, 2)) == [
+        "v_mov_b32_dpp v39, v52" + q3, "v_mov_b32_dpp v46, v51" + q3, "v_cmp_ge_f32_e32 vcc, v46, v39",
+        "v_bfe_u32 v40, v74, 0, 1", "v_bfe_u32 v41, v76, 0, 1", "v_cmp_ne_u32_e64 s[42:43], 0, v40", "v_cmp_ne_u32_e64 s[44:45], 0, v41",
+        "s_nop 0", "s_or_b64 vcc, vcc, s[42:43]", "s_andn2_b64 vcc, vcc, s[44:45]", "v_cndmask_b32_e32 v54, v52, v51, vcc"]
+    # exp: e = exp(av); isv ? e : e a — the float pass's routine, called
+    assert d(clause(OP["EXP_LHS"], 4, 1)) == [
+        "v_mov_b32_e32 v43, v51", "v_mov_b32_dpp v35, v51" + q3, "s_swappc_b64 s[70:71], s[76:77]", "v_mul_f32_e32 v38, v37, v43",
+        "v_cndmask_b32_e64 v54, v38, v37, s[98:99]"]
+    # a register written by one of the two instructions before a DPP read gets its wait states
+    code = generated(mpr, [clause(0, 1, 2, 3), clause(OP["ADD_LHS_RHS"], 4, 1, 2), clause(OP["SQUARE_LHS"], 5, 4), clause(0, 5)], 2)
+    assert code[:3] == ["v_add_f32_e32 v54, v51, v52", "s_nop 1", "v_mul_f32_dpp v38, v54, v54" + q3]
+
+
 def test_whole_tapes(mpr):
     allowed = {"v_mov_b32_e32", "v_add_f32_e64", "v_add_f32_e32", "v_sub_f32_e32", "v_subrev_f32_e32", "v_xor_b32_e32", "v_mul_f32_e64",
                "v_mul_f32_e32", "s_swappc_b64", "s_setpc_b64", "v_cndmask_b32_e64", "v_cndmask_b32_e32", "v_or_b32_e32", "v_and_b32_e32",
@@ -106,13 +142,16 @@ def test_whole_tapes(mpr):
                "v_lshlrev_b32_e32", "s_mov_b64", "global_store_dwordx2", "s_nop"}
     tape = mpr.Tape(mpr.model("bear"))
     words = [int(w) for w in np.asarray(tape.data)]
-    for which in (0, 1):
+    allowed |= {"v_mul_f32_dpp", "v_mov_b32_dpp", "v_cmp_lt_f32_e32", "v_cmp_ge_f32_e32", "v_cmp_ne_u32_e64", "s_or_b64", "s_andn2_b64"}
+    for which in (0, 1, 2):
         code = generated(mpr, words, which)
         assert code is not None and code[-1] == "s_setpc_b64 s[38:39]"
         assert {l.split()[0] for l in code} <= allowed
         # one store per clause in the backward code, one decision record per min / max clause in the forward code
         if which == 1:
             assert sum(l.startswith("global_store") for l in code) == len(words) - 2
+        elif which == 2:
+            assert sum(l.startswith("s_andn2_b64 vcc") for l in code) == tape.num_choices
         else:
             assert sum(l.startswith("v_or_b32_e32 v56") or l.startswith("v_or_b32_e32 v57") for l in code) == tape.num_choices
     # tapes the conventions do not fit are left to the interpreter
