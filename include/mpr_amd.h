@@ -232,6 +232,8 @@ int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap
  * "k_eval_voxels_jit<2, 24>" (generated code per tile), "k_eval_voxels_asm<3>" (assembly interpreter) or
  * "k_eval_voxels<3>" (C++ interpreter: instrumented frames).  Owned by the context; "" before a frame. */
 const char* mpr_ctx_float_kernel(const mpr_context* ctx);
+/* ... and its normals pass: "k_eval_normals_gen" (the root tape's generated code), "k_eval_normals_asm", "k_eval_normals_q" */
+const char* mpr_ctx_normals_kernel(const mpr_context* ctx);
 
 /* 1 when the last frame's last tile stage pushed per-tile tapes (the reference's state), 0 when it did not need to (its own
  * sample of the tapes it would push said that float and normals pass do as well on the tapes it walked: DESIGN.md 3).

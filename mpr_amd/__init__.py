@@ -161,12 +161,14 @@ def lib():
     L.mpr_get_counters.argtypes = [vp, P(Counters)]
     L.mpr_get_timings.argtypes = [vp, P(ctypes.c_char_p), P(f32), i32, P(i32)]
     L.mpr_ctx_float_kernel.argtypes = [vp]
+    L.mpr_ctx_normals_kernel.argtypes = [vp]
     L.mpr_ctx_last_stage_pushed.argtypes = [vp]
     L.mpr_ctx_resident_bytes.argtypes = [vp]
     L.mpr_column_weights.argtypes = [vp, vp, i32, vp, f32, vp]
     L.mpr_ctx_resident_bytes.restype = ctypes.c_int64
     L.mpr_ctx_last_stage_pushed.restype = i32
     L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
+    L.mpr_ctx_normals_kernel.restype = ctypes.c_char_p
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
     L.mpr_compiled_create.argtypes = [i32, vp, P(vp)]
     L.mpr_compiled_destroy.argtypes = [vp]
@@ -560,6 +562,10 @@ class Context:
         n = ctypes.c_int32()
         _check(lib().mpr_get_timings(self._h, names, ms, cap, ctypes.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def normals_kernel(self):
+        """Name of the kernel the last frame's normals pass ran as (mpr_ctx_normals_kernel)."""
+        return lib().mpr_ctx_normals_kernel(self._h).decode()
 
     def float_kernel(self):
         """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""

@@ -87,6 +87,7 @@ struct mpr_context {
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
+    const char* normals_kernel = "";   /* mpr_ctx_normals_kernel: ... and its normals pass */
     /* Frames that do not leave the reference's tiles and tapes behind ("fast" frames: what render* does by default; the
      * images are the reference's bit for bit):
      *  - the last tile stage pushes no tapes (TileStageArgs::no_push) when both the float and the normals pass run on the
@@ -1215,6 +1216,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         TimedScope ts(c, "eval_pixels_d");
         if (c->normals_asm && !cnt) mprk::launch_eval_normals_asm(s, n);
         else mprk::launch_eval_normals(s, n);
+        c->normals_kernel = !(c->normals_asm && !cnt) ? "k_eval_normals_q" : n.gen_code ? "k_eval_normals_gen" : "k_eval_normals_asm";
     }
     HIP_TRY(hipGetLastError());
     c->frame_pending = true;
@@ -1629,6 +1631,7 @@ int mpr_get_counters(mpr_context* c, mpr_counters* out)
 }
 
 const char* mpr_ctx_float_kernel(const mpr_context* c) { return c ? c->float_kernel : ""; }
+const char* mpr_ctx_normals_kernel(const mpr_context* c) { return c ? c->normals_kernel : ""; }
 
 int mpr_get_timings(mpr_context* c, const char** names, float* ms, int32_t cap, int32_t* n)
 {

@@ -483,6 +483,28 @@ def test_first_stage_without_generated_code(mpr, orc, tapes, name, dim, S, gen, 
     compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
 
 
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("trig", 128), ("trig", 256), ("two_spheres", 128), ("sphere", 128)])
+def test_normals_on_the_root_tapes_generated_code(mpr, orc, tapes, name, S, monkeypatch):
+    """Frames that start at the 16^3 tiles on generated code and end in group form give every pixel's normal by the ROOT tape's
+    generated Deriv code with the decisions of the pixel's 16^3 and 4^3 tiles applied (k_eval_normals_gen); MPR_NORMALS_GEN=0
+    interprets the tiles' tapes instead.  The oracle's normals either way, frame after frame."""
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    fast = mpr.Context(S)
+    monkeypatch.setenv("MPR_NORMALS_GEN", "0")
+    slow = mpr.Context(S)
+    for ctx, kernel in ((fast, "k_eval_normals_gen"), (slow, "k_eval_normals_asm")):
+        seen = set()
+        for _ in range(3):
+            ctx.render3D(tape, view3())
+            seen.add(ctx.normals_kernel())
+            assert np.array_equal(ctx.image, ref.filled[3]), int((ctx.image != ref.filled[3]).sum())
+            assert np.array_equal(ctx.normals, ref.normals), int((ctx.normals != ref.normals).sum())
+        assert kernel in seen, seen
+    fast.close()
+    slow.close()
+
+
 @pytest.mark.parametrize("name,dim,S", [("prospero", 2, 256), ("involute_gear_2d", 2, 512), ("trig", 2, 256),
                                         ("bear", 3, 256), ("architecture", 3, 256)])
 def test_compiled_forward_walk_matches_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):
