@@ -160,6 +160,7 @@ struct mpr_context {
     /* ... and the normals pass on that tape's generated Deriv code, for frames whose first stage recorded its tiles' decisions
      * (MPR_NORMALS_GEN=0: never) */
     bool normals_gen = true;
+    bool tile_gen_last = true;         /* MPR_TILE_GEN_LAST=0: the last stage of such a frame interprets its parents' tapes */
     unsigned long long* gen_dec = nullptr;      /* four words per 16^3 tile of such a frame (TileStageArgs::gen_decisions) */
     size_t gen_dec_cap = 0;
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
@@ -383,6 +384,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
@@ -881,6 +883,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 a.gen_decisions = c->gen_dec;
                 decisions_recorded = true;
             }
+        } else if (decisions_recorded && last && si == 2 && try_lean && c->tile_gen_last && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0) {
+            /* ... and the stage below walks its parents' tapes as that code with the parents' decisions imposed */
+            a.gen_fwd = c->gen_code;
+            a.gen_parent = c->gen_dec;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
         }
         a.pipe_slots = nullptr;
         a.pipe_ctl = nullptr;
@@ -1087,6 +1095,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             a.len_stats = nullptr;
             a.groups = nullptr;
             a.choice_masks = nullptr;
+            a.gen_fwd = nullptr;             /* (pushing a parent's tape takes walking it: the interpreter) */
+            a.gen_parent = nullptr;
             {
                 TimedScope ts(c, "eval_tiles_i");
                 mprk::launch_eval_tiles(s, dim, a);

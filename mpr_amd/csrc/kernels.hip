@@ -191,7 +191,11 @@ k_eval_tiles(TileStageArgs a)
     const int tape = __builtin_amdgcn_readlane(node.tape, leader);
     /* the tape's first 64 words travel under the interval arithmetic of the prologue */
     uint64_t first_block = 0;
-    if (ASM && !GEN) first_block = a.tape_ro[tape + 1 + lane];
+    /* (see below: the groups of the sample; with a.gen_parent they walk their tape by the interpreter, which can also push it) */
+    const bool sampled = a.len_stats && ((unsigned)((int)blockIdx.x - a.measure_at[0]) < (unsigned)a.measure_len ||
+                                         (unsigned)((int)blockIdx.x - a.measure_at[1]) < (unsigned)a.measure_len);
+    const bool gen_wave = GEN && !(a.gen_parent && sampled);
+    if (ASM && !gen_wave) first_block = a.tape_ro[tape + 1 + lane];
 
     /* tile corners in round-to-nearest (reference :91-96) */
     const float t = (float)a.tps;
@@ -255,22 +259,39 @@ k_eval_tiles(TileStageArgs a)
     float2 res_vs = make_float2(0.0f, 0.0f);
     uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};      /* GEN: this lane's decisions (bit k: chose lhs / rhs at min / max clause k) */
     unsigned char* const gen_io = smem + (size_t)a.choice_cap * 16;
-    if constexpr (GEN) {
+    if (gen_wave) {
+        /* a.gen_parent: the tape these tiles walk is their parent's — the root tape with the parent's decisions (which its
+         * backward walk turned into copies) and without the clauses nothing reads any more.  The root tape's code with those
+         * decisions imposed computes the same intervals (a decided min / max IS the chosen operand: the parent proved the
+         * other one out of the way on a superset of this tile); clauses the parent's tape does not keep as min / max are not
+         * this tile's choices */
+        unsigned long long keeps = a.gen_nchoices >= 64 ? ~0ull : ((1ull << a.gen_nchoices) - 1ull), above_l = 0, above_r = 0;
+        if (a.gen_parent && tape != 0) {
+            const unsigned long long* const rec = a.gen_parent + (size_t)__builtin_amdgcn_readlane(node.next, leader) * 4;
+            above_l = rec[0];
+            above_r = rec[1];
+            keeps = rec[2];
+        }
         tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
                          2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                         make_float2(vz.lo, vz.hi), &res_vs, chl, chr);
-        ci = a.gen_nchoices;
+                         make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r);
+        chl[0] &= (uint32_t)keeps; chl[1] &= (uint32_t)(keeps >> 32);
+        chr[0] &= (uint32_t)keeps; chr[1] &= (uint32_t)(keeps >> 32);
+        ci = __popcll(keeps);
         fwd_words = a.gen_words;
         nclauses = fwd_words - 1;
-        end_index = tape + a.gen_words;
+        end_index = a.gen_words;
         d = tro[end_index];
         any_choice = ballot((chl[0] | chl[1] | chr[0] | chr[1]) != 0) & alive_mask;
         if (!a.gen_bwd) {
-            /* the assembly backward walk reads the decisions as masks over the lanes */
-            for (int k = 0; k < ci && k < a.choice_cap; ++k) {
+            /* as masks over the lanes, numbered by the clauses the walked tape keeps: what the assembly backward walk and the
+             * group's record want */
+            int j = 0;
+            for (unsigned long long m = keeps; m != 0 && j < a.choice_cap; m &= m - 1, ++j) {
+                const int k = __ffsll((long long)m) - 1;
                 const uint64_t m1 = ballot((chl[k >> 5] >> (k & 31)) & 1u) & alive_mask;
                 const uint64_t m2 = ballot((chr[k >> 5] >> (k & 31)) & 1u) & alive_mask;
-                if (lane == 0) choices[k] = make_ulonglong2(m1, m2);
+                if (lane == 0) choices[j] = make_ulonglong2(m1, m2);
             }
         }
     } else if (ASM) {
@@ -423,8 +444,6 @@ k_eval_tiles(TileStageArgs a)
      * sample is two runs of consecutive groups well before the end of the list: a pushing wavefront takes nearly twice as
      * long, and sprinkled over the launch (every 16th group) such waves cost the stage 40 % — a long tail, and two bodies
      * of code competing for the instruction cache throughout. */
-    const bool sampled = a.len_stats && ((unsigned)((int)blockIdx.x - a.measure_at[0]) < (unsigned)a.measure_len ||
-                                         (unsigned)((int)blockIdx.x - a.measure_at[1]) < (unsigned)a.measure_len);
     const bool measure_only = a.no_push && sampled;
     const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1) && (!a.no_push || measure_only);
     uint64_t live = ballot(push);     /* lanes still writing a tape */
@@ -485,7 +504,7 @@ k_eval_tiles(TileStageArgs a)
         lm_set(lm, i_out, live);
 
         MPR_PHASE(2);
-        if (GEN && a.gen_bwd) {
+        if (gen_wave && a.gen_bwd) {
             /* backward walk by the root tape's generated code (tile_gen_asm.hpp) */
             TileGenPush gp;
             gp.active = writing ? (1u << i_out) : 0u;
@@ -1209,7 +1228,7 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
     const int vs = (use_asm && a.vgpr_slots && !(a.debug & 4)) ? tile_stage_vgpr_class(a.nslots, a.choice_cap) : 0;
     const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
-    if (a.gen_fwd && use_asm && a.vgpr_slots && a.nslots <= TI_VS_SMALL_SLOTS && !a.groups) {
+    if (a.gen_fwd && use_asm && a.vgpr_slots && a.nslots <= TI_VS_SMALL_SLOTS && (a.gen_parent ? (a.no_push && !a.pipe_slots) : !a.groups)) {
         const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
         if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);

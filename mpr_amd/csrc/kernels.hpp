@@ -79,6 +79,9 @@ struct TileStageArgs {
                                           * 64 min / max clauses: its walks as generated code (tile_gen.hpp) — else null */
     const uint32_t* gen_bwd = nullptr;   /* (null with gen_fwd set: the assembly interpreter walks backward; development) */
     int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
+    const unsigned long long* gen_parent = nullptr;   /* with gen_fwd, instead of gen_bwd: the launch is the stage BELOW the one that wrote these records
+                                                       * (gen_decisions there): its tiles walk their parents' shortened tapes — as the root tape's
+                                                       * generated code with the parent's decisions imposed, their own renumbered to that tape's */
     unsigned long long* gen_decisions = nullptr;   /* with gen_bwd, optional: per tile that pushes a tape, four words — the root tape's min / max
                                                     * clauses it decided for the lhs, for the rhs, those its tape keeps, 0 (the normals pass on
                                                     * the root tape's generated code applies them, kernels_normals_gen.hip) */

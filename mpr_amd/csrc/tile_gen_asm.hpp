@@ -21,19 +21,32 @@ namespace mprk {
 /* smem_io: 4 KB of LDS ([16][64] words) the register state travels through: the statement below names all but ten vector
  * registers.  ax / ay / az: 2 * the axes' slots; x / y / z: their intervals.  Out: the end clause's interval, and the lanes'
  * decisions at the tape's min / max clauses (bit k of chl / chr: chose lhs / rhs at clause k; two words each). */
+/* decided_lhs / decided_rhs: min / max clauses (bit k: the root tape's k-th) somebody above has decided for all 64 tiles — the
+ * parent tile whose shortened tape they would otherwise walk: the routine's outcome is overridden, the interval is the
+ * chosen operand's as on that tape (0, 0: nobody, the first stage) */
 DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane, uint32_t ax, uint32_t ay, uint32_t az,
-                          float2 x, float2 y, float2 z, float2* res, uint32_t* chl, uint32_t* chr)
+                          float2 x, float2 y, float2 z, float2* res, uint32_t* chl, uint32_t* chr,
+                          unsigned long long decided_lhs = 0, unsigned long long decided_rhs = 0)
 {
     float* const io = reinterpret_cast<float*>(smem_io);
     io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
     const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
     const uint32_t lane8 = (uint32_t)lane * 8u;
     const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
-    ax = rdfirst(ax);
-    ay = rdfirst(ay);
-    az = rdfirst(az);
+    const uint32_t axyz = rdfirst(ax | ay << 8 | az << 16);
+    const uint32_t llo = rdfirst((uint32_t)decided_lhs), lhi = rdfirst((uint32_t)(decided_lhs >> 32));
+    const uint32_t rlo = rdfirst((uint32_t)decided_rhs), rhi = rdfirst((uint32_t)(decided_rhs >> 32));
     asm volatile(
-        TI_VS_ENTER
+        /* the axes' intervals into their slots (TI_VS_ENTER with the three slot numbers in one operand) */
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
+        "ds_read_b32 v36, v32\n ds_read_b32 v37, v32 offset:256\n ds_read_b32 v38, v32 offset:512\n"
+        "ds_read_b32 v39, v32 offset:768\n ds_read_b32 v42, v32 offset:1024\n ds_read_b32 v43, v32 offset:1280\n"
+        "s_bfe_u32 s40, %[axyz], 0x80000\n s_bfe_u32 s41, %[axyz], 0x80008\n s_bfe_u32 s42, %[axyz], 0x80010\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_set_gpr_idx_on s40, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v36\n v_mov_b32 " TI_VS_BASE1 ", v37\n s_set_gpr_idx_off\n"
+        "s_set_gpr_idx_on s41, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v38\n v_mov_b32 " TI_VS_BASE1 ", v39\n s_set_gpr_idx_off\n"
+        "s_set_gpr_idx_on s42, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v42\n v_mov_b32 " TI_VS_BASE1 ", v43\n s_set_gpr_idx_off\n"
+        "s_mov_b32 s60, %[llo]\n s_mov_b32 s61, %[lhi]\n s_mov_b32 s32, %[rlo]\n s_mov_b32 s33, %[rhi]\n"
         "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
         "s_getpc_b64 s[40:41]\n"
         "L_pc_%=:\n"
@@ -75,6 +88,15 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         "v_max_f32 v43, v37, v37\n"
         "v_max_f32 v43, v43, v44\n"
         "L_gsel_%=:\n"
+        /* clause m0 decided from above: every lane takes that operand */
+        "s_bitcmp1_b64 s[60:61], m0\n"
+        "s_cselect_b64 s[94:95], exec, 0\n"
+        "s_andn2_b64 vcc, vcc, s[94:95]\n"
+        "s_andn2_b64 s[92:93], s[92:93], s[94:95]\n"
+        "s_bitcmp1_b64 s[32:33], m0\n"
+        "s_cselect_b64 s[94:95], exec, 0\n"
+        "s_or_b64 vcc, vcc, s[94:95]\n"
+        "s_or_b64 s[92:93], s[92:93], s[94:95]\n"
         "v_cndmask_b32 v40, v42, v38, s[92:93]\n"
         "v_cndmask_b32 v41, v43, v39, s[92:93]\n"
         "v_cndmask_b32 v40, v36, v40, vcc\n"
@@ -89,9 +111,10 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         "s_not_b64 s[58:59], s[58:59]\n s_branch L_idiv_%=\n"
         "L_end_%=:\n"
         :
-        : [lane8] "v"(lane8), [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi)
-        : "memory", "vcc", "scc",
-          "s34", "s35", "s36", "s37", "s38", "s39",
+        : [lane8] "v"(lane8), [axyz] "s"(axyz), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi), [llo] "s"(llo), [lhi] "s"(lhi),
+          [rlo] "s"(rlo), [rhi] "s"(rhi)
+        : "memory", "vcc", "scc", "m0",
+          "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
           "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
           "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",

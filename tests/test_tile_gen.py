@@ -68,7 +68,9 @@ def test_forward_rows(mpr):
         "s_swappc_b64 s[36:37], s[82:83]"]
     # min / max: the routine leaves the lanes' decisions in vcc (did not choose the lhs) and s[92:93] (chose the rhs); bit k
     # of v56 / v58 keeps them for the backward walk
-    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[4:] == [
+    # ... and m0 tells the routine which clause it is (a stage below the first has decisions from above to impose)
+    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[0] == "s_movk_i32 m0, 0x0"
+    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[5:] == [
         "s_swappc_b64 s[36:37], s[80:81]", "v_mov_b32_e32 v76, v40", "v_mov_b32_e32 v77, v41", "v_mov_b32_e32 v42, 1",
         "v_cndmask_b32_e64 v43, v42, 0, vcc", "v_or_b32_e32 v56, v56, v43", "v_cndmask_b32_e64 v43, 0, v42, s[92:93]",
         "v_or_b32_e32 v58, v58, v43"]
@@ -139,7 +141,7 @@ def test_whole_tapes(mpr):
     allowed = {"v_mov_b32_e32", "v_add_f32_e64", "v_add_f32_e32", "v_sub_f32_e32", "v_subrev_f32_e32", "v_xor_b32_e32", "v_mul_f32_e64",
                "v_mul_f32_e32", "s_swappc_b64", "s_setpc_b64", "v_cndmask_b32_e64", "v_cndmask_b32_e32", "v_or_b32_e32", "v_and_b32_e32",
                "v_bfe_u32", "v_lshl_or_b32", "v_sub_u32_e32", "v_add_u32_e32", "v_cmp_eq_u32_e32", "v_cmp_ne_u32_e32", "s_cbranch_vccz",
-               "v_lshlrev_b32_e32", "s_mov_b64", "global_store_dwordx2", "s_nop"}
+               "v_lshlrev_b32_e32", "s_mov_b64", "global_store_dwordx2", "s_nop", "s_movk_i32"}
     tape = mpr.Tape(mpr.model("bear"))
     words = [int(w) for w in np.asarray(tape.data)]
     allowed |= {"v_mul_f32_dpp", "v_mov_b32_dpp", "v_cmp_lt_f32_e32", "v_cmp_ge_f32_e32", "v_cmp_ne_u32_e64", "s_or_b64", "s_andn2_b64"}
