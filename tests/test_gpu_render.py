@@ -491,9 +491,11 @@ def test_normals_on_the_root_tapes_generated_code(mpr, orc, tapes, name, S, monk
     tape = tapes(name)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
     fast = mpr.Context(S)
+    monkeypatch.setenv("MPR_TILE_GEN_LAST", "0")     # ... the last tile stage interprets its parents' tapes (default: the root tape's
+    middle = mpr.Context(S)                           # generated code with the parents' decisions imposed)
     monkeypatch.setenv("MPR_NORMALS_GEN", "0")
     slow = mpr.Context(S)
-    for ctx, kernel in ((fast, "k_eval_normals_gen"), (slow, "k_eval_normals_asm")):
+    for ctx, kernel in ((fast, "k_eval_normals_gen"), (middle, "k_eval_normals_gen"), (slow, "k_eval_normals_asm")):
         seen = set()
         for _ in range(3):
             ctx.render3D(tape, view3())
@@ -502,6 +504,7 @@ def test_normals_on_the_root_tapes_generated_code(mpr, orc, tapes, name, S, monk
             assert np.array_equal(ctx.normals, ref.normals), int((ctx.normals != ref.normals).sum())
         assert kernel in seen, seen
     fast.close()
+    middle.close()
     slow.close()
 
 
