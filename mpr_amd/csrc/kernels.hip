@@ -1251,15 +1251,25 @@ __global__ void k_copy_code(uint32_t* __restrict__ dst, const uint32_t* __restri
     const size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
     if (i < n) dst[i] = src[i];
 }
-__global__ void k_icache_inv()
+/* every CU drops its instruction cache: one workgroup per CU — each asks for more than half a CU's LDS, so no two share one —,
+ * all of them resident at the same time (each stays 20 us; the launch is on an otherwise idle stream), every wavefront of
+ * every SIMD invalidating.  (A kernel boundary is expected to do as much; code that was just replaced is not left to that.) */
+__global__ void __launch_bounds__(1024) k_icache_inv()
 {
-    asm volatile("s_icache_inv\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0" ::: "memory");
+    extern __shared__ unsigned char hold[];
+    if (threadIdx.x == 0) hold[0] = 1;
+    const unsigned long long t0 = wall_clock64();
+    asm volatile("s_icache_inv\n s_nop 7\n s_nop 7" ::: "memory");
+    while (wall_clock64() - t0 < 2000ull) __builtin_amdgcn_s_sleep(16);      /* 100 MHz ticks */
+    asm volatile("s_icache_inv\n s_nop 7\n s_nop 7" ::: "memory");
 }
 void launch_install_code(hipStream_t s, uint32_t* exec_dst, const uint32_t* src, size_t dwords, int cus)
 {
     hipLaunchKernelGGL(k_copy_code, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, s, exec_dst, src, dwords);
     /* (a kernel boundary writes the copy back to memory; the instruction caches are not part of that) */
-    hipLaunchKernelGGL(k_icache_inv, dim3((unsigned)cus * 32u), dim3(64), 0, s);
+    static const hipError_t lds_opt_in = hipFuncSetAttribute(reinterpret_cast<const void*>(k_icache_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)lds_opt_in;
+    hipLaunchKernelGGL(k_icache_inv, dim3((unsigned)cus), dim3(1024), 96 * 1024, s);
 }
 static CopyFilled copy_filled_args(const int* prev, int* next, int size, int first_block, unsigned* extra)
 {
