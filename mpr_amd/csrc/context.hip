@@ -24,6 +24,7 @@
 #include "internal.hpp"
 #include "kernels.hpp"
 #include "tile_gen.hpp"
+static_assert(mpr::TILE_GEN_RECORD_U64 == mprk::GEN_RECORD_U64 && mpr::TILE_GEN_PRESENCE_WORDS == mprk::GEN_PRESENCE_WORDS, "one record layout");
 
 namespace {
 
@@ -156,13 +157,15 @@ struct mpr_context {
     uint32_t* gen_stage = nullptr;     /* what the host hands over (device memory; copied into gen_code by a kernel) */
     size_t gen_cap_dw = 0;
     bool gen_ok = false;
-    int gen_fwd_dw = 0, gen_bwd_dw = 0, gen_words = 0, gen_nchoices = 0;
+    int gen_fwd_dw = 0, gen_bwd_dw = 0, gen_deriv_dw = 0, gen_words = 0, gen_nchoices = 0;
     /* ... and the normals pass on that tape's generated Deriv code, for frames whose first stage recorded its tiles' decisions
      * (MPR_NORMALS_GEN=0: never) */
     bool normals_gen = true;
     bool tile_gen_last = true;         /* MPR_TILE_GEN_LAST=0: the last stage of such a frame interprets its parents' tapes */
-    unsigned long long* gen_dec = nullptr;      /* four words per 16^3 tile of such a frame (TileStageArgs::gen_decisions) */
-    size_t gen_dec_cap = 0;
+    unsigned long long* gen_dec[3] = {nullptr, nullptr, nullptr};   /* the tiles' records, per stage (TileStageArgs::gen_decisions) */
+    size_t gen_dec_cap[3] = {0, 0, 0};
+    int gen_full_dw = 0;               /* dwords of the backward code for tapes that are shortened again (0: the tape is too long for it) */
+    bool tile_gen_chain = true;        /* MPR_TILE_GEN_CHAIN=0: only a frame's first stage (and, in frames that start at the 16^3 tiles, the last) */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
     uint16_t* sched_prev = nullptr;    /* TapeSchedule::prev_writer */
@@ -385,6 +388,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_CHAIN")) c->tile_gen_chain = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
@@ -488,7 +492,7 @@ void mpr_ctx_destroy(mpr_context* c)
     free_executable(c->jit_code);
     free_executable(c->gen_code);
     if (c->gen_stage) (void)hipFree(c->gen_stage);
-    if (c->gen_dec) (void)hipFree(c->gen_dec);
+    for (int i = 0; i < 3; ++i) if (c->gen_dec[i]) (void)hipFree(c->gen_dec[i]);
     if (c->groups) (void)hipFree(c->groups);
     if (c->group_alive) (void)hipFree(c->group_alive);
     if (c->group_list) (void)hipFree(c->group_list);
@@ -531,7 +535,7 @@ int64_t mpr_ctx_resident_bytes(const mpr_context* c)
     for (int i = 0; i < 4; ++i) b += c->tiles_cap[i] * sizeof(mpr_tile_node);
     b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + c->group_list_cap * sizeof(int);
     b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t) + c->pipe_slots_cap * sizeof(int);
-    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t) + c->gen_dec_cap * sizeof(unsigned long long);
+    b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t) + (c->gen_dec_cap[0] + c->gen_dec_cap[1] + c->gen_dec_cap[2]) * sizeof(unsigned long long);
     b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
     return (int64_t)b;
 }
@@ -558,7 +562,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         c->gen_ok = false;
         if (c->tile_gen && c->tiles_asm && c->tiles_vgpr && tape->num_slots <= mpr::TILE_GEN_MAX_SLOTS) {
             const mpr::TileGen g = mpr::tile_gen_build(tape->clauses.data(), len);
-            const size_t ndw = g.fwd.size() + g.bwd.size() + g.deriv.size();
+            const size_t ndw = g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size();
             if (g.ok && ndw > 0) {
                 if (ndw > c->gen_cap_dw) {
                     free_executable(c->gen_code);
@@ -574,12 +578,15 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     std::vector<uint32_t> both(g.fwd);
                     both.insert(both.end(), g.bwd.begin(), g.bwd.end());
                     both.insert(both.end(), g.deriv.begin(), g.deriv.end());
+                    both.insert(both.end(), g.bwd_full.begin(), g.bwd_full.end());
                     HIP_TRY(hipMemcpyAsync(c->gen_stage, both.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                     mprk::launch_install_code(c->stream, c->gen_code, c->gen_stage, ndw, std::max(c->cus, 1));
                     HIP_TRY(hipStreamSynchronize(c->stream));
                     c->gen_ok = true;
                     c->gen_fwd_dw = (int)g.fwd.size();
                     c->gen_bwd_dw = (int)g.bwd.size();
+                    c->gen_deriv_dw = (int)g.deriv.size();
+                    c->gen_full_dw = (int)g.bwd_full.size();
                     c->gen_words = g.words;
                     c->gen_nchoices = g.nchoices;
                 }
@@ -825,7 +832,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     }
 
     bool prev_wide = false;
-    bool decisions_recorded = false;       /* the first stage ran over the 16^3 tiles on generated code and kept its tiles' decisions */
+    bool decisions_recorded = false;       /* the stages so far ran generated code and kept their tiles' decisions ... */
+    bool presence_recorded = false;        /* ... with the clauses of the tapes they pushed */
+    bool last_recorded = false;            /* ... down to the smallest tiles */
     for (int si = skip0 ? 1 : 0; si < nstages; ++si) {
         const int i = stage_list[si];
         const bool last = (si == nstages - 1);
@@ -870,25 +879,68 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             group_cap = std::max(stage_cap, 1);
         }
         mprk::TileStageArgs a;
-        if (c->gen_ok && si == (skip0 ? 1 : 0) && !last && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0) {
-            /* every tile of the frame's first stage walks the root tape */
-            a.gen_fwd = c->gen_code;
-            a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
-            a.gen_words = c->gen_words;
-            a.gen_nchoices = c->gen_nchoices;
-            if (skip0 && dim == 3 && a.gen_bwd && c->normals_gen && c->normals_asm && nstages == 3) {
-                /* the tiles' decisions on the root tape's min / max clauses, for the normals pass */
-                rc = ensure_buffer(&c->gen_dec, &c->gen_dec_cap, (size_t)count * 4);
+        {
+            /* Tile stages on the root tape's generated code (tile_gen.hpp).  The first stage: every tile walks that tape.  A stage
+             * below walks its parents' tapes as the same code with the parents' recorded decisions imposed, and — where it pushes —
+             * shortens them by the backward code that follows the parent's tape clause by clause (records with presence bits). */
+            const bool gen_here = c->gen_ok && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0 && !c->pipeline;
+            const bool first_stage = si == (skip0 ? 1 : 0);
+            const bool records = dim == 3 && nstages == 3 && c->tile_gen == 1 && c->normals_asm && !cnt;
+            const uint32_t* const code_full = c->gen_full_dw ? c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw : nullptr;
+            const bool chain = records && c->tile_gen_chain && code_full != nullptr;
+            auto record_into = [&](int k) -> int {
+                const int e = ensure_buffer(&c->gen_dec[k], &c->gen_dec_cap[k], (size_t)count * mprk::GEN_RECORD_U64 + 16);
+                if (e == MPR_OK) a.gen_decisions = c->gen_dec[k];
+                return e;
+            };
+            if (gen_here && first_stage && !last) {
+                a.gen_fwd = c->gen_code;
+                a.gen_words = c->gen_words;
+                a.gen_nchoices = c->gen_nchoices;
+                decisions_recorded = false;
+                presence_recorded = false;
+                if (skip0) {
+                    /* the stage below pushes nothing: the decisions are all it and the normals pass need */
+                    a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
+                    if (records && a.gen_bwd && (c->normals_gen || c->tile_gen_last)) {
+                        rc = record_into(i);
+                        if (rc) return rc;
+                        decisions_recorded = true;
+                    }
+                } else if (chain) {
+                    a.gen_bwd_full = code_full;
+                    rc = record_into(i);
+                    if (rc) return rc;
+                    decisions_recorded = presence_recorded = true;
+                } else {
+                    a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
+                }
+            } else if (gen_here && !first_stage && !last && presence_recorded && chain) {
+                a.gen_fwd = c->gen_code;
+                a.gen_words = c->gen_words;
+                a.gen_nchoices = c->gen_nchoices;
+                a.gen_parent = c->gen_dec[stage_list[si - 1]];
+                a.gen_bwd_full = code_full;
+                rc = record_into(i);
                 if (rc) return rc;
-                a.gen_decisions = c->gen_dec;
-                decisions_recorded = true;
+            } else if (gen_here && last && si == 2 && decisions_recorded && try_lean && c->tile_gen_last) {
+                a.gen_fwd = c->gen_code;
+                a.gen_words = c->gen_words;
+                a.gen_nchoices = c->gen_nchoices;
+                a.gen_parent = c->gen_dec[1];
+            } else if (gen_here && last && si == 2 && presence_recorded && chain && !try_lean) {
+                /* a last stage that pushes (a frame whose tiles and tapes are read): every tile gets a record of its own */
+                a.gen_fwd = c->gen_code;
+                a.gen_words = c->gen_words;
+                a.gen_nchoices = c->gen_nchoices;
+                a.gen_parent = c->gen_dec[1];
+                a.gen_bwd_full = code_full;
+                rc = record_into(2);
+                if (rc) return rc;
+                last_recorded = true;
+            } else if (!last) {
+                decisions_recorded = presence_recorded = false;       /* an interpreted stage keeps no record: the chain ends */
             }
-        } else if (decisions_recorded && last && si == 2 && try_lean && c->tile_gen_last && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0) {
-            /* ... and the stage below walks its parents' tapes as that code with the parents' decisions imposed */
-            a.gen_fwd = c->gen_code;
-            a.gen_parent = c->gen_dec;
-            a.gen_words = c->gen_words;
-            a.gen_nchoices = c->gen_nchoices;
         }
         a.pipe_slots = nullptr;
         a.pipe_ctl = nullptr;
@@ -1205,9 +1257,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         n.choice_masks = normals_on_groups ? c->choice_masks : nullptr;
         n.choice_cap = group_cap;
         n.vgpr_slots = c->tiles_vgpr;
-        if (decisions_recorded && normals_on_groups && group_stage == 2) {
+        if (c->normals_gen && decisions_recorded && ((normals_on_groups && group_stage == 2) || last_recorded)) {
             n.gen_code = c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw;
-            n.gen_decisions = c->gen_dec;
+            n.gen_decisions0 = skip0 ? nullptr : c->gen_dec[0];
+            n.gen_decisions = c->gen_dec[1];
+            n.gen_decisions2 = last_recorded ? c->gen_dec[2] : nullptr;
             n.gen_nchoices = c->gen_nchoices;
         }
         if (owner && c->normals_asm && !cnt) {

@@ -194,7 +194,7 @@ k_eval_tiles(TileStageArgs a)
     /* (see below: the groups of the sample; with a.gen_parent they walk their tape by the interpreter, which can also push it) */
     const bool sampled = a.len_stats && ((unsigned)((int)blockIdx.x - a.measure_at[0]) < (unsigned)a.measure_len ||
                                          (unsigned)((int)blockIdx.x - a.measure_at[1]) < (unsigned)a.measure_len);
-    const bool gen_wave = GEN && !(a.gen_parent && sampled);
+    const bool gen_wave = GEN && !(a.gen_parent && sampled && !a.gen_bwd_full);
     if (ASM && !gen_wave) first_block = a.tape_ro[tape + 1 + lane];
 
     /* tile corners in round-to-nearest (reference :91-96) */
@@ -258,6 +258,9 @@ k_eval_tiles(TileStageArgs a)
     uint64_t d = 0;
     float2 res_vs = make_float2(0.0f, 0.0f);
     uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};      /* GEN: this lane's decisions (bit k: chose lhs / rhs at min / max clause k) */
+    unsigned long long above_l = 0, above_r = 0;    /* ... what the parent tile decided for all of them (a.gen_parent) */
+    unsigned long long gen_keeps = ~0ull;           /* ... the min / max clauses the tape they walk keeps */
+    const unsigned long long* parent_rec = nullptr; /* ... the parent's record (null: the tape they walk is the root tape) */
     unsigned char* const gen_io = smem + (size_t)a.choice_cap * 16;
     if (gen_wave) {
         /* a.gen_parent: the tape these tiles walk is their parent's — the root tape with the parent's decisions (which its
@@ -265,13 +268,19 @@ k_eval_tiles(TileStageArgs a)
          * decisions imposed computes the same intervals (a decided min / max IS the chosen operand: the parent proved the
          * other one out of the way on a superset of this tile); clauses the parent's tape does not keep as min / max are not
          * this tile's choices */
-        unsigned long long keeps = a.gen_nchoices >= 64 ? ~0ull : ((1ull << a.gen_nchoices) - 1ull), above_l = 0, above_r = 0;
+        unsigned long long keeps = a.gen_nchoices >= 64 ? ~0ull : ((1ull << a.gen_nchoices) - 1ull);
+        int walked = a.gen_words - 1;               /* clauses of the tape these tiles walk (the sample's statistics) */
         if (a.gen_parent && tape != 0) {
-            const unsigned long long* const rec = a.gen_parent + (size_t)__builtin_amdgcn_readlane(node.next, leader) * 4;
-            above_l = rec[0];
-            above_r = rec[1];
-            keeps = rec[2];
+            parent_rec = a.gen_parent + (size_t)__builtin_amdgcn_readlane(node.next, leader) * GEN_RECORD_U64;
+            above_l = parent_rec[0];
+            above_r = parent_rec[1];
+            keeps = parent_rec[2];
+            if (a.len_stats && a.gen_bwd_full) {
+                walked = 0;
+                for (int k = 4; k < GEN_RECORD_U64; ++k) walked += __popcll(parent_rec[k]);
+            }
         }
+        gen_keeps = keeps;
         tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
                          2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
                          make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r);
@@ -279,11 +288,11 @@ k_eval_tiles(TileStageArgs a)
         chr[0] &= (uint32_t)keeps; chr[1] &= (uint32_t)(keeps >> 32);
         ci = __popcll(keeps);
         fwd_words = a.gen_words;
-        nclauses = fwd_words - 1;
+        nclauses = walked;
         end_index = a.gen_words;
         d = tro[end_index];
         any_choice = ballot((chl[0] | chl[1] | chr[0] | chr[1]) != 0) & alive_mask;
-        if (!a.gen_bwd) {
+        if (a.groups || (!a.gen_bwd && !a.gen_bwd_full)) {
             /* as masks over the lanes, numbered by the clauses the walked tape keeps: what the assembly backward walk and the
              * group's record want */
             int j = 0;
@@ -504,7 +513,7 @@ k_eval_tiles(TileStageArgs a)
         lm_set(lm, i_out, live);
 
         MPR_PHASE(2);
-        if (gen_wave && a.gen_bwd) {
+        if (gen_wave && (a.gen_bwd || a.gen_bwd_full)) {
             /* backward walk by the root tape's generated code (tile_gen_asm.hpp) */
             TileGenPush gp;
             gp.active = writing ? (1u << i_out) : 0u;
@@ -512,7 +521,13 @@ k_eval_tiles(TileStageArgs a)
             gp.first = (uint32_t)out_index;
             gp.run_end = (uint32_t)run_end;
             const long long lim = a.pool_cap - 65;
-            tile_gen_backward(a.gen_bwd, tro, gen_io, lane, gp, chl, chr, (uint32_t)(lim < 0 ? 0 : (lim > 0x7FFFFF00ll ? 0x7FFFFF00ll : lim)));
+            const uint32_t plim = (uint32_t)(lim < 0 ? 0 : (lim > 0x7FFFFF00ll ? 0x7FFFFF00ll : lim));
+            if (a.gen_bwd_full)
+                tile_gen_backward_full(a.gen_bwd_full, tro, gen_io, lane, gp, chl, chr, plim, above_l, above_r,
+                                       parent_rec ? reinterpret_cast<const uint32_t*>(parent_rec + 4) : nullptr,
+                                       reinterpret_cast<uint32_t*>(a.gen_decisions), (uint32_t)(((size_t)gidx * GEN_RECORD_U64 + 4) * 8));
+            else
+                tile_gen_backward(a.gen_bwd, tro, gen_io, lane, gp, chl, chr, plim);
             if (writing) {
                 out_index = (int)gp.first;
                 out_offset = (int)(gp.pos - gp.first);
@@ -521,9 +536,9 @@ k_eval_tiles(TileStageArgs a)
             writing = push && !overflow;
             live = ballot(writing);
             if (a.gen_decisions && writing) {
-                unsigned long long* const rec = a.gen_decisions + (size_t)gidx * 4;
-                rec[0] = (unsigned long long)chl[0] | ((unsigned long long)chl[1] << 32);
-                rec[1] = (unsigned long long)chr[0] | ((unsigned long long)chr[1] << 32);
+                unsigned long long* const rec = a.gen_decisions + (size_t)gidx * GEN_RECORD_U64;
+                rec[0] = (unsigned long long)chl[0] | ((unsigned long long)chl[1] << 32) | above_l;
+                rec[1] = (unsigned long long)chr[0] | ((unsigned long long)chr[1] << 32) | above_r;
                 rec[2] = (unsigned long long)gp.kept_lo | ((unsigned long long)gp.kept_hi << 32);
                 rec[3] = 0;
             }
@@ -653,6 +668,16 @@ k_eval_tiles(TileStageArgs a)
              * Counted from where the walk ended, so that the assembly walk (which keeps no count) reports it too. */
             written = (long long)(out_index - first_index) + (MPR_SUBTAPE_CHUNK - out_offset);
         }
+    }
+    if (gen_wave && a.gen_decisions && a.gen_parent && alive && !(push && !overflow)) {
+        /* a tile below the first stage that pushes nothing hands its parent's tape on: with the parent's record (the root
+         * tape: nothing decided, everything there) */
+        unsigned long long* const rec = a.gen_decisions + (size_t)gidx * GEN_RECORD_U64;
+        rec[0] = above_l;
+        rec[1] = above_r;
+        rec[2] = gen_keeps;
+        rec[3] = 0;
+        for (int k = 4; k < GEN_RECORD_U64; ++k) rec[k] = parent_rec ? parent_rec[k] : ~0ull;
     }
     if (sampled) {
         /* (a sample of the groups: one pair of atomics per wave on two words would be felt) */
@@ -1228,7 +1253,8 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
     const int vs = (use_asm && a.vgpr_slots && !(a.debug & 4)) ? tile_stage_vgpr_class(a.nslots, a.choice_cap) : 0;
     const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
-    if (a.gen_fwd && use_asm && a.vgpr_slots && a.nslots <= TI_VS_SMALL_SLOTS && (a.gen_parent ? (a.no_push && !a.pipe_slots) : !a.groups)) {
+    if (a.gen_fwd && use_asm && a.vgpr_slots && a.nslots <= TI_VS_SMALL_SLOTS && !a.pipe_slots &&
+        (a.gen_bwd_full ? true : a.gen_parent ? a.no_push : !a.groups)) {
         const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
         if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);

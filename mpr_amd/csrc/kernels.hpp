@@ -43,6 +43,9 @@ struct GroupInfo {
  * sit 128 bytes apart. */
 enum { PIPE_TAIL = 0, PIPE_HEAD = 32, PIPE_DONE = 64, PIPE_ERROR = 96, PIPE_CTL_WORDS = 128 };
 
+/* a tile's record of what it decided (csrc/tile_gen.hpp: TILE_GEN_RECORD_U64, TILE_GEN_PRESENCE_WORDS), 64-bit words */
+constexpr int GEN_RECORD_U64 = 16, GEN_PRESENCE_WORDS = 24;
+
 struct TileStageArgs {
     const uint64_t* tape_ro;   /* tape pool, read side (parents' tapes; never written by this launch) */
     uint64_t* tape_wr;         /* same pool, write side (freshly claimed chunks) */
@@ -78,6 +81,9 @@ struct TileStageArgs {
     const uint32_t* gen_fwd = nullptr;   /* a launch whose tiles all walk the ROOT tape (a frame's first stage), tape of at most 24 slots and
                                           * 64 min / max clauses: its walks as generated code (tile_gen.hpp) — else null */
     const uint32_t* gen_bwd = nullptr;   /* (null with gen_fwd set: the assembly interpreter walks backward; development) */
+    const uint32_t* gen_bwd_full = nullptr;   /* instead of gen_bwd: the tapes pushed here are shortened again by a stage that runs generated code
+                                               * too, or this launch is such a stage (gen_parent): the walk that follows the PARENT's tape clause
+                                               * by clause and records the clauses of the tape it writes (tile_gen.cpp) */
     int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
     const unsigned long long* gen_parent = nullptr;   /* with gen_fwd, instead of gen_bwd: the launch is the stage BELOW the one that wrote these records
                                                        * (gen_decisions there): its tiles walk their parents' shortened tapes — as the root tape's
@@ -141,7 +147,10 @@ struct NormalArgs {
      * (TileStageArgs::gen_decisions), group form: every pixel on the ROOT tape's generated Deriv code (tile_gen.hpp) with the
      * decisions of its 16^3 and 4^3 tiles applied — one walk per footprint whatever tapes its pixels carry (else null) */
     const uint32_t* gen_code = nullptr;
-    const unsigned long long* gen_decisions = nullptr;
+    const unsigned long long* gen_decisions = nullptr;    /* the 16^3 tiles' records (GEN_RECORD_U64 words each) */
+    const unsigned long long* gen_decisions0 = nullptr;   /* the 64^3 tiles', when that stage ran */
+    const unsigned long long* gen_decisions2 = nullptr;   /* the 4^3 tiles', when the last stage pushed: everything decided for a pixel in one record
+                                                           * (else: the 16^3 tile's record and the group's masks) */
     int gen_nchoices = 0;
 };
 

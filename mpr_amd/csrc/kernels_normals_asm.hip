@@ -656,12 +656,14 @@ k_eval_normals_gen(NormalArgs a)
     const float vz = (a.mat[2] * fx + a.mat[6] * fy + a.mat[10] * fz + a.mat[14]) / fw;
 
     /* the pixel's 16^3 tile (index in its stage's list, and the tape that tile pushed: 0 = none) and 4^3 tile (:1034-1066) */
-    int my_sub = -1, sub_tape = 0, my_micro = -1;
+    int my_sub = -1, sub_tape = 0, my_micro = -1, my_top = -1;
     if (filled) {
         const int t64 = S / 64;
         const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
         const mpr_tile_node tn = a.tiles[tile];
-        if (tn.next != -1) {
+        if (tn.next == -1) {
+            if (tn.tape != 0 && a.gen_decisions0) my_top = tile;           /* a 64^3 tile that pushed a tape and was decided afterwards */
+        } else {
             my_sub = tn.next * 64 + (px % 64) / 16 + ((py % 64) / 16) * 4 + ((pz % 64) / 16) * 16;
             const mpr_tile_node sn = a.subtiles[my_sub];
             sub_tape = sn.tape;
@@ -672,7 +674,13 @@ k_eval_normals_gen(NormalArgs a)
     unsigned long long dl = 0, dr = 0;
     /* pixels with a 4^3 tile: the 16^3 tile's decisions, then the 4^3 tile's, renumbered from the clauses its tape keeps to the
      * root tape's; one (16^3 tile, 4^3 tile) at a time — a footprint meets a handful */
-    uint64_t pending = ballot(my_micro >= 0);
+    uint64_t pending = a.gen_decisions2 ? 0 : ballot(my_micro >= 0);
+    if (a.gen_decisions2 && my_micro >= 0) {
+        /* the last stage pushed: the pixel's 4^3 tile has everything in its own record */
+        const unsigned long long* const rec = a.gen_decisions2 + (size_t)my_micro * GEN_RECORD_U64;
+        dl = rec[0];
+        dr = rec[1];
+    }
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
         const int micro = __builtin_amdgcn_readlane(my_micro, leader);
@@ -682,7 +690,7 @@ k_eval_normals_gen(NormalArgs a)
         const int g = micro >> 6, child = micro & 63;
         unsigned long long L = 0, R = 0, K = all;
         if (stape != 0) {
-            const unsigned long long* const rec = a.gen_decisions + (size_t)sub * 4;
+            const unsigned long long* const rec = a.gen_decisions + (size_t)sub * GEN_RECORD_U64;
             L = rec[0];
             R = rec[1];
             K = rec[2];
@@ -714,11 +722,17 @@ k_eval_normals_gen(NormalArgs a)
         const int sub = __builtin_amdgcn_readlane(my_sub, leader);
         const bool mine = my_micro < 0 && my_sub == sub;
         pending &= ~ballot(mine);
-        const unsigned long long* const rec = a.gen_decisions + (size_t)sub * 4;
+        const unsigned long long* const rec = a.gen_decisions + (size_t)sub * GEN_RECORD_U64;
         if (mine) {
             dl = rec[0];
             dr = rec[1];
         }
+    }
+
+    if (my_top >= 0) {
+        const unsigned long long* const rec = a.gen_decisions0 + (size_t)my_top * GEN_RECORD_U64;
+        dl = rec[0];
+        dr = rec[1];
     }
 
     const uint64_t head0 = a.tape_ro[0];
@@ -743,7 +757,7 @@ void launch_eval_normals_asm(hipStream_t s, const NormalArgs& a)
     if (groups <= 0) return;
     /* slots in registers when the LDS slot file would hold a CU under the 12 wavefronts those registers allow (tried for
      * small slot files too: bear, 23 slots, 0.378 -> 0.420 ms — one wavefront per SIMD fewer, and the index switching) */
-    if (a.gen_code && a.gen_decisions && a.groups) {
+    if (a.gen_code && a.gen_decisions && (a.groups || a.gen_decisions2)) {
         hipLaunchKernelGGL(k_eval_normals_gen, dim3(groups), dim3(64), 0, s, a);
         return;
     }

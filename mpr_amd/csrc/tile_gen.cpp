@@ -273,6 +273,114 @@ void backward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uin
     store_word(e, 35, W1, cur_hi);
 }
 
+/* ---- the backward walk for tapes that are shortened again, and for the stages that shorten them ----
+ * The tape a stage below the first shortens is its parent's: not the root tape under the parent's decisions, but the very
+ * words the parent's walk emitted — a clause it turned into a COPY keeps its unused operand field, the reference's walk (and
+ * the interpreter's) marks that operand's slot active like any plain clause's, and whichever earlier clause OF THAT TAPE writes
+ * the slot is kept.  So a record carries, besides the decisions, one PRESENCE bit per clause of the root tape (bit i - 1:
+ * clause i is on the tape), this code skips the rows of absent clauses (s[0..23]: the parent's bits, all set for the first
+ * stage), walks the clauses decided above as the plain COPYs they are there (s[64:65] / s[66:67]), and collects the presence
+ * bits of the tape it writes in v64.. (one register per 32 clauses). */
+void full_store(Emit& b, int ef, uint32_t W0, uint32_t W1, int pw, int pbit)
+{
+    b.mov_lit(46, W0);
+    b.mov_lit(47, W1);
+    b.vop3(V3_LSHL_OR, 64 + pw, Emit::V(ef), Emit::I(pbit), Emit::V(64 + pw));
+    b.vopc(VC_NE_U32, Emit::I(0), ef);
+    b.vop2(V_LSHLREV, 44, Emit::I(3), 61);
+    b.mov_exec(VCC);
+    b.store_x2(44, 46, 76);
+    b.mov_exec(193);
+}
+void full_plain(Emit& b, int o, int l, int r, uint32_t W0, uint32_t W1, int pw, int pbit)
+{
+    b.vop3(V3_BFE_U32, 32, Emit::V(60), Emit::I(o), Emit::I(1));
+    take_word(b, 32);
+    if (l != o && r != o) b.vop2_lit(V_AND, 60, ~(1u << o), 60);
+    if (l != 0 && l != o) b.vop3(V3_LSHL_OR, 60, Emit::V(32), Emit::I(l), Emit::V(60));
+    if (r != 0 && r != o && r != l) b.vop3(V3_LSHL_OR, 60, Emit::V(32), Emit::I(r), Emit::V(60));
+    full_store(b, 32, W0, W1, pw, pbit);
+}
+void backward_full_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uint32_t W1, int choice, int index)
+{
+    const int pw = (index - 1) >> 5, pbit = (index - 1) & 31;
+    std::vector<uint32_t> body;
+    Emit b{body};
+    if (!mpr_op_is_minmax(op)) {
+        full_plain(b, o, l, r, W0, W1, pw, pbit);
+    } else {
+        std::vector<uint32_t> body_own, body_l, body_r;
+        {
+            Emit x{body_l};
+            if (l != o) full_plain(x, o, l, r, (W0 & ~0xFFu) | MPR_OP_COPY_LHS, W1, pw, pbit);
+        }
+        {
+            Emit x{body_r};
+            if (!(r != 0 && r == o)) full_plain(x, o, l, r, (W0 & ~0xFFu) | (r != 0 ? MPR_OP_COPY_RHS : MPR_OP_COPY_IMM), W1, pw, pbit);
+        }
+        {
+            Emit x{body_own};
+            x.vop3(V3_BFE_U32, 32, Emit::V(60), Emit::I(o), Emit::I(1));
+            x.vop3(V3_BFE_U32, 33, Emit::V(56 + (choice >> 5)), Emit::I(choice & 31), Emit::I(1));
+            x.vop3(V3_BFE_U32, 34, Emit::V(58 + (choice >> 5)), Emit::I(choice & 31), Emit::I(1));
+            x.vop2(V_OR, 36, Emit::V(33), 34);
+            x.vop2(V_XOR, 36, Emit::I(1), 36);
+            x.vop2(V_AND, 36, Emit::V(36), 32);
+            x.vop2(V_ADD_U32, 54, Emit::V(54), 36);
+            x.vop3(V3_LSHL_OR, 41 + (choice >> 5), Emit::V(36), Emit::I(choice & 31), Emit::V(41 + (choice >> 5)));
+            const bool dropL = l == o, dropR = r != 0 && r == o;
+            if (!dropL && !dropR) {
+                x.mov(35, Emit::V(32));
+            } else if (dropL && dropR) {
+                x.mov(35, Emit::V(36));
+            } else {
+                x.vop2(V_XOR, 35, Emit::I(1), dropL ? 33 : 34);
+                x.vop2(V_AND, 35, Emit::V(35), 32);
+            }
+            take_word(x, 35);
+            x.vop2(V_XOR, 37, Emit::I(1), 34);
+            x.vop2(V_AND, 37, Emit::V(37), 32);
+            if (r != 0) {
+                x.vop2(V_XOR, 38, Emit::I(1), 33);
+                x.vop2(V_AND, 38, Emit::V(38), 32);
+            }
+            x.vop2_lit(V_AND, 60, ~(1u << o), 60);
+            if (l != 0) x.vop3(V3_LSHL_OR, 60, Emit::V(37), Emit::I(l), Emit::V(60));
+            if (r != 0) x.vop3(V3_LSHL_OR, 60, Emit::V(38), Emit::I(r), Emit::V(60));
+            x.vopc(VC_NE_U32, Emit::I(0), 33);
+            x.mov_lit(46, W0);
+            x.mov_lit(39, (W0 & ~0xFFu) | MPR_OP_COPY_LHS);
+            x.vop2(V_CNDMASK, 46, Emit::V(46), 39);
+            x.vopc(VC_NE_U32, Emit::I(0), 34);
+            x.mov_lit(40, (W0 & ~0xFFu) | (r != 0 ? MPR_OP_COPY_RHS : MPR_OP_COPY_IMM));
+            x.nop(0);
+            x.vop2(V_CNDMASK, 46, Emit::V(46), 40);
+            x.mov_lit(47, W1);
+            x.vop3(V3_LSHL_OR, 64 + pw, Emit::V(35), Emit::I(pbit), Emit::V(64 + pw));
+            x.vopc(VC_NE_U32, Emit::I(0), 35);
+            x.vop2(V_LSHLREV, 44, Emit::I(3), 61);
+            x.mov_exec(VCC);
+            x.store_x2(44, 46, 76);
+            x.mov_exec(193);
+        }
+        /* s_bitcmp1_b64 s[64:65], k ; s_cbranch_scc1 L ; s_bitcmp1_b64 s[66:67], k ; s_cbranch_scc1 R ; own ; s_branch E ;
+         * L: the COPY_LHS it is above ; s_branch E ; R: the COPY_RHS / COPY_IMM ; E: */
+        const int n_own = (int)body_own.size(), n_l = (int)body_l.size(), n_r = (int)body_r.size();
+        b.d(0xBF0F0040u | (uint32_t)(128 + choice) << 8);
+        b.d(0xBF850000u | (uint32_t)((n_own + 3) & 0xFFFF));
+        b.d(0xBF0F0042u | (uint32_t)(128 + choice) << 8);
+        b.d(0xBF850000u | (uint32_t)((n_own + n_l + 2) & 0xFFFF));
+        for (uint32_t w : body_own) b.d(w);
+        b.d(0xBF820000u | (uint32_t)((n_l + 1 + n_r) & 0xFFFF));
+        for (uint32_t w : body_l) b.d(w);
+        b.d(0xBF820000u | (uint32_t)(n_r & 0xFFFF));
+        for (uint32_t w : body_r) b.d(w);
+    }
+    e.d(0xBF0D0000u | (uint32_t)(128 + pbit) << 8 | (uint32_t)pw);          /* s_bitcmp1_b32 s[pw], pbit: on the parent's tape? */
+    e.d(0xBF840000u | (uint32_t)(body.size() & 0xFFFF));                     /* s_cbranch_scc0: no */
+    for (uint32_t w : body) e.d(w);
+}
+
 /* ---- the Deriv walk of the normals pass (reference :1067-1121; the interpreter's handlers: kernels_normals_asm.hip) ---- */
 /* Lane = pixel * 4 + component (dx, dy, dz, value); slot s = v[50 + s]; s[98:99] = the value lanes; the shared float routines
  * take v35 (, v36) and return v37 through s[70:71] (entry points: TileGenReg TD_*).  Every row computes exactly the handler's
@@ -520,6 +628,17 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
         backward_clause(b, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)w, (uint32_t)(w >> 32), choice, cur_hi);
     }
     b.setpc(TG_RET_CODE);
+    if (end - 1 <= 32 * TILE_GEN_PRESENCE_WORDS) {
+        Emit bf{g.bwd_full};
+        int ch = nch;
+        for (int i = end - 1; i >= 1; --i) {
+            const uint64_t w = clauses[i];
+            const uint32_t op = (uint32_t)w & 0xFF;
+            if (mpr_op_is_minmax(op)) --ch;
+            backward_full_clause(bf, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)w, (uint32_t)(w >> 32), ch, i);
+        }
+        bf.setpc(TG_RET_CODE);
+    }
     g.words = end;
     g.nchoices = nch;
     g.ok = true;
@@ -531,8 +650,8 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
     const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
-    if (!g.ok || which < 0 || which > 2) return -1;
-    const std::vector<uint32_t>& c = which == 2 ? g.deriv : which ? g.bwd : g.fwd;
+    if (!g.ok || which < 0 || which > 3) return -1;
+    const std::vector<uint32_t>& c = which == 3 ? g.bwd_full : which == 2 ? g.deriv : which ? g.bwd : g.fwd;
     if (out && (int)c.size() <= cap)
         for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
     return (int)c.size();

@@ -26,6 +26,11 @@ namespace mpr {
 
 constexpr int TILE_GEN_MAX_SLOTS = 24;      /* slots 0..23 */
 constexpr int TILE_GEN_MAX_CHOICES = 64;
+constexpr int TILE_GEN_PRESENCE_WORDS = 24; /* tapes of up to 768 clauses can be shortened again by generated code */
+/* a tile's record (TileStageArgs::gen_decisions), 64-bit words: the root tape's min / max clauses decided for the lhs, for the
+ * rhs (its own decisions and everything decided above it), those its tape keeps as min / max, 0; then one bit per clause of
+ * the root tape: on the tile's tape (TILE_GEN_PRESENCE_WORDS dwords) */
+constexpr int TILE_GEN_RECORD_U64 = 4 + TILE_GEN_PRESENCE_WORDS / 2;
 
 enum TileGenReg : int {
     TG_RT_SQUARE = 62, TG_RT_ABS = 64, TG_RT_MUL = 66, TG_RT_SQRT = 68, TG_RT_MIN = 70, TG_RT_MAX = 80, TG_RT_DIV = 82,
@@ -40,6 +45,8 @@ struct TileGen {
     bool ok = false;
     std::vector<uint32_t> fwd;      /* forward walk: axes in their slots -> result in v[36:37], decisions in v56..v59 */
     std::vector<uint32_t> bwd;      /* backward walk of tape pushing */
+    std::vector<uint32_t> bwd_full; /* the same for tapes that are shortened again, and for the stages below the first (tile_gen.cpp); empty:
+                                     * the tape has more clauses than a record has presence bits */
     std::vector<uint32_t> deriv;    /* the normals pass's walk (value + three partials per pixel: four lanes), decisions in v74..v77 */
     int words = 0;                  /* clause words a walk visits: the operations and the end clause (or the head) */
     int nchoices = 0;               /* min / max clauses */

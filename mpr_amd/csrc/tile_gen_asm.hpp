@@ -217,6 +217,113 @@ DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned 
     st.kept_hi = io[832 + lane];
 }
 
+/* The backward walk for tapes that are shortened again (tile_gen.cpp: backward_full_clause).  decided_lhs / decided_rhs:
+ * min / max clauses that are copies already on the tape being shortened; parent_presence: that tape's clauses, one bit per
+ * clause of the root tape (TILE_GEN_PRESENCE_WORDS dwords; null: all of them — the first stage); the presence bits of the
+ * tapes written go to presence_out + presence_off (per lane, bytes) for the lanes that entered with an active slot. */
+DEV void tile_gen_backward_full(const uint32_t* code, const uint64_t* pool, unsigned char* smem_io, int lane, TileGenPush& st,
+                                const uint32_t* chl, const uint32_t* chr, uint32_t pool_limit, unsigned long long decided_lhs,
+                                unsigned long long decided_rhs, const uint32_t* parent_presence, uint32_t* presence_out, uint32_t presence_off)
+{
+    uint32_t* const io = reinterpret_cast<uint32_t*>(smem_io);
+    io[lane] = st.active; io[64 + lane] = st.pos; io[128 + lane] = st.first; io[192 + lane] = st.run_end;
+    io[256 + lane] = chl[0]; io[320 + lane] = chl[1]; io[384 + lane] = chr[0]; io[448 + lane] = chr[1];
+    io[896 + lane] = presence_off;
+    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    const uint32_t plo = rdfirst((uint32_t)(uintptr_t)pool), phi = rdfirst((uint32_t)((uintptr_t)pool >> 32));
+    const uint32_t plim = rdfirst(pool_limit);
+    const uint32_t llo = rdfirst((uint32_t)decided_lhs), lhi = rdfirst((uint32_t)(decided_lhs >> 32));
+    const uint32_t rlo = rdfirst((uint32_t)decided_rhs), rhi = rdfirst((uint32_t)(decided_rhs >> 32));
+    const uint32_t qlo = rdfirst((uint32_t)(uintptr_t)parent_presence), qhi = rdfirst((uint32_t)((uintptr_t)parent_presence >> 32));
+    const uint32_t olo = rdfirst((uint32_t)(uintptr_t)presence_out), ohi = rdfirst((uint32_t)((uintptr_t)presence_out >> 32));
+    asm volatile(
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
+        "ds_read_b32 v60, v32\n ds_read_b32 v61, v32 offset:256\n ds_read_b32 v62, v32 offset:512\n ds_read_b32 v63, v32 offset:768\n"
+        "ds_read_b32 v56, v32 offset:1024\n ds_read_b32 v57, v32 offset:1280\n ds_read_b32 v58, v32 offset:1536\n ds_read_b32 v59, v32 offset:1792\n"
+        "ds_read_b32 v53, v32 offset:3584\n"
+        "v_mov_b32 v47, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n"
+        "v_mov_b32 v64, 0\n v_mov_b32 v65, 0\n v_mov_b32 v66, 0\n v_mov_b32 v67, 0\n v_mov_b32 v68, 0\n v_mov_b32 v69, 0\n"
+        "v_mov_b32 v70, 0\n v_mov_b32 v71, 0\n v_mov_b32 v72, 0\n v_mov_b32 v73, 0\n v_mov_b32 v74, 0\n v_mov_b32 v75, 0\n"
+        "v_mov_b32 v76, 0\n v_mov_b32 v77, 0\n v_mov_b32 v78, 0\n v_mov_b32 v79, 0\n v_mov_b32 v80, 0\n v_mov_b32 v81, 0\n"
+        "v_mov_b32 v82, 0\n v_mov_b32 v83, 0\n v_mov_b32 v84, 0\n v_mov_b32 v85, 0\n v_mov_b32 v86, 0\n v_mov_b32 v87, 0\n"
+        "s_mov_b32 s76, %[plo]\n s_mov_b32 s77, %[phi]\n s_mov_b32 s98, %[plim]\n"
+        "s_mov_b32 s64, %[llo]\n s_mov_b32 s65, %[lhi]\n s_mov_b32 s66, %[rlo]\n s_mov_b32 s67, %[rhi]\n"
+        "s_mov_b32 s68, %[olo]\n s_mov_b32 s69, %[ohi]\n"
+        /* the parent's tape: s[0:23] */
+        "s_mov_b32 s34, %[qlo]\n s_mov_b32 s35, %[qhi]\n"
+        "s_cmp_eq_u64 s[34:35], 0\n"
+        "s_cbranch_scc1 L_all_%=\n"
+        "s_load_dwordx8 s[0:7], s[34:35], 0x0\n s_load_dwordx8 s[8:15], s[34:35], 0x20\n s_load_dwordx8 s[16:23], s[34:35], 0x40\n"
+        "s_branch L_have_%=\n"
+        "L_all_%=:\n"
+        "s_mov_b64 s[0:1], -1\n s_mov_b64 s[2:3], -1\n s_mov_b64 s[4:5], -1\n s_mov_b64 s[6:7], -1\n s_mov_b64 s[8:9], -1\n s_mov_b64 s[10:11], -1\n"
+        "s_mov_b64 s[12:13], -1\n s_mov_b64 s[14:15], -1\n s_mov_b64 s[16:17], -1\n s_mov_b64 s[18:19], -1\n s_mov_b64 s[20:21], -1\n s_mov_b64 s[22:23], -1\n"
+        "L_have_%=:\n"
+        "s_getpc_b64 s[40:41]\n"
+        "L_pc_%=:\n"
+        TG_ADDR(62, 63, "L_chunk")
+        "s_mov_b32 s34, %[clo]\n"
+        "s_mov_b32 s35, %[chi]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_cmp_ne_u32 s[70:71], 0, v60\n"                /* the lanes that write a tape */
+        "s_swappc_b64 s[38:39], s[34:35]\n"
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
+        "ds_write_b32 v32, v61 offset:2048\n ds_write_b32 v32, v62 offset:2304\n"
+        "ds_write_b32 v32, v55 offset:2560\n ds_write_b32 v32, v54 offset:2816\n"
+        "ds_write_b32 v32, v41 offset:3072\n ds_write_b32 v32, v42 offset:3328\n"
+        "s_mov_b64 exec, s[70:71]\n"
+        "global_store_dwordx4 v53, v[64:67], s[68:69]\n global_store_dwordx4 v53, v[68:71], s[68:69] offset:16\n"
+        "global_store_dwordx4 v53, v[72:75], s[68:69] offset:32\n global_store_dwordx4 v53, v[76:79], s[68:69] offset:48\n"
+        "global_store_dwordx4 v53, v[80:83], s[68:69] offset:64\n global_store_dwordx4 v53, v[84:87], s[68:69] offset:80\n"
+        "s_mov_b64 exec, -1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_branch L_end_%=\n"
+        "L_chunk_%=:\n"
+        "v_cmp_eq_u32 vcc, v61, v62\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_mov_b32 v52, v62\n"
+        "v_add_u32 v62, 64, v62\n"
+        "v_cmp_ge_u32 vcc, v62, v63\n"
+        "v_cmp_gt_u32 s[92:93], v62, s98\n"
+        "s_or_b64 vcc, vcc, s[92:93]\n"
+        "v_cndmask_b32 v60, v60, 0, vcc\n"
+        "v_cndmask_b32 v32, v32, 0, vcc\n"
+        "v_cndmask_b32 v35, v35, 0, vcc\n"
+        "v_cndmask_b32 v55, v55, 1, vcc\n"
+        "s_andn2_b64 exec, exec, vcc\n"
+        "v_add_lshl_u32 v44, v62, 63, 3\n"
+        "v_lshlrev_b32 v45, 3, v52\n"
+        "v_mov_b32 v48, 1\n"
+        "v_mov_b32 v49, 0xffffff81\n"
+        "v_mov_b32 v50, 1\n"
+        "v_mov_b32 v51, 127\n"
+        "global_store_dwordx2 v44, v[48:49], s[76:77]\n"
+        "global_store_dwordx2 v45, v[50:51], s[76:77]\n"
+        "v_add_u32 v61, 62, v62\n"
+        "s_mov_b64 exec, -1\n"
+        "s_setpc_b64 s[36:37]\n"
+        "L_end_%=:\n"
+        :
+        : [lane8] "v"(lane8), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi), [plo] "s"(plo), [phi] "s"(phi), [plim] "s"(plim),
+          [llo] "s"(llo), [lhi] "s"(lhi), [rlo] "s"(rlo), [rhi] "s"(rhi), [qlo] "s"(qlo), [qhi] "s"(qhi), [olo] "s"(olo), [ohi] "s"(ohi)
+        : "memory", "vcc", "scc", "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15",
+          "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23",
+          "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s76", "s77",
+          "s92", "s93", "s98",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+          "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+          "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+    st.pos = io[512 + lane];
+    st.first = io[576 + lane];
+    st.overflow = io[640 + lane];
+    st.kept = io[704 + lane];
+    st.kept_lo = io[768 + lane];
+    st.kept_hi = io[832 + lane];
+}
+
 #undef TG_ADDR
 
 }  // namespace mprk

@@ -101,6 +101,30 @@ def test_backward_rows(mpr):
     assert "v_mov_b32_e32 v40, 0x4041b" in code                     # COPY_IMM
 
 
+def test_backward_rows_for_tapes_that_are_shortened_again(mpr):
+    """which = 3: the walk a stage below the first pushes by, and the one that writes tapes such a stage will shorten.  The tape
+    being shortened is the PARENT's: s[0..23] hold one bit per clause of the root tape (is it on that tape?), a clause decided
+    above (s[64:65] lhs / s[66:67] rhs) is walked as the COPY it is there, and v64.. collect the clauses of the tape written."""
+    OP = mpr.OP
+    take = ["v_cmp_eq_u32_e32 vcc, v61, v62", "s_cbranch_vccz 1", "s_swappc_b64 s[36:37], s[62:63]"]
+    store = ["v_lshlrev_b32_e32 v44, 3, v61", "s_mov_b64 exec, vcc", "global_store_dwordx2 v44, v[46:47], s[76:77]", "s_mov_b64 exec, -1"]
+    code = one(mpr, clause(OP["ADD_LHS_RHS"], 4, 1, 2), 3)
+    assert code[0] == "s_bitcmp1_b32 s0, 0" and code[1] == "s_cbranch_scc0 24"      # not on the parent's tape: over the row (24 dwords)
+    assert code[2:] == ["v_bfe_u32 v32, v60, 4, 1", "v_sub_u32_e32 v61, v61, v32"] + take + [
+        "v_and_b32_e32 v60, 0xffffffef, v60", "v_lshl_or_b32 v60, v32, 1, v60", "v_lshl_or_b32 v60, v32, 2, v60",
+        "v_mov_b32_e32 v46, 0x201040e", "v_mov_b32_e32 v47, 0", "v_lshl_or_b32 v64, v32, 0, v64", "v_cmp_ne_u32_e32 vcc, 0, v32"] + store
+    # a min: its own body (decided by the lanes or not at all), or the COPY it became above
+    code = one(mpr, clause(OP["MIN_LHS_RHS"], 4, 1, 2), 3)
+    assert code[2] == "s_bitcmp1_b64 s[64:65], 0" and code[4] == "s_bitcmp1_b64 s[66:67], 0"
+    branches = [k for k, l in enumerate(code) if l.startswith("s_branch")]
+    assert len(branches) == 2
+    lhs = code[branches[0] + 1:branches[1]]
+    assert lhs[0] == "v_bfe_u32 v32, v60, 4, 1" and "v_mov_b32_e32 v46, 0x201041c" in lhs and "v_lshl_or_b32 v60, v32, 2, v60" in lhs   # a COPY's unused operand counts
+    assert "v_mov_b32_e32 v46, 0x201041d" in code[branches[1] + 1:]
+    own = code[6:branches[0]]
+    assert "v_lshl_or_b32 v64, v35, 0, v64" in own and "v_lshl_or_b32 v41, v36, 0, v41" in own
+
+
 def test_deriv_rows(mpr):
     """The normals pass's walk: lane = pixel * 4 + component (dx, dy, dz, value), slot s = v[50 + s], s[98:99] = the value lanes,
     the value of an operand reaches its quad through DPP quad_perm:[3,3,3,3]; routines return through s[70:71]."""
@@ -145,13 +169,16 @@ def test_whole_tapes(mpr):
     tape = mpr.Tape(mpr.model("bear"))
     words = [int(w) for w in np.asarray(tape.data)]
     allowed |= {"v_mul_f32_dpp", "v_mov_b32_dpp", "v_cmp_lt_f32_e32", "v_cmp_ge_f32_e32", "v_cmp_ne_u32_e64", "s_or_b64", "s_andn2_b64"}
-    for which in (0, 1, 2):
+    allowed |= {"s_bitcmp1_b32", "s_bitcmp1_b64", "s_cbranch_scc0", "s_cbranch_scc1", "s_branch"}
+    for which in (0, 1, 2, 3):
         code = generated(mpr, words, which)
         assert code is not None and code[-1] == "s_setpc_b64 s[38:39]"
         assert {l.split()[0] for l in code} <= allowed
         # one store per clause in the backward code, one decision record per min / max clause in the forward code
         if which == 1:
             assert sum(l.startswith("global_store") for l in code) == len(words) - 2
+        elif which == 3:
+            assert sum(l.startswith("s_bitcmp1_b32") for l in code) == len(words) - 2
         elif which == 2:
             assert sum(l.startswith("s_andn2_b64 vcc") for l in code) == tape.num_choices
         else:
