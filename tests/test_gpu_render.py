@@ -483,6 +483,25 @@ def test_first_stage_without_generated_code(mpr, orc, tapes, name, dim, S, gen, 
     compare_frame(mpr, orc, tapes(name), dim, S, view2() if dim == 2 else view3())
 
 
+@pytest.mark.parametrize("name,S", [("bear", 256), ("trig", 128), ("two_spheres", 128)])
+@pytest.mark.parametrize("chain", ["0", "1"])
+def test_frames_that_are_read_on_chains_of_generated_stages(mpr, orc, tapes, name, S, chain, monkeypatch):
+    """A frame whose tiles and tapes are read runs all three tile stages: with MPR_TILE_GEN_CHAIN=1 (default) every one of them on
+    the root tape's generated code — the stages below the first shorten their parents' tapes by the backward code that follows
+    the parent's tape clause by clause (records with presence bits) — and the normals pass on the 4^3 tiles' own records; with 0
+    only the first stage.  compare_frame: the oracle's tiles and tapes at every stage; then frames that are not read."""
+    monkeypatch.setenv("MPR_TILE_GEN_CHAIN", chain)
+    tape = tapes(name)
+    cnt, ref = compare_frame(mpr, orc, tape, 3, S, view3())
+    monkeypatch.setenv("MPR_LAST_STAGE_PUSH", "1")
+    ctx = mpr.Context(S)
+    for _ in range(2):
+        ctx.render3D(tape, view3())
+        assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals)
+    assert ctx.normals_kernel() == ("k_eval_normals_gen" if chain == "1" else "k_eval_normals_asm")
+    ctx.close()
+
+
 @pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("trig", 128), ("trig", 256), ("two_spheres", 128), ("sphere", 128)])
 def test_normals_on_the_root_tapes_generated_code(mpr, orc, tapes, name, S, monkeypatch):
     """Frames that start at the 16^3 tiles on generated code and end in group form give every pixel's normal by the ROOT tape's
