@@ -1,11 +1,14 @@
 /*
- * tile_gen.hpp — the ROOT tape's interval walks as gfx950 machine code, generated on the host when a tape is made resident.
+ * tile_gen.hpp — the ROOT tape's walks as gfx950 machine code, generated on the host when a tape is made resident.
  *
  * Every tile of a frame's first stage walks the same tape (reference src/context.cu:188-321 forward, :323-458 backward), so
  * unlike the tapes pushed later this one is worth compiling: a clause becomes the handful of instructions its opcode needs,
  * with the slot registers and the immediate in the instruction words — no fetch, no decode, no dispatch, no operand moves
  * through a register index.  The arithmetic is the interpreter's own (tile_interp_asm.hpp): simple clauses are emitted in
  * line, the others call the interpreter's routine bodies.  Counterpart on the device: tile_gen_asm.hpp.
+ * The tapes pushed later are this tape with decisions applied; with a tile's decisions kept as bits over the root tape's
+ * min / max clauses (its RECORD, below) the stages below the first and the normals pass (reference :978-1132; the Deriv walk,
+ * run by kernels_normals_asm.hip: k_eval_normals_gen) run the same one piece of code per tape as well.
  *
  * Register conventions of the generated code (fixed: the harness and the routine bodies are written against them)
  *   slot s                  v[68 + 2 s] (lower bound), v[69 + 2 s] (upper bound)           s <= 24
@@ -16,7 +19,11 @@
  * backward walk
  *   v60 active slots (bit s), v61 pool index of the last word written, v62 first index of the current chunk,
  *   v[46:47] the clause word being stored (v47 keeps the last upper half), s[76:77] pool, s[62:63] "chunk full" routine,
- *   v54 number of min / max clauses the lane's tape keeps, v41 / v42 which ones (bit k: clause k)
+ *   v54 number of min / max clauses the lane's tape keeps, v41 / v42 which ones (bit k: clause k);
+ *   the walk for tapes that are shortened again also: s[0..23] the clauses of the tape being shortened, s[64:65] / s[66:67] the
+ *   min / max clauses that are copies on it (decided above for the lhs / rhs), v64..v87 the clauses of the tape being written
+ * Deriv walk: slot s = v[50 + s], routine operands v35 (, v36), result v37, return address s[70:71]; s[98:99] the value lanes;
+ *   v74 / v75 (v76 / v77): min / max clauses decided for the lhs (rhs) for the lane's pixel
  */
 #pragma once
 #include <cstdint>
