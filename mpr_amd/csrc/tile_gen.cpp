@@ -150,7 +150,7 @@ bool forward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t K, int c
         case MPR_OP_MAX_LHS_RHS: {
             const bool is_min = op <= MPR_OP_MIN_LHS_RHS;
             const bool has_rhs = op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS;
-            e.d(0xB07C0000u | (uint32_t)choice);                                 /* s_movk_i32 m0, clause: the routine may know better */
+            e.d(0xB04C0000u | (uint32_t)choice);                                 /* s_movk_i32 s76, clause: the routine may know better */
             call2(e, is_min ? TG_RT_MIN : TG_RT_MAX, o, l, has_rhs ? r : -1, K);
             /* the routine leaves vcc = lanes that did NOT choose the lhs, s[92:93] = lanes that chose the rhs */
             e.mov_lit(42, 1u << (choice & 31));

@@ -32,21 +32,28 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
     io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
     const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
     const uint32_t lane8 = (uint32_t)lane * 8u;
-    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
-    const uint32_t axyz = rdfirst(ax | ay << 8 | az << 16);
-    const uint32_t llo = rdfirst((uint32_t)decided_lhs), lhi = rdfirst((uint32_t)(decided_lhs >> 32));
-    const uint32_t rlo = rdfirst((uint32_t)decided_rhs), rhi = rdfirst((uint32_t)(decided_rhs >> 32));
+    /* the wave-uniform words travel through LDS as well (the statement names nearly every scalar register too) */
+    if (lane == 0) {
+        uint32_t* const u = reinterpret_cast<uint32_t*>(io) + 960;
+        u[0] = (uint32_t)decided_lhs; u[1] = (uint32_t)(decided_lhs >> 32);
+        u[2] = (uint32_t)decided_rhs; u[3] = (uint32_t)(decided_rhs >> 32);
+        u[4] = (uint32_t)(uintptr_t)code; u[5] = (uint32_t)((uintptr_t)code >> 32);
+        u[6] = ax; u[7] = ay; u[8] = az;
+    }
     asm volatile(
         /* the axes' intervals into their slots (TI_VS_ENTER with the three slot numbers in one operand) */
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_read_b32 v36, v32\n ds_read_b32 v37, v32 offset:256\n ds_read_b32 v38, v32 offset:512\n"
         "ds_read_b32 v39, v32 offset:768\n ds_read_b32 v42, v32 offset:1024\n ds_read_b32 v43, v32 offset:1280\n"
-        "s_bfe_u32 s40, %[axyz], 0x80000\n s_bfe_u32 s41, %[axyz], 0x80008\n s_bfe_u32 s42, %[axyz], 0x80010\n"
+        "v_mov_b32 v33, %[io]\n"
+        "ds_read_b128 v[44:47], v33 offset:3840\n ds_read_b128 v[48:51], v33 offset:3856\n ds_read_b32 v52, v33 offset:3872\n"
         "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s72, v44\n v_readfirstlane_b32 s73, v45\n v_readfirstlane_b32 s74, v46\n v_readfirstlane_b32 s75, v47\n"
+        "v_readfirstlane_b32 s34, v48\n v_readfirstlane_b32 s35, v49\n"
+        "v_readfirstlane_b32 s40, v50\n v_readfirstlane_b32 s41, v51\n v_readfirstlane_b32 s42, v52\n"
         "s_set_gpr_idx_on s40, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v36\n v_mov_b32 " TI_VS_BASE1 ", v37\n s_set_gpr_idx_off\n"
         "s_set_gpr_idx_on s41, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v38\n v_mov_b32 " TI_VS_BASE1 ", v39\n s_set_gpr_idx_off\n"
         "s_set_gpr_idx_on s42, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v42\n v_mov_b32 " TI_VS_BASE1 ", v43\n s_set_gpr_idx_off\n"
-        "s_mov_b32 s60, %[llo]\n s_mov_b32 s61, %[lhi]\n s_mov_b32 s32, %[rlo]\n s_mov_b32 s33, %[rhi]\n"
         "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
         "s_getpc_b64 s[40:41]\n"
         "L_pc_%=:\n"
@@ -54,8 +61,6 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         TG_ADDR(70, 71, "L_gmin") TG_ADDR(80, 81, "L_gmax") TG_ADDR(82, 83, "L_gdiv") TG_ADDR(84, 85, "L_gdivi")
         TG_ADDR(86, 87, "L_casin") TG_ADDR(88, 89, "L_cacos") TG_ADDR(90, 91, "L_catan") TG_ADDR(98, 99, "L_cexp")
         TG_ADDR(96, 97, "L_clog")
-        "s_mov_b32 s34, %[clo]\n"
-        "s_mov_b32 s35, %[chi]\n"
         "s_swappc_b64 s[38:39], s[34:35]\n"
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
@@ -88,12 +93,12 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         "v_max_f32 v43, v37, v37\n"
         "v_max_f32 v43, v43, v44\n"
         "L_gsel_%=:\n"
-        /* clause m0 decided from above: every lane takes that operand */
-        "s_bitcmp1_b64 s[60:61], m0\n"
+        /* clause s76 decided from above (s[72:73] for the lhs, s[74:75] for the rhs): every lane takes that operand */
+        "s_bitcmp1_b64 s[72:73], s76\n"
         "s_cselect_b64 s[94:95], exec, 0\n"
         "s_andn2_b64 vcc, vcc, s[94:95]\n"
         "s_andn2_b64 s[92:93], s[92:93], s[94:95]\n"
-        "s_bitcmp1_b64 s[32:33], m0\n"
+        "s_bitcmp1_b64 s[74:75], s76\n"
         "s_cselect_b64 s[94:95], exec, 0\n"
         "s_or_b64 vcc, vcc, s[94:95]\n"
         "s_or_b64 s[92:93], s[92:93], s[94:95]\n"
@@ -111,12 +116,12 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         "s_not_b64 s[58:59], s[58:59]\n s_branch L_idiv_%=\n"
         "L_end_%=:\n"
         :
-        : [lane8] "v"(lane8), [axyz] "s"(axyz), [io] "s"(ioaddr), [clo] "s"(clo), [chi] "s"(chi), [llo] "s"(llo), [lhi] "s"(lhi),
-          [rlo] "s"(rlo), [rhi] "s"(rhi)
-        : "memory", "vcc", "scc", "m0",
-          "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
+        : [lane8] "v"(lane8), [io] "s"(ioaddr)
+        : "memory", "vcc", "scc",
+          "s34", "s35", "s36", "s37", "s38", "s39",
           "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
           "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+          "s72", "s73", "s74", "s75", "s76",
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
           "s97", "s98", "s99",
           "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",

@@ -68,8 +68,8 @@ def test_forward_rows(mpr):
         "s_swappc_b64 s[36:37], s[82:83]"]
     # min / max: the routine leaves the lanes' decisions in vcc (did not choose the lhs) and s[92:93] (chose the rhs); bit k
     # of v56 / v58 keeps them for the backward walk
-    # ... and m0 tells the routine which clause it is (a stage below the first has decisions from above to impose)
-    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[0] == "s_movk_i32 m0, 0x0"
+    # ... and s76 tells the routine which clause it is (a stage below the first has decisions from above to impose)
+    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[0] == "s_movk_i32 s76, 0x0"
     assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[5:] == [
         "s_swappc_b64 s[36:37], s[80:81]", "v_mov_b32_e32 v76, v40", "v_mov_b32_e32 v77, v41", "v_mov_b32_e32 v42, 1",
         "v_cndmask_b32_e64 v43, v42, 0, vcc", "v_or_b32_e32 v56, v56, v43", "v_cndmask_b32_e64 v43, 0, v42, s[92:93]",
