@@ -99,7 +99,7 @@ constexpr uint32_t CSELECT = 0x85DE80C1u;                                      /
  * issue_rates2.hip: "v_cndmask"), the VOP3 form with an SGPR pair at half rate (0.82-0.90: "v_cndmask e64 sgpr") */
 constexpr uint32_t CND64_LO = 0xD1000000u;                                     /* | vdst */
 constexpr uint32_t CND64_HI = (94u << 18) | (1u << 17);                        /* | src0 (9 bits) | vsrc1 << 9; src1 is a VGPR */
-constexpr uint32_t V_CNDMASK = 0, V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21, V_FMAMK = 23;
+constexpr uint32_t V_ADD = 1, V_SUB = 2, V_SUBREV = 3, V_MUL = 5, V_MIN = 10, V_MAX = 11, V_AND = 19, V_XOR = 21, V_FMAMK = 23;
 constexpr uint32_t CLASS_V39_V7 = 0x7C200F27u;                                 /* v_cmp_class_f32 vcc, v39, v7 */
 constexpr uint32_t BRANCH_VCCZ_2 = 0xBF860002u;                                /* s_cbranch_vccz +2 dwords */
 constexpr uint32_t CLASS_NOT_POSITIVE_NORMAL = 0x2FFu;                         /* what v7 holds while generated code runs */
