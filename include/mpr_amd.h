@@ -228,7 +228,7 @@ int mpr_get_counters(mpr_context* ctx, mpr_counters* out);
 int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
 
 /* Name of the kernel the last frame's float pass (eval_voxels_f) ran as, as rocprofv3 prints it without
- * the namespace: "k_eval_voxels_jit_groups<3, 24, false>" (generated code, one translation per 64 sibling tiles; true: pipelined),
+ * the namespace: "k_eval_voxels_jit_groups<3, 24>" (generated code, one translation per 64 sibling tiles),
  * "k_eval_voxels_jit<2, 24>" (generated code per tile), "k_eval_voxels_asm<3>" (assembly interpreter) or
  * "k_eval_voxels<3>" (C++ interpreter: instrumented frames).  Owned by the context; "" before a frame. */
 const char* mpr_ctx_float_kernel(const mpr_context* ctx);

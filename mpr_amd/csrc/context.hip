@@ -119,19 +119,6 @@ struct mpr_context {
     bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
     int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
-    /* pipelined tail of a 3-D frame: last tile stage on `stream`, float pass beside it on `stream2` (kernels.hpp: PIPE_*) */
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int* pipe_slots = nullptr;
-    size_t pipe_slots_cap = 0;
-    int* pipe_ctl = nullptr;
-    bool pipeline = false;             /* MPR_PIPELINE=1 (off by default: measured, no gain — the two kernels take as long side by side as
-                                          one after the other, both being bound by the time their vector instructions take to issue;
-                                          DESIGN.md 8) */
-    int pipe_wgs = 4;                  /* MPR_PIPE_WGS: workgroups per CU of the float pass while the tile stage runs (the rest follow behind it) */
-    bool pipe_vs = false;              /* MPR_PIPE_VS=1: the tile stage keeps its slots in registers while pipelined (fewer waves beside the float pass) */
-    bool last_frame_piped = false;
-    int piped_since_measure = 0;
     int jit_wgs_per_cu = 0;            /* MPR_JIT_WGS (development): workgroups per CU of the group form's persistent grid */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     bool jit_always_invalidate = false;/* MPR_VOXEL_JIT=3 (development): the group form invalidates the instruction cache after every translation */
@@ -371,9 +358,6 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_GROUPS")) { c->voxel_groups = atoi(e) != 0; c->groups_always = atoi(e) == 2; }
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
     if (const char* e = getenv("MPR_JIT_WGS")) c->jit_wgs_per_cu = atoi(e);
-    if (const char* e = getenv("MPR_PIPELINE")) c->pipeline = atoi(e) != 0;
-    if (const char* e = getenv("MPR_PIPE_WGS")) c->pipe_wgs = std::max(atoi(e), 1);
-    if (const char* e = getenv("MPR_PIPE_VS")) c->pipe_vs = atoi(e) != 0;
     if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
     {
         hipDeviceProp_t prop;
@@ -424,10 +408,6 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
         }                                                            \
     } while (0)
     CT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CT(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    CT(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    CT(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    CT(hipMalloc((void**)&c->pipe_ctl, mprk::PIPE_CTL_WORDS * sizeof(int)));
     {
         /* the four filled images and the normals (src/context.cpp:21-27) live in one allocation, in this
          * order, so that one kernel resets them at the start of a frame (mprk::launch_begin_frame) */
@@ -516,11 +496,6 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->sched_levels) (void)hipFree(c->sched_levels);
     if (c->sched_prev) (void)hipFree(c->sched_prev);
     if (c->sched_defs) (void)hipFree(c->sched_defs);
-    if (c->pipe_slots) (void)hipFree(c->pipe_slots);
-    if (c->pipe_ctl) (void)hipFree(c->pipe_ctl);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -534,7 +509,7 @@ int64_t mpr_ctx_resident_bytes(const mpr_context* c)
     size_t b = c->arena_words * sizeof(int) + ((size_t)c->pool_cap + 128) * sizeof(uint64_t) + c->jit_code_bytes;
     for (int i = 0; i < 4; ++i) b += c->tiles_cap[i] * sizeof(mpr_tile_node);
     b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + c->group_list_cap * sizeof(int);
-    b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t) + c->pipe_slots_cap * sizeof(int);
+    b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t);
     b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t) + (c->gen_dec_cap[0] + c->gen_dec_cap[1] + c->gen_dec_cap[2]) * sizeof(unsigned long long);
     b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
     return (int64_t)b;
@@ -787,7 +762,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     /* the reference's way (every stage from the 64 px tiles down, every tape pushed): asked for, or a frame that is inspected */
     const bool reference = c->reference_frames || c->force_reference || brute || cnt || heat;
     int hint = (c->hint_serial == tape->serial && c->hint_dim == dim) ? c->hint_mode : (int)mpr_context::HINT_UNKNOWN;
-    bool lean_now = false, piped = false;
+    bool lean_now = false;
     /* 3-D: the 64^3 stage of a frame up to 1024^3 is 64 wavefronts walking the whole tape one clause after the other — 0.15 ms
      * of latency on an idle chip — while ALL of its 16^3 tiles are one round of wavefronts for the next stage.  A
      * frame nobody inspects starts there: every 64^3 tile counts as ambiguous.  The hierarchy is conservative at every level, so
@@ -883,7 +858,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             /* Tile stages on the root tape's generated code (tile_gen.hpp).  The first stage: every tile walks that tape.  A stage
              * below walks its parents' tapes as the same code with the parents' recorded decisions imposed, and — where it pushes —
              * shortens them by the backward code that follows the parent's tape clause by clause (records with presence bits). */
-            const bool gen_here = c->gen_ok && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0 && !c->pipeline;
+            const bool gen_here = c->gen_ok && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0 &&
+                                  mprk::tile_stage_gen_possible(nslots, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
             const bool first_stage = si == (skip0 ? 1 : 0);
             const bool records = dim == 3 && nstages == 3 && c->tile_gen == 1 && c->normals_asm && !cnt;
             const uint32_t* const code_full = c->gen_full_dw ? c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw : nullptr;
@@ -942,36 +918,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 decisions_recorded = presence_recorded = false;       /* an interpreted stage keeps no record: the chain ends */
             }
         }
-        a.pipe_slots = nullptr;
-        a.pipe_ctl = nullptr;
         a.no_mask = c->stage0_only;
-        /* Pipelined tail (3-D, a tape known to take the group form, a launch of several rounds of wavefronts): the last tile
-         * stage and the float pass at the same time, as producer and consumer of a queue of groups (kernels.hpp: PIPE_*).  The
-         * stage's wavefronts are dependent chains that leave the vector units half idle, the float pass is bound by their issue
-         * rate: side by side they take about as long as the float pass alone.  No compaction in between: the float pass gets
-         * every tile that was ambiguous when its wavefront finished and leaves the hidden ones at its skip test. */
-        JitPlan pipe_plan;
-        bool pipe_now = last && dim == 3 && try_lean && hint == mpr_context::HINT_GROUPS && c->pipeline && !wide_now &&
-                        count >= 128 * std::max(c->cus, 1) && (c->zsort & 2) && c->piped_since_measure < 63;
-        /* (a pipelined frame measures nothing — nobody could read the sample in time —, so every 64th frame of a tape is not
-         * pipelined and looks at how much its last stage shortens, in case the view has drifted) */
-        if (last && groups_now) c->piped_since_measure = pipe_now ? c->piped_since_measure + 1 : 0;
-        if (pipe_now) {
-            rc = jit_prepare(c, tape, dim, nslots, true, &pipe_plan);
-            if (rc) return rc;
-            pipe_now = pipe_plan.ok && pipe_plan.grid > c->cus;
-        }
-        if (pipe_now) {
-            const int ng = (count + 63) / 64;
-            rc = ensure_buffer(&c->pipe_slots, &c->pipe_slots_cap, (size_t)ng);
-            if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(c->pipe_slots, 0, (size_t)ng * sizeof(int), s));
-            HIP_TRY(hipMemsetAsync(c->pipe_ctl, 0, mprk::PIPE_CTL_WORDS * sizeof(int), s));
-            HIP_TRY(hipEventRecord(c->ev_fork, s));
-            HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            a.pipe_slots = c->pipe_slots;
-            a.pipe_ctl = c->pipe_ctl;
-        }
         if (count > 0) {
             a.groups = groups_now ? c->groups : nullptr;
             a.choice_masks = groups_now ? c->choice_masks : nullptr;
@@ -999,10 +946,10 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 if (!try_lean || hint == mpr_context::HINT_UNKNOWN) a.measure_len = std::max(ng / 32, std::min(ng, 4));
                 else a.measure_len = ng >= 32 * std::max(c->cus, 1) ? ng / 128 : 0;
                 if (c->measure_len_forced >= 0) a.measure_len = c->measure_len_forced;
-                if ((a.measure_len == 0 && groups_now) || pipe_now) a.len_stats = nullptr;      /* (a pipelined frame has nobody to read the sample in time) */
+                if (a.measure_len == 0 && groups_now) a.len_stats = nullptr;
             }
             a.compiled_walk = !c->tiles_asm;
-            a.vgpr_slots = pipe_now ? (c->tiles_vgpr && c->pipe_vs) : c->tiles_vgpr;
+            a.vgpr_slots = c->tiles_vgpr;
             a.z = z;
             fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
             a.counters = cnt;
@@ -1037,60 +984,14 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 }
                 mprk::launch_eval_tiles_wide(s, dim, w, c->wide_threads);
             } else {
-                mprk::launch_eval_tiles(s, dim, a);
+                const bool ran_gen = mprk::launch_eval_tiles(s, dim, a);
+                if (a.gen_fwd && !ran_gen)          /* the records this frame counts on would not exist */
+                    return mpr::set_error(MPR_ERR_INVALID, "internal: a tile stage planned on generated code ran another kernel");
             }
         }
         if (c->stage0_only) {
             HIP_TRY(hipStreamSynchronize(s));
             return MPR_OK;
-        }
-        if (pipe_now) {
-            /* behind the stage on its stream: the flag that says the queue is complete, then the rest of the float pass's
-             * workgroups (the chip has room for them once the stage's wavefronts are gone); beside it on the second stream: the
-             * float pass itself */
-            mprk::launch_pipe_done(s, c->pipe_ctl);
-            mprk::VoxelArgs v;
-            v.tape_ro = c->pool;
-            v.image = c->filled[3];
-            v.tps = S / 4;
-            v.tiles = c->tiles[i];
-            v.count = count;
-            v.nslots = nslots;
-            v.z = z;
-            fill_mat(v.mat, mat, 16);
-            v.counters = nullptr;
-            v.heat = nullptr;
-            v.vgpr_slots = c->tiles_vgpr;
-            const int g1 = std::min(pipe_plan.grid, c->pipe_wgs * c->cus), g2 = pipe_plan.grid - g1;
-            group_cap = std::max(stage_cap, 1);
-            {
-                TimedScope ts(c, "eval_voxels_f", c->stream2);
-                mprk::launch_eval_voxels_jit_pipe(c->stream2, v, c->jit_code, (uint32_t)pipe_plan.region, (int)pipe_plan.slot_dw, (int)pipe_plan.nslot, g1, 0,
-                                                  (int)tape->clauses.size(), c->groups, c->choice_masks, group_cap, c->pipe_slots, c->pipe_ctl,
-                                                  c->filled[2], pipe_plan.always_inv, c->pub_dev + 15);
-            }
-            if (g2 > 0) {
-                TimedScope ts(c, "eval_voxels_f_behind");
-                mprk::launch_eval_voxels_jit_pipe(s, v, c->jit_code, (uint32_t)pipe_plan.region, (int)pipe_plan.slot_dw, (int)pipe_plan.nslot, g2, g1,
-                                                  (int)tape->clauses.size(), c->groups, c->choice_masks, group_cap, c->pipe_slots, c->pipe_ctl,
-                                                  c->filled[2], pipe_plan.always_inv, c->pub_dev + 15);
-            }
-            HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-            {
-                TimedScope ts(c, "copy_filled");
-                mprk::launch_merge_filled(s, c->filled[2], c->filled[3], S);
-            }
-            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit_groups<3, %d, true>", mprk::jit_slot_class(nslots));
-            group_form = true;
-            group_stage = i;
-            group_count = count;
-            lean_now = true;
-            piped = true;
-            c->last.tiles_active[si] = -1;            /* nobody counted: a reader gets the frame again the reference's way */
-            count = 0;
-            c->tiles_n[next] = 0;
-            break;
         }
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
@@ -1180,7 +1081,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->tiles_n[next] = (size_t)count;
         prev_wide = wide_now && c->wide_later != 0;
     }
-    c->last.voxel_tiles = piped ? -1 : count;
+    c->last.voxel_tiles = count;
     if (count > 0) {
         mprk::VoxelArgs v;
         v.tape_ro = c->pool;
@@ -1225,9 +1126,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             return again;
         }
         if (jitted) {
-            /* (as rocprofv3 prints it: the group form's kernel has a third template argument, `pipelined`) */
-            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d%s>", group_form && !brute ? "_groups" : "", dim,
-                     mprk::jit_slot_class(nslots), group_form && !brute ? ", false" : "");
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
+                     mprk::jit_slot_class(nslots));
         } else if (c->voxel_asm && !cnt && !heat) {
             mprk::launch_eval_voxels_asm(s, dim, v);
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_asm<%d>", dim);
@@ -1287,7 +1187,6 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     c->pending_dim = dim;
     c->last_frame_lean = lean_now;
     c->last_frame_fast = lean_now || skip0;
-    c->last_frame_piped = piped;
     c->last_key = key;
     if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != tape->serial)) c->last_tape.reset(new mpr_tape(*tape));
     if (blocking) return mpr_ctx_sync(c);
@@ -1319,11 +1218,6 @@ int mpr_ctx_sync(mpr_context* c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_pending = false;
-    if (c->pub_host[15] != 0) {
-        c->pub_host[15] = 0;
-        c->pipeline = false;
-        return mpr::set_error(MPR_ERR_NO_DEVICE, "pipelined frame: a float-pass workgroup waited 0.2 s for the last tile stage (pipelining is off from now on)");
-    }
     return MPR_OK;
 }
 

@@ -406,46 +406,17 @@ k_eval_tiles(TileStageArgs a)
         const int nrec = ci < a.choice_cap ? ci : a.choice_cap;
         ulonglong2* const dst = a.choice_masks + (size_t)blockIdx.x * a.choice_cap;
         const uint64_t would_push = ballot(ambiguous && ((any_choice >> lane) & 1));
-        if (!a.pipe_slots) {
-            for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
-            if (lane == 0) {
-                GroupInfo gi;
-                gi.tape = tape;
-                gi.nchoices = nrec;
-                gi.pushed = would_push;
-                gi.alive = 0;
-                gi.base_position = 0;
-                gi.reserved = 0;
-                a.groups[blockIdx.x] = gi;
-            }
-        } else {
-            /* pipelined frame: a workgroup of the float pass — on another XCD as likely as not, behind another L2 — reads this
-             * record as soon as the slot below says so.  Device-scope stores go through to memory; once they have been
-             * acknowledged (vmcnt) the slot is published.  (No release fence: that is a write-back of the whole L2 here.) */
-            unsigned long long* const d64 = reinterpret_cast<unsigned long long*>(dst);
-            for (int i = lane; i < nrec; i += 64) {
-                __hip_atomic_store(d64 + 2 * i, choices[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(d64 + 2 * i + 1, choices[i].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const uint64_t amb = ballot(ambiguous);
-            /* child 0's position from any live tile: lane = x + 4 y + 16 z inside the parent (subdivide_active_tiles_3d) */
-            const int sps = a.tps;
-            const int my_base = node.position - ((lane & 3) + ((lane >> 2) & 3) * sps + (lane >> 4) * sps * sps);
-            const int base_position = __builtin_amdgcn_readlane(my_base, leader);
-            if (lane == 0) {
-                unsigned long long* const g64 = reinterpret_cast<unsigned long long*>(a.groups + blockIdx.x);
-                __hip_atomic_store(g64 + 0, (unsigned long long)(unsigned)tape | ((unsigned long long)(unsigned)nrec << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g64 + 1, would_push, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g64 + 2, amb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g64 + 3, (unsigned long long)(unsigned)base_position, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (amb != 0) {
-                __builtin_amdgcn_s_waitcnt(0);                      /* every store above has been acknowledged */
-                if (lane == 0) {
-                    const int r = __hip_atomic_fetch_add(a.pipe_ctl + PIPE_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(a.pipe_slots + r, (int)blockIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+        for (int i = lane; i < nrec; i += 64) dst[i] = choices[i];
+        if (lane == 0) {
+            GroupInfo gi;
+            gi.tape = tape;
+            gi.nchoices = nrec;
+            gi.pushed = would_push;
+            /* the record of the tile these 64 are the children of (TileStageArgs::gen_parent; the float pass on the root
+             * tape's generated code maps the group's decisions to the root tape's numbering with it) */
+            gi.parent = __builtin_amdgcn_readlane(node.next, leader);
+            gi.reserved = 0;
+            a.groups[blockIdx.x] = gi;
         }
     }
     /* a.no_push with a.len_stats: the groups of the sample still walk backward and write their tapes — into chunks nobody will
@@ -1007,24 +978,6 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
     }
 }
 
-/* pipelined frames: the float pass ran beside the last tile stage, before that stage's fills could be copied down
- * (copy_filled_3d, :664-692, writes 4 t + 3 and the voxel pass then raises it: the maximum of the two either way) */
-__global__ void k_merge_filled(const int* __restrict__ prev, int* __restrict__ image, int size)
-{
-    const int x = threadIdx.x + blockIdx.x * blockDim.x;
-    const int y = threadIdx.y + blockIdx.y * blockDim.y;
-    if (x < size && y < size) {
-        const int t = prev[x / 4 + (y / 4) * (size / 4)];
-        if (t) {
-            const int h = t * 4 + 3;
-            if (image[x + y * size] < h) image[x + y * size] = h;
-        }
-    }
-}
-__global__ void k_pipe_done(int* ctl)
-{
-    __hip_atomic_store(ctl + PIPE_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 /* copy_filled — reference :664-692 */
 template <int DIM>
@@ -1243,22 +1196,33 @@ int tile_stage_vgpr_class(int nslots, int choice_cap)
     if (nslots > TI_VS_SMALL_SLOTS && nslots <= TI_VS_MAX_SLOTS && waves_by_lds < 8) return TI_VS_MAX_SLOTS;
     return 0;
 }
-void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
+/* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers, and the assembly backward walk forms
+ * 32-bit byte offsets into the pool (compiled_walk: MPR_TILES_ASM=0) */
+static bool tile_stage_uses_asm(int nslots, long long pool_cap, bool compiled_walk, int debug)
+{
+    return !compiled_walk && nslots <= 128 && !(debug & 2) && pool_cap < (1ll << 29);
+}
+/* The ONE test for "this launch can run the root tape's generated code" (given gen_fwd): the frame driver decides with it which
+ * stages keep records, the launcher which kernel runs — a stage that the driver believes wrote records and that ran another
+ * kernel would hand uninitialised decisions to the stages below and to the normals pass. */
+bool tile_stage_gen_possible(int nslots, long long pool_cap, bool compiled_walk, bool vgpr_slots, int debug)
+{
+    return tile_stage_uses_asm(nslots, pool_cap, compiled_walk, debug) && vgpr_slots && nslots <= TI_VS_SMALL_SLOTS;
+}
+bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
 {
     opt_in_once();
     const int groups = (a.count + 63) / 64;
     const size_t lds = tile_stage_lds_bytes(a.nslots, a.choice_cap);
-    /* the assembly forward walk addresses slots through a byte of pre-doubled slot numbers */
-    /* ... and the assembly backward walk forms 32-bit byte offsets into the pool (a.compiled_walk: MPR_TILES_ASM=0) */
-    const bool use_asm = !a.compiled_walk && a.nslots <= 128 && !(a.debug & 2) && a.pool_cap < (1ll << 29);
+    const bool use_asm = tile_stage_uses_asm(a.nslots, a.pool_cap, a.compiled_walk, a.debug);
     const int vs = (use_asm && a.vgpr_slots && !(a.debug & 4)) ? tile_stage_vgpr_class(a.nslots, a.choice_cap) : 0;
     const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
-    if (a.gen_fwd && use_asm && a.vgpr_slots && a.nslots <= TI_VS_SMALL_SLOTS && !a.pipe_slots &&
+    if (a.gen_fwd && tile_stage_gen_possible(a.nslots, a.pool_cap, a.compiled_walk, a.vgpr_slots, a.debug) &&
         (a.gen_bwd_full ? true : a.gen_parent ? a.no_push : !a.groups)) {
         const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
         if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
-        return;
+        return true;
     }
     if (dim == 3) {
         if (vs == TI_VS_SMALL_SLOTS) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS>), dim3(groups), dim3(64), lds_vs, s, a);
@@ -1271,6 +1235,7 @@ void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
         else if (use_asm) hipLaunchKernelGGL((k_eval_tiles<2, true>), dim3(groups), dim3(64), lds, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, false>), dim3(groups), dim3(64), lds, s, a);
     }
+    return false;
 }
 __global__ void k_copy_code(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n)
 {
@@ -1374,12 +1339,6 @@ void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int
     if (dim == 3) hipLaunchKernelGGL(k_copy_filled<3>, g, b, 0, s, prev, image, size);
     else hipLaunchKernelGGL(k_copy_filled<2>, g, b, 0, s, prev, image, size);
 }
-void launch_merge_filled(hipStream_t s, const int* prev, int* image, int size)
-{
-    const dim3 b(32, 8), g((size + 31) / 32, (size + 7) / 8);
-    hipLaunchKernelGGL(k_merge_filled, g, b, 0, s, prev, image, size);
-}
-void launch_pipe_done(hipStream_t s, int* pipe_ctl) { hipLaunchKernelGGL(k_pipe_done, dim3(1), dim3(1), 0, s, pipe_ctl); }
 void launch_pack(hipStream_t s, const int* heights, const uint32_t* normals, int S, const int* col_list,
                  int ncols, int capacity, int with_normals, int* out)
 {

@@ -29,19 +29,10 @@ struct GroupInfo {
     int nchoices;
     unsigned long long pushed;     /* the tiles whose own tape is this one shortened by their decisions (ambiguous tiles that
                                       chose a side somewhere): the others' own tape IS this one */
-    unsigned long long alive;      /* pipelined frames: the tiles still ambiguous when their wavefront finished (the float pass's
-                                      children, before any later fill hides them) ... */
-    int base_position;             /* ... and the position of the group's child 0 (child c: + its x, y, z offsets) */
+    int parent;                    /* index, in its stage's list, of the tile these 64 are the children of (its record:
+                                      TileStageArgs::gen_parent) */
     int reserved;
 };
-
-/* Pipelined tail of a 3-D frame (context.hip: pipe): the last tile stage and the float pass run at the same time, on two
- * streams, as producer and consumer of a queue of groups.  A wavefront of the last stage that leaves ambiguous tiles writes
- * its group's record and masks with device-scope stores, waits for them, takes the next slot (an atomic on ctl[PIPE_TAIL])
- * and stores group + 1 there; a workgroup of the float pass takes the next slot number (ctl[PIPE_HEAD]) and waits for it to
- * fill.  ctl[PIPE_DONE] is set by a kernel behind the stage on its stream: from then on ctl[PIPE_TAIL] is final.  Counters
- * sit 128 bytes apart. */
-enum { PIPE_TAIL = 0, PIPE_HEAD = 32, PIPE_DONE = 64, PIPE_ERROR = 96, PIPE_CTL_WORDS = 128 };
 
 /* a tile's record of what it decided (csrc/tile_gen.hpp: TILE_GEN_RECORD_U64, TILE_GEN_PRESENCE_WORDS), 64-bit words */
 constexpr int GEN_RECORD_U64 = 16, GEN_PRESENCE_WORDS = 24;
@@ -73,8 +64,6 @@ struct TileStageArgs {
     bool compiled_walk;        /* development (MPR_TILES_ASM=0): the compiled forward / backward walks instead of the assembly ones */
     bool no_mask;              /* mpr_column_weights: no tile is culled by a fill (src/context.cu:299-305) — which tiles a stage leaves
                                 * ambiguous then depends on the tape and the view alone, not on the order its wavefronts finish in */
-    int* pipe_slots;           /* pipelined frames (see PIPE_*): the queue, one word per group, zero = not yet; else null */
-    int* pipe_ctl;
     int measure_at[2], measure_len;   /* the sample len_stats is taken over: groups [measure_at[k], measure_at[k] + measure_len) */
     int* len_stats;            /* last stage with `groups`: [0] += clauses of the tapes handed on, [1] += clauses of the tapes
                                 * walked x tiles handed on, over a sample of the groups (the float pass's form depends on it) */
@@ -165,7 +154,9 @@ void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int 
 void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngroups, int* list);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
-void launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
+/* returns whether the launch ran the root tape's generated code (a.gen_fwd given and tile_stage_gen_possible) */
+bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
+bool tile_stage_gen_possible(int nslots, long long pool_cap, bool compiled_walk, bool vgpr_slots, int debug);
 /* host-generated code (tile_gen.hpp) into executable memory: copied by a kernel, then every CU drops its instruction cache */
 void launch_install_code(hipStream_t s, uint32_t* exec_dst, const uint32_t* src, size_t dwords, int cus);
 bool wide_stage_fits(int nclauses);
@@ -193,14 +184,6 @@ int jit_grid(int dim, int nslots, int cus, bool group);
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
                             int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
                             const int* group_list, bool always_invalidate = false);
-/* pipelined frames: the consumer side.  region_first: index of this launch's first code region (two launches share the
- * queue: one beside the tile stage, one behind it); image2 / tps2: the last tile stage's filled image, whose fills have not
- * been copied down yet while the float pass runs */
-void launch_eval_voxels_jit_pipe(hipStream_t s, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
-                                 int region_first, int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap,
-                                 const int* pipe_slots, int* pipe_ctl, const int* image2, bool always_invalidate, int* host_error);
-void launch_pipe_done(hipStream_t s, int* pipe_ctl);
-void launch_merge_filled(hipStream_t s, const int* prev, int* image, int size);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

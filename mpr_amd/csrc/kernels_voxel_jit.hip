@@ -759,9 +759,8 @@ struct JitVoxel {
     int px, py, pz;
     bool skip;
     float vx, vy, vz;
-    /* returns false when every lane is hidden.  image2 (pipelined frames): the last tile stage's image, S / 4 a side — its
-     * fills (tile z at that level; the top voxel of a filled tile is 4 t + 3) have not been copied into a.image yet */
-    DEV bool setup(const VoxelArgs& a, int position, int lane, const int* image2 = nullptr)
+    /* returns false when every lane is hidden */
+    DEV bool setup(const VoxelArgs& a, int position, int lane)
     {
         constexpr int SUB = (DIM == 3) ? 4 : 8;
         const int S = a.tps * SUB;
@@ -776,10 +775,6 @@ struct JitVoxel {
              * read past this CU's vector L1: the heights other tiles of the column have written so far */
             const int pz_low = pos.z * 4 + (sub.z & 1);
             skip = __hip_atomic_load(&a.image[px + py * S], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= pz_low + 2;
-            if (image2) {
-                const int t = __hip_atomic_load(&image2[(px >> 2) + (py >> 2) * a.tps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                skip = skip || (t != 0 && t * 4 + 3 >= pz_low + 2);
-            }
             if (ballot(!skip) == 0) return false;
         }
         const float size_recip = 1.0f / (float)(unsigned)S;
@@ -827,12 +822,6 @@ struct JitVoxelArgs {
     const int* group_list;     /* group form: the groups with a surviving tile, in list order; [number of groups] = how many */
     int always_invalidate;     /* group form: s_icache_inv after every translation, not once per trip round the ring of code slots
                                 * (context.hip: slots closer than the validated 4 KB, a device other than gfx950, MPR_VOXEL_JIT=3) */
-    /* pipelined frames (kernels.hpp: PIPE_*): the groups come from a queue the last tile stage fills while this kernel runs */
-    const int* pipe_slots;
-    int* pipe_ctl;
-    const int* image2;         /* the last tile stage's filled image (see JitVoxel::setup) */
-    int region_first;          /* this launch's first code region */
-    int* host_error;           /* host-coherent word: set when a wait for the queue timed out */
 };
 
 /* ---- tile form: a wavefront per smallest tile, each with its own tape ------------------------------------------ */
@@ -883,7 +872,7 @@ k_eval_voxels_jit(JitVoxelArgs j)
 
 /* ---- group form: a workgroup per group of 64 sibling tiles, one translation, every surviving child runs it ---- */
 constexpr int JIT_GROUP_WAVES = 4;
-template <int DIM, int NS, bool PIPE = false>
+template <int DIM, int NS>
 /* registers: slots + 48; the bound keeps the compiler's own values from costing a wavefront of occupancy */
 __global__ void __launch_bounds__(64 * JIT_GROUP_WAVES, NS <= 24 ? 6 : NS <= 40 ? 5 : NS <= 96 ? 3 : 2)
 k_eval_voxels_jit_groups(JitVoxelArgs j)
@@ -901,7 +890,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
      * the ring.  Slots are 4 KB apart beyond the longest code: the sequential instruction prefetch that runs past
      * the end of one slot's code must not reach the next slot before that is written (256 bytes were not enough,
      * 1 KB was). */
-    uint32_t* const region = j.code + ((size_t)blockIdx.x + (PIPE ? (size_t)j.region_first : 0)) * j.region_dwords;
+    uint32_t* const region = j.code + (size_t)blockIdx.x * j.region_dwords;
     __shared__ int next_child_lds;
     __shared__ ulonglong2 more_masks[64];
     int* const next_child = &next_child_lds;
@@ -916,67 +905,24 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
      * workgroups come free: their cost varies with the number of surviving children — a fixed stride left a third of the
      * kernel's duration to a tail of long workgroups — and the order is what lets the groups behind a surface find it
      * already drawn (handing out four at a time cost bear 30 %) */
-    const int nlisted = PIPE ? 0 : j.group_list[ngroups];
+    const int nlisted = j.group_list[ngroups];
     for (;;) {
         int g, position = -1, gtape, nch;
         uint64_t alive;
-        if (PIPE) {
-            /* the next slot of the queue, and the wait for the last tile stage to fill it: either the slot shows a group, or the
-             * stage has finished (PIPE_DONE, set behind it on its stream) and the slot lies beyond everything it published */
-            if (threadIdx.x == 0) {
-                const int r = __hip_atomic_fetch_add(j.pipe_ctl + PIPE_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int got = 0;
-                const unsigned long long t0 = wall_clock64();
-                for (;;) {
-                    got = __hip_atomic_load(j.pipe_slots + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (got != 0) break;
-                    if (__hip_atomic_load(j.pipe_ctl + PIPE_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-                        r >= __hip_atomic_load(j.pipe_ctl + PIPE_TAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        got = -1;
-                        break;
-                    }
-                    if (wall_clock64() - t0 > 20000000ull) {      /* 0.2 s of a 100 MHz clock: something is broken; never hang the device */
-                        __hip_atomic_store(j.pipe_ctl + PIPE_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (j.host_error) __hip_atomic_store(j.host_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        got = -1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                next_group = got;
-            }
-            __syncthreads();
-            const int got = next_group;
-            __syncthreads();
-            if (got < 0) break;
-            g = got - 1;
-            /* the group's record as the stage stored it (device scope on both sides: the two kernels share no cache) */
-            const unsigned long long* const g64 = reinterpret_cast<const unsigned long long*>(j.groups + g);
-            const unsigned long long w0 = __hip_atomic_load(g64 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            alive = __hip_atomic_load(g64 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long w3 = __hip_atomic_load(g64 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            alive = rfl64(alive);
-            gtape = __builtin_amdgcn_readfirstlane((int)(unsigned)w0);
-            nch = __builtin_amdgcn_readfirstlane((int)(unsigned)(w0 >> 32));
-            const int sps = a.tps;
-            position = (int)(unsigned)w3 + ((lane & 3) + ((lane >> 2) & 3) * sps + (lane >> 4) * sps * sps);
-            if (alive == 0) continue;
-        } else {
-            if (threadIdx.x == 0) next_group = atomicAdd(j.group_counter, 1);
-            __syncthreads();
-            const int r = next_group;
-            __syncthreads();
-            if (r >= nlisted) break;
-            g = j.group_list[r];
-            /* the 64 siblings as the last compaction left them: position -1 = empty, filled or hidden */
-            const int idx = g * 64 + lane;
-            if (idx < a.count) position = a.tiles[idx].position;
-            alive = ballot(position != -1);
-            if (alive == 0) continue;                         /* the same for every wavefront of the workgroup */
-            const GroupInfo gi = j.groups[g];
-            gtape = __builtin_amdgcn_readfirstlane(gi.tape);
-            nch = __builtin_amdgcn_readfirstlane(gi.nchoices);
-        }
+        if (threadIdx.x == 0) next_group = atomicAdd(j.group_counter, 1);
+        __syncthreads();
+        const int r = next_group;
+        __syncthreads();
+        if (r >= nlisted) break;
+        g = j.group_list[r];
+        /* the 64 siblings as the last compaction left them: position -1 = empty, filled or hidden */
+        const int idx = g * 64 + lane;
+        if (idx < a.count) position = a.tiles[idx].position;
+        alive = ballot(position != -1);
+        if (alive == 0) continue;                         /* the same for every wavefront of the workgroup */
+        const GroupInfo gi = j.groups[g];
+        gtape = __builtin_amdgcn_readfirstlane(gi.tape);
+        nch = __builtin_amdgcn_readfirstlane(gi.nchoices);
         if (!first_group) slot = slot + 1 == j.slots ? 0 : slot + 1;
         first_group = false;
         uint32_t* const code = region + (size_t)slot * j.slot_dwords;
@@ -989,13 +935,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
         }
         /* lane i: the decisions of the group's 64 tiles at its i-th min / max */
         ulonglong2 m = make_ulonglong2(0ull, 0ull);
-        auto load_mask = [&](int i) {
-            const ulonglong2* const p = j.choice_masks + (size_t)g * j.choice_cap + i;
-            if (!PIPE) return *p;
-            const unsigned long long* const q = reinterpret_cast<const unsigned long long*>(p);
-            return make_ulonglong2(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                   __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        };
+        auto load_mask = [&](int i) { return j.choice_masks[(size_t)g * j.choice_cap + i]; };
         if (lane < nch) m = load_mask(lane);
         if (nch > 64 && threadIdx.x < 64) {
             /* decisions 64..127 wait in LDS (registers held across the children's loop would cost a wave of occupancy) */
@@ -1017,7 +957,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
             const int c = 63 - __builtin_clzll(rest);
             const int cpos = (int)rdlane((uint32_t)position, (uint32_t)c);
             JitVoxel<DIM> vox;
-            if (!vox.setup(a, cpos, lane, PIPE ? j.image2 : nullptr)) continue;
+            if (!vox.setup(a, cpos, lane)) continue;
             uint32_t decisions = (uint32_t)((m.x >> c) & 1ull) | ((uint32_t)((m.y >> c) & 1ull) << 1);
             if (nch > 64) {
                 const ulonglong2 m1 = more_masks[lane];
@@ -1045,36 +985,6 @@ k_test_float_jit(const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, 
     const float r = jit_run<24>(my, 1u, i < n ? a[i] : 0.0f, (i < n && b) ? b[i] : 0.0f, 0.0f);
     if (i < n) out[i] = r;
 }
-void launch_eval_voxels_jit_pipe(hipStream_t s, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
-                                 int region_first, int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap,
-                                 const int* pipe_slots, int* pipe_ctl, const int* image2, bool always_invalidate, int* host_error)
-{
-    if (grid <= 0) return;
-    JitVoxelArgs j;
-    j.v = a;
-    j.code = code;
-    j.region_dwords = region_dwords;
-    j.slot_dwords = (uint32_t)slot_dwords;
-    j.slots = (uint32_t)slots;
-    j.tape_len = tape_len;
-    j.groups = groups;
-    j.choice_masks = choice_masks;
-    j.choice_cap = choice_cap;
-    j.group_counter = nullptr;
-    j.group_list = nullptr;
-    j.always_invalidate = always_invalidate ? 1 : 0;
-    j.pipe_slots = pipe_slots;
-    j.pipe_ctl = pipe_ctl;
-    j.image2 = image2;
-    j.region_first = region_first;
-    j.host_error = host_error;
-    const int ns = jit_slot_class(a.nslots);
-    const dim3 g(grid), b(64 * JIT_GROUP_WAVES);
-#define JIT_LAUNCH(N) hipLaunchKernelGGL((k_eval_voxels_jit_groups<3, N, true>), g, b, 0, s, j)
-    if (ns == 24) JIT_LAUNCH(24); else if (ns == 40) JIT_LAUNCH(40); else if (ns == 96) JIT_LAUNCH(96); else JIT_LAUNCH(192);
-#undef JIT_LAUNCH
-}
-
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out)
 {
@@ -1124,11 +1034,6 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
     j.group_counter = group_counter;
     j.group_list = group_list;
     j.always_invalidate = always_invalidate ? 1 : 0;
-    j.pipe_slots = nullptr;
-    j.pipe_ctl = nullptr;
-    j.image2 = nullptr;
-    j.region_first = 0;
-    j.host_error = nullptr;
     const int ns = jit_slot_class(a.nslots);
     if (groups) {
         const dim3 g(std::min(grid, (a.count + 63) / 64)), b(64 * JIT_GROUP_WAVES);

@@ -74,3 +74,40 @@ def check_default_path(mpr, ref, tape, dim, S, mat, z=0.0, frames=3):
             assert bad == 0, "normals of the default path differ at %d pixels (%s)" % (bad, kinds[-1])
     ctx.close()
     return kinds
+
+
+def compare_reader_frame(mpr, orc, tape, S, mat, ref=None, frames=1):
+    """What a reader of `stages[k].tiles` / `tape_data` gets from a context WITHOUT work counters — compare_frame's contexts carry
+    MPR_CTX_COUNTERS, which keeps every tile stage on the instrumented walks; this is the path callers of mpr.hpp are on (for
+    tapes the host generates code for: every stage on that code, tapes pushed by TileGen::bwd_full).  `frames` 3-D frames are
+    rendered first; reading then returns the reference's state (a frame that took a shortcut is rendered again the reference's
+    way).  Checked against the oracle, stage by stage: stage images, survivor sets, and the clause sequence of the shortened
+    tape every surviving tile carries; heights and normals.  Returns (ctx, ref); the caller closes ctx."""
+    if ref is None:
+        ref = orc.Frame(tape.data, 3, S, mpr.colmajor(mat, 4), threads=0)
+    ctx = mpr.Context(S)
+    for _ in range(frames):
+        ctx.render3D(tape, mat)
+        assert np.array_equal(ctx.image, ref.filled[3]), "heights differ (%d cells)" % int((ctx.image != ref.filled[3]).sum())
+        assert np.array_equal(ctx.normals, ref.normals), "normals differ at %d pixels" % int((ctx.normals != ref.normals).sum())
+    pool = ctx.tape_data                     # a reader: from here on the context holds the reference's state
+    assert ctx.last_stage_pushed()
+    for s in (0, 1, 2, 3):
+        assert np.array_equal(ctx.stages[s].filled, ref.filled[s]), "filled image of stage %d differs" % s
+    assert np.array_equal(ctx.normals, ref.normals)
+    for s in (0, 1, 2):
+        gt, rt = ctx.stages[s].tiles, ref.tiles[s]
+        assert gt.size == rt.size, "stage %d evaluates %d tiles, oracle %d" % (s, gt.size, rt.size)
+        if s < 2:
+            assert np.array_equal(active_positions(gt), active_positions(rt)), "tiles stage %d subdivides differ" % s
+        g_next, r_next = ctx.stages[s + 1].tiles, ref.tiles[s + 1]
+        assert g_next.size == r_next.size, "stage %d hands %d tiles on, oracle %d" % (s, g_next.size, r_next.size)
+        g_live, r_live = g_next[g_next["position"] != -1], r_next[r_next["position"] != -1]
+        go, ro = np.argsort(g_live["position"]), np.argsort(r_live["position"])
+        assert np.array_equal(g_live["position"][go], r_live["position"][ro]), "survivor sets differ after stage %d" % s
+        if g_live.size:
+            glen, ghash = orc.tiles_digest(pool, g_live[go])
+            rlen, rhash = orc.tiles_digest(ref.pool, r_live[ro])
+            assert np.array_equal(glen, rlen), "shortened tape lengths differ after stage %d (%d tiles)" % (s, int((glen != rlen).sum()))
+            assert np.array_equal(ghash, rhash), "shortened tape contents differ after stage %d (%d tiles)" % (s, int((ghash != rhash).sum()))
+    return ctx, ref
