@@ -307,6 +307,15 @@ int mpr_test_jit_row(int32_t table, int32_t row, uint32_t clause_lo, uint32_t im
  * (csrc/tile_gen.hpp): which = 0 forward, 1 backward.  Returns the number of dwords (copied to `out` when they fit `cap`),
  * -1 for a tape the generator does not take (a slot beyond 23, more than 64 min / max clauses, a jump, an unknown opcode) */
 int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap);
+/* the float walk of a tape as the machine code the float pass runs for tapes the host generates code for
+ * (csrc/voxel_gen.hpp): min_run = shortest run of dead clauses that gets a guard (0: none).  Returns the number of dwords
+ * (copied to `out` when they fit `cap`), -1 for a tape the generator does not take; info[0..2] = min / max clauses, guarded
+ * runs, out-of-line stubs */
+int mpr_test_voxel_gen(const uint64_t* clauses, int32_t len, int32_t min_run, uint32_t* out, int32_t cap, int32_t* info);
+/* one clause through that code on the device: variant 0 out = a fresh slot, 1 / 2 the result overwrites its lhs / rhs operand;
+ * dl / dr bit 0: the tile decided this (min / max) clause for the lhs / rhs */
+int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t dl, uint64_t dr, int32_t n, const float* a,
+                          const float* b, float imm, float* out);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,9 @@ def lib():
     L.mpr_test_jit_row.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_uint32, i32, vp, i32]
     L.mpr_test_tile_gen.argtypes = [vp, i32, i32, vp, i32]
     L.mpr_test_tile_gen.restype = ctypes.c_int
+    L.mpr_test_voxel_gen.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.mpr_test_voxel_gen.restype = ctypes.c_int
+    L.mpr_test_float_op_gen.argtypes = [i32, i32, i32, ctypes.c_uint64, ctypes.c_uint64, i32, vp, vp, f32, vp]
     _LIB = L
     return L
 
@@ -703,6 +706,16 @@ def dev_float_op(op, a, b=None, imm=0.0, device=0, asm=False, variant=0):
         _check(lib().mpr_test_float_op_asm(device, op, variant, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
     else:
         _check(lib().mpr_test_float_op(device, op, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
+    return out
+
+
+def dev_float_op_gen(op, a, b=None, imm=0.0, device=0, variant=0, dl=0, dr=0):
+    """One float clause through the host-generated float walk (csrc/voxel_gen.cpp) on the device; variant 1 / 2: the result
+    overwrites its lhs / rhs operand; dl / dr: the tile's decisions (bit 0 = this clause)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    _check(lib().mpr_test_float_op_gen(device, op, variant, dl, dr, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
     return out
 
 

@@ -24,6 +24,7 @@
 #include "internal.hpp"
 #include "kernels.hpp"
 #include "tile_gen.hpp"
+#include "voxel_gen.hpp"
 static_assert(mpr::TILE_GEN_RECORD_U64 == mprk::GEN_RECORD_U64 && mpr::TILE_GEN_PRESENCE_WORDS == mprk::GEN_PRESENCE_WORDS, "one record layout");
 
 namespace {
@@ -152,6 +153,10 @@ struct mpr_context {
     unsigned long long* gen_dec[3] = {nullptr, nullptr, nullptr};   /* the tiles' records, per stage (TileStageArgs::gen_decisions) */
     size_t gen_dec_cap[3] = {0, 0, 0};
     int gen_full_dw = 0;               /* dwords of the backward code for tapes that are shortened again (0: the tape is too long for it) */
+    int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
+    bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
+    int voxel_gen_min_run = 5;         /* MPR_VOXEL_GEN_RUN (development): shortest run of dead clauses that gets a guard (0: none) */
+    int vox_grid_cache[2] = {0, 0};
     bool tile_gen_chain = true;        /* MPR_TILE_GEN_CHAIN=0: only a frame's first stage (and, in frames that start at the 16^3 tiles, the last) */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
@@ -371,6 +376,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_CHAIN")) c->tile_gen_chain = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
@@ -537,7 +544,9 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         c->gen_ok = false;
         if (c->tile_gen && c->tiles_asm && c->tiles_vgpr && tape->num_slots <= mpr::TILE_GEN_MAX_SLOTS) {
             const mpr::TileGen g = mpr::tile_gen_build(tape->clauses.data(), len);
-            const size_t ndw = g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size();
+            mpr::VoxelGen vg;
+            if (c->voxel_gen && g.ok) vg = mpr::voxel_gen_build(tape->clauses.data(), len, c->voxel_gen_min_run);
+            const size_t ndw = g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + (vg.ok ? vg.code.size() : 0);
             if (g.ok && ndw > 0) {
                 if (ndw > c->gen_cap_dw) {
                     free_executable(c->gen_code);
@@ -554,6 +563,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     both.insert(both.end(), g.bwd.begin(), g.bwd.end());
                     both.insert(both.end(), g.deriv.begin(), g.deriv.end());
                     both.insert(both.end(), g.bwd_full.begin(), g.bwd_full.end());
+                    if (vg.ok) both.insert(both.end(), vg.code.begin(), vg.code.end());
                     HIP_TRY(hipMemcpyAsync(c->gen_stage, both.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                     mprk::launch_install_code(c->stream, c->gen_code, c->gen_stage, ndw, std::max(c->cus, 1));
                     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -562,6 +572,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     c->gen_bwd_dw = (int)g.bwd.size();
                     c->gen_deriv_dw = (int)g.deriv.size();
                     c->gen_full_dw = (int)g.bwd_full.size();
+                    c->gen_vox_dw = vg.ok ? (int)vg.code.size() : 0;
                     c->gen_words = g.words;
                     c->gen_nchoices = g.nchoices;
                 }
@@ -1097,8 +1108,21 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         v.vgpr_slots = c->tiles_vgpr;
         TimedScope ts(c, "eval_voxels_f");
         /* the assembly interpreter keeps no work counters: instrumented and heatmap frames use the C++ one */
-        bool jitted = false;
-        if (!cnt && !heat) {
+        bool jitted = false, on_root_code = false;
+        /* The root tape's host-generated float walk (voxel_gen.hpp), the tiles' decisions as bits: frames whose tile stages kept their
+         * tiles' records down to the stage above the last one, whose last stage recorded its groups' masks */
+        if (!cnt && !heat && !brute && group_form && dim == 3 && group_stage == 2 && decisions_recorded && c->voxel_gen && c->gen_ok && c->gen_vox_dw > 0 &&
+            c->cus > 0) {
+            mprk::VoxelArgs gv = v;
+            gv.tiles = c->tiles[group_stage];
+            gv.count = group_count;
+            int& grid = c->vox_grid_cache[dim - 2];
+            if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
+            mprk::launch_eval_voxels_gen(s, dim, gv, c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw + c->gen_full_dw, grid, c->groups,
+                                         c->choice_masks, group_cap, c->num_active + 7, c->group_list, c->gen_dec[1], c->gen_nchoices);
+            jitted = on_root_code = true;
+        }
+        if (!cnt && !heat && !jitted) {
             /* every tape as machine code */
             const bool gf = group_form && !brute;
             JitPlan jp;
@@ -1125,7 +1149,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             c->force_reference = false;
             return again;
         }
-        if (jitted) {
+        if (on_root_code) {
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_gen<%d>", dim);
+        } else if (jitted) {
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
                      mprk::jit_slot_class(nslots));
         } else if (c->voxel_asm && !cnt && !heat) {
@@ -1747,6 +1773,41 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
     mprk::launch_test_float_asm(nullptr, (const uint64_t*)dt.p, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+/* One clause through the host-generated float walk (voxel_gen.hpp; mpr_test_voxel_gen shows the code): a, b arrive in slots 1, 2.
+ * variant 0: out = slot 4; 1: a copy of a in slot 5 is the lhs AND the out slot (result written over its operand); 2: the same for
+ * the rhs.  dl / dr: the tile's decisions, bit 0 = this clause (a decided min / max is a copy of that operand). */
+int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t dl, uint64_t dr, int32_t n, const float* a, const float* b,
+                          float imm, float* out)
+{
+    if (n <= 0 || !a || !out || variant < 0 || variant > 2) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t immbits;
+    memcpy(&immbits, &imm, 4);
+    const uint32_t lhs = variant == 1 ? 5 : 1, rhs = b ? (variant == 2 ? 5 : 2) : 0, outs = variant == 0 ? 4 : 5;
+    const uint64_t tape[4] = {mpr_cl_make(0, 1, 2, 3, 0),
+                              variant == 2 ? mpr_cl_make(MPR_OP_COPY_RHS, 5, 0, 2, 0) : mpr_cl_make(MPR_OP_COPY_LHS, 5, 1, 0, 0),
+                              mpr_cl_make((uint32_t)op, outs, lhs, rhs, immbits), mpr_cl_make(0, outs, 0, 0, 0)};
+    const mpr::VoxelGen g = mpr::voxel_gen_build(tape, 4, 1);
+    if (!g.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "no generated code for this clause");
+    const size_t bytes = (size_t)n * 4, cbytes = (g.code.size() + 64) * sizeof(uint32_t);
+    DevBuf da, db, dout, dc;
+    HIP_TRY(da.alloc(bytes)); HIP_TRY(db.alloc(bytes)); HIP_TRY(dout.alloc(bytes)); HIP_TRY(dc.alloc(cbytes));
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc.p, g.code.data(), g.code.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    uint32_t* code = static_cast<uint32_t*>(alloc_executable(device, cbytes));
+    if (!code) return mpr::set_error(MPR_ERR_UNSUPPORTED, "no executable device memory");
+    int cus = 1;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    mprk::launch_install_code(nullptr, code, (const uint32_t*)dc.p, g.code.size(), std::max(cus, 1));
+    mprk::launch_test_float_gen(nullptr, code, n, (float*)da.p, b ? (float*)db.p : nullptr, (float*)dout.p, dl, dr);
+    const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+    free_executable(code);
+    HIP_TRY(e1);
+    HIP_TRY(e2);
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return MPR_OK;
 }

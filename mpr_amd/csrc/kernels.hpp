@@ -184,6 +184,14 @@ int jit_grid(int dim, int nslots, int cus, bool group);
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
                             int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
                             const int* group_list, bool always_invalidate = false);
+/* same pass on the ROOT tape's host-generated code (voxel_gen.hpp) with the tiles' recorded decisions; groups / masks / list as for the
+ * group form, parent_records: the records of the tiles of the stage above the last one */
+int voxel_gen_grid(int dim, int cus);
+void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const GroupInfo* groups,
+                            const ulonglong2* choice_masks, int choice_cap, int* group_counter, const int* group_list,
+                            const unsigned long long* parent_records, int nchoices);
+void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
+                           unsigned long long dr);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,
                            const float* b, float* out);
 size_t normals_lds_bytes(int nslots);

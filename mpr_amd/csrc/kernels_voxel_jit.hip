@@ -970,6 +970,176 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
     }
 }
 
+/* ---- the pass on the ROOT tape's host-generated code (voxel_gen.hpp) -------------------------------------------
+ * For tapes the host generates code for (at most 24 slots and 64 min / max clauses) in frames whose tile stages kept
+ * their tiles' decisions as bits over the root tape's min / max clauses (TileStageArgs::gen_decisions): a smallest
+ * tile's own tape is the root tape with the decisions of the 16^3 tile above it (its record) and its own (the group's
+ * masks, numbered by the clauses the parent's tape keeps) applied, so every tile runs the ONE piece of code there is
+ * per tape — nothing is translated on the device, no code ring, no instruction-cache invalidates, and dead clauses are
+ * jumped over by the code's own scalar branches on the decisions.  Work is handed out as in the group form (persistent
+ * workgroups take the groups that still have a tile in list order, their wavefronts the group's surviving children). */
+#define VG_ASM_TEXT                                                                                    \
+    "s_getpc_b64 s[50:51]\n"                                                                           \
+    "L_pc_%=:\n"                                                                                       \
+    JIT_ROUTINE_ADDR(52, 53, "L_div") JIT_ROUTINE_ADDR(54, 55, "L_sqrt") JIT_ROUTINE_ADDR(56, 57, "L_exp")  \
+    JIT_ROUTINE_ADDR(58, 59, "L_log") JIT_ROUTINE_ADDR(60, 61, "L_sin") JIT_ROUTINE_ADDR(62, 63, "L_cos")   \
+    JIT_LEAF_ADDR(64, 65, "mpr_fj_asin") JIT_LEAF_ADDR(66, 67, "mpr_fj_acos") JIT_LEAF_ADDR(68, 69, "mpr_fj_atan") \
+    "s_mov_b32 s90, 0x260\n"                            /* class mask of the square root's slow path */ \
+    "s_mov_b32 s80, 0x42ae0000\n"                       /* 87.0: exp without special cases (voxel_gen.hpp) */ \
+    "s_movk_i32 s81, 0x100\n"                           /* class mask: positive normal (log) */         \
+    "s_mov_b32 s76, %[dl0]\n s_mov_b32 s77, %[dl1]\n s_mov_b32 s78, %[dr0]\n s_mov_b32 s79, %[dr1]\n"   \
+    "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
+    "v_mov_b32 v7, 0x2ff\n"                             /* class mask of the inline constant division */ \
+    "v_mov_b32 v46, 0\n v_mov_b32 v47, 1.0\n"           /* L_sin / L_cos: (argument, cosine) seen last */ \
+    "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
+    "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0\n"  /* MODE.IEEE off while generated code runs (see jt::minmax) */ \
+    "s_swappc_b64 s[72:73], s[74:75]\n"                                                                \
+    "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 1\n"                                                 \
+    "v_mov_b32 %[res], v37\n"                                                                          \
+    "s_branch L_end_%=\n"                                                                              \
+    "L_div_%=:\n" MPR_ASM_DIV_BODY "s_setpc_b64 s[30:31]\n"                                            \
+    "L_sqrt_%=:\n" MPR_ASM_SQRT_BODY "s_setpc_b64 s[30:31]\n" MPR_ASM_SQRT_TAIL                        \
+    "L_exp_%=:\n" MPR_ASM_EXP_BODY "s_setpc_b64 s[30:31]\n" MPR_ASM_EXP_TAIL                           \
+    "L_log_%=:\n" MPR_ASM_LOG_BODY "s_setpc_b64 s[30:31]\n" MPR_ASM_LOG_TAIL                           \
+    "L_sin_%=:\n" MPR_ASM_SINCOS_BODY "v_mov_b32 v46, v35\n v_mov_b32 v47, v36\n s_setpc_b64 s[30:31]\n"     \
+    "L_cos_%=:\n"                                                                                      \
+    "v_cmp_ne_u32 vcc, v35, v46\n"                                                                      \
+    "s_cbranch_vccnz L_cosmiss_%=\n"                                                                    \
+    "v_mov_b32 v37, v47\n"                                                                              \
+    "s_setpc_b64 s[30:31]\n"                                                                            \
+    "L_cosmiss_%=:\n" MPR_ASM_SINCOS_BODY "v_mov_b32 v37, v36\n v_mov_b32 v46, v35\n v_mov_b32 v47, v36\n s_setpc_b64 s[30:31]\n" \
+    "L_end_%=:\n"
+
+/* dl / dr: the tile's decisions, bit k = min / max clause k of the root tape decided for the lhs / rhs (wave-uniform) */
+DEV float vox_gen_run(const uint32_t* code, float vx, float vy, float vz, uint64_t dl, uint64_t dr)
+{
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    const uint32_t dl0 = rdfirst((uint32_t)dl), dl1 = rdfirst((uint32_t)(dl >> 32)), dr0 = rdfirst((uint32_t)dr), dr1 = rdfirst((uint32_t)(dr >> 32));
+    float res;
+    asm volatile(VG_ASM_TEXT
+                 : [res] "=&v"(res)
+                 : [vx] "v"(vx), [vy] "v"(vy), [vz] "v"(vz), [clo] "s"(clo), [chi] "s"(chi), [dl0] "s"(dl0), [dl1] "s"(dl1), [dr0] "s"(dr0), [dr1] "s"(dr1)
+                 : JIT_CLOBBER_BASE, "s80", "s81");
+    return res;
+}
+
+struct GenVoxelArgs {
+    VoxelArgs v;                       /* tiles / count: the LAST tile stage's list, after its compaction */
+    const uint32_t* code;              /* the root tape's float walk (executable memory) */
+    const GroupInfo* groups;
+    const ulonglong2* choice_masks;
+    int choice_cap;
+    int* group_counter;
+    const int* group_list;
+    const unsigned long long* parent_records;   /* records of the tiles of the stage above (GEN_RECORD_U64 words each) */
+    int nchoices;                      /* min / max clauses of the root tape */
+};
+
+template <int DIM>
+__global__ void __launch_bounds__(64 * JIT_GROUP_WAVES, 6)
+k_eval_voxels_gen(GenVoxelArgs j)
+{
+    const VoxelArgs& a = j.v;
+    const int lane = threadIdx.x & 63;
+    __shared__ int next_child_lds, next_group;
+    int* const next_child = &next_child_lds;
+    const int ngroups = (a.count + 63) / 64;
+    const int nlisted = j.group_list[ngroups];
+    const unsigned long long all = j.nchoices >= 64 ? ~0ull : ((1ull << j.nchoices) - 1ull);
+    for (;;) {
+        if (threadIdx.x == 0) {
+            next_group = atomicAdd(j.group_counter, 1);
+            *next_child = 0;
+        }
+        __syncthreads();
+        const int r = next_group;
+        if (r >= nlisted) break;
+        const int g = j.group_list[r];
+        /* the 64 siblings as the last compaction left them: position -1 = empty, filled or hidden */
+        int position = -1;
+        const int idx = g * 64 + lane;
+        if (idx < a.count) position = a.tiles[idx].position;
+        const uint64_t alive = ballot(position != -1);
+        if (alive != 0) {                                   /* the same for every wavefront of the workgroup */
+            const GroupInfo gi = j.groups[g];
+            /* what the tile above decided (and everything above it), and the min / max clauses its tape keeps: the group's masks
+             * are numbered by those */
+            unsigned long long L = 0, R = 0, K = all;
+            if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
+                const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
+                L = rfl64(rec[0]);
+                R = rfl64(rec[1]);
+                K = rfl64(rec[2]);
+            }
+            /* lane k: root clause k is the i-th clause that tape keeps */
+            const bool kept = (K >> lane) & 1ull;
+            const int i = __popcll(K & ((1ull << lane) - 1ull));
+            ulonglong2 mk = make_ulonglong2(0ull, 0ull);
+            if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
+            /* front to back: children with the larger z first (lane = x + 4 y + 16 z) */
+            const int nalive = __popcll(alive);
+            for (;;) {
+                int k = 0;
+                if (lane == 0) k = atomicAdd(next_child, 1);
+                k = __builtin_amdgcn_readfirstlane(k);
+                if (k >= nalive) break;
+                uint64_t rest = alive;
+                for (int skip = 0; skip < k; ++skip) rest &= ~(1ull << (63 - __builtin_clzll(rest)));
+                const int c = 63 - __builtin_clzll(rest);
+                const int cpos = (int)rdlane((uint32_t)position, (uint32_t)c);
+                JitVoxel<DIM> vox;
+                if (!vox.setup(a, cpos, lane)) continue;
+                const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
+                const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
+                vox.finish(a, res);
+            }
+        }
+        __syncthreads();                                    /* next_group / next_child are rewritten */
+    }
+}
+
+int voxel_gen_grid(int dim, int cus)
+{
+    int per_cu = 0;
+    const hipError_t e = dim == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen<3>, 64 * JIT_GROUP_WAVES, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen<2>, 64 * JIT_GROUP_WAVES, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = 1;
+    return per_cu * cus;
+}
+void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const GroupInfo* groups,
+                            const ulonglong2* choice_masks, int choice_cap, int* group_counter, const int* group_list,
+                            const unsigned long long* parent_records, int nchoices)
+{
+    if (a.count <= 0) return;
+    GenVoxelArgs j;
+    j.v = a;
+    j.code = code;
+    j.groups = groups;
+    j.choice_masks = choice_masks;
+    j.choice_cap = choice_cap;
+    j.group_counter = group_counter;
+    j.group_list = group_list;
+    j.parent_records = parent_records;
+    j.nchoices = nchoices;
+    const dim3 g(std::min(grid, (a.count + 63) / 64)), b(64 * JIT_GROUP_WAVES);
+    if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_gen<3>, g, b, 0, s, j);
+    else hipLaunchKernelGGL(k_eval_voxels_gen<2>, g, b, 0, s, j);
+}
+
+/* one tape through the host-generated code: a and b in the x and y slots, the tile's decisions wave-uniform */
+__global__ void __launch_bounds__(64)
+k_test_float_gen(const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl, unsigned long long dr)
+{
+    const int i = blockIdx.x * 64 + (int)threadIdx.x;
+    const float r = vox_gen_run(code, i < n ? a[i] : 0.0f, (i < n && b) ? b[i] : 0.0f, 0.0f, dl, dr);
+    if (i < n) out[i] = r;
+}
+void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
+                           unsigned long long dr)
+{
+    hipLaunchKernelGGL(k_test_float_gen, dim3((n + 63) / 64), dim3(64), 0, s, code, n, a, b, out, dl, dr);
+}
+
 /* one clause through the translator and the generated code: tape3 as for k_test_float_asm */
 __global__ void __launch_bounds__(64)
 k_test_float_jit(const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a, const float* b, float* out)

@@ -105,6 +105,66 @@ def test_float_ops_assembly_interpreter_bit_exact(mpr, orc, opname, kind, varian
         assert bad.size == 0, (opname, kind, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:5]])
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
+@pytest.mark.parametrize("opname", INTERVAL_OPS)
+def test_float_ops_host_generated_code_bit_exact(mpr, orc, opname, kind, variant):
+    """Every opcode through the float walk the HOST generates (csrc/voxel_gen.cpp: what the float pass runs for bear-class tapes):
+    same bits as the oracle on every class of bit pattern — the inline bodies' fast paths (unit: all 64 lanes ordinary) and their
+    stubs into the interpreters' full routines (special / bits / wide: some lane is not); variant 0: result in a fresh register,
+    1 / 2: over its lhs / rhs operand (the inline bodies read their operand to the end)."""
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32((opname + kind + "f").encode()))
+    a = gen_floats(rng, N, kind)
+    b = gen_floats(rng, N, kind)
+    for imm in (0.75, -1.25, 0.5, -4.0, 3.0e10, 0.0):    # ... a constant division in line / as a product / by the general routine
+        g = mpr.dev_float_op_gen(op, a, b, imm, variant=variant)
+        o = orc.float_op(op, a, b, imm)
+        bad = np.flatnonzero(~same_bits(g, o))
+        assert bad.size == 0, (opname, kind, imm, bad.size, [(a[i], b[i], g[i], o[i]) for i in bad[:5]])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("opname", ["MIN_LHS_IMM", "MIN_LHS_RHS", "MAX_LHS_IMM", "MAX_LHS_RHS"])
+def test_decided_min_max_in_host_generated_code(mpr, orc, opname, variant):
+    """A min / max clause the tile decided is a copy of the chosen operand, raw (COPY_LHS / COPY_RHS / COPY_IMM of the tile's own
+    tape, reference src/context.cu:415-447): NaNs and signed zeros go through untouched."""
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32(opname.encode()))
+    a = gen_floats(rng, N, "bits")
+    b = gen_floats(rng, N, "bits")
+    imm = -1.25
+    has_rhs = opname.endswith("RHS")
+    assert same_bits(mpr.dev_float_op_gen(op, a, b, imm, variant=variant, dl=1), a).all()
+    want = b if has_rhs else np.full_like(a, imm)
+    assert same_bits(mpr.dev_float_op_gen(op, a, b, imm, variant=variant, dr=1), want).all()
+    # a decision for ANOTHER clause (bit 1) changes nothing
+    assert same_bits(mpr.dev_float_op_gen(op, a, b, imm, variant=variant, dl=2, dr=2), orc.float_op(op, a, b, imm)).all()
+
+
+@pytest.mark.parametrize("imm", [0.9, 0.3, 11.0, 5.612245082855225, 30.55555534362793, 0.15, 1.5, 3.0, 7.0, 0.1, -0.7,
+                                 1.0000001, 0.99999994, 1.9999999, 2.0 ** -30 * 1.5, 2.0 ** 30 * 1.25, 1e-12, 1e12, 1.17549435e-38])
+def test_division_by_a_constant_in_host_generated_code(mpr, orc, imm):
+    """The same inline division as kernels_voxel_jit.hip's row 30, with RN(1 / c) computed on the host: the IEEE quotient for
+    every operand (test_division_by_a_constant_in_generated_code's operand classes)."""
+    op = mpr.OP["DIV_LHS_IMM"]
+    rng = np.random.default_rng(zlib.crc32(repr(imm).encode()))
+    n = 1 << 19
+    cases = [
+        (rng.standard_normal(n) * np.exp2(rng.uniform(-55, 55, n))).astype(np.float32),
+        (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.integers(-63, 63, n))).astype(np.float32),
+        (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.choice([-63.0, -62.0, 62.0, 63.0], n))).astype(np.float32),
+        gen_floats(rng, 1 << 16, "wide"), gen_floats(rng, 1 << 16, "special"), gen_floats(rng, 1 << 16, "bits"),
+        (np.exp2(rng.integers(-20, 20, n)) * (1 + rng.integers(-3, 4, n) * 2.0 ** -23)).astype(np.float32),
+    ]
+    for a in cases:
+        for variant in (0, 1):
+            g = mpr.dev_float_op_gen(op, a, a, imm, variant=variant)
+            o = orc.float_op(op, a, a, imm)
+            bad = np.flatnonzero(~same_bits(g, o))
+            assert bad.size == 0, (imm, variant, bad.size, [(a[i], g[i], o[i]) for i in bad[:5]])
+
+
 @pytest.mark.parametrize("kind", ["unit", "wide", "special"])
 @pytest.mark.parametrize("opname", INTERVAL_OPS)
 def test_deriv_ops_bit_exact(mpr, orc, opname, kind):

@@ -293,6 +293,7 @@ def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name
     hierarchical and brute force — the latter runs the whole root tape as one piece of generated code."""
     tape = tapes(name)
     monkeypatch.setenv("MPR_WIDE_LATER", "0")      # a level-parallel last stage keeps no decision masks: group form off
+    monkeypatch.setenv("MPR_VOXEL_GEN", "0")       # (tapes the HOST generates a float walk for would take that: see the next test but one)
     monkeypatch.setenv("MPR_VOXEL_GROUPS", groups)
     monkeypatch.setenv("MPR_VOXEL_JIT", "0")
     a = mpr.Context(S)
@@ -323,6 +324,32 @@ def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name
     b.close()
 
 
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("bear", 1024), ("trig", 128), ("trig", 256), ("two_spheres", 128), ("sphere", 128)])
+def test_float_pass_on_the_root_tapes_host_generated_code(mpr, orc, tapes, name, S, monkeypatch):
+    """Tapes of at most 24 slots and 64 min / max clauses, 3-D frames whose tile stages kept their tiles' decisions: the float pass
+    runs the ROOT tape's float walk as code generated on the host (csrc/voxel_gen.cpp, k_eval_voxels_gen) with the decisions of a
+    tile's 16^3 parent (its record) and its own (the group's masks) as bits — dead runs of clauses jumped over.  The oracle's
+    heights and normals, frame after frame; the same with no guards at all (MPR_VOXEL_GEN_RUN=0), with a guard in front of every
+    dead clause (=1), and as the device-translated group form gives them (MPR_VOXEL_GEN=0)."""
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    ctxs = [(mpr.Context(S), "k_eval_voxels_gen<3>")]
+    monkeypatch.setenv("MPR_VOXEL_GEN_RUN", "0")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen<3>"))
+    monkeypatch.setenv("MPR_VOXEL_GEN_RUN", "1")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen<3>"))
+    monkeypatch.delenv("MPR_VOXEL_GEN_RUN")
+    monkeypatch.setenv("MPR_VOXEL_GEN", "0")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_jit_groups<3, 24>"))
+    for ctx, kernel in ctxs:
+        for _ in range(3):
+            ctx.render3D(tape, view3())
+            assert ctx.float_kernel() == kernel, (ctx.float_kernel(), kernel)
+            assert np.array_equal(ctx.image, ref.filled[3]), (kernel, int((ctx.image != ref.filled[3]).sum()))
+            assert np.array_equal(ctx.normals, ref.normals)
+        ctx.close()
+
+
 @pytest.mark.parametrize("name,dim,S", [("bear", 3, 512), ("architecture", 3, 1024), ("hello_world", 2, 256)])
 def test_code_ring_against_an_invalidate_per_group(mpr, tapes, name, dim, S, monkeypatch):
     """The group form writes a group's code into the next slot of a ring and invalidates the instruction cache only when
@@ -331,6 +358,7 @@ def test_code_ring_against_an_invalidate_per_group(mpr, tapes, name, dim, S, mon
     (MPR_JIT_GAP) falls back to it by itself: all three give the same frame, repeatedly."""
     tape = tapes(name)
     monkeypatch.setenv("MPR_VOXEL_GROUPS", "2")
+    monkeypatch.setenv("MPR_VOXEL_GEN", "0")
     monkeypatch.setenv("MPR_WIDE_LATER", "0")      # a level-parallel last stage keeps no decision masks: group form off
     ring = mpr.Context(S)
     monkeypatch.setenv("MPR_VOXEL_JIT", "3")
@@ -401,7 +429,7 @@ def test_frames_without_last_stage_tapes(mpr, orc, tapes, name, S, monkeypatch):
         bad = np.flatnonzero(ctx.normals.ravel() != ref.normals.ravel())
         assert bad.size == 0, (bad.size, kinds, [(hex(ctx.normals.ravel()[i]), hex(ref.normals.ravel()[i])) for i in bad[:5]])
     if name == "bear":
-        assert kinds == [(False, "k_eval_voxels_jit_groups")] * 4, kinds           # no tapes from the very first frame
+        assert kinds == [(False, "k_eval_voxels_gen")] * 4, kinds                  # no tapes from the very first frame
     if name == "involute_gear_3d":
         assert all(k == (True, "k_eval_voxels_asm") for k in kinds), kinds         # per-tile tapes: measured by the first frame, known after
     # the reference's state on request: tiles and tapes as a frame rendered the reference's way leaves them
