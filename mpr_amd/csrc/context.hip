@@ -153,10 +153,12 @@ struct mpr_context {
     unsigned long long* gen_dec[3] = {nullptr, nullptr, nullptr};   /* the tiles' records, per stage (TileStageArgs::gen_decisions) */
     size_t gen_dec_cap[3] = {0, 0, 0};
     int gen_full_dw = 0;               /* dwords of the backward code for tapes that are shortened again (0: the tape is too long for it) */
+    std::shared_ptr<const mpr::TapeCode> resident_code;   /* what gen_code holds (kept alive: the upload is asynchronous) */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
     int voxel_gen_min_run = 5;         /* MPR_VOXEL_GEN_RUN (development): shortest run of dead clauses that gets a guard (0: none) */
     int vox_grid_cache[2] = {0, 0};
+    int voxel_gen_wgs = 0;             /* MPR_VOXEL_GEN_WGS (development): at most this many persistent workgroups per CU */
     bool tile_gen_chain = true;        /* MPR_TILE_GEN_CHAIN=0: only a frame's first stage (and, in frames that start at the 16^3 tiles, the last) */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
@@ -378,6 +380,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
+    if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
     if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_CHAIN")) c->tile_gen_chain = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
@@ -540,15 +543,17 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         HIP_TRY(hipStreamSynchronize(c->stream));   /* pageable source must stay valid */
         c->tape_serial = tape->serial;
         c->tape_len = len;
-        /* the tape's interval walks as machine code, for the stage whose tiles all walk this very tape */
+        /* the tape's walks as machine code (made with the tape: internal.hpp TapeCode; a development switch that asks for other
+         * code has it made here): copied into executable memory by a kernel on the frame's stream — the frame's launches queue
+         * behind it, nothing waits on the host; the context keeps the source alive */
         c->gen_ok = false;
         if (c->tile_gen && c->tiles_asm && c->tiles_vgpr && tape->num_slots <= mpr::TILE_GEN_MAX_SLOTS) {
-            const mpr::TileGen g = mpr::tile_gen_build(tape->clauses.data(), len);
-            mpr::VoxelGen vg;
-            if (c->voxel_gen && g.ok) vg = mpr::voxel_gen_build(tape->clauses.data(), len, c->voxel_gen_min_run);
-            const size_t ndw = g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + (vg.ok ? vg.code.size() : 0);
-            if (g.ok && ndw > 0) {
+            std::shared_ptr<const mpr::TapeCode> code = tape->code;
+            if (!code || code->vox_min_run != c->voxel_gen_min_run) code = mpr::build_tape_code(tape->clauses.data(), len, c->voxel_gen_min_run);
+            const size_t ndw = code ? code->words.size() : 0;
+            if (ndw > 0) {
                 if (ndw > c->gen_cap_dw) {
+                    HIP_TRY(hipStreamSynchronize(c->stream));
                     free_executable(c->gen_code);
                     if (c->gen_stage) (void)hipFree(c->gen_stage);
                     c->gen_code = nullptr;
@@ -559,22 +564,18 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     if (c->gen_code && hipMalloc((void**)&c->gen_stage, want * sizeof(uint32_t)) == hipSuccess) c->gen_cap_dw = want;
                 }
                 if (c->gen_cap_dw >= ndw) {
-                    std::vector<uint32_t> both(g.fwd);
-                    both.insert(both.end(), g.bwd.begin(), g.bwd.end());
-                    both.insert(both.end(), g.deriv.begin(), g.deriv.end());
-                    both.insert(both.end(), g.bwd_full.begin(), g.bwd_full.end());
-                    if (vg.ok) both.insert(both.end(), vg.code.begin(), vg.code.end());
-                    HIP_TRY(hipMemcpyAsync(c->gen_stage, both.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                    c->resident_code = code;
+                    HIP_TRY(hipMemcpyAsync(c->gen_stage, code->words.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                     mprk::launch_install_code(c->stream, c->gen_code, c->gen_stage, ndw, std::max(c->cus, 1));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    HIP_TRY(hipGetLastError());
                     c->gen_ok = true;
-                    c->gen_fwd_dw = (int)g.fwd.size();
-                    c->gen_bwd_dw = (int)g.bwd.size();
-                    c->gen_deriv_dw = (int)g.deriv.size();
-                    c->gen_full_dw = (int)g.bwd_full.size();
-                    c->gen_vox_dw = vg.ok ? (int)vg.code.size() : 0;
-                    c->gen_words = g.words;
-                    c->gen_nchoices = g.nchoices;
+                    c->gen_fwd_dw = code->fwd_dw;
+                    c->gen_bwd_dw = code->bwd_dw;
+                    c->gen_deriv_dw = code->deriv_dw;
+                    c->gen_full_dw = code->full_dw;
+                    c->gen_vox_dw = c->voxel_gen ? code->vox_dw : 0;
+                    c->gen_words = code->walk_words;
+                    c->gen_nchoices = code->nchoices;
                 }
             }
         }
@@ -1118,7 +1119,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             gv.count = group_count;
             int& grid = c->vox_grid_cache[dim - 2];
             if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
-            mprk::launch_eval_voxels_gen(s, dim, gv, c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw + c->gen_full_dw, grid, c->groups,
+            const int use_grid = c->voxel_gen_wgs > 0 ? std::min(grid, c->voxel_gen_wgs * c->cus) : grid;
+            mprk::launch_eval_voxels_gen(s, dim, gv, c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw + c->gen_full_dw, use_grid, c->groups,
                                          c->choice_masks, group_cap, c->num_active + 7, c->group_list, c->gen_dec[1], c->gen_nchoices);
             jitted = on_root_code = true;
         }

@@ -2,10 +2,26 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "tape_schedule.hpp"
+
+namespace mpr {
+/* A tape's walks as gfx950 machine code (tile_gen.hpp: interval forward / backward / Deriv / backward for tapes that are
+ * shortened again; voxel_gen.hpp: the float walk), generated once, on the host, when the tape is made — not in the first frame
+ * that renders it — and shared by every copy of the tape.  words = the five pieces back to back. */
+struct TapeCode {
+    std::vector<uint32_t> words;
+    int fwd_dw = 0, bwd_dw = 0, deriv_dw = 0, full_dw = 0, vox_dw = 0;
+    int walk_words = 0, nchoices = 0;
+    int vox_min_run = 0;             /* the shortest guarded run the float walk was generated with */
+};
+constexpr int TAPE_CODE_DEFAULT_MIN_RUN = 5;
+/* null: the generators do not take this tape (more than 24 slots or 64 min / max clauses, ...) */
+std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len, int vox_min_run);
+}  // namespace mpr
 
 struct mpr_tape {
     std::vector<uint64_t> clauses;   /* head, operations, end — host copy */
@@ -14,6 +30,7 @@ struct mpr_tape {
     int32_t flags = 0;
     uint64_t serial = 0;             /* identity, so a context can cache per-tape state */
     mpr::TapeSchedule schedule;      /* dependency levels for the wide first-stage kernel (ok == false: not usable) */
+    std::shared_ptr<const mpr::TapeCode> code;   /* its walks as machine code, or null */
 };
 
 namespace mpr {

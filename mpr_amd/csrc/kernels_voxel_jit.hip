@@ -990,6 +990,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
     "s_mov_b32 s76, %[dl0]\n s_mov_b32 s77, %[dl1]\n s_mov_b32 s78, %[dr0]\n s_mov_b32 s79, %[dr1]\n"   \
     "v_mov_b32 v32, %[vx]\n v_mov_b32 v33, %[vy]\n v_mov_b32 v34, %[vz]\n"                             \
     "v_mov_b32 v7, 0x2ff\n"                             /* class mask of the inline constant division */ \
+    "v_mov_b32 v5, 0x39506967\n v_mov_b32 v6, 0x3d9021bb\n"   /* leading coefficients of the exp / log polynomials (voxel_gen.hpp) */ \
     "v_mov_b32 v46, 0\n v_mov_b32 v47, 1.0\n"           /* L_sin / L_cos: (argument, cosine) seen last */ \
     "s_mov_b32 s74, %[clo]\n s_mov_b32 s75, %[chi]\n"                                                  \
     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0\n"  /* MODE.IEEE off while generated code runs (see jt::minmax) */ \

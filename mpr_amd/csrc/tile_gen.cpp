@@ -4,6 +4,8 @@
 
 #include "../../include/mpr_clause.h"
 #include "gfx950_emit.hpp"
+#include "internal.hpp"
+#include "voxel_gen.hpp"
 
 namespace mpr {
 namespace {
@@ -591,6 +593,31 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
     return g;
 }
 
+}  // namespace mpr
+
+namespace mpr {
+std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len, int vox_min_run)
+{
+    const TileGen g = tile_gen_build(clauses, len);
+    if (!g.ok || g.fwd.empty()) return nullptr;
+    const VoxelGen v = voxel_gen_build(clauses, len, vox_min_run);
+    auto c = std::make_shared<TapeCode>();
+    c->words.reserve(g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size());
+    c->words.insert(c->words.end(), g.fwd.begin(), g.fwd.end());
+    c->words.insert(c->words.end(), g.bwd.begin(), g.bwd.end());
+    c->words.insert(c->words.end(), g.deriv.begin(), g.deriv.end());
+    c->words.insert(c->words.end(), g.bwd_full.begin(), g.bwd_full.end());
+    if (v.ok) c->words.insert(c->words.end(), v.code.begin(), v.code.end());
+    c->fwd_dw = (int)g.fwd.size();
+    c->bwd_dw = (int)g.bwd.size();
+    c->deriv_dw = (int)g.deriv.size();
+    c->full_dw = (int)g.bwd_full.size();
+    c->vox_dw = v.ok ? (int)v.code.size() : 0;
+    c->walk_words = g.words;
+    c->nchoices = g.nchoices;
+    c->vox_min_run = vox_min_run;
+    return c;
+}
 }  // namespace mpr
 
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)

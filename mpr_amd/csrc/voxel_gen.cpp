@@ -135,8 +135,7 @@ struct Gen {
         vop2_lit(V_ADD_F32, 38, 0xcb400000u, 42);             /* kf */
         fmamk(39, 38, 0xbf318000u, A);
         fmamk(39, 38, 0x395e8083u, 39);                       /* r */
-        mov_k(c, 40, 0x3ab743ceu);
-        vop2_lit(V_FMAC, 40, 0x39506967u, 39);
+        fmaak(40, VG_K_EXP_C5, 39, 0x3ab743ceu);              /* (v_mov + v_fmac in the routine: the same fused operation) */
         fmaak(40, 40, 39, 0x3c088908u);
         fmaak(40, 40, 39, 0x3d2aa9c1u);
         fmaak(40, 40, 39, 0x3e2aaaaau);
@@ -166,8 +165,7 @@ struct Gen {
         vop2(V_CNDMASK, 41, V(41), 38);
         vop2(V_ADD_F32, 38, V(41), 38);                       /* m + m, or m + (-0) */
         vop2(V_ADD_F32, 38, K_MONE, 38);
-        mov_k(c, 40, 0xbdebd1b8u);
-        vop2_lit(V_FMAC, 40, 0x3d9021bbu, 38);
+        fmaak(40, VG_K_LOG_C8, 38, 0xbdebd1b8u);
         fmaak(40, 40, 38, 0x3def251au);
         fmaak(40, 40, 38, 0xbdfe5d4fu);
         fmaak(40, 40, 38, 0x3e11e9bfu);
@@ -223,6 +221,8 @@ struct Gen {
         call(c, routine);
         mov(c, O, V(0));
         mov_k(c, 7, 0x2ffu);                                  /* the compiled leaves may use v0..v7 */
+        mov_k(c, VG_K_EXP_C5, 0x39506967u);
+        mov_k(c, VG_K_LOG_C8, 0x3d9021bbu);
     }
     /* l / r: slot registers, r < 0: the immediate */
     void minmax(int op, int k, int A, int B, uint32_t K, int O)

@@ -24,7 +24,9 @@
  * Register conventions (the harness, kernels_voxel_gen.hip, and the routines are written against them)
  *   slot s                v[48 + s]                                   s <= 23
  *   inputs                v32, v33, v34 = x, y, z (copied into their slots by the code's first instructions)
- *   temporaries           v35 .. v47; v7 = 0x2ff (class mask of the inline constant division)
+ *   temporaries           v35 .. v47; v7 = 0x2ff (class mask of the inline constant division); v5 = 0x39506967, v6 = 0x3d9021bb
+ *                         (the leading coefficients of the exp / log polynomials: p = c v + c' is ONE v_fmaak with c in a register,
+ *                         where the routines, which may not keep registers between calls, spend a v_mov and a v_fmac)
  *   result                v37; the code returns through s[72:73]
  *   routines              argument v35 (, v36), result v37, return address s[30:31]; entry points in SGPR pairs (VoxelGenReg)
  *   decisions             s[76:77] / s[78:79]: bit k set = the tile decided min / max clause k of the root tape for the lhs / rhs
@@ -41,6 +43,7 @@ enum VoxelGenReg : int {
     VG_RT_DIV = 52, VG_RT_SQRT = 54, VG_RT_EXP = 56, VG_RT_LOG = 58, VG_RT_SIN = 60, VG_RT_COS = 62,
     VG_RT_ASIN = 64, VG_RT_ACOS = 66, VG_RT_ATAN = 68,
     VG_RET = 72, VG_DEC_L = 76, VG_DEC_R = 78, VG_K_87 = 80, VG_K_POSNORMAL = 81,
+    VG_K_EXP_C5 = 5, VG_K_LOG_C8 = 6,        /* VGPRs: the leading coefficients of the exp / log polynomials */
 };
 
 struct VoxelGen {

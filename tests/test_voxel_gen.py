@@ -146,6 +146,10 @@ def test_square_root_exp_log_in_line(mpr, o):
     main, stubs = split_main(code, o)
     body = [l for l in body_of("MPR_ASM_EXP_BODY") if not l.endswith(":")]
     assert body[-3].startswith("s_mov_b32 s91, 0x42ae0000") and body[-2].startswith("v_cmp_nle_f32 vcc, |v35|, s91") and body[-1].startswith("s_cbranch_vccnz")
+    # (the polynomial's first step, c r + c', is one v_fmaak with c waiting in v5 where the routine spends a v_mov and a v_fmac)
+    k = body.index("v_mov_b32 v40, 0x3ab743ce")
+    assert body[k + 1] == "v_fmac_f32 v40, 0x39506967, v39"
+    body[k:k + 2] = ["v_fmaak_f32 v40, v5, v39, 0x3ab743ce"]
     want = assemble(["v_cmp_nle_f32 vcc, |v49|, s80", "s_cbranch_vccnz 0"] + renamed(body[:-3], 49, o))
     assert main[:2] == want[:2] and main[3:] == want[3:], disassemble(main)
     assert (main[2] >> 16) == 0xBF87 and (main[2] & 0xFFFF) == len(main) + 2 - 3
@@ -158,6 +162,9 @@ def test_square_root_exp_log_in_line(mpr, o):
     body = body[body.index("L_logmain_%=:") + 1:]
     assert body[0] == "v_lshrrev_b32 v39, 23, v38" and body[1] == "v_add_u32 v39, v39, v40" and body[2] == "v_and_b32 v38, 0x7fffff, v38"
     assert body[-3].startswith("s_cmp_eq_u32 s91, 1") and body[-1] == "L_logdone_%=:"
+    k = body.index("v_mov_b32 v40, 0xbdebd1b8")
+    assert body[k + 1] == "v_fmac_f32 v40, 0x3d9021bb, v38"
+    body[k:k + 2] = ["v_fmaak_f32 v40, v6, v38, 0xbdebd1b8"]
     fast = ["v_lshrrev_b32 v39, 23, v49", "v_add_u32 v39, 0xffffff82, v39", "v_and_b32 v38, 0x7fffff, v49"] + renamed(body[3:-3], 49, o)
     want = assemble(["v_cmp_class_f32 vcc, v49, s81", "s_cmp_eq_u64 vcc, exec", "s_cbranch_scc0 0"] + fast)
     assert main[:3] == want[:3] and main[4:] == want[4:], disassemble(main)
@@ -193,7 +200,7 @@ def test_called_routines(mpr):
     for name, pair in (("ASIN_LHS", 64), ("ACOS_LHS", 66), ("ATAN_LHS", 68)):
         code, info = one(mpr, clause(OP[name], 4, 1))
         assert split_main(code, 52)[0] == assemble(["v_mov_b32 v0, v49", "s_swappc_b64 s[30:31], s[%d:%d]" % (pair, pair + 1), "v_mov_b32 v52, v0",
-                                                    "v_mov_b32 v7, 0x2ff"])
+                                                    "v_mov_b32 v7, 0x2ff", "v_mov_b32 v5, 0x39506967", "v_mov_b32 v6, 0x3d9021bb"])
 
 
 def test_min_max_with_the_tiles_decisions(mpr):
