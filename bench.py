@@ -129,6 +129,8 @@ def roofline_of(work, S, vox_ms, kname, avg, ms_per_step, world, model):
         out = {"kernel": name}
         out.update({k: hbm[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes")})
         out["limiter"] = "valu issue (no committed SQ counters for this kernel: profiles/pmc_summary.json)"
+        out["hbm_frac"] = hbm["frac"]
+        out["hbm_achieved_gbs"] = hbm["achieved"]
         out.update(common)
         return out
     valu = float(sq["SQ_INSTS_VALU"])
@@ -161,6 +163,8 @@ def roofline_of(work, S, vox_ms, kname, avg, ms_per_step, world, model):
                           "lds_frac": round(sq.get("SQ_INSTS_LDS", 0) / dur / (LDS_PER_NS * ISSUE_CUS * 1e9), 4),
                           "busy_cu_clock_ghz": round(sq.get("SQ_BUSY_CU_CYCLES", 0) / ISSUE_CUS / dur / 1e9, 3) if sq.get("SQ_BUSY_CU_CYCLES") else None}
     out["hbm"] = hbm
+    out["hbm_frac"] = hbm["frac"]              # north_star's figure, where the driver's parser keeps it
+    out["hbm_achieved_gbs"] = hbm["achieved"]
     out.update(common)
     return out
 
@@ -508,6 +512,32 @@ def main():
                         "ms_per_frame_std": round(ps, 4), "value": round(1024 * 1024 / (pm * 1e-3) / 1e6, 2),
                         "unit": "Mpixel/s", "vs_baseline": round(V100_PROSPERO_1024_MS / pm, 3),
                         "baseline": "3.85596 ms/frame on 1x V100 (reference README.md:111)"}]
+        # the other GPU configurations of BASELINE.json, so that every one of them has a driver-timed number
+        for model, dim, size in (("involute_gear_2d", 2, 4096), ("architecture", 3, 2048)):
+            otape = m.Tape(m.model(model))
+            octx = m.Context(size, device=local_rank)
+            fn = (lambda: octx.render3D(otape, T)) if dim == 3 else (lambda: octx.render2D(otape))
+            _, oper = time_frames(fn, min(args.warmup, 10), min(args.steps, 50), lambda: None, sync)
+            om, osd = stats(oper)
+            okern = octx.float_kernel()
+            octx.close()
+            out["also"].append({"workload": "%s.frep render%dD at %d^%d" % (model, dim, size, dim), "ms_per_frame_mean": round(om, 4),
+                                "ms_per_frame_std": round(osd, 4), "value": round(size * size / (om * 1e-3) / 1e6, 2), "unit": "Mpixel/s",
+                                "float_kernel": okern, "vs_baseline": None})
+        # what a reader of tiles / tapes pays on top of an ordinary frame (mpr_read_tiles after render3D: the tile stages again,
+        # the reference's way; heights and normals are left as they are)
+        rd = []
+        for _ in range(min(args.steps, 12)):
+            ctx.render3D(tape, T)
+            sync()
+            t1 = time.perf_counter()
+            n_tiles = ctx.stages[3].tile_array_size
+            rd.append((time.perf_counter() - t1) * 1e3)
+        rm, rs = stats(rd[2:] if len(rd) > 4 else rd)
+        out["reader"] = {"ms_read_tiles_after_a_frame_mean": round(rm, 4), "ms_std": round(rs, 4), "tiles": int(n_tiles),
+                         "frame_plus_read_over_full_frame": round((mean_ms + rm) / out["full_frames"]["ms_per_frame_mean"], 3),
+                         "note": "stages[3].tile_array_size right after an ordinary frame: the context runs the frame's tile stages again the "
+                                 "reference's way (every stage from the 64^3 tiles down, every tape pushed); no float pass, no normals pass"}
 
     # ---- CPU baseline: the oracle (a port of the algorithm, NOT libfive's renderer) at the bench configuration itself: all host
     #      cores on the whole frame (1 warm-up + 3 timed, the 750 ms rule of benchmark/render_3d_table.cpp:71 in spirit), one core on

@@ -100,6 +100,9 @@ struct mpr_context {
      * What a reader of tiles / tapes / counters needs to get the reference's state back: */
     bool reference_frames = false;     /* MPR_LAST_STAGE_PUSH=1: every frame the reference's way (all stages, all tapes) */
     bool force_reference = false;      /* set while a reader re-renders the frame the reference's way */
+    bool tiles_only = false;           /* ... and only its tile stages: heights and normals of the frame being read are complete and are
+                                          the reference's, so the re-render leaves them alone — no float pass, no normals pass, the last
+                                          stage's fills are not copied down again (they are part of the heightmap already) */
     bool stage0_only = false;          /* set by mpr_column_weights: the frame stops behind its first tile stage's evaluation */
     bool last_frame_fast = false;      /* the last frame took one of the shortcuts above ... */
     bool last_frame_lean = false;      /* ... this one: no tapes from its last tile stage */
@@ -786,8 +789,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     /* a reader's reference frame of a partitioned context keeps the columns other ranks sent (mpr_unpack_*): only this rank's
      * columns are cleared */
     const bool keep_foreign = c->force_reference && owner != nullptr;
-    if (keep_foreign) mprk::launch_zero_owned(s, c->arena, dim == 3, S, c->owner_dev, rank);
-    const size_t zero_now = keep_foreign ? 0 : zero_words;
+    const bool tiles_only = c->tiles_only && c->force_reference && !brute && !cnt && !heat;
+    if (keep_foreign) mprk::launch_zero_owned(s, c->arena, tiles_only ? 3 : dim == 3 ? 5 : 4, S, c->owner_dev, rank);
+    const size_t zero_now = keep_foreign ? 0 : tiles_only ? (size_t)(c->filled[3] - c->arena) : zero_words;
     if (!brute) {
         const int t0 = S / 64;
         count = t0 * t0 * (dim == 3 ? t0 : 1);
@@ -1016,12 +1020,13 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             if (zs) {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
-                                             c->zs_hist, c->zs_cursor, c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub),
+                                             c->zs_hist, c->zs_cursor, c->pub_dev, seq, (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub),
                                              c->num_active + 4, mark_groups ? c->group_alive : nullptr, c->tape_index);
             } else {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
-                                               c->pub_dev, seq, c->filled[next], S / (tile_size_px / sub), mark_groups ? c->group_alive : nullptr, c->tape_index);
+                                               c->pub_dev, seq, (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub),
+                                               mark_groups ? c->group_alive : nullptr, c->tape_index);
             }
             if (mark_groups) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
             return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
@@ -1029,7 +1034,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (count > 0) {
             rc = compact(groups_now);
             if (rc) return rc;
-        } else {
+        } else if (!(last && tiles_only)) {
             /* copy_filled rides in the compaction's launch; no compaction, a launch of its own */
             TimedScope ts(c, "copy_filled");
             mprk::launch_copy_filled(s, dim, c->filled[i], c->filled[next], S / (tile_size_px / sub));
@@ -1094,6 +1099,16 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         prev_wide = wide_now && c->wide_later != 0;
     }
     c->last.voxel_tiles = count;
+    if (tiles_only) {
+        /* a reader's re-render: tiles and tapes are the reference's now; heights and normals were all along */
+        HIP_TRY(hipGetLastError());
+        c->frame_pending = true;
+        c->pending_dim = dim;
+        c->last_frame_lean = false;
+        c->last_frame_fast = false;
+        c->last_key = key;
+        return blocking ? mpr_ctx_sync(c) : MPR_OK;
+    }
     if (count > 0) {
         mprk::VoxelArgs v;
         v.tape_ro = c->pool;
@@ -1231,8 +1246,10 @@ static int ensure_full_frame(mpr_context* c)
     if (!c->last_tape) return mpr::set_error(MPR_ERR_INVALID, "no tape to render the last frame's tapes from");
     const mpr_context::FrameKey k = c->last_key;
     c->force_reference = true;
+    c->tiles_only = true;
     const int rc = render_frame(c, c->last_tape.get(), k.dim, k.mat, k.z, k.parted ? c->owner_host.data() : nullptr, k.rank, false, true);
     c->force_reference = false;
+    c->tiles_only = false;
     return rc;
 }
 
@@ -1431,6 +1448,10 @@ int mpr_read_filled(mpr_context* c, int32_t stage, int32_t* host)
 {
     if (!c || !host || stage < 0 || stage > 3) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    /* the images of the tile stages are the reference's only after a frame that ran every stage (a frame that started at the 16^3
+     * tiles left stages[0].filled empty); the heightmap / 2-D image is the reference's after any frame */
+    if (stage < 3)
+        if (const int rc = ensure_full_frame(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(host, c->filled[stage], c->filled_n[stage] * sizeof(int), hipMemcpyDeviceToHost));
     return MPR_OK;

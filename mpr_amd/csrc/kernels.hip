@@ -87,12 +87,12 @@ k_preload_tiles(int4* __restrict__ zero_base, size_t zero_n4, unsigned long long
  * four filled images (and the normals), leave the others as mpr_unpack_* filled them.  arena = the images in order, each
  * padded to 64 words */
 __global__ void __launch_bounds__(256)
-k_zero_owned(int* __restrict__ arena, int with_normals, int S, const int* __restrict__ owner, int rank)
+k_zero_owned(int* __restrict__ arena, int levels, int S, const int* __restrict__ owner, int rank)
 {
     const int cols = S / 64;
     size_t off = 0;
     for (int level = 0; level < 5; ++level) {
-        if (level == 4 && !with_normals) break;
+        if (level >= levels) break;                  /* 3: the images of the tile stages, 4: + the heightmap, 5: + the normals */
         const int side = level < 4 ? S / (64 >> (2 * level)) : S;
         const int per_col = side / cols;             /* pixels of this image per column side */
         const size_t n = (size_t)side * side;
@@ -1182,9 +1182,9 @@ void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsign
     hipLaunchKernelGGL(k_preload_tiles, dim3(std::max(blocks, 1)), dim3(256), 0, s, reinterpret_cast<int4*>(zero_base), n4,
                        tape_index, tape_len, num_active, tiles, count, cols, owner, rank, children, t0);
 }
-void launch_zero_owned(hipStream_t s, int* arena, bool with_normals, int S, const int* owner, int rank)
+void launch_zero_owned(hipStream_t s, int* arena, int levels, int S, const int* owner, int rank)
 {
-    hipLaunchKernelGGL(k_zero_owned, dim3(1024), dim3(256), 0, s, arena, with_normals ? 1 : 0, S, owner, rank);
+    hipLaunchKernelGGL(k_zero_owned, dim3(1024), dim3(256), 0, s, arena, levels, S, owner, rank);
 }
 size_t tile_stage_lds_bytes(int nslots, int choice_cap) { return (size_t)nslots * 512 + (size_t)choice_cap * 16 + (nslots > 128 ? 1024 : 0); }
 /* Slots in registers (k_eval_tiles<.., .., VS>) when that puts more wavefronts on a CU than the LDS planes do: up to 24
@@ -1269,7 +1269,7 @@ static CopyFilled copy_filled_args(const int* prev, int* next, int size, int fir
     cf.next = next;
     cf.size = size;
     cf.first_block = first_block;
-    *extra = (unsigned)(((long long)size * size + 1023) / 1024);
+    *extra = next ? (unsigned)(((long long)size * size + 1023) / 1024) : 0u;      /* no next image: nothing is copied down */
     return cf;
 }
 /* The groups of the last tile stage that still have a tile for the float pass, in list order (front to back): the float

@@ -146,7 +146,8 @@ struct NormalArgs {
 /* children != null (3-D frames that start at the 16^3 tiles): also the 64 children of every first-stage tile, t0 = S / 64 */
 void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,
                         mpr_tile_node* tiles, int count, int cols, const int* owner, int rank, mpr_tile_node* children = nullptr, int t0 = 0);
-void launch_zero_owned(hipStream_t s, int* arena, bool with_normals, int S, const int* owner, int rank);
+/* levels: 3 = the three tile stages' images, 4 = + the heightmap / 2-D image, 5 = + the normals */
+void launch_zero_owned(hipStream_t s, int* arena, int levels, int S, const int* owner, int rank);
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,

@@ -76,7 +76,7 @@ def check_default_path(mpr, ref, tape, dim, S, mat, z=0.0, frames=3):
     return kinds
 
 
-def compare_reader_frame(mpr, orc, tape, S, mat, ref=None, frames=1):
+def compare_reader_frame(mpr, orc, tape, S, mat, ref=None, frames=1, read_first="tape_data"):
     """What a reader of `stages[k].tiles` / `tape_data` gets from a context WITHOUT work counters — compare_frame's contexts carry
     MPR_CTX_COUNTERS, which keeps every tile stage on the instrumented walks; this is the path callers of mpr.hpp are on (for
     tapes the host generates code for: every stage on that code, tapes pushed by TileGen::bwd_full).  `frames` 3-D frames are
@@ -90,8 +90,15 @@ def compare_reader_frame(mpr, orc, tape, S, mat, ref=None, frames=1):
         ctx.render3D(tape, mat)
         assert np.array_equal(ctx.image, ref.filled[3]), "heights differ (%d cells)" % int((ctx.image != ref.filled[3]).sum())
         assert np.array_equal(ctx.normals, ref.normals), "normals differ at %d pixels" % int((ctx.normals != ref.normals).sum())
-    pool = ctx.tape_data                     # a reader: from here on the context holds the reference's state
+    # a reader: from here on the context holds the reference's state (whatever is read first; the re-render runs the tile stages
+    # only and must leave the frame's heights and normals as they are)
+    if read_first == "filled0":
+        assert np.array_equal(ctx.stages[0].filled, ref.filled[0]), "stages[0].filled read first differs"
+    elif read_first == "tiles":
+        assert ctx.stages[1].tiles.size == ref.tiles[1].size
+    pool = ctx.tape_data
     assert ctx.last_stage_pushed()
+    assert np.array_equal(ctx.image, ref.filled[3]), "heights changed by the reader's re-render"
     for s in (0, 1, 2, 3):
         assert np.array_equal(ctx.stages[s].filled, ref.filled[s]), "filled image of stage %d differs" % s
     assert np.array_equal(ctx.normals, ref.normals)

@@ -540,7 +540,8 @@ def test_readers_tapes_on_chains_of_generated_stages_match_the_oracle(mpr, orc, 
     if key not in _READER_REFS:
         _READER_REFS.clear()             # one oracle frame at a time (bear 1024^3 keeps a 1 GB pool)
         _READER_REFS[key] = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
-    ctx, ref = compare_reader_frame(mpr, orc, tape, S, view3(), ref=_READER_REFS[key], frames=1 if how == "always" else 2)
+    ctx, ref = compare_reader_frame(mpr, orc, tape, S, view3(), ref=_READER_REFS[key], frames=1 if how == "always" else 2,
+                                    read_first={"0": "filled0", "1": "tiles"}[chain] if how != "always" else "tape_data")
     # the path this test means to exercise (a flag must not silently move it onto another one)
     assert ctx.normals_kernel() == ("k_eval_normals_gen" if chain == "1" else "k_eval_normals_asm"), ctx.normals_kernel()
     assert ctx.float_kernel().startswith("k_eval_voxels_"), ctx.float_kernel()
