@@ -234,6 +234,12 @@ int mpr_get_timings(mpr_context* ctx, const char** names, float* ms, int32_t cap
 const char* mpr_ctx_float_kernel(const mpr_context* ctx);
 /* ... and its normals pass: "k_eval_normals_gen" (the root tape's generated code), "k_eval_normals_asm", "k_eval_normals_q" */
 const char* mpr_ctx_normals_kernel(const mpr_context* ctx);
+/* ... and the form each of its tile stages took (the last frame that ran tile stages: a reader's re-render counts), e.g.
+ * "1:gen+bwd+records 2:gen/parent+guards" or "0:wide 1:interp 2:interp": <stage>:<wide | interp | gen[/parent][+guards][+bwd | +bwd_full]
+ * [+records] | none>.  gen = the root tape's host-generated interval code (csrc/tile_gen.hpp), /parent = with the parent tiles' recorded
+ * decisions imposed, +guards = jumping over what they left dead, +bwd / +bwd_full = tapes pushed by generated code too.  Tests assert
+ * the path they mean to exercise with it.  Owned by the context. */
+const char* mpr_ctx_tile_stage_forms(const mpr_context* ctx);
 
 /* 1 when the last frame's last tile stage pushed per-tile tapes (the reference's state), 0 when it did not need to (its own
  * sample of the tapes it would push said that float and normals pass do as well on the tapes it walked: DESIGN.md 3).

@@ -169,6 +169,8 @@ def lib():
     L.mpr_ctx_last_stage_pushed.restype = i32
     L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
     L.mpr_ctx_normals_kernel.restype = ctypes.c_char_p
+    L.mpr_ctx_tile_stage_forms.argtypes = [vp]
+    L.mpr_ctx_tile_stage_forms.restype = ctypes.c_char_p
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
     L.mpr_compiled_create.argtypes = [i32, vp, P(vp)]
     L.mpr_compiled_destroy.argtypes = [vp]
@@ -569,6 +571,10 @@ class Context:
     def normals_kernel(self):
         """Name of the kernel the last frame's normals pass ran as (mpr_ctx_normals_kernel)."""
         return lib().mpr_ctx_normals_kernel(self._h).decode()
+
+    def tile_stage_forms(self):
+        """The form each tile stage of the last frame took (mpr_ctx_tile_stage_forms), e.g. "1:gen+bwd+records 2:gen/parent+guards"."""
+        return lib().mpr_ctx_tile_stage_forms(self._h).decode()
 
     def float_kernel(self):
         """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""

@@ -89,6 +89,7 @@ struct mpr_context {
     size_t jit_code_bytes = 0;
     int cus = 0;                       /* compute units of the device */
     char float_kernel[64] = "";        /* mpr_ctx_float_kernel: the kernel the last frame's float pass ran as */
+    std::string stage_forms;           /* mpr_ctx_tile_stage_forms: the form each tile stage of the last frame took */
     const char* normals_kernel = "";   /* mpr_ctx_normals_kernel: ... and its normals pass */
     /* Frames that do not leave the reference's tiles and tapes behind ("fast" frames: what render* does by default; the
      * images are the reference's bit for bit):
@@ -157,6 +158,9 @@ struct mpr_context {
     size_t gen_dec_cap[3] = {0, 0, 0};
     int gen_full_dw = 0;               /* dwords of the backward code for tapes that are shortened again (0: the tape is too long for it) */
     std::shared_ptr<const mpr::TapeCode> resident_code;   /* what gen_code holds (kept alive: the upload is asynchronous) */
+    int gen_vox_at = 0, gen_fwdg_at = 0;   /* where the float walk / the guarded forward walk start in gen_code (dwords) */
+    int gen_fwdg_dw = 0;               /* dwords of the forward walk with guarded dead runs (TileGen::fwd_guarded), behind the float walk (0: none) */
+    bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
     int voxel_gen_min_run = 5;         /* MPR_VOXEL_GEN_RUN (development): shortest run of dead clauses that gets a guard (0: none) */
@@ -382,6 +386,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
     if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
@@ -577,6 +582,9 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     c->gen_deriv_dw = code->deriv_dw;
                     c->gen_full_dw = code->full_dw;
                     c->gen_vox_dw = c->voxel_gen ? code->vox_dw : 0;
+                    c->gen_vox_at = code->fwd_dw + code->bwd_dw + code->deriv_dw + code->full_dw;
+                    c->gen_fwdg_dw = c->tile_gen_guards ? code->fwdg_dw : 0;
+                    c->gen_fwdg_at = c->gen_vox_at + code->vox_dw;
                     c->gen_words = code->walk_words;
                     c->gen_nchoices = code->nchoices;
                 }
@@ -916,7 +924,9 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 rc = record_into(i);
                 if (rc) return rc;
             } else if (gen_here && last && si == 2 && decisions_recorded && try_lean && c->tile_gen_last) {
-                a.gen_fwd = c->gen_code;
+                /* (pushes nothing: the walk that jumps over what the parent's decisions left dead; the groups of its sample take
+                 * the interpreter) */
+                a.gen_fwd = c->gen_fwdg_dw > 0 ? c->gen_code + c->gen_fwdg_at : c->gen_code;
                 a.gen_words = c->gen_words;
                 a.gen_nchoices = c->gen_nchoices;
                 a.gen_parent = c->gen_dec[1];
@@ -935,6 +945,19 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             }
         }
         a.no_mask = c->stage0_only;
+        {
+            /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
+            if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
+            std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
+            if (a.gen_fwd && count > 0) {
+                if (a.gen_parent) f += "/parent";
+                if (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) f += "+guards";
+                f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : "";
+                if (a.gen_decisions) f += "+records";
+            }
+            if (!c->stage_forms.empty()) c->stage_forms += " ";
+            c->stage_forms += std::to_string(i) + ":" + f;
+        }
         if (count > 0) {
             a.groups = groups_now ? c->groups : nullptr;
             a.choice_masks = groups_now ? c->choice_masks : nullptr;
@@ -1135,7 +1158,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             int& grid = c->vox_grid_cache[dim - 2];
             if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
             const int use_grid = c->voxel_gen_wgs > 0 ? std::min(grid, c->voxel_gen_wgs * c->cus) : grid;
-            mprk::launch_eval_voxels_gen(s, dim, gv, c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw + c->gen_full_dw, use_grid, c->groups,
+            mprk::launch_eval_voxels_gen(s, dim, gv, c->gen_code + c->gen_vox_at, use_grid, c->groups,
                                          c->choice_masks, group_cap, c->num_active + 7, c->group_list, c->gen_dec[1], c->gen_nchoices);
             jitted = on_root_code = true;
         }
@@ -1256,6 +1279,7 @@ static int ensure_full_frame(mpr_context* c)
 extern "C" {
 
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
+const char* mpr_ctx_tile_stage_forms(const mpr_context* c) { return c ? c->stage_forms.c_str() : ""; }
 
 int mpr_ctx_sync(mpr_context* c)
 {

@@ -2,6 +2,9 @@
  * this file emits with the ROCm assembler and compares it with the instructions it is meant to be. */
 #include "tile_gen.hpp"
 
+#include <algorithm>
+#include <utility>
+
 #include "../../include/mpr_clause.h"
 #include "gfx950_emit.hpp"
 #include "internal.hpp"
@@ -549,6 +552,40 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
     f.mov(36, Emit::V(lo(g.result_slot)));
     f.mov(37, Emit::V(hi(g.result_slot)));
     f.setpc(TG_RET_CODE);
+    {
+        /* the same walk with the dead runs guarded: `s_bitcmp1_b64 <decided above for the other side>, k; s_cbranch_scc1 <behind the run>` */
+        std::vector<DeadRun> runs = tape_dead_runs(clauses, end, 3);
+        std::stable_sort(runs.begin(), runs.end(), [](const DeadRun& a, const DeadRun& b) { return a.first != b.first ? a.first < b.first : a.last > b.last; });
+        Emit fg{g.fwd_guarded};
+        std::vector<int> pos((size_t)end + 1, 0);
+        std::vector<std::pair<size_t, int>> fix;                    /* branch word, clause behind the run */
+        size_t next_run = 0;
+        int ch = 0;
+        for (int i = 1; i < end; ++i) {
+            pos[(size_t)i] = (int)g.fwd_guarded.size();
+            for (; next_run < runs.size() && runs[next_run].first == i; ++next_run) {
+                const DeadRun& r = runs[next_run];
+                fg.d(0xBF0F0000u | (uint32_t)(128 + r.choice) << 8 | (r.by_lhs ? 72u : 74u));      /* s_bitcmp1_b64 s[72:73] / s[74:75], choice */
+                fix.emplace_back(g.fwd_guarded.size(), r.last + 1);
+                fg.d(0xBF850000u);                                   /* s_cbranch_scc1 */
+            }
+            const uint64_t w = clauses[i];
+            const uint32_t op = (uint32_t)w & 0xFF;
+            (void)forward_clause(fg, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), ch);
+            if (mpr_op_is_minmax(op)) ++ch;
+        }
+        pos[(size_t)end] = (int)g.fwd_guarded.size();
+        fg.mov(36, Emit::V(lo(g.result_slot)));
+        fg.mov(37, Emit::V(hi(g.result_slot)));
+        fg.setpc(TG_RET_CODE);
+        bool fits = true;
+        for (const auto& fx : fix) {
+            const long d = (long)pos[(size_t)fx.second] - ((long)fx.first + 1);
+            if (d < 0 || d > 32767) fits = false;
+            g.fwd_guarded[fx.first] |= (uint32_t)(d & 0xFFFF);
+        }
+        if (!fits || runs.empty()) g.fwd_guarded.clear();          /* nothing to jump over: the plain walk */
+    }
 
     {
         Emit de{g.deriv};
@@ -602,12 +639,14 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     if (!g.ok || g.fwd.empty()) return nullptr;
     const VoxelGen v = voxel_gen_build(clauses, len, vox_min_run);
     auto c = std::make_shared<TapeCode>();
-    c->words.reserve(g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size());
+    c->words.reserve(g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size() + g.fwd_guarded.size());
     c->words.insert(c->words.end(), g.fwd.begin(), g.fwd.end());
     c->words.insert(c->words.end(), g.bwd.begin(), g.bwd.end());
     c->words.insert(c->words.end(), g.deriv.begin(), g.deriv.end());
     c->words.insert(c->words.end(), g.bwd_full.begin(), g.bwd_full.end());
     if (v.ok) c->words.insert(c->words.end(), v.code.begin(), v.code.end());
+    c->words.insert(c->words.end(), g.fwd_guarded.begin(), g.fwd_guarded.end());
+    c->fwdg_dw = (int)g.fwd_guarded.size();
     c->fwd_dw = (int)g.fwd.size();
     c->bwd_dw = (int)g.bwd.size();
     c->deriv_dw = (int)g.deriv.size();
@@ -623,8 +662,8 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
     const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
-    if (!g.ok || which < 0 || which > 3) return -1;
-    const std::vector<uint32_t>& c = which == 3 ? g.bwd_full : which == 2 ? g.deriv : which ? g.bwd : g.fwd;
+    if (!g.ok || which < 0 || which > 4) return -1;
+    const std::vector<uint32_t>& c = which == 4 ? g.fwd_guarded : which == 3 ? g.bwd_full : which == 2 ? g.deriv : which ? g.bwd : g.fwd;
     if (out && (int)c.size() <= cap)
         for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
     return (int)c.size();

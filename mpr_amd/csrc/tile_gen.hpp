@@ -51,6 +51,11 @@ enum TileGenReg : int {
 struct TileGen {
     bool ok = false;
     std::vector<uint32_t> fwd;      /* forward walk: axes in their slots -> result in v[36:37], decisions in v56..v59 */
+    std::vector<uint32_t> fwd_guarded;   /* the forward walk for a stage BELOW the first that pushes nothing (a frame's lean last stage): runs of clauses
+                                          * that are dead under what the parent tile decided (s[72:73] / s[74:75], wave-uniform: the 64 tiles of a
+                                          * wavefront share their parent) are jumped over — voxel_gen.hpp: tape_dead_runs.  The min / max clauses in
+                                          * such a run record no decision: nothing of the tile's tape depends on them.  Not for stages that push:
+                                          * the reference's backward walk keeps some dead clauses (slot liveness), and their decisions are on the tape */
     std::vector<uint32_t> bwd;      /* backward walk of tape pushing */
     std::vector<uint32_t> bwd_full; /* the same for tapes that are shortened again, and for the stages below the first (tile_gen.cpp); empty:
                                      * the tape has more clauses than a record has presence bits */

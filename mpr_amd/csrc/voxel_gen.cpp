@@ -271,15 +271,12 @@ bool uses_rhs(uint32_t op)
            op == MPR_OP_COPY_RHS;
 }
 
-/* a run of consecutive clauses [first, last] that is dead when min / max clause `choice` (its number among the tape's
- * min / max clauses) is decided for the lhs (by_lhs) / the rhs */
-struct Run { int first, last, choice; bool by_lhs; };
+}  // namespace
 
-/* The clauses only one operand of a min / max clause reaches, as runs.  defs: per clause the clause that wrote its lhs / rhs
- * operand (-1: an axis or nothing). */
-std::vector<Run> dead_runs(const uint64_t* cl, int end, int min_run)
+/* The clauses only one operand of a min / max clause reaches, as runs (voxel_gen.hpp). */
+std::vector<DeadRun> tape_dead_runs(const uint64_t* cl, int end, int min_run)
 {
-    std::vector<Run> runs;
+    std::vector<DeadRun> runs;
     if (min_run <= 0) return runs;
     std::vector<int> ldef(end, -1), rdef(end, -1), choice_of(end, -1);
     int cur[256];
@@ -328,8 +325,6 @@ std::vector<Run> dead_runs(const uint64_t* cl, int end, int min_run)
     return runs;
 }
 
-}  // namespace
-
 VoxelGen voxel_gen_build(const uint64_t* clauses, int len, int min_run)
 {
     VoxelGen g;
@@ -351,9 +346,9 @@ VoxelGen voxel_gen_build(const uint64_t* clauses, int len, int min_run)
     const int hx = (int)mpr_cl_out(clauses[0]), hy = (int)mpr_cl_lhs(clauses[0]), hz = (int)mpr_cl_rhs(clauses[0]);
     if (hx >= VG_MAX_SLOTS || hy >= VG_MAX_SLOTS || hz >= VG_MAX_SLOTS) return g;
 
-    std::vector<Run> runs = dead_runs(clauses, end, min_run);
+    std::vector<DeadRun> runs = tape_dead_runs(clauses, end, min_run);
     /* at a clause: outer runs first */
-    std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.first != b.first ? a.first < b.first : a.last > b.last; });
+    std::stable_sort(runs.begin(), runs.end(), [](const DeadRun& a, const DeadRun& b) { return a.first != b.first ? a.first < b.first : a.last > b.last; });
 
     Gen e;
     e.mov(e.c, Gen::R(hx), Gen::V(32));
@@ -366,7 +361,7 @@ VoxelGen voxel_gen_build(const uint64_t* clauses, int len, int min_run)
     for (int i = 1; i < end; ++i) {
         pos[i] = (int)e.c.size();
         for (; next_run < runs.size() && runs[next_run].first == i; ++next_run) {
-            const Run& r = runs[next_run];
+            const DeadRun& r = runs[next_run];
             e.bitcmp1(r.by_lhs ? VG_DEC_L : VG_DEC_R, r.choice);
             guards.push_back({e.c.size(), r.last + 1});
             e.c.push_back(0xBF850000u);                       /* s_cbranch_scc1 */

@@ -46,6 +46,12 @@ enum VoxelGenReg : int {
     VG_K_EXP_C5 = 5, VG_K_LOG_C8 = 6,        /* VGPRs: the leading coefficients of the exp / log polynomials */
 };
 
+/* A run of consecutive clauses [first, last] of a tape that is dead when the tape's `choice`-th min / max clause is decided for
+ * the lhs (by_lhs) / for the rhs: the clauses only the OTHER operand of that clause reaches (its exclusive sub-DAG).  Runs of
+ * one clause pair nest or are disjoint.  end = index of the tape's end clause; runs shorter than min_run are left out. */
+struct DeadRun { int first, last, choice; bool by_lhs; };
+std::vector<DeadRun> tape_dead_runs(const uint64_t* clauses, int end, int min_run);
+
 struct VoxelGen {
     bool ok = false;
     std::vector<uint32_t> code;

@@ -542,9 +542,20 @@ def test_readers_tapes_on_chains_of_generated_stages_match_the_oracle(mpr, orc, 
         _READER_REFS[key] = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
     ctx, ref = compare_reader_frame(mpr, orc, tape, S, view3(), ref=_READER_REFS[key], frames=1 if how == "always" else 2,
                                     read_first={"0": "filled0", "1": "tiles"}[chain] if how != "always" else "tape_data")
-    # the path this test means to exercise (a flag must not silently move it onto another one)
-    assert ctx.normals_kernel() == ("k_eval_normals_gen" if chain == "1" else "k_eval_normals_asm"), ctx.normals_kernel()
-    assert ctx.float_kernel().startswith("k_eval_voxels_"), ctx.float_kernel()
+    # the path this test means to exercise (a flag must not silently move it onto another one): the tile stages that left the
+    # tiles and tapes just compared ...
+    forms = ctx.tile_stage_forms().split()
+    assert [f.split(":")[0] for f in forms] == ["0", "1", "2"], forms
+    if chain == "1":      # every stage on the root tape's generated code, tapes pushed by the walk that follows the parent's tape
+        assert all(f.split(":")[1].startswith("gen") and "+bwd_full" in f for f in forms), forms
+        assert "/parent" in forms[1] and "/parent" in forms[2] and "/parent" not in forms[0], forms
+    else:                 # the first stage only (its lean backward walk), the interpreter below it
+        assert forms[0].startswith("0:gen+bwd") and "bwd_full" not in forms[0] and forms[1:] == ["1:interp", "2:interp"], forms
+    # ... and the normals pass of the frame whose normals were compared (a reader's re-render runs no normals pass)
+    if how == "always":
+        assert ctx.normals_kernel() == ("k_eval_normals_gen" if chain == "1" else "k_eval_normals_asm"), ctx.normals_kernel()
+    else:
+        assert ctx.normals_kernel() == "k_eval_normals_gen" and ctx.float_kernel() == "k_eval_voxels_gen<3>", (ctx.normals_kernel(), ctx.float_kernel())
     ctx.close()
 
 

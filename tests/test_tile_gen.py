@@ -187,3 +187,37 @@ def test_whole_tapes(mpr):
     for name in ("architecture", "prospero"):
         t = mpr.Tape(mpr.model(name))
         assert generated(mpr, [int(w) for w in np.asarray(t.data)], 0) is None
+
+
+def test_forward_walk_with_guarded_dead_runs(mpr, tapes):
+    """which = 4: the forward walk a frame's lean last stage runs — its tiles walk their parent's tape as the ROOT tape's code with
+    the parent's decisions imposed (s[72:73] decided for the lhs, s[74:75] for the rhs, wave-uniform), and runs of clauses that are
+    dead under those decisions are jumped over (csrc/voxel_gen.hpp: tape_dead_runs, the analysis tests/test_voxel_gen.py checks by
+    symbolic execution).  With nothing decided it runs exactly the plain forward walk; a decision skips whole clauses only."""
+    from test_voxel_gen import disassemble, walk
+    words = [int(w) for w in tapes("bear").data]
+    arr = np.array(words, dtype=np.uint64)
+    buf = (ctypes.c_uint32 * 65536)()
+    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 0, buf, 65536)
+    plain = list(buf[:n])
+    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 4, buf, 65536)
+    guarded = list(buf[:n])
+    assert n > len(plain)
+    text = disassemble(guarded)
+    guards = [k for k, l in enumerate(text) if l.startswith("s_bitcmp1_b64 s[72:73]") or l.startswith("s_bitcmp1_b64 s[74:75]")]
+    assert len(guards) >= 30 and all(text[k + 1].startswith("s_cbranch_scc1") for k in guards)
+    ptext = [l for l in disassemble(plain) if not l.startswith("s_setpc_b64 s[38:39]")]
+    assert walk(guarded, 0, 0) == ptext
+    # decided: fewer instructions, and what runs is the plain walk with whole clauses missing (a subsequence)
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        dl = int(rng.integers(0, 1 << 27)) & ~int(rng.integers(0, 1 << 27))
+        dr = int(rng.integers(0, 1 << 27)) & ~dl & ~int(rng.integers(0, 1 << 27))
+        got = walk(guarded, dl, dr)
+        it = iter(ptext)
+        assert all(any(x == y for y in it) for x in got)
+        assert len(got) < len(ptext)
+    # tapes without a min / max clause have nothing to guard: no such code
+    sphere = [int(w) for w in tapes("sphere").data]
+    arr = np.array(sphere, dtype=np.uint64)
+    assert mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 4, buf, 65536) == 0

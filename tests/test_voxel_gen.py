@@ -60,6 +60,36 @@ def disassemble(dwords, sizes=False):
     return (out, sz) if sizes else out
 
 
+def insn_lengths(code):
+    """dwords of every instruction of `code`, decoded from the words themselves (llvm-mc -show-encoding re-encodes what it
+    disassembled, and a literal that has an inline-constant twin comes back shorter than it went in)."""
+    out, pc = [], 0
+    while pc < len(code):
+        w = code[pc]
+        top = w >> 23
+        n = 1
+        if top == 0b101111101:                                   # SOP1
+            n += (w & 0xFF) == 255
+        elif top == 0b101111110:                                 # SOPC
+            n += (w & 0xFF) == 255 or ((w >> 8) & 0xFF) == 255
+        elif top == 0b101111111:                                 # SOPP
+            pass
+        elif (w >> 28) == 0b1011:                                # SOPK (s_setreg_imm32_b32 carries a literal)
+            n += ((w >> 23) & 0x1F) == 20
+        elif (w >> 30) == 0b10:                                  # SOP2
+            n += (w & 0xFF) == 255 or ((w >> 8) & 0xFF) == 255
+        elif (w >> 26) in (0b110100, 0b110110, 0b110111, 0b111000, 0b110000):      # VOP3, DS, FLAT / GLOBAL, MUBUF, SMEM
+            n = 2
+        elif (w >> 25) in (0b0111110, 0b0111111):                # VOPC, VOP1
+            n += (w & 0x1FF) in (249, 250, 255)
+        else:                                                    # VOP2 (v_fmamk_f32 / v_fmaak_f32 always carry their constant)
+            n += (w & 0x1FF) in (249, 250, 255) or (w >> 25) in (23, 24)
+        out.append(n)
+        pc += n
+    assert pc == len(code), "the code does not end on an instruction boundary"
+    return out
+
+
 def body_of(macro):
     """the instructions of one MPR_ASM_* macro of asm_float_bodies.hpp (labels kept, as 'L_x:')"""
     src = open(os.path.join(ROOT, "mpr_amd", "csrc", "asm_float_bodies.hpp")).read()
@@ -231,7 +261,8 @@ def test_min_max_with_the_tiles_decisions(mpr):
 def walk(code, dl, dr):
     """Follow the code's scalar branches for a tile with decisions (dl, dr); routines return at once, v_cmp-driven branches (the
     rare operands) are not taken.  -> the disassembled instructions executed, in order."""
-    text, sizes = disassemble(code, sizes=True)
+    text, sizes = disassemble(code), insn_lengths(code)
+    assert len(text) == len(sizes)
     at, pc = [], 0
     for n in sizes:                       # dword index of every instruction
         at.append(pc)
@@ -240,11 +271,11 @@ def walk(code, dl, dr):
     out, k, scc = [], 0, 0
     for _ in range(100000):
         l = text[k]
-        if l.startswith("s_setpc_b64 s[72:73]"):
+        if l.startswith("s_setpc_b64 s[72:73]") or l.startswith("s_setpc_b64 s[38:39]"):
             return out
         m = re.match(r"s_bitcmp1_b64 s\[(\d+):\d+\], (\d+)", l)
-        if m:
-            scc = ((dl if m.group(1) == "76" else dr) >> int(m.group(2))) & 1
+        if m:      # (the float walk keeps the tile's decisions in s[76:79], the interval walk those from above in s[72:75])
+            scc = ((dl if m.group(1) in ("76", "72") else dr) >> int(m.group(2))) & 1
         m = re.match(r"(s_branch|s_cbranch_scc1|s_cbranch_scc0|s_cbranch_vccnz) (\d+)", l)
         if m:
             off = int(m.group(2))
@@ -318,13 +349,14 @@ def symbolic(lines):
     return reg.get("v37")
 
 
-def test_guards_of_bear_keep_every_live_clause(mpr, tapes):
+@pytest.mark.parametrize("min_run", [5, 3, 1])
+def test_guards_of_bear_keep_every_live_clause(mpr, tapes, min_run):
     """For the tape the benchmark is quoted on: whatever the tile's decisions, the code with its guards computes the same
     expression as the code without any (symbolic execution of both instruction streams: a jumped-over clause that the result
     still depends on would leave a stale register in the dataflow), while running fewer instructions."""
     tape = tapes("bear").data
     words = [int(w) for w in tape]
-    code, info = generated(mpr, words)
+    code, info = generated(mpr, words, min_run=min_run)
     plain, pinfo = generated(mpr, words, min_run=0)
     assert info[0] == 27 and info[1] >= 20 and pinfo[1] == 0
     assert walk(code, 0, 0) == walk(plain, 0, 0)                    # nothing decided: every clause runs
