@@ -140,6 +140,8 @@ struct mpr_context {
     unsigned char* group_alive = nullptr;  /* per group: a tile left for the float pass (written by the last compaction) */
     int* group_list = nullptr;             /* those groups in list order, then their number (k_list_alive_groups) */
     size_t group_alive_cap = 0, group_list_cap = 0;
+    int* tile_source = nullptr;            /* per smallest tile: its index in the last tile stage's list (the float pass on the root tape's code) */
+    size_t tile_source_cap = 0;
 
     uint64_t tape_serial = 0;          /* tape currently resident at pool[0..] */
     /* the resident tape's interval walks as generated code (tile_gen.hpp), for the frame's first tile stage; MPR_TILE_GEN=0: never,
@@ -494,6 +496,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->groups) (void)hipFree(c->groups);
     if (c->group_alive) (void)hipFree(c->group_alive);
     if (c->group_list) (void)hipFree(c->group_list);
+    if (c->tile_source) (void)hipFree(c->tile_source);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->num_active) (void)hipFree(c->num_active);
@@ -526,7 +529,7 @@ int64_t mpr_ctx_resident_bytes(const mpr_context* c)
     if (!c) return 0;
     size_t b = c->arena_words * sizeof(int) + ((size_t)c->pool_cap + 128) * sizeof(uint64_t) + c->jit_code_bytes;
     for (int i = 0; i < 4; ++i) b += c->tiles_cap[i] * sizeof(mpr_tile_node);
-    b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + c->group_list_cap * sizeof(int);
+    b += c->groups_cap * sizeof(mprk::GroupInfo) + c->masks_cap * sizeof(ulonglong2) + c->group_alive_cap + (c->group_list_cap + c->tile_source_cap) * sizeof(int);
     b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t);
     b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t) + (c->gen_dec_cap[0] + c->gen_dec_cap[1] + c->gen_dec_cap[2]) * sizeof(unsigned long long);
     b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
@@ -834,6 +837,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     bool decisions_recorded = false;       /* the stages so far ran generated code and kept their tiles' decisions ... */
     bool presence_recorded = false;        /* ... with the clauses of the tapes they pushed */
     bool last_recorded = false;            /* ... down to the smallest tiles */
+    bool vox_gen_planned = false;          /* the last stage's compaction kept, per smallest tile, where it sat in that stage's list */
     for (int si = skip0 ? 1 : 0; si < nstages; ++si) {
         const int i = stage_list[si];
         const bool last = (si == nstages - 1);
@@ -1038,20 +1042,31 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         const bool zs = dim == 3 && mprk::zsort_supported(tps) && (c->zsort & (last ? 2 : 1));
         int act3[5] = {0, 0, 0, 0, 0};
         /* second mask_filled_tiles + assign_next_nodes + subdivide / copy_active_tiles + copy_filled, then the survivor count */
+        /* the float pass on the root tape's host-generated code (voxel_gen.hpp) takes the smallest tiles one by one and looks their
+         * decisions up by where they sat in this stage's list */
+        const bool vox_gen_next = last && groups_now && dim == 3 && i == 2 && decisions_recorded && c->voxel_gen && c->gen_ok && c->gen_vox_dw > 0 &&
+                                  c->cus > 0;
+        vox_gen_planned = vox_gen_next;
+        if (vox_gen_next) {
+            rc = ensure_buffer(&c->tile_source, &c->tile_source_cap, (size_t)std::max(count, 1));
+            if (rc) return rc;
+        }
         auto compact = [&](bool mark_groups) -> int {
             const int seq = ++c->pub_seq;
             if (zs) {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
                                              c->zs_hist, c->zs_cursor, c->pub_dev, seq, (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub),
-                                             c->num_active + 4, mark_groups ? c->group_alive : nullptr, c->tape_index);
+                                             c->num_active + 4, mark_groups ? c->group_alive : nullptr, c->tape_index,
+                                             (mark_groups && vox_gen_next) ? c->tile_source : nullptr);
             } else {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
                                                c->pub_dev, seq, (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub),
-                                               mark_groups ? c->group_alive : nullptr, c->tape_index);
+                                               mark_groups ? c->group_alive : nullptr, c->tape_index,
+                                               (mark_groups && vox_gen_next) ? c->tile_source : nullptr);
             }
-            if (mark_groups) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
+            if (mark_groups && !vox_gen_next) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
             return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
         };
         if (count > 0) {
@@ -1150,16 +1165,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         bool jitted = false, on_root_code = false;
         /* The root tape's host-generated float walk (voxel_gen.hpp), the tiles' decisions as bits: frames whose tile stages kept their
          * tiles' records down to the stage above the last one, whose last stage recorded its groups' masks */
-        if (!cnt && !heat && !brute && group_form && dim == 3 && group_stage == 2 && decisions_recorded && c->voxel_gen && c->gen_ok && c->gen_vox_dw > 0 &&
-            c->cus > 0) {
-            mprk::VoxelArgs gv = v;
-            gv.tiles = c->tiles[group_stage];
-            gv.count = group_count;
+        if (vox_gen_planned && group_form && !brute) {
             int& grid = c->vox_grid_cache[dim - 2];
             if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
             const int use_grid = c->voxel_gen_wgs > 0 ? std::min(grid, c->voxel_gen_wgs * c->cus) : grid;
-            mprk::launch_eval_voxels_gen(s, dim, gv, c->gen_code + c->gen_vox_at, use_grid, c->groups,
-                                         c->choice_masks, group_cap, c->num_active + 7, c->group_list, c->gen_dec[1], c->gen_nchoices);
+            mprk::launch_eval_voxels_gen(s, dim, v, c->gen_code + c->gen_vox_at, use_grid, c->tile_source, c->groups, c->choice_masks, group_cap,
+                                         c->num_active + 7, c->gen_dec[1], c->gen_nchoices);
             jitted = on_root_code = true;
         }
         if (!cnt && !heat && !jitted) {

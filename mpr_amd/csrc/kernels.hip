@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(1024)
 k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
                     const int* __restrict__ image, int* __restrict__ num_active,
                     mpr_tile_node* __restrict__ out, int* __restrict__ pub, int seq, CopyFilled cf,
-                    unsigned char* __restrict__ group_alive, const unsigned long long* __restrict__ tape_index)
+                    unsigned char* __restrict__ group_alive, const unsigned long long* __restrict__ tape_index, int* __restrict__ source_out)
 {
     if ((int)blockIdx.x >= cf.first_block) {
         copy_filled_block<DIM>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
@@ -832,6 +832,7 @@ k_compact_subdivide(mpr_tile_node* __restrict__ tiles, int count, int tps,
             o.tape = n.tape;
             o.next = -1;
             out[next] = o;
+            if (source_out) source_out[next] = gidx;      /* where the tile sits in this stage's list: its group and child */
         }
         return;
     }
@@ -920,7 +921,7 @@ k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __rest
 template <bool LAST>
 __global__ void __launch_bounds__(1024)
 k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restrict__ cursor, mpr_tile_node* __restrict__ out,
-             unsigned char* __restrict__ group_alive)
+             unsigned char* __restrict__ group_alive, int* __restrict__ source_out)
 {
     __shared__ int lh[ZS_MAX_BINS], gb[ZS_MAX_BINS];
     for (int i = threadIdx.x; i < tps; i += blockDim.x) lh[i] = 0;
@@ -957,6 +958,7 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
             o.tape = n.tape;
             o.next = -1;
             out[next] = o;
+            if (source_out) source_out[next] = gidx;
         }
         return;
     }
@@ -1305,24 +1307,24 @@ void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngr
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
                               int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive,
-                              const unsigned long long* tape_index)
+                              const unsigned long long* tape_index, int* source_out)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb + extra), b(1024);
     if (dim == 3) {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
-        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<3, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index, source_out);
+        else hipLaunchKernelGGL((k_compact_subdivide<3, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index, source_out);
     } else {
-        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
-        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index);
+        if (last) hipLaunchKernelGGL((k_compact_subdivide<2, true>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index, source_out);
+        else hipLaunchKernelGGL((k_compact_subdivide<2, false>), g, b, 0, s, tiles, count, tps, image, num_active, out, pub, seq, cf, group_alive, tape_index, source_out);
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need, unsigned char* group_alive, const unsigned long long* tape_index)
+                            int* need, unsigned char* group_alive, const unsigned long long* tape_index, int* source_out)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
@@ -1330,8 +1332,8 @@ void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int 
     const dim3 g(nb), b(1024);
     hipLaunchKernelGGL(k_zs_hist, dim3(nb + extra), b, 0, s, tiles, count, tps, image, hist, cf);
     hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need, tape_index);
-    if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out, group_alive);
-    else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out, nullptr);
+    if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out, group_alive, source_out);
+    else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out, nullptr, nullptr);
 }
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size)
 {

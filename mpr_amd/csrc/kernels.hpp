@@ -151,7 +151,8 @@ void launch_zero_owned(hipStream_t s, int* arena, int levels, int S, const int* 
 bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need, unsigned char* group_alive = nullptr, const unsigned long long* tape_index = nullptr);
+                            int* need, unsigned char* group_alive = nullptr, const unsigned long long* tape_index = nullptr,
+                            int* source_out = nullptr);
 void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngroups, int* list);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
@@ -166,7 +167,8 @@ void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int 
 void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* tiles, int count, int tps,
                               const int* image, int* num_active, mpr_tile_node* out,
                               int* pub, int seq, int* next_image, int next_size, unsigned char* group_alive = nullptr,
-                              const unsigned long long* tape_index = nullptr);
+                              const unsigned long long* tape_index = nullptr, int* source_out = nullptr);
+/* source_out (last stage): per tile of the list handed on, its index in THIS stage's list (group = index / 64, child = index % 64) */
 void launch_copy_filled(hipStream_t s, int dim, const int* prev, int* image, int size);
 size_t voxel_lds_bytes(int nslots);
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a);
@@ -185,12 +187,13 @@ int jit_grid(int dim, int nslots, int cus, bool group);
 void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t* code, uint32_t region_dwords, int slot_dwords, int slots, int grid,
                             int tape_len, const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* group_counter,
                             const int* group_list, bool always_invalidate = false);
-/* same pass on the ROOT tape's host-generated code (voxel_gen.hpp) with the tiles' recorded decisions; groups / masks / list as for the
- * group form, parent_records: the records of the tiles of the stage above the last one */
+/* same pass on the ROOT tape's host-generated code (voxel_gen.hpp) with the tiles' recorded decisions: a.tiles / a.count = the smallest
+ * tiles, source[t] = tile t's index in the last tile stage's list (launch_compact_*: source_out), groups / masks of that stage,
+ * parent_records: the records of the tiles of the stage above it; tile_counter: zero at the start of the frame */
 int voxel_gen_grid(int dim, int cus);
-void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const GroupInfo* groups,
-                            const ulonglong2* choice_masks, int choice_cap, int* group_counter, const int* group_list,
-                            const unsigned long long* parent_records, int nchoices);
+void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
+                            const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
+                            int nchoices);
 void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
                            unsigned long long dr);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,

@@ -976,8 +976,7 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
  * tile's own tape is the root tape with the decisions of the 16^3 tile above it (its record) and its own (the group's
  * masks, numbered by the clauses the parent's tape keeps) applied, so every tile runs the ONE piece of code there is
  * per tape — nothing is translated on the device, no code ring, no instruction-cache invalidates, and dead clauses are
- * jumped over by the code's own scalar branches on the decisions.  Work is handed out as in the group form (persistent
- * workgroups take the groups that still have a tile in list order, their wavefronts the group's surviving children). */
+ * jumped over by the code's own scalar branches on the decisions. */
 #define VG_ASM_TEXT                                                                                    \
     "s_getpc_b64 s[50:51]\n"                                                                           \
     "L_pc_%=:\n"                                                                                       \
@@ -1025,104 +1024,83 @@ DEV float vox_gen_run(const uint32_t* code, float vx, float vy, float vz, uint64
 }
 
 struct GenVoxelArgs {
-    VoxelArgs v;                       /* tiles / count: the LAST tile stage's list, after its compaction */
+    VoxelArgs v;                       /* tiles / count: the smallest tiles the last compaction left, front to back */
     const uint32_t* code;              /* the root tape's float walk (executable memory) */
+    const int* source;                 /* per smallest tile: its index in the last tile stage's list (group = / 64, child = % 64) */
     const GroupInfo* groups;
     const ulonglong2* choice_masks;
     int choice_cap;
-    int* group_counter;
-    const int* group_list;
+    int* tile_counter;                 /* the next tile to hand out (zero at the start of the frame) */
     const unsigned long long* parent_records;   /* records of the tiles of the stage above (GEN_RECORD_U64 words each) */
     int nchoices;                      /* min / max clauses of the root tape */
 };
 
+/* A wavefront per smallest tile, taken in list order (front to back: the tiles behind a surface find it drawn) with one atomic
+ * each — nothing is shared between the tiles of a group any more (the group form's workgroup translated one tape for its 64
+ * children and waited for the slowest of its four wavefronts), so there is no barrier, no idle wavefront at the end of a group,
+ * and a rank with an eighth of the tiles (multi-GPU) ends when its last TILE does, not its last group. */
 template <int DIM>
-__global__ void __launch_bounds__(64 * JIT_GROUP_WAVES, 6)
+__global__ void __launch_bounds__(64, 6)         /* (7 waves per SIMD would take the SGPRs the routines name away: s90..s95) */
 k_eval_voxels_gen(GenVoxelArgs j)
 {
     const VoxelArgs& a = j.v;
-    const int lane = threadIdx.x & 63;
-    __shared__ int next_child_lds, next_group;
-    int* const next_child = &next_child_lds;
-    const int ngroups = (a.count + 63) / 64;
-    const int nlisted = j.group_list[ngroups];
+    const int lane = threadIdx.x;
     const unsigned long long all = j.nchoices >= 64 ? ~0ull : ((1ull << j.nchoices) - 1ull);
     for (;;) {
-        if (threadIdx.x == 0) {
-            next_group = atomicAdd(j.group_counter, 1);
-            *next_child = 0;
+        int t = 0;
+        if (lane == 0) t = atomicAdd(j.tile_counter, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= a.count) break;
+        const int position = __builtin_amdgcn_readfirstlane(a.tiles[t].position);
+        JitVoxel<DIM> vox;
+        if (!vox.setup(a, position, lane)) continue;
+        const int src = __builtin_amdgcn_readfirstlane(j.source[t]);
+        const int g = src >> 6, c = src & 63;
+        const GroupInfo gi = j.groups[g];
+        /* what the tile above decided (and everything above it), and the min / max clauses its tape keeps: the group's masks are
+         * numbered by those */
+        unsigned long long L = 0, R = 0, K = all;
+        if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
+            const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
+            L = rfl64(rec[0]);
+            R = rfl64(rec[1]);
+            K = rfl64(rec[2]);
         }
-        __syncthreads();
-        const int r = next_group;
-        if (r >= nlisted) break;
-        const int g = j.group_list[r];
-        /* the 64 siblings as the last compaction left them: position -1 = empty, filled or hidden */
-        int position = -1;
-        const int idx = g * 64 + lane;
-        if (idx < a.count) position = a.tiles[idx].position;
-        const uint64_t alive = ballot(position != -1);
-        if (alive != 0) {                                   /* the same for every wavefront of the workgroup */
-            const GroupInfo gi = j.groups[g];
-            /* what the tile above decided (and everything above it), and the min / max clauses its tape keeps: the group's masks
-             * are numbered by those */
-            unsigned long long L = 0, R = 0, K = all;
-            if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
-                const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
-                L = rfl64(rec[0]);
-                R = rfl64(rec[1]);
-                K = rfl64(rec[2]);
-            }
-            /* lane k: root clause k is the i-th clause that tape keeps */
-            const bool kept = (K >> lane) & 1ull;
-            const int i = __popcll(K & ((1ull << lane) - 1ull));
-            ulonglong2 mk = make_ulonglong2(0ull, 0ull);
-            if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
-            /* front to back: children with the larger z first (lane = x + 4 y + 16 z) */
-            const int nalive = __popcll(alive);
-            for (;;) {
-                int k = 0;
-                if (lane == 0) k = atomicAdd(next_child, 1);
-                k = __builtin_amdgcn_readfirstlane(k);
-                if (k >= nalive) break;
-                uint64_t rest = alive;
-                for (int skip = 0; skip < k; ++skip) rest &= ~(1ull << (63 - __builtin_clzll(rest)));
-                const int c = 63 - __builtin_clzll(rest);
-                const int cpos = (int)rdlane((uint32_t)position, (uint32_t)c);
-                JitVoxel<DIM> vox;
-                if (!vox.setup(a, cpos, lane)) continue;
-                const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
-                const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
-                vox.finish(a, res);
-            }
-        }
-        __syncthreads();                                    /* next_group / next_child are rewritten */
+        /* lane k: root clause k is the i-th clause that tape keeps; its mask's bit c = this tile's decision there */
+        const bool kept = (K >> lane) & 1ull;
+        const int i = __popcll(K & ((1ull << lane) - 1ull));
+        ulonglong2 mk = make_ulonglong2(0ull, 0ull);
+        if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
+        const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
+        const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
+        vox.finish(a, res);
     }
 }
 
 int voxel_gen_grid(int dim, int cus)
 {
     int per_cu = 0;
-    const hipError_t e = dim == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen<3>, 64 * JIT_GROUP_WAVES, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen<2>, 64 * JIT_GROUP_WAVES, 0);
-    if (e != hipSuccess || per_cu <= 0) per_cu = 1;
+    const hipError_t e = dim == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen<3>, 64, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen<2>, 64, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = 16;
     return per_cu * cus;
 }
-void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const GroupInfo* groups,
-                            const ulonglong2* choice_masks, int choice_cap, int* group_counter, const int* group_list,
-                            const unsigned long long* parent_records, int nchoices)
+void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
+                            const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
+                            int nchoices)
 {
     if (a.count <= 0) return;
     GenVoxelArgs j;
     j.v = a;
     j.code = code;
+    j.source = source;
     j.groups = groups;
     j.choice_masks = choice_masks;
     j.choice_cap = choice_cap;
-    j.group_counter = group_counter;
-    j.group_list = group_list;
+    j.tile_counter = tile_counter;
     j.parent_records = parent_records;
     j.nchoices = nchoices;
-    const dim3 g(std::min(grid, (a.count + 63) / 64)), b(64 * JIT_GROUP_WAVES);
+    const dim3 g(std::min(grid, a.count)), b(64);
     if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_gen<3>, g, b, 0, s, j);
     else hipLaunchKernelGGL(k_eval_voxels_gen<2>, g, b, 0, s, j);
 }
