@@ -154,7 +154,9 @@ int mpr_ctx_sync(mpr_context* ctx);
  * `owner` has (S/64)^2 entries (column index = x + y*(S/64)), each the owning rank; columns
  * of other ranks are skipped at stage 0 and their pixels stay 0. */
 /* Work proxy for the column deal: weights[(S/64)^2] = first-stage tiles per 64 x 64 column that the interval
- * evaluation of this tape and view leaves ambiguous.  Runs the 64 px stage only; identical on every rank. */
+ * evaluation of this tape and view leaves ambiguous.  Runs the 64 px stage only; identical on every rank.  The call replaces
+ * the context's previous frame: the images and normals are cleared, stages[0].tiles is this call's list, the other lists are
+ * empty, until the next frame is rendered. */
 int mpr_column_weights(mpr_context* ctx, const mpr_tape* tape, int32_t dim, const float* mat_colmajor, float z, float* weights);
 int mpr_render3d_part(mpr_context* ctx, const mpr_tape* tape, const float mat4_colmajor[16],
                       const int32_t* owner, int32_t rank);

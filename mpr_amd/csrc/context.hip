@@ -140,6 +140,7 @@ struct mpr_context {
     unsigned char* group_alive = nullptr;  /* per group: a tile left for the float pass (written by the last compaction) */
     int* group_list = nullptr;             /* those groups in list order, then their number (k_list_alive_groups) */
     size_t group_alive_cap = 0, group_list_cap = 0;
+    int* vox_counters = nullptr;           /* the float pass on the root tape's code: its tile counters (kernels_voxel_jit.hip: VG_LISTS) */
     int* tile_source = nullptr;            /* per smallest tile: its index in the last tile stage's list (the float pass on the root tape's code) */
     size_t tile_source_cap = 0;
 
@@ -167,6 +168,7 @@ struct mpr_context {
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
     int voxel_gen_min_run = 5;         /* MPR_VOXEL_GEN_RUN (development): shortest run of dead clauses that gets a guard (0: none) */
     int vox_grid_cache[2] = {0, 0};
+    int voxel_gen_tiles = 0;           /* MPR_VOXEL_GEN_TILES (development): consecutive tiles a wavefront takes per atomic (default 4) */
     int voxel_gen_wgs = 0;             /* MPR_VOXEL_GEN_WGS (development): at most this many persistent workgroups per CU */
     bool tile_gen_chain = true;        /* MPR_TILE_GEN_CHAIN=0: only a frame's first stage (and, in frames that start at the 16^3 tiles, the last) */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
@@ -391,6 +393,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
+    if (const char* e = getenv("MPR_VOXEL_GEN_TILES")) c->voxel_gen_tiles = atoi(e);
     if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_CHAIN")) c->tile_gen_chain = atoi(e) != 0;
     if (const char* e = getenv("MPR_WIDE_STAGE0")) c->wide_stage0 = atoi(e) != 0;
@@ -497,6 +500,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->group_alive) (void)hipFree(c->group_alive);
     if (c->group_list) (void)hipFree(c->group_list);
     if (c->tile_source) (void)hipFree(c->tile_source);
+    if (c->vox_counters) (void)hipFree(c->vox_counters);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
     if (c->num_active) (void)hipFree(c->num_active);
@@ -544,9 +548,25 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
     if (!c || !tape) return mpr::set_error(MPR_ERR_INVALID, "null context or tape");
     HIP_TRY(hipSetDevice(c->device));
     const int len = (int)tape->clauses.size();
-    if (len < 2 || (long long)len >= c->pool_cap) return mpr::set_error(MPR_ERR_INVALID, "tape does not fit the pool");
+    if (len < 2) return mpr::set_error(MPR_ERR_INVALID, "empty tape");
     if (c->frame_pending) HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_pending = false;
+    if (c->pool_auto && (long long)len + 4096 >= c->pool_cap) {
+        /* a pool this context sized itself also grows for the root tape (pushes make it grow later, frame by frame) */
+        long long bigger = c->pool_cap;
+        while ((long long)len + 4096 >= bigger && bigger < (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) bigger *= 2;
+        bigger = std::min<long long>(bigger, (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK);
+        uint64_t* fresh = nullptr;
+        if (bigger > c->pool_cap && hipMalloc((void**)&fresh, ((size_t)bigger + 128) * sizeof(uint64_t)) == hipSuccess) {
+            (void)hipFree(c->pool);
+            c->pool = fresh;
+            c->pool_cap = bigger;
+            c->tape_serial = 0;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if ((long long)len >= c->pool_cap) return mpr::set_error(MPR_ERR_INVALID, "tape does not fit the pool");
     /* copy the tape to pool[0..len) (src/context.cu:1139-1142); skipped when already resident,
      * the pool's first len words are never overwritten by pushes */
     if (c->tape_serial != tape->serial) {
@@ -739,9 +759,68 @@ static int jit_prepare(mpr_context* c, const mpr_tape* tape, int dim, int nslots
     return MPR_OK;
 }
 
-static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const float* mat, float z,
-                        const int32_t* owner, int rank, bool brute, bool blocking)
+/* One frame being issued: what was decided before its first launch (the plan) and what its stages leave for the ones behind
+ * them.  render_frame drives frame_begin -> frame_tile_stage x (2 | 3) -> frame_float_pass -> frame_normals_pass -> frame_finish. */
+namespace {
+enum { FRAME_AGAIN = -1001,             /* the tape pool grew: the frame starts over */
+       FRAME_AGAIN_REFERENCE = -1002,   /* the tapes this frame did not push are needed after all: again, the reference's way */
+       FRAME_STOP = -1003 };            /* mpr_column_weights: the frame ends behind its first stage's evaluation */
+struct Frame {
+    mpr_context* c = nullptr;
+    const mpr_tape* tape = nullptr;
+    int dim = 0;
+    const float* mat = nullptr;
+    float z = 0.0f;
+    const int32_t* owner = nullptr;
+    int rank = 0;
+    bool brute = false, blocking = true;
+    /* the plan */
+    int S = 0;
+    hipStream_t s = nullptr;
+    unsigned long long* cnt = nullptr;     /* instrumented frame */
+    float* heat = nullptr;                 /* heatmap frame */
+    int nslots = 1, choice_cap = 0;
+    int stage_list[3] = {0, 0, 0};
+    int nstages = 0;
+    bool reference = false;                /* the reference's way: every stage from the 64 px tiles down, every tape pushed */
+    bool skip0 = false;                    /* starts at the 16^3 tiles */
+    bool tiles_only = false;               /* a reader's re-render: tile stages only */
+    mpr_context::FrameKey key;
+    /* what the stages leave behind */
+    int count = 0;                         /* tiles of the stage about to run; in the end: smallest tiles */
+    int stage_choice_cap = 0;              /* min / max clauses the tapes of the stage about to run can hold (reported by the stage before) */
+    int hint = 0;
+    bool prev_wide = false;
+    bool decisions_recorded = false;       /* the stages so far ran generated code and kept their tiles' decisions ... */
+    bool presence_recorded = false;        /* ... with the clauses of the tapes they pushed */
+    bool last_recorded = false;            /* ... down to the smallest tiles */
+    bool vox_gen_planned = false;          /* the last stage's compaction kept, per smallest tile, where it sat in that stage's list */
+    bool group_form = false;               /* the last stage recorded its groups' tapes and decisions, and the float pass takes them */
+    bool lean_now = false;                 /* the last stage pushed no tapes */
+    int group_stage = 0, group_count = 0, group_cap = 1;
+};
+/* the members under their old local names (the bodies below were one function once) */
+#define FRAME_LOCALS                                                                                                       \
+    mpr_context* const c = f.c; const mpr_tape* const tape = f.tape; const int dim = f.dim; const float* const mat = f.mat;  \
+    const float z = f.z; const int32_t* const owner = f.owner; const int rank = f.rank; const bool brute = f.brute;         \
+    const int S = f.S; hipStream_t const s = f.s; unsigned long long* const cnt = f.cnt; float* const heat = f.heat;        \
+    const int nslots = f.nslots; const int choice_cap = f.choice_cap; const int nstages = f.nstages;                         \
+    const int* const stage_list = f.stage_list; const bool reference = f.reference; const bool skip0 = f.skip0;             \
+    const bool tiles_only = f.tiles_only;                                                                                   \
+    (void)tape; (void)mat; (void)z; (void)owner; (void)rank; (void)brute; (void)S; (void)s; (void)cnt; (void)heat; (void)nslots;  \
+    (void)choice_cap; (void)nstages; (void)stage_list; (void)reference; (void)skip0; (void)tiles_only; (void)dim; (void)c
+}  // namespace
+
+/* validate, decide what kind of frame this is, reset the images and write the first tile list (one launch) */
+static int frame_begin(Frame& f)
 {
+    mpr_context* const c = f.c;
+    const mpr_tape* const tape = f.tape;
+    const int dim = f.dim, rank = f.rank;
+    const float* const mat = f.mat;
+    const float z = f.z;
+    const int32_t* const owner = f.owner;
+    const bool brute = f.brute;
     int rc = begin_frame(c, tape, owner);
     if (rc) return rc;
     if (!mat) return mpr::set_error(MPR_ERR_INVALID, "null matrix");
@@ -776,9 +855,6 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
      * upper bound counted by the backward walks), not by the root tape's min / max count: with 488 of
      * them architecture fits two waves per CU in its last tile stage, with the 58 it needs, three */
     int stage_choice_cap = choice_cap;
-    const bool dynamic_choices = c->dynamic_choices;
-    bool group_form = false;
-    int group_stage = 0, group_count = 0, group_cap = 1;
     mpr_context::FrameKey key;
     key.dim = dim;
     key.rank = rank;
@@ -788,7 +864,6 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
     /* the reference's way (every stage from the 64 px tiles down, every tape pushed): asked for, or a frame that is inspected */
     const bool reference = c->reference_frames || c->force_reference || brute || cnt || heat;
     int hint = (c->hint_serial == tape->serial && c->hint_dim == dim) ? c->hint_mode : (int)mpr_context::HINT_UNKNOWN;
-    bool lean_now = false;
     /* 3-D: the 64^3 stage of a frame up to 1024^3 is 64 wavefronts walking the whole tape one clause after the other — 0.15 ms
      * of latency on an idle chip — while ALL of its 16^3 tiles are one round of wavefronts for the next stage.  A
      * frame nobody inspects starts there: every 64^3 tile counts as ambiguous.  The hierarchy is conservative at every level, so
@@ -832,13 +907,200 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                                  c->tiles[3], count, count, nullptr, 0);
         c->tiles_n[3] = (size_t)count;
     }
+    f.S = S; f.s = s; f.cnt = cnt; f.heat = heat; f.nslots = nslots; f.choice_cap = choice_cap;
+    for (int k = 0; k < 3; ++k) f.stage_list[k] = stage_list[k];
+    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key;
+    f.count = count; f.stage_choice_cap = stage_choice_cap; f.hint = hint;
+    return MPR_OK;
+}
 
-    bool prev_wide = false;
-    bool decisions_recorded = false;       /* the stages so far ran generated code and kept their tiles' decisions ... */
-    bool presence_recorded = false;        /* ... with the clauses of the tapes they pushed */
-    bool last_recorded = false;            /* ... down to the smallest tiles */
-    bool vox_gen_planned = false;          /* the last stage's compaction kept, per smallest tile, where it sat in that stage's list */
-    for (int si = skip0 ? 1 : 0; si < nstages; ++si) {
+/* Tile stages on the root tape's generated code (tile_gen.hpp): which code stage si runs, which records it reads and writes */
+static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bool try_lean, mprk::TileStageArgs& a)
+{
+    FRAME_LOCALS;
+    int rc;
+    const int count = f.count;
+    bool& decisions_recorded = f.decisions_recorded;
+    bool& presence_recorded = f.presence_recorded;
+    bool& last_recorded = f.last_recorded;
+    {
+        /* Tile stages on the root tape's generated code (tile_gen.hpp).  The first stage: every tile walks that tape.  A stage
+         * below walks its parents' tapes as the same code with the parents' recorded decisions imposed, and — where it pushes —
+         * shortens them by the backward code that follows the parent's tape clause by clause (records with presence bits). */
+        const bool gen_here = c->gen_ok && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0 &&
+                              mprk::tile_stage_gen_possible(nslots, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
+        const bool first_stage = si == (skip0 ? 1 : 0);
+        const bool records = dim == 3 && nstages == 3 && c->tile_gen == 1 && c->normals_asm && !cnt;
+        const uint32_t* const code_full = c->gen_full_dw ? c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw : nullptr;
+        const bool chain = records && c->tile_gen_chain && code_full != nullptr;
+        auto record_into = [&](int k) -> int {
+            const int e = ensure_buffer(&c->gen_dec[k], &c->gen_dec_cap[k], (size_t)count * mprk::GEN_RECORD_U64 + 16);
+            if (e == MPR_OK) a.gen_decisions = c->gen_dec[k];
+            return e;
+        };
+        if (gen_here && first_stage && !last) {
+            a.gen_fwd = c->gen_code;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
+            decisions_recorded = false;
+            presence_recorded = false;
+            if (skip0) {
+                /* the stage below pushes nothing: the decisions are all it and the normals pass need */
+                a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
+                if (records && a.gen_bwd && (c->normals_gen || c->tile_gen_last)) {
+                    rc = record_into(i);
+                    if (rc) return rc;
+                    decisions_recorded = true;
+                }
+            } else if (chain) {
+                a.gen_bwd_full = code_full;
+                rc = record_into(i);
+                if (rc) return rc;
+                decisions_recorded = presence_recorded = true;
+            } else {
+                a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
+            }
+        } else if (gen_here && !first_stage && !last && presence_recorded && chain) {
+            a.gen_fwd = c->gen_code;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
+            a.gen_parent = c->gen_dec[stage_list[si - 1]];
+            a.gen_bwd_full = code_full;
+            rc = record_into(i);
+            if (rc) return rc;
+        } else if (gen_here && last && si == 2 && decisions_recorded && try_lean && c->tile_gen_last) {
+            /* (pushes nothing: the walk that jumps over what the parent's decisions left dead; the groups of its sample take
+             * the interpreter) */
+            a.gen_fwd = c->gen_fwdg_dw > 0 ? c->gen_code + c->gen_fwdg_at : c->gen_code;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
+            a.gen_parent = c->gen_dec[1];
+        } else if (gen_here && last && si == 2 && presence_recorded && chain && !try_lean) {
+            /* a last stage that pushes (a frame whose tiles and tapes are read): every tile gets a record of its own */
+            a.gen_fwd = c->gen_code;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
+            a.gen_parent = c->gen_dec[1];
+            a.gen_bwd_full = code_full;
+            rc = record_into(2);
+            if (rc) return rc;
+            last_recorded = true;
+        } else if (!last) {
+            decisions_recorded = presence_recorded = false;       /* an interpreted stage keeps no record: the chain ends */
+        }
+    }
+    {
+        /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
+        if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
+        std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
+        if (a.gen_fwd && count > 0) {
+            if (a.gen_parent) f += "/parent";
+            if (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) f += "+guards";
+            f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : "";
+            if (a.gen_decisions) f += "+records";
+        }
+        if (!c->stage_forms.empty()) c->stage_forms += " ";
+        c->stage_forms += std::to_string(i) + ":" + f;
+    }
+    return MPR_OK;
+}
+
+/* the stage's arguments and its launch: level-parallel (one workgroup per tile) or 64 sibling tiles per wavefront */
+static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_now, bool groups_now, bool try_lean, mprk::TileStageArgs& a)
+{
+    FRAME_LOCALS;
+    int rc;
+    const int count = f.count, stage_choice_cap = f.stage_choice_cap, hint = f.hint;
+    const bool dynamic_choices = c->dynamic_choices;
+    a.groups = groups_now ? c->groups : nullptr;
+    a.choice_masks = groups_now ? c->choice_masks : nullptr;
+    a.tape_ro = c->pool;
+    a.tape_wr = c->pool;
+    a.tape_index = c->tape_index;
+    a.pool_cap = c->pool_cap;
+    a.image = c->filled[i];
+    a.tps = tps;
+    a.tiles = c->tiles[i];
+    a.count = count;
+    a.nslots = nslots;
+    a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
+    a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
+    a.len_stats = groups_now ? c->num_active + 5 : nullptr;
+    if (c->debug_choices && si == nstages - 2) a.len_stats = c->num_active + 5;
+    a.no_push = try_lean;
+    {
+        /* the sample the stage measures its tapes on (a.len_stats): about a sixteenth of the groups while nothing is known
+         * about this tape; a sixty-fourth afterwards, and only where the launch is long enough to hide the sample's longer
+         * waves (a wrong hint costs time, never a pixel); everything in frames that push anyway */
+        const int ng = (count + 63) / 64;
+        a.measure_at[0] = ng / 4;
+        a.measure_at[1] = ng / 2;
+        if (!try_lean || hint == mpr_context::HINT_UNKNOWN) a.measure_len = std::max(ng / 32, std::min(ng, 4));
+        else a.measure_len = ng >= 32 * std::max(c->cus, 1) ? ng / 128 : 0;
+        if (c->measure_len_forced >= 0) a.measure_len = c->measure_len_forced;
+        if (a.measure_len == 0 && groups_now) a.len_stats = nullptr;
+    }
+    a.compiled_walk = !c->tiles_asm;
+    a.vgpr_slots = c->tiles_vgpr;
+    a.z = z;
+    fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
+    a.counters = cnt;
+    a.heat = heat;
+    a.heat_stride = S;
+    a.debug = c->debug_tiles;
+    if (a.debug & 4) a.debug |= si << 4;
+    if ((c->debug_tiles & 8) && last) a.debug |= 1;          /* 8: skip tape pushing in the last stage only */
+    if (heat && dim == 3) mprk::launch_mask_filled(s, c->tiles[i], count, tps, c->filled[i]);
+    TimedScope ts(c, "eval_tiles_i");
+    /* ... and only while the stage has few tiles (a workgroup per tile is latency-bound at low lane
+     * utilisation: with 32768 tiles at 2048^3 the 64-tiles-per-wave walk is 1.5x faster) */
+    if (wide_now) {
+        /* few tiles -> one workgroup per tile, level by level over the root tape's DAG */
+        mprk::WideStageArgs w;
+        w.t = a;
+        w.recs = c->sched_recs;
+        w.level_start = c->sched_levels;
+        w.nlevels = c->sched_nlevels;
+        w.nclauses = c->sched_nclauses;
+        w.root_val = c->sched_root;
+        w.root_tape = 0;
+        w.wpt = (c->sched_nclauses + 15) / 16;
+        w.prev_writer = c->sched_prev;
+        w.defs = c->sched_defs;
+        w.bits_in = si == 0 ? nullptr : c->wide_bits[(si - 1) & 1];
+        w.bits_out = nullptr;
+        if (!last && c->wide_later != 0) {          /* the next stage may run this way too */
+            rc = ensure_buffer(&c->wide_bits[si & 1], &c->wide_bits_cap[si & 1], (size_t)count * (size_t)w.wpt);
+            if (rc) return rc;
+            w.bits_out = c->wide_bits[si & 1];
+        }
+        mprk::launch_eval_tiles_wide(s, dim, w, c->wide_threads);
+    } else {
+        const bool ran_gen = mprk::launch_eval_tiles(s, dim, a);
+        if (a.gen_fwd && !ran_gen)          /* the records this frame counts on would not exist */
+            return mpr::set_error(MPR_ERR_INVALID, "internal: a tile stage planned on generated code ran another kernel");
+    }
+    return MPR_OK;
+}
+
+/* one tile stage: evaluation, compaction (+ copy_filled), the survivor count */
+static int frame_tile_stage(Frame& f, int si)
+{
+    FRAME_LOCALS;
+    int rc;
+    int& count = f.count;
+    int& stage_choice_cap = f.stage_choice_cap;
+    int& hint = f.hint;
+    bool& prev_wide = f.prev_wide;
+    bool& decisions_recorded = f.decisions_recorded;
+    bool& vox_gen_planned = f.vox_gen_planned;
+    bool& group_form = f.group_form;
+    bool& lean_now = f.lean_now;
+    int& group_stage = f.group_stage;
+    int& group_count = f.group_count;
+    int& group_cap = f.group_cap;
+    const bool dynamic_choices = c->dynamic_choices;
+    {
         const int i = stage_list[si];
         const bool last = (si == nstages - 1);
         const int next = (dim == 3) ? i + 1 : (i ? 3 : 2);
@@ -882,159 +1144,16 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             group_cap = std::max(stage_cap, 1);
         }
         mprk::TileStageArgs a;
-        {
-            /* Tile stages on the root tape's generated code (tile_gen.hpp).  The first stage: every tile walks that tape.  A stage
-             * below walks its parents' tapes as the same code with the parents' recorded decisions imposed, and — where it pushes —
-             * shortens them by the backward code that follows the parent's tape clause by clause (records with presence bits). */
-            const bool gen_here = c->gen_ok && !wide_now && !heat && !(c->debug_tiles & 3) && count > 0 &&
-                                  mprk::tile_stage_gen_possible(nslots, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
-            const bool first_stage = si == (skip0 ? 1 : 0);
-            const bool records = dim == 3 && nstages == 3 && c->tile_gen == 1 && c->normals_asm && !cnt;
-            const uint32_t* const code_full = c->gen_full_dw ? c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw + c->gen_deriv_dw : nullptr;
-            const bool chain = records && c->tile_gen_chain && code_full != nullptr;
-            auto record_into = [&](int k) -> int {
-                const int e = ensure_buffer(&c->gen_dec[k], &c->gen_dec_cap[k], (size_t)count * mprk::GEN_RECORD_U64 + 16);
-                if (e == MPR_OK) a.gen_decisions = c->gen_dec[k];
-                return e;
-            };
-            if (gen_here && first_stage && !last) {
-                a.gen_fwd = c->gen_code;
-                a.gen_words = c->gen_words;
-                a.gen_nchoices = c->gen_nchoices;
-                decisions_recorded = false;
-                presence_recorded = false;
-                if (skip0) {
-                    /* the stage below pushes nothing: the decisions are all it and the normals pass need */
-                    a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
-                    if (records && a.gen_bwd && (c->normals_gen || c->tile_gen_last)) {
-                        rc = record_into(i);
-                        if (rc) return rc;
-                        decisions_recorded = true;
-                    }
-                } else if (chain) {
-                    a.gen_bwd_full = code_full;
-                    rc = record_into(i);
-                    if (rc) return rc;
-                    decisions_recorded = presence_recorded = true;
-                } else {
-                    a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
-                }
-            } else if (gen_here && !first_stage && !last && presence_recorded && chain) {
-                a.gen_fwd = c->gen_code;
-                a.gen_words = c->gen_words;
-                a.gen_nchoices = c->gen_nchoices;
-                a.gen_parent = c->gen_dec[stage_list[si - 1]];
-                a.gen_bwd_full = code_full;
-                rc = record_into(i);
-                if (rc) return rc;
-            } else if (gen_here && last && si == 2 && decisions_recorded && try_lean && c->tile_gen_last) {
-                /* (pushes nothing: the walk that jumps over what the parent's decisions left dead; the groups of its sample take
-                 * the interpreter) */
-                a.gen_fwd = c->gen_fwdg_dw > 0 ? c->gen_code + c->gen_fwdg_at : c->gen_code;
-                a.gen_words = c->gen_words;
-                a.gen_nchoices = c->gen_nchoices;
-                a.gen_parent = c->gen_dec[1];
-            } else if (gen_here && last && si == 2 && presence_recorded && chain && !try_lean) {
-                /* a last stage that pushes (a frame whose tiles and tapes are read): every tile gets a record of its own */
-                a.gen_fwd = c->gen_code;
-                a.gen_words = c->gen_words;
-                a.gen_nchoices = c->gen_nchoices;
-                a.gen_parent = c->gen_dec[1];
-                a.gen_bwd_full = code_full;
-                rc = record_into(2);
-                if (rc) return rc;
-                last_recorded = true;
-            } else if (!last) {
-                decisions_recorded = presence_recorded = false;       /* an interpreted stage keeps no record: the chain ends */
-            }
-        }
+        rc = stage_pick_code(f, si, i, last, wide_now, try_lean, a);
+        if (rc) return rc;
         a.no_mask = c->stage0_only;
-        {
-            /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
-            if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
-            std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
-            if (a.gen_fwd && count > 0) {
-                if (a.gen_parent) f += "/parent";
-                if (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) f += "+guards";
-                f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : "";
-                if (a.gen_decisions) f += "+records";
-            }
-            if (!c->stage_forms.empty()) c->stage_forms += " ";
-            c->stage_forms += std::to_string(i) + ":" + f;
-        }
         if (count > 0) {
-            a.groups = groups_now ? c->groups : nullptr;
-            a.choice_masks = groups_now ? c->choice_masks : nullptr;
-            a.tape_ro = c->pool;
-            a.tape_wr = c->pool;
-            a.tape_index = c->tape_index;
-            a.pool_cap = c->pool_cap;
-            a.image = c->filled[i];
-            a.tps = tps;
-            a.tiles = c->tiles[i];
-            a.count = count;
-            a.nslots = nslots;
-            a.choice_cap = dynamic_choices ? stage_choice_cap : choice_cap;
-            a.next_choices = dynamic_choices ? c->num_active + 4 : nullptr;
-            a.len_stats = groups_now ? c->num_active + 5 : nullptr;
-            if (c->debug_choices && si == nstages - 2) a.len_stats = c->num_active + 5;
-            a.no_push = try_lean;
-            {
-                /* the sample the stage measures its tapes on (a.len_stats): about a sixteenth of the groups while nothing is known
-                 * about this tape; a sixty-fourth afterwards, and only where the launch is long enough to hide the sample's longer
-                 * waves (a wrong hint costs time, never a pixel); everything in frames that push anyway */
-                const int ng = (count + 63) / 64;
-                a.measure_at[0] = ng / 4;
-                a.measure_at[1] = ng / 2;
-                if (!try_lean || hint == mpr_context::HINT_UNKNOWN) a.measure_len = std::max(ng / 32, std::min(ng, 4));
-                else a.measure_len = ng >= 32 * std::max(c->cus, 1) ? ng / 128 : 0;
-                if (c->measure_len_forced >= 0) a.measure_len = c->measure_len_forced;
-                if (a.measure_len == 0 && groups_now) a.len_stats = nullptr;
-            }
-            a.compiled_walk = !c->tiles_asm;
-            a.vgpr_slots = c->tiles_vgpr;
-            a.z = z;
-            fill_mat(a.mat, mat, dim == 3 ? 16 : 9);
-            a.counters = cnt;
-            a.heat = heat;
-            a.heat_stride = S;
-            a.debug = c->debug_tiles;
-            if (a.debug & 4) a.debug |= si << 4;
-            if ((c->debug_tiles & 8) && last) a.debug |= 1;          /* 8: skip tape pushing in the last stage only */
-            if (heat && dim == 3) mprk::launch_mask_filled(s, c->tiles[i], count, tps, c->filled[i]);
-            TimedScope ts(c, "eval_tiles_i");
-            /* ... and only while the stage has few tiles (a workgroup per tile is latency-bound at low lane
-             * utilisation: with 32768 tiles at 2048^3 the 64-tiles-per-wave walk is 1.5x faster) */
-            if (wide_now) {
-                /* few tiles -> one workgroup per tile, level by level over the root tape's DAG */
-                mprk::WideStageArgs w;
-                w.t = a;
-                w.recs = c->sched_recs;
-                w.level_start = c->sched_levels;
-                w.nlevels = c->sched_nlevels;
-                w.nclauses = c->sched_nclauses;
-                w.root_val = c->sched_root;
-                w.root_tape = 0;
-                w.wpt = (c->sched_nclauses + 15) / 16;
-                w.prev_writer = c->sched_prev;
-                w.defs = c->sched_defs;
-                w.bits_in = si == 0 ? nullptr : c->wide_bits[(si - 1) & 1];
-                w.bits_out = nullptr;
-                if (!last && c->wide_later != 0) {          /* the next stage may run this way too */
-                    rc = ensure_buffer(&c->wide_bits[si & 1], &c->wide_bits_cap[si & 1], (size_t)count * (size_t)w.wpt);
-                    if (rc) return rc;
-                    w.bits_out = c->wide_bits[si & 1];
-                }
-                mprk::launch_eval_tiles_wide(s, dim, w, c->wide_threads);
-            } else {
-                const bool ran_gen = mprk::launch_eval_tiles(s, dim, a);
-                if (a.gen_fwd && !ran_gen)          /* the records this frame counts on would not exist */
-                    return mpr::set_error(MPR_ERR_INVALID, "internal: a tile stage planned on generated code ran another kernel");
-            }
+            rc = stage_launch(f, si, i, tps, last, wide_now, groups_now, try_lean, a);
+            if (rc) return rc;
         }
         if (c->stage0_only) {
             HIP_TRY(hipStreamSynchronize(s));
-            return MPR_OK;
+            return FRAME_STOP;
         }
         /* worst case: every tile survives */
         rc = ensure_tiles(c, next, last ? (size_t)std::max(count, 1) : (size_t)std::max(count, 1) * 64);
@@ -1124,7 +1243,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 c->pool = fresh;
                 c->pool_cap = bigger;
                 c->tape_serial = 0;                  /* the root tape has to be copied in again */
-                return render_frame(c, tape, dim, mat, z, owner, rank, brute, blocking);
+                return FRAME_AGAIN;
             }
             (void)hipGetLastError();                 /* no memory for a larger pool: carry on with the fallback, as the reference would */
         }
@@ -1136,18 +1255,19 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         c->tiles_n[next] = (size_t)count;
         prev_wide = wide_now && c->wide_later != 0;
     }
-    c->last.voxel_tiles = count;
-    if (tiles_only) {
-        /* a reader's re-render: tiles and tapes are the reference's now; heights and normals were all along */
-        HIP_TRY(hipGetLastError());
-        c->frame_pending = true;
-        c->pending_dim = dim;
-        c->last_frame_lean = false;
-        c->last_frame_fast = false;
-        c->last_key = key;
-        return blocking ? mpr_ctx_sync(c) : MPR_OK;
-    }
-    if (count > 0) {
+    return MPR_OK;
+}
+
+/* eval_voxels_f: the smallest tiles' voxels / pixels */
+static int frame_float_pass(Frame& f)
+{
+    FRAME_LOCALS;
+    int rc;
+    const int count = f.count;
+    const bool group_form = f.group_form, lean_now = f.lean_now, vox_gen_planned = f.vox_gen_planned;
+    const int group_stage = f.group_stage, group_count = f.group_count, group_cap = f.group_cap;
+    if (count <= 0) return MPR_OK;
+    {
         mprk::VoxelArgs v;
         v.tape_ro = c->pool;
         v.image = c->filled[3];
@@ -1169,8 +1289,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             int& grid = c->vox_grid_cache[dim - 2];
             if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
             const int use_grid = c->voxel_gen_wgs > 0 ? std::min(grid, c->voxel_gen_wgs * c->cus) : grid;
+            if (!c->vox_counters) HIP_TRY(hipMalloc((void**)&c->vox_counters, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int)));
+            HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
             mprk::launch_eval_voxels_gen(s, dim, v, c->gen_code + c->gen_vox_at, use_grid, c->tile_source, c->groups, c->choice_masks, group_cap,
-                                         c->num_active + 7, c->gen_dec[1], c->gen_nchoices);
+                                         c->vox_counters, c->gen_dec[1], c->gen_nchoices,
+                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : count >= (1 << 18) ? 8 : 4);      /* (measured: bear 1024^3 0.816 ms
+                                                                                           with 8, 0.831 with 4; 256^3 0.128 / 0.113) */
             jitted = on_root_code = true;
         }
         if (!cnt && !heat && !jitted) {
@@ -1195,10 +1319,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (lean_now && !(jitted && group_form)) {
             /* no executable memory after all (the allocation above failed): the tapes this frame did not push are needed — the
              * whole frame again, the reference's way */
-            c->force_reference = true;
-            const int again = render_frame(c, tape, dim, mat, z, owner, rank, brute, blocking);
-            c->force_reference = false;
-            return again;
+            return FRAME_AGAIN_REFERENCE;
         }
         if (on_root_code) {
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_gen<%d>", dim);
@@ -1213,7 +1334,16 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels<%d>", dim);
         }
     }
-    if (dim == 3) {
+    return MPR_OK;
+}
+
+/* eval_pixels_d: the normals of the heightmap's pixels */
+static int frame_normals_pass(Frame& f)
+{
+    FRAME_LOCALS;
+    const bool group_form = f.group_form, lean_now = f.lean_now, decisions_recorded = f.decisions_recorded, last_recorded = f.last_recorded;
+    const int group_stage = f.group_stage, group_cap = f.group_cap;
+    {
         mprk::NormalArgs n;
         n.tape_ro = c->pool;
         n.image = c->filled[3];
@@ -1259,16 +1389,53 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         else mprk::launch_eval_normals(s, n);
         c->normals_kernel = !(c->normals_asm && !cnt) ? "k_eval_normals_q" : n.gen_code ? "k_eval_normals_gen" : "k_eval_normals_asm";
     }
-    HIP_TRY(hipGetLastError());
-    c->frame_pending = true;
-    c->pending_dim = dim;
-    c->last_frame_lean = lean_now;
-    c->last_frame_fast = lean_now || skip0;
-    c->last_key = key;
-    if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != tape->serial)) c->last_tape.reset(new mpr_tape(*tape));
-    if (blocking) return mpr_ctx_sync(c);
     return MPR_OK;
 }
+
+static int frame_finish(Frame& f)
+{
+    mpr_context* const c = f.c;
+    HIP_TRY(hipGetLastError());
+    c->frame_pending = true;
+    c->pending_dim = f.dim;
+    c->last_frame_lean = f.lean_now && !f.tiles_only;
+    c->last_frame_fast = (f.lean_now || f.skip0) && !f.tiles_only;
+    c->last_key = f.key;
+    if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != f.tape->serial)) c->last_tape.reset(new mpr_tape(*f.tape));
+    return f.blocking ? mpr_ctx_sync(c) : MPR_OK;
+}
+
+static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const float* mat, float z,
+                        const int32_t* owner, int rank, bool brute, bool blocking)
+{
+    for (;;) {
+        Frame f;
+        f.c = c; f.tape = tape; f.dim = dim; f.mat = mat; f.z = z; f.owner = owner; f.rank = rank; f.brute = brute; f.blocking = blocking;
+        int rc = frame_begin(f);
+        if (rc) return rc;
+        for (int si = f.skip0 ? 1 : 0; si < f.nstages && rc == MPR_OK; ++si) rc = frame_tile_stage(f, si);
+        if (rc == FRAME_AGAIN) continue;
+        if (rc == FRAME_STOP) return MPR_OK;
+        if (rc) return rc;
+        c->last.voxel_tiles = f.count;
+        if (!f.tiles_only) {          /* (a reader's re-render: tiles and tapes are the reference's now; heights and normals were all along) */
+            rc = frame_float_pass(f);
+            if (rc == FRAME_AGAIN_REFERENCE) {
+                c->force_reference = true;
+                rc = render_frame(c, tape, dim, mat, z, owner, rank, brute, blocking);
+                c->force_reference = false;
+                return rc;
+            }
+            if (rc) return rc;
+            if (dim == 3) {
+                rc = frame_normals_pass(f);
+                if (rc) return rc;
+            }
+        }
+        return frame_finish(f);
+    }
+}
+
 
 /* A reader of tiles, tapes or counters wants the state the reference leaves: if the last frame took a shortcut (no tapes from
  * its last tile stage, or no 64^3 stage) the frame is rendered again the reference's way — same tape (the context kept a copy),
@@ -1361,7 +1528,12 @@ int mpr_column_weights(mpr_context* c, const mpr_tape* t, int32_t dim, const flo
     const int rc = render_frame(c, t, dim, mat, z, nullptr, 0, false, true);
     c->force_reference = false;
     c->stage0_only = false;
+    /* the previous frame is gone (its images were cleared, its first tile list overwritten): readers get what is there — this
+     * call's first stage — until the next frame is rendered */
     c->last_frame_fast = false;
+    c->last_frame_lean = false;
+    c->last_tape.reset();
+    for (int i = 1; i < 4; ++i) c->tiles_n[i] = 0;
     if (rc) return rc;
     const int t0 = c->S / 64, cols = t0 * t0;
     const size_t n = (size_t)cols * (dim == 3 ? t0 : 1);

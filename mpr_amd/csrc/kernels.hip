@@ -1260,8 +1260,8 @@ void launch_install_code(hipStream_t s, uint32_t* exec_dst, const uint32_t* src,
 {
     hipLaunchKernelGGL(k_copy_code, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, s, exec_dst, src, dwords);
     /* (a kernel boundary writes the copy back to memory; the instruction caches are not part of that) */
-    static const hipError_t lds_opt_in = hipFuncSetAttribute(reinterpret_cast<const void*>(k_icache_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)lds_opt_in;
+    /* (per call: the attribute belongs to the device that is current, and contexts may live on several) */
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_icache_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipLaunchKernelGGL(k_icache_inv, dim3((unsigned)cus), dim3(1024), 96 * 1024, s);
 }
 static CopyFilled copy_filled_args(const int* prev, int* next, int size, int first_block, unsigned* extra)

@@ -189,11 +189,12 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
                             const int* group_list, bool always_invalidate = false);
 /* same pass on the ROOT tape's host-generated code (voxel_gen.hpp) with the tiles' recorded decisions: a.tiles / a.count = the smallest
  * tiles, source[t] = tile t's index in the last tile stage's list (launch_compact_*: source_out), groups / masks of that stage,
- * parent_records: the records of the tiles of the stage above it; tile_counter: zero at the start of the frame */
+ * parent_records: the records of the tiles of the stage above it; tile_counter: voxel_gen_counter_ints() zeroed ints */
 int voxel_gen_grid(int dim, int cus);
+int voxel_gen_counter_ints();
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
-                            int nchoices);
+                            int nchoices, int run = 0);
 void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
                            unsigned long long dr);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,

@@ -1030,15 +1030,21 @@ struct GenVoxelArgs {
     const GroupInfo* groups;
     const ulonglong2* choice_masks;
     int choice_cap;
-    int* tile_counter;                 /* the next tile to hand out (zero at the start of the frame) */
+    int* tile_counter;                 /* VG_LISTS counters, VG_COUNTER_STRIDE ints apart, zero when the kernel starts */
     const unsigned long long* parent_records;   /* records of the tiles of the stage above (GEN_RECORD_U64 words each) */
     int nchoices;                      /* min / max clauses of the root tape */
+    int run;                           /* consecutive tiles a wavefront takes per atomic */
 };
 
-/* A wavefront per smallest tile, taken in list order (front to back: the tiles behind a surface find it drawn) with one atomic
- * each — nothing is shared between the tiles of a group any more (the group form's workgroup translated one tape for its 64
- * children and waited for the slowest of its four wavefronts), so there is no barrier, no idle wavefront at the end of a group,
- * and a rank with an eighth of the tiles (multi-GPU) ends when its last TILE does, not its last group. */
+/* A wavefront per smallest tile, in list order (front to back: the tiles behind a surface find it drawn).  Nothing is shared
+ * between the tiles of a group any more (the group form's workgroup translated one tape for its 64 children and waited for the
+ * slowest of its four wavefronts): no barrier, no idle wavefront at the end of a group, and a rank with an eighth of the tiles
+ * (multi-GPU) ends when its last handful of tiles does, not its last group.
+ * Handing out: runs of VG_RUN consecutive tiles, one atomic each — but not on ONE word: same-address atomics serialise at about
+ * 12 ns each on this part, and one per tile (0.58 M for bear 1024^3) made the counter the kernel: 6.7 ms instead of 0.8.  The
+ * runs are dealt round robin to VG_LISTS counters a cache line or more apart; a wavefront works through the counter of its own
+ * number first and helps with the others when that one runs dry. */
+constexpr int VG_RUN = 4, VG_LISTS = 8, VG_COUNTER_STRIDE = 64;      /* (ints between counters; VG_RUN: the default of GenVoxelArgs::run) */
 template <int DIM>
 __global__ void __launch_bounds__(64, 6)         /* (7 waves per SIMD would take the SGPRs the routines name away: s90..s95) */
 k_eval_voxels_gen(GenVoxelArgs j)
@@ -1046,37 +1052,45 @@ k_eval_voxels_gen(GenVoxelArgs j)
     const VoxelArgs& a = j.v;
     const int lane = threadIdx.x;
     const unsigned long long all = j.nchoices >= 64 ? ~0ull : ((1ull << j.nchoices) - 1ull);
-    for (;;) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(j.tile_counter, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= a.count) break;
-        const int position = __builtin_amdgcn_readfirstlane(a.tiles[t].position);
-        JitVoxel<DIM> vox;
-        if (!vox.setup(a, position, lane)) continue;
-        const int src = __builtin_amdgcn_readfirstlane(j.source[t]);
-        const int g = src >> 6, c = src & 63;
-        const GroupInfo gi = j.groups[g];
-        /* what the tile above decided (and everything above it), and the min / max clauses its tape keeps: the group's masks are
-         * numbered by those */
-        unsigned long long L = 0, R = 0, K = all;
-        if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
-            const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
-            L = rfl64(rec[0]);
-            R = rfl64(rec[1]);
-            K = rfl64(rec[2]);
+    const int run_len = j.run;
+    const int nruns = (a.count + run_len - 1) / run_len;
+    for (int turn = 0; turn < VG_LISTS; ++turn) {
+        const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
+        for (;;) {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(j.tile_counter + list * VG_COUNTER_STRIDE, 1);
+            const int run = __builtin_amdgcn_readfirstlane(q) * VG_LISTS + list;
+            if (run >= nruns) break;
+            for (int t = run * run_len; t < min(run * run_len + run_len, a.count); ++t) {
+                const int position = __builtin_amdgcn_readfirstlane(a.tiles[t].position);
+                JitVoxel<DIM> vox;
+                if (!vox.setup(a, position, lane)) continue;
+                const int src = __builtin_amdgcn_readfirstlane(j.source[t]);
+                const int g = src >> 6, c = src & 63;
+                const GroupInfo gi = j.groups[g];
+                /* what the tile above decided (and everything above it), and the min / max clauses its tape keeps: the group's
+                 * masks are numbered by those */
+                unsigned long long L = 0, R = 0, K = all;
+                if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
+                    const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
+                    L = rfl64(rec[0]);
+                    R = rfl64(rec[1]);
+                    K = rfl64(rec[2]);
+                }
+                /* lane k: root clause k is the i-th clause that tape keeps; its mask's bit c = this tile's decision there */
+                const bool kept = (K >> lane) & 1ull;
+                const int i = __popcll(K & ((1ull << lane) - 1ull));
+                ulonglong2 mk = make_ulonglong2(0ull, 0ull);
+                if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
+                const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
+                const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
+                vox.finish(a, res);
+            }
         }
-        /* lane k: root clause k is the i-th clause that tape keeps; its mask's bit c = this tile's decision there */
-        const bool kept = (K >> lane) & 1ull;
-        const int i = __popcll(K & ((1ull << lane) - 1ull));
-        ulonglong2 mk = make_ulonglong2(0ull, 0ull);
-        if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
-        const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
-        const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
-        vox.finish(a, res);
     }
 }
 
+int voxel_gen_counter_ints() { return VG_LISTS * VG_COUNTER_STRIDE; }
 int voxel_gen_grid(int dim, int cus)
 {
     int per_cu = 0;
@@ -1087,10 +1101,11 @@ int voxel_gen_grid(int dim, int cus)
 }
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
-                            int nchoices)
+                            int nchoices, int run)
 {
     if (a.count <= 0) return;
     GenVoxelArgs j;
+    j.run = run > 0 ? run : VG_RUN;
     j.v = a;
     j.code = code;
     j.source = source;

@@ -51,6 +51,37 @@ def routine_bodies():
     return out
 
 
+def host_generated(R):
+    """The float walk the HOST generates (csrc/voxel_gen.cpp) for the tapes it takes: the instructions a walk of the whole root tape
+    executes (nothing decided: no run jumped over), disassembled with llvm-mc; the routines it still calls (sin / cos, general
+    division) from their assembly text."""
+    import ctypes, struct, subprocess
+    mc = "/opt/rocm/lib/llvm/bin/llvm-mc"
+    out = {}
+    if not os.path.exists(mc):
+        return out
+    for model in ("bear",):
+        d = np.ascontiguousarray(m.Tape(m.model(model)).data, dtype=np.uint64)
+        buf = (ctypes.c_uint32 * 131072)()
+        info = (ctypes.c_int32 * 3)()
+        n = m.lib().mpr_test_voxel_gen(d.ctypes.data, len(d), 0, buf, 131072, info)      # no guards: the straight walk
+        if n < 0:
+            continue
+        text = ",".join("0x%02x" % b for w in buf[:n] for b in struct.pack("<I", w))
+        dis = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-disassemble"], input=text.encode(), capture_output=True, check=True).stdout.decode()
+        lines = [" ".join(l.split()) for l in dis.splitlines() if l.strip() and not l.strip().startswith(".")]
+        main_code = lines[:next(k for k, l in enumerate(lines) if l.startswith("s_setpc_b64 s[72:73]"))]       # the stubs behind it never run here
+        total = classify("\n".join(main_code))
+        calls = collections.Counter(l.split(",")[-1].strip() for l in main_code if l.startswith("s_swappc_b64"))
+        total = total + calls.get("s[52:53]", 0) * R["DIV"] + calls.get("s[60:61]", 0) * (R["SINCOS"] + np.array([2.0, 0, 0])) + \
+            calls.get("s[62:63]", 0) * np.array([1.0, 1, 0])                      # (bear: every cosine is of the argument just seen)
+        frac = total / total.sum()
+        out[model] = {"full": round(float(frac[0]), 4), "half": round(float(frac[1]), 4), "quarter": round(float(frac[2]), 4),
+                      "valu_per_walk_of_the_root_tape": float(total.sum()), "issue_units_per_walk": float(total @ np.array([1.0, 2.0, 4.0])),
+                      "guarded_runs": int(info[1]), "note": "a tile's walk runs 451 of the 544 clauses on average (scripts/skip_study.py)"}
+    return out
+
+
 def main():
     R = routine_bodies()
     one = np.array([1.0, 0, 0])
@@ -110,6 +141,7 @@ def main():
                              "valu_per_walk_of_the_root_tape": float(total.sum()), "issue_units_per_walk": units,
                              "issue_units_by_opcode": {k: round(v / units, 4) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}
     result["k_eval_voxels_jit_groups"] = per_kernel
+    result["k_eval_voxels_gen"] = host_generated(R)
     with open(os.path.join(ROOT, "profiles", "valu_mix.json"), "w") as f:
         json.dump(result, f, indent=1)
         f.write("\n")
