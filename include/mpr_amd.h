@@ -242,6 +242,10 @@ const char* mpr_ctx_normals_kernel(const mpr_context* ctx);
  * decisions imposed, +guards = jumping over what they left dead, +bwd / +bwd_full = tapes pushed by generated code too.  Tests assert
  * the path they mean to exercise with it.  Owned by the context. */
 const char* mpr_ctx_tile_stage_forms(const mpr_context* ctx);
+/* Tiles of the last frame as it ran (no re-render; mpr_get_counters gives the reference's): out[0..2] tiles evaluated per stage,
+ * out[3..5] tiles left ambiguous, out[6] smallest tiles handed to the float pass.  A frame nobody reads may start at the 16^3
+ * tiles and cull with sound but looser bounds than the reference: the same heights and normals from a few more tiles. */
+int mpr_ctx_frame_tiles(mpr_context* ctx, int64_t out[7]);
 
 /* 1 when the last frame's last tile stage pushed per-tile tapes (the reference's state), 0 when it did not need to (its own
  * sample of the tapes it would push said that float and normals pass do as well on the tapes it walked: DESIGN.md 3).
@@ -303,6 +307,12 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
 /* the square-root routine of the float interpreters and of the generated code on the bit patterns [first, first + count): the
  * number of results that are not the correctly rounded root (NaN for NaN counts as equal), and one such input */
 int mpr_test_sqrt_all(int32_t device, uint64_t first, uint64_t count, uint64_t* mismatches, uint32_t* example);
+/* the tile stages' exp / log enclosures of frames nobody reads (hardware base-2 instructions, widened by their error bound:
+ * csrc/tile_gen_asm.hpp) on every bit pattern of [first, first + count) that lies in their domain, as the interval [x, x],
+ * against the correctly rounded enclosure: ends that fail to enclose it (must be 0), one such pattern, operands tested, the
+ * widest result in units of 2^-24 of the value.  op: MPR_OP_EXP_LHS or MPR_OP_LOG_LHS */
+int mpr_test_loose_interval(int32_t device, int32_t op, uint64_t first, uint64_t count, uint64_t* not_enclosing, uint32_t* example,
+                            uint64_t* tested, uint64_t* widest_2m24);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
                       float imm, float* out4);

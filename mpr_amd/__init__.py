@@ -169,6 +169,7 @@ def lib():
     L.mpr_ctx_last_stage_pushed.restype = i32
     L.mpr_ctx_float_kernel.restype = ctypes.c_char_p
     L.mpr_ctx_normals_kernel.restype = ctypes.c_char_p
+    L.mpr_ctx_frame_tiles.argtypes = [vp, vp]
     L.mpr_ctx_tile_stage_forms.argtypes = [vp]
     L.mpr_ctx_tile_stage_forms.restype = ctypes.c_char_p
     L.mpr_tape_schedule_info.argtypes = [vp, P(i32), P(i32), vp]
@@ -194,6 +195,7 @@ def lib():
     L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_sqrt_all.argtypes = [i32, ctypes.c_uint64, ctypes.c_uint64, vp, vp]
+    L.mpr_test_loose_interval.argtypes = [i32, i32, ctypes.c_uint64, ctypes.c_uint64, vp, vp, vp, vp]
     L.mpr_test_jit_row.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_uint32, i32, vp, i32]
     L.mpr_test_tile_gen.argtypes = [vp, i32, i32, vp, i32]
     L.mpr_test_tile_gen.restype = ctypes.c_int
@@ -576,6 +578,12 @@ class Context:
         """The form each tile stage of the last frame took (mpr_ctx_tile_stage_forms), e.g. "1:gen+bwd+records 2:gen/parent+guards"."""
         return lib().mpr_ctx_tile_stage_forms(self._h).decode()
 
+    def frame_tiles(self):
+        """Tiles of the last frame as it ran (mpr_ctx_frame_tiles): (evaluated per stage [3], left ambiguous [3], smallest tiles)."""
+        a = np.zeros(7, dtype=np.int64)
+        _check(lib().mpr_ctx_frame_tiles(self._h, _ptr(a)))
+        return a[:3].tolist(), a[3:6].tolist(), int(a[6])
+
     def float_kernel(self):
         """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""
         return lib().mpr_ctx_float_kernel(self._h).decode()
@@ -723,6 +731,15 @@ def dev_float_op_gen(op, a, b=None, imm=0.0, device=0, variant=0, dl=0, dr=0):
     out = np.empty_like(a)
     _check(lib().mpr_test_float_op_gen(device, op, variant, dl, dr, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
     return out
+
+
+def dev_loose_interval(op, first=0, count=1 << 32, device=0):
+    """The loose exp / log enclosures (csrc/tile_gen_asm.hpp) on the bit patterns [first, first + count) of their domain against
+    the exact routine's: (ends that fail to enclose, one such pattern, operands tested, widest result in 2^-24 of the value)."""
+    bad, tested, widest = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    ex = ctypes.c_uint32(0)
+    _check(lib().mpr_test_loose_interval(device, op, first, count, ctypes.byref(bad), ctypes.byref(ex), ctypes.byref(tested), ctypes.byref(widest)))
+    return int(bad.value), int(ex.value), int(tested.value), int(widest.value)
 
 
 def dev_sqrt_all(first=0, count=1 << 32, device=0):

@@ -163,6 +163,7 @@ struct mpr_context {
     std::shared_ptr<const mpr::TapeCode> resident_code;   /* what gen_code holds (kept alive: the upload is asynchronous) */
     int gen_vox_at = 0, gen_fwdg_at = 0;   /* where the float walk / the guarded forward walk start in gen_code (dwords) */
     int gen_fwdg_dw = 0;               /* dwords of the forward walk with guarded dead runs (TileGen::fwd_guarded), behind the float walk (0: none) */
+    bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
@@ -391,6 +392,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_TILES")) c->voxel_gen_tiles = atoi(e);
@@ -990,12 +992,15 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         }
     }
     {
+        /* frames nobody reads owe the reference heights and normals, not tile occupancy: sound but wider exp / log enclosures */
+        a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose;
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
         std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
         if (a.gen_fwd && count > 0) {
             if (a.gen_parent) f += "/parent";
             if (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) f += "+guards";
+            if (a.gen_loose) f += "+loose";
             f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : "";
             if (a.gen_decisions) f += "+records";
         }
@@ -1458,6 +1463,20 @@ extern "C" {
 
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
 const char* mpr_ctx_tile_stage_forms(const mpr_context* c) { return c ? c->stage_forms.c_str() : ""; }
+/* tiles of the last frame AS IT RAN (no re-render: a frame nobody reads may start at the 16^3 tiles and cull with looser bounds than
+ * the reference): per stage the tiles evaluated and the tiles left ambiguous, then the smallest tiles handed to the float pass */
+int mpr_ctx_frame_tiles(mpr_context* c, int64_t out[7])
+{
+    if (!c || !out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; ++i) {
+        out[i] = c->last.tiles_in[i];
+        out[3 + i] = c->last.tiles_active[i];
+    }
+    out[6] = c->last.voxel_tiles;
+    return MPR_OK;
+}
 
 int mpr_ctx_sync(mpr_context* c)
 {
@@ -2039,6 +2058,27 @@ int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t 
     HIP_TRY(e1);
     HIP_TRY(e2);
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+/* the loose exp / log enclosures of frames nobody reads (tile_gen_asm.hpp) on the bit patterns [first, first + count) that lie in
+ * their domain, against the exact routine's: ends that fail to enclose, one such bit pattern, operands tested, widest result */
+int mpr_test_loose_interval(int32_t device, int32_t op, uint64_t first, uint64_t count, uint64_t* not_enclosing, uint32_t* example,
+                            uint64_t* tested, uint64_t* widest_2m24)
+{
+    if (!not_enclosing || (op != MPR_OP_EXP_LHS && op != MPR_OP_LOG_LHS)) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf d;
+    HIP_TRY(d.alloc(32));
+    HIP_TRY(hipMemset(d.p, 0, 32));
+    mprk::launch_test_loose_interval(nullptr, op, first, count, (unsigned long long*)d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost));
+    *not_enclosing = h[0];
+    if (example) *example = (uint32_t)h[1];
+    if (tested) *tested = h[2];
+    if (widest_2m24) *widest_2m24 = h[3];
     return MPR_OK;
 }
 /* the square-root routine of the float interpreters / generated code on the bit patterns [first, first + count): number of results

@@ -283,7 +283,7 @@ k_eval_tiles(TileStageArgs a)
         gen_keeps = keeps;
         tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
                          2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                         make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r);
+                         make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, a.gen_loose);
         chl[0] &= (uint32_t)keeps; chl[1] &= (uint32_t)(keeps >> 32);
         chr[0] &= (uint32_t)keeps; chr[1] &= (uint32_t)(keeps >> 32);
         ci = __popcll(keeps);
@@ -1081,6 +1081,50 @@ __global__ void k_test_interval(int op, int n, const float* a_lo, const float* a
         out_hi[i] = r.hi;
         if (choice) choice[i] = c;
     }
+}
+/* The loose exp / log of frames nobody reads (tile_gen_asm.hpp: TG_FEXP_CORE / TG_FLOG_CORE) on every float of their domain,
+ * each as the degenerate interval [x, x], against the exact routine's enclosure: out[0] = ends that do NOT enclose (must be 0),
+ * out[1] = one such bit pattern, out[2] = operands tested, out[3] = the largest width met, in units of 2^-24 of the value. */
+__global__ void __launch_bounds__(256)
+k_test_loose_interval(int op, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    float dummy0 = 0, dummy1 = 0, dummy2 = 0, dummy3 = 0, dummy4 = 0, dummy5 = 0;
+    round_up_begin(dummy0, dummy1, dummy2, dummy3, dummy4, dummy5);
+    unsigned long long bad = 0, tested = 0, example = 0, widest = 0;
+    for (unsigned long long k = threadIdx.x + (unsigned long long)blockIdx.x * blockDim.x; k < count; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t bits = (uint32_t)(first + k);
+        const float x = mpr_u2f(bits);
+        const bool in_domain = op == MPR_OP_EXP_LHS ? (__builtin_fabsf(x) <= 80.0f) : (bits >= 0x0D800000u && bits <= 0x71800000u);
+        if (!in_domain) continue;
+        int c = 0;
+        const ival exact = interval_clause((uint32_t)op, iv(x, x), iv(0.0f, 0.0f), 0.0f, c);
+        float lo, hi;
+        if (op == MPR_OP_EXP_LHS)
+            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FEXP_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                         : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+        else
+            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FLOG_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                         : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+        ++tested;
+        if (!(lo <= exact.lo && hi >= exact.hi)) {
+            ++bad;
+            example = bits;
+        }
+        const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
+        const double scale = __builtin_fabs(mid) > 1e-30 ? __builtin_fabs(mid) : 1e-30;
+        const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
+        if (units > widest) widest = units;
+    }
+    if (bad) {
+        atomicAdd(&out[0], bad);
+        out[1] = example;
+    }
+    atomicAdd(&out[2], tested);
+    atomicMax(&out[3], widest);
+}
+void launch_test_loose_interval(hipStream_t s, int op, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_test_loose_interval, dim3(2048), dim3(256), 0, s, op, first, count, out);
 }
 /* one clause through the assembly forward walk of the tile stages: tape = {head (slots 1, 2, 3),
  * [copy], the clause (out = slot 4), end}; 64 operand pairs per wave; slot 3 is unused */

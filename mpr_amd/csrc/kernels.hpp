@@ -74,6 +74,8 @@ struct TileStageArgs {
                                                * too, or this launch is such a stage (gen_parent): the walk that follows the PARENT's tape clause
                                                * by clause and records the clauses of the tape it writes (tile_gen.cpp) */
     int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
+    bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened
+                                          * by their error bound, instead of the correctly rounded ones (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */
     const unsigned long long* gen_parent = nullptr;   /* with gen_fwd, instead of gen_bwd: the launch is the stage BELOW the one that wrote these records
                                                        * (gen_decisions there): its tiles walk their parents' shortened tapes — as the root tape's
                                                        * generated code with the parent's decisions imposed, their own renumbered to that tape's */
@@ -216,6 +218,7 @@ void launch_debug_interp_cycles(hipStream_t s, const uint64_t* tape, int reps, l
 void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
                           const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice);
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
+void launch_test_loose_interval(hipStream_t s, int op, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
 
 /* mpr::Effects (kernels_effects.hip) */

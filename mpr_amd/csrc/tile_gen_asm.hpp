@@ -18,6 +18,69 @@ namespace mprk {
 /* entry point of a routine, relative to L_pc (s[40:41]) */
 #define TG_ADDR(lo, hi, label) "s_add_u32 s" #lo ", s40, " label "_%=-L_pc_%=\n s_addc_u32 s" #hi ", s41, 0\n"
 
+/* ---- exp and log of an interval WITHOUT double precision, for frames nobody reads (round 4) ----
+ * The tile stages' exp / log (reference inc/gpu_interval.hpp:332-336, :382-390) are the correctly rounded enclosures
+ * {RD(exp(lo)), RU(exp(hi))}, computed in double precision (OCML: 119 / 361 instructions per clause, most at the f64 rate): half of
+ * the generated forward walk of bear's tape.  Which tiles a stage finds empty / filled / ambiguous, and which min / max clauses it
+ * decides, is reference state only in frames that are READ; an ordinary frame (context.hip: !reference) owes the reference its
+ * heights and normals, and those do not depend on how tight a SOUND enclosure is: a wider interval leaves a tile ambiguous that
+ * the reference would have culled or filled (its children / voxels are evaluated and give the same heights: the hierarchy is
+ * conservative at every level) or a min / max undecided that the reference would have decided (the comparison then picks the same
+ * operand at every point).  So those frames take the hardware's v_exp_f32 / v_log_f32 (base 2) and widen the result by an error
+ * bound that covers the argument's rounding, the constant's and the instruction's:
+ *   exp:  t = RU(x log2e),  r = v_exp_f32(t),  k = (|t| + 4) 2^-23:        [RD(r - r k), RU(r + r k)]
+ *         (t is off by at most |t| 1.13 2^-23: a factor 2^(that) = 1 +- 0.79 |t| 2^-23 on the result; v_exp_f32: 1 ulp, 2 assumed)
+ *   log:  p = RU(v_log_f32(x) ln2),  e = (|p| + 1) 2^-21:                  [RD(p - e), RU(p + e)]
+ * about 1e-5 relative where the exact route has 6e-8, on values that feed sums of terms of magnitude 1 over tiles whose natural
+ * extension is 0.3 wide: the classification barely moves (DESIGN.md has the counts).  Only when EVERY lane's ends are ordinary
+ * (exp: |x| <= 80; log: 2^-100 <= x <= 2^100) — anything else takes the exact routine, with all of its special cases.
+ * SOUNDNESS IS NOT ARGUED ONLY: mpr_test_loose_interval runs these very instructions on every float of the domain on the device
+ * and holds each end against the exact routine's (tests/test_gpu_primitives.py: test_loose_exp_log_enclose_the_exact_ones).
+ * In: v36 = lo, v37 = hi; out v40, v41; temporaries v42..v47; round-up mode. */
+#define TG_FEXP_CORE                                                                                              \
+    "v_mul_f32 v42, 0x3fb8aa3b, v36\n"                  /* t = x log2(e) */                                       \
+    "v_mul_f32 v43, 0x3fb8aa3b, v37\n"                                                                            \
+    "v_exp_f32 v44, v42\n"                                                                                        \
+    "v_exp_f32 v45, v43\n"                                                                                        \
+    "v_add_f32_e64 v46, |v42|, 4.0\n"                                                                             \
+    "v_add_f32_e64 v47, |v43|, 4.0\n"                                                                             \
+    "v_mul_f32 v46, 0x34000000, v46\n"                  /* k = (|t| + 4) 2^-23, rounded up */                      \
+    "v_mul_f32 v47, 0x34000000, v47\n"                                                                            \
+    "v_fma_f32 v40, v44, v46, -v44\n"                   /* RU(r k - r) = -RD(r - r k) */                          \
+    "v_fma_f32 v41, v45, v47, v45\n"                    /* RU(r + r k) */                                         \
+    "v_xor_b32 v40, 0x80000000, v40\n"
+#define TG_FLOG_CORE                                                                                              \
+    "v_log_f32 v42, v36\n"                                                                                        \
+    "v_log_f32 v43, v37\n"                                                                                        \
+    "s_nop 0\n"                                                                                                   \
+    "v_mul_f32 v42, 0x3f317218, v42\n"                  /* p = log2(x) ln2 */                                     \
+    "v_mul_f32 v43, 0x3f317218, v43\n"                                                                            \
+    "v_add_f32_e64 v44, |v42|, 1.0\n"                                                                             \
+    "v_add_f32_e64 v45, |v43|, 1.0\n"                                                                             \
+    "v_mul_f32 v44, 0x35000000, v44\n"                  /* e = (|p| + 1) 2^-21, rounded up */                      \
+    "v_mul_f32 v45, 0x35000000, v45\n"                                                                            \
+    "v_sub_f32 v40, v44, v42\n"                         /* RU(e - p) = -RD(p - e) */                              \
+    "v_add_f32 v41, v43, v45\n"                         /* RU(p + e) */                                           \
+    "v_xor_b32 v40, 0x80000000, v40\n"
+/* the routines: the range test, then the core or the exact routine */
+#define TG_LOOSE_ROUTINES                                                                                         \
+    "L_fexp_%=:\n"                                                                                                \
+    "s_mov_b32 s40, 0x42a00000\n"                       /* 80 */                                                  \
+    "v_cmp_nle_f32 vcc, |v36|, s40\n"                                                                             \
+    "v_cmp_nle_f32 s[42:43], |v37|, s40\n"                                                                        \
+    "s_or_b64 vcc, vcc, s[42:43]\n"                                                                               \
+    "s_cbranch_vccnz L_cexp_%=\n"                                                                                 \
+    TG_FEXP_CORE                                                                                                  \
+    "s_setpc_b64 s[36:37]\n"                                                                                      \
+    "L_flog_%=:\n"                                                                                                \
+    "v_add_u32 v42, 0xf2800000, v36\n"                  /* bits - bits(2^-100) */                                 \
+    "v_add_u32 v43, 0xf2800000, v37\n"                                                                            \
+    "v_max_u32 v42, v42, v43\n"                                                                                   \
+    "v_cmp_le_u32 vcc, 0x64000001, v42\n"               /* an end beyond 2^100, or below 2^-100 (wraps), negative, NaN */ \
+    "s_cbranch_vccnz L_clog_%=\n"                                                                                 \
+    TG_FLOG_CORE                                                                                                  \
+    "s_setpc_b64 s[36:37]\n"
+
 /* smem_io: 4 KB of LDS ([16][64] words) the register state travels through: the statement below names all but ten vector
  * registers.  ax / ay / az: 2 * the axes' slots; x / y / z: their intervals.  Out: the end clause's interval, and the lanes'
  * decisions at the tape's min / max clauses (bit k of chl / chr: chose lhs / rhs at clause k; two words each). */
@@ -26,7 +89,7 @@ namespace mprk {
  * chosen operand's as on that tape (0, 0: nobody, the first stage) */
 DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane, uint32_t ax, uint32_t ay, uint32_t az,
                           float2 x, float2 y, float2 z, float2* res, uint32_t* chl, uint32_t* chr,
-                          unsigned long long decided_lhs = 0, unsigned long long decided_rhs = 0)
+                          unsigned long long decided_lhs = 0, unsigned long long decided_rhs = 0, bool loose = false)
 {
     float* const io = reinterpret_cast<float*>(smem_io);
     io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
@@ -39,6 +102,7 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         u[2] = (uint32_t)decided_rhs; u[3] = (uint32_t)(decided_rhs >> 32);
         u[4] = (uint32_t)(uintptr_t)code; u[5] = (uint32_t)((uintptr_t)code >> 32);
         u[6] = ax; u[7] = ay; u[8] = az;
+        u[9] = loose ? 1u : 0u;       /* exp / log by the hardware's base-2 instructions, widened (TG_LOOSE_ROUTINES) */
     }
     asm volatile(
         /* the axes' intervals into their slots (TI_VS_ENTER with the three slot numbers in one operand) */
@@ -47,7 +111,9 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         "ds_read_b32 v39, v32 offset:768\n ds_read_b32 v42, v32 offset:1024\n ds_read_b32 v43, v32 offset:1280\n"
         "v_mov_b32 v33, %[io]\n"
         "ds_read_b128 v[44:47], v33 offset:3840\n ds_read_b128 v[48:51], v33 offset:3856\n ds_read_b32 v52, v33 offset:3872\n"
+        "ds_read_b32 v53, v33 offset:3876\n"
         "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s43, v53\n"
         "v_readfirstlane_b32 s72, v44\n v_readfirstlane_b32 s73, v45\n v_readfirstlane_b32 s74, v46\n v_readfirstlane_b32 s75, v47\n"
         "v_readfirstlane_b32 s34, v48\n v_readfirstlane_b32 s35, v49\n"
         "v_readfirstlane_b32 s40, v50\n v_readfirstlane_b32 s41, v51\n v_readfirstlane_b32 s42, v52\n"
@@ -61,6 +127,9 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         TG_ADDR(70, 71, "L_gmin") TG_ADDR(80, 81, "L_gmax") TG_ADDR(82, 83, "L_gdiv") TG_ADDR(84, 85, "L_gdivi")
         TG_ADDR(86, 87, "L_casin") TG_ADDR(88, 89, "L_cacos") TG_ADDR(90, 91, "L_catan") TG_ADDR(98, 99, "L_cexp")
         TG_ADDR(96, 97, "L_clog")
+        TG_ADDR(44, 45, "L_fexp") TG_ADDR(46, 47, "L_flog")
+        "s_cmp_lg_u32 s43, 0\n"
+        "s_cselect_b32 s98, s44, s98\n s_cselect_b32 s99, s45, s99\n s_cselect_b32 s96, s46, s96\n s_cselect_b32 s97, s47, s97\n"
         "s_swappc_b64 s[38:39], s[34:35]\n"
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
@@ -69,6 +138,7 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         "s_waitcnt lgkmcnt(0)\n"
         "s_branch L_end_%=\n"
         TI_BODIES_TEXT
+        TG_LOOSE_ROUTINES
         /* min / max of v[36:37], v[38:39] -> v[40:41] (device_math.hpp i_min / i_max); the decisions stay with the lanes:
          * vcc = did NOT choose the lhs, s[92:93] = chose the rhs (the caller records them) */
         "L_gmin_%=:\n"

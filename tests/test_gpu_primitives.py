@@ -205,6 +205,19 @@ def test_division_by_a_constant_in_generated_code(mpr, orc, imm):
         assert bad.size == 0, (imm, bad.size, [(a[i], g[i], o[i]) for i in bad[:5]])
 
 
+@pytest.mark.parametrize("opname", ["EXP_LHS", "LOG_LHS"])
+def test_loose_exp_log_enclose_the_exact_ones(mpr, opname):
+    """Frames nobody reads take exp / log of an interval from the hardware's v_exp_f32 / v_log_f32, widened by an error bound
+    (csrc/tile_gen_asm.hpp: TG_FEXP_CORE / TG_FLOG_CORE), where frames that are read take the correctly rounded enclosure through
+    double precision.  Sound means: contains the exact enclosure — checked here for EVERY float of the routines' domain
+    (|x| <= 80; 2^-100 <= x <= 2^100: anything else takes the exact routine), each as the interval [x, x], on the device; and not
+    absurdly wide (a few 1e-5 of the value)."""
+    bad, example, tested, widest = mpr.dev_loose_interval(mpr.OP[opname])
+    assert tested > (2_000_000_000 if opname == "EXP_LHS" else 800_000_000), tested
+    assert bad == 0, (bad, hex(example), np.uint32(example).view(np.float32))
+    assert widest < (1 << 24) * (5e-5 if opname == "EXP_LHS" else 1.0), widest      # (log: near x = 1 the value itself is tiny)
+
+
 def test_square_root_routine_on_every_float(mpr):
     """The float pass's square root (asm_float_bodies.hpp: v_rsq_f32, one coupled Newton step, the exact residual) must be the
     correctly rounded root — what sqrtf gives the oracle — for all 2^32 bit patterns: fast path (positive normal numbers from

@@ -350,6 +350,38 @@ def test_float_pass_on_the_root_tapes_host_generated_code(mpr, orc, tapes, name,
         ctx.close()
 
 
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 1024), ("trig", 128), ("trig", 256)])
+def test_tile_stages_with_loose_exp_and_log(mpr, orc, tapes, name, S, monkeypatch):
+    """Frames nobody reads run their generated tile stages with exp / log enclosures from the hardware's base-2 instructions
+    (sound, about 1e-5 wide instead of correctly rounded; MPR_TILE_GEN_LOOSE=0: the exact ones): a few tiles that the reference
+    culls, fills or shortens stay ambiguous / undecided, the heights and normals are the oracle's bit for bit, and a reader
+    still gets the reference's tiles and tapes."""
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
+    loose = mpr.Context(S)
+    monkeypatch.setenv("MPR_TILE_GEN_LOOSE", "0")
+    exact = mpr.Context(S)
+    counts = []
+    for ctx, tag in ((loose, "+loose"), (exact, "")):
+        for _ in range(2):
+            ctx.render3D(tape, view3())
+            assert np.array_equal(ctx.image, ref.filled[3]), (tag, int((ctx.image != ref.filled[3]).sum()))
+            assert np.array_equal(ctx.normals, ref.normals), (tag, int((ctx.normals != ref.normals).sum()))
+        forms = ctx.tile_stage_forms().split()
+        assert all(("+loose" in f) == (tag != "") for f in forms if ":gen" in f), forms
+        counts.append(ctx.frame_tiles())
+    # looser bounds leave more tiles ambiguous, not many more (which tiles a fill of the same launch still culls depends on timing:
+    # half a per cent of slack)
+    (lin, lamb, lvox), (ein, eamb, evox) = counts
+    assert evox * 0.995 - 8 <= lvox <= evox * 1.03 + 8, (lvox, evox)
+    assert all(a >= b * 0.995 - 8 for a, b in zip(lamb, eamb)), (lamb, eamb)
+    print("smallest tiles: loose %d, exact %d; ambiguous per stage: %s / %s" % (lvox, evox, lamb, eamb))
+    # the reader's state is the reference's either way
+    assert loose.stages[3].tile_array_size == ref.tiles[3].size == exact.stages[3].tile_array_size
+    for c in (loose, exact):
+        c.close()
+
+
 @pytest.mark.parametrize("name,dim,S", [("bear", 3, 512), ("architecture", 3, 1024), ("hello_world", 2, 256)])
 def test_code_ring_against_an_invalidate_per_group(mpr, tapes, name, dim, S, monkeypatch):
     """The group form writes a group's code into the next slot of a ring and invalidates the instruction cache only when
