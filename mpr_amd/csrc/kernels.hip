@@ -1084,7 +1084,7 @@ __global__ void k_test_interval(int op, int n, const float* a_lo, const float* a
 }
 /* The loose exp / log of frames nobody reads (tile_gen_asm.hpp: TG_FEXP_CORE / TG_FLOG_CORE) on every float of their domain,
  * each as the degenerate interval [x, x], against the exact routine's enclosure: out[0] = ends that do NOT enclose (must be 0),
- * out[1] = one such bit pattern, out[2] = operands tested, out[3] = the largest width met, in units of 2^-24 of the value. */
+ * out[1] = one such bit pattern, out[2] = operands tested, out[3] = the largest width met, in units of 2^-24 of max(|value|, 1). */
 __global__ void __launch_bounds__(256)
 k_test_loose_interval(int op, unsigned long long first, unsigned long long count, unsigned long long* out)
 {
@@ -1094,7 +1094,7 @@ k_test_loose_interval(int op, unsigned long long first, unsigned long long count
     for (unsigned long long k = threadIdx.x + (unsigned long long)blockIdx.x * blockDim.x; k < count; k += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t bits = (uint32_t)(first + k);
         const float x = mpr_u2f(bits);
-        const bool in_domain = op == MPR_OP_EXP_LHS ? (__builtin_fabsf(x) <= 80.0f) : (bits >= 0x0D800000u && bits <= 0x71800000u);
+        const bool in_domain = op == MPR_OP_EXP_LHS ? (x <= 80.0f) : (bits >= 0x00800000u && bits <= 0x7F7FFFFFu);      /* (the routines' own tests) */
         if (!in_domain) continue;
         int c = 0;
         const ival exact = interval_clause((uint32_t)op, iv(x, x), iv(0.0f, 0.0f), 0.0f, c);
@@ -1111,7 +1111,7 @@ k_test_loose_interval(int op, unsigned long long first, unsigned long long count
             example = bits;
         }
         const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
-        const double scale = __builtin_fabs(mid) > 1e-30 ? __builtin_fabs(mid) : 1e-30;
+        const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;        /* relative above 1, absolute below */
         const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
         if (units > widest) widest = units;
     }

@@ -33,13 +33,16 @@ namespace mprk {
  *   log:  p = RU(v_log_f32(x) ln2),  e = (|p| + 1) 2^-21:                  [RD(p - e), RU(p + e)]
  * about 1e-5 relative where the exact route has 6e-8, on values that feed sums of terms of magnitude 1 over tiles whose natural
  * extension is 0.3 wide: the classification barely moves (DESIGN.md has the counts).  Only when EVERY lane's ends are ordinary
- * (exp: |x| <= 80; log: 2^-100 <= x <= 2^100) — anything else takes the exact routine, with all of its special cases.
+ * (exp: x <= 80, any negative number — results below 2^-120 become [0, 2^-120]; log: positive normal numbers) — anything else takes
+ * the exact routine, with all of its special cases.
  * SOUNDNESS IS NOT ARGUED ONLY: mpr_test_loose_interval runs these very instructions on every float of the domain on the device
  * and holds each end against the exact routine's (tests/test_gpu_primitives.py: test_loose_exp_log_enclose_the_exact_ones).
  * In: v36 = lo, v37 = hi; out v40, v41; temporaries v42..v47; round-up mode. */
 #define TG_FEXP_CORE                                                                                              \
     "v_mul_f32 v42, 0x3fb8aa3b, v36\n"                  /* t = x log2(e) */                                       \
     "v_mul_f32 v43, 0x3fb8aa3b, v37\n"                                                                            \
+    "v_max_f32 v42, 0xc3480000, v42\n"                  /* ... at least -200 (2^-200 is 0 here; -inf must not reach k) */ \
+    "v_max_f32 v43, 0xc3480000, v43\n"                                                                            \
     "v_exp_f32 v44, v42\n"                                                                                        \
     "v_exp_f32 v45, v43\n"                                                                                        \
     "v_add_f32_e64 v46, |v42|, 4.0\n"                                                                             \
@@ -48,7 +51,10 @@ namespace mprk {
     "v_mul_f32 v47, 0x34000000, v47\n"                                                                            \
     "v_fma_f32 v40, v44, v46, -v44\n"                   /* RU(r k - r) = -RD(r - r k) */                          \
     "v_fma_f32 v41, v45, v47, v45\n"                    /* RU(r + r k) */                                         \
-    "v_xor_b32 v40, 0x80000000, v40\n"
+    /* results below 2^-120 (t < -120: v_exp_f32 flushes, or loses bits in, what is not a normal number): [0, 2^-120] */ \
+    "v_add_f32 v40, 0x04800000, v40\n"                  /* the lower end 2^-118 lower ... */                      \
+    "v_max_f32 v41, 0x03800000, v41\n"                  /* the upper end at least 2^-120 */                       \
+    "v_max_f32_e64 v40, -v40, 0\n"                      /* ... and not below 0 */
 #define TG_FLOG_CORE                                                                                              \
     "v_log_f32 v42, v36\n"                                                                                        \
     "v_log_f32 v43, v37\n"                                                                                        \
@@ -66,17 +72,17 @@ namespace mprk {
 #define TG_LOOSE_ROUTINES                                                                                         \
     "L_fexp_%=:\n"                                                                                                \
     "s_mov_b32 s40, 0x42a00000\n"                       /* 80 */                                                  \
-    "v_cmp_nle_f32 vcc, |v36|, s40\n"                                                                             \
-    "v_cmp_nle_f32 s[42:43], |v37|, s40\n"                                                                        \
+    "v_cmp_nle_f32 vcc, v36, s40\n"                     /* an end above 80, or NaN */                             \
+    "v_cmp_nle_f32 s[42:43], v37, s40\n"                                                                          \
     "s_or_b64 vcc, vcc, s[42:43]\n"                                                                               \
     "s_cbranch_vccnz L_cexp_%=\n"                                                                                 \
     TG_FEXP_CORE                                                                                                  \
     "s_setpc_b64 s[36:37]\n"                                                                                      \
     "L_flog_%=:\n"                                                                                                \
-    "v_add_u32 v42, 0xf2800000, v36\n"                  /* bits - bits(2^-100) */                                 \
-    "v_add_u32 v43, 0xf2800000, v37\n"                                                                            \
+    "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
+    "v_add_u32 v43, 0xff800000, v37\n"                                                                            \
     "v_max_u32 v42, v42, v43\n"                                                                                   \
-    "v_cmp_le_u32 vcc, 0x64000001, v42\n"               /* an end beyond 2^100, or below 2^-100 (wraps), negative, NaN */ \
+    "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* an end that is not a positive normal number */          \
     "s_cbranch_vccnz L_clog_%=\n"                                                                                 \
     TG_FLOG_CORE                                                                                                  \
     "s_setpc_b64 s[36:37]\n"
