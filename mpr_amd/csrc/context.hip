@@ -2062,15 +2062,16 @@ int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t 
 }
 /* the loose exp / log enclosures of frames nobody reads (tile_gen_asm.hpp) on the bit patterns [first, first + count) that lie in
  * their domain, against the exact routine's: ends that fail to enclose, one such bit pattern, operands tested, widest result */
-int mpr_test_loose_interval(int32_t device, int32_t op, uint64_t first, uint64_t count, uint64_t* not_enclosing, uint32_t* example,
+int mpr_test_loose_interval(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t* not_enclosing, uint32_t* example,
                             uint64_t* tested, uint64_t* widest_2m24)
 {
-    if (!not_enclosing || (op != MPR_OP_EXP_LHS && op != MPR_OP_LOG_LHS)) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    if (!not_enclosing || (op != MPR_OP_EXP_LHS && op != MPR_OP_LOG_LHS && op != MPR_OP_SQRT_LHS && op != MPR_OP_DIV_LHS_IMM && op != 100))
+        return mpr::set_error(MPR_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(device));
     DevBuf d;
     HIP_TRY(d.alloc(32));
     HIP_TRY(hipMemset(d.p, 0, 32));
-    mprk::launch_test_loose_interval(nullptr, op, first, count, (unsigned long long*)d.p);
+    mprk::launch_test_loose_interval(nullptr, op, imm, first, count, (unsigned long long*)d.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long h[4] = {0, 0, 0, 0};

@@ -1086,7 +1086,7 @@ __global__ void k_test_interval(int op, int n, const float* a_lo, const float* a
  * each as the degenerate interval [x, x], against the exact routine's enclosure: out[0] = ends that do NOT enclose (must be 0),
  * out[1] = one such bit pattern, out[2] = operands tested, out[3] = the largest width met, in units of 2^-24 of max(|value|, 1). */
 __global__ void __launch_bounds__(256)
-k_test_loose_interval(int op, unsigned long long first, unsigned long long count, unsigned long long* out)
+k_test_loose_interval(int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
 {
     float dummy0 = 0, dummy1 = 0, dummy2 = 0, dummy3 = 0, dummy4 = 0, dummy5 = 0;
     round_up_begin(dummy0, dummy1, dummy2, dummy3, dummy4, dummy5);
@@ -1094,22 +1094,50 @@ k_test_loose_interval(int op, unsigned long long first, unsigned long long count
     for (unsigned long long k = threadIdx.x + (unsigned long long)blockIdx.x * blockDim.x; k < count; k += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t bits = (uint32_t)(first + k);
         const float x = mpr_u2f(bits);
-        const bool in_domain = op == MPR_OP_EXP_LHS ? (x <= 80.0f) : (bits >= 0x00800000u && bits <= 0x7F7FFFFFu);      /* (the routines' own tests) */
+        const bool pos_normal = bits >= 0x00800000u && bits <= 0x7F7FFFFFu;
+        if (op == 100) {
+            /* the reciprocal's bounds of the division by a constant: 1 / x in [y_dn, y_up], checked exactly (a product of two
+             * floats is a double) */
+            const uint32_t mag = bits & 0x7FFFFFFFu;
+            if (mag < 0x0D800000u || mag > 0x71800000u) continue;
+            float yup, ndn;
+            asm volatile("v_mov_b32 v38, %2\n" TG_FRCP_CORE "v_mov_b32 %0, v45\n v_mov_b32 %1, v46\n"
+                         : "=&v"(yup), "=&v"(ndn) : "v"(x) : "v38", "v42", "v43", "v44", "v45", "v46");
+            const double pu = (double)yup * (double)x, pd = -(double)ndn * (double)x;
+            ++tested;
+            const bool ok = x > 0.0f ? (pd <= 1.0 && 1.0 <= pu) : (pu <= 1.0 && 1.0 <= pd);
+            if (!ok) {
+                ++bad;
+                example = bits;
+            }
+            continue;
+        }
+        const bool in_domain = op == MPR_OP_EXP_LHS ? (x <= 80.0f) : op == MPR_OP_DIV_LHS_IMM ? true : pos_normal;      /* (the routines' own tests) */
         if (!in_domain) continue;
         int c = 0;
-        const ival exact = interval_clause((uint32_t)op, iv(x, x), iv(0.0f, 0.0f), 0.0f, c);
+        const ival exact = interval_clause((uint32_t)op, iv(x, x), iv(0.0f, 0.0f), imm, c);
         float lo, hi;
-        if (op == MPR_OP_EXP_LHS)
+        if (op == MPR_OP_SQRT_LHS)
+            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FSQRT_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                         : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44");
+        else if (op == MPR_OP_DIV_LHS_IMM)
+            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n v_mov_b32 v38, %3\n" TG_FDIVI_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                         : "=&v"(lo), "=&v"(hi) : "v"(x), "v"(imm)
+                         : "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50");
+        else if (op == MPR_OP_EXP_LHS)
             asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FEXP_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
                          : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
         else
             asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FLOG_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
                          : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
         ++tested;
-        if (!(lo <= exact.lo && hi >= exact.hi)) {
+        /* encloses: a NaN end of the exact enclosure (an operation without a value there) must be a NaN here too */
+        const bool lo_ok = exact.lo != exact.lo ? lo != lo : lo <= exact.lo, hi_ok = exact.hi != exact.hi ? hi != hi : hi >= exact.hi;
+        if (!(lo_ok && hi_ok)) {
             ++bad;
             example = bits;
         }
+        if (exact.lo != exact.lo || exact.hi != exact.hi || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f) continue;   /* (no width to speak of) */
         const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
         const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;        /* relative above 1, absolute below */
         const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
@@ -1122,9 +1150,9 @@ k_test_loose_interval(int op, unsigned long long first, unsigned long long count
     atomicAdd(&out[2], tested);
     atomicMax(&out[3], widest);
 }
-void launch_test_loose_interval(hipStream_t s, int op, unsigned long long first, unsigned long long count, unsigned long long* out)
+void launch_test_loose_interval(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
 {
-    hipLaunchKernelGGL(k_test_loose_interval, dim3(2048), dim3(256), 0, s, op, first, count, out);
+    hipLaunchKernelGGL(k_test_loose_interval, dim3(2048), dim3(256), 0, s, op, imm, first, count, out);
 }
 /* one clause through the assembly forward walk of the tile stages: tape = {head (slots 1, 2, 3),
  * [copy], the clause (out = slot 4), end}; 64 operand pairs per wave; slot 3 is unused */

@@ -218,7 +218,7 @@ void launch_debug_interp_cycles(hipStream_t s, const uint64_t* tape, int reps, l
 void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
                           const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice);
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
-void launch_test_loose_interval(hipStream_t s, int op, unsigned long long first, unsigned long long count, unsigned long long* out);
+void launch_test_loose_interval(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
 
 /* mpr::Effects (kernels_effects.hip) */

@@ -26,8 +26,9 @@ namespace mprk {
  * heights and normals, and those do not depend on how tight a SOUND enclosure is: a wider interval leaves a tile ambiguous that
  * the reference would have culled or filled (its children / voxels are evaluated and give the same heights: the hierarchy is
  * conservative at every level) or a min / max undecided that the reference would have decided (the comparison then picks the same
- * operand at every point).  So those frames take the hardware's v_exp_f32 / v_log_f32 (base 2) and widen the result by an error
- * bound that covers the argument's rounding, the constant's and the instruction's:
+ * operand at every point).  So those frames take the hardware's v_exp_f32 / v_log_f32 (base 2) — and v_sqrt_f32 and, for the
+ * division by a constant, v_rcp_f32: below — and widen the result by an error bound that covers the argument's rounding, the
+ * constant's and the instruction's:
  *   exp:  t = RU(x log2e),  r = v_exp_f32(t),  k = (|t| + 4) 2^-23:        [RD(r - r k), RU(r + r k)]
  *         (t is off by at most |t| 1.13 2^-23: a factor 2^(that) = 1 +- 0.79 |t| 2^-23 on the result; v_exp_f32: 1 ulp, 2 assumed)
  *   log:  p = RU(v_log_f32(x) ln2),  e = (|p| + 1) 2^-21:                  [RD(p - e), RU(p + e)]
@@ -68,8 +69,53 @@ namespace mprk {
     "v_sub_f32 v40, v44, v42\n"                         /* RU(e - p) = -RD(p - e) */                              \
     "v_add_f32 v41, v43, v45\n"                         /* RU(p + e) */                                           \
     "v_xor_b32 v40, 0x80000000, v40\n"
+/* square root: r = v_sqrt_f32(x) (1 ulp; 2 assumed): [RD(r - r 2^-22), RU(r + r 2^-22)], for positive normal ends (7 instructions
+ * where the correctly rounded pair takes ~50) */
+#define TG_FSQRT_CORE                                                                                             \
+    "v_sqrt_f32 v42, v36\n"                                                                                       \
+    "v_sqrt_f32 v43, v37\n"                                                                                       \
+    "v_mov_b32 v44, 0x34800000\n"                       /* 2^-22 */                                               \
+    "s_nop 0\n"                                                                                                   \
+    "v_fma_f32 v40, v42, v44, -v42\n"                   /* RU(r c - r) = -RD(r - r c) */                          \
+    "v_fma_f32 v41, v43, v44, v43\n"                    /* RU(r + r c) */                                         \
+    "v_xor_b32 v40, 0x80000000, v40\n"
+/* division by a constant c (v38; 2^-100 <= |c| <= 2^100): y = v_rcp_f32(c) (1 ulp; 2 assumed), 1 / c lies in [y_dn, y_up] =
+ * [RD(y - |y| 2^-22), RU(y + |y| 2^-22)], so x / c lies between x y_dn and x y_up whatever the signs: the lower end is the smaller of
+ * the two products rounded down, the upper end the larger rounded up (12 instructions where the correctly rounded pair takes ~75:
+ * bear divides by a constant 39 times per walk).  TG_FRCP_CORE leaves y_up in v45 and -y_dn in v46. */
+#define TG_FRCP_CORE                                                                                              \
+    "v_rcp_f32 v42, v38\n"                                                                                        \
+    "v_mov_b32 v44, 0x34800000\n"                                                                                 \
+    "s_nop 0\n"                                                                                                   \
+    "v_mul_f32_e64 v43, |v42|, v44\n"                   /* w = |y| 2^-22 */                                       \
+    "v_add_f32 v45, v42, v43\n"                         /* y_up = RU(y + w) */                                    \
+    "v_sub_f32 v46, v43, v42\n"                         /* RU(w - y) = -y_dn */
+#define TG_FDIVI_CORE                                                                                             \
+    TG_FRCP_CORE                                                                                                  \
+    "v_mul_f32 v47, v36, v46\n"                         /* RU(lo (-y_dn)) = -RD(lo y_dn) */                       \
+    "v_mul_f32_e64 v48, -v36, v45\n"                    /* RU((-lo) y_up) = -RD(lo y_up) */                       \
+    "v_mul_f32_e64 v49, v37, -v46\n"                    /* RU(hi y_dn) */                                         \
+    "v_mul_f32 v50, v37, v45\n"                         /* RU(hi y_up) */                                         \
+    "v_max_f32 v40, v47, v48\n"                         /* - lower end */                                         \
+    "v_max_f32 v41, v49, v50\n"                                                                                   \
+    "v_xor_b32 v40, 0x80000000, v40\n"
 /* the routines: the range test, then the core or the exact routine */
 #define TG_LOOSE_ROUTINES                                                                                         \
+    "L_fsqrt_%=:\n"                                                                                               \
+    "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
+    "v_add_u32 v43, 0xff800000, v37\n"                                                                            \
+    "v_max_u32 v42, v42, v43\n"                                                                                   \
+    "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* an end that is not a positive normal number */          \
+    "s_cbranch_vccnz L_isqrt_%=\n"                                                                                \
+    TG_FSQRT_CORE                                                                                                 \
+    "s_setpc_b64 s[36:37]\n"                                                                                      \
+    "L_fdivi_%=:\n"                                                                                               \
+    "v_and_b32 v42, 0x7fffffff, v38\n"                                                                            \
+    "v_add_u32 v42, 0xf2800000, v42\n"                  /* |c| bits - bits(2^-100) */                             \
+    "v_cmp_le_u32 vcc, 0x64000001, v42\n"               /* |c| outside 2^-100 .. 2^100 (zero, NaN, inf included) */ \
+    "s_cbranch_vccnz L_gdivi_%=\n"                                                                                \
+    TG_FDIVI_CORE                                                                                                 \
+    "s_setpc_b64 s[36:37]\n"                                                                                      \
     "L_fexp_%=:\n"                                                                                                \
     "s_mov_b32 s40, 0x42a00000\n"                       /* 80 */                                                  \
     "v_cmp_nle_f32 vcc, v36, s40\n"                     /* an end above 80, or NaN */                             \
@@ -133,9 +179,10 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         TG_ADDR(70, 71, "L_gmin") TG_ADDR(80, 81, "L_gmax") TG_ADDR(82, 83, "L_gdiv") TG_ADDR(84, 85, "L_gdivi")
         TG_ADDR(86, 87, "L_casin") TG_ADDR(88, 89, "L_cacos") TG_ADDR(90, 91, "L_catan") TG_ADDR(98, 99, "L_cexp")
         TG_ADDR(96, 97, "L_clog")
-        TG_ADDR(44, 45, "L_fexp") TG_ADDR(46, 47, "L_flog")
+        TG_ADDR(44, 45, "L_fexp") TG_ADDR(46, 47, "L_flog") TG_ADDR(48, 49, "L_fsqrt") TG_ADDR(50, 51, "L_fdivi")
         "s_cmp_lg_u32 s43, 0\n"
         "s_cselect_b32 s98, s44, s98\n s_cselect_b32 s99, s45, s99\n s_cselect_b32 s96, s46, s96\n s_cselect_b32 s97, s47, s97\n"
+        "s_cselect_b32 s68, s48, s68\n s_cselect_b32 s69, s49, s69\n s_cselect_b32 s84, s50, s84\n s_cselect_b32 s85, s51, s85\n"
         "s_swappc_b64 s[38:39], s[34:35]\n"
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
