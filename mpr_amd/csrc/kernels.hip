@@ -1137,7 +1137,9 @@ k_test_loose_interval(int op, float imm, unsigned long long first, unsigned long
             ++bad;
             example = bits;
         }
-        if (exact.lo != exact.lo || exact.hi != exact.hi || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f) continue;   /* (no width to speak of) */
+        if (exact.lo != exact.lo || exact.hi != exact.hi || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f || lo - lo != 0.0f ||
+            hi - hi != 0.0f)
+            continue;                                  /* (no width to speak of: an end at infinity — a quotient that overflows one rounding earlier) */
         const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
         const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;        /* relative above 1, absolute below */
         const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
