@@ -3,10 +3,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
 
 namespace mprk {
+
+/* hipFuncSetAttribute belongs to the function ON THE DEVICE THAT IS CURRENT: a process that drives several devices (one host
+ * thread per GPU, benchmark/render_table_multi.cpp) opts in once per device, not once per process.  true the first time. */
+inline bool first_use_on_this_device(std::atomic<unsigned long long>& done_mask)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (done_mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
 
 struct int4_ { int x, y, z, w; };
 /* src/context.cu:23-30 */

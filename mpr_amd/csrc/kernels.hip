@@ -27,6 +27,7 @@
  * :340-458) so a tape pool read back from the device is interchangeable.
  */
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -1227,9 +1228,8 @@ __global__ void k_test_deriv(int op, int n, const float4* a, const float4* b, fl
 /* gfx950 offers 160 KiB of LDS per workgroup; anything above the 64 KiB default must be opted in */
 static void opt_in_once()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    static std::atomic<unsigned long long> done{0};
+    if (!first_use_on_this_device(done)) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

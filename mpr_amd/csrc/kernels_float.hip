@@ -368,9 +368,8 @@ static void allow_big_lds(K kernel)
 }
 static void opt_in_once()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    static std::atomic<unsigned long long> done{0};
+    if (!first_use_on_this_device(done)) return;
     allow_big_lds(k_eval_voxels<2>);
     allow_big_lds(k_eval_voxels<3>);
     allow_big_lds(k_eval_normals_q);

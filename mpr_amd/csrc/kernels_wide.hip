@@ -418,9 +418,8 @@ size_t wide_stage_lds_bytes(int nclauses)
 bool wide_stage_fits(int nclauses) { return wide_stage_lds_bytes(nclauses) <= 150 * 1024; }
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced)
 {
-    static bool once = false;
-    if (!once) {
-        once = true;
+    static std::atomic<unsigned long long> done{0};
+    if (first_use_on_this_device(done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }

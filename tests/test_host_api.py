@@ -249,3 +249,29 @@ def test_archives_are_canonical(mpr):
         bytes([3, 21]) + struct.pack("<II", 5, 5) + bytes([22]) + struct.pack("<II", 6, 4) + \
         bytes([1]) + struct.pack("<f", 0.5) + bytes([24]) + struct.pack("<II", 8, 7) + bytes([0xFF, 0xFF])
     assert np.array_equal(mpr.Tape(mpr.Tree.from_frep(blob)).data, mpr.Tape(built).data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_cpp_multi_gpu_driver_gathers_the_single_gpu_frame(mpr, gpus):
+    """benchmark/render_table_multi.cpp — the tile-parallel loop in C++ against the C ABI: one host thread and one context per
+    rank, the column deal by the first stage's verdict, partial frames, packs, peer copies ordered by events, unpack.  On this
+    box every rank sits on device 0 (--share-device): the loop's logic is what is checked — every rank must end with the frame a
+    single context renders, heights and normals bit for bit (--verify makes the program compare and exit 3 otherwise)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "render_table_multi")
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "benchmark", "render_table_multi.cpp"), "-L" + os.path.join(ROOT, "mpr_amd"), "-lmpr_amd",
+                               "-Wl,-rpath," + os.path.join(ROOT, "mpr_amd"), "-pthread", "-o", exe])
+        out = subprocess.run([exe, os.path.join(ROOT, "fixtures", "models", "bear.frep"), "--gpus", str(gpus), "--share-device", "--verify",
+                              "--sizes", "256,512", "--frames", "5", "--warmup", "2"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-500:])
+        lines = [l for l in out.stdout.splitlines() if l and l[0].isdigit()]
+        assert [l.split()[:2] for l in lines] == [["256", str(gpus)], ["512", str(gpus)]], out.stdout
+        assert out.stdout.count("verified") == 2
