@@ -161,7 +161,9 @@ struct mpr_context {
     size_t gen_dec_cap[3] = {0, 0, 0};
     int gen_full_dw = 0;               /* dwords of the backward code for tapes that are shortened again (0: the tape is too long for it) */
     std::shared_ptr<const mpr::TapeCode> resident_code;   /* what gen_code holds (kept alive: the upload is asynchronous) */
-    int gen_vox_at = 0, gen_fwdg_at = 0;   /* where the float walk / the guarded forward walk start in gen_code (dwords) */
+    int gen_vox_at = 0, gen_fwdg_at = 0, gen_derivg_at = 0, gen_derivg_dw = 0;   /* where the float walk / the guarded forward walk / the guarded
+                                                                                   Deriv walk start in gen_code (dwords) */
+    bool normals_guards = true;        /* MPR_NORMALS_GUARDS=0: the normals pass runs the plain Deriv walk */
     int gen_fwdg_dw = 0;               /* dwords of the forward walk with guarded dead runs (TileGen::fwd_guarded), behind the float walk (0: none) */
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
@@ -393,6 +395,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
+    if (const char* e = getenv("MPR_NORMALS_GUARDS")) c->normals_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_TILES")) c->voxel_gen_tiles = atoi(e);
@@ -610,6 +613,8 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     c->gen_vox_at = code->fwd_dw + code->bwd_dw + code->deriv_dw + code->full_dw;
                     c->gen_fwdg_dw = c->tile_gen_guards ? code->fwdg_dw : 0;
                     c->gen_fwdg_at = c->gen_vox_at + code->vox_dw;
+                    c->gen_derivg_at = c->gen_fwdg_at + code->fwdg_dw;
+                    c->gen_derivg_dw = c->normals_guards ? code->derivg_dw : 0;
                     c->gen_words = code->walk_words;
                     c->gen_nchoices = code->nchoices;
                 }
@@ -1371,6 +1376,7 @@ static int frame_normals_pass(Frame& f)
         n.vgpr_slots = c->tiles_vgpr;
         if (c->normals_gen && decisions_recorded && ((normals_on_groups && group_stage == 2) || last_recorded)) {
             n.gen_code = c->gen_code + c->gen_fwd_dw + c->gen_bwd_dw;
+            n.gen_code_guarded = c->gen_derivg_dw > 0 ? c->gen_code + c->gen_derivg_at : nullptr;
             n.gen_decisions0 = skip0 ? nullptr : c->gen_dec[0];
             n.gen_decisions = c->gen_dec[1];
             n.gen_decisions2 = last_recorded ? c->gen_dec[2] : nullptr;

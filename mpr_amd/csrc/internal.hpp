@@ -11,10 +11,10 @@
 namespace mpr {
 /* A tape's walks as gfx950 machine code (tile_gen.hpp: interval forward / backward / Deriv / backward for tapes that are
  * shortened again; voxel_gen.hpp: the float walk), generated once, on the host, when the tape is made — not in the first frame
- * that renders it — and shared by every copy of the tape.  words = the six pieces back to back. */
+ * that renders it — and shared by every copy of the tape.  words = the seven pieces back to back. */
 struct TapeCode {
     std::vector<uint32_t> words;
-    int fwd_dw = 0, bwd_dw = 0, deriv_dw = 0, full_dw = 0, vox_dw = 0, fwdg_dw = 0;   /* (fwdg: TileGen::fwd_guarded, last) */
+    int fwd_dw = 0, bwd_dw = 0, deriv_dw = 0, full_dw = 0, vox_dw = 0, fwdg_dw = 0, derivg_dw = 0;   /* (in this order; fwdg / derivg: the guarded walks) */
     int walk_words = 0, nchoices = 0;
     int vox_min_run = 0;             /* the shortest guarded run the float walk was generated with */
 };

@@ -138,6 +138,7 @@ struct NormalArgs {
      * (TileStageArgs::gen_decisions), group form: every pixel on the ROOT tape's generated Deriv code (tile_gen.hpp) with the
      * decisions of its 16^3 and 4^3 tiles applied — one walk per footprint whatever tapes its pixels carry (else null) */
     const uint32_t* gen_code = nullptr;
+    const uint32_t* gen_code_guarded = nullptr;           /* the same walk with its dead runs guarded (TileGen::deriv_guarded), or null */
     const unsigned long long* gen_decisions = nullptr;    /* the 16^3 tiles' records (GEN_RECORD_U64 words each) */
     const unsigned long long* gen_decisions0 = nullptr;   /* the 64^3 tiles', when that stage ran */
     const unsigned long long* gen_decisions2 = nullptr;   /* the 4^3 tiles', when the last stage pushed: everything decided for a pixel in one record

@@ -569,9 +569,11 @@ k_eval_normals_asm(NormalArgs a)
     "s_swappc_b64 s[30:31], s[40:41]\n"                                                          \
     "v_mov_b32 v37, v0\n s_setpc_b64 s[70:71]\n"
 DEV float normals_gen_walk(const uint32_t* code, uint32_t ax, uint32_t ay, uint32_t az, float xin, float yin, float zin,
-                           uint32_t dl0, uint32_t dl1, uint32_t dr0, uint32_t dr1)
+                           uint32_t dl0, uint32_t dl1, uint32_t dr0, uint32_t dr1, uint64_t all_l = 0, uint64_t all_r = 0)
 {
     const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    /* min / max clauses every lane of the wavefront has decided for the lhs / rhs: the guarded walk jumps over what they leave dead */
+    const uint32_t al0 = rdfirst((uint32_t)all_l), al1 = rdfirst((uint32_t)(all_l >> 32)), ar0 = rdfirst((uint32_t)all_r), ar1 = rdfirst((uint32_t)(all_r >> 32));
     ax = rdfirst(ax);
     ay = rdfirst(ay);
     az = rdfirst(az);
@@ -584,6 +586,7 @@ DEV float normals_gen_walk(const uint32_t* code, uint32_t ax, uint32_t ay, uint3
         "s_set_gpr_idx_on %[ay], gpr_idx(DST)\n v_mov_b32 v50, %[yin]\n s_set_gpr_idx_off\n"
         "s_set_gpr_idx_on %[az], gpr_idx(DST)\n v_mov_b32 v50, %[zin]\n s_set_gpr_idx_off\n"
         "v_mov_b32 v74, %[dl0]\n v_mov_b32 v75, %[dl1]\n v_mov_b32 v76, %[dr0]\n v_mov_b32 v77, %[dr1]\n"
+        "s_mov_b32 s64, %[al0]\n s_mov_b32 s65, %[al1]\n s_mov_b32 s66, %[ar0]\n s_mov_b32 s67, %[ar1]\n"
         "s_getpc_b64 s[40:41]\n"
         "L_pc_%=:\n"
         NG_ADDR(72, 73, "L_div") NG_ADDR(74, 75, "L_sqrt") NG_ADDR(76, 77, "L_exp") NG_ADDR(78, 79, "L_log") NG_ADDR(68, 69, "L_sincos")
@@ -606,7 +609,7 @@ DEV float normals_gen_walk(const uint32_t* code, uint32_t ax, uint32_t ay, uint3
         "L_end_%=:\n"
         : [res] "=&v"(res)
         : [ax] "s"(ax), [ay] "s"(ay), [az] "s"(az), [xin] "v"(xin), [yin] "v"(yin), [zin] "v"(zin), [dl0] "v"(dl0), [dl1] "v"(dl1),
-          [dr0] "v"(dr0), [dr1] "v"(dr1), [clo] "s"(clo), [chi] "s"(chi)
+          [dr0] "v"(dr0), [dr1] "v"(dr1), [clo] "s"(clo), [chi] "s"(chi), [al0] "s"(al0), [al1] "s"(al1), [ar0] "s"(ar0), [ar1] "s"(ar1)
         : "memory", "vcc", "scc",
           "s34", "s35", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
           "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
@@ -738,8 +741,23 @@ k_eval_normals_gen(NormalArgs a)
     const uint64_t head0 = a.tape_ro[0];
     const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
     /* :1021-1031 — value first, then the unit partials */
-    const float result = normals_gen_walk(a.gen_code, sx, sy, sz, isv ? vx : (comp == 0 ? 1.0f : 0.0f), isv ? vy : (comp == 1 ? 1.0f : 0.0f),
-                                          isv ? vz : (comp == 2 ? 1.0f : 0.0f), (uint32_t)dl, (uint32_t)(dl >> 32), (uint32_t)dr, (uint32_t)(dr >> 32));
+    /* what EVERY filled pixel of the footprint has decided (pixels without a surface decide nothing and see nothing): bit by bit,
+     * one ballot per min / max clause and side */
+    uint64_t all_l = 0, all_r = 0;
+    if (a.gen_code_guarded) {
+        const uint64_t want = ballot(filled);
+        for (int k = 0; k < a.gen_nchoices; ++k) {
+            if ((ballot(filled && ((dl >> k) & 1ull)) == want)) all_l |= 1ull << k;
+            if ((ballot(filled && ((dr >> k) & 1ull)) == want)) all_r |= 1ull << k;
+        }
+        if (!filled) {           /* their lanes walk along (and store nothing): let them take the same branches of every min / max */
+            dl = all_l;
+            dr = all_r;
+        }
+    }
+    const float result = normals_gen_walk(a.gen_code_guarded ? a.gen_code_guarded : a.gen_code, sx, sy, sz, isv ? vx : (comp == 0 ? 1.0f : 0.0f),
+                                          isv ? vy : (comp == 1 ? 1.0f : 0.0f), isv ? vz : (comp == 2 ? 1.0f : 0.0f), (uint32_t)dl,
+                                          (uint32_t)(dl >> 32), (uint32_t)dr, (uint32_t)(dr >> 32), all_l, all_r);
 
     /* :1123-1131 */
     const float gx = quad_bcast_a(result, 0), gy = quad_bcast_a(result, 1), gz = quad_bcast_a(result, 2);

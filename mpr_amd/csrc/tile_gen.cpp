@@ -604,6 +604,42 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
         de.mov(37, Emit::V(DerivEmit::slot(g.result_slot)));
         de.setpc(TG_RET_CODE);
     }
+    {
+        /* ... and with the dead runs guarded (the 16 pixels of a footprint mostly share their tiles' decisions) */
+        std::vector<DeadRun> runs = tape_dead_runs(clauses, end, 4);
+        std::stable_sort(runs.begin(), runs.end(), [](const DeadRun& a, const DeadRun& b) { return a.first != b.first ? a.first < b.first : a.last > b.last; });
+        Emit de{g.deriv_guarded};
+        DerivEmit dg{de};
+        std::vector<int> pos((size_t)end + 1, 0);
+        std::vector<std::pair<size_t, int>> fix;
+        size_t next_run = 0;
+        int ch = 0;
+        for (int i = 1; i < end; ++i) {
+            pos[(size_t)i] = (int)g.deriv_guarded.size();
+            for (; next_run < runs.size() && runs[next_run].first == i; ++next_run) {
+                const DeadRun& r = runs[next_run];
+                de.d(0xBF0F0000u | (uint32_t)(128 + r.choice) << 8 | (r.by_lhs ? 64u : 66u));      /* s_bitcmp1_b64 s[64:65] / s[66:67], choice */
+                fix.emplace_back(g.deriv_guarded.size(), r.last + 1);
+                de.d(0xBF850000u);                                   /* s_cbranch_scc1 */
+                de.wrote(-1);                                        /* (a jump target: no DPP hazard is carried across it) */
+                de.wrote(-1);
+            }
+            const uint64_t w = clauses[i];
+            const uint32_t op = (uint32_t)w & 0xFF;
+            (void)deriv_clause(dg, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), ch);
+            if (mpr_op_is_minmax(op)) ++ch;
+        }
+        pos[(size_t)end] = (int)g.deriv_guarded.size();
+        de.mov(37, Emit::V(DerivEmit::slot(g.result_slot)));
+        de.setpc(TG_RET_CODE);
+        bool fits = true;
+        for (const auto& fx : fix) {
+            const long d = (long)pos[(size_t)fx.second] - ((long)fx.first + 1);
+            if (d < 0 || d > 32767) fits = false;
+            g.deriv_guarded[fx.first] |= (uint32_t)(d & 0xFFFF);
+        }
+        if (!fits || runs.empty()) g.deriv_guarded.clear();
+    }
 
     uint32_t cur_hi = 0;                                      /* the harness enters with v47 = 0 */
     for (int i = end - 1; i >= 1; --i) {
@@ -639,7 +675,7 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     if (!g.ok || g.fwd.empty()) return nullptr;
     const VoxelGen v = voxel_gen_build(clauses, len, vox_min_run);
     auto c = std::make_shared<TapeCode>();
-    c->words.reserve(g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size() + g.fwd_guarded.size());
+    c->words.reserve(g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size() + g.fwd_guarded.size() + g.deriv_guarded.size());
     c->words.insert(c->words.end(), g.fwd.begin(), g.fwd.end());
     c->words.insert(c->words.end(), g.bwd.begin(), g.bwd.end());
     c->words.insert(c->words.end(), g.deriv.begin(), g.deriv.end());
@@ -647,6 +683,8 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     if (v.ok) c->words.insert(c->words.end(), v.code.begin(), v.code.end());
     c->words.insert(c->words.end(), g.fwd_guarded.begin(), g.fwd_guarded.end());
     c->fwdg_dw = (int)g.fwd_guarded.size();
+    c->words.insert(c->words.end(), g.deriv_guarded.begin(), g.deriv_guarded.end());
+    c->derivg_dw = (int)g.deriv_guarded.size();
     c->fwd_dw = (int)g.fwd.size();
     c->bwd_dw = (int)g.bwd.size();
     c->deriv_dw = (int)g.deriv.size();
@@ -662,8 +700,8 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
     const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
-    if (!g.ok || which < 0 || which > 4) return -1;
-    const std::vector<uint32_t>& c = which == 4 ? g.fwd_guarded : which == 3 ? g.bwd_full : which == 2 ? g.deriv : which ? g.bwd : g.fwd;
+    if (!g.ok || which < 0 || which > 5) return -1;
+    const std::vector<uint32_t>& c = which == 5 ? g.deriv_guarded : which == 4 ? g.fwd_guarded : which == 3 ? g.bwd_full : which == 2 ? g.deriv : which ? g.bwd : g.fwd;
     if (out && (int)c.size() <= cap)
         for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
     return (int)c.size();

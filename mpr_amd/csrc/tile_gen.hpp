@@ -60,6 +60,8 @@ struct TileGen {
     std::vector<uint32_t> bwd_full; /* the same for tapes that are shortened again, and for the stages below the first (tile_gen.cpp); empty:
                                      * the tape has more clauses than a record has presence bits */
     std::vector<uint32_t> deriv;    /* the normals pass's walk (value + three partials per pixel: four lanes), decisions in v74..v77 */
+    std::vector<uint32_t> deriv_guarded;   /* the same walk jumping over the runs that are dead for EVERY pixel of the wavefront: s[64:65] / s[66:67] =
+                                            * min / max clauses decided for the lhs / rhs in all 64 lanes (the AND of their v74..v77) */
     int words = 0;                  /* clause words a walk visits: the operations and the end clause (or the head) */
     int nchoices = 0;               /* min / max clauses */
     int result_slot = 0;

@@ -221,3 +221,30 @@ def test_forward_walk_with_guarded_dead_runs(mpr, tapes):
     sphere = [int(w) for w in tapes("sphere").data]
     arr = np.array(sphere, dtype=np.uint64)
     assert mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 4, buf, 65536) == 0
+
+
+def test_deriv_walk_with_guarded_dead_runs(mpr, tapes):
+    """which = 5: the normals pass's walk jumping over the runs that are dead for EVERY pixel of the wavefront (s[64:65] / s[66:67]:
+    the min / max clauses all 64 lanes decided for the lhs / rhs).  Nothing decided: exactly the plain Deriv walk; decisions skip
+    whole clauses only."""
+    from test_voxel_gen import disassemble, walk
+    words = [int(w) for w in tapes("bear").data]
+    arr = np.array(words, dtype=np.uint64)
+    buf = (ctypes.c_uint32 * 65536)()
+    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 2, buf, 65536)
+    plain = list(buf[:n])
+    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 5, buf, 65536)
+    guarded = list(buf[:n])
+    assert n > len(plain)
+    # (a guard resets the emitter's DPP hazard bookkeeping: an s_nop the plain code needs in front of a quad_perm read may be
+    # missing or extra right behind a guard, never wrong: two scalar instructions stand in for the wait states)
+    strip = lambda lines: [l for l in lines if not l.startswith("s_nop") and not l.startswith("s_setpc_b64 s[38:39]")]
+    assert strip(walk(guarded, 0, 0)) == strip(disassemble(plain))
+    rng = np.random.default_rng(4)
+    for trial in range(6):
+        dl = int(rng.integers(0, 1 << 27)) & ~int(rng.integers(0, 1 << 27))
+        dr = int(rng.integers(0, 1 << 27)) & ~dl & ~int(rng.integers(0, 1 << 27))
+        got = strip(walk(guarded, dl, dr))
+        it = iter(strip(disassemble(plain)))
+        assert all(any(x == y for y in it) for x in got)
+        assert len(got) < len(strip(disassemble(plain)))

@@ -275,7 +275,7 @@ def walk(code, dl, dr):
             return out
         m = re.match(r"s_bitcmp1_b64 s\[(\d+):\d+\], (\d+)", l)
         if m:      # (the float walk keeps the tile's decisions in s[76:79], the interval walk those from above in s[72:75])
-            scc = ((dl if m.group(1) in ("76", "72") else dr) >> int(m.group(2))) & 1
+            scc = ((dl if m.group(1) in ("76", "72", "64") else dr) >> int(m.group(2))) & 1      # (the Deriv walk: s[64:65] / s[66:67])
         m = re.match(r"(s_branch|s_cbranch_scc1|s_cbranch_scc0|s_cbranch_vccnz) (\d+)", l)
         if m:
             off = int(m.group(2))
