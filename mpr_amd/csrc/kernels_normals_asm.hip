@@ -741,14 +741,18 @@ k_eval_normals_gen(NormalArgs a)
     const uint64_t head0 = a.tape_ro[0];
     const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;
     /* :1021-1031 — value first, then the unit partials */
-    /* what EVERY filled pixel of the footprint has decided (pixels without a surface decide nothing and see nothing): bit by bit,
-     * one ballot per min / max clause and side */
+    /* what EVERY filled pixel of the footprint has decided (pixels without a surface decide nothing and see nothing): the AND over
+     * the distinct (dl, dr) pairs among them — a footprint meets a handful of tiles */
     uint64_t all_l = 0, all_r = 0;
     if (a.gen_code_guarded) {
-        const uint64_t want = ballot(filled);
-        for (int k = 0; k < a.gen_nchoices; ++k) {
-            if ((ballot(filled && ((dl >> k) & 1ull)) == want)) all_l |= 1ull << k;
-            if ((ballot(filled && ((dr >> k) & 1ull)) == want)) all_r |= 1ull << k;
+        all_l = all_r = ~0ull;
+        uint64_t todo = ballot(filled);
+        while (todo) {
+            const uint32_t leader = (uint32_t)(__ffsll((long long)todo) - 1);
+            const uint64_t vl = rdlane64(dl, leader), vr = rdlane64(dr, leader);
+            all_l &= vl;
+            all_r &= vr;
+            todo &= ~ballot(filled && dl == vl && dr == vr);
         }
         if (!filled) {           /* their lanes walk along (and store nothing): let them take the same branches of every min / max */
             dl = all_l;
