@@ -121,6 +121,7 @@ static void finish_tape(mpr_tape* t)
         const uint64_t c = t->clauses[i];
         max_slot = std::max<int>(max_slot, std::max<int>(mpr_cl_out(c), std::max<int>(mpr_cl_lhs(c), mpr_cl_rhs(c))));
         if (i > 0 && i + 1 < t->clauses.size() && mpr_op_is_minmax(mpr_cl_op(c))) choices++;
+        if (mpr_cl_op(c) == MPR_OP_ASIN_LHS || mpr_cl_op(c) == MPR_OP_ACOS_LHS) t->has_asin_acos = true;
     }
     t->num_slots = max_slot + 1;
     t->num_choices = choices;

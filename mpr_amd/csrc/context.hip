@@ -998,7 +998,7 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
     }
     {
         /* frames nobody reads owe the reference heights and normals, not tile occupancy: sound but wider exp / log enclosures */
-        a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose;
+        a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose && !tape->has_asin_acos;
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
         std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";

@@ -1095,7 +1095,6 @@ k_test_loose_interval(int op, float imm, unsigned long long first, unsigned long
     for (unsigned long long k = threadIdx.x + (unsigned long long)blockIdx.x * blockDim.x; k < count; k += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t bits = (uint32_t)(first + k);
         const float x = mpr_u2f(bits);
-        const bool pos_normal = bits >= 0x00800000u && bits <= 0x7F7FFFFFu;
         if (op == 100) {
             /* the reciprocal's bounds of the division by a constant: 1 / x in [y_dn, y_up], checked exactly (a product of two
              * floats is a double) */
@@ -1113,38 +1112,48 @@ k_test_loose_interval(int op, float imm, unsigned long long first, unsigned long
             }
             continue;
         }
-        const bool in_domain = op == MPR_OP_EXP_LHS ? (x <= 80.0f) : op == MPR_OP_DIV_LHS_IMM ? true : pos_normal;      /* (the routines' own tests) */
-        if (!in_domain) continue;
-        int c = 0;
-        const ival exact = interval_clause((uint32_t)op, iv(x, x), iv(0.0f, 0.0f), imm, c);
-        float lo, hi;
-        if (op == MPR_OP_SQRT_LHS)
-            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FSQRT_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                         : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44");
-        else if (op == MPR_OP_DIV_LHS_IMM)
-            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n v_mov_b32 v38, %3\n" TG_FDIVI_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                         : "=&v"(lo), "=&v"(hi) : "v"(x), "v"(imm)
-                         : "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50");
-        else if (op == MPR_OP_EXP_LHS)
-            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FEXP_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                         : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
-        else
-            asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %2\n" TG_FLOG_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                         : "=&v"(lo), "=&v"(hi) : "v"(x) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
-        ++tested;
-        /* encloses: a NaN end of the exact enclosure (an operation without a value there) must be a NaN here too */
-        const bool lo_ok = exact.lo != exact.lo ? lo != lo : lo <= exact.lo, hi_ok = exact.hi != exact.hi ? hi != hi : hi >= exact.hi;
-        if (!(lo_ok && hi_ok)) {
-            ++bad;
-            example = bits;
+        const auto in_domain = [&](float v, uint32_t vb) {      /* (the routines' own tests) */
+            return op == MPR_OP_EXP_LHS ? (v <= 80.0f) : op == MPR_OP_DIV_LHS_IMM ? (v == v) : (vb >= 0x00800000u && vb <= 0x7F7FFFFFu);
+        };
+        if (!in_domain(x, bits)) continue;
+        /* [x, x], and the interval between x and a second float of the domain (a scrambled copy of its bits): an end taken from the
+         * wrong side — the division by a NEGATIVE constant swaps them — shows only when the ends differ */
+        const uint32_t bits2 = (bits * 2654435761u) ^ 0x9E3779B9u;
+        const float x2 = mpr_u2f(bits2);
+        for (int variant = 0; variant < 2; ++variant) {
+            if (variant == 1 && !in_domain(x2, bits2)) break;
+            const float in_lo = variant == 0 ? x : (x < x2 ? x : x2), in_hi = variant == 0 ? x : (x < x2 ? x2 : x);
+            int c = 0;
+            const ival exact = interval_clause((uint32_t)op, iv(in_lo, in_hi), iv(0.0f, 0.0f), imm, c);
+            float lo, hi;
+            if (op == MPR_OP_SQRT_LHS)
+                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n" TG_FSQRT_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi) : "v36", "v37", "v40", "v41", "v42", "v43", "v44");
+            else if (op == MPR_OP_DIV_LHS_IMM)
+                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n v_mov_b32 v38, %4\n" TG_FDIVI_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi), "v"(imm)
+                             : "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "vcc");
+            else if (op == MPR_OP_EXP_LHS)
+                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n" TG_FEXP_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+            else
+                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n" TG_FLOG_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
+                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+            ++tested;
+            /* encloses: a NaN end of the exact enclosure (an operation without a value there) must be a NaN here too */
+            const bool lo_ok = exact.lo != exact.lo ? lo != lo : lo <= exact.lo, hi_ok = exact.hi != exact.hi ? hi != hi : hi >= exact.hi;
+            if (!(lo_ok && hi_ok)) {
+                ++bad;
+                example = bits;
+            }
+            if (variant == 1 || exact.lo != exact.lo || exact.hi != exact.hi || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f ||
+                lo - lo != 0.0f || hi - hi != 0.0f)
+                continue;                              /* (no width to speak of: an end at infinity — a quotient that overflows one rounding earlier) */
+            const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
+            const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;        /* relative above 1, absolute below */
+            const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
+            if (units > widest) widest = units;
         }
-        if (exact.lo != exact.lo || exact.hi != exact.hi || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f || lo - lo != 0.0f ||
-            hi - hi != 0.0f)
-            continue;                                  /* (no width to speak of: an end at infinity — a quotient that overflows one rounding earlier) */
-        const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
-        const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;        /* relative above 1, absolute below */
-        const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
-        if (units > widest) widest = units;
     }
     if (bad) {
         atomicAdd(&out[0], bad);

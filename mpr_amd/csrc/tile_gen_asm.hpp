@@ -34,8 +34,22 @@ namespace mprk {
  *   log:  p = RU(v_log_f32(x) ln2),  e = (|p| + 1) 2^-21:                  [RD(p - e), RU(p + e)]
  * about 1e-5 relative where the exact route has 6e-8, on values that feed sums of terms of magnitude 1 over tiles whose natural
  * extension is 0.3 wide: the classification barely moves (DESIGN.md has the counts).  Only when EVERY lane's ends are ordinary
- * (exp: x <= 80, any negative number — results below 2^-120 become [0, 2^-120]; log: positive normal numbers) — anything else takes
- * the exact routine, with all of its special cases.
+ * (exp: x <= 80, any negative number — results below 2^-120 become [0, 2^-120]; log, sqrt: positive normal numbers) — anything else
+ * takes the exact routine, with all of its special cases.
+ * What "sound" has to mean here: the loose result of an operation encloses the exact one WHENEVER its operands enclose the exact
+ * operands — by induction over the tape every loose interval then encloses the reference's, and whatever the loose walk proves (a
+ * tile empty or filled, a min / max decided) the reference proves too; what it fails to prove is evaluated one level further down,
+ * to the same pixels — as long as the reference's own proofs are facts about the float pass's values.  Two things break that, and
+ * the loose walk must stay away from both:
+ *  - an exact routine that is not inclusion-isotone, handed the loose walk's wider operands: log returns the lower bound 0 for
+ *    x.lo <= 0 and log(x.lo) — as low as -103 — for a tiny positive one (reference inc/gpu_interval.hpp:382-390), and a loose lower
+ *    end can be 0 where the exact one is tiny and positive;
+ *  - exact bounds that are not facts: the same lower bound 0 where the logarithm is very negative (a steep exp / log blend far from
+ *    its surface: the reference then drops the OTHER operand of a min, and its image lacks what that operand drew — tests: "smooth"),
+ *    sqrt's [0, ..] over an interval whose negative part is NaN to the float pass, asin / acos outside [-1, 1].
+ * So: a log whose lower end is not a positive normal number, a sqrt whose lower end is negative -> the WHOLE walk again with the
+ * exact routines (L_redo: the wave's tiles then are exactly the reference's); tapes with asin / acos clauses never run loose
+ * (context.hip).
  * SOUNDNESS IS NOT ARGUED ONLY: mpr_test_loose_interval runs these very instructions on every float of the domain on the device
  * and holds each end against the exact routine's (tests/test_gpu_primitives.py: test_loose_exp_log_enclose_the_exact_ones).
  * In: v36 = lo, v37 = hi; out v40, v41; temporaries v42..v47; round-up mode. */
@@ -81,7 +95,7 @@ namespace mprk {
     "v_xor_b32 v40, 0x80000000, v40\n"
 /* division by a constant c (v38; 2^-100 <= |c| <= 2^100): y = v_rcp_f32(c) (1 ulp; 2 assumed), 1 / c lies in [y_dn, y_up] =
  * [RD(y - |y| 2^-22), RU(y + |y| 2^-22)], so x / c lies between x y_dn and x y_up whatever the signs: the lower end is the smaller of
- * the two products rounded down, the upper end the larger rounded up (12 instructions where the correctly rounded pair takes ~75:
+ * the two products of the end it comes from (lo for c > 0, hi for c < 0) rounded down, the upper end the larger of the other end's rounded up (15 instructions where the correctly rounded pair takes ~75:
  * bear divides by a constant 39 times per walk).  TG_FRCP_CORE leaves y_up in v45 and -y_dn in v46. */
 #define TG_FRCP_CORE                                                                                              \
     "v_rcp_f32 v42, v38\n"                                                                                        \
@@ -92,16 +106,21 @@ namespace mprk {
     "v_sub_f32 v46, v43, v42\n"                         /* RU(w - y) = -y_dn */
 #define TG_FDIVI_CORE                                                                                             \
     TG_FRCP_CORE                                                                                                  \
-    "v_mul_f32 v47, v36, v46\n"                         /* RU(lo (-y_dn)) = -RD(lo y_dn) */                       \
-    "v_mul_f32_e64 v48, -v36, v45\n"                    /* RU((-lo) y_up) = -RD(lo y_up) */                       \
-    "v_mul_f32_e64 v49, v37, -v46\n"                    /* RU(hi y_dn) */                                         \
-    "v_mul_f32 v50, v37, v45\n"                         /* RU(hi y_up) */                                         \
+    "v_cmp_gt_f32 vcc, 0, v38\n"                        /* a negative divisor: the quotient falls, the ends trade places */ \
+    "v_cndmask_b32 v49, v36, v37, vcc\n"                /* a: the end the lower end comes from */                 \
+    "v_cndmask_b32 v50, v37, v36, vcc\n"                /* b: ... the upper end */                                \
+    "v_mul_f32 v47, v49, v46\n"                         /* RU(a (-y_dn)) = -RD(a y_dn) */                         \
+    "v_mul_f32_e64 v48, -v49, v45\n"                    /* RU((-a) y_up) = -RD(a y_up) */                         \
+    "v_mul_f32_e64 v49, v50, -v46\n"                    /* RU(b y_dn) */                                          \
+    "v_mul_f32 v50, v50, v45\n"                         /* RU(b y_up) */                                          \
     "v_max_f32 v40, v47, v48\n"                         /* - lower end */                                         \
     "v_max_f32 v41, v49, v50\n"                                                                                   \
     "v_xor_b32 v40, 0x80000000, v40\n"
 /* the routines: the range test, then the core or the exact routine */
 #define TG_LOOSE_ROUTINES                                                                                         \
     "L_fsqrt_%=:\n"                                                                                               \
+    "v_cmp_gt_f32 vcc, 0, v36\n"                        /* a negative lower end: the float pass's NaN is near */   \
+    "s_cbranch_vccnz L_redo_%=\n"                                                                                 \
     "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
     "v_add_u32 v43, 0xff800000, v37\n"                                                                            \
     "v_max_u32 v42, v42, v43\n"                                                                                   \
@@ -126,12 +145,20 @@ namespace mprk {
     "s_setpc_b64 s[36:37]\n"                                                                                      \
     "L_flog_%=:\n"                                                                                                \
     "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
+    "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* a LOWER end that is not a positive normal number: the exact */ \
+    "s_cbranch_vccnz L_redo_%=\n"                       /* walk may be in the branch that is not isotone */        \
     "v_add_u32 v43, 0xff800000, v37\n"                                                                            \
-    "v_max_u32 v42, v42, v43\n"                                                                                   \
-    "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* an end that is not a positive normal number */          \
+    "v_cmp_le_u32 vcc, 0x7f000000, v43\n"               /* the upper end: inf, NaN */                              \
     "s_cbranch_vccnz L_clog_%=\n"                                                                                 \
     TG_FLOG_CORE                                                                                                  \
-    "s_setpc_b64 s[36:37]\n"
+    "s_setpc_b64 s[36:37]\n"                                                                                      \
+    /* the walk again, with the exact routines (the axes' intervals and the wave's words are still in LDS) */     \
+    "L_redo_%=:\n"                                                                                                \
+    "v_mov_b32 v33, %[io]\n"                                                                                      \
+    "v_mov_b32 v53, 0\n"                                                                                          \
+    "ds_write_b32 v33, v53 offset:3876\n"                                                                         \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "s_branch L_again_%=\n"
 
 /* smem_io: 4 KB of LDS ([16][64] words) the register state travels through: the statement below names all but ten vector
  * registers.  ax / ay / az: 2 * the axes' slots; x / y / z: their intervals.  Out: the end clause's interval, and the lanes'
@@ -158,6 +185,7 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
     }
     asm volatile(
         /* the axes' intervals into their slots (TI_VS_ENTER with the three slot numbers in one operand) */
+        "L_again_%=:\n"
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_read_b32 v36, v32\n ds_read_b32 v37, v32 offset:256\n ds_read_b32 v38, v32 offset:512\n"
         "ds_read_b32 v39, v32 offset:768\n ds_read_b32 v42, v32 offset:1024\n ds_read_b32 v43, v32 offset:1280\n"

@@ -53,6 +53,11 @@ def tapes(mpr):
             t = mpr.tmin(mpr.sin(X * 3) + mpr.cos(Y * 2) * 0.5 + mpr.atan(Z + X) * 0.3 - 0.2,
                          mpr.tmax(mpr.exp(X) * 0.2 - mpr.log(Y * Y + 1.5) + mpr.asin(X * 0.5) * mpr.acos(Y * 0.5) * 0.1,
                                   mpr.tabs(Z) - 0.8 + X / (Y * Y + 2.0)))
+        elif name == "smooth":        # exp / log blends the way bear has them, steep enough that exp underflows far from the surface
+            d1 = mpr.sqrt((X + 0.3) * (X + 0.3) + Y * Y + Z * Z) - 0.35
+            d2 = mpr.sqrt((X - 0.3) * (X - 0.3) + (Y - 0.1) * (Y - 0.1) + Z * Z) - 0.3
+            blend = mpr.log(mpr.exp(d1 * -64.0) + mpr.exp(d2 * -64.0)) / -64.0
+            t = mpr.tmax(mpr.tmin(blend, mpr.sqrt(X * X + (Y + 0.6) * (Y + 0.6) + Z * Z) / 3.0 - 0.1), Z - 0.25)
         elif name == "many_slots":    # > 128 simultaneously live values: every s_i is used by a product and, later, a sum
             terms = [(X - (i % 13) * 0.11 + 0.6) * (Y + (i % 7) * 0.13 - 0.4) + Z * (0.01 * i) for i in range(150)]
             prod = terms[0]

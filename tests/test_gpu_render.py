@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name,S", [("circle", 128), ("circle", 256), ("two_spheres", 256), ("ring", 256),
                                     ("hello_world", 256), ("prospero", 256), ("involute_gear_2d", 512),
-                                    ("trig", 256), ("architecture", 256)])
+                                    ("trig", 256), ("architecture", 256), ("smooth", 256)])
 def test_render2d_matches_oracle(mpr, orc, tapes, name, S):
     compare_frame(mpr, orc, tapes(name), 2, S, view2())
 
@@ -24,7 +24,7 @@ def test_render2d_general_view(mpr, orc, tapes):
 
 
 @pytest.mark.parametrize("name,S", [("sphere", 128), ("two_spheres", 256), ("hello_world", 256), ("bear", 256),
-                                    ("architecture", 256), ("involute_gear_3d", 256), ("trig", 128)])
+                                    ("architecture", 256), ("involute_gear_3d", 256), ("trig", 128), ("smooth", 256)])
 def test_render3d_matches_oracle(mpr, orc, tapes, name, S):
     compare_frame(mpr, orc, tapes(name), 3, S, view3())
 
@@ -324,7 +324,7 @@ def test_generated_code_float_pass_matches_assembly_interpreter(mpr, tapes, name
     b.close()
 
 
-@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("bear", 1024), ("trig", 128), ("trig", 256), ("two_spheres", 128), ("sphere", 128)])
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("bear", 1024), ("trig", 128), ("trig", 256), ("two_spheres", 128), ("sphere", 128), ("smooth", 256), ("smooth", 512)])
 def test_float_pass_on_the_root_tapes_host_generated_code(mpr, orc, tapes, name, S, monkeypatch):
     """Tapes of at most 24 slots and 64 min / max clauses, 3-D frames whose tile stages kept their tiles' decisions: the float pass
     runs the ROOT tape's float walk as code generated on the host (csrc/voxel_gen.cpp, k_eval_voxels_gen) with the decisions of a
@@ -350,7 +350,7 @@ def test_float_pass_on_the_root_tapes_host_generated_code(mpr, orc, tapes, name,
         ctx.close()
 
 
-@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 1024), ("trig", 128), ("trig", 256)])
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 1024), ("smooth", 128), ("smooth", 256), ("smooth", 1024), ("trig", 128), ("trig", 256)])
 def test_tile_stages_with_loose_exp_and_log(mpr, orc, tapes, name, S, monkeypatch):
     """Frames nobody reads run their generated tile stages with exp / log enclosures from the hardware's base-2 instructions
     (sound, about 1e-5 wide instead of correctly rounded; MPR_TILE_GEN_LOOSE=0: the exact ones): a few tiles that the reference
@@ -362,7 +362,8 @@ def test_tile_stages_with_loose_exp_and_log(mpr, orc, tapes, name, S, monkeypatc
     monkeypatch.setenv("MPR_TILE_GEN_LOOSE", "0")
     exact = mpr.Context(S)
     counts = []
-    for ctx, tag in ((loose, "+loose"), (exact, "")):
+    # (asin / acos are not inclusion-isotone — a wider operand can miss their out-of-domain NaN: such a tape keeps the exact routines)
+    for ctx, tag in ((loose, "" if name == "trig" else "+loose"), (exact, "")):
         for _ in range(2):
             ctx.render3D(tape, view3())
             assert np.array_equal(ctx.image, ref.filled[3]), (tag, int((ctx.image != ref.filled[3]).sum()))
