@@ -93,6 +93,13 @@ int32_t mpr_tape_num_choices(const mpr_tape* t);       /* number of min/max clau
 int32_t mpr_tape_flags(const mpr_tape* t);             /* bit1: unsupported opcodes (src/tape.cpp:182-196).  Bit0 is never set:
                                                           where the reference prints "Ran out of slots!" and renders with slot 0
                                                           (:79-81), mpr_tape_from_tree fails with MPR_ERR_UNSUPPORTED */
+/* Does every interval operation of the tape stay, over the WHOLE view of a frame with this matrix (column-major, (dim + 1)^2; z: the
+ * 2-D frame's), where the reference's interval routines are inclusion-isotone — operands finite and inside the function's domain
+ * (inc/gpu_interval.hpp: log's zero bound :382-390, the NaN ends of asin / acos :306-324, a divisor that holds zero :162-190 are
+ * where they are not)?  1 / 0; frames of a view that is not keep the reference's literal procedure (every stage from the 64^3
+ * tiles, the correctly rounded enclosures: csrc/frame_domain.hpp).  trace: null, or 2 * length doubles for the enclosure of every
+ * clause's result (tests). */
+int mpr_tape_frame_is_tame(const mpr_tape* t, int dim, const float* mat, float z, double* trace);
 void mpr_tape_free(mpr_tape* t);
 
 /* ---- context (mpr::Context, inc/context.hpp:38-73, src/context.cpp:17-49) ---- */
@@ -198,6 +205,9 @@ int mpr_read_normals(mpr_context* ctx, uint32_t* host);
  * (stage 0: all top-level tiles).  cap in entries.  (Renders the last frame again the reference's way first when it was an
  * ordinary one: see mpr_ctx_last_stage_pushed.  So do mpr_read_tape_pool and mpr_get_counters.) */
 int mpr_read_tiles(mpr_context* ctx, int32_t stage, mpr_tile_node* host, size_t cap, size_t* n);
+/* Frames whose shortcut past the 64^3 tiles failed its verification and that were rendered again from those tiles down (csrc/kernels.hpp:
+ * launch_skip0_parents; the tape's next 64 frames then start at the 64^3 tiles by themselves).  Tests. */
+int64_t mpr_ctx_skip0_vetoes(const mpr_context* c);
 /* tape_data / *tape_index -> host; copies min(cap, *tape_index) clauses */
 int mpr_read_tape_pool(mpr_context* ctx, uint64_t* host, size_t cap, int32_t* tape_index);
 /* device pointers (for zero-copy consumers such as the multi-GPU gather) */

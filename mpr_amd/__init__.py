@@ -126,6 +126,7 @@ def lib():
     L.mpr_tape_data.restype = P(ctypes.c_uint64)
     for name in ("mpr_tape_num_slots", "mpr_tape_num_choices", "mpr_tape_flags"):
         getattr(L, name).argtypes = [vp]
+    L.mpr_tape_frame_is_tame.argtypes = [vp, i32, vp, f32, vp]
     L.mpr_tape_free.argtypes = [vp]
     L.mpr_ctx_create.argtypes = [i32, i32, P(vp)]
     L.mpr_ctx_create_ex.argtypes = [P(CtxOptions), P(vp)]
@@ -163,6 +164,8 @@ def lib():
     L.mpr_ctx_float_kernel.argtypes = [vp]
     L.mpr_ctx_normals_kernel.argtypes = [vp]
     L.mpr_ctx_last_stage_pushed.argtypes = [vp]
+    L.mpr_ctx_skip0_vetoes.argtypes = [vp]
+    L.mpr_ctx_skip0_vetoes.restype = ctypes.c_int64
     L.mpr_ctx_resident_bytes.argtypes = [vp]
     L.mpr_column_weights.argtypes = [vp, vp, i32, vp, f32, vp]
     L.mpr_ctx_resident_bytes.restype = ctypes.c_int64
@@ -383,6 +386,16 @@ class Tape:
     def flags(self):
         return lib().mpr_tape_flags(self._h)
 
+    def frame_is_tame(self, mat, dim=3, z=0.0, trace=False):
+        """Does every interval operation stay, over the whole view of a frame with this matrix, where the reference's interval
+        routines are inclusion-isotone (csrc/frame_domain.hpp)?  trace=True: (verdict, enclosures[length, 2] of the clauses' results)."""
+        m = np.ascontiguousarray(colmajor(mat, dim + 1), dtype=np.float32)
+        tr = np.zeros((self.length, 2), dtype=np.float64) if trace else None
+        rc = lib().mpr_tape_frame_is_tame(self._h, dim, _ptr(m), float(z), _ptr(tr) if trace else None)
+        if rc < 0:
+            _check(rc)
+        return (bool(rc), tr) if trace else bool(rc)
+
 
 def clause(op, out=0, lhs=0, rhs=0, imm=0.0):
     """Pack one clause (inc/clause.hpp:18-23)."""
@@ -595,6 +608,10 @@ class Context:
     def last_stage_pushed(self):
         """False when the last frame's last tile stage pushed no per-tile tapes (mpr_ctx_last_stage_pushed)."""
         return bool(lib().mpr_ctx_last_stage_pushed(self._h))
+
+    def skip0_vetoes(self):
+        """Frames whose shortcut past the 64^3 tiles failed its verification against those tiles and were rendered again from them."""
+        return int(lib().mpr_ctx_skip0_vetoes(self._h))
 
     def dev_filled(self, stage=3):
         return lib().mpr_dev_filled(self._h, stage)

@@ -12,6 +12,7 @@
 
 #include "../../include/mpr_amd.h"
 #include "internal.hpp"
+#include "frame_domain.hpp"
 #include "tape_builder.hpp"
 #include "tree.hpp"
 
@@ -121,7 +122,11 @@ static void finish_tape(mpr_tape* t)
         const uint64_t c = t->clauses[i];
         max_slot = std::max<int>(max_slot, std::max<int>(mpr_cl_out(c), std::max<int>(mpr_cl_lhs(c), mpr_cl_rhs(c))));
         if (i > 0 && i + 1 < t->clauses.size() && mpr_op_is_minmax(mpr_cl_op(c))) choices++;
-        if (mpr_cl_op(c) == MPR_OP_ASIN_LHS || mpr_cl_op(c) == MPR_OP_ACOS_LHS) t->has_asin_acos = true;
+        if (mpr_cl_op(c) == MPR_OP_ASIN_LHS || mpr_cl_op(c) == MPR_OP_ACOS_LHS) t->loose_ok = false;
+        if (mpr_cl_op(c) == MPR_OP_DIV_LHS_IMM) {
+            const uint32_t mag = mpr_cl_immbits(c) & 0x7FFFFFFFu;
+            if (mag < 0x0D800000u || mag > 0x71800000u) t->loose_ok = false;
+        }
     }
     t->num_slots = max_slot + 1;
     t->num_choices = choices;
@@ -199,6 +204,13 @@ const uint64_t* mpr_tape_data(const mpr_tape* t) { return t ? t->clauses.data() 
 int32_t mpr_tape_num_slots(const mpr_tape* t) { return t ? t->num_slots : 0; }
 int32_t mpr_tape_num_choices(const mpr_tape* t) { return t ? t->num_choices : 0; }
 int32_t mpr_tape_flags(const mpr_tape* t) { return t ? t->flags : 0; }
+/* frame_domain.hpp: 1 if every interval operation of the tape stays, over the whole view, where the reference's interval routines are
+ * inclusion-isotone (frames of such a view may start at the 16^3 tiles and take the loose enclosures), 0 if not, < 0: an error */
+int mpr_tape_frame_is_tame(const mpr_tape* t, int dim, const float* mat, float z, double* trace)
+{
+    if (!t || !mat || (dim != 2 && dim != 3)) return mpr::set_error(MPR_ERR_INVALID, "null argument or bad dimension");
+    return mpr::frame_is_tame(t->clauses.data(), (int)t->clauses.size(), dim, mat, z, trace) ? 1 : 0;
+}
 void mpr_tape_free(mpr_tape* t) { delete t; }
 
 /* ---- column partition: longest-processing-time-first deal ---- */

@@ -25,6 +25,7 @@
 #include "kernels.hpp"
 #include "tile_gen.hpp"
 #include "voxel_gen.hpp"
+#include "frame_domain.hpp"
 static_assert(mpr::TILE_GEN_RECORD_U64 == mprk::GEN_RECORD_U64 && mpr::TILE_GEN_PRESENCE_WORDS == mprk::GEN_PRESENCE_WORDS, "one record layout");
 
 namespace {
@@ -165,6 +166,29 @@ struct mpr_context {
                                                                                    Deriv walk start in gen_code (dwords) */
     bool normals_guards = true;        /* MPR_NORMALS_GUARDS=0: the normals pass runs the plain Deriv walk */
     int gen_fwdg_dw = 0;               /* dwords of the forward walk with guarded dead runs (TileGen::fwd_guarded), behind the float walk (0: none) */
+    /* frame_domain.hpp: does the last (tape, view) asked about keep every interval operation where the reference's routines are
+     * isotone (the shortcuts below that are only then the reference's procedure: skip0, the loose enclosures) */
+    uint64_t tame_serial = 0;
+    FrameKey tame_key;
+    bool tame_value = false;
+    bool tame_check = true;            /* MPR_TAME_CHECK=0 (development): every frame counts as tame */
+    /* frames that start at the 16^3 tiles and are not tame: the 64^3 tiles walked beside the frame, every 16^3 tile held against
+     * its parent before the float pass is launched (kernels.hpp: launch_skip0_parents / launch_skip0_compare) */
+    hipStream_t side = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_stage = nullptr, ev_check = nullptr, ev_done = nullptr;   /* code installed (frame's stream) / first stage through
+                                          (frame's) / 64^3 tiles walked (side) / compared (side; frames that do not block) */
+    bool side_must_wait = false;       /* the tape's code was installed since the side stream last looked */
+    bool skip0_unchecked = false;      /* a comparison has been launched whose verdict nobody has read yet */
+    unsigned long long* skip0_parents = nullptr;
+    size_t skip0_parents_cap = 0;
+    unsigned long long* skip0_children = nullptr;
+    size_t skip0_children_cap = 0;
+    int* skip0_flag_host = nullptr;    /* host-coherent; 1: some 16^3 tile did not do what its parent would have made it do */
+    int* skip0_flag_dev = nullptr;
+    bool skip0_verify = true;          /* MPR_SKIP0_CHECK=0 (development): such frames go unverified */
+    uint64_t skip0_veto_serial = 0;    /* the tape whose last verified frame failed: its next frames start at the 64^3 tiles ... */
+    int skip0_veto_left = 0;           /* ... this many of them, then one tries again */
+    long long skip0_vetoes = 0;        /* frames rendered again (mpr_ctx_skip0_vetoes: tests) */
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
@@ -395,6 +419,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TAME_CHECK")) c->tame_check = atoi(e) != 0;
+    if (const char* e = getenv("MPR_SKIP0_CHECK")) c->skip0_verify = atoi(e) != 0;
     if (const char* e = getenv("MPR_NORMALS_GUARDS")) c->normals_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
@@ -468,6 +494,14 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipHostMalloc((void**)&c->pub_host, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->pub_host, 0, 16 * sizeof(int));
     CT(hipHostGetDevicePointer((void**)&c->pub_dev, c->pub_host, 0));
+    CT(hipHostMalloc((void**)&c->skip0_flag_host, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->skip0_flag_host, 0, 16 * sizeof(int));
+    CT(hipHostGetDevicePointer((void**)&c->skip0_flag_dev, c->skip0_flag_host, 0));
+    CT(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    CT(hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
+    CT(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+    CT(hipEventCreateWithFlags(&c->ev_check, hipEventDisableTiming));
+    CT(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     CT(hipMemsetAsync(c->num_active, 0, 8 * sizeof(int), c->stream));
     CT(hipMemsetAsync(c->arena, 0, c->arena_words * sizeof(int), c->stream));
     CT(hipStreamSynchronize(c->stream));
@@ -490,6 +524,17 @@ void mpr_ctx_destroy(mpr_context* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+    if (c->ev_check) (void)hipEventDestroy(c->ev_check);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->skip0_parents) (void)hipFree(c->skip0_parents);
+    if (c->skip0_children) (void)hipFree(c->skip0_children);
+    if (c->skip0_flag_host) (void)hipHostFree(c->skip0_flag_host);
     for (int i = 0; i < 4; ++i) {
         c->filled[i] = nullptr;
         if (c->tiles[i]) (void)hipFree(c->tiles[i]);
@@ -604,6 +649,8 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     HIP_TRY(hipMemcpyAsync(c->gen_stage, code->words.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                     mprk::launch_install_code(c->stream, c->gen_code, c->gen_stage, ndw, std::max(c->cus, 1));
                     HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipEventRecord(c->ev_begin, c->stream));       /* (the side stream's walk of the 64^3 tiles waits for it) */
+                    c->side_must_wait = true;
                     c->gen_ok = true;
                     c->gen_fwd_dw = code->fwd_dw;
                     c->gen_bwd_dw = code->bwd_dw;
@@ -791,6 +838,9 @@ struct Frame {
     int nstages = 0;
     bool reference = false;                /* the reference's way: every stage from the 64 px tiles down, every tape pushed */
     bool skip0 = false;                    /* starts at the 16^3 tiles */
+    bool tame = false;                     /* frame_domain.hpp: every interval operation stays where the reference's routines are isotone */
+    bool skip0_checked = false;            /* skip0 of a frame that is not tame: verified against the 64^3 tiles before the float pass */
+    mprk::Skip0ParentsArgs skip0_args;
     bool tiles_only = false;               /* a reader's re-render: tile stages only */
     mpr_context::FrameKey key;
     /* what the stages leave behind */
@@ -877,8 +927,38 @@ static int frame_begin(Frame& f)
      * the heights and normals are the same; tile lists and tapes of the first two stages are not the reference's, and a reader gets
      * the frame again the reference's way (ensure_reference_frame).  Tapes with wide DAGs keep the level-parallel first stage. */
     const int t16 = S / 16;
-    const bool skip0 = !reference && c->skip_stage0 && dim == 3 && !(c->wide_stage0 && c->sched_ok) && c->cus > 0 &&
-                       (long long)t16 * t16 * t16 / 64 <= 16ll * c->cus && c->normals_asm && c->tiles_asm;
+    bool skip0 = !reference && c->skip_stage0 && dim == 3 && !(c->wide_stage0 && c->sched_ok) && c->cus > 0 &&
+                 (long long)t16 * t16 * t16 / 64 <= 16ll * c->cus && c->normals_asm && c->tiles_asm;
+    /* ... which is the reference's procedure only while its interval routines are inclusion-isotone (the children decide by
+     * themselves what the 64^3 tile would have decided for them): not where a NaN end or log's zero bound takes over — a
+     * shape that leaves a function's domain somewhere in the view keeps the 64^3 stage (frame_domain.hpp) */
+    bool tame = false;
+    if (!reference && (skip0 || c->tile_gen_loose)) {
+        if (!c->tame_check) {
+            tame = true;
+        } else {
+            const bool known = c->tame_serial == tape->serial && c->tame_key.dim == key.dim && c->tame_key.z == key.z &&
+                               std::memcmp(c->tame_key.mat, key.mat, sizeof(key.mat)) == 0;
+            if (!known) {
+                c->tame_value = mpr::frame_is_tame(tape->clauses.data(), (int)tape->clauses.size(), dim, mat, z);
+                c->tame_serial = tape->serial;
+                c->tame_key = key;
+            }
+            tame = c->tame_value;
+        }
+    }
+    /* not tame (bear: the exp / log blends of its far tiles underflow in every frame): the shortcut is taken and VERIFIED — the
+     * 64^3 tiles are walked beside the frame and every 16^3 tile is held against its parent (kernels.hpp); a tape whose last
+     * verified frame failed keeps the 64^3 stage for a while */
+    bool skip0_checked = false;
+    if (skip0 && !tame && c->skip0_verify) {
+        const bool can = c->gen_ok && c->gen_nchoices <= 64 && !(c->debug_tiles & 3) && c->tile_gen == 1 &&
+                         mprk::tile_stage_gen_possible(nslots, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
+        const bool vetoed = c->skip0_veto_serial == tape->serial && c->skip0_veto_left > 0;
+        if (vetoed) --c->skip0_veto_left;
+        if (!can || vetoed) skip0 = false;
+        else skip0_checked = true;
+    }
     /* a reader's reference frame of a partitioned context keeps the columns other ranks sent (mpr_unpack_*): only this rank's
      * columns are cleared */
     const bool keep_foreign = c->force_reference && owner != nullptr;
@@ -898,6 +978,27 @@ static int frame_begin(Frame& f)
         mprk::launch_begin_frame(s, c->arena, zero_now, c->tape_index, (int)tape->clauses.size(), c->num_active,
                                  c->tiles[0], count, t0 * t0, owner ? c->owner_dev : nullptr, rank, skip0 ? c->tiles[1] : nullptr, t0);
         c->tiles_n[0] = (size_t)count;
+        if (skip0_checked) {
+            /* the 64^3 tiles' own walk, beside the frame: behind whatever the frame's stream has uploaded (the tape, its code) */
+            rc = ensure_buffer(&c->skip0_parents, &c->skip0_parents_cap, (size_t)count * mprk::SKIP0_INFO_U64);
+            if (rc) return rc;
+            rc = ensure_buffer(&c->skip0_children, &c->skip0_children_cap, (size_t)count * 64 * mprk::SKIP0_INFO_U64);
+            if (rc) return rc;
+            *reinterpret_cast<volatile int*>(c->skip0_flag_host) = 0;
+            if (c->side_must_wait) {
+                HIP_TRY(hipStreamWaitEvent(c->side, c->ev_begin, 0));
+                c->side_must_wait = false;
+            }
+            mprk::Skip0ParentsArgs& pa = f.skip0_args;
+            pa.tape_ro = c->pool;
+            pa.gen_fwd = c->gen_code;
+            pa.parents = c->skip0_parents;
+            pa.count = count;
+            pa.tps = t0;
+            std::memcpy(pa.mat, mat, sizeof(pa.mat));
+            mprk::launch_skip0_parents(c->side, pa);
+            HIP_TRY(hipEventRecord(c->ev_check, c->side));
+        }
         if (skip0) {
             c->last.tiles_in[0] = count;
             c->last.tiles_active[0] = count;
@@ -916,7 +1017,7 @@ static int frame_begin(Frame& f)
     }
     f.S = S; f.s = s; f.cnt = cnt; f.heat = heat; f.nslots = nslots; f.choice_cap = choice_cap;
     for (int k = 0; k < 3; ++k) f.stage_list[k] = stage_list[k];
-    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key;
+    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.tame = tame; f.skip0_checked = skip0_checked;
     f.count = count; f.stage_choice_cap = stage_choice_cap; f.hint = hint;
     return MPR_OK;
 }
@@ -998,7 +1099,17 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
     }
     {
         /* frames nobody reads owe the reference heights and normals, not tile occupancy: sound but wider exp / log enclosures */
-        a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose && !tape->has_asin_acos;
+        const bool verified_stage = f.skip0_checked && si == 1;
+        if (verified_stage) {
+            if (!a.gen_fwd || a.gen_parent) {          /* (not expected: frame_begin asked the same questions) */
+                c->skip0_veto_serial = tape->serial;
+                c->skip0_veto_left = 64;
+                return FRAME_AGAIN;
+            }
+            a.self_info = c->skip0_children;
+        }
+        /* (not the stage that is held against its exact parents: a looser child decides less than they did) */
+        a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose && tape->loose_ok && !verified_stage;
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
         std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
@@ -1160,6 +1271,14 @@ static int frame_tile_stage(Frame& f, int si)
         if (count > 0) {
             rc = stage_launch(f, si, i, tps, last, wide_now, groups_now, try_lean, a);
             if (rc) return rc;
+            if (a.self_info && !f.blocking) {
+                /* a frame that does not block (the multi-GPU pipeline packs its columns behind it on the same stream) must have
+                 * its verdict before the float pass is launched: the comparison on the side stream, as soon as both are through */
+                HIP_TRY(hipEventRecord(c->ev_stage, s));
+                HIP_TRY(hipStreamWaitEvent(c->side, c->ev_stage, 0));
+                mprk::launch_skip0_compare(c->side, f.skip0_args, c->skip0_children, c->skip0_flag_dev);
+                HIP_TRY(hipEventRecord(c->ev_done, c->side));
+            }
         }
         if (c->stage0_only) {
             HIP_TRY(hipStreamSynchronize(s));
@@ -1416,6 +1535,19 @@ static int frame_finish(Frame& f)
     return f.blocking ? mpr_ctx_sync(c) : MPR_OK;
 }
 
+/* the comparison has been waited for: did the frame's shortcut past the 64^3 tiles fail its verification?  Then the tape's
+ * next frames start at those tiles (the caller renders this one again) */
+static bool skip0_verdict_failed(mpr_context* c, const mpr_tape* tape)
+{
+    if (!c->skip0_unchecked) return false;
+    c->skip0_unchecked = false;
+    if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0) return false;
+    c->skip0_veto_serial = tape->serial;
+    c->skip0_veto_left = 64;
+    ++c->skip0_vetoes;
+    return true;
+}
+
 static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const float* mat, float z,
                         const int32_t* owner, int rank, bool brute, bool blocking)
 {
@@ -1429,6 +1561,11 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (rc == FRAME_STOP) return MPR_OK;
         if (rc) return rc;
         c->last.voxel_tiles = f.count;
+        if (f.skip0_checked && !blocking) {
+            HIP_TRY(hipEventSynchronize(c->ev_done));        /* (long there: two tile stages have been waited for since) */
+            c->skip0_unchecked = true;
+            if (skip0_verdict_failed(c, tape)) continue;
+        }
         if (!f.tiles_only) {          /* (a reader's re-render: tiles and tapes are the reference's now; heights and normals were all along) */
             rc = frame_float_pass(f);
             if (rc == FRAME_AGAIN_REFERENCE) {
@@ -1443,7 +1580,17 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 if (rc) return rc;
             }
         }
-        return frame_finish(f);
+        if (f.skip0_checked && blocking) {
+            /* every tile of the frame's first stage against its 64^3 parent, behind the frame: the side stream's walk of those
+             * has long ended, nothing waits; the verdict is read once the frame has been waited for */
+            HIP_TRY(hipStreamWaitEvent(f.s, c->ev_check, 0));
+            mprk::launch_skip0_compare(f.s, f.skip0_args, c->skip0_children, c->skip0_flag_dev);
+            c->skip0_unchecked = true;
+        }
+        rc = frame_finish(f);
+        if (rc) return rc;
+        if (f.skip0_checked && blocking && skip0_verdict_failed(c, tape)) continue;      /* again, from the 64^3 tiles down */
+        return MPR_OK;
     }
 }
 
@@ -1468,6 +1615,7 @@ static int ensure_full_frame(mpr_context* c)
 extern "C" {
 
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
+int64_t mpr_ctx_skip0_vetoes(const mpr_context* c) { return c ? c->skip0_vetoes : 0; }
 const char* mpr_ctx_tile_stage_forms(const mpr_context* c) { return c ? c->stage_forms.c_str() : ""; }
 /* tiles of the last frame AS IT RAN (no re-render: a frame nobody reads may start at the 16^3 tiles and cull with looser bounds than
  * the reference): per stage the tiles evaluated and the tiles left ambiguous, then the smallest tiles handed to the float pass */

@@ -28,7 +28,8 @@ struct mpr_tape {
     int32_t num_slots = 0;           /* highest slot index used + 1 */
     int32_t num_choices = 0;         /* min/max clauses */
     int32_t flags = 0;
-    bool has_asin_acos = false;    /* such a tape keeps the exact interval routines (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */
+    bool loose_ok = true;          /* no asin / acos, no division by a constant that is zero or outside 2^-100 .. 2^100: the tile stages of
+                                      frames nobody reads may take the loose enclosures (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */
     uint64_t serial = 0;             /* identity, so a context can cache per-tape state */
     mpr::TapeSchedule schedule;      /* dependency levels for the wide first-stage kernel (ok == false: not usable) */
     std::shared_ptr<const mpr::TapeCode> code;   /* its walks as machine code, or null */

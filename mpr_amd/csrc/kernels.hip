@@ -187,7 +187,10 @@ k_eval_tiles(TileStageArgs a)
         }
     }
     const uint64_t alive_mask = ballot(alive);
-    if (alive_mask == 0) return;
+    if (alive_mask == 0) {
+        if (GEN && a.self_info && valid) a.self_info[(size_t)gidx * SKIP0_INFO_U64 + 2] = SKIP0_UNSEEN;
+        return;
+    }
     const int leader = __ffsll((long long)alive_mask) - 1;
     const int tape = __builtin_amdgcn_readlane(node.tape, leader);
     /* the tape's first 64 words travel under the interval arithmetic of the prologue */
@@ -388,18 +391,28 @@ k_eval_tiles(TileStageArgs a)
 
     /* ---- classification (reference :293-321) ---- */
     bool ambiguous = false;
+    int verdict = SKIP0_UNSEEN;
     if (alive) {
         if (res.x > 0.0f) {                                   /* empty */
             a.tiles[gidx].position = -1;
+            verdict = SKIP0_EMPTY;
         } else if (DIM == 3 && !a.no_mask && __hip_atomic_load(&a.image[pos.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos.z) {
             a.tiles[gidx].position = -1;                      /* masked */
         } else if (res.y < 0.0f) {                            /* filled */
             a.tiles[gidx].position = -1;
             if (DIM == 3) atomicMax(&a.image[pos.w], pos.z);
             else a.image[pos.w] = 1;
+            verdict = SKIP0_FILLED;
         } else {
             ambiguous = true;
+            verdict = SKIP0_AMBIGUOUS;
         }
+    }
+    if (GEN && a.self_info && valid) {
+        unsigned long long* const info = a.self_info + (size_t)gidx * SKIP0_INFO_U64;
+        info[0] = (unsigned long long)chl[0] | ((unsigned long long)chl[1] << 32);
+        info[1] = (unsigned long long)chr[0] | ((unsigned long long)chr[1] << 32);
+        info[2] = (unsigned long long)verdict;
     }
     if (a.groups) {
         /* last tile stage: keep the group's min / max decisions for the float pass, which runs THIS tape for every
@@ -1231,6 +1244,105 @@ __global__ void k_test_deriv(int op, int n, const float4* a, const float4* b, fl
         const deriv r = deriv_clause((uint32_t)op, dv(x.w, x.x, x.y, x.z), dv(y.w, y.x, y.y, y.z), imm);
         out[i] = make_float4(r.dx, r.dy, r.dz, r.v);
     }
+}
+
+/* ---- frames that start at the 16^3 tiles: the 64^3 tiles they skip, walked beside the frame (kernels.hpp) ---- */
+__global__ void __launch_bounds__(64, 4)
+k_skip0_parents(Skip0ParentsArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gen_io[4096];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x * 64 + lane;
+    const bool valid = p < a.count;
+    const int4_ pos = unpack(valid ? p : 0, a.tps);
+    /* tile corners in round-to-nearest, then interval arithmetic in round-up mode: as k_eval_tiles (reference src/context.cu:91-113) */
+    const float t = (float)a.tps;
+    float c0 = (pos.x / t - 0.5f) * 2.0f, c1 = ((pos.x + 1) / t - 0.5f) * 2.0f;
+    float c2 = (pos.y / t - 0.5f) * 2.0f, c3 = ((pos.y + 1) / t - 0.5f) * 2.0f;
+    float c4 = (pos.z / t - 0.5f) * 2.0f, c5 = ((pos.z + 1) / t - 0.5f) * 2.0f;
+    round_up_begin(c0, c1, c2, c3, c4, c5);
+    const ival ix = iv(c0, c1), iy = iv(c2, c3), iz = iv(c4, c5);
+    ival r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = i_add_f(i_add(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 4])), i_mul_f(iz, a.mat[i + 8])), a.mat[i + 12]);
+    const ival vx = i_div(r[0], r[3]), vy = i_div(r[1], r[3]), vz = i_div(r[2], r[3]);
+    const uint64_t head0 = a.tape_ro[0];
+    float2 res = make_float2(0.0f, 0.0f);
+    uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};
+    tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                     2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                     make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0, false);
+    round_nearest_begin();
+    if (valid) {
+        /* the reference's classification (:293-321; nothing is filled yet when its first stage runs: no tile is masked) */
+        unsigned long long* const info = a.parents + (size_t)p * SKIP0_INFO_U64;
+        info[0] = (unsigned long long)chl[0] | ((unsigned long long)chl[1] << 32);
+        info[1] = (unsigned long long)chr[0] | ((unsigned long long)chr[1] << 32);
+        info[2] = res.x > 0.0f ? SKIP0_EMPTY : res.y < 0.0f ? SKIP0_FILLED : SKIP0_AMBIGUOUS;
+    }
+}
+/* one wavefront per 64^3 parent, its 64 children as lanes */
+__global__ void __launch_bounds__(64, 4)
+k_skip0_compare(Skip0ParentsArgs a, const unsigned long long* __restrict__ children, int* flag)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gen_io[4096];
+    const int lane = threadIdx.x;
+    const int t0 = a.tps, cols = t0 * t0;
+    /* the children of the parent with compacted id j (k_preload_tiles: nearest z layer first) */
+    const int j = blockIdx.x;
+    const int pz = t0 - 1 - j / cols, pxy = j % cols;
+    const int p = pxy + pz * cols;
+    const unsigned long long* const pi = a.parents + (size_t)p * SKIP0_INFO_U64;
+    const unsigned long long* const ci = children + ((size_t)j * 64 + lane) * SKIP0_INFO_U64;
+    const int pv = (int)pi[2], cv = (int)ci[2];
+    const unsigned long long pl = pi[0], pr = pi[1];
+    /* UNSEEN: whatever the child would have drawn lies under a filled tile */
+    bool bad = false, again = false;
+    if (cv != SKIP0_UNSEEN) {
+        if (pv == SKIP0_AMBIGUOUS) again = ((pl & ~ci[0]) | (pr & ~ci[1])) != 0;       /* a decision of the parent's the child did not make */
+        else bad = cv != pv;                             /* the reference culls all 64 at once */
+    }
+    if (ballot(again) != 0) {
+        /* Children that did not decide what their parent decided: what the reference's children do — the walk with the parent's
+         * decisions imposed — may still come to the same end: a child that culled itself, and is culled the same way on its
+         * parent's tape, draws the same (bear at 256^3: a blend whose exp underflows over a quarter of the view gets log's zero
+         * bound, the parent drops the OTHER operand of a min on the strength of it, and the tiles are empty either way).  A child
+         * that stays ambiguous hands a different tape down: that is not verified here. */
+        const int sub = lane, sps = t0 * 4;
+        const int cx = (pxy % t0) * 4 + (sub & 3), cy = (pxy / t0) * 4 + ((sub >> 2) & 3), cz = pz * 4 + (sub >> 4);
+        const float t = (float)sps;
+        float c0 = (cx / t - 0.5f) * 2.0f, c1 = ((cx + 1) / t - 0.5f) * 2.0f;
+        float c2 = (cy / t - 0.5f) * 2.0f, c3 = ((cy + 1) / t - 0.5f) * 2.0f;
+        float c4 = (cz / t - 0.5f) * 2.0f, c5 = ((cz + 1) / t - 0.5f) * 2.0f;
+        round_up_begin(c0, c1, c2, c3, c4, c5);
+        const ival ix = iv(c0, c1), iy = iv(c2, c3), iz = iv(c4, c5);
+        ival r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            r[i] = i_add_f(i_add(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 4])), i_mul_f(iz, a.mat[i + 8])), a.mat[i + 12]);
+        const ival vx = i_div(r[0], r[3]), vy = i_div(r[1], r[3]), vz = i_div(r[2], r[3]);
+        const uint64_t head0 = a.tape_ro[0];
+        float2 res = make_float2(0.0f, 0.0f);
+        uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};
+        tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                         2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                         make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr, false);
+        round_nearest_begin();
+        if (again) {
+            const bool same_end = (cv == SKIP0_EMPTY && res.x > 0.0f) || (cv == SKIP0_FILLED && !(res.x > 0.0f) && res.y < 0.0f);
+            bad = !same_end;
+        }
+    }
+    if (bad) *reinterpret_cast<volatile int*>(flag) = 1;
+}
+void launch_skip0_parents(hipStream_t s, const Skip0ParentsArgs& a)
+{
+    hipLaunchKernelGGL(k_skip0_parents, dim3((a.count + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_skip0_compare(hipStream_t s, const Skip0ParentsArgs& a, const unsigned long long* children, int* flag)
+{
+    hipLaunchKernelGGL(k_skip0_compare, dim3(a.count), dim3(64), 0, s, a, children, flag);
 }
 
 /* ---- launchers ---------------------------------------------------------------------- */

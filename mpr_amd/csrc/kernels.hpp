@@ -74,6 +74,9 @@ struct TileStageArgs {
                                                * too, or this launch is such a stage (gen_parent): the walk that follows the PARENT's tape clause
                                                * by clause and records the clauses of the tape it writes (tile_gen.cpp) */
     int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
+    unsigned long long* self_info = nullptr;   /* with gen_fwd, the first stage of a frame that starts at the 16^3 tiles: per tile
+                                                * SKIP0_INFO_U64 words — what it decided by itself (lhs, rhs: bit k = the root tape's k-th
+                                                * min / max) and its verdict (SKIP0_*), for k_skip0_compare */
     bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened
                                           * by their error bound, instead of the correctly rounded ones (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */
     const unsigned long long* gen_parent = nullptr;   /* with gen_fwd, instead of gen_bwd: the launch is the stage BELOW the one that wrote these records
@@ -147,6 +150,29 @@ struct NormalArgs {
 };
 
 /* children != null (3-D frames that start at the 16^3 tiles): also the 64 children of every first-stage tile, t0 = S / 64 */
+/* ---- frames that start at the 16^3 tiles, verified (context.hip: skip0) ----
+ * Such a frame lets every 16^3 tile decide by itself, on the root tape, what its 64^3 parent would have decided for it: the
+ * reference's procedure wherever the interval routines are inclusion-isotone — and they are not everywhere (frame_domain.hpp: log's
+ * zero bound, NaN ends that fmin / fmax drop; bear's far tiles take the former in every frame).  So the 64^3 tiles ARE walked: on a
+ * second stream, beside the frame (64 wavefronts that nothing waits for until the float pass is launched), and a third kernel holds
+ * every 16^3 tile against its parent: a parent the reference culls must have 64 children that culled themselves the same way, an
+ * ambiguous parent's decisions must all have been made again by each child (then the child's walk of the root tape IS its walk of
+ * the parent's shortened tape, value for value) — or the child must have culled itself the way it is culled on the parent's tape.
+ * One violation and the frame is rendered again from the 64^3 tiles down. */
+constexpr int SKIP0_INFO_U64 = 4;
+enum { SKIP0_UNSEEN = 0, SKIP0_EMPTY = 1, SKIP0_FILLED = 2, SKIP0_AMBIGUOUS = 3 };   /* UNSEEN: dead, another rank's, or occluded before / while evaluated */
+struct Skip0ParentsArgs {
+    const uint64_t* tape_ro = nullptr;       /* the pool: [0] = the root tape's head */
+    const uint32_t* gen_fwd = nullptr;       /* the root tape's forward walk (exact routines) */
+    unsigned long long* parents = nullptr;   /* [count][SKIP0_INFO_U64] */
+    int count = 0, tps = 0;                  /* 64^3 tiles, per side */
+    float mat[16] = {0};
+};
+void launch_skip0_parents(hipStream_t s, const Skip0ParentsArgs& a);
+/* children: [64 a.count][SKIP0_INFO_U64], what the frame's first stage left (TileStageArgs::self_info); flag: host-coherent
+ * memory, set to 1, never cleared.  A child that did not make a decision of its parent's again gets the reference's walk — the
+ * parent's decisions imposed — and passes if it ends culled the way it culled itself. */
+void launch_skip0_compare(hipStream_t s, const Skip0ParentsArgs& a, const unsigned long long* children, int* flag);
 void launch_begin_frame(hipStream_t s, int* zero_base, size_t zero_words, unsigned long long* tape_index, int tape_len, int* num_active,
                         mpr_tile_node* tiles, int count, int cols, const int* owner, int rank, mpr_tile_node* children = nullptr, int t0 = 0);
 /* levels: 3 = the three tile stages' images, 4 = + the heightmap / 2-D image, 5 = + the normals */

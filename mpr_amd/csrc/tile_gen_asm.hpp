@@ -47,9 +47,11 @@ namespace mprk {
  *  - exact bounds that are not facts: the same lower bound 0 where the logarithm is very negative (a steep exp / log blend far from
  *    its surface: the reference then drops the OTHER operand of a min, and its image lacks what that operand drew — tests: "smooth"),
  *    sqrt's [0, ..] over an interval whose negative part is NaN to the float pass, asin / acos outside [-1, 1].
- * So: a log whose lower end is not a positive normal number, a sqrt whose lower end is negative -> the WHOLE walk again with the
- * exact routines (L_redo: the wave's tiles then are exactly the reference's); tapes with asin / acos clauses never run loose
- * (context.hip).
+ * So: a log whose lower end is not a positive normal number, a sqrt whose lower end is negative, an exp that can overflow, a divisor
+ * that holds zero (infinities: a wider interval elsewhere can then meet 0 x inf where the exact walk does not, and the NaN is gone
+ * from the next min / max) -> the WHOLE walk again with the exact routines (L_redo: the wave's tiles then are exactly the
+ * reference's); tapes with asin / acos clauses, or that divide by a constant outside 2^-100 .. 2^100, never run loose
+ * (mpr_tape::loose_ok).
  * SOUNDNESS IS NOT ARGUED ONLY: mpr_test_loose_interval runs these very instructions on every float of the domain on the device
  * and holds each end against the exact routine's (tests/test_gpu_primitives.py: test_loose_exp_log_enclose_the_exact_ones).
  * In: v36 = lo, v37 = hi; out v40, v41; temporaries v42..v47; round-up mode. */
@@ -140,9 +142,23 @@ namespace mprk {
     "v_cmp_nle_f32 vcc, v36, s40\n"                     /* an end above 80, or NaN */                             \
     "v_cmp_nle_f32 s[42:43], v37, s40\n"                                                                          \
     "s_or_b64 vcc, vcc, s[42:43]\n"                                                                               \
-    "s_cbranch_vccnz L_cexp_%=\n"                                                                                 \
+    "s_cbranch_vccnz L_fexp_big_%=\n"                                                                             \
     TG_FEXP_CORE                                                                                                  \
     "s_setpc_b64 s[36:37]\n"                                                                                      \
+    "L_fexp_big_%=:\n"                                  /* up to 88 the exact routine; beyond, exp can overflow: an infinity */ \
+    "s_mov_b32 s40, 0x42b00000\n"                       /* in a walk whose other intervals are wider than the exact ones can */ \
+    "v_cmp_nle_f32 vcc, v37, s40\n"                     /* meet a zero the exact walk does not (0 x inf: NaN) */   \
+    "v_cmp_u_f32 s[42:43], v36, v36\n"                                                                            \
+    "s_or_b64 vcc, vcc, s[42:43]\n"                                                                               \
+    "s_cbranch_vccnz L_redo_%=\n"                                                                                 \
+    "s_branch L_cexp_%=\n"                                                                                        \
+    /* a divisor that holds zero: [-inf, inf] to the exact routine — the exact walk's, narrower, may not hold it */ \
+    "L_fdiv_%=:\n"                                                                                                \
+    "v_cmp_ge_f32 s[58:59], 0, v38\n v_cmp_le_f32 vcc, 0, v39\n"                                                  \
+    "s_and_b64 s[58:59], s[58:59], vcc\n"                                                                         \
+    "s_cmp_lg_u64 s[58:59], 0\n"                                                                                  \
+    "s_cbranch_scc1 L_redo_%=\n"                                                                                  \
+    "s_branch L_idiv_%=\n"                                                                                        \
     "L_flog_%=:\n"                                                                                                \
     "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
     "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* a LOWER end that is not a positive normal number: the exact */ \
@@ -208,9 +224,11 @@ DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane
         TG_ADDR(86, 87, "L_casin") TG_ADDR(88, 89, "L_cacos") TG_ADDR(90, 91, "L_catan") TG_ADDR(98, 99, "L_cexp")
         TG_ADDR(96, 97, "L_clog")
         TG_ADDR(44, 45, "L_fexp") TG_ADDR(46, 47, "L_flog") TG_ADDR(48, 49, "L_fsqrt") TG_ADDR(50, 51, "L_fdivi")
+        TG_ADDR(52, 53, "L_fdiv")
         "s_cmp_lg_u32 s43, 0\n"
         "s_cselect_b32 s98, s44, s98\n s_cselect_b32 s99, s45, s99\n s_cselect_b32 s96, s46, s96\n s_cselect_b32 s97, s47, s97\n"
         "s_cselect_b32 s68, s48, s68\n s_cselect_b32 s69, s49, s69\n s_cselect_b32 s84, s50, s84\n s_cselect_b32 s85, s51, s85\n"
+        "s_cselect_b32 s82, s52, s82\n s_cselect_b32 s83, s53, s83\n"
         "s_swappc_b64 s[38:39], s[34:35]\n"
         "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
         "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"

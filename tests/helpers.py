@@ -118,3 +118,42 @@ def compare_reader_frame(mpr, orc, tape, S, mat, ref=None, frames=1, read_first=
             assert np.array_equal(glen, rlen), "shortened tape lengths differ after stage %d (%d tiles)" % (s, int((glen != rlen).sum()))
             assert np.array_equal(ghash, rhash), "shortened tape contents differ after stage %d (%d tiles)" % (s, int((ghash != rhash).sum()))
     return ctx, ref
+
+
+# ---- the oracle's interval routines over tiles, clause by clause (test_frame_domain.py, scripts/isotone_study.py) ----
+def oracle_axes_of_tiles(mpr, orc, pos, tps, mat):
+    """the tile stages' axis intervals (reference src/context.cu:91-113): corners in round-to-nearest float, then interval arithmetic"""
+    t = np.float32(tps)
+    two, half = np.float32(2.0), np.float32(0.5)
+    iv = []
+    for k in range(3):
+        p = pos[:, k].astype(np.float32)
+        iv.append(((p / t - half) * two, ((p + np.float32(1)) / t - half) * two))
+    rows = []
+    for i in range(4):
+        acc = None
+        for k in range(3):
+            lo, hi, _ = orc.interval_op(mpr.OP["MUL_LHS_IMM"], iv[k][0], iv[k][1], imm=float(mat[i + 4 * k]))
+            acc = (lo, hi) if acc is None else orc.interval_op(mpr.OP["ADD_LHS_RHS"], acc[0], acc[1], lo, hi)[:2]
+        rows.append(orc.interval_op(mpr.OP["ADD_LHS_IMM"], acc[0], acc[1], imm=float(mat[i + 12]))[:2])
+    return [orc.interval_op(mpr.OP["DIV_LHS_RHS"], rows[k][0], rows[k][1], rows[3][0], rows[3][1])[:2] for k in range(3)]
+
+
+def oracle_walk_tiles(mpr, orc, clauses, axes):
+    """every clause's interval for every tile: (lo[n_clauses, n_tiles], hi)"""
+    d = mpr.decode(clauses)
+    n = axes[0][0].size
+    slots = {}
+    head = d[0]
+    slots[head[1]], slots[head[2]], slots[head[3]] = axes[0], axes[1], axes[2]
+    zero = (np.zeros(n, np.float32), np.zeros(n, np.float32))
+    lo_all = np.full((len(d), n), np.nan, np.float32)
+    hi_all = np.full((len(d), n), np.nan, np.float32)
+    for i in range(1, len(d) - 1):
+        name, out, lhs, rhs, imm = d[i]
+        a = slots.get(lhs, zero)
+        b = slots.get(rhs, zero)
+        lo, hi, _ = orc.interval_op(mpr.OP[name], a[0], a[1], b[0], b[1], imm)
+        slots[out] = (lo, hi)
+        lo_all[i], hi_all[i] = lo, hi
+    return d, lo_all, hi_all
