@@ -13,7 +13,7 @@
  * that leaves [-1, 1] (:306-324; fmin / fmax then DROP them: a min / max with such an operand returns the other one's bounds), sqrt's
  * NaN below zero, division by an interval that holds zero, anything that overflows.  There the reference's image depends on its
  * hierarchy (what a 64^3 tile decided with a NaN in its bounds binds its children), and only its literal procedure reproduces it
- * (found by tests/test_gpu_fuzz.py: random shapes with asin / acos leaving their domain inside the view).
+ * (found by tests/test_gpu_fuzz_shapes.py: random shapes with asin / acos leaving their domain inside the view).
  *
  * The test: the tape once, on the host, over the box of the WHOLE view, in double precision with every result widened outward by
  * two float ulps (an enclosure of what the device's correctly rounded float routines return for any tile: tiles' axis intervals lie

@@ -1,4 +1,4 @@
-"""Development aid: one of tests/test_gpu_fuzz.py's random shapes (size:seed[:S]) under a list of switch settings — which of this
+"""Development aid: one of tests/test_gpu_fuzz_shapes.py's random shapes (size:seed[:S]) under a list of switch settings — which of this
 library's paths give the oracle's frame, and does the oracle's hierarchy give its own brute-force image (if not, the reference's
 interval proofs are not facts for this shape: a partial function left its domain)."""
 import os
@@ -13,7 +13,7 @@ import mpr_amd as mpr
 from oracle import orc
 
 orc.lib()
-src = open(os.path.join(ROOT, "tests", "test_gpu_fuzz.py")).read().split("@pytest.mark.parametrize")[0]
+src = open(os.path.join(ROOT, "tests", "test_gpu_fuzz_shapes.py")).read().split("@pytest.mark.parametrize")[0]
 src = src.replace("from conftest import view2, view3", "").replace("from helpers import check_default_path, compare_frame, compare_reader_frame", "")
 ns = {}
 exec(src, ns)

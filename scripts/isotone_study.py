@@ -31,7 +31,7 @@ def main():
     what = sys.argv[1]
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     if what.startswith("fuzz:"):
-        src = open(os.path.join(ROOT, "tests", "test_gpu_fuzz.py")).read().split("@pytest.mark.parametrize")[0]
+        src = open(os.path.join(ROOT, "tests", "test_gpu_fuzz_shapes.py")).read().split("@pytest.mark.parametrize")[0]
         src = src.replace("from conftest import view2, view3", "").replace("from helpers import check_default_path, compare_frame, compare_reader_frame", "")
         ns = {}
         exec(src, ns)

@@ -1,0 +1,117 @@
+"""Random shapes against the oracle, on the paths bear takes.  tests/test_gpu_fuzz.py's deep random trees have wide DAGs: their
+frames run the level-parallel first stage and the interpreters; the fixed models exercise what their authors wrote — bear divides
+by positive constants only, and a routine that took an interval's ends from the wrong side for a NEGATIVE divisor passed every one
+of them (round 4: the loose division of the tile stages).  Here: seeded random CHAINS of primitives (spheres, boxes, tori, planes,
+gyroid-ish waves, asin / acos that leave their domain inside the view), constants of either sign, every unary opcode, hard and
+smooth (exp / log) unions — narrow DAGs of at most 24 slots like bear's: host-generated code in every stage, frames that start at
+the 16^3 tiles (which is how the shapes were found whose 64^3 tiles bind their children: test_gpu_render.py:
+test_frames_that_start_at_the_16_tiles_are_verified_against_the_64_tiles), loose enclosures — as the caller's default frames, as
+frames somebody reads, and as instrumented frames; 2-D and 3-D; 2 to 64 primitives (up to 1200 clauses and beyond 64 min / max
+clauses: off the generated paths again)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import view2, view3
+from helpers import check_default_path, compare_frame, compare_reader_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def random_tree(mpr, rng, size):
+    X, Y, Z = mpr.Tree.X(), mpr.Tree.Y(), mpr.Tree.Z()
+
+    def const(lo=0.1, hi=1.0, signed=False):
+        v = float(np.float32(rng.uniform(lo, hi)))
+        return -v if signed and rng.random() < 0.5 else v
+
+    def point():
+        # a moved, scaled (by a constant of either sign: a mirror), sometimes sheared copy of the axes
+        s = const(0.6, 1.6, signed=True)
+        x = (X - const(-0.5, 0.5)) / s
+        y = (Y - const(-0.5, 0.5)) * const(0.7, 1.5, signed=True)
+        z = (Z - const(-0.4, 0.4)) / const(0.7, 1.4, signed=True)
+        if rng.random() < 0.3:
+            x = x + y * const(0.1, 0.4, signed=True)
+        return x, y, z
+
+    def primitive():
+        x, y, z = point()
+        k = rng.integers(0, 9)
+        if k == 0:
+            return mpr.sqrt(x * x + y * y + z * z) - const(0.2, 0.6)
+        if k == 1:      # a box
+            return mpr.tmax(mpr.tmax(mpr.tabs(x) - const(0.1, 0.5), mpr.tabs(y) - const(0.1, 0.5)), mpr.tabs(z) - const(0.1, 0.5))
+        if k == 2:      # a torus
+            q = mpr.sqrt(mpr.square(x) + mpr.square(y)) - const(0.3, 0.5)
+            return mpr.sqrt(q * q + z * z) - const(0.05, 0.2)
+        if k == 3:      # a slab between two planes
+            return mpr.tabs(x * const(0.2, 1.0, signed=True) + y * const(0.2, 1.0, signed=True) + z * const(0.2, 1.0)) - const(0.05, 0.3)
+        if k == 4:      # waves
+            f = const(3.0, 9.0)
+            return mpr.sin(x * f) * mpr.cos(y * f) + mpr.sin(y * f) * mpr.cos(z * f) + mpr.sin(z * f) * mpr.cos(x * f) - const(-0.5, 0.8)
+        if k == 5:      # a cylinder with a reciprocal profile
+            return mpr.sqrt(x * x + y * y) - const(0.1, 0.3) / (z * z + const(0.3, 1.0))
+        if k == 6:      # an ellipsoid by way of exp / log: log(exp(a) * exp(b)) = a + b
+            return mpr.log(mpr.exp(x * x * const(1.0, 4.0)) * mpr.exp(y * y * const(1.0, 4.0))) + z * z - const(0.1, 0.5)
+        if k == 7:      # a cone by atan
+            return mpr.atan(mpr.sqrt(x * x + y * y) / (mpr.tabs(z) + 0.1)) - const(0.3, 1.0)
+        return mpr.asin(x * 0.6) * mpr.acos(y * 0.6) + z * z - const(0.1, 0.6)       # (arguments inside [-1, 1] over most of the view)
+
+    def combine(a, b):
+        k = rng.integers(0, 8)
+        if k <= 1:
+            return mpr.tmin(a, b)
+        if k == 2:
+            return mpr.tmax(a, b)
+        if k == 3:
+            return mpr.tmax(a, -b)                       # difference
+        if k == 4:      # a smooth union, steepness of either sign's divisor: -log(e^(-s a) + e^(-s b)) / s
+            s = const(4.0, 48.0)
+            return mpr.log(mpr.exp(a * -s) + mpr.exp(b * -s)) / -s
+        if k == 5:
+            s = const(4.0, 24.0)                         # ... and the smooth intersection
+            return mpr.log(mpr.exp(a * s) + mpr.exp(b * s)) / s
+        if k == 6:
+            return mpr.tmin(a, b) - const(0.0, 0.05)     # an offset union
+        return mpr.tmin(a + const(0.0, 0.1), mpr.tmax(b, a - const(0.05, 0.3)))      # a shell
+
+    t = primitive()
+    for _ in range(size - 1):
+        t = combine(t, primitive())
+    return t
+
+
+def fuzz_tape(mpr, seed, size):
+    rng = np.random.default_rng(zlib.crc32(b"fuzz") + seed)
+    for _ in range(50):
+        try:
+            return mpr.Tape(random_tree(mpr, rng, size))
+        except mpr.MprError:
+            continue
+    raise AssertionError("no tape")
+
+
+@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("size", [2, 4, 12, 64])
+def test_random_shapes_default_frames_match_the_oracle(mpr, orc, seed, size):
+    """What a caller gets (no counters, nobody reading): fast frames from the 16^3 tiles down, host-generated or device-translated
+    float pass, loose enclosures in the tile stages where the tape allows them — heights and normals of three frames in a row."""
+    tape = fuzz_tape(mpr, seed, size)
+    S3, S2 = (256, 512) if seed % 3 == 0 else (128, 256)
+    ref = orc.Frame(tape.data, 3, S3, mpr.colmajor(view3(), 4), threads=0)
+    check_default_path(mpr, ref, tape, 3, S3, view3())
+    ref2 = orc.Frame(tape.data, 2, S2, mpr.colmajor(view2(), 3), z=0.05, threads=0)
+    check_default_path(mpr, ref2, tape, 2, S2, view2(), z=0.05)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("size", [2, 4, 12, 64])
+def test_random_shapes_instrumented_and_read_frames_match_the_oracle(mpr, orc, seed, size):
+    """... the instrumented frame (every stage's images, survivor sets, shortened tapes, work counters), and what a reader of
+    tiles and tapes gets after an ordinary frame."""
+    tape = fuzz_tape(mpr, 100 + seed, size)
+    compare_frame(mpr, orc, tape, 3, 128, view3())
+    compare_frame(mpr, orc, tape, 2, 256, view2())
+    compare_reader_frame(mpr, orc, tape, 128, view3())

@@ -389,14 +389,14 @@ def test_frames_that_start_at_the_16_tiles_are_verified_against_the_64_tiles(mpr
     """A frame nobody reads starts at the 16^3 tiles: each decides by itself, on the root tape, what its 64^3 parent would have
     decided for it — the reference's procedure only where its interval routines are inclusion-isotone.  They are not where a
     special case takes over (csrc/frame_domain.hpp), and then the reference's image depends on what the 64^3 tile did: this shape
-    (tests/test_gpu_fuzz.py found it) takes asin / acos outside [-1, 1] in part of the view; the NaN end makes the reference's
+    (tests/test_gpu_fuzz_shapes.py found it) takes asin / acos outside [-1, 1] in part of the view; the NaN end makes the reference's
     interval product [0, 0], the 64^3 tile decides on the strength of it, its children inherit the decision — and children
     left to themselves draw something else (shown here with the verification switched off).  With it, the 64^3 tiles are walked
     beside the frame, every 16^3 tile is held against its parent, the frame fails, is rendered again from the 64^3 tiles down
     (and so are the tape's next frames): the oracle's image.  bear's frames pass it in every frame — at 512^3 and 1024^3; at
     256^3, where a 64^3 tile is a quarter of the view, they do not, and start at the 64^3 tiles."""
-    import test_gpu_fuzz
-    tape = test_gpu_fuzz.fuzz_tape(mpr, 14, 12)
+    import test_gpu_fuzz_shapes
+    tape = test_gpu_fuzz_shapes.fuzz_tape(mpr, 14, 12)
     assert not tape.frame_is_tame(view3())
     ref = orc.Frame(tape.data, 3, 128, mpr.colmajor(view3(), 4), threads=0)
     ctx = mpr.Context(128)
