@@ -115,3 +115,85 @@ def test_random_shapes_instrumented_and_read_frames_match_the_oracle(mpr, orc, s
     compare_frame(mpr, orc, tape, 3, 128, view3())
     compare_frame(mpr, orc, tape, 2, 256, view2())
     compare_reader_frame(mpr, orc, tape, 128, view3())
+
+
+def random_view3(rng):
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] += rng.uniform(-0.25, 0.25, (3, 3)).astype(np.float32)
+    if rng.random() < 0.5:
+        T[0] *= np.float32(-1.0)                       # a mirrored axis
+    T[:3, 3] = rng.uniform(-0.15, 0.15, 3).astype(np.float32)
+    T[3, :3] = rng.uniform(-0.3, 0.3, 3).astype(np.float32)       # perspective along any axis
+    return T
+
+
+@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("size", [3, 12])
+def test_random_shapes_in_general_views(mpr, orc, seed, size):
+    """... in views the benchmarks never use (rotated, sheared, mirrored, perspective along any axis): the tile stages' interval
+    transform of the axes, the float pass's and the normals pass's own, the whole-view domain check of csrc/frame_domain.cpp and the
+    64^3 tiles' walk of the verification all take the matrix."""
+    tape = fuzz_tape(mpr, 200 + seed, size)
+    rng = np.random.default_rng(zlib.crc32(b"view") + seed)
+    T = random_view3(rng)
+    ref = orc.Frame(tape.data, 3, 128, mpr.colmajor(T, 4), threads=0)
+    check_default_path(mpr, ref, tape, 3, 128, T)
+    T2 = np.eye(3, dtype=np.float32)
+    T2[:2, :2] += rng.uniform(-0.3, 0.3, (2, 2)).astype(np.float32)
+    T2[:2, 2] = rng.uniform(-0.2, 0.2, 2).astype(np.float32)
+    T2[2, :2] = rng.uniform(-0.2, 0.2, 2).astype(np.float32)
+    z = float(np.float32(rng.uniform(-0.3, 0.3)))
+    ref2 = orc.Frame(tape.data, 2, 256, mpr.colmajor(T2, 3), z=z, threads=0)
+    check_default_path(mpr, ref2, tape, 2, 256, T2, z=z)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7, "fails_its_verification"])
+def test_random_shapes_dealt_to_three_ranks_on_one_device(mpr, orc, seed):
+    """... and as the multi-GPU pipeline renders them: three contexts on one device, each its share of the 64 x 64 columns in a
+    frame that does not block (its start at the 16^3 tiles is verified BEFORE its float pass is launched: the columns are packed
+    behind it on the same stream), packed, exchanged by device copies, unpacked — every rank ends up with the oracle's frame."""
+    torch = pytest.importorskip("torch")
+    from mpr_amd.multigpu import TileParallelRenderer
+    if seed == "fails_its_verification":       # (test_gpu_render.py: ..._are_verified_against_the_64_tiles)
+        tape, S = fuzz_tape(mpr, 14, 12), 128
+    else:
+        tape, S = fuzz_tape(mpr, 300 + seed, 12 if seed % 2 else 4), 256
+    T, world = view3(), 3
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(T, 4), threads=0)
+    ctxs = [mpr.Context(S) for _ in range(world)]
+
+    def make_buffer(n):
+        t = torch.zeros(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        return t, t.data_ptr()
+
+    rs = []
+    for r in range(world):
+        tpr = TileParallelRenderer(ctxs[r], mpr, r, world, make_buffer, lambda o, i: None, dim=3)
+        tpr.plan(tape, T)
+        rs.append(tpr)
+    for frame in range(2):
+        for r, t in enumerate(rs):
+            ctxs[r].render3D_part(tape, T, t.owner, r, blocking=False)
+            ctxs[r].pack_planned(t.send_ptr)
+        for r, t in enumerate(rs):
+            for o, u in enumerate(rs):
+                ctxs[o].sync()
+                with torch.cuda.stream(torch.cuda.ExternalStream(ctxs[r].stream)):
+                    t.recv[o * t.per_rank:(o + 1) * t.per_rank].copy_(u.send)
+            ctxs[r].unpack_planned(t.recv_ptr)
+            ctxs[r].sync()
+            assert np.array_equal(ctxs[r].image, ref.filled[3]), (r, int((ctxs[r].image != ref.filled[3]).sum()))
+            assert np.array_equal(ctxs[r].normals, ref.normals), (r, int((ctxs[r].normals != ref.normals).sum()))
+    if seed == "fails_its_verification":
+        assert sum(c.skip0_vetoes() for c in ctxs) >= 1
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_shapes_at_1024(mpr, orc, seed):
+    """... and at the size the bench line is quoted on: 4096 parents, 262 144 tiles in the verified first stage."""
+    tape = fuzz_tape(mpr, 400 + seed, 12)
+    ref = orc.Frame(tape.data, 3, 1024, mpr.colmajor(view3(), 4), threads=0)
+    check_default_path(mpr, ref, tape, 3, 1024, view3(), frames=2)
