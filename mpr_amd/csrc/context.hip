@@ -189,6 +189,13 @@ struct mpr_context {
     uint64_t skip0_veto_serial = 0;    /* the tape whose last verified frame failed: its next frames start at the 64^3 tiles ... */
     int skip0_veto_left = 0;           /* ... this many of them, then one tries again */
     long long skip0_vetoes = 0;        /* frames rendered again (mpr_ctx_skip0_vetoes: tests) */
+    /* frames that start at the 16^3 tiles, of a tape whose float pass and normals pass run on its root code with records: nobody
+     * walks the tapes the first stage pushes (the sample of the last stage apart: such frames take none; every 32nd frame is an
+     * ordinary one and refreshes the hint) -> no backward walk in that stage, records only (TileStageArgs::gen_forward_only) */
+    bool lean_first = true;            /* MPR_LEAN_FIRST=0: the first stage always walks backward and pushes */
+    uint64_t lean_first_veto = 0;      /* the tape whose frame found a later stage that needs the tapes after all */
+    uint64_t lean_first_serial = 0;    /* ... frames of this tape since it became resident */
+    unsigned lean_first_frames = 0;
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
@@ -421,6 +428,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
     if (const char* e = getenv("MPR_TAME_CHECK")) c->tame_check = atoi(e) != 0;
     if (const char* e = getenv("MPR_SKIP0_CHECK")) c->skip0_verify = atoi(e) != 0;
+    if (const char* e = getenv("MPR_LEAN_FIRST")) c->lean_first = atoi(e) != 0;
     if (const char* e = getenv("MPR_NORMALS_GUARDS")) c->normals_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
@@ -841,6 +849,7 @@ struct Frame {
     bool tame = false;                     /* frame_domain.hpp: every interval operation stays where the reference's routines are isotone */
     bool skip0_checked = false;            /* skip0 of a frame that is not tame: verified against the 64^3 tiles before the float pass */
     mprk::Skip0ParentsArgs skip0_args;
+    bool lean_first = false;               /* the first stage walks forward only and leaves records, no tapes */
     bool tiles_only = false;               /* a reader's re-render: tile stages only */
     mpr_context::FrameKey key;
     /* what the stages leave behind */
@@ -959,6 +968,20 @@ static int frame_begin(Frame& f)
         if (!can || vetoed) skip0 = false;
         else skip0_checked = true;
     }
+    /* ... and whose first stage leaves records only, where everything behind it takes records: the tape's hint says its last stage
+     * pushes nothing (group form), the float pass and the normals pass run the root tape's code.  Every 32nd frame of the tape is
+     * an ordinary one (its last stage's sample keeps the hint honest); a frame that finds a later stage in need of tapes after all
+     * starts over and the tape stays off this path */
+    bool lean_first = false;
+    if (skip0 && c->lean_first && hint == mpr_context::HINT_GROUPS && c->lean_first_veto != tape->serial && c->gen_ok && c->tile_gen == 1 &&
+        c->tile_gen_last && c->normals_gen && c->normals_asm && c->voxel_gen && c->gen_vox_dw > 0 && c->voxel_groups && c->gen_nchoices <= 64 &&
+        !(c->debug_tiles & 3) && c->measure_len_forced < 0 && !c->debug_choices) {
+        if (c->lean_first_serial != tape->serial) {
+            c->lean_first_serial = tape->serial;
+            c->lean_first_frames = 0;
+        }
+        lean_first = (c->lean_first_frames++ % 32u) != 31u;
+    }
     /* a reader's reference frame of a partitioned context keeps the columns other ranks sent (mpr_unpack_*): only this rank's
      * columns are cleared */
     const bool keep_foreign = c->force_reference && owner != nullptr;
@@ -1017,7 +1040,7 @@ static int frame_begin(Frame& f)
     }
     f.S = S; f.s = s; f.cnt = cnt; f.heat = heat; f.nslots = nslots; f.choice_cap = choice_cap;
     for (int k = 0; k < 3; ++k) f.stage_list[k] = stage_list[k];
-    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.tame = tame; f.skip0_checked = skip0_checked;
+    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.tame = tame; f.skip0_checked = skip0_checked; f.lean_first = lean_first;
     f.count = count; f.stage_choice_cap = stage_choice_cap; f.hint = hint;
     return MPR_OK;
 }
@@ -1052,7 +1075,13 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             a.gen_nchoices = c->gen_nchoices;
             decisions_recorded = false;
             presence_recorded = false;
-            if (skip0) {
+            if (skip0 && f.lean_first && records) {
+                /* nobody will walk this stage's tapes: records only */
+                a.gen_forward_only = true;
+                rc = record_into(i);
+                if (rc) return rc;
+                decisions_recorded = true;
+            } else if (skip0) {
                 /* the stage below pushes nothing: the decisions are all it and the normals pass need */
                 a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
                 if (records && a.gen_bwd && (c->normals_gen || c->tile_gen_last)) {
@@ -1096,6 +1125,12 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         } else if (!last) {
             decisions_recorded = presence_recorded = false;       /* an interpreted stage keeps no record: the chain ends */
         }
+        if (f.lean_first && count > 0 && (first_stage ? !a.gen_forward_only : !(a.gen_fwd && a.gen_parent && !a.gen_bwd_full))) {
+            /* the first stage left (or would leave) records and no tapes, and this stage cannot do with records (a last stage
+             * of few tiles runs level-parallel, on the tiles' own tapes): the frame again, its first stage pushing */
+            c->lean_first_veto = tape->serial;
+            return FRAME_AGAIN;
+        }
     }
     {
         /* frames nobody reads owe the reference heights and normals, not tile occupancy: sound but wider exp / log enclosures */
@@ -1117,7 +1152,7 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             if (a.gen_parent) f += "/parent";
             if (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) f += "+guards";
             if (a.gen_loose) f += "+loose";
-            f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : "";
+            f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : a.gen_forward_only ? "+fwdonly" : "";
             if (a.gen_decisions) f += "+records";
         }
         if (!c->stage_forms.empty()) c->stage_forms += " ";
@@ -1159,6 +1194,7 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
         if (!try_lean || hint == mpr_context::HINT_UNKNOWN) a.measure_len = std::max(ng / 32, std::min(ng, 4));
         else a.measure_len = ng >= 32 * std::max(c->cus, 1) ? ng / 128 : 0;
         if (c->measure_len_forced >= 0) a.measure_len = c->measure_len_forced;
+        if (f.lean_first) a.measure_len = 0;           /* (the sample's groups walk their parents' tapes: there are none) */
         if (a.measure_len == 0 && groups_now) a.len_stats = nullptr;
     }
     a.compiled_walk = !c->tiles_asm;
@@ -1561,6 +1597,12 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (rc == FRAME_STOP) return MPR_OK;
         if (rc) return rc;
         c->last.voxel_tiles = f.count;
+        if (f.lean_first && !(f.vox_gen_planned && f.group_form && f.lean_now && f.decisions_recorded && f.group_stage == 2 && !f.last_recorded)) {
+            /* a stage behind the first one, or a pass behind them, wants tapes after all (a last stage with few tiles runs
+             * level-parallel, for one): the frame again with a first stage that pushes them, and so the tape's next frames */
+            c->lean_first_veto = tape->serial;
+            continue;
+        }
         if (f.skip0_checked && !blocking) {
             HIP_TRY(hipEventSynchronize(c->ev_done));        /* (long there: two tile stages have been waited for since) */
             c->skip0_unchecked = true;

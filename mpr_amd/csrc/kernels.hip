@@ -296,7 +296,7 @@ k_eval_tiles(TileStageArgs a)
         end_index = a.gen_words;
         d = tro[end_index];
         any_choice = ballot((chl[0] | chl[1] | chr[0] | chr[1]) != 0) & alive_mask;
-        if (a.groups || (!a.gen_bwd && !a.gen_bwd_full)) {
+        if (a.groups || (!a.gen_bwd && !a.gen_bwd_full && !a.gen_forward_only)) {
             /* as masks over the lanes, numbered by the clauses the walked tape keeps: what the assembly backward walk and the
              * group's record want */
             int j = 0;
@@ -439,7 +439,20 @@ k_eval_tiles(TileStageArgs a)
      * long, and sprinkled over the launch (every 16th group) such waves cost the stage 40 % — a long tail, and two bodies
      * of code competing for the instruction cache throughout. */
     const bool measure_only = a.no_push && sampled;
-    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1) && (!a.no_push || measure_only);
+    if (GEN && a.gen_forward_only && a.gen_decisions && ambiguous && ((any_choice >> lane) & 1)) {
+        /* a first stage whose tapes nobody walks: the tile's record instead of its tape (TileStageArgs::gen_forward_only); the stages
+         * below, the float pass and the normals pass take "tape != 0" for "has a record" */
+        const unsigned long long l = (unsigned long long)chl[0] | ((unsigned long long)chl[1] << 32);
+        const unsigned long long r = (unsigned long long)chr[0] | ((unsigned long long)chr[1] << 32);
+        unsigned long long* const rec = a.gen_decisions + (size_t)gidx * GEN_RECORD_U64;
+        rec[0] = l | above_l;
+        rec[1] = r | above_r;
+        rec[2] = gen_keeps & ~(l | r);
+        rec[3] = 0;
+        for (int k = 4; k < GEN_RECORD_U64; ++k) rec[k] = ~0ull;
+        a.tiles[gidx].tape = 1;
+    }
+    const bool push = ambiguous && ((any_choice >> lane) & 1) && !(a.debug & 1) && (!a.no_push || measure_only) && !(GEN && a.gen_forward_only);
     uint64_t live = ballot(push);     /* lanes still writing a tape */
 
     long long written = 0;

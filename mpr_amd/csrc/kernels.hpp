@@ -74,6 +74,10 @@ struct TileStageArgs {
                                                * too, or this launch is such a stage (gen_parent): the walk that follows the PARENT's tape clause
                                                * by clause and records the clauses of the tape it writes (tile_gen.cpp) */
     int gen_words = 0, gen_nchoices = 0; /* words a walk of that tape visits (operations + end), its min / max clauses */
+    bool gen_forward_only = false;       /* with gen_fwd and gen_decisions, a first stage whose tapes nobody will walk (context.hip: lean_first):
+                                          * no backward walk, nothing pushed — a tile that decided anything leaves its record (what it
+                                          * decided; as kept min / max clauses every undecided one, dead or alive: a superset of what its
+                                          * shortened tape would keep) and a tape field that only says "there is a record" (1) */
     unsigned long long* self_info = nullptr;   /* with gen_fwd, the first stage of a frame that starts at the 16^3 tiles: per tile
                                                 * SKIP0_INFO_U64 words — what it decided by itself (lhs, rhs: bit k = the root tape's k-th
                                                 * min / max) and its verdict (SKIP0_*), for k_skip0_compare */

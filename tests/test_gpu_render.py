@@ -427,6 +427,47 @@ def test_frames_that_start_at_the_16_tiles_are_verified_against_the_64_tiles(mpr
     assert mpr.Tape(mpr.model("hello_world")).frame_is_tame(view3())
 
 
+def test_first_stage_that_leaves_records_and_no_tapes(mpr, orc, tapes, monkeypatch):
+    """Frames that start at the 16^3 tiles, of a tape whose last stage pushes nothing and whose float and normals passes run the root
+    tape's code with the tiles' records: nobody walks the tapes the first stage would push, so it walks forward only and leaves
+    records (TileStageArgs::gen_forward_only; "+fwdonly" in mpr_ctx_tile_stage_forms).  From the second frame of a tape on (the
+    first one's sample says that the group form pays), every 32nd frame an ordinary one again; the oracle's heights and normals
+    in every frame, and the same with the switch off.  A shape whose last stage has too few tiles for the 64-tiles-per-wavefront
+    kernel (it runs level-parallel, on the tiles' own tapes) starts over once and stays off the path."""
+    tape = tapes("bear")
+    ref = orc.Frame(tape.data, 3, 512, mpr.colmajor(view3(), 4), threads=0)
+    ctx = mpr.Context(512)
+    kinds = []
+    for k in range(36):
+        ctx.render3D(tape, view3())
+        assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals), k
+        kinds.append("+fwdonly" in ctx.tile_stage_forms().split()[0])
+        assert ctx.tile_stage_forms().startswith("1:gen") and ctx.float_kernel() == "k_eval_voxels_gen<3>" and ctx.normals_kernel() == "k_eval_normals_gen"
+    # (the very first frame of a fresh context may start over — its pool grows — and then already knows the hint)
+    first = kinds.index(True)
+    assert first <= 1 and kinds[first:first + 31] == [True] * 31 and kinds[first + 31] is False and kinds[first + 32:] == [True] * (35 - first - 31), kinds
+    assert ctx.skip0_vetoes() == 0
+    # a reader after such a frame still gets the reference's tiles and tapes
+    assert ctx.stages[3].tile_array_size == ref.tiles[3].size
+    ctx.close()
+    monkeypatch.setenv("MPR_LEAN_FIRST", "0")
+    ctx = mpr.Context(512)
+    for k in range(3):
+        ctx.render3D(tape, view3())
+        assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals)
+        assert "+fwdonly" not in ctx.tile_stage_forms()
+    ctx.close()
+    monkeypatch.delenv("MPR_LEAN_FIRST")
+    for name, S in (("two_spheres", 128), ("sphere", 256), ("smooth", 128)):
+        tape = tapes(name)
+        ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
+        ctx = mpr.Context(S)
+        for k in range(5):
+            ctx.render3D(tape, view3())
+            assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals), (name, k, ctx.tile_stage_forms())
+        ctx.close()
+
+
 @pytest.mark.parametrize("name,dim,S", [("bear", 3, 512), ("architecture", 3, 1024), ("hello_world", 2, 256)])
 def test_code_ring_against_an_invalidate_per_group(mpr, tapes, name, dim, S, monkeypatch):
     """The group form writes a group's code into the next slot of a ring and invalidates the instruction cache only when
