@@ -968,12 +968,13 @@ static int frame_begin(Frame& f)
         if (!can || vetoed) skip0 = false;
         else skip0_checked = true;
     }
-    /* ... and whose first stage leaves records only, where everything behind it takes records: the tape's hint says its last stage
+    /* ... and the stages above the last one leave records only, where everything behind them takes records: the tape's hint says its last stage
      * pushes nothing (group form), the float pass and the normals pass run the root tape's code.  Every 32nd frame of the tape is
      * an ordinary one (its last stage's sample keeps the hint honest); a frame that finds a later stage in need of tapes after all
      * starts over and the tape stays off this path */
     bool lean_first = false;
-    if (skip0 && c->lean_first && hint == mpr_context::HINT_GROUPS && c->lean_first_veto != tape->serial && c->gen_ok && c->tile_gen == 1 &&
+    if (!reference && dim == 3 && nstages == 3 && c->lean_first && hint == mpr_context::HINT_GROUPS && c->lean_first_veto != tape->serial && c->gen_ok && c->tile_gen == 1 &&
+        !(c->wide_stage0 && c->sched_ok) && c->tiles_asm && c->tiles_vgpr && (skip0 || c->tile_gen_chain) &&
         c->tile_gen_last && c->normals_gen && c->normals_asm && c->voxel_gen && c->gen_vox_dw > 0 && c->voxel_groups && c->gen_nchoices <= 64 &&
         !(c->debug_tiles & 3) && c->measure_len_forced < 0 && !c->debug_choices) {
         if (c->lean_first_serial != tape->serial) {
@@ -1075,7 +1076,7 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             a.gen_nchoices = c->gen_nchoices;
             decisions_recorded = false;
             presence_recorded = false;
-            if (skip0 && f.lean_first && records) {
+            if (f.lean_first && records) {
                 /* nobody will walk this stage's tapes: records only */
                 a.gen_forward_only = true;
                 rc = record_into(i);
@@ -1097,6 +1098,16 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             } else {
                 a.gen_bwd = c->tile_gen == 2 ? nullptr : c->gen_code + c->gen_fwd_dw;
             }
+        } else if (gen_here && !first_stage && !last && decisions_recorded && f.lean_first && records) {
+            /* ... and so does a stage between the first and the last one: the root tape's forward walk with the parents' decisions
+             * imposed (jumping over what they left dead), the tile's record = its parent's decisions and its own */
+            a.gen_fwd = c->gen_fwdg_dw > 0 ? c->gen_code + c->gen_fwdg_at : c->gen_code;
+            a.gen_words = c->gen_words;
+            a.gen_nchoices = c->gen_nchoices;
+            a.gen_parent = c->gen_dec[stage_list[si - 1]];
+            a.gen_forward_only = true;
+            rc = record_into(i);
+            if (rc) return rc;
         } else if (gen_here && !first_stage && !last && presence_recorded && chain) {
             a.gen_fwd = c->gen_code;
             a.gen_words = c->gen_words;

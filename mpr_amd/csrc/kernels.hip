@@ -667,7 +667,8 @@ k_eval_tiles(TileStageArgs a)
             written = (long long)(out_index - first_index) + (MPR_SUBTAPE_CHUNK - out_offset);
         }
     }
-    if (gen_wave && a.gen_decisions && a.gen_parent && alive && !(push && !overflow)) {
+    if (gen_wave && a.gen_decisions && a.gen_parent && alive && !(push && !overflow) &&
+        !(a.gen_forward_only && ambiguous && ((any_choice >> lane) & 1))) {         /* (that one wrote its own record above) */
         /* a tile below the first stage that pushes nothing hands its parent's tape on: with the parent's record (the root
          * tape: nothing decided, everything there) */
         unsigned long long* const rec = a.gen_decisions + (size_t)gidx * GEN_RECORD_U64;
@@ -1428,7 +1429,7 @@ bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     const int vs = (use_asm && a.vgpr_slots && !(a.debug & 4)) ? tile_stage_vgpr_class(a.nslots, a.choice_cap) : 0;
     const size_t lds_vs = (size_t)std::max(a.choice_cap, 1) * 16 + 2048;      /* choices, then the walk's in / out scratch */
     if (a.gen_fwd && tile_stage_gen_possible(a.nslots, a.pool_cap, a.compiled_walk, a.vgpr_slots, a.debug) &&
-        (a.gen_bwd_full ? true : a.gen_parent ? a.no_push : !a.groups)) {
+        ((a.gen_bwd_full || a.gen_forward_only) ? true : a.gen_parent ? a.no_push : !a.groups)) {
         const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
         if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
