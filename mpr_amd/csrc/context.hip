@@ -595,6 +595,7 @@ int64_t mpr_ctx_resident_bytes(const mpr_context* c)
     b += (c->wide_bits_cap[0] + c->wide_bits_cap[1]) * sizeof(uint32_t);
     b += c->sched_recs_cap + c->sched_levels_cap + c->sched_prev_cap + c->sched_defs_cap + 2 * c->gen_cap_dw * sizeof(uint32_t) + (c->gen_dec_cap[0] + c->gen_dec_cap[1] + c->gen_dec_cap[2]) * sizeof(unsigned long long);
     b += 3 * (size_t)(c->S / 64) * (c->S / 64) * sizeof(int) + (c->heat ? (size_t)c->S * c->S * sizeof(float) : 0);
+    b += (c->skip0_parents_cap + c->skip0_children_cap) * sizeof(unsigned long long);       /* 8 MB at 1024^3: the verification's notes */
     return (int64_t)b;
 }
 

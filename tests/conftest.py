@@ -67,6 +67,8 @@ def tapes(mpr):
             for s_ in terms[1:]:
                 total = total + s_
             t = mpr.tmin(prod - 0.2, total * 0.01 - 0.05)
+        elif name.startswith("shape_"):   # tests/golden/shapes: random shapes of test_gpu_fuzz_shapes.py (tests/golden/make_shapes.py)
+            t = mpr.Tree.from_frep(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes", name + ".frep"))
         else:
             t = mpr.model(name)
         cache[name] = mpr.Tape(t)

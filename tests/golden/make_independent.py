@@ -451,12 +451,27 @@ CONFIGS = {
     "involute_gear_2d_2d_4096_sample": ("involute_gear_2d", 2, 4096, 1 << 18),
     "hello_world_2d_256": ("hello_world", 2, 256, 0),
     "circle_2d_256": ("circle", 2, 256, 0),
+    # random shapes of tests/test_gpu_fuzz_shapes.py (tests/golden/make_shapes.py wrote their .frep files): divisions by negative
+    # constants, steep exp / log blends, asin / acos.  Not the shapes whose asin / acos LEAVE their domain inside the view: the
+    # reference's hierarchy then draws what no evaluation voxel by voxel predicts (a tile "filled" on the strength of a NaN end:
+    # DESIGN.md 3, frames that start at the 16^3 tiles) - those are held against the oracle only
+    "shape_12_0_3d_128": ("shape_12_0", 3, 128, 0),
+    "shape_12_3_3d_128": ("shape_12_3", 3, 128, 0),
+    "shape_4_15_3d_128": ("shape_4_15", 3, 128, 0),
+    "shape_4_9_3d_128": ("shape_4_9", 3, 128, 0),
+    "shape_12_21_3d_128": ("shape_12_21", 3, 128, 0),
+    "shape_64_5_3d_128": ("shape_64_5", 3, 128, 0),
+    "shape_4_15_2d_256": ("shape_4_15", 2, 256, 0),
+    "shape_4_9_2d_256": ("shape_4_9", 2, 256, 0),
+    "shape_12_21_2d_256": ("shape_12_21", 2, 256, 0),
+    "shape_64_5_2d_256": ("shape_64_5", 2, 256, 0),
 }
+SHAPES = os.path.join(HERE, "shapes")
 
 
 def make(name):
     model, dim, S, nsample = CONFIGS[name]
-    path = os.path.join(MODELS, model + ".frep")
+    path = os.path.join(SHAPES if model.startswith("shape_") else MODELS, model + ".frep")
     nodes = parse_frep(path) if os.path.exists(path) else expression(model)
     pixels = None
     if nsample:

@@ -52,7 +52,7 @@ def check_heights(h, d, max_fragile=0.01):
     assert (hmin > 0).sum() > 100
 
 
-def check_normals(n, h, d, max_fragile=0.12):
+def check_normals(n, h, d, max_fragile=0.12, identical=0.97):
     n = pick(n, d).astype(np.int64)
     h = pick(h, d)
     want = d["normal"].astype(np.int64)
@@ -65,7 +65,7 @@ def check_normals(n, h, d, max_fragile=0.12):
         worst = np.abs(a - b).max() if use.any() else 0
         assert worst <= 1, "normal channel %d differs by %d LSB" % (shift // 8, worst)
     # and they are not all off by one: the vast majority is identical
-    assert (n[use] == want[use]).mean() > 0.97
+    assert (n[use] == want[use]).mean() > identical
 
 
 def check_image2d(img, d, max_fragile=0.002):
@@ -80,8 +80,15 @@ def check_image2d(img, d, max_fragile=0.002):
 
 # ---------------------------------------------------------------------------------------------
 # CPU: the oracle
-CPU_3D = ["two_spheres_3d_128", "hello_world_3d_128", "bear_3d_128", "architecture_3d_128", "involute_gear_3d_128"]
-CPU_2D = ["circle_2d_256", "hello_world_2d_256", "prospero_2d_512", "involute_gear_2d_2d_512"]
+# shape_*: random shapes of tests/test_gpu_fuzz_shapes.py (divisions by negative constants, steep exp / log blends, asin / acos inside
+# their domain), tests/golden/make_shapes.py.  (Shapes whose asin / acos leave the domain inside the view are not here: the
+# reference's hierarchy then draws what no voxel-by-voxel evaluation predicts — tests/golden/make_independent.py.)
+SHAPES_3D = ["shape_12_0_3d_128", "shape_12_3_3d_128", "shape_4_15_3d_128", "shape_4_9_3d_128", "shape_12_21_3d_128", "shape_64_5_3d_128"]
+SHAPES_2D = ["shape_4_15_2d_256", "shape_4_9_2d_256", "shape_12_21_2d_256", "shape_64_5_2d_256"]
+CPU_3D = ["two_spheres_3d_128", "hello_world_3d_128", "bear_3d_128", "architecture_3d_128", "involute_gear_3d_128"] + SHAPES_3D
+CPU_2D = ["circle_2d_256", "hello_world_2d_256", "prospero_2d_512", "involute_gear_2d_2d_512"] + SHAPES_2D
+# (blends: exp and log of this package against numpy's; more normals one unit apart than in the models, none further)
+NORMALS_IDENTICAL = {n: 0.9 for n in SHAPES_3D}
 
 
 @pytest.mark.parametrize("name", CPU_3D)
@@ -89,7 +96,7 @@ def test_oracle_3d_against_independent_evaluator(mpr, orc, tapes, name):
     d = load(name)
     ref = orc.Frame(tapes(d["model"]).data, 3, d["size"], mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
     check_heights(ref.image, d)
-    check_normals(ref.normals, ref.image, d)
+    check_normals(ref.normals, ref.image, d, identical=NORMALS_IDENTICAL.get(name, 0.97))
 
 
 @pytest.mark.parametrize("name", CPU_2D)
@@ -114,7 +121,7 @@ def test_gpu_3d_against_independent_evaluator(mpr, tapes, name):
     h, n = ctx.image, ctx.normals
     ctx.close()
     check_heights(h, d)
-    check_normals(n, h, d)
+    check_normals(n, h, d, identical=NORMALS_IDENTICAL.get(name, 0.97))
 
 
 @pytest.mark.gpu
