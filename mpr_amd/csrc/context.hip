@@ -188,6 +188,7 @@ struct mpr_context {
     bool skip0_verify = true;          /* MPR_SKIP0_CHECK=0 (development): such frames go unverified */
     uint64_t skip0_veto_serial = 0;    /* the tape whose last verified frame failed: its next frames start at the 64^3 tiles ... */
     int skip0_veto_left = 0;           /* ... this many of them, then one tries again */
+    int skip0_veto_span = 64;          /* ... twice as many after every failure in a row */
     long long skip0_vetoes = 0;        /* frames rendered again (mpr_ctx_skip0_vetoes: tests) */
     /* frames that start at the 16^3 tiles, of a tape whose float pass and normals pass run on its root code with records: nobody
      * walks the tapes the first stage pushes (the sample of the last stage apart: such frames take none; every 32nd frame is an
@@ -1590,8 +1591,10 @@ static bool skip0_verdict_failed(mpr_context* c, const mpr_tape* tape)
     if (!c->skip0_unchecked) return false;
     c->skip0_unchecked = false;
     if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0) return false;
+    /* (a view that changes may pass later: the tape tries again after 64 frames, after 128 if that fails too, ... 4096) */
+    c->skip0_veto_span = c->skip0_veto_serial == tape->serial ? std::min(c->skip0_veto_span * 2, 4096) : 64;
     c->skip0_veto_serial = tape->serial;
-    c->skip0_veto_left = 64;
+    c->skip0_veto_left = c->skip0_veto_span;
     ++c->skip0_vetoes;
     return true;
 }

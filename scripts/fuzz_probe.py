@@ -35,9 +35,9 @@ for arg in sys.argv[1:]:
     print("%s: %d clauses, %d slots, %d min / max" % (arg, tape.length, tape.num_slots, tape.num_choices))
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(T, 4), threads=0)
     ref2 = orc.Frame(tape.data, 2, 2 * S, mpr.colmajor(T2, 3), z=0.05, threads=0)
-    if S <= 256:
-        brute = orc.Frame(tape.data, 3, S, mpr.colmajor(T, 4), threads=0, brute=True)
-        print("  the oracle's hierarchy against its brute force: %d pixels differ" % int((brute.filled[3] != ref.filled[3]).sum()))
+    # (the reference has a brute-force renderer in 2-D only, and so has the oracle: render2D_brute, src/context.cu:1461-1508)
+    brute2 = orc.Frame(tape.data, 2, 2 * S, mpr.colmajor(T2, 3), z=0.05, threads=0, brute=True)
+    print("  the oracle's 2-D hierarchy against its brute force: %d pixels differ" % int((brute2.filled[3] != ref2.filled[3]).sum()))
     for env in settings:
         for key in list(os.environ):
             if key.startswith("MPR_"):

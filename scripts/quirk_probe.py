@@ -35,9 +35,8 @@ for k in (8.0, 64.0):
     for S in (128, 512):
         ref = orc.Frame(tape.data, 3, S, mpr.colmajor(T, 4), threads=0)
         ref2 = orc.Frame(tape.data, 2, S, mpr.colmajor(T2, 3), threads=0)
-        brute = orc.Frame(tape.data, 3, S, mpr.colmajor(T, 4), threads=0, brute=True) if S == 128 else None
-        if brute is not None:
-            print("k=%g S=%d: the oracle's own hierarchy against its brute force: %d pixels differ" % (k, S, int((brute.filled[3] != ref.filled[3]).sum())))
+        brute2 = orc.Frame(tape.data, 2, S, mpr.colmajor(T2, 3), threads=0, brute=True)      # (2-D only: the reference's render2D_brute)
+        print("k=%g S=%d: the oracle's own 2-D hierarchy against its brute force: %d pixels differ" % (k, S, int((brute2.filled[3] != ref2.filled[3]).sum())))
         for env in settings:
             for key in list(os.environ):
                 if key.startswith("MPR_"):
