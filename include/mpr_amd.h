@@ -206,7 +206,7 @@ int mpr_read_normals(mpr_context* ctx, uint32_t* host);
  * ordinary one: see mpr_ctx_last_stage_pushed.  So do mpr_read_tape_pool and mpr_get_counters.) */
 int mpr_read_tiles(mpr_context* ctx, int32_t stage, mpr_tile_node* host, size_t cap, size_t* n);
 /* Frames whose shortcut past the 64^3 tiles failed its verification and that were rendered again from those tiles down (csrc/kernels.hpp:
- * launch_skip0_parents; the tape's next 64 frames then start at the 64^3 tiles by themselves).  Tests. */
+ * launch_skip0_parents; the tape's next 64 frames then start at the 64^3 tiles by themselves, twice as many after every further failure).  Tests. */
 int64_t mpr_ctx_skip0_vetoes(const mpr_context* c);
 /* tape_data / *tape_index -> host; copies min(cap, *tape_index) clauses */
 int mpr_read_tape_pool(mpr_context* ctx, uint64_t* host, size_t cap, int32_t* tape_index);
