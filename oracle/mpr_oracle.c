@@ -761,7 +761,10 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                       int32_t rank, int32_t flags)
 {
     if (!tape || length < 2 || (dim != 2 && dim != 3) || S < 64 || S % 64) return NULL;
-    const int brute = (flags & 1) && dim == 2;
+    /* brute force: 2-D the reference's render2D_brute (:1461-1508); 3-D — the reference has none — the same idea: every 4^3 tile of
+     * the volume straight to the float pass with the root tape, normals from the root tape: what a renderer without a hierarchy
+     * draws (tests: where the reference's hierarchy draws the same, and where — a NaN end in its intervals — it does not) */
+    const int brute = (flags & 1) != 0;
     const int skip_normals = (flags & 2) != 0;
     /* heatmap: 1 = as executed here, 2 = lower bound, 3 = upper bound over the timing-dependent
      * parts of a 3-D frame (a tile culled mid-stage by a neighbour's fill does not push; a voxel
@@ -813,9 +816,9 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
             if (owner && owner[i % ((size_t)t0 * t0)] != rank) f->tiles[0][i].position = -1;
         }
     } else {
-        /* render2D_brute — :1461-1508: every 8x8 tile goes straight to the pixel pass */
-        const int32_t t8 = S / 8;
-        count = (size_t)t8 * t8;
+        /* render2D_brute — :1461-1508: every 8x8 tile goes straight to the pixel pass (3-D: every 4^3 tile) */
+        const int32_t t8 = S / (dim == 3 ? 4 : 8);
+        count = (size_t)t8 * t8 * (dim == 3 ? t8 : 1);
         grow_tiles(f, 3, count);
         for (size_t i = 0; i < count; ++i) {
             f->tiles[3][i].position = (int32_t)i;
@@ -1104,7 +1107,9 @@ orc_frame* orc_render(const uint64_t* tape, int32_t length, int32_t dim, int32_t
                 int32_t tape_at;
                 const int32_t t64 = S / 64;
                 const int32_t tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
-                if (tiles[tile].next == -1) {
+                if (brute) {
+                    tape_at = 0;
+                } else if (tiles[tile].next == -1) {
                     tape_at = tiles[tile].tape;
                 } else {
                     const int32_t subtile = tiles[tile].next * 64 + (px % 64) / 16 + ((py % 64) / 16) * 4 +

@@ -51,6 +51,38 @@ def test_hierarchy_equals_brute_force_2d(orc, tapes, name, S):
     assert np.array_equal(hier.image, brute.image)
 
 
+@pytest.mark.parametrize("name,S", [("two_spheres", 128), ("hello_world", 128), ("bear", 128), ("architecture", 128), ("involute_gear_3d", 128),
+                                    ("trig", 128), ("smooth", 128), ("shape_12_0", 128), ("shape_12_3", 128), ("shape_4_9", 128), ("shape_12_21", 128),
+                                    ("shape_64_5", 128)])
+def test_hierarchy_equals_brute_force_3d(orc, tapes, mpr, name, S):
+    """... and in 3-D, where the reference has no brute-force renderer: the oracle's (`brute=True`: every 4^3 tile of the volume
+    straight to the float pass with the root tape, the normals from the root tape) draws the heights AND the normals the
+    64 -> 16 -> 4 hierarchy with its shortened tapes draws — for every benchmark model and for random shapes whose partial
+    functions stay inside their domains."""
+    tape = tapes(name).data
+    hier = orc.Frame(tape, 3, S, mpr.colmajor(view3(), 4), threads=0)
+    brute = orc.Frame(tape, 3, S, mpr.colmajor(view3(), 4), threads=0, brute=True)
+    assert hier.image.any()
+    assert np.array_equal(hier.image, brute.image)
+    assert np.array_equal(hier.normals, brute.normals)
+
+
+def test_where_the_references_hierarchy_is_not_its_brute_force(orc, mpr):
+    """The invariant is a property of sound intervals, and the reference's are not sound where asin / acos leave [-1, 1] inside a
+    tile: inc/gpu_interval.hpp:306-324 returns a NaN end, the interval product with it is [0, 0] (:86-146: every sign test is
+    false), and a tile is "filled" or a min / max "decided" on the strength of it — the hierarchy then draws what no evaluation
+    voxel by voxel does (117 pixels of this shape: the very pixels where tests/golden/make_independent.py's evaluator
+    disagrees).  Parity means the REFERENCE's image, so this is what the product must reproduce — and what makes its shortcut
+    past the 64^3 tiles a thing to verify (tests/test_gpu_render.py:
+    test_frames_that_start_at_the_16_tiles_are_verified_against_the_64_tiles)."""
+    import test_gpu_fuzz_shapes
+    for seed, pixels in ((14, 117), (9, 1870), (15, 14)):
+        tape = test_gpu_fuzz_shapes.fuzz_tape(mpr, seed, 12).data
+        hier = orc.Frame(tape, 3, 128, mpr.colmajor(view3(), 4), threads=0)
+        brute = orc.Frame(tape, 3, 128, mpr.colmajor(view3(), 4), threads=0, brute=True)
+        assert int((hier.image != brute.image).sum()) == pixels
+
+
 def test_heightmap_equals_brute_force_column_scan(orc, tapes, mpr):
     """3-D: the heightmap is the top-most voxel with f < 0 in every column (z = 0 excluded)."""
     S = 64
