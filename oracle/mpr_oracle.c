@@ -12,6 +12,8 @@
  *                                 incl. tape pushing, mask, assign_next, subdivide, copy_filled,
  *                                 calculate_voxels/pixels, eval_voxels_f, eval_pixels_d)
  *   src/context.cu:1136-1508      stage order of render2D / render3D / render2D_brute
+ *                                 (+ a brute force in 3-D, which the reference does not have: every 4^3 tile to the float
+ *                                 pass with the root tape — tests/test_oracle_kat.py holds the hierarchy against it)
  *   src/context.cpp:17-49         buffer sizes
  *
  * Pinning status: the reference ships no tests, golden images or stored vectors for this
@@ -21,7 +23,10 @@
  * answers derivable from the reference's own source text (tests/test_oracle_kat.py):
  * the compiled two-sphere kernel of benchmark/brute.cu:39-61, the hierarchy == brute-force
  * invariant that benchmark/brute.cu relies on, the tile-occupancy semantics of
- * benchmark/circle.cpp:42-103 and the clause table of benchmark/print_tape_table.cpp:29-51.
+ * benchmark/circle.cpp:42-103 and the clause table of benchmark/print_tape_table.cpp:29-51 —
+ * and two routes that share none of this file's code: an independent numpy evaluator's frames of
+ * the benchmark models and of random shapes (tests/golden/make_independent.py, tests/test_independent.py)
+ * and exact rational arithmetic for every interval opcode (tests/test_soundness.py).
  *
  * Deliberate, documented choices where the CUDA toolchain's behaviour cannot be known:
  *   - no FMA contraction anywhere (nvcc may contract; irrelevant for the benchmark views,
