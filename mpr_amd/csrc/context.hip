@@ -24,6 +24,7 @@
 #include "internal.hpp"
 #include "kernels.hpp"
 #include "tile_gen.hpp"
+#include "interval_gen.hpp"
 #include "voxel_gen.hpp"
 #include "frame_domain.hpp"
 static_assert(mpr::TILE_GEN_RECORD_U64 == mprk::GEN_RECORD_U64 && mpr::TILE_GEN_PRESENCE_WORDS == mprk::GEN_PRESENCE_WORDS, "one record layout");
@@ -198,6 +199,10 @@ struct mpr_context {
     uint64_t lean_first_serial = 0;    /* ... frames of this tape since it became resident */
     unsigned lean_first_frames = 0;
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
+    bool tile_gen_sched = true;        /* MPR_TILE_GEN_SCHED=0: the tile stages' forward walks on round 4's code (calls the interpreter's routines) instead of
+                                        * the scheduled walks of interval_gen.hpp */
+    int gen_iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gen_iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    unsigned int* redo_count = nullptr;   /* MPR_DEBUG_REDO=1: {wavefronts that ran generated forward code, of them: redone on the exact code} */
     bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
@@ -426,6 +431,9 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_SCHED")) c->tile_gen_sched = atoi(e) != 0;
+    if (const char* e = getenv("MPR_DEBUG_REDO"))
+        if (atoi(e) != 0 && hipMalloc((void**)&c->redo_count, 2 * sizeof(unsigned int)) == hipSuccess) (void)hipMemset(c->redo_count, 0, 2 * sizeof(unsigned int));
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
     if (const char* e = getenv("MPR_TAME_CHECK")) c->tame_check = atoi(e) != 0;
     if (const char* e = getenv("MPR_SKIP0_CHECK")) c->skip0_verify = atoi(e) != 0;
@@ -674,6 +682,11 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     c->gen_derivg_dw = c->normals_guards ? code->derivg_dw : 0;
                     c->gen_words = code->walk_words;
                     c->gen_nchoices = code->nchoices;
+                    for (int k = 0; k < 3; ++k)
+                        for (int l = 0; l < 2; ++l) {
+                            c->gen_iw_at[k][l] = code->iw_at[k][l];
+                            c->gen_iw_dw[k][l] = c->tile_gen_sched ? code->iw_dw[k][l] : 0;
+                        }
                 }
             }
         }
@@ -1018,6 +1031,8 @@ static int frame_begin(Frame& f)
             mprk::Skip0ParentsArgs& pa = f.skip0_args;
             pa.tape_ro = c->pool;
             pa.gen_fwd = c->gen_code;
+            pa.gen_fwd2_first = c->gen_iw_dw[0][0] ? c->gen_code + c->gen_iw_at[0][0] : nullptr;
+            pa.gen_fwd2_below = c->gen_iw_dw[1][0] ? c->gen_code + c->gen_iw_at[1][0] : nullptr;
             pa.parents = c->skip0_parents;
             pa.count = count;
             pa.tps = t0;
@@ -1158,6 +1173,16 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         }
         /* (not the stage that is held against its exact parents: a looser child decides less than they did) */
         a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose && tape->loose_ok && !verified_stage;
+        if (a.gen_fwd) {
+            /* the scheduled walk of the kind this stage needs (interval_gen.hpp); a loose one falls back on the exact one of its kind */
+            const int kind = !a.gen_parent ? mpr::IW_FIRST : (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) ? mpr::IW_BELOW_GUARDED : mpr::IW_BELOW;
+            if (c->gen_iw_dw[kind][0] > 0) {
+                a.gen_fwd2_exact = c->gen_code + c->gen_iw_at[kind][0];
+                a.gen_fwd2 = a.gen_loose && c->gen_iw_dw[kind][1] > 0 ? c->gen_code + c->gen_iw_at[kind][1] : a.gen_fwd2_exact;
+                if (a.gen_fwd2 == a.gen_fwd2_exact) a.gen_loose = false;
+                a.gen_redo_count = c->redo_count;
+            }
+        }
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
         std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
@@ -1167,6 +1192,7 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             if (a.gen_loose) f += "+loose";
             f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : a.gen_forward_only ? "+fwdonly" : "";
             if (a.gen_decisions) f += "+records";
+            if (a.gen_fwd2) f += "+sched";
         }
         if (!c->stage_forms.empty()) c->stage_forms += " ";
         c->stage_forms += std::to_string(i) + ":" + f;
@@ -1673,6 +1699,21 @@ extern "C" {
 
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
 int64_t mpr_ctx_skip0_vetoes(const mpr_context* c) { return c ? c->skip0_vetoes : 0; }
+/* development (MPR_DEBUG_REDO=1): wavefronts that ran a scheduled forward walk since the context was made, and how many of them had
+ * their loose walk redone on the exact code */
+extern "C" int mpr_debug_redo_counts(mpr_context* c, uint32_t out[2])
+{
+    if (!c || !out) return MPR_ERR_INVALID;
+    out[0] = out[1] = 0;
+    if (!c->redo_count) return MPR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned int h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, c->redo_count, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0] + h[1];
+    out[1] = h[1];
+    return MPR_OK;
+}
 const char* mpr_ctx_tile_stage_forms(const mpr_context* c) { return c ? c->stage_forms.c_str() : ""; }
 /* tiles of the last frame AS IT RAN (no re-render: a frame nobody reads may start at the 16^3 tiles and cull with looser bounds than
  * the reference): per stage the tiles evaluated and the tiles left ambiguous, then the smallest tiles handed to the float pass */

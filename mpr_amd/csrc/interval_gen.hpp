@@ -1,0 +1,62 @@
+/*
+ * interval_gen.hpp — the ROOT tape's interval forward walk (reference src/context.cu:188-321, inc/gpu_interval.hpp:71-391) as
+ * scheduled gfx950 code: every clause's routine in line on the registers its operands live in, independent clauses interleaved.
+ *
+ * Round 4's generated walk (tile_gen.cpp) was a dependent chain that called the interpreter's routines: half of its in-line
+ * instructions were v_movs into and out of the routines' fixed registers, and a lone wavefront had nothing to issue under each
+ * dependent result (a tile stage runs four wavefronts per SIMD; the DAG of a tape has 5-8 independent clauses per level).  Here
+ * a clause is expanded to instructions over VIRTUAL registers (gfx950_ir.hpp) — slots are renamed away: a value is a pair of
+ * virtual registers, COPY and NEG cost nothing —, the instructions of neighbouring clauses are list-scheduled by their
+ * dependencies (a window of clauses bounds the register pressure), a linear scan hands out physical registers, and a last pass
+ * inserts the wait states the chip does not interlock (VALU-written SGPR -> VALU: 2; transcendental -> other VALU: 1).
+ *
+ * Two kinds of arithmetic:
+ *  - EXACT: the reference's enclosures bit for bit — the instruction sequences of the interpreter's routines
+ *    (tile_interp_asm.hpp: TI_BODIES_TEXT; tile_gen_asm.hpp: L_gmin / L_gmax) on renamed registers; sqrt / div / exp / log /
+ *    asin / acos / atan stay calls (operands v[36:39], result v[40:41], entry points in the SGPR pairs of TileGenReg).
+ *  - LOOSE (frames nobody reads; tile_gen_asm.hpp explains what such a frame owes the reference): sound, slightly wider
+ *    enclosures on NEGATED lower bounds (a value is (-lo, hi), so that both ends round up and sums, differences and products by
+ *    constants take two instructions), products by the four-products rule, exp / log / sqrt / reciprocals from the hardware's
+ *    base-2 instructions widened by their error bound, constants' reciprocals rounded on the host.  The loose walk is straight-
+ *    line code: instead of testing each operand where it is used it keeps two sticky flags — the largest magnitude any product,
+ *    square, quotient or exponential produced (v42..v45; below 2^120 at the end: no infinity and hence no NaN ever existed, every
+ *    loose value is an ordinary real enclosure) and the lanes in which an operand left its routine's domain (s[40:41]: a negative
+ *    radicand, a logarithm's lower end that is not a positive normal number, a divisor that holds zero) — and when either is
+ *    raised at the end the WHOLE walk runs again on the exact code (s[60:61]: the harness's redo entry).
+ *
+ * Kinds of walk: FIRST (nobody above decided anything), BELOW (a stage below the first: the parent tile's decisions
+ * s[72:73] / s[74:75] are imposed on the min / max clauses), BELOW_GUARDED (also jumps over the runs of clauses those decisions
+ * leave dead — voxel_gen.hpp: tape_dead_runs; for stages that push no tapes).
+ *
+ * Register conventions of the code (the harness: tile_gen_asm.hpp: tile_gen_forward2)
+ *   in:  v0..v5 = x.lo, x.hi, y.lo, y.hi, z.lo, z.hi; s[72:73] / s[74:75] decided above; v56..v59 = 0; round-up mode, all lanes on
+ *   out: v[36:37] = the end clause's interval; v56 / v57 (v58 / v59): bit k = the lane chose the lhs (rhs) at min / max clause k
+ *   returns through s[38:39]; loose code leaves through s[60:61] when the walk has to be redone
+ */
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mpr {
+
+enum IntervalWalkKind : int { IW_FIRST = 0, IW_BELOW = 1, IW_BELOW_GUARDED = 2 };
+
+struct IntervalCode {
+    bool ok = false;
+    std::vector<uint32_t> words;
+    std::vector<std::string> text;      /* one line per instruction (assembler syntax; kept when asked for: tests) */
+    int instructions = 0, nops = 0, window = 0;
+    int max_vgprs = 0, max_sgpr_pairs = 0;
+    int nchoices = 0, walk_words = 0, result_slot = 0;
+    int est_cycles = 0;                 /* the scheduler's own estimate for a lone wavefront */
+};
+
+constexpr int IGEN_MAX_CHOICES = 64;
+
+/* clauses: head, operations, end (the host copy of a root tape).  loose: see above (false for tapes with asin / acos / atan
+ * clauses or a constant divisor outside 2^-100 .. 2^100: ok == false).  window: clauses the scheduler may look ahead (0: the
+ * default, shrunk until the registers suffice; 1: the tape's own order).  min_run: shortest dead run worth a guard. */
+IntervalCode interval_gen_build(const uint64_t* clauses, int len, int kind, bool loose, int window = 0, int min_run = 3, bool keep_text = false);
+
+}  // namespace mpr

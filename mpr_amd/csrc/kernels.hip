@@ -285,9 +285,16 @@ k_eval_tiles(TileStageArgs a)
             }
         }
         gen_keeps = keeps;
-        tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
-                         2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                         make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, a.gen_loose);
+        if (a.gen_fwd2) {
+            uint32_t redone = 0;
+            tile_gen_forward2(a.gen_fwd2, a.gen_fwd2_exact, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                              make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, &redone);
+            if (a.gen_redo_count && lane == 0) atomicAdd(a.gen_redo_count + (redone ? 1 : 0), 1u);
+        } else {
+            tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                             2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                             make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, a.gen_loose);
+        }
         chl[0] &= (uint32_t)keeps; chl[1] &= (uint32_t)(keeps >> 32);
         chr[0] &= (uint32_t)keeps; chr[1] &= (uint32_t)(keeps >> 32);
         ci = __popcll(keeps);
@@ -1284,9 +1291,13 @@ k_skip0_parents(Skip0ParentsArgs a)
     const uint64_t head0 = a.tape_ro[0];
     float2 res = make_float2(0.0f, 0.0f);
     uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};
-    tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
-                     2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                     make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0, false);
+    if (a.gen_fwd2_first)
+        tile_gen_forward2(a.gen_fwd2_first, nullptr, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                          make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0);
+    else
+        tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                         2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                         make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0, false);
     round_nearest_begin();
     if (valid) {
         /* the reference's classification (:293-321; nothing is filled yet when its first stage runs: no tile is masked) */
@@ -1339,9 +1350,13 @@ k_skip0_compare(Skip0ParentsArgs a, const unsigned long long* __restrict__ child
         const uint64_t head0 = a.tape_ro[0];
         float2 res = make_float2(0.0f, 0.0f);
         uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};
-        tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
-                         2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                         make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr, false);
+        if (a.gen_fwd2_below)
+            tile_gen_forward2(a.gen_fwd2_below, nullptr, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                              make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr);
+        else
+            tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
+                             2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                             make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr, false);
         round_nearest_begin();
         if (again) {
             const bool same_end = (cv == SKIP0_EMPTY && res.x > 0.0f) || (cv == SKIP0_FILLED && !(res.x > 0.0f) && res.y < 0.0f);

@@ -81,6 +81,10 @@ struct TileStageArgs {
     unsigned long long* self_info = nullptr;   /* with gen_fwd, the first stage of a frame that starts at the 16^3 tiles: per tile
                                                 * SKIP0_INFO_U64 words — what it decided by itself (lhs, rhs: bit k = the root tape's k-th
                                                 * min / max) and its verdict (SKIP0_*), for k_skip0_compare */
+    const uint32_t* gen_fwd2 = nullptr;        /* round 5: the scheduled forward walk this stage runs (interval_gen.hpp: the kind the stage needs, loose or
+                                                * exact) and the exact walk of the same kind a loose one falls back on (null: gen_fwd's code and harness) */
+    const uint32_t* gen_fwd2_exact = nullptr;
+    unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
     bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened
                                           * by their error bound, instead of the correctly rounded ones (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */
     const unsigned long long* gen_parent = nullptr;   /* with gen_fwd, instead of gen_bwd: the launch is the stage BELOW the one that wrote these records
@@ -168,6 +172,8 @@ enum { SKIP0_UNSEEN = 0, SKIP0_EMPTY = 1, SKIP0_FILLED = 2, SKIP0_AMBIGUOUS = 3 
 struct Skip0ParentsArgs {
     const uint64_t* tape_ro = nullptr;       /* the pool: [0] = the root tape's head */
     const uint32_t* gen_fwd = nullptr;       /* the root tape's forward walk (exact routines) */
+    const uint32_t* gen_fwd2_first = nullptr, *gen_fwd2_below = nullptr;   /* round 5: the scheduled exact walks (interval_gen.hpp: IW_FIRST for the
+                                              * parents, IW_BELOW for the children their decisions are imposed on); null: gen_fwd */
     unsigned long long* parents = nullptr;   /* [count][SKIP0_INFO_U64] */
     int count = 0, tps = 0;                  /* 64^3 tiles, per side */
     float mat[16] = {0};

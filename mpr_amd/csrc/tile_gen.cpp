@@ -8,6 +8,7 @@
 #include "../../include/mpr_clause.h"
 #include "gfx950_emit.hpp"
 #include "internal.hpp"
+#include "interval_gen.hpp"
 #include "voxel_gen.hpp"
 
 namespace mpr {
@@ -693,6 +694,15 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     c->walk_words = g.words;
     c->nchoices = g.nchoices;
     c->vox_min_run = vox_min_run;
+    for (int kind = 0; kind < 3; ++kind)
+        for (int loose = 0; loose < 2; ++loose) {
+            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0);
+            if (!ic.ok) continue;
+            c->iw_at[kind][loose] = (int)c->words.size();
+            c->iw_dw[kind][loose] = (int)ic.words.size();
+            c->iw_instructions[kind][loose] = ic.instructions;
+            c->words.insert(c->words.end(), ic.words.begin(), ic.words.end());
+        }
     return c;
 }
 }  // namespace mpr
