@@ -190,6 +190,7 @@ struct mpr_context {
     uint64_t skip0_veto_serial = 0;    /* the tape whose last verified frame failed: its next frames start at the 64^3 tiles ... */
     int skip0_veto_left = 0;           /* ... this many of them, then one tries again */
     int skip0_veto_span = 64;          /* ... twice as many after every failure in a row */
+    bool skip0_normals_veto = false;   /* the last frame's normals pass could not take the 64^3 tiles' decisions (frame_normals_pass) */
     long long skip0_vetoes = 0;        /* frames rendered again (mpr_ctx_skip0_vetoes: tests) */
     /* frames that start at the 16^3 tiles, of a tape whose float pass and normals pass run on its root code with records: nobody
      * walks the tapes the first stage pushes (the sample of the last stage apart: such frames take none; every 32nd frame is an
@@ -1575,6 +1576,15 @@ static int frame_normals_pass(Frame& f)
             n.gen_decisions = c->gen_dec[1];
             n.gen_decisions2 = last_recorded ? c->gen_dec[2] : nullptr;
             n.gen_nchoices = c->gen_nchoices;
+            if (f.skip0_checked) {
+                /* the 64^3 tiles' decisions, walked beside the frame (kernels.hpp: NormalArgs::skip0_parents): long there */
+                HIP_TRY(hipStreamWaitEvent(s, c->ev_check, 0));
+                n.skip0_parents = c->skip0_parents;
+            }
+        } else if (f.skip0_checked) {
+            /* the interpreters walk tapes, and the 16^3 tiles this frame culled carry none of their 64^3 tiles': such a frame's
+             * normals are the reference's only where every decision is a fact — the frame again, from the 64^3 tiles down */
+            c->skip0_normals_veto = true;
         }
         if (owner && c->normals_asm && !cnt) {
             /* owned columns only; the list is rebuilt when the ownership table or the rank changes */
@@ -1616,7 +1626,9 @@ static bool skip0_verdict_failed(mpr_context* c, const mpr_tape* tape)
 {
     if (!c->skip0_unchecked) return false;
     c->skip0_unchecked = false;
-    if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0) return false;
+    const bool normals_veto = c->skip0_normals_veto;
+    c->skip0_normals_veto = false;
+    if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0 && !normals_veto) return false;
     /* (a view that changes may pass later: the tape tries again after 64 frames, after 128 if that fails too, ... 4096) */
     c->skip0_veto_span = c->skip0_veto_serial == tape->serial ? std::min(c->skip0_veto_span * 2, 4096) : 64;
     c->skip0_veto_serial = tape->serial;
@@ -1662,6 +1674,10 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 rc = frame_normals_pass(f);
                 if (rc) return rc;
             }
+        }
+        if (f.skip0_checked && !blocking && c->skip0_normals_veto) {
+            c->skip0_unchecked = true;
+            if (skip0_verdict_failed(c, tape)) continue;
         }
         if (f.skip0_checked && blocking) {
             /* every tile of the frame's first stage against its 64^3 parent, behind the frame: the side stream's walk of those
@@ -2196,6 +2212,53 @@ int mpr_test_interval_op_asm(int32_t device, int32_t op, int32_t variant, int32_
     HIP_TRY(hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
     if (out_choice) HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+/* development aid (scripts/walk_cycles.py): mean cycles per scheduled forward walk (interval_gen.hpp) of `clauses`, per wavefront, with
+ * `waves` wavefronts in flight (one per workgroup, four per SIMD at most); empty != 0: the harness alone (code that returns at once) */
+extern "C" int mpr_debug_walk_cycles(int32_t device, const uint64_t* clauses, int32_t length, int32_t kind, int32_t loose, int32_t window,
+                                     int32_t empty, int32_t reps, int32_t waves, long long* out, uint32_t* redone, int32_t* info)
+{
+    HIP_TRY(hipSetDevice(device));
+    std::vector<uint32_t> words, exact;
+    if (empty) {
+        words.push_back(0xBE801D26u);                        /* s_setpc_b64 s[38:39] */
+    } else {
+        const mpr::IntervalCode g = mpr::interval_gen_build(clauses, length, kind, loose != 0, window);
+        if (!g.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "the generator does not take this tape");
+        words = g.words;
+        if (info) { info[0] = g.instructions; info[1] = g.window; info[2] = g.max_vgprs; info[3] = g.est_cycles; }
+        if (loose) {
+            const mpr::IntervalCode x = mpr::interval_gen_build(clauses, length, kind, false, window);
+            if (!x.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "the generator does not take this tape");
+            exact = x.words;
+        }
+    }
+    const size_t n1 = (words.size() + 63) & ~(size_t)63, n2 = (exact.size() + 63) & ~(size_t)63;
+    uint32_t* code = static_cast<uint32_t*>(alloc_executable(device, (n1 + n2 + 64) * sizeof(uint32_t)));
+    if (!code) return mpr::set_error(MPR_ERR_NO_DEVICE, "no executable memory");
+    DevBuf stage, dout, dred;
+    HIP_TRY(stage.alloc((n1 + n2 + 64) * sizeof(uint32_t)));
+    HIP_TRY(dout.alloc((size_t)waves * 8));
+    HIP_TRY(dred.alloc(8));
+    HIP_TRY(hipMemset(dred.p, 0, 8));
+    std::vector<uint32_t> all(n1 + n2 + 64, 0xBF800000u);
+    std::copy(words.begin(), words.end(), all.begin());
+    std::copy(exact.begin(), exact.end(), all.begin() + (long)n1);
+    HIP_TRY(hipMemcpy(stage.p, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+        /* (one workgroup per compute unit: each invalidates its own instruction cache) */
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        mprk::launch_install_code(nullptr, code, (const uint32_t*)stage.p, all.size(), std::max(prop.multiProcessorCount, 1));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    mprk::launch_debug_walk_cycles(nullptr, code, exact.empty() ? nullptr : code + n1, reps, (long long*)dout.p, (unsigned int*)dred.p, waves);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)waves * 8, hipMemcpyDeviceToHost));
+    if (redone) HIP_TRY(hipMemcpy(redone, dred.p, 4, hipMemcpyDeviceToHost));
+    free_executable(code);
     return MPR_OK;
 }
 /* development aid (scripts/interp_cycles.py): cycles per forward walk of `clauses` (head, body, end) */

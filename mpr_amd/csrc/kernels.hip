@@ -285,7 +285,9 @@ k_eval_tiles(TileStageArgs a)
             }
         }
         gen_keeps = keeps;
-        if (a.gen_fwd2) {
+        if (a.debug & 32) {                          /* development: no walk at all, every tile empty (what the rest of the kernel costs) */
+            res_vs = make_float2(1.0f, 2.0f);
+        } else if (a.gen_fwd2) {
             uint32_t redone = 0;
             tile_gen_forward2(a.gen_fwd2, a.gen_fwd2_exact, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
                               make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, &redone);
@@ -1249,6 +1251,44 @@ k_debug_interp_cycles(const uint64_t* tape, int reps, long long* out)
         const long long t1 = (long long)__builtin_readcyclecounter();
         if (lane == 0) out[r] = (t1 - t0) + (ir.words & 0);
     }
+}
+/* development (scripts/walk_cycles.py): cycles a wavefront needs for one scheduled forward walk (tile_gen_forward2: the harness's LDS traffic
+ * included) on tiles of a 16^3-stage-like grid; out[wave] = mean over reps.  code == null: the harness alone. */
+__global__ void __launch_bounds__(64, 4)
+k_debug_walk_cycles(const uint32_t* code, const uint32_t* code_exact, int reps, long long* out, unsigned int* redone_out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gen_io[4096];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x * 64 + lane;
+    const float t = 64.0f;
+    const int px = g & 63, py = (g >> 6) & 63, pz = (g >> 12) & 63;
+    float c0 = (px / t - 0.5f) * 2.0f, c1 = ((px + 1) / t - 0.5f) * 2.0f;
+    float c2 = (py / t - 0.5f) * 2.0f, c3 = ((py + 1) / t - 0.5f) * 2.0f;
+    float c4 = (pz / t - 0.5f) * 2.0f, c5 = ((pz + 1) / t - 0.5f) * 2.0f;
+    round_up_begin(c0, c1, c2, c3, c4, c5);
+    long long total = 0;
+    uint32_t redone_any = 0;
+    float acc = 0.0f;
+    for (int r = 0; r < reps; ++r) {
+        float2 res = make_float2(0.0f, 0.0f);
+        uint32_t chl[2] = {0, 0}, chr[2] = {0, 0}, redone = 0;
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        tile_gen_forward2(code, code_exact, gen_io, lane, make_float2(c0, c1), make_float2(c2, c3), make_float2(c4, c5), &res, chl, chr, 0, 0, &redone);
+        const long long t1 = (long long)__builtin_readcyclecounter();
+        total += t1 - t0;
+        redone_any |= redone;
+        acc += res.x + res.y + (float)(chl[0] ^ chr[0]);
+    }
+    round_nearest_begin();
+    if (lane == 0) {
+        out[blockIdx.x] = total / (reps > 0 ? reps : 1);
+        if (redone_any) atomicAdd(redone_out, 1u);
+    }
+    if (acc == 12345.678f) out[0] = 0;
+}
+void launch_debug_walk_cycles(hipStream_t s, const uint32_t* code, const uint32_t* code_exact, int reps, long long* out, unsigned int* redone, int waves)
+{
+    hipLaunchKernelGGL(k_debug_walk_cycles, dim3(waves), dim3(64), 0, s, code, code_exact, reps, out, redone);
 }
 __global__ void k_test_float(int op, int n, const float* a, const float* b, float imm, float* out)
 {

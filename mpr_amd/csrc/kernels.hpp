@@ -155,6 +155,11 @@ struct NormalArgs {
     const unsigned long long* gen_decisions2 = nullptr;   /* the 4^3 tiles', when the last stage pushed: everything decided for a pixel in one record
                                                            * (else: the 16^3 tile's record and the group's masks) */
     int gen_nchoices = 0;
+    /* frames that start at the 16^3 tiles (context.hip: skip0, verified): what each 64^3 tile of the reference's first stage decides
+     * (Skip0ParentsArgs::parents).  The reference's tape for a voxel inside an ambiguous 64^3 tile is that tile's or a deeper one:
+     * its decisions are imposed on every pixel there — also where the 16^3 tile was culled and keeps no record of its own (round 5:
+     * scripts/fuzz_sweep.py, seeds 1989 / 2074 / 2435 / 2762 / 2891: decisions that are not facts about the float values) */
+    const unsigned long long* skip0_parents = nullptr;
 };
 
 /* children != null (3-D frames that start at the 16^3 tiles): also the 64 children of every first-stage tile, t0 = S / 64 */
@@ -179,6 +184,7 @@ struct Skip0ParentsArgs {
     float mat[16] = {0};
 };
 void launch_skip0_parents(hipStream_t s, const Skip0ParentsArgs& a);
+void launch_debug_walk_cycles(hipStream_t s, const uint32_t* code, const uint32_t* code_exact, int reps, long long* out, unsigned int* redone, int waves);
 /* children: [64 a.count][SKIP0_INFO_U64], what the frame's first stage left (TileStageArgs::self_info); flag: host-coherent
  * memory, set to 1, never cleared.  A child that did not make a decision of its parent's again gets the reference's walk — the
  * parent's decisions imposed — and passes if it ends culled the way it culled itself. */

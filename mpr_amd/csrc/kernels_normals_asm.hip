@@ -660,9 +660,17 @@ k_eval_normals_gen(NormalArgs a)
 
     /* the pixel's 16^3 tile (index in its stage's list, and the tape that tile pushed: 0 = none) and 4^3 tile (:1034-1066) */
     int my_sub = -1, sub_tape = 0, my_micro = -1, my_top = -1;
+    unsigned long long parent_l = 0, parent_r = 0;             /* what the pixel's 64^3 tile decided in a frame that skipped that stage */
     if (filled) {
         const int t64 = S / 64;
         const int tile = px / 64 + (py / 64) * t64 + (pz / 64) * t64 * t64;
+        if (a.skip0_parents) {
+            const unsigned long long* const pi = a.skip0_parents + (size_t)tile * SKIP0_INFO_U64;
+            if (pi[2] == (unsigned long long)SKIP0_AMBIGUOUS) {
+                parent_l = pi[0];
+                parent_r = pi[1];
+            }
+        }
         const mpr_tile_node tn = a.tiles[tile];
         if (tn.next == -1) {
             if (tn.tape != 0 && a.gen_decisions0) my_top = tile;           /* a 64^3 tile that pushed a tape and was decided afterwards */
@@ -737,6 +745,8 @@ k_eval_normals_gen(NormalArgs a)
         dl = rec[0];
         dr = rec[1];
     }
+    dl |= parent_l & ~dr;
+    dr |= parent_r & ~dl;
 
     const uint64_t head0 = a.tape_ro[0];
     const uint32_t sx = (head0 >> 8) & 0xFF, sy = (head0 >> 16) & 0xFF, sz = (head0 >> 24) & 0xFF;

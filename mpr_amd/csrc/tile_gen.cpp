@@ -3,6 +3,7 @@
 #include "tile_gen.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 #include "../../include/mpr_clause.h"
@@ -694,9 +695,11 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     c->walk_words = g.words;
     c->nchoices = g.nchoices;
     c->vox_min_run = vox_min_run;
+    int window = 0;                                           /* development: MPR_IGEN_WINDOW=1: the tape's own order */
+    if (const char* e = getenv("MPR_IGEN_WINDOW")) window = atoi(e);
     for (int kind = 0; kind < 3; ++kind)
         for (int loose = 0; loose < 2; ++loose) {
-            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0);
+            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window);
             if (!ic.ok) continue;
             c->iw_at[kind][loose] = (int)c->words.size();
             c->iw_dw[kind][loose] = (int)ic.words.size();

@@ -1,5 +1,5 @@
 """Development aid (gpurun): a wider one-off sweep of tests/test_gpu_fuzz_shapes.py's random shapes than the suite keeps —
-default frames (3 in a row) in 3-D and 2-D against the oracle; prints the seeds that differ (as it goes: about two seeds a second,\nmost of it the oracle on the host).  usage: fuzz_sweep.py FIRST COUNT"""
+default frames (3 in a row) in 3-D and 2-D against the oracle; prints the seeds that differ (as it goes: about two seeds a second,\nmost of it the oracle on the host).  usage: fuzz_sweep.py FIRST COUNT [ORACLE_THREADS]   (scripts/r05_fuzz.sh runs a dozen of these side by side)"""
 import os
 import sys
 
@@ -29,6 +29,7 @@ def random_view3(rng):
 
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+THREADS = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 T = np.eye(4, dtype=np.float32)
 T[3, 2] = 0.3
 T2 = np.eye(3, dtype=np.float32)
@@ -40,7 +41,7 @@ for seed in range(first, first + count):
         rng = np.random.default_rng(seed * 7 + size)
         S = int(rng.choice([128, 256]))
         view = T if rng.random() < 0.6 else random_view3(rng)
-        ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view, 4), threads=0)
+        ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view, 4), threads=THREADS)
         ctx = mpr.Context(S)
         for k in range(3):
             ctx.render3D(tape, view)
@@ -51,7 +52,7 @@ for seed in range(first, first + count):
                 break
         vetoes += ctx.skip0_vetoes()
         ctx.close()
-        ref2 = orc.Frame(tape.data, 2, 256, mpr.colmajor(T2, 3), z=0.1, threads=0)
+        ref2 = orc.Frame(tape.data, 2, 256, mpr.colmajor(T2, 3), z=0.1, threads=THREADS)
         ctx = mpr.Context(256)
         for k in range(2):
             ctx.render2D(tape, T2, 0.1)

@@ -197,3 +197,40 @@ def test_random_shapes_at_1024(mpr, orc, seed):
     tape = fuzz_tape(mpr, 400 + seed, 12)
     ref = orc.Frame(tape.data, 3, 1024, mpr.colmajor(view3(), 4), threads=0)
     check_default_path(mpr, ref, tape, 3, 1024, view3(), frames=2)
+
+
+def sweep_view(rng):
+    """scripts/fuzz_sweep.py's views: the benchmark's, or a sheared / mirrored / moved / perspective one"""
+    if rng.random() < 0.6:
+        return view3()
+    V = np.eye(4, dtype=np.float32)
+    V[:3, :3] += rng.uniform(-0.25, 0.25, (3, 3)).astype(np.float32)
+    if rng.random() < 0.5:
+        V[0] *= np.float32(-1.0)
+    V[:3, 3] = rng.uniform(-0.15, 0.15, 3).astype(np.float32)
+    V[3, :3] = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+    return V
+
+
+@pytest.mark.parametrize("seed,size", [(1989, 8), (2074, 3), (2435, 3), (2762, 16), (2891, 3)])
+def test_shapes_the_wide_sweep_found(mpr, orc, seed, size):
+    """scripts/fuzz_sweep.py over seeds 1000..3039 (round 5; profiles/r05_fuzz_sweep.txt): five of its 6120 frames had the reference's
+    heights and 46 to 4096 wrong NORMALS — in round 4's code too.  A pixel's normal is evaluated one voxel above its surface, on the
+    tape of the deepest tile there (reference src/context.cu:1034-1066); where that voxel's 16^3 tile was culled, the reference
+    takes its ambiguous 64^3 parent's shortened tape — the parent's decisions imposed — and a frame that starts at the 16^3 tiles
+    took the root tape: the same normals only where every decision is a fact about the float values.  The normals pass now imposes
+    the 64^3 tiles' decisions (which the verification walks anyway) on every pixel inside an ambiguous one."""
+    tape = fuzz_tape(mpr, seed, size)
+    rng = np.random.default_rng(seed * 7 + size)
+    S = int(rng.choice([128, 256]))
+    view = sweep_view(rng)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view, 4), threads=0)
+    ctx = mpr.Context(S)
+    started_below = False
+    for k in range(3):
+        ctx.render3D(tape, view)
+        assert np.array_equal(ctx.image, ref.filled[3]), (k, ctx.tile_stage_forms())
+        assert np.array_equal(ctx.normals, ref.normals), (k, int((ctx.normals != ref.normals).sum()), ctx.tile_stage_forms(), ctx.normals_kernel())
+        started_below |= ctx.tile_stage_forms().startswith("1:")
+    assert started_below or ctx.skip0_vetoes() > 0      # (the path the finding is about: frames that start at the 16^3 tiles)
+    ctx.close()
