@@ -204,6 +204,9 @@ struct mpr_context {
                                         * the scheduled walks of interval_gen.hpp */
     int gen_iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gen_iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     unsigned int* redo_count = nullptr;   /* MPR_DEBUG_REDO=1: {wavefronts that ran generated forward code, of them: redone on the exact code} */
+    bool tile_gen_lean = true;         /* MPR_TILE_GEN_LEAN=0: loose stages that push nothing in the 128-register kernel too (four wavefronts per SIMD) */
+    unsigned char* redo_flags = nullptr;  /* per workgroup of a lean stage: the launch behind it runs the wavefronts flagged here */
+    size_t redo_flags_cap = 0;
     bool tile_gen_guards = true;       /* MPR_TILE_GEN_GUARDS=0: a lean last stage runs the plain forward walk */
     int gen_vox_dw = 0;                /* dwords of the float walk (voxel_gen.hpp), behind the four above (0: none) */
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
@@ -433,6 +436,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_SCHED")) c->tile_gen_sched = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_LEAN")) c->tile_gen_lean = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_REDO"))
         if (atoi(e) != 0 && hipMalloc((void**)&c->redo_count, 2 * sizeof(unsigned int)) == hipSuccess) (void)hipMemset(c->redo_count, 0, 2 * sizeof(unsigned int));
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
@@ -562,6 +566,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->tape_index) (void)hipFree(c->tape_index);
     free_executable(c->jit_code);
     free_executable(c->gen_code);
+    if (c->redo_flags) (void)hipFree(c->redo_flags);
     if (c->gen_stage) (void)hipFree(c->gen_stage);
     for (int i = 0; i < 3; ++i) if (c->gen_dec[i]) (void)hipFree(c->gen_dec[i]);
     if (c->groups) (void)hipFree(c->groups);
@@ -1272,6 +1277,27 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
             w.bits_out = c->wide_bits[si & 1];
         }
         mprk::launch_eval_tiles_wide(s, dim, w, c->wide_threads);
+    } else if (a.gen_fwd2 && a.gen_loose && a.gen_fwd2 != a.gen_fwd2_exact && c->tile_gen_lean && dim == 3 && !cnt && !heat && !a.self_info &&
+               !a.gen_bwd && !a.gen_bwd_full && !(a.debug & 36) && (a.gen_forward_only || (a.gen_parent && a.no_push && a.groups))) {
+        /* a loose stage that pushes nothing: six wavefronts per SIMD (kernels.hip: k_eval_tiles<.., LEAN>); what its walks hand back
+         * — a walk that asks for the exact code, a group of the stage's sample — the ordinary kernel runs behind it */
+        const size_t nwg = (size_t)(count + 63) / 64;
+        if (nwg > c->redo_flags_cap) {
+            if (c->redo_flags) (void)hipFree(c->redo_flags);
+            c->redo_flags = nullptr;
+            c->redo_flags_cap = 0;
+            HIP_TRY(hipMalloc((void**)&c->redo_flags, nwg * 2 + 64));
+            c->redo_flags_cap = nwg * 2 + 64;
+        }
+        a.lean = true;
+        a.redo_flags = c->redo_flags;
+        (void)mprk::launch_eval_tiles(s, dim, a);
+        a.lean = false;
+        a.redo_flags = nullptr;
+        a.only_flagged = c->redo_flags;
+        a.gen_fwd2 = a.gen_fwd2_exact;
+        (void)mprk::launch_eval_tiles(s, dim, a);
+        c->stage_forms += "+lean";
     } else {
         const bool ran_gen = mprk::launch_eval_tiles(s, dim, a);
         if (a.gen_fwd && !ran_gen)          /* the records this frame counts on would not exist */
@@ -1509,11 +1535,13 @@ static int frame_float_pass(Frame& f)
             rc = jit_prepare(c, tape, dim, nslots, gf, &jp);
             if (rc) return rc;
             if (jp.ok && gf) {
+                if (!c->vox_counters) HIP_TRY(hipMalloc((void**)&c->vox_counters, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int)));
+                HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
                 mprk::VoxelArgs gv = v;
                 gv.tiles = c->tiles[group_stage];
                 gv.count = group_count;
                 mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)jp.region, (int)jp.slot_dw, (int)jp.nslot, jp.grid, (int)tape->clauses.size(), c->groups,
-                                             c->choice_masks, group_cap, c->num_active + 7, c->group_list, jp.always_inv);
+                                             c->choice_masks, group_cap, c->vox_counters, c->group_list, jp.always_inv);
                 jitted = true;
             } else if (jp.ok && !group_form && (brute || c->voxel_jit_tiles)) {
                 mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)jp.region, (int)jp.slot_dw, 1, jp.grid, (int)tape->clauses.size(), nullptr,

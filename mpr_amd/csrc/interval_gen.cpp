@@ -667,10 +667,11 @@ struct Pools {
     std::vector<int> v_unsafe, v_safe;      /* vector registers a call may / may not clobber */
     std::vector<int> s_pairs;
 };
-Pools pools_for(bool loose)
+Pools pools_for(bool loose, int vgpr_limit)
 {
     Pools p;
-    auto range = [](std::vector<int>& v, int a, int b, int step = 1) { for (int r = a; r <= b; r += step) v.push_back(r); };
+    /* (vgpr_limit: the harness that runs the code names only the vector registers below it: a wavefront with fewer registers) */
+    auto range = [vgpr_limit](std::vector<int>& v, int a, int b, int step = 1) { for (int r = a; r <= b; r += step) if (step != 1 || vgpr_limit <= 0 || r < vgpr_limit) v.push_back(r); };
     if (loose) {
         /* no calls: everything but the output pair, the magnitude accumulators and the decision words */
         range(p.v_safe, 60, 117);
@@ -696,7 +697,7 @@ Pools pools_for(bool loose)
     return p;
 }
 
-bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int* max_v, int* max_s)
+bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limit, int* max_v, int* max_s)
 {
     const int n = (int)code.size();
     std::vector<int> vdef(nv, -1), vlast(nv, -1), sdef(ns, -1), slast(ns, -1);
@@ -716,7 +717,7 @@ bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int* max_v, i
         else if (in.dst.k == K::S) { if (sdef[in.dst.id] < 0) sdef[in.dst.id] = j; slast[in.dst.id] = std::max(slast[in.dst.id], j); }
         else if (in.dst.k == K::PV) pv_written[in.dst.id] = 1;
     }
-    Pools pools = pools_for(loose);
+    Pools pools = pools_for(loose, vgpr_limit);
     std::vector<char> safe_reg(256, 0), pool_reg(256, 0);
     for (int r : pools.v_safe) safe_reg[r] = pool_reg[r] = 1;
     for (int r : pools.v_unsafe) pool_reg[r] = 1;
@@ -879,7 +880,7 @@ void insert_wait_states(std::vector<Inst>& code, int* nops)
 
 }  // namespace
 
-IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text)
+IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text, int vgpr_limit)
 {
     IntervalCode g;
     if (!cl || len < 2 || kind < IW_FIRST || kind > IW_BELOW_GUARDED) return g;
@@ -1086,7 +1087,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             }
         }
         int mv = 0, ms = 0;
-        if (!allocate(code, e.nv, e.ns, loose, &mv, &ms)) {
+        if (!allocate(code, e.nv, e.ns, loose, vgpr_limit, &mv, &ms)) {
             if (window > 0 && w == window && w == 1) return g;
             continue;
         }
@@ -1143,7 +1144,8 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
 extern "C" int mpr_test_interval_gen(const uint64_t* clauses, int32_t len, int32_t kind, int32_t loose, int32_t window, int32_t min_run,
                                      uint32_t* out, int32_t cap, char* text_out, int32_t text_cap, int32_t* info)
 {
-    const mpr::IntervalCode g = mpr::interval_gen_build(clauses, len, kind, loose != 0, window, min_run, text_out != nullptr);
+    /* (loose & 2: the code for the harness with 64 vector registers, as the tile stages run it) */
+    const mpr::IntervalCode g = mpr::interval_gen_build(clauses, len, kind, (loose & 1) != 0, window, min_run, text_out != nullptr, (loose & 2) ? mpr::IGEN_LEAN_VGPRS : 0);
     if (!g.ok) return -1;
     if (info) {
         info[0] = g.instructions; info[1] = g.nops; info[2] = g.window; info[3] = g.max_vgprs; info[4] = g.max_sgpr_pairs;

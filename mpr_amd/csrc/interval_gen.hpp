@@ -53,10 +53,13 @@ struct IntervalCode {
 };
 
 constexpr int IGEN_MAX_CHOICES = 64;
+/* loose walks name vector registers below this only (interval_gen_build: vgpr_limit): the tile stages run them in wavefronts of 80
+ * registers, six to a SIMD instead of four (tile_gen_asm.hpp: tile_gen_forward2_lean) */
+constexpr int IGEN_LEAN_VGPRS = 64;
 
 /* clauses: head, operations, end (the host copy of a root tape).  loose: see above (false for tapes with asin / acos / atan
  * clauses or a constant divisor outside 2^-100 .. 2^100: ok == false).  window: clauses the scheduler may look ahead (0: the
  * default, shrunk until the registers suffice; 1: the tape's own order).  min_run: shortest dead run worth a guard. */
-IntervalCode interval_gen_build(const uint64_t* clauses, int len, int kind, bool loose, int window = 0, int min_run = 3, bool keep_text = false);
+IntervalCode interval_gen_build(const uint64_t* clauses, int len, int kind, bool loose, int window = 0, int min_run = 3, bool keep_text = false, int vgpr_limit = 0);
 
 }  // namespace mpr

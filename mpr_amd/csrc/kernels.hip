@@ -151,11 +151,15 @@ __device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, fl
  * planes would leave room for fewer than 8 wavefronts per CU); LDS then holds the choices and 2 KB of scratch */
 /* GEN (with VS = 24): every tile of the launch walks the ROOT tape, whose walks exist as generated code (tile_gen.hpp,
  * TileStageArgs::gen_fwd / gen_bwd): a frame's first stage */
-template <int DIM, bool ASM, int VS = 0, bool GEN = false>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
-__global__ void __launch_bounds__(64, VS == TI_VS_SMALL_SLOTS ? 4 : VS ? 2 : 0)
+/* LEAN (with GEN; TileStageArgs::lean): a stage that runs LOOSE scheduled code and neither pushes nor measures — 80 vector registers
+ * instead of 128, six wavefronts per SIMD instead of four: the stage is bound by what its few wavefronts leave idle, not by issue */
+template <int DIM, bool ASM, int VS = 0, bool GEN = false, bool LEAN = false>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
+__global__ void __launch_bounds__(64, LEAN ? 6 : VS == TI_VS_SMALL_SLOTS ? 4 : VS ? 2 : 0)
 k_eval_tiles(TileStageArgs a)
 {
     static_assert(!GEN || (ASM && VS == TI_VS_SMALL_SLOTS), "generated code runs on the small register slot file");
+    static_assert(!LEAN || GEN, "the lean kernel runs generated code only");
+    if (!LEAN && a.only_flagged && !a.only_flagged[blockIdx.x]) return;      /* the launch behind a lean one: the wavefronts it left */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const size_t planes_bytes = VS ? 0 : (size_t)a.nslots * 512;
     float2* const slots = reinterpret_cast<float2*>(smem);                       /* [nslots][64] */
@@ -189,6 +193,7 @@ k_eval_tiles(TileStageArgs a)
     const uint64_t alive_mask = ballot(alive);
     if (alive_mask == 0) {
         if (GEN && a.self_info && valid) a.self_info[(size_t)gidx * SKIP0_INFO_U64 + 2] = SKIP0_UNSEEN;
+        if (LEAN && lane == 0) a.redo_flags[blockIdx.x] = 0;
         return;
     }
     const int leader = __ffsll((long long)alive_mask) - 1;
@@ -199,7 +204,11 @@ k_eval_tiles(TileStageArgs a)
     const bool sampled = a.len_stats && ((unsigned)((int)blockIdx.x - a.measure_at[0]) < (unsigned)a.measure_len ||
                                          (unsigned)((int)blockIdx.x - a.measure_at[1]) < (unsigned)a.measure_len);
     const bool gen_wave = GEN && !(a.gen_parent && sampled && !a.gen_bwd_full);
-    if (ASM && !gen_wave) first_block = a.tape_ro[tape + 1 + lane];
+    if (LEAN && !gen_wave) {                         /* a group of the sample walks its parent's tape: the launch behind this one */
+        if (lane == 0) a.redo_flags[blockIdx.x] = 1;
+        return;
+    }
+    if (ASM && !gen_wave && !LEAN) first_block = a.tape_ro[tape + 1 + lane];
 
     /* tile corners in round-to-nearest (reference :91-96) */
     const float t = (float)a.tps;
@@ -236,7 +245,7 @@ k_eval_tiles(TileStageArgs a)
         vz = iv(a.z, a.z);
     }
 
-    const bool prof = (a.debug & 4) && a.counters;      /* development: cycle breakdown per phase */
+    const bool prof = !LEAN && (a.debug & 4) && a.counters;      /* development: cycle breakdown per phase */
     unsigned long long* const pc = a.counters + CNT_COUNT + ((a.debug >> 4) & 3) * 6;
     long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define MPR_PHASE(k) do { if (prof) { const long long tn = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&pc[k], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
@@ -285,7 +294,15 @@ k_eval_tiles(TileStageArgs a)
             }
         }
         gen_keeps = keeps;
-        if (a.debug & 32) {                          /* development: no walk at all, every tile empty (what the rest of the kernel costs) */
+        if (LEAN) {
+            uint32_t redone = 0;
+            tile_gen_forward2_lean(a.gen_fwd2, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi), make_float2(vz.lo, vz.hi),
+                                   &res_vs, chl, chr, above_l, above_r, &redone);
+            redone = __builtin_amdgcn_readfirstlane(redone);
+            if (lane == 0) a.redo_flags[blockIdx.x] = redone ? 1 : 0;
+            if (a.gen_redo_count && lane == 0) atomicAdd(a.gen_redo_count + (redone ? 1 : 0), 1u);
+            if (redone) return;                      /* nothing has been written yet: the launch behind this one takes these tiles */
+        } else if (a.debug & 32) {                          /* development: no walk at all, every tile empty (what the rest of the kernel costs) */
             res_vs = make_float2(1.0f, 2.0f);
         } else if (a.gen_fwd2) {
             uint32_t redone = 0;
@@ -316,7 +333,7 @@ k_eval_tiles(TileStageArgs a)
                 if (lane == 0) choices[j] = make_ulonglong2(m1, m2);
             }
         }
-    } else if (ASM) {
+    } else if (ASM && !LEAN) {
         const TileInterpResult ir =
             VS ? tile_interp_asm_vgpr<(VS ? VS : TI_VS_MAX_SLOTS)>(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, a.choice_cap, &first_block,
                                       2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
@@ -329,7 +346,7 @@ k_eval_tiles(TileStageArgs a)
         nclauses = ir.words - 1;
         end_index = ir.end_index;
         d = tro[end_index];
-    } else {
+    } else if (!LEAN) {
         int base = tape + 1;
         uint64_t blk = tro[base + lane];
         int j = 0;
@@ -469,7 +486,7 @@ k_eval_tiles(TileStageArgs a)
     int bwd_words = 0;
     int kept_minmax = 0;              /* min / max words some lane kept undecided: bounds the choices of the pushed tapes */
     bool overflow = false;
-    if (live != 0) {
+    if (!LEAN && live != 0) {
         /* ---- tape pushing (reference :323-458) ---- */
         LaneMasks lm = {0, 0, 0, 0, act};
         if (a.nslots > 128) {
@@ -704,10 +721,12 @@ k_eval_tiles(TileStageArgs a)
          * each) or, for an ambiguous tile that did not push one, this very tape again */
         int need = kept_minmax;
         if (ballot(ambiguous && !(push && !overflow)) != 0) need = max(need, nchoices_fwd);
-        if (need > 0 && lane == 0) atomicMax(a.next_choices, need);
+        /* (only a wavefront that raises the maximum writes: 20 000 wavefronts' atomics on ONE word take 8.7 ns each, one after the
+         * other — round 5: that, not the walk, was the duration of every tile stage of many wavefronts) */
+        if (need > 0 && lane == 0 && need > __hip_atomic_load(a.next_choices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.next_choices, need);
     }
     if (prof && lane == 0) atomicAdd(&pc[5], 1ull);
-    if (a.heat) {
+    if (!LEAN && a.heat) {
         /* heatmap frames (reference eval_tiles_i_heatmap, src/context.cu:1622-1632, :1817-1826): the
          * words a tile walked forward (terminator excluded) spread over its xy footprint, then the
          * words of its backward walk the same way.  The wave splats one tile at a time so that the
@@ -731,7 +750,7 @@ k_eval_tiles(TileStageArgs a)
             }
         }
     }
-    if (a.counters) {
+    if (!LEAN && a.counters) {
         if (lane == 0) {
             atomicAdd((unsigned long long*)&a.counters[CNT_FWD], (unsigned long long)fwd_words);
             atomicAdd((unsigned long long*)&a.counters[CNT_BWD], (unsigned long long)bwd_words);
@@ -1486,6 +1505,10 @@ bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
     if (a.gen_fwd && tile_stage_gen_possible(a.nslots, a.pool_cap, a.compiled_walk, a.vgpr_slots, a.debug) &&
         ((a.gen_bwd_full || a.gen_forward_only) ? true : a.gen_parent ? a.no_push : !a.groups)) {
         const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
+        if (a.lean && dim == 3) {
+            hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true, true>), dim3(groups), dim3(64), lds_gen, s, a);
+            return true;
+        }
         if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
         else hipLaunchKernelGGL((k_eval_tiles<2, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);
         return true;

@@ -84,6 +84,11 @@ struct TileStageArgs {
     const uint32_t* gen_fwd2 = nullptr;        /* round 5: the scheduled forward walk this stage runs (interval_gen.hpp: the kind the stage needs, loose or
                                                 * exact) and the exact walk of the same kind a loose one falls back on (null: gen_fwd's code and harness) */
     const uint32_t* gen_fwd2_exact = nullptr;
+    bool lean = false;                         /* run as k_eval_tiles<.., LEAN>: gen_fwd2 is loose code for 64 vector registers, the stage neither pushes nor
+                                                * measures, six wavefronts per SIMD.  A wavefront whose walk asks for the exact code (or that belongs to the
+                                                * stage's sample) only raises redo_flags[its workgroup]: a second launch (only_flagged) runs those */
+    unsigned char* redo_flags = nullptr;
+    const unsigned char* only_flagged = nullptr;
     unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
     bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened
                                           * by their error bound, instead of the correctly rounded ones (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */

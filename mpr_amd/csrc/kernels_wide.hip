@@ -221,7 +221,9 @@ k_eval_tiles_wide(WideStageArgs w)
     uint32_t* __restrict__ const leave = w.bits_out ? w.bits_out + (size_t)gidx * w.wpt : nullptr;
     if (!(sh[1] == 1 && sh[0] != 0)) {             /* only ambiguous tiles that chose a side shorten their tape */
         /* an ambiguous tile that keeps its tape: the next stage needs room for all of its choices */
-        if (sh[1] == 1 && tid == 0 && a.next_choices && a.choice_cap > 0) atomicMax(a.next_choices, a.choice_cap);
+        if (sh[1] == 1 && tid == 0 && a.next_choices && a.choice_cap > 0 &&
+            a.choice_cap > __hip_atomic_load(a.next_choices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))       /* (kernels.hip: one word, many writers) */
+            atomicMax(a.next_choices, a.choice_cap);
         if (sh[1] == 1 && leave) {                 /* ... and its children inherit what it inherited */
             for (int k = tid; k < w.wpt; k += nt) leave[k] = inherited ? inherited[k] : 0x55555555u;
         }
@@ -355,7 +357,7 @@ k_eval_tiles_wide(WideStageArgs w)
         if (!ok && a.counters) a.counters[CNT_OVERFLOW] = 1;
         if (a.next_choices) {
             const int need = ok ? sh[1036] : a.choice_cap;      /* pool exhausted: the tile keeps the root tape */
-            if (need > 0) atomicMax(a.next_choices, need);
+            if (need > 0 && need > __hip_atomic_load(a.next_choices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.next_choices, need);
         }
     }
     __syncthreads();

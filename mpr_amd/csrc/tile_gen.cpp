@@ -699,7 +699,7 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     if (const char* e = getenv("MPR_IGEN_WINDOW")) window = atoi(e);
     for (int kind = 0; kind < 3; ++kind)
         for (int loose = 0; loose < 2; ++loose) {
-            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window);
+            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window, 3, false, loose ? IGEN_LEAN_VGPRS : 0);
             if (!ic.ok) continue;
             c->iw_at[kind][loose] = (int)c->words.size();
             c->iw_dw[kind][loose] = (int)ic.words.size();

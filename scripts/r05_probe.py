@@ -32,6 +32,7 @@ def run(model, S, frames, sched, reference=False):
     m.lib().mpr_debug_redo_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     m.lib().mpr_debug_redo_counts(ctx._h, out)
     ctx.close()
+    os.environ.pop("MPR_DEBUG_REDO", None)          # (its counter is one word every wavefront adds to: 9 ns each, one after the other)
     ctx = m.Context(S)
     for _ in range(10):
         ctx.render3D(tape, T)

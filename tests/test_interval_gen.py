@@ -30,7 +30,8 @@ def generate(mpr, words, kind, loose, window=0, min_run=3):
     buf = (ctypes.c_uint32 * 400000)()
     txt = ctypes.create_string_buffer(8_000_000)
     info = (ctypes.c_int32 * 8)()
-    n = f(arr.ctypes.data, len(arr), kind, int(loose), window, min_run, buf, 400000, txt, 8_000_000, info)
+    # (loose = 3: loose code for the harness with 64 vector registers, as the tile stages run it)
+    n = f(arr.ctypes.data, len(arr), kind, 3 if loose else 0, window, min_run, buf, 400000, txt, 8_000_000, info)
     if n < 0:
         return None
     names = ["instructions", "nops", "window", "max_vgprs", "max_sgpr_pairs", "nchoices", "est_cycles"]
@@ -328,11 +329,13 @@ def test_the_schedule_is_shorter_than_the_tape_order(mpr, tapes):
         scheduled = generate(mpr, words, FIRST, loose)[2]
         assert scheduled["window"] > 1
         assert scheduled["est_cycles"] < 0.8 * in_order["est_cycles"]
-        assert scheduled["max_vgprs"] <= (108 if loose else 96)
+        assert scheduled["max_vgprs"] <= (54 if loose else 96)
     # the loose walk: no calls, no branches but the redo at the end, a third of the instructions of round 4's walk
     lines = generate(mpr, words, FIRST, True)[1]
     assert not any(l.startswith("s_swappc") for l in lines)
     assert sum(l.startswith("s_cbranch") for l in lines) == 1
     assert len(lines) < 2700
+    # ... and no vector register beyond v63: the kernel around it runs six wavefronts per SIMD (interval_gen.hpp: IGEN_LEAN_VGPRS)
+    assert max(int(r) for l in lines for r in re.findall(r"\bv(\d+)", l)) <= 63
     # tapes the loose arithmetic does not take (asin / acos / atan: the exact routines only)
     assert generate(mpr, [int(w) for w in tapes("trig").data], FIRST, True) is None
