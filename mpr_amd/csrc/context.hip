@@ -1535,13 +1535,11 @@ static int frame_float_pass(Frame& f)
             rc = jit_prepare(c, tape, dim, nslots, gf, &jp);
             if (rc) return rc;
             if (jp.ok && gf) {
-                if (!c->vox_counters) HIP_TRY(hipMalloc((void**)&c->vox_counters, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int)));
-                HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
                 mprk::VoxelArgs gv = v;
                 gv.tiles = c->tiles[group_stage];
                 gv.count = group_count;
                 mprk::launch_eval_voxels_jit(s, dim, gv, c->jit_code, (uint32_t)jp.region, (int)jp.slot_dw, (int)jp.nslot, jp.grid, (int)tape->clauses.size(), c->groups,
-                                             c->choice_masks, group_cap, c->vox_counters, c->group_list, jp.always_inv);
+                                             c->choice_masks, group_cap, c->num_active + 7, c->group_list, jp.always_inv);
                 jitted = true;
             } else if (jp.ok && !group_form && (brute || c->voxel_jit_tiles)) {
                 mprk::launch_eval_voxels_jit(s, dim, v, c->jit_code, (uint32_t)jp.region, (int)jp.slot_dw, 1, jp.grid, (int)tape->clauses.size(), nullptr,

@@ -809,9 +809,6 @@ struct JitVoxel {
     }
 };
 
-/* work counters of the float pass's persistent kernels (k_eval_voxels_gen below explains them) */
-constexpr int VG_RUN = 4, VG_LISTS = 8, VG_COUNTER_STRIDE = 64;      /* (ints between counters; VG_RUN: the default of GenVoxelArgs::run) */
-
 struct JitVoxelArgs {
     VoxelArgs v;               /* tile form: the smallest tiles; group form: the LAST tile stage's list, after its compaction */
     uint32_t* code;            /* executable; one region per wavefront (tile form) / workgroup (group form) */
@@ -821,8 +818,7 @@ struct JitVoxelArgs {
     const GroupInfo* groups;   /* group form: the tape each group of 64 siblings walked, and their min / max decisions */
     const ulonglong2* choice_masks;
     int choice_cap;
-    int* group_counter;        /* group form: VG_LISTS counters, VG_COUNTER_STRIDE ints apart: the next entry of group_list (of those congruent to the
-                                * counter's number) to hand out; zero when the kernel starts */
+    int* group_counter;        /* group form: the next entry of group_list to hand out (zero at the start of the frame) */
     const int* group_list;     /* group form: the groups with a surviving tile, in list order; [number of groups] = how many */
     int always_invalidate;     /* group form: s_icache_inv after every translation, not once per trip round the ring of code slots
                                 * (context.hip: slots closer than the validated 4 KB, a device other than gfx950, MPR_VOXEL_JIT=3) */
@@ -910,25 +906,10 @@ k_eval_voxels_jit_groups(JitVoxelArgs j)
      * kernel's duration to a tail of long workgroups — and the order is what lets the groups behind a surface find it
      * already drawn (handing out four at a time cost bear 30 %) */
     const int nlisted = j.group_list[ngroups];
-    /* (not on ONE word: same-address atomics take about 9 ns each, one after the other — architecture 2048^3 hands out 30 000 groups;
-     * the listed groups are dealt round robin to VG_LISTS counters as the tiles of k_eval_voxels_gen are, round 5) */
-    int turn = 0, list = (int)(blockIdx.x % VG_LISTS);
     for (;;) {
         int g, position = -1, gtape, nch;
         uint64_t alive;
-        if (threadIdx.x == 0) {
-            int r = nlisted;
-            for (; turn < VG_LISTS; ++turn, list = list + 1 == VG_LISTS ? 0 : list + 1) {
-                const int list_groups = (nlisted - list + VG_LISTS - 1) / VG_LISTS;
-                int q = __hip_atomic_load(j.group_counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (q < list_groups) q = atomicAdd(j.group_counter + list * VG_COUNTER_STRIDE, 1);
-                if (q < list_groups) {
-                    r = q * VG_LISTS + list;
-                    break;
-                }
-            }
-            next_group = r;
-        }
+        if (threadIdx.x == 0) next_group = atomicAdd(j.group_counter, 1);
         __syncthreads();
         const int r = next_group;
         __syncthreads();
@@ -1063,6 +1044,7 @@ struct GenVoxelArgs {
  * 12 ns each on this part, and one per tile (0.58 M for bear 1024^3) made the counter the kernel: 6.7 ms instead of 0.8.  The
  * runs are dealt round robin to VG_LISTS counters a cache line or more apart; a wavefront works through the counter of its own
  * number first and helps with the others when that one runs dry. */
+constexpr int VG_RUN = 4, VG_LISTS = 8, VG_COUNTER_STRIDE = 64;      /* (ints between counters; VG_RUN: the default of GenVoxelArgs::run) */
 template <int DIM>
 __global__ void __launch_bounds__(64, 6)         /* (7 waves per SIMD would take the SGPRs the routines name away: s90..s95) */
 k_eval_voxels_gen(GenVoxelArgs j)
@@ -1074,15 +1056,9 @@ k_eval_voxels_gen(GenVoxelArgs j)
     const int nruns = (a.count + run_len - 1) / run_len;
     for (int turn = 0; turn < VG_LISTS; ++turn) {
         const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
-        const int list_runs = (nruns - list + VG_LISTS - 1) / VG_LISTS;
         for (;;) {
             int q = 0;
-            if (lane == 0) {
-                /* (a look before the claim: when the frame ends every wavefront asks every list, and 7168 claims on a word that has
-                 * nothing left take their 9 ns one after the other — round 5) */
-                q = __hip_atomic_load(j.tile_counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (q < list_runs) q = atomicAdd(j.tile_counter + list * VG_COUNTER_STRIDE, 1);
-            }
+            if (lane == 0) q = atomicAdd(j.tile_counter + list * VG_COUNTER_STRIDE, 1);
             const int run = __builtin_amdgcn_readfirstlane(q) * VG_LISTS + list;
             if (run >= nruns) break;
             for (int t = run * run_len; t < min(run * run_len + run_len, a.count); ++t) {
