@@ -28,6 +28,7 @@ Rank 0 prints ONE JSON line.  Extra objects on that line:
     python bench.py --all [--out profiles/r03_records.jsonl]     one JSON record per model x size
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -272,8 +273,15 @@ def run_all(args):
             render(ctx)
             per.append((time.perf_counter() - t1) * 1e3)
         mean, std = stats(per)
+        # (a frame that takes many times the others must be seen, and explained: the slowest timed frame, where it
+        # was, and what the context did since it was made — scripts/outlier_probe.py runs 2000 frames per configuration)
+        fstats = (ctypes.c_int64 * 4)()
+        m.lib().mpr_debug_frame_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        m.lib().mpr_debug_frame_stats(ctx._h, fstats)
         b_frame, terms = frame_b_alg(work, S, dim)
         rec = {"model": model, "dim": dim, "size": S, "gpus": 1, "ms_mean": round(mean, 4), "ms_std": round(std, 4),
+               "ms_median": round(float(np.median(per)), 4), "ms_max": round(float(np.max(per)), 4), "slowest_timed_frame": int(np.argmax(per)),
+               "pool_clauses": int(fstats[0]), "pool_growths": int(fstats[1]), "frames_restarted": int(fstats[2]), "skip0_vetoes": int(fstats[3]),
                "mpixel_per_s": round(S * S / (mean * 1e-3) / 1e6, 2), "B_alg_bytes": int(b_frame), "B_alg_terms": terms,
                "roofline_hbm": round(b_frame / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                "roofline_lds": None, "roofline_valu": None,

@@ -759,6 +759,36 @@ def dev_loose_interval(op, first=0, count=1 << 32, device=0, imm=0.0):
     return int(bad.value), int(ex.value), int(tested.value), int(widest.value)
 
 
+def dev_interval_gen_op(op, a_lo, a_hi, b_lo=None, b_hi=None, imm=0.0, loose=False, device=0):
+    """One interval clause through the tile stages' SCHEDULED code (csrc/interval_gen.cpp) on the device, exact or loose:
+    (lo, hi, the lanes' choice 0 / 1 / 2, lanes whose loose walk asks for the exact one)."""
+    a_lo = np.ascontiguousarray(a_lo, dtype=np.float32)
+    a_hi = np.ascontiguousarray(a_hi, dtype=np.float32)
+    b_lo = None if b_lo is None else np.ascontiguousarray(b_lo, dtype=np.float32)
+    b_hi = None if b_hi is None else np.ascontiguousarray(b_hi, dtype=np.float32)
+    lo, hi = np.empty_like(a_lo), np.empty_like(a_lo)
+    ch = np.zeros(a_lo.size, dtype=np.int32)
+    asks = np.zeros(a_lo.size, dtype=np.int32)
+    f = lib().mpr_test_interval_gen_op
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                  ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    _check(f(device, op, int(loose), a_lo.size, _ptr(a_lo), _ptr(a_hi), _ptr(b_lo), _ptr(b_hi), imm, _ptr(lo), _ptr(hi), _ptr(ch), _ptr(asks)))
+    return lo, hi, ch, asks
+
+
+def dev_loose_gen(op, imm=0.0, other=(0.0, 0.0), x_is_rhs=False, first=0, count=1 << 32, device=0):
+    """The LOOSE scheduled code of one clause on the bit patterns [first, first + count) — as [x, x] and as the interval between x
+    and a scrambled copy of its bits; the other operand is the interval `other` — against the exact routine's enclosure:
+    dict(bad, example, tested, asked_for_exact, widest in 2^-24 of the value)."""
+    out = (ctypes.c_uint64 * 5)()
+    f = lib().mpr_test_loose_gen
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    _check(f(device, op, imm, other[0], other[1], int(x_is_rhs), first, count, out))
+    return dict(bad=int(out[0]), example=int(out[1]), tested=int(out[2]), asked_for_exact=int(out[3]), widest=int(out[4]))
+
+
 def dev_sqrt_all(first=0, count=1 << 32, device=0):
     """The float pass's square-root routine on the bit patterns [first, first + count): (mismatches against the correctly
     rounded root, one offending bit pattern)."""

@@ -190,6 +190,11 @@ struct mpr_context {
     uint64_t skip0_veto_serial = 0;    /* the tape whose last verified frame failed: its next frames start at the 64^3 tiles ... */
     int skip0_veto_left = 0;           /* ... this many of them, then one tries again */
     int skip0_veto_span = 64;          /* ... twice as many after every failure in a row */
+    long long frames_restarted = 0;    /* frames that started over (the pool grew, a shortcut's veto, ...): mpr_debug_frame_stats */
+    long long pool_growths = 0;
+    bool pool_grow_pending = false;    /* the last frame's pushes filled more than 3/4 of a pool this context sized itself: it doubles before the next
+                                        * frame starts — not inside a later one whose pushes happen to run over (which tiles a neighbour's fill culls before
+                                        * they push is a matter of timing, the fill level moves by a few per cent from frame to frame): round 5 */
     bool skip0_normals_veto = false;   /* the last frame's normals pass could not take the 64^3 tiles' decisions (frame_normals_pass) */
     long long skip0_vetoes = 0;        /* frames rendered again (mpr_ctx_skip0_vetoes: tests) */
     /* frames that start at the 16^3 tiles, of a tape whose float pass and normals pass run on its root code with records: nobody
@@ -625,6 +630,20 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
     if (len < 2) return mpr::set_error(MPR_ERR_INVALID, "empty tape");
     if (c->frame_pending) HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_pending = false;
+    if (c->pool_auto && c->pool_grow_pending && c->pool_cap < (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) {
+        const long long bigger = std::min<long long>(c->pool_cap * 2, (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK);
+        uint64_t* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, ((size_t)bigger + 128) * sizeof(uint64_t)) == hipSuccess) {
+            (void)hipFree(c->pool);
+            c->pool = fresh;
+            c->pool_cap = bigger;
+            c->tape_serial = 0;
+            ++c->pool_growths;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    c->pool_grow_pending = false;
     if (c->pool_auto && (long long)len + 4096 >= c->pool_cap) {
         /* a pool this context sized itself also grows for the root tape (pushes make it grow later, frame by frame) */
         long long bigger = c->pool_cap;
@@ -1474,10 +1493,12 @@ static int frame_tile_stage(Frame& f, int si)
                 c->pool = fresh;
                 c->pool_cap = bigger;
                 c->tape_serial = 0;                  /* the root tape has to be copied in again */
+                ++c->pool_growths;
                 return FRAME_AGAIN;
             }
             (void)hipGetLastError();                 /* no memory for a larger pool: carry on with the fallback, as the reference would */
         }
+        if (count > 0 && c->pool_auto && (long long)(act3[4] & 0x7FFFFFFF) * 4 > c->pool_cap * 3) c->pool_grow_pending = true;
         const int active = act3[0];
         if (count > 0) stage_choice_cap = std::min(choice_cap, std::max(act3[3], 1));
         if (c->debug_choices) fprintf(stderr, "stage %d: %d tiles, reports %d choices for the next stage (root %d); tapes handed on %d, walked %d\n", si, count, act3[3], choice_cap, act3[1], act3[2]);
@@ -1672,7 +1693,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         int rc = frame_begin(f);
         if (rc) return rc;
         for (int si = f.skip0 ? 1 : 0; si < f.nstages && rc == MPR_OK; ++si) rc = frame_tile_stage(f, si);
-        if (rc == FRAME_AGAIN) continue;
+        if (rc == FRAME_AGAIN) { ++c->frames_restarted; continue; }
         if (rc == FRAME_STOP) return MPR_OK;
         if (rc) return rc;
         c->last.voxel_tiles = f.count;
@@ -1743,6 +1764,17 @@ int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_fr
 int64_t mpr_ctx_skip0_vetoes(const mpr_context* c) { return c ? c->skip0_vetoes : 0; }
 /* development (MPR_DEBUG_REDO=1): wavefronts that ran a scheduled forward walk since the context was made, and how many of them had
  * their loose walk redone on the exact code */
+/* development: {capacity of the tape pool in clauses, times it grew, frames that started over, frames whose start at the 16^3 tiles
+ * was vetoed} since the context was made (scripts/outlier_probe.py) */
+extern "C" int mpr_debug_frame_stats(const mpr_context* c, int64_t out[4])
+{
+    if (!c || !out) return MPR_ERR_INVALID;
+    out[0] = c->pool_cap;
+    out[1] = c->pool_growths;
+    out[2] = c->frames_restarted;
+    out[3] = c->skip0_vetoes;
+    return MPR_OK;
+}
 extern "C" int mpr_debug_redo_counts(mpr_context* c, uint32_t out[2])
 {
     if (!c || !out) return MPR_ERR_INVALID;
@@ -2238,6 +2270,81 @@ int mpr_test_interval_op_asm(int32_t device, int32_t op, int32_t variant, int32_
     HIP_TRY(hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
     if (out_choice) HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+/* ---- one clause through the scheduled interval code on the device (include/mpr_amd.h: mpr_test_interval_gen_op / mpr_test_loose_gen) ---- */
+namespace {
+struct OneClauseCode {
+    uint32_t* code = nullptr;
+    ~OneClauseCode() { free_executable(code); }
+    /* tape {head (1, 2, 3), clause (out 4, lhs 1, rhs 2 where the opcode has one), end (4)} -> installed code */
+    int make(int device, int op, float imm, bool loose)
+    {
+        uint32_t immbits;
+        memcpy(&immbits, &imm, 4);
+        const bool has_l = !(op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_DIV_IMM_RHS || op == MPR_OP_COPY_IMM || op == MPR_OP_COPY_RHS);
+        const bool has_r = op == MPR_OP_ADD_LHS_RHS || op == MPR_OP_MUL_LHS_RHS || op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS ||
+                           op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_SUB_LHS_RHS || op == MPR_OP_DIV_IMM_RHS || op == MPR_OP_DIV_LHS_RHS || op == MPR_OP_COPY_RHS;
+        const uint64_t tape[3] = {mpr_cl_make(0, 1, 2, 3, 0), mpr_cl_make((uint32_t)op, 4, has_l ? 1 : 0, has_r ? 2 : 0, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
+        const mpr::IntervalCode g = mpr::interval_gen_build(tape, 3, mpr::IW_FIRST, loose, 0, 3, false, loose ? mpr::IGEN_LEAN_VGPRS : 0, loose);
+        if (!g.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "the generator does not take this clause");
+        const size_t n = (g.words.size() + 127) & ~(size_t)63;
+        code = static_cast<uint32_t*>(alloc_executable(device, n * sizeof(uint32_t)));
+        if (!code) return mpr::set_error(MPR_ERR_NO_DEVICE, "no executable memory");
+        DevBuf stage;
+        HIP_TRY(stage.alloc(n * sizeof(uint32_t)));
+        std::vector<uint32_t> all(n, 0xBF800000u);
+        std::copy(g.words.begin(), g.words.end(), all.begin());
+        HIP_TRY(hipMemcpy(stage.p, all.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        mprk::launch_install_code(nullptr, code, (const uint32_t*)stage.p, n, std::max(prop.multiProcessorCount, 1));
+        HIP_TRY(hipDeviceSynchronize());
+        return MPR_OK;
+    }
+};
+}  // namespace
+extern "C" int mpr_test_interval_gen_op(int32_t device, int32_t op, int32_t loose, int32_t n, const float* a_lo, const float* a_hi, const float* b_lo,
+                                        const float* b_hi, float imm, float* out_lo, float* out_hi, int32_t* out_choice, int32_t* out_asks_exact)
+{
+    if (n <= 0 || !a_lo || !a_hi || !out_lo || !out_hi || !out_choice || !out_asks_exact) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    OneClauseCode oc;
+    const int rc = oc.make(device, op, imm, loose != 0);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n * 4;
+    DevBuf al, ah, bl, bh, ol, oh, ch, ax;
+    HIP_TRY(al.alloc(bytes)); HIP_TRY(ah.alloc(bytes)); HIP_TRY(bl.alloc(bytes)); HIP_TRY(bh.alloc(bytes));
+    HIP_TRY(ol.alloc(bytes)); HIP_TRY(oh.alloc(bytes)); HIP_TRY(ch.alloc(bytes)); HIP_TRY(ax.alloc(bytes));
+    HIP_TRY(hipMemcpy(al.p, a_lo, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ah.p, a_hi, bytes, hipMemcpyHostToDevice));
+    if (b_lo) HIP_TRY(hipMemcpy(bl.p, b_lo, bytes, hipMemcpyHostToDevice));
+    if (b_hi) HIP_TRY(hipMemcpy(bh.p, b_hi, bytes, hipMemcpyHostToDevice));
+    mprk::launch_test_interval_gen(nullptr, oc.code, loose != 0, n, (float*)al.p, (float*)ah.p, b_lo ? (float*)bl.p : nullptr, b_hi ? (float*)bh.p : nullptr,
+                                   (float*)ol.p, (float*)oh.p, (int*)ch.p, (int*)ax.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_choice, ch.p, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_asks_exact, ax.p, bytes, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+extern "C" int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float other_lo, float other_hi, int32_t x_is_rhs, uint64_t first, uint64_t count,
+                                  uint64_t out[5])
+{
+    if (!out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    OneClauseCode oc;
+    const int rc = oc.make(device, op, imm, true);
+    if (rc) return rc;
+    DevBuf d;
+    HIP_TRY(d.alloc(5 * 8));
+    HIP_TRY(hipMemset(d.p, 0, 5 * 8));
+    mprk::launch_test_loose_gen(nullptr, oc.code, op, imm, other_lo, other_hi, x_is_rhs, first, count, (unsigned long long*)d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d.p, 5 * 8, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
 /* development aid (scripts/walk_cycles.py): mean cycles per scheduled forward walk (interval_gen.hpp) of `clauses`, per wavefront, with

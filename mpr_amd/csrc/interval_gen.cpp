@@ -498,8 +498,12 @@ struct Gen {
         Opnd y1 = op1(Op::V_RCP, B.b);                              /* 1 / b.hi: the lower end */
         Opnd y2 = op1(Op::V_RCP, B.a, 1);                           /* 1 / b.lo */
         const Opnd c = kreg(0x34800000u);
-        IV R; R.a = op3(Op::V_FMA_F32, y1, c, y1, 4, 1);            /* RU(|y| c - y) */
-        R.b = op3(Op::V_FMA_F32, y2, c, y2, 0, 1);                  /* RU(|y| c + y) */
+        /* (a reciprocal below 2^-126 in magnitude — a divisor beyond 2^126 — comes back as zero: 2^-126 either side covers what
+         * was flushed; found by the sweep over every float, tests/test_gpu_primitives.py) */
+        Opnd ra = op3(Op::V_FMA_F32, y1, c, y1, 4, 1);              /* RU(|y| c - y) */
+        Opnd rb = op3(Op::V_FMA_F32, y2, c, y2, 0, 1);              /* RU(|y| c + y) */
+        IV R; R.a = lit2(Op::V_ADD_F32, 0x00800000u, ra);
+        R.b = lit2(Op::V_ADD_F32, 0x00800000u, rb);
         IV q = l_mul_raw(A, R);
         const Opnd inf = kreg(0x7f800000u);
         IV o; o.a = sel(inf, q.a, okm);
@@ -880,7 +884,7 @@ void insert_wait_states(std::vector<Inst>& code, int* nops)
 
 }  // namespace
 
-IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text, int vgpr_limit)
+IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text, int vgpr_limit, bool report_only)
 {
     IntervalCode g;
     if (!cl || len < 2 || kind < IW_FIRST || kind > IW_BELOW_GUARDED) return g;
@@ -1050,16 +1054,20 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
         Opnd m3 = e.op2(Op::V_ADD_F32, m1, m2);
         Opnd big = e.cmp(Op::C_U, m3, m3);                              /* a NaN somewhere */
         e.e(Op::S_OR_B64, PS(S_BAD), PS(S_BAD), big);
-        e.e(Op::S_CMP_LG_U64, NONE(), PS(S_BAD), INT(0));
-        Inst& br = e.e(Op::S_CBRANCH_SCC1, NONE());
-        br.imm = -redo_label - 1;
+        if (!report_only) {                 /* (report_only: the caller reads the lanes that ask for the exact walk from s[40:41]: tests) */
+            e.e(Op::S_CMP_LG_U64, NONE(), PS(S_BAD), INT(0));
+            Inst& br = e.e(Op::S_CBRANCH_SCC1, NONE());
+            br.imm = -redo_label - 1;
+        }
         ++e.clause;
         e.e(Op::V_XOR, PV(R_OUT_LO), Gen::const_src(SIGN), R.a, NONE(), 0, 0, SIGN);
         e.e(Op::V_MOV, PV(R_OUT_HI), R.b);
         e.e(Op::S_SETPC, NONE(), PS(S_RET_CODE));
-        Inst& l = e.e(Op::LABEL, NONE());
-        l.imm = redo_label;
-        e.e(Op::S_SETPC, NONE(), PS(S_REDO));
+        if (!report_only) {
+            Inst& l = e.e(Op::LABEL, NONE());
+            l.imm = redo_label;
+            e.e(Op::S_SETPC, NONE(), PS(S_REDO));
+        }
     } else {
         e.e(Op::V_MOV, PV(R_OUT_LO), R.a);
         e.e(Op::V_MOV, PV(R_OUT_HI), R.b);
@@ -1144,8 +1152,8 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
 extern "C" int mpr_test_interval_gen(const uint64_t* clauses, int32_t len, int32_t kind, int32_t loose, int32_t window, int32_t min_run,
                                      uint32_t* out, int32_t cap, char* text_out, int32_t text_cap, int32_t* info)
 {
-    /* (loose & 2: the code for the harness with 64 vector registers, as the tile stages run it) */
-    const mpr::IntervalCode g = mpr::interval_gen_build(clauses, len, kind, (loose & 1) != 0, window, min_run, text_out != nullptr, (loose & 2) ? mpr::IGEN_LEAN_VGPRS : 0);
+    /* (loose & 2: the code for the harness with 64 vector registers, as the tile stages run it; & 4: report_only) */
+    const mpr::IntervalCode g = mpr::interval_gen_build(clauses, len, kind, (loose & 1) != 0, window, min_run, text_out != nullptr, (loose & 2) ? mpr::IGEN_LEAN_VGPRS : 0, (loose & 4) != 0);
     if (!g.ok) return -1;
     if (info) {
         info[0] = g.instructions; info[1] = g.nops; info[2] = g.window; info[3] = g.max_vgprs; info[4] = g.max_sgpr_pairs;

@@ -59,7 +59,9 @@ constexpr int IGEN_LEAN_VGPRS = 64;
 
 /* clauses: head, operations, end (the host copy of a root tape).  loose: see above (false for tapes with asin / acos / atan
  * clauses or a constant divisor outside 2^-100 .. 2^100: ok == false).  window: clauses the scheduler may look ahead (0: the
- * default, shrunk until the registers suffice; 1: the tape's own order).  min_run: shortest dead run worth a guard. */
-IntervalCode interval_gen_build(const uint64_t* clauses, int len, int kind, bool loose, int window = 0, int min_run = 3, bool keep_text = false, int vgpr_limit = 0);
+ * default, shrunk until the registers suffice; 1: the tape's own order).  min_run: shortest dead run worth a guard.
+ * report_only (loose, tests): no branch to the redo entry — the code returns with the lanes that ask for the exact walk in s[40:41]. */
+IntervalCode interval_gen_build(const uint64_t* clauses, int len, int kind, bool loose, int window = 0, int min_run = 3, bool keep_text = false, int vgpr_limit = 0,
+                                bool report_only = false);
 
 }  // namespace mpr

@@ -1271,6 +1271,106 @@ k_debug_interp_cycles(const uint64_t* tape, int reps, long long* out)
         if (lane == 0) out[r] = (t1 - t0) + (ir.words & 0);
     }
 }
+/* ---- the scheduled interval code on the chip, one clause at a time (tests/test_gpu_primitives.py) ----
+ * code: the walk of the tape {head (slots 1, 2, 3), the clause (lhs = slot 1, rhs = slot 2, out = slot 4), end}; loose: code for the lean
+ * harness that only REPORTS the lanes that ask for the exact walk (interval_gen.hpp: report_only); 64 operand pairs per wavefront */
+__global__ void __launch_bounds__(64, 4)
+k_test_interval_gen(const uint32_t* code, int loose, int n, const float* a_lo, const float* a_hi, const float* b_lo, const float* b_hi,
+                    float* out_lo, float* out_hi, int* choice, int* asks_exact)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gen_io[4096];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    float al = 0, ah = 0, bl = 0, bh = 0, e = 0, f = 0;
+    if (i < n) {
+        al = a_lo[i]; ah = a_hi[i];
+        if (b_lo) { bl = b_lo[i]; bh = b_hi[i]; }
+    }
+    round_up_begin(al, ah, bl, bh, e, f);
+    float2 res = make_float2(0.0f, 0.0f);
+    uint32_t chl[2] = {0, 0}, chr[2] = {0, 0}, redone = 0, bad = 0;
+    if (loose) tile_gen_forward2_lean(code, gen_io, lane, make_float2(al, ah), make_float2(bl, bh), make_float2(e, f), &res, chl, chr, 0, 0, &redone, &bad);
+    else tile_gen_forward2(code, nullptr, gen_io, lane, make_float2(al, ah), make_float2(bl, bh), make_float2(e, f), &res, chl, chr, 0, 0);
+    round_nearest_begin();
+    if (i < n) {
+        out_lo[i] = res.x;
+        out_hi[i] = res.y;
+        choice[i] = (chl[0] & 1u) ? 1 : (chr[0] & 1u) ? 2 : 0;
+        asks_exact[i] = (int)bad;
+    }
+}
+void launch_test_interval_gen(hipStream_t s, const uint32_t* code, int loose, int n, const float* a_lo, const float* a_hi, const float* b_lo, const float* b_hi,
+                              float* out_lo, float* out_hi, int* choice, int* asks_exact)
+{
+    hipLaunchKernelGGL(k_test_interval_gen, dim3((n + 63) / 64), dim3(64), 0, s, code, loose, n, a_lo, a_hi, b_lo, b_hi, out_lo, out_hi, choice, asks_exact);
+}
+/* The LOOSE code of one clause on every float of a range of bit patterns — as the degenerate interval [x, x] and as the interval
+ * between x and a scrambled copy of its bits — against the exact routine's enclosure (device_math.hpp), with the other operand
+ * [imm_lo, imm_hi]: out[0] = ends that do NOT enclose where the code did not ask for the exact walk (must be 0), out[1] = one such bit
+ * pattern, out[2] = operands tested, out[3] = operands that asked for the exact walk, out[4] = the largest width met, in units of
+ * 2^-24 of max(|value|, 1).  The soundness of the loose frames rests on what the hardware's v_exp_f32 / v_log_f32 / v_sqrt_f32 /
+ * v_rcp_f32 return: this is where that is checked, on the instructions themselves. */
+__global__ void __launch_bounds__(64, 6)
+k_test_loose_gen(const uint32_t* code, int op, float imm, float other_lo, float other_hi, int x_is_rhs, unsigned long long first,
+                 unsigned long long count, unsigned long long* out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gen_io[4096];
+    const int lane = threadIdx.x;
+    float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
+    round_up_begin(d0, d1, d2, d3, d4, d5);
+    unsigned long long bad = 0, tested = 0, example = 0, widest = 0, asked = 0;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 64; base < count; base += (unsigned long long)gridDim.x * 64) {
+        const uint32_t bits = (uint32_t)(first + base + lane);
+        const bool mine = base + lane < count;
+        const float x = mpr_u2f(bits);
+        const uint32_t bits2 = (bits * 2654435761u) ^ 0x9E3779B9u;
+        const float x2 = mpr_u2f(bits2);
+        for (int variant = 0; variant < 2; ++variant) {
+            float in_lo = variant == 0 ? x : (x < x2 ? x : x2), in_hi = variant == 0 ? x : (x < x2 ? x2 : x);
+            const bool usable = mine && in_lo == in_lo && in_hi == in_hi;       /* (NaN ends: no interval) */
+            if (!usable) { in_lo = 1.0f; in_hi = 2.0f; }
+            const ival X = iv(in_lo, in_hi), O = iv(other_lo, other_hi);
+            int c = 0;
+            const ival exact = interval_clause((uint32_t)op, x_is_rhs ? O : X, x_is_rhs ? X : O, imm, c);
+            float2 res = make_float2(0.0f, 0.0f);
+            uint32_t chl[2] = {0, 0}, chr[2] = {0, 0}, redone = 0, asks = 0;
+            tile_gen_forward2_lean(code, gen_io, lane, x_is_rhs ? make_float2(other_lo, other_hi) : make_float2(in_lo, in_hi),
+                                   x_is_rhs ? make_float2(in_lo, in_hi) : make_float2(other_lo, other_hi), make_float2(0.0f, 0.0f), &res, chl, chr, 0, 0,
+                                   &redone, &asks);
+            if (!usable) continue;
+            ++tested;
+            if (asks) { ++asked; continue; }
+            const float lo = res.x, hi = res.y;
+            /* encloses; an end the exact routine leaves a NaN (an operation without a value there) is outside this test: the loose
+             * walk must have asked for the exact one */
+            const bool lo_ok = exact.lo == exact.lo && lo <= exact.lo, hi_ok = exact.hi == exact.hi && hi >= exact.hi;
+            /* a decision the loose walk makes the exact one must make too */
+            const int lc = (chl[0] & 1u) ? 1 : (chr[0] & 1u) ? 2 : 0;
+            if (!(lo_ok && hi_ok) || (lc != 0 && lc != c)) {
+                ++bad;
+                example = bits;
+            }
+            if (variant == 1 || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f || lo - lo != 0.0f || hi - hi != 0.0f) continue;
+            const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo) - ((double)exact.hi - (double)exact.lo);
+            const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;
+            const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? (w > 0 ? w / scale * 16777216.0 : 0.0) : 1e15);
+            if (units > widest) widest = units;
+        }
+    }
+    round_nearest_begin();
+    if (bad) {
+        atomicAdd(&out[0], bad);
+        out[1] = example;
+    }
+    atomicAdd(&out[2], tested);
+    atomicAdd(&out[3], asked);
+    atomicMax(&out[4], widest);
+}
+void launch_test_loose_gen(hipStream_t s, const uint32_t* code, int op, float imm, float other_lo, float other_hi, int x_is_rhs, unsigned long long first,
+                           unsigned long long count, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_test_loose_gen, dim3(6144), dim3(64), 0, s, code, op, imm, other_lo, other_hi, x_is_rhs, first, count, out);
+}
 /* development (scripts/walk_cycles.py): cycles a wavefront needs for one scheduled forward walk (tile_gen_forward2: the harness's LDS traffic
  * included) on tiles of a 16^3-stage-like grid; out[wave] = mean over reps.  code == null: the harness alone. */
 __global__ void __launch_bounds__(64, 4)

@@ -398,7 +398,7 @@ DEV void tile_gen_forward2(const uint32_t* code, const uint32_t* code_exact, uns
  * redone here: *redone = 1 and the results are garbage (k_eval_tiles<.., LEAN> hands the wavefront's tiles to the launch behind it). */
 DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, int lane, float2 x, float2 y, float2 z,
                                 float2* res, uint32_t* chl, uint32_t* chr, unsigned long long decided_lhs, unsigned long long decided_rhs,
-                                uint32_t* redone)
+                                uint32_t* redone, uint32_t* bad_lane = nullptr)
 {
     float* const io = reinterpret_cast<float*>(smem_io);
     io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
@@ -429,6 +429,8 @@ DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, in
         "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
         "ds_write_b32 v32, v56 offset:2048\n ds_write_b32 v32, v57 offset:2304\n"
         "ds_write_b32 v32, v58 offset:2560\n ds_write_b32 v32, v59 offset:2816\n"
+        "v_cndmask_b32 v54, 0, 1, s[40:41]\n"             /* (the lanes that ask for the exact walk, of code that only reports them: tests) */
+        "ds_write_b32 v32, v54 offset:3072\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_branch L_end_%=\n"
         "L_redo_%=:\n"
@@ -457,6 +459,7 @@ DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, in
     chr[0] = iw[640 + lane];
     chr[1] = iw[704 + lane];
     *redone = iw[968];
+    if (bad_lane) *bad_lane = iw[768 + lane];
 }
 
 /* The backward walk.  Per lane in: active (bit = slot: the end clause's out slot for a pushing lane, 0 otherwise), pos = pool

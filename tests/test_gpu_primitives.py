@@ -243,3 +243,76 @@ def test_square_root_routine_on_every_float(mpr):
     2^-96 up), scaled path (tiny and subnormal), zeros, infinities, negative numbers, NaNs."""
     bad, example = mpr.dev_sqrt_all(0, 1 << 32)
     assert bad == 0, "sqrt differs from the correctly rounded root for %d inputs, e.g. bits 0x%08x" % (bad, example)
+
+
+# ---- the tile stages' scheduled interval code (csrc/interval_gen.cpp), one clause at a time, on the chip ----
+@pytest.mark.parametrize("kind", ["unit", "wide", "special", "bits"])
+@pytest.mark.parametrize("opname", INTERVAL_OPS)
+def test_scheduled_exact_interval_code_bit_exact(mpr, orc, opname, kind):
+    """the EXACT code: the interpreter's routines in line on renamed registers (square, abs, the product's sign-case table, min / max
+    with the lanes' decisions) and the calls it keeps (sqrt, div, exp, log, asin, acos, atan) — bounds and choices, every operand class"""
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32((opname + kind + "gen").encode()))
+    a_lo, a_hi = gen_intervals(rng, N // 4, kind)
+    b_lo, b_hi = gen_intervals(rng, N // 4, kind)
+    for imm in (0.75, -1.25, 0.0):
+        g_lo, g_hi, g_ch, _ = mpr.dev_interval_gen_op(op, a_lo, a_hi, b_lo, b_hi, imm)
+        o_lo, o_hi, o_ch = orc.interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
+        ok = same_bits(g_lo, o_lo) & same_bits(g_hi, o_hi) & (g_ch == o_ch)
+        bad = np.flatnonzero(~ok)
+        assert bad.size == 0, (opname, kind, imm, bad.size,
+                               [(a_lo[i], a_hi[i], b_lo[i], b_hi[i], g_lo[i], g_hi[i], o_lo[i], o_hi[i], g_ch[i], o_ch[i]) for i in bad[:5]])
+
+
+LOOSE_OPS = [o for o in INTERVAL_OPS if o not in ("ASIN_LHS", "ACOS_LHS", "ATAN_LHS")]
+
+
+@pytest.mark.parametrize("kind", ["unit", "wide"])
+@pytest.mark.parametrize("opname", LOOSE_OPS)
+def test_scheduled_loose_interval_code_encloses(mpr, orc, opname, kind):
+    """the LOOSE code on ordered intervals: wherever a lane does not ask for the exact walk its result encloses the oracle's and it
+    decides nothing the oracle does not; ordinary operands never ask"""
+    op = mpr.OP[opname]
+    rng = np.random.default_rng(zlib.crc32((opname + kind + "loose").encode()))
+    a_lo, a_hi = gen_intervals(rng, N // 4, kind)
+    b_lo, b_hi = gen_intervals(rng, N // 4, kind)
+    for imm in (0.75, -1.25, 3.0e-3):
+        g_lo, g_hi, g_ch, asks = mpr.dev_interval_gen_op(op, a_lo, a_hi, b_lo, b_hi, imm, loose=True)
+        o_lo, o_hi, o_ch = orc.interval_op(op, a_lo, a_hi, b_lo, b_hi, imm)
+        ok = asks == 0
+        with np.errstate(invalid="ignore"):
+            encl = (g_lo <= o_lo) & (g_hi >= o_hi)
+        bad = np.flatnonzero(ok & ~encl)
+        assert bad.size == 0, (opname, kind, imm, bad.size, [(a_lo[i], a_hi[i], b_lo[i], b_hi[i], g_lo[i], g_hi[i], o_lo[i], o_hi[i]) for i in bad[:5]])
+        assert not (ok & (g_ch != 0) & (g_ch != o_ch)).any(), opname
+        if opname not in ("SQRT_LHS", "LOG_LHS", "MUL_LHS_RHS", "DIV_LHS_RHS", "DIV_IMM_RHS"):
+            assert ok.all(), (opname, int((~ok).sum()))             # (no domain to leave, no 0 x inf to meet)
+        else:
+            assert ok.mean() > 0.15, (opname, ok.mean())
+
+
+@pytest.mark.parametrize("case", ["EXP_LHS", "LOG_LHS", "SQRT_LHS", "SQUARE_LHS", "ABS_LHS", "DIV_LHS_IMM:3.7", "DIV_LHS_IMM:-0.0125", "DIV_LHS_IMM:1.5e6",
+                                  "MUL_LHS_IMM:-2.5", "ADD_LHS_IMM:0.3", "MUL_LHS_RHS:-2.5:3.0", "MUL_LHS_RHS:0.25:7.0", "DIV_LHS_RHS/lhs:1.5:4.0",
+                                  "DIV_LHS_RHS/rhs:-2.0:5.0", "MIN_LHS_RHS:-1.0:2.0", "MAX_LHS_RHS:-1.0:2.0", "ADD_LHS_RHS:-3.0:1.0e30", "SUB_LHS_RHS:-1.0:2.0"])
+def test_loose_interval_code_on_every_float(mpr, case):
+    """Every float (all 2^32 bit patterns, as [x, x] and as one end of a wide interval) through the loose code of one clause on the
+    chip, against the exact routine's enclosure: NO end that fails to enclose wherever the code does not ask for the exact walk.  This
+    is the check of what the hardware's v_exp_f32 / v_log_f32 / v_sqrt_f32 / v_rcp_f32 return that the loose frames' soundness rests on
+    (csrc/interval_gen.cpp: two ulps assumed); and the results are not much wider than the exact ones."""
+    name, _, rest = case.partition(":")
+    name, _, side = name.partition("/")
+    args = [float(v) for v in rest.split(":")] if rest else []
+    op = mpr.OP[name]
+    kw = {}
+    if name.endswith("_IMM"):
+        kw["imm"] = args[0]
+    elif len(args) == 2:
+        kw["other"] = (args[0], args[1])
+        kw["x_is_rhs"] = side == "lhs"           # ".../lhs: the OTHER operand is the lhs": x is the divisor
+    r = mpr.dev_loose_gen(op, **kw)
+    assert r["tested"] > (1 << 32) and r["bad"] == 0, (case, r, hex(r["example"]))
+    # an operand outside the operation's domain asks for the exact walk, nothing else does
+    if name in ("EXP_LHS", "SQUARE_LHS", "ABS_LHS", "MUL_LHS_IMM", "ADD_LHS_IMM", "DIV_LHS_IMM", "MIN_LHS_RHS", "MAX_LHS_RHS", "SUB_LHS_RHS"):
+        assert r["asked_for_exact"] <= 4, (case, r)          # ([inf, inf] and [-inf, -inf]: no width)
+    # widths: 2^-24 units of the value beyond the exact enclosure's (exp: (|t| + 4) 2^-23 either side at t up to 128 -> a few hundred)
+    assert r["widest"] < (1 << 12), (case, r)
