@@ -317,13 +317,18 @@ int mpr_test_float_op_asm(int32_t device, int32_t op, int32_t variant, int32_t n
 /* the square-root routine of the float interpreters and of the generated code on the bit patterns [first, first + count): the
  * number of results that are not the correctly rounded root (NaN for NaN counts as equal), and one such input */
 int mpr_test_sqrt_all(int32_t device, uint64_t first, uint64_t count, uint64_t* mismatches, uint32_t* example);
-/* the tile stages' loose enclosures of frames nobody reads (the hardware's v_exp_f32 / v_log_f32 / v_sqrt_f32 / v_rcp_f32, widened
- * by their error bound: csrc/tile_gen_asm.hpp) on every bit pattern of [first, first + count) that lies in their domain, as the
- * interval [x, x], against the correctly rounded enclosure: ends that fail to enclose it (must be 0), one such pattern, operands
- * tested, the widest result in units of 2^-24 of max(|value|, 1).  op: MPR_OP_EXP_LHS, MPR_OP_LOG_LHS, MPR_OP_SQRT_LHS,
- * MPR_OP_DIV_LHS_IMM (x / imm), or 100: the reciprocal's bounds of the division by a constant, 1 / x in [y_dn, y_up], exactly */
-int mpr_test_loose_interval(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t* not_enclosing, uint32_t* example,
-                            uint64_t* tested, uint64_t* widest_2m24);
+/* one interval clause through the tile stages' scheduled code (csrc/interval_gen.cpp) on the device — exact (loose = 0) or loose:
+ * bounds, the lanes' choice at a min / max clause, and (loose) the lanes whose walk asks for the exact one */
+int mpr_test_interval_gen_op(int32_t device, int32_t op, int32_t loose, int32_t n, const float* a_lo, const float* a_hi, const float* b_lo,
+                             const float* b_hi, float imm, float* out_lo, float* out_hi, int32_t* out_choice, int32_t* out_asks_exact);
+/* the LOOSE code of one clause (the hardware's v_exp_f32 / v_log_f32 / v_sqrt_f32 / v_rcp_f32 widened by their error bound, four-
+ * products multiplication, constants' reciprocals rounded on the host) on every bit pattern x of [first, first + count), as the
+ * interval [x, x] and as one end of an interval to a scrambled copy of its bits, the other operand being [other_lo, other_hi] (x is
+ * the rhs when x_is_rhs), against the correctly rounded enclosure of csrc/device_math.hpp: out[0] = ends that fail to enclose it
+ * where the code did not ask for the exact walk (must be 0), [1] = one such pattern, [2] = operands tested, [3] = operands that asked
+ * for the exact walk, [4] = the widest result beyond the exact one in units of 2^-24 of max(|value|, 1) */
+int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float other_lo, float other_hi, int32_t x_is_rhs, uint64_t first, uint64_t count,
+                       uint64_t out[5]);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
                       float imm, float* out4);

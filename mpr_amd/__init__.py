@@ -198,7 +198,6 @@ def lib():
     L.mpr_test_float_op_asm.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_deriv_op.argtypes = [i32, i32, i32, vp, vp, f32, vp]
     L.mpr_test_sqrt_all.argtypes = [i32, ctypes.c_uint64, ctypes.c_uint64, vp, vp]
-    L.mpr_test_loose_interval.argtypes = [i32, i32, f32, ctypes.c_uint64, ctypes.c_uint64, vp, vp, vp, vp]
     L.mpr_test_jit_row.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_uint32, i32, vp, i32]
     L.mpr_test_tile_gen.argtypes = [vp, i32, i32, vp, i32]
     L.mpr_test_tile_gen.restype = ctypes.c_int
@@ -748,15 +747,6 @@ def dev_float_op_gen(op, a, b=None, imm=0.0, device=0, variant=0, dl=0, dr=0):
     out = np.empty_like(a)
     _check(lib().mpr_test_float_op_gen(device, op, variant, dl, dr, a.size, _ptr(a), _ptr(b), imm, _ptr(out)))
     return out
-
-
-def dev_loose_interval(op, first=0, count=1 << 32, device=0, imm=0.0):
-    """The loose exp / log enclosures (csrc/tile_gen_asm.hpp) on the bit patterns [first, first + count) of their domain against
-    the exact routine's: (ends that fail to enclose, one such pattern, operands tested, widest result in 2^-24 of the value)."""
-    bad, tested, widest = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
-    ex = ctypes.c_uint32(0)
-    _check(lib().mpr_test_loose_interval(device, op, imm, first, count, ctypes.byref(bad), ctypes.byref(ex), ctypes.byref(tested), ctypes.byref(widest)))
-    return int(bad.value), int(ex.value), int(tested.value), int(widest.value)
 
 
 def dev_interval_gen_op(op, a_lo, a_hi, b_lo=None, b_hi=None, imm=0.0, loose=False, device=0):

@@ -163,10 +163,9 @@ struct mpr_context {
     size_t gen_dec_cap[3] = {0, 0, 0};
     int gen_full_dw = 0;               /* dwords of the backward code for tapes that are shortened again (0: the tape is too long for it) */
     std::shared_ptr<const mpr::TapeCode> resident_code;   /* what gen_code holds (kept alive: the upload is asynchronous) */
-    int gen_vox_at = 0, gen_fwdg_at = 0, gen_derivg_at = 0, gen_derivg_dw = 0;   /* where the float walk / the guarded forward walk / the guarded
+    int gen_vox_at = 0, gen_derivg_at = 0, gen_derivg_dw = 0;   /* where the float walk / the guarded forward walk / the guarded
                                                                                    Deriv walk start in gen_code (dwords) */
     bool normals_guards = true;        /* MPR_NORMALS_GUARDS=0: the normals pass runs the plain Deriv walk */
-    int gen_fwdg_dw = 0;               /* dwords of the forward walk with guarded dead runs (TileGen::fwd_guarded), behind the float walk (0: none) */
     /* frame_domain.hpp: does the last (tape, view) asked about keep every interval operation where the reference's routines are
      * isotone (the shortcuts below that are only then the reference's procedure: skip0, the loose enclosures) */
     uint64_t tame_serial = 0;
@@ -205,8 +204,7 @@ struct mpr_context {
     uint64_t lean_first_serial = 0;    /* ... frames of this tape since it became resident */
     unsigned lean_first_frames = 0;
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
-    bool tile_gen_sched = true;        /* MPR_TILE_GEN_SCHED=0: the tile stages' forward walks on round 4's code (calls the interpreter's routines) instead of
-                                        * the scheduled walks of interval_gen.hpp */
+    /* the scheduled interval forward walks (interval_gen.hpp) in gen_code: [kind][exact, loose] */
     int gen_iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gen_iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     unsigned int* redo_count = nullptr;   /* MPR_DEBUG_REDO=1: {wavefronts that ran generated forward code, of them: redone on the exact code} */
     bool tile_gen_lean = true;         /* MPR_TILE_GEN_LEAN=0: loose stages that push nothing in the 128-register kernel too (four wavefronts per SIMD) */
@@ -440,7 +438,6 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
-    if (const char* e = getenv("MPR_TILE_GEN_SCHED")) c->tile_gen_sched = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LEAN")) c->tile_gen_lean = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_REDO"))
         if (atoi(e) != 0 && hipMalloc((void**)&c->redo_count, 2 * sizeof(unsigned int)) == hipSuccess) (void)hipMemset(c->redo_count, 0, 2 * sizeof(unsigned int));
@@ -701,16 +698,14 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     c->gen_full_dw = code->full_dw;
                     c->gen_vox_dw = c->voxel_gen ? code->vox_dw : 0;
                     c->gen_vox_at = code->fwd_dw + code->bwd_dw + code->deriv_dw + code->full_dw;
-                    c->gen_fwdg_dw = c->tile_gen_guards ? code->fwdg_dw : 0;
-                    c->gen_fwdg_at = c->gen_vox_at + code->vox_dw;
-                    c->gen_derivg_at = c->gen_fwdg_at + code->fwdg_dw;
+                    c->gen_derivg_at = c->gen_vox_at + code->vox_dw;
                     c->gen_derivg_dw = c->normals_guards ? code->derivg_dw : 0;
                     c->gen_words = code->walk_words;
                     c->gen_nchoices = code->nchoices;
                     for (int k = 0; k < 3; ++k)
                         for (int l = 0; l < 2; ++l) {
                             c->gen_iw_at[k][l] = code->iw_at[k][l];
-                            c->gen_iw_dw[k][l] = c->tile_gen_sched ? code->iw_dw[k][l] : 0;
+                            c->gen_iw_dw[k][l] = code->iw_dw[k][l];
                         }
                 }
             }
@@ -1055,7 +1050,6 @@ static int frame_begin(Frame& f)
             }
             mprk::Skip0ParentsArgs& pa = f.skip0_args;
             pa.tape_ro = c->pool;
-            pa.gen_fwd = c->gen_code;
             pa.gen_fwd2_first = c->gen_iw_dw[0][0] ? c->gen_code + c->gen_iw_at[0][0] : nullptr;
             pa.gen_fwd2_below = c->gen_iw_dw[1][0] ? c->gen_code + c->gen_iw_at[1][0] : nullptr;
             pa.parents = c->skip0_parents;
@@ -1143,7 +1137,8 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         } else if (gen_here && !first_stage && !last && decisions_recorded && f.lean_first && records) {
             /* ... and so does a stage between the first and the last one: the root tape's forward walk with the parents' decisions
              * imposed (jumping over what they left dead), the tile's record = its parent's decisions and its own */
-            a.gen_fwd = c->gen_fwdg_dw > 0 ? c->gen_code + c->gen_fwdg_at : c->gen_code;
+            a.gen_fwd = c->gen_code;
+            a.gen_guarded = c->tile_gen_guards;
             a.gen_words = c->gen_words;
             a.gen_nchoices = c->gen_nchoices;
             a.gen_parent = c->gen_dec[stage_list[si - 1]];
@@ -1161,7 +1156,8 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         } else if (gen_here && last && si == 2 && decisions_recorded && try_lean && c->tile_gen_last) {
             /* (pushes nothing: the walk that jumps over what the parent's decisions left dead; the groups of its sample take
              * the interpreter) */
-            a.gen_fwd = c->gen_fwdg_dw > 0 ? c->gen_code + c->gen_fwdg_at : c->gen_code;
+            a.gen_fwd = c->gen_code;
+            a.gen_guarded = c->tile_gen_guards;
             a.gen_words = c->gen_words;
             a.gen_nchoices = c->gen_nchoices;
             a.gen_parent = c->gen_dec[1];
@@ -1200,24 +1196,22 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         a.gen_loose = a.gen_fwd != nullptr && !reference && c->tile_gen_loose && tape->loose_ok && !verified_stage;
         if (a.gen_fwd) {
             /* the scheduled walk of the kind this stage needs (interval_gen.hpp); a loose one falls back on the exact one of its kind */
-            const int kind = !a.gen_parent ? mpr::IW_FIRST : (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) ? mpr::IW_BELOW_GUARDED : mpr::IW_BELOW;
-            if (c->gen_iw_dw[kind][0] > 0) {
-                a.gen_fwd2_exact = c->gen_code + c->gen_iw_at[kind][0];
-                a.gen_fwd2 = a.gen_loose && c->gen_iw_dw[kind][1] > 0 ? c->gen_code + c->gen_iw_at[kind][1] : a.gen_fwd2_exact;
-                if (a.gen_fwd2 == a.gen_fwd2_exact) a.gen_loose = false;
-                a.gen_redo_count = c->redo_count;
-            }
+            const int kind = !a.gen_parent ? mpr::IW_FIRST : a.gen_guarded ? mpr::IW_BELOW_GUARDED : mpr::IW_BELOW;
+            if (c->gen_iw_dw[kind][0] <= 0) return mpr::set_error(MPR_ERR_INVALID, "internal: a tile stage planned on generated code the tape has none of");
+            a.gen_fwd2_exact = c->gen_code + c->gen_iw_at[kind][0];
+            a.gen_fwd2 = a.gen_loose && c->gen_iw_dw[kind][1] > 0 ? c->gen_code + c->gen_iw_at[kind][1] : a.gen_fwd2_exact;
+            if (a.gen_fwd2 == a.gen_fwd2_exact) a.gen_loose = false;
+            a.gen_redo_count = c->redo_count;
         }
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
         std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
         if (a.gen_fwd && count > 0) {
             if (a.gen_parent) f += "/parent";
-            if (c->gen_fwdg_dw > 0 && a.gen_fwd == c->gen_code + c->gen_fwdg_at) f += "+guards";
+            if (a.gen_guarded) f += "+guards";
             if (a.gen_loose) f += "+loose";
             f += a.gen_bwd_full ? "+bwd_full" : a.gen_bwd ? "+bwd" : a.gen_forward_only ? "+fwdonly" : "";
             if (a.gen_decisions) f += "+records";
-            if (a.gen_fwd2) f += "+sched";
         }
         if (!c->stage_forms.empty()) c->stage_forms += " ";
         c->stage_forms += std::to_string(i) + ":" + f;
@@ -2506,28 +2500,6 @@ int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t 
     HIP_TRY(e1);
     HIP_TRY(e2);
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
-    return MPR_OK;
-}
-/* the loose exp / log enclosures of frames nobody reads (tile_gen_asm.hpp) on the bit patterns [first, first + count) that lie in
- * their domain, against the exact routine's: ends that fail to enclose, one such bit pattern, operands tested, widest result */
-int mpr_test_loose_interval(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t* not_enclosing, uint32_t* example,
-                            uint64_t* tested, uint64_t* widest_2m24)
-{
-    if (!not_enclosing || (op != MPR_OP_EXP_LHS && op != MPR_OP_LOG_LHS && op != MPR_OP_SQRT_LHS && op != MPR_OP_DIV_LHS_IMM && op != 100))
-        return mpr::set_error(MPR_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(device));
-    DevBuf d;
-    HIP_TRY(d.alloc(32));
-    HIP_TRY(hipMemset(d.p, 0, 32));
-    mprk::launch_test_loose_interval(nullptr, op, imm, first, count, (unsigned long long*)d.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    unsigned long long h[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost));
-    *not_enclosing = h[0];
-    if (example) *example = (uint32_t)h[1];
-    if (tested) *tested = h[2];
-    if (widest_2m24) *widest_2m24 = h[3];
     return MPR_OK;
 }
 /* the square-root routine of the float interpreters / generated code on the bit patterns [first, first + count): number of results

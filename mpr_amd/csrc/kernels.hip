@@ -304,15 +304,11 @@ k_eval_tiles(TileStageArgs a)
             if (redone) return;                      /* nothing has been written yet: the launch behind this one takes these tiles */
         } else if (a.debug & 32) {                          /* development: no walk at all, every tile empty (what the rest of the kernel costs) */
             res_vs = make_float2(1.0f, 2.0f);
-        } else if (a.gen_fwd2) {
+        } else {
             uint32_t redone = 0;
             tile_gen_forward2(a.gen_fwd2, a.gen_fwd2_exact, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
                               make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, &redone);
             if (a.gen_redo_count && lane == 0) atomicAdd(a.gen_redo_count + (redone ? 1 : 0), 1u);
-        } else {
-            tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
-                             2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                             make_float2(vz.lo, vz.hi), &res_vs, chl, chr, above_l, above_r, a.gen_loose);
         }
         chl[0] &= (uint32_t)keeps; chl[1] &= (uint32_t)(keeps >> 32);
         chr[0] &= (uint32_t)keeps; chr[1] &= (uint32_t)(keeps >> 32);
@@ -1138,89 +1134,6 @@ __global__ void k_test_interval(int op, int n, const float* a_lo, const float* a
         if (choice) choice[i] = c;
     }
 }
-/* The loose exp / log of frames nobody reads (tile_gen_asm.hpp: TG_FEXP_CORE / TG_FLOG_CORE) on every float of their domain,
- * each as the degenerate interval [x, x], against the exact routine's enclosure: out[0] = ends that do NOT enclose (must be 0),
- * out[1] = one such bit pattern, out[2] = operands tested, out[3] = the largest width met, in units of 2^-24 of max(|value|, 1). */
-__global__ void __launch_bounds__(256)
-k_test_loose_interval(int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
-{
-    float dummy0 = 0, dummy1 = 0, dummy2 = 0, dummy3 = 0, dummy4 = 0, dummy5 = 0;
-    round_up_begin(dummy0, dummy1, dummy2, dummy3, dummy4, dummy5);
-    unsigned long long bad = 0, tested = 0, example = 0, widest = 0;
-    for (unsigned long long k = threadIdx.x + (unsigned long long)blockIdx.x * blockDim.x; k < count; k += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t bits = (uint32_t)(first + k);
-        const float x = mpr_u2f(bits);
-        if (op == 100) {
-            /* the reciprocal's bounds of the division by a constant: 1 / x in [y_dn, y_up], checked exactly (a product of two
-             * floats is a double) */
-            const uint32_t mag = bits & 0x7FFFFFFFu;
-            if (mag < 0x0D800000u || mag > 0x71800000u) continue;
-            float yup, ndn;
-            asm volatile("v_mov_b32 v38, %2\n" TG_FRCP_CORE "v_mov_b32 %0, v45\n v_mov_b32 %1, v46\n"
-                         : "=&v"(yup), "=&v"(ndn) : "v"(x) : "v38", "v42", "v43", "v44", "v45", "v46");
-            const double pu = (double)yup * (double)x, pd = -(double)ndn * (double)x;
-            ++tested;
-            const bool ok = x > 0.0f ? (pd <= 1.0 && 1.0 <= pu) : (pu <= 1.0 && 1.0 <= pd);
-            if (!ok) {
-                ++bad;
-                example = bits;
-            }
-            continue;
-        }
-        const auto in_domain = [&](float v, uint32_t vb) {      /* (the routines' own tests) */
-            return op == MPR_OP_EXP_LHS ? (v <= 80.0f) : op == MPR_OP_DIV_LHS_IMM ? (v == v) : (vb >= 0x00800000u && vb <= 0x7F7FFFFFu);
-        };
-        if (!in_domain(x, bits)) continue;
-        /* [x, x], and the interval between x and a second float of the domain (a scrambled copy of its bits): an end taken from the
-         * wrong side — the division by a NEGATIVE constant swaps them — shows only when the ends differ */
-        const uint32_t bits2 = (bits * 2654435761u) ^ 0x9E3779B9u;
-        const float x2 = mpr_u2f(bits2);
-        for (int variant = 0; variant < 2; ++variant) {
-            if (variant == 1 && !in_domain(x2, bits2)) break;
-            const float in_lo = variant == 0 ? x : (x < x2 ? x : x2), in_hi = variant == 0 ? x : (x < x2 ? x2 : x);
-            int c = 0;
-            const ival exact = interval_clause((uint32_t)op, iv(in_lo, in_hi), iv(0.0f, 0.0f), imm, c);
-            float lo, hi;
-            if (op == MPR_OP_SQRT_LHS)
-                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n" TG_FSQRT_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi) : "v36", "v37", "v40", "v41", "v42", "v43", "v44");
-            else if (op == MPR_OP_DIV_LHS_IMM)
-                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n v_mov_b32 v38, %4\n" TG_FDIVI_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi), "v"(imm)
-                             : "v36", "v37", "v38", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "vcc");
-            else if (op == MPR_OP_EXP_LHS)
-                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n" TG_FEXP_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
-            else
-                asm volatile("v_mov_b32 v36, %2\n v_mov_b32 v37, %3\n" TG_FLOG_CORE "v_mov_b32 %0, v40\n v_mov_b32 %1, v41\n"
-                             : "=&v"(lo), "=&v"(hi) : "v"(in_lo), "v"(in_hi) : "v36", "v37", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
-            ++tested;
-            /* encloses: a NaN end of the exact enclosure (an operation without a value there) must be a NaN here too */
-            const bool lo_ok = exact.lo != exact.lo ? lo != lo : lo <= exact.lo, hi_ok = exact.hi != exact.hi ? hi != hi : hi >= exact.hi;
-            if (!(lo_ok && hi_ok)) {
-                ++bad;
-                example = bits;
-            }
-            if (variant == 1 || exact.lo != exact.lo || exact.hi != exact.hi || exact.lo - exact.lo != 0.0f || exact.hi - exact.hi != 0.0f ||
-                lo - lo != 0.0f || hi - hi != 0.0f)
-                continue;                              /* (no width to speak of: an end at infinity — a quotient that overflows one rounding earlier) */
-            const double mid = 0.5 * ((double)exact.lo + (double)exact.hi), w = ((double)hi - (double)lo);
-            const double scale = __builtin_fabs(mid) > 1.0 ? __builtin_fabs(mid) : 1.0;        /* relative above 1, absolute below */
-            const unsigned long long units = (unsigned long long)(w / scale * 16777216.0 < 1e15 ? w / scale * 16777216.0 : 1e15);
-            if (units > widest) widest = units;
-        }
-    }
-    if (bad) {
-        atomicAdd(&out[0], bad);
-        out[1] = example;
-    }
-    atomicAdd(&out[2], tested);
-    atomicMax(&out[3], widest);
-}
-void launch_test_loose_interval(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
-{
-    hipLaunchKernelGGL(k_test_loose_interval, dim3(2048), dim3(256), 0, s, op, imm, first, count, out);
-}
 /* one clause through the assembly forward walk of the tile stages: tape = {head (slots 1, 2, 3),
  * [copy], the clause (out = slot 4), end}; 64 operand pairs per wave; slot 3 is unused */
 __global__ void __launch_bounds__(64)
@@ -1447,16 +1360,10 @@ k_skip0_parents(Skip0ParentsArgs a)
     for (int i = 0; i < 4; ++i)
         r[i] = i_add_f(i_add(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 4])), i_mul_f(iz, a.mat[i + 8])), a.mat[i + 12]);
     const ival vx = i_div(r[0], r[3]), vy = i_div(r[1], r[3]), vz = i_div(r[2], r[3]);
-    const uint64_t head0 = a.tape_ro[0];
     float2 res = make_float2(0.0f, 0.0f);
     uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};
-    if (a.gen_fwd2_first)
-        tile_gen_forward2(a.gen_fwd2_first, nullptr, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                          make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0);
-    else
-        tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
-                         2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                         make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0, false);
+    tile_gen_forward2(a.gen_fwd2_first, nullptr, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                      make_float2(vz.lo, vz.hi), &res, chl, chr, 0, 0);
     round_nearest_begin();
     if (valid) {
         /* the reference's classification (:293-321; nothing is filled yet when its first stage runs: no tile is masked) */
@@ -1506,16 +1413,10 @@ k_skip0_compare(Skip0ParentsArgs a, const unsigned long long* __restrict__ child
         for (int i = 0; i < 4; ++i)
             r[i] = i_add_f(i_add(i_add(i_mul_f(ix, a.mat[i]), i_mul_f(iy, a.mat[i + 4])), i_mul_f(iz, a.mat[i + 8])), a.mat[i + 12]);
         const ival vx = i_div(r[0], r[3]), vy = i_div(r[1], r[3]), vz = i_div(r[2], r[3]);
-        const uint64_t head0 = a.tape_ro[0];
         float2 res = make_float2(0.0f, 0.0f);
         uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};
-        if (a.gen_fwd2_below)
-            tile_gen_forward2(a.gen_fwd2_below, nullptr, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                              make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr);
-        else
-            tile_gen_forward(a.gen_fwd, gen_io, lane, 2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
-                             2u * ((uint32_t)(head0 >> 24) & 0xFFu), make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
-                             make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr, false);
+        tile_gen_forward2(a.gen_fwd2_below, nullptr, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi),
+                          make_float2(vz.lo, vz.hi), &res, chl, chr, pl, pr);
         round_nearest_begin();
         if (again) {
             const bool same_end = (cv == SKIP0_EMPTY && res.x > 0.0f) || (cv == SKIP0_FILLED && !(res.x > 0.0f) && res.y < 0.0f);

@@ -90,6 +90,8 @@ struct TileStageArgs {
     unsigned char* redo_flags = nullptr;
     const unsigned char* only_flagged = nullptr;
     unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
+    bool gen_guarded = false;            /* with gen_parent: the walk that jumps over the runs the parents' decisions leave dead (interval_gen.hpp:
+                                          * IW_BELOW_GUARDED; stages that push nothing) */
     bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened
                                           * by their error bound, instead of the correctly rounded ones (tile_gen_asm.hpp: TG_LOOSE_ROUTINES) */
     const unsigned long long* gen_parent = nullptr;   /* with gen_fwd, instead of gen_bwd: the launch is the stage BELOW the one that wrote these records
@@ -181,9 +183,8 @@ constexpr int SKIP0_INFO_U64 = 4;
 enum { SKIP0_UNSEEN = 0, SKIP0_EMPTY = 1, SKIP0_FILLED = 2, SKIP0_AMBIGUOUS = 3 };   /* UNSEEN: dead, another rank's, or occluded before / while evaluated */
 struct Skip0ParentsArgs {
     const uint64_t* tape_ro = nullptr;       /* the pool: [0] = the root tape's head */
-    const uint32_t* gen_fwd = nullptr;       /* the root tape's forward walk (exact routines) */
-    const uint32_t* gen_fwd2_first = nullptr, *gen_fwd2_below = nullptr;   /* round 5: the scheduled exact walks (interval_gen.hpp: IW_FIRST for the
-                                              * parents, IW_BELOW for the children their decisions are imposed on); null: gen_fwd */
+    const uint32_t* gen_fwd2_first = nullptr, *gen_fwd2_below = nullptr;   /* the root tape's exact forward walks (interval_gen.hpp: IW_FIRST for the
+                                              * parents, IW_BELOW for the children their decisions are imposed on) */
     unsigned long long* parents = nullptr;   /* [count][SKIP0_INFO_U64] */
     int count = 0, tps = 0;                  /* 64^3 tiles, per side */
     float mat[16] = {0};
@@ -270,7 +271,6 @@ void launch_debug_interp_cycles(hipStream_t s, const uint64_t* tape, int reps, l
 void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
                           const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice);
 void launch_test_float(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
-void launch_test_loose_interval(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float* b, float imm, float* out);
 
 /* mpr::Effects (kernels_effects.hip) */

@@ -17,140 +17,6 @@ namespace {
 
 using namespace gfx;
 
-inline int lo(int s) { return 68 + 2 * s; }
-inline int hi(int s) { return 69 + 2 * s; }
-
-/* ---- forward ---- */
-void call1(Emit& e, int target, int o, int l)
-{
-    e.mov(36, Emit::V(lo(l)));
-    e.mov(37, Emit::V(hi(l)));
-    e.swappc(TG_RET_ROUTINE, target);
-    e.mov(lo(o), Emit::V(40));
-    e.mov(hi(o), Emit::V(41));
-}
-/* lhs (slot, or the immediate when l < 0) and rhs likewise */
-void call2(Emit& e, int target, int o, int l, int r, uint32_t imm)
-{
-    if (l >= 0) {
-        e.mov(36, Emit::V(lo(l)));
-        e.mov(37, Emit::V(hi(l)));
-    } else {
-        e.mov_lit(36, imm);
-        e.mov(37, Emit::V(36));
-    }
-    if (r >= 0) {
-        e.mov(38, Emit::V(lo(r)));
-        e.mov(39, Emit::V(hi(r)));
-    } else {
-        e.mov_lit(38, imm);
-        e.mov(39, Emit::V(38));
-    }
-    e.swappc(TG_RET_ROUTINE, target);
-    e.mov(lo(o), Emit::V(40));
-    e.mov(hi(o), Emit::V(41));
-}
-
-bool forward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t K, int choice)
-{
-    const int Ol = lo(o), Oh = hi(o), Al = lo(l), Ah = hi(l), Bl = lo(r), Bh = hi(r);
-    switch (op) {
-        case MPR_OP_SQUARE_LHS: call1(e, TG_RT_SQUARE, o, l); break;
-        case MPR_OP_SQRT_LHS: call1(e, TG_RT_SQRT, o, l); break;
-        case MPR_OP_NEG_LHS:                                 /* [-hi, -lo] */
-            e.vop2_lit(V_XOR, 40, SIGN, Ah);
-            e.vop2_lit(V_XOR, Oh, SIGN, Al);
-            e.mov(Ol, Emit::V(40));
-            break;
-        case MPR_OP_SIN_LHS:
-        case MPR_OP_COS_LHS:                                 /* the constant interval [-1, 1] (inc/gpu_interval.hpp:346-380) */
-            e.mov(Ol, 243);
-            e.mov(Oh, 242);
-            break;
-        case MPR_OP_ASIN_LHS: call1(e, TG_RT_ASIN, o, l); break;
-        case MPR_OP_ACOS_LHS: call1(e, TG_RT_ACOS, o, l); break;
-        case MPR_OP_ATAN_LHS: call1(e, TG_RT_ATAN, o, l); break;
-        case MPR_OP_EXP_LHS: call1(e, TG_RT_EXP, o, l); break;
-        case MPR_OP_ABS_LHS: call1(e, TG_RT_ABS, o, l); break;
-        case MPR_OP_LOG_LHS: call1(e, TG_RT_LOG, o, l); break;
-        /* sums and differences in round-up mode: the lower bound as minus the rounded-up negation.  The lower ends are
-         * consumed first, so that out may be one of the operands */
-        case MPR_OP_ADD_LHS_IMM:
-            e.vop2_lit(V_SUB_F32, 40, K ^ SIGN, Al);                          /* -(lo + K) = (-K) - lo */
-            e.vop2_lit(V_ADD_F32, Oh, K, Ah);
-            e.vop2_lit(V_XOR, Ol, SIGN, 40);
-            break;
-        case MPR_OP_ADD_LHS_RHS:
-            e.vop3(V3_ADD_F32, 40, Emit::V(Al), Emit::V(Bl), 0, 3);            /* (-a.lo) + (-b.lo) */
-            e.vop2(V_ADD_F32, Oh, Emit::V(Ah), Bh);
-            e.vop2_lit(V_XOR, Ol, SIGN, 40);
-            break;
-        case MPR_OP_MUL_LHS_IMM: {
-            /* K < 0 swaps the ends (the comparison the interpreter makes at run time: false for -0 and NaN) */
-            union { uint32_t u; float f; } k;
-            k.u = K;
-            const bool neg = k.f < 0.0f;
-            e.mov_lit(42, K);
-            e.vop3(V3_MUL_F32, 40, Emit::V(neg ? Ah : Al), Emit::V(42), 0, 1);  /* -lo = RU((-p) K) */
-            e.vop2(V_MUL_F32, Oh, Emit::V(neg ? Al : Ah), 42);                 /* hi = RU(q K) */
-            e.vop2_lit(V_XOR, Ol, SIGN, 40);
-            break;
-        }
-        case MPR_OP_MUL_LHS_RHS: call2(e, TG_RT_MUL, o, l, r, K); break;
-        case MPR_OP_MIN_LHS_IMM:
-        case MPR_OP_MIN_LHS_RHS:
-        case MPR_OP_MAX_LHS_IMM:
-        case MPR_OP_MAX_LHS_RHS: {
-            const bool is_min = op <= MPR_OP_MIN_LHS_RHS;
-            const bool has_rhs = op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS;
-            e.d(0xB04C0000u | (uint32_t)choice);                                 /* s_movk_i32 s76, clause: the routine may know better */
-            call2(e, is_min ? TG_RT_MIN : TG_RT_MAX, o, l, has_rhs ? r : -1, K);
-            /* the routine leaves vcc = lanes that did NOT choose the lhs, s[92:93] = lanes that chose the rhs */
-            e.mov_lit(42, 1u << (choice & 31));
-            e.vop3(V3_CNDMASK, 43, Emit::V(42), Emit::I(0), VCC);
-            e.vop2(V_OR, 56 + (choice >> 5), Emit::V(56 + (choice >> 5)), 43);
-            e.vop3(V3_CNDMASK, 43, Emit::I(0), Emit::V(42), 92);
-            e.vop2(V_OR, 58 + (choice >> 5), Emit::V(58 + (choice >> 5)), 43);
-            break;
-        }
-        case MPR_OP_SUB_LHS_IMM:
-            e.vop2_lit(V_SUB_F32, 40, K, Al);                                  /* K - lo */
-            e.vop2_lit(V_SUBREV_F32, Oh, K, Ah);                               /* hi - K */
-            e.vop2_lit(V_XOR, Ol, SIGN, 40);
-            break;
-        case MPR_OP_SUB_IMM_RHS:
-            e.vop2_lit(V_SUBREV_F32, 40, K, Bh);                               /* hi - K */
-            e.vop2_lit(V_SUB_F32, Oh, K, Bl);                                  /* K - lo */
-            e.vop2_lit(V_XOR, Ol, SIGN, 40);
-            break;
-        case MPR_OP_SUB_LHS_RHS:
-            e.vop2(V_SUB_F32, 40, Emit::V(Bh), Al);                            /* b.hi - a.lo */
-            e.vop2(V_SUB_F32, Oh, Emit::V(Ah), Bl);                            /* a.hi - b.lo */
-            e.vop2_lit(V_XOR, Ol, SIGN, 40);
-            break;
-        case MPR_OP_DIV_LHS_IMM: call2(e, TG_RT_DIVI, o, l, -1, K); break;
-        case MPR_OP_DIV_IMM_RHS: call2(e, TG_RT_DIV, o, -1, r, K); break;
-        case MPR_OP_DIV_LHS_RHS: call2(e, TG_RT_DIV, o, l, r, K); break;
-        case MPR_OP_COPY_IMM:
-            e.mov_lit(Ol, K);
-            e.mov(Oh, Emit::V(Ol));
-            break;
-        case MPR_OP_COPY_LHS:
-            if (o != l) {
-                e.mov(Ol, Emit::V(Al));
-                e.mov(Oh, Emit::V(Ah));
-            }
-            break;
-        case MPR_OP_COPY_RHS:
-            if (o != r) {
-                e.mov(Ol, Emit::V(Bl));
-                e.mov(Oh, Emit::V(Bh));
-            }
-            break;
-        default: return false;
-    }
-    return true;
-}
 
 /* ---- backward (reference :351-458; the compiled restatement: kernels.hip, "backward walk") ---- */
 /* pos -= the lanes' emit flag (VGPR ef); lanes whose chunk is full move to the next one of their run */
@@ -539,54 +405,12 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
         const int hx = (int)(clauses[0] >> 8) & 0xFF, hy = (int)(clauses[0] >> 16) & 0xFF, hz = (int)(clauses[0] >> 24) & 0xFF;
         if (hx >= TILE_GEN_MAX_SLOTS || hy >= TILE_GEN_MAX_SLOTS || hz >= TILE_GEN_MAX_SLOTS) return g;
     }
-    Emit f{g.fwd}, b{g.bwd};
-    int choice = 0;
-    for (int i = 1; i < end; ++i) {
-        const uint64_t w = clauses[i];
-        const uint32_t op = (uint32_t)w & 0xFF;
-        if (!forward_clause(f, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), choice)) {
-            g.fwd.clear();
-            return g;
-        }
-        if (mpr_op_is_minmax(op)) ++choice;
-    }
+    Emit b{g.bwd};
+    int choice = nch;
     g.result_slot = (int)(clauses[end] >> 8) & 0xFF;
-    f.mov(36, Emit::V(lo(g.result_slot)));
-    f.mov(37, Emit::V(hi(g.result_slot)));
-    f.setpc(TG_RET_CODE);
-    {
-        /* the same walk with the dead runs guarded: `s_bitcmp1_b64 <decided above for the other side>, k; s_cbranch_scc1 <behind the run>` */
-        std::vector<DeadRun> runs = tape_dead_runs(clauses, end, 3);
-        std::stable_sort(runs.begin(), runs.end(), [](const DeadRun& a, const DeadRun& b) { return a.first != b.first ? a.first < b.first : a.last > b.last; });
-        Emit fg{g.fwd_guarded};
-        std::vector<int> pos((size_t)end + 1, 0);
-        std::vector<std::pair<size_t, int>> fix;                    /* branch word, clause behind the run */
-        size_t next_run = 0;
-        int ch = 0;
-        for (int i = 1; i < end; ++i) {
-            pos[(size_t)i] = (int)g.fwd_guarded.size();
-            for (; next_run < runs.size() && runs[next_run].first == i; ++next_run) {
-                const DeadRun& r = runs[next_run];
-                fg.d(0xBF0F0000u | (uint32_t)(128 + r.choice) << 8 | (r.by_lhs ? 72u : 74u));      /* s_bitcmp1_b64 s[72:73] / s[74:75], choice */
-                fix.emplace_back(g.fwd_guarded.size(), r.last + 1);
-                fg.d(0xBF850000u);                                   /* s_cbranch_scc1 */
-            }
-            const uint64_t w = clauses[i];
-            const uint32_t op = (uint32_t)w & 0xFF;
-            (void)forward_clause(fg, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), ch);
-            if (mpr_op_is_minmax(op)) ++ch;
-        }
-        pos[(size_t)end] = (int)g.fwd_guarded.size();
-        fg.mov(36, Emit::V(lo(g.result_slot)));
-        fg.mov(37, Emit::V(hi(g.result_slot)));
-        fg.setpc(TG_RET_CODE);
-        bool fits = true;
-        for (const auto& fx : fix) {
-            const long d = (long)pos[(size_t)fx.second] - ((long)fx.first + 1);
-            if (d < 0 || d > 32767) fits = false;
-            g.fwd_guarded[fx.first] |= (uint32_t)(d & 0xFFFF);
-        }
-        if (!fits || runs.empty()) g.fwd_guarded.clear();          /* nothing to jump over: the plain walk */
+    for (int i = 1; i < end; ++i) {
+        const uint32_t op = (uint32_t)clauses[i] & 0xFF;
+        if (op == MPR_OP_INVALID || op == MPR_OP_JUMP || op >= MPR_OP_COUNT) return g;
     }
 
     {
@@ -597,7 +421,6 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
             const uint64_t w = clauses[i];
             const uint32_t op = (uint32_t)w & 0xFF;
             if (!deriv_clause(dg, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)(w >> 32), ch)) {
-                g.fwd.clear();
                 g.deriv.clear();
                 return g;
             }
@@ -674,20 +497,17 @@ namespace mpr {
 std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len, int vox_min_run)
 {
     const TileGen g = tile_gen_build(clauses, len);
-    if (!g.ok || g.fwd.empty()) return nullptr;
+    if (!g.ok || g.deriv.empty()) return nullptr;
     const VoxelGen v = voxel_gen_build(clauses, len, vox_min_run);
     auto c = std::make_shared<TapeCode>();
-    c->words.reserve(g.fwd.size() + g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size() + g.fwd_guarded.size() + g.deriv_guarded.size());
-    c->words.insert(c->words.end(), g.fwd.begin(), g.fwd.end());
+    c->words.reserve(g.bwd.size() + g.deriv.size() + g.bwd_full.size() + v.code.size() + g.deriv_guarded.size() + 40000);
     c->words.insert(c->words.end(), g.bwd.begin(), g.bwd.end());
     c->words.insert(c->words.end(), g.deriv.begin(), g.deriv.end());
     c->words.insert(c->words.end(), g.bwd_full.begin(), g.bwd_full.end());
     if (v.ok) c->words.insert(c->words.end(), v.code.begin(), v.code.end());
-    c->words.insert(c->words.end(), g.fwd_guarded.begin(), g.fwd_guarded.end());
-    c->fwdg_dw = (int)g.fwd_guarded.size();
     c->words.insert(c->words.end(), g.deriv_guarded.begin(), g.deriv_guarded.end());
     c->derivg_dw = (int)g.deriv_guarded.size();
-    c->fwd_dw = (int)g.fwd.size();
+    c->fwd_dw = 0;                  /* (round 4's forward walk stood here; the forward walks are the iw_* pieces behind the rest) */
     c->bwd_dw = (int)g.bwd.size();
     c->deriv_dw = (int)g.deriv.size();
     c->full_dw = (int)g.bwd_full.size();
@@ -713,8 +533,8 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
     const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
-    if (!g.ok || which < 0 || which > 5) return -1;
-    const std::vector<uint32_t>& c = which == 5 ? g.deriv_guarded : which == 4 ? g.fwd_guarded : which == 3 ? g.bwd_full : which == 2 ? g.deriv : which ? g.bwd : g.fwd;
+    if (!g.ok || which < 1 || which > 5 || which == 4) return -1;        /* (0 / 4 were round 4's forward walks: mpr_test_interval_gen) */
+    const std::vector<uint32_t>& c = which == 5 ? g.deriv_guarded : which == 3 ? g.bwd_full : which == 2 ? g.deriv : g.bwd;
     if (out && (int)c.size() <= cap)
         for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
     return (int)c.size();

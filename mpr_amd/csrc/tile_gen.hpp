@@ -4,15 +4,15 @@
  * Every tile of a frame's first stage walks the same tape (reference src/context.cu:188-321 forward, :323-458 backward), so
  * unlike the tapes pushed later this one is worth compiling: a clause becomes the handful of instructions its opcode needs,
  * with the slot registers and the immediate in the instruction words — no fetch, no decode, no dispatch, no operand moves
- * through a register index.  The arithmetic is the interpreter's own (tile_interp_asm.hpp): simple clauses are emitted in
- * line, the others call the interpreter's routine bodies.  Counterpart on the device: tile_gen_asm.hpp.
+ * through a register index.  This file: the BACKWARD walks (tape pushing) and the Deriv walk of the normals pass; the forward
+ * walk is interval_gen.hpp's (round 5: scheduled code on renamed registers; round 3 / 4's forward walk — one row per clause on
+ * fixed slot registers, calling the interpreter's routines — is gone).  Counterpart on the device: tile_gen_asm.hpp.
  * The tapes pushed later are this tape with decisions applied; with a tile's decisions kept as bits over the root tape's
  * min / max clauses (its RECORD, below) the stages below the first and the normals pass (reference :978-1132; the Deriv walk,
  * run by kernels_normals_asm.hip: k_eval_normals_gen) run the same one piece of code per tape as well.
  *
  * Register conventions of the generated code (fixed: the harness and the routine bodies are written against them)
- *   slot s                  v[68 + 2 s] (lower bound), v[69 + 2 s] (upper bound)           s <= 24
- *   routine operands        v[36:37] lhs, v[38:39] rhs; result v[40:41]
+ *   (forward walk: interval_gen.hpp)
  *   decisions               v56 / v57: bit k set = this lane's tile chose the LHS at min / max clause k (k < 32 / k >= 32),
  *                           v58 / v59: the same for the RHS
  *   routine entry points    SGPR pairs (TileGenReg), return address s[36:37]; the code itself returns through s[38:39]
@@ -50,12 +50,6 @@ enum TileGenReg : int {
 
 struct TileGen {
     bool ok = false;
-    std::vector<uint32_t> fwd;      /* forward walk: axes in their slots -> result in v[36:37], decisions in v56..v59 */
-    std::vector<uint32_t> fwd_guarded;   /* the forward walk for a stage BELOW the first that pushes nothing (a frame's lean last stage): runs of clauses
-                                          * that are dead under what the parent tile decided (s[72:73] / s[74:75], wave-uniform: the 64 tiles of a
-                                          * wavefront share their parent) are jumped over — voxel_gen.hpp: tape_dead_runs.  The min / max clauses in
-                                          * such a run record no decision: nothing of the tile's tape depends on them.  Not for stages that push:
-                                          * the reference's backward walk keeps some dead clauses (slot liveness), and their decisions are on the tape */
     std::vector<uint32_t> bwd;      /* backward walk of tape pushing */
     std::vector<uint32_t> bwd_full; /* the same for tapes that are shortened again, and for the stages below the first (tile_gen.cpp); empty:
                                      * the tape has more clauses than a record has presence bits */

@@ -18,298 +18,25 @@ namespace mprk {
 /* entry point of a routine, relative to L_pc (s[40:41]) */
 #define TG_ADDR(lo, hi, label) "s_add_u32 s" #lo ", s40, " label "_%=-L_pc_%=\n s_addc_u32 s" #hi ", s41, 0\n"
 
-/* ---- exp and log of an interval WITHOUT double precision, for frames nobody reads (round 4) ----
+/* ---- frames nobody reads: what a LOOSE walk owes the reference (round 4; the arithmetic itself: interval_gen.hpp, round 5) ----
  * The tile stages' exp / log (reference inc/gpu_interval.hpp:332-336, :382-390) are the correctly rounded enclosures
  * {RD(exp(lo)), RU(exp(hi))}, computed in double precision (OCML: 119 / 361 instructions per clause, most at the f64 rate): half of
- * the generated forward walk of bear's tape.  Which tiles a stage finds empty / filled / ambiguous, and which min / max clauses it
+ * an exact forward walk of bear's tape.  Which tiles a stage finds empty / filled / ambiguous, and which min / max clauses it
  * decides, is reference state only in frames that are READ; an ordinary frame (context.hip: !reference) owes the reference its
  * heights and normals, and those do not depend on how tight a SOUND enclosure is: a wider interval leaves a tile ambiguous that
  * the reference would have culled or filled (its children / voxels are evaluated and give the same heights: the hierarchy is
  * conservative at every level) or a min / max undecided that the reference would have decided (the comparison then picks the same
- * operand at every point).  So those frames take the hardware's v_exp_f32 / v_log_f32 (base 2) — and v_sqrt_f32 and, for the
- * division by a constant, v_rcp_f32: below — and widen the result by an error bound that covers the argument's rounding, the
- * constant's and the instruction's:
- *   exp:  t = RU(x log2e),  r = v_exp_f32(t),  k = (|t| + 4) 2^-23:        [RD(r - r k), RU(r + r k)]
- *         (t is off by at most |t| 1.13 2^-23: a factor 2^(that) = 1 +- 0.79 |t| 2^-23 on the result; v_exp_f32: 1 ulp, 2 assumed)
- *   log:  p = RU(v_log_f32(x) ln2),  e = (|p| + 1) 2^-21:                  [RD(p - e), RU(p + e)]
- * about 1e-5 relative where the exact route has 6e-8, on values that feed sums of terms of magnitude 1 over tiles whose natural
- * extension is 0.3 wide: the classification barely moves (DESIGN.md has the counts).  Only when EVERY lane's ends are ordinary
- * (exp: x <= 80, any negative number — results below 2^-120 become [0, 2^-120]; log, sqrt: positive normal numbers) — anything else
- * takes the exact routine, with all of its special cases.
- * What "sound" has to mean here: the loose result of an operation encloses the exact one WHENEVER its operands enclose the exact
- * operands — by induction over the tape every loose interval then encloses the reference's, and whatever the loose walk proves (a
- * tile empty or filled, a min / max decided) the reference proves too; what it fails to prove is evaluated one level further down,
- * to the same pixels — as long as the reference's own proofs are facts about the float pass's values.  Two things break that, and
- * the loose walk must stay away from both:
- *  - an exact routine that is not inclusion-isotone, handed the loose walk's wider operands: log returns the lower bound 0 for
- *    x.lo <= 0 and log(x.lo) — as low as -103 — for a tiny positive one (reference inc/gpu_interval.hpp:382-390), and a loose lower
- *    end can be 0 where the exact one is tiny and positive;
+ * operand at every point).  What "sound" has to mean: the loose result of an operation encloses the exact one WHENEVER its operands
+ * enclose the exact operands — by induction over the tape every loose interval then encloses the reference's, and whatever the loose
+ * walk proves (a tile empty or filled, a min / max decided) the reference proves too; what it fails to prove is evaluated one level
+ * further down, to the same pixels — as long as the reference's own proofs are facts about the float pass's values.  Two things
+ * break that, and a loose walk stays away from both by asking for the exact walk (interval_gen.hpp):
+ *  - an exact routine that is not inclusion-isotone: log returns the lower bound 0 for x.lo <= 0 and log(x.lo) — as low as -103 —
+ *    for a tiny positive one (reference inc/gpu_interval.hpp:382-390), and a loose lower end can be 0 where the exact one is tiny;
  *  - exact bounds that are not facts: the same lower bound 0 where the logarithm is very negative (a steep exp / log blend far from
  *    its surface: the reference then drops the OTHER operand of a min, and its image lacks what that operand drew — tests: "smooth"),
- *    sqrt's [0, ..] over an interval whose negative part is NaN to the float pass, asin / acos outside [-1, 1].
- * So: a log whose lower end is not a positive normal number, a sqrt whose lower end is negative, an exp that can overflow, a divisor
- * that holds zero (infinities: a wider interval elsewhere can then meet 0 x inf where the exact walk does not, and the NaN is gone
- * from the next min / max) -> the WHOLE walk again with the exact routines (L_redo: the wave's tiles then are exactly the
- * reference's); tapes with asin / acos clauses, or that divide by a constant outside 2^-100 .. 2^100, never run loose
- * (mpr_tape::loose_ok).
- * SOUNDNESS IS NOT ARGUED ONLY: mpr_test_loose_interval runs these very instructions on every float of the domain on the device
- * and holds each end against the exact routine's (tests/test_gpu_primitives.py: test_loose_exp_log_enclose_the_exact_ones).
- * In: v36 = lo, v37 = hi; out v40, v41; temporaries v42..v47; round-up mode. */
-#define TG_FEXP_CORE                                                                                              \
-    "v_mul_f32 v42, 0x3fb8aa3b, v36\n"                  /* t = x log2(e) */                                       \
-    "v_mul_f32 v43, 0x3fb8aa3b, v37\n"                                                                            \
-    "v_max_f32 v42, 0xc3480000, v42\n"                  /* ... at least -200 (2^-200 is 0 here; -inf must not reach k) */ \
-    "v_max_f32 v43, 0xc3480000, v43\n"                                                                            \
-    "v_exp_f32 v44, v42\n"                                                                                        \
-    "v_exp_f32 v45, v43\n"                                                                                        \
-    "v_add_f32_e64 v46, |v42|, 4.0\n"                                                                             \
-    "v_add_f32_e64 v47, |v43|, 4.0\n"                                                                             \
-    "v_mul_f32 v46, 0x34000000, v46\n"                  /* k = (|t| + 4) 2^-23, rounded up */                      \
-    "v_mul_f32 v47, 0x34000000, v47\n"                                                                            \
-    "v_fma_f32 v40, v44, v46, -v44\n"                   /* RU(r k - r) = -RD(r - r k) */                          \
-    "v_fma_f32 v41, v45, v47, v45\n"                    /* RU(r + r k) */                                         \
-    /* results below 2^-120 (t < -120: v_exp_f32 flushes, or loses bits in, what is not a normal number): [0, 2^-120] */ \
-    "v_add_f32 v40, 0x04800000, v40\n"                  /* the lower end 2^-118 lower ... */                      \
-    "v_max_f32 v41, 0x03800000, v41\n"                  /* the upper end at least 2^-120 */                       \
-    "v_max_f32_e64 v40, -v40, 0\n"                      /* ... and not below 0 */
-#define TG_FLOG_CORE                                                                                              \
-    "v_log_f32 v42, v36\n"                                                                                        \
-    "v_log_f32 v43, v37\n"                                                                                        \
-    "s_nop 0\n"                                                                                                   \
-    "v_mul_f32 v42, 0x3f317218, v42\n"                  /* p = log2(x) ln2 */                                     \
-    "v_mul_f32 v43, 0x3f317218, v43\n"                                                                            \
-    "v_add_f32_e64 v44, |v42|, 1.0\n"                                                                             \
-    "v_add_f32_e64 v45, |v43|, 1.0\n"                                                                             \
-    "v_mul_f32 v44, 0x35000000, v44\n"                  /* e = (|p| + 1) 2^-21, rounded up */                      \
-    "v_mul_f32 v45, 0x35000000, v45\n"                                                                            \
-    "v_sub_f32 v40, v44, v42\n"                         /* RU(e - p) = -RD(p - e) */                              \
-    "v_add_f32 v41, v43, v45\n"                         /* RU(p + e) */                                           \
-    "v_xor_b32 v40, 0x80000000, v40\n"
-/* square root: r = v_sqrt_f32(x) (1 ulp; 2 assumed): [RD(r - r 2^-22), RU(r + r 2^-22)], for positive normal ends (7 instructions
- * where the correctly rounded pair takes ~50) */
-#define TG_FSQRT_CORE                                                                                             \
-    "v_sqrt_f32 v42, v36\n"                                                                                       \
-    "v_sqrt_f32 v43, v37\n"                                                                                       \
-    "v_mov_b32 v44, 0x34800000\n"                       /* 2^-22 */                                               \
-    "s_nop 0\n"                                                                                                   \
-    "v_fma_f32 v40, v42, v44, -v42\n"                   /* RU(r c - r) = -RD(r - r c) */                          \
-    "v_fma_f32 v41, v43, v44, v43\n"                    /* RU(r + r c) */                                         \
-    "v_xor_b32 v40, 0x80000000, v40\n"
-/* division by a constant c (v38; 2^-100 <= |c| <= 2^100): y = v_rcp_f32(c) (1 ulp; 2 assumed), 1 / c lies in [y_dn, y_up] =
- * [RD(y - |y| 2^-22), RU(y + |y| 2^-22)], so x / c lies between x y_dn and x y_up whatever the signs: the lower end is the smaller of
- * the two products of the end it comes from (lo for c > 0, hi for c < 0) rounded down, the upper end the larger of the other end's rounded up (15 instructions where the correctly rounded pair takes ~75:
- * bear divides by a constant 39 times per walk).  TG_FRCP_CORE leaves y_up in v45 and -y_dn in v46. */
-#define TG_FRCP_CORE                                                                                              \
-    "v_rcp_f32 v42, v38\n"                                                                                        \
-    "v_mov_b32 v44, 0x34800000\n"                                                                                 \
-    "s_nop 0\n"                                                                                                   \
-    "v_mul_f32_e64 v43, |v42|, v44\n"                   /* w = |y| 2^-22 */                                       \
-    "v_add_f32 v45, v42, v43\n"                         /* y_up = RU(y + w) */                                    \
-    "v_sub_f32 v46, v43, v42\n"                         /* RU(w - y) = -y_dn */
-#define TG_FDIVI_CORE                                                                                             \
-    TG_FRCP_CORE                                                                                                  \
-    "v_cmp_gt_f32 vcc, 0, v38\n"                        /* a negative divisor: the quotient falls, the ends trade places */ \
-    "v_cndmask_b32 v49, v36, v37, vcc\n"                /* a: the end the lower end comes from */                 \
-    "v_cndmask_b32 v50, v37, v36, vcc\n"                /* b: ... the upper end */                                \
-    "v_mul_f32 v47, v49, v46\n"                         /* RU(a (-y_dn)) = -RD(a y_dn) */                         \
-    "v_mul_f32_e64 v48, -v49, v45\n"                    /* RU((-a) y_up) = -RD(a y_up) */                         \
-    "v_mul_f32_e64 v49, v50, -v46\n"                    /* RU(b y_dn) */                                          \
-    "v_mul_f32 v50, v50, v45\n"                         /* RU(b y_up) */                                          \
-    "v_max_f32 v40, v47, v48\n"                         /* - lower end */                                         \
-    "v_max_f32 v41, v49, v50\n"                                                                                   \
-    "v_xor_b32 v40, 0x80000000, v40\n"
-/* the routines: the range test, then the core or the exact routine */
-#define TG_LOOSE_ROUTINES                                                                                         \
-    "L_fsqrt_%=:\n"                                                                                               \
-    "v_cmp_gt_f32 vcc, 0, v36\n"                        /* a negative lower end: the float pass's NaN is near */   \
-    "s_cbranch_vccnz L_redo_%=\n"                                                                                 \
-    "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
-    "v_add_u32 v43, 0xff800000, v37\n"                                                                            \
-    "v_max_u32 v42, v42, v43\n"                                                                                   \
-    "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* an end that is not a positive normal number */          \
-    "s_cbranch_vccnz L_isqrt_%=\n"                                                                                \
-    TG_FSQRT_CORE                                                                                                 \
-    "s_setpc_b64 s[36:37]\n"                                                                                      \
-    "L_fdivi_%=:\n"                                                                                               \
-    "v_and_b32 v42, 0x7fffffff, v38\n"                                                                            \
-    "v_add_u32 v42, 0xf2800000, v42\n"                  /* |c| bits - bits(2^-100) */                             \
-    "v_cmp_le_u32 vcc, 0x64000001, v42\n"               /* |c| outside 2^-100 .. 2^100 (zero, NaN, inf included) */ \
-    "s_cbranch_vccnz L_gdivi_%=\n"                                                                                \
-    TG_FDIVI_CORE                                                                                                 \
-    "s_setpc_b64 s[36:37]\n"                                                                                      \
-    "L_fexp_%=:\n"                                                                                                \
-    "s_mov_b32 s40, 0x42a00000\n"                       /* 80 */                                                  \
-    "v_cmp_nle_f32 vcc, v36, s40\n"                     /* an end above 80, or NaN */                             \
-    "v_cmp_nle_f32 s[42:43], v37, s40\n"                                                                          \
-    "s_or_b64 vcc, vcc, s[42:43]\n"                                                                               \
-    "s_cbranch_vccnz L_fexp_big_%=\n"                                                                             \
-    TG_FEXP_CORE                                                                                                  \
-    "s_setpc_b64 s[36:37]\n"                                                                                      \
-    "L_fexp_big_%=:\n"                                  /* up to 88 the exact routine; beyond, exp can overflow: an infinity */ \
-    "s_mov_b32 s40, 0x42b00000\n"                       /* in a walk whose other intervals are wider than the exact ones can */ \
-    "v_cmp_nle_f32 vcc, v37, s40\n"                     /* meet a zero the exact walk does not (0 x inf: NaN) */   \
-    "v_cmp_u_f32 s[42:43], v36, v36\n"                                                                            \
-    "s_or_b64 vcc, vcc, s[42:43]\n"                                                                               \
-    "s_cbranch_vccnz L_redo_%=\n"                                                                                 \
-    "s_branch L_cexp_%=\n"                                                                                        \
-    /* a divisor that holds zero: [-inf, inf] to the exact routine — the exact walk's, narrower, may not hold it */ \
-    "L_fdiv_%=:\n"                                                                                                \
-    "v_cmp_ge_f32 s[58:59], 0, v38\n v_cmp_le_f32 vcc, 0, v39\n"                                                  \
-    "s_and_b64 s[58:59], s[58:59], vcc\n"                                                                         \
-    "s_cmp_lg_u64 s[58:59], 0\n"                                                                                  \
-    "s_cbranch_scc1 L_redo_%=\n"                                                                                  \
-    "s_branch L_idiv_%=\n"                                                                                        \
-    "L_flog_%=:\n"                                                                                                \
-    "v_add_u32 v42, 0xff800000, v36\n"                  /* bits - bits(2^-126) */                                 \
-    "v_cmp_le_u32 vcc, 0x7f000000, v42\n"               /* a LOWER end that is not a positive normal number: the exact */ \
-    "s_cbranch_vccnz L_redo_%=\n"                       /* walk may be in the branch that is not isotone */        \
-    "v_add_u32 v43, 0xff800000, v37\n"                                                                            \
-    "v_cmp_le_u32 vcc, 0x7f000000, v43\n"               /* the upper end: inf, NaN */                              \
-    "s_cbranch_vccnz L_clog_%=\n"                                                                                 \
-    TG_FLOG_CORE                                                                                                  \
-    "s_setpc_b64 s[36:37]\n"                                                                                      \
-    /* the walk again, with the exact routines (the axes' intervals and the wave's words are still in LDS) */     \
-    "L_redo_%=:\n"                                                                                                \
-    "v_mov_b32 v33, %[io]\n"                                                                                      \
-    "v_mov_b32 v53, 0\n"                                                                                          \
-    "ds_write_b32 v33, v53 offset:3876\n"                                                                         \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    "s_branch L_again_%=\n"
-
-/* smem_io: 4 KB of LDS ([16][64] words) the register state travels through: the statement below names all but ten vector
- * registers.  ax / ay / az: 2 * the axes' slots; x / y / z: their intervals.  Out: the end clause's interval, and the lanes'
- * decisions at the tape's min / max clauses (bit k of chl / chr: chose lhs / rhs at clause k; two words each). */
-/* decided_lhs / decided_rhs: min / max clauses (bit k: the root tape's k-th) somebody above has decided for all 64 tiles — the
- * parent tile whose shortened tape they would otherwise walk: the routine's outcome is overridden, the interval is the
- * chosen operand's as on that tape (0, 0: nobody, the first stage) */
-DEV void tile_gen_forward(const uint32_t* code, unsigned char* smem_io, int lane, uint32_t ax, uint32_t ay, uint32_t az,
-                          float2 x, float2 y, float2 z, float2* res, uint32_t* chl, uint32_t* chr,
-                          unsigned long long decided_lhs = 0, unsigned long long decided_rhs = 0, bool loose = false)
-{
-    float* const io = reinterpret_cast<float*>(smem_io);
-    io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
-    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
-    const uint32_t lane8 = (uint32_t)lane * 8u;
-    /* the wave-uniform words travel through LDS as well (the statement names nearly every scalar register too) */
-    if (lane == 0) {
-        uint32_t* const u = reinterpret_cast<uint32_t*>(io) + 960;
-        u[0] = (uint32_t)decided_lhs; u[1] = (uint32_t)(decided_lhs >> 32);
-        u[2] = (uint32_t)decided_rhs; u[3] = (uint32_t)(decided_rhs >> 32);
-        u[4] = (uint32_t)(uintptr_t)code; u[5] = (uint32_t)((uintptr_t)code >> 32);
-        u[6] = ax; u[7] = ay; u[8] = az;
-        u[9] = loose ? 1u : 0u;       /* exp / log by the hardware's base-2 instructions, widened (TG_LOOSE_ROUTINES) */
-    }
-    asm volatile(
-        /* the axes' intervals into their slots (TI_VS_ENTER with the three slot numbers in one operand) */
-        "L_again_%=:\n"
-        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
-        "ds_read_b32 v36, v32\n ds_read_b32 v37, v32 offset:256\n ds_read_b32 v38, v32 offset:512\n"
-        "ds_read_b32 v39, v32 offset:768\n ds_read_b32 v42, v32 offset:1024\n ds_read_b32 v43, v32 offset:1280\n"
-        "v_mov_b32 v33, %[io]\n"
-        "ds_read_b128 v[44:47], v33 offset:3840\n ds_read_b128 v[48:51], v33 offset:3856\n ds_read_b32 v52, v33 offset:3872\n"
-        "ds_read_b32 v53, v33 offset:3876\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_readfirstlane_b32 s43, v53\n"
-        "v_readfirstlane_b32 s72, v44\n v_readfirstlane_b32 s73, v45\n v_readfirstlane_b32 s74, v46\n v_readfirstlane_b32 s75, v47\n"
-        "v_readfirstlane_b32 s34, v48\n v_readfirstlane_b32 s35, v49\n"
-        "v_readfirstlane_b32 s40, v50\n v_readfirstlane_b32 s41, v51\n v_readfirstlane_b32 s42, v52\n"
-        "s_set_gpr_idx_on s40, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v36\n v_mov_b32 " TI_VS_BASE1 ", v37\n s_set_gpr_idx_off\n"
-        "s_set_gpr_idx_on s41, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v38\n v_mov_b32 " TI_VS_BASE1 ", v39\n s_set_gpr_idx_off\n"
-        "s_set_gpr_idx_on s42, gpr_idx(DST)\n v_mov_b32 " TI_VS_BASE ", v42\n v_mov_b32 " TI_VS_BASE1 ", v43\n s_set_gpr_idx_off\n"
-        "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
-        "s_getpc_b64 s[40:41]\n"
-        "L_pc_%=:\n"
-        TG_ADDR(62, 63, "L_square") TG_ADDR(64, 65, "L_abs") TG_ADDR(66, 67, "L_mul") TG_ADDR(68, 69, "L_isqrt")
-        TG_ADDR(70, 71, "L_gmin") TG_ADDR(80, 81, "L_gmax") TG_ADDR(82, 83, "L_gdiv") TG_ADDR(84, 85, "L_gdivi")
-        TG_ADDR(86, 87, "L_casin") TG_ADDR(88, 89, "L_cacos") TG_ADDR(90, 91, "L_catan") TG_ADDR(98, 99, "L_cexp")
-        TG_ADDR(96, 97, "L_clog")
-        TG_ADDR(44, 45, "L_fexp") TG_ADDR(46, 47, "L_flog") TG_ADDR(48, 49, "L_fsqrt") TG_ADDR(50, 51, "L_fdivi")
-        TG_ADDR(52, 53, "L_fdiv")
-        "s_cmp_lg_u32 s43, 0\n"
-        "s_cselect_b32 s98, s44, s98\n s_cselect_b32 s99, s45, s99\n s_cselect_b32 s96, s46, s96\n s_cselect_b32 s97, s47, s97\n"
-        "s_cselect_b32 s68, s48, s68\n s_cselect_b32 s69, s49, s69\n s_cselect_b32 s84, s50, s84\n s_cselect_b32 s85, s51, s85\n"
-        "s_cselect_b32 s82, s52, s82\n s_cselect_b32 s83, s53, s83\n"
-        "s_swappc_b64 s[38:39], s[34:35]\n"
-        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
-        "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
-        "ds_write_b32 v32, v56 offset:2048\n ds_write_b32 v32, v57 offset:2304\n"
-        "ds_write_b32 v32, v58 offset:2560\n ds_write_b32 v32, v59 offset:2816\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_branch L_end_%=\n"
-        TI_BODIES_TEXT
-        TG_LOOSE_ROUTINES
-        /* min / max of v[36:37], v[38:39] -> v[40:41] (device_math.hpp i_min / i_max); the decisions stay with the lanes:
-         * vcc = did NOT choose the lhs, s[92:93] = chose the rhs (the caller records them) */
-        "L_gmin_%=:\n"
-        "v_max_f32 v42, v38, v38\n"
-        "v_max_f32 v43, v36, v36\n"
-        "v_max_f32 v44, v39, v39\n"
-        "v_cmp_nlt_f32 vcc, v37, v38\n"                  /* !c1, c1: x.hi < y.lo */
-        "v_cmp_gt_f32 s[92:93], v36, v39\n"              /* y.hi < x.lo */
-        "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
-        "v_min_f32 v42, v43, v42\n"
-        "v_max_f32 v43, v37, v37\n"
-        "v_min_f32 v43, v43, v44\n"
-        "s_branch L_gsel_%=\n"
-        "L_gmax_%=:\n"
-        "v_max_f32 v42, v38, v38\n"
-        "v_max_f32 v43, v36, v36\n"
-        "v_max_f32 v44, v39, v39\n"
-        "v_cmp_ngt_f32 vcc, v36, v39\n"                  /* !c1, c1: x.lo > y.hi */
-        "v_cmp_lt_f32 s[92:93], v37, v38\n"              /* y.lo > x.hi */
-        "s_and_b64 s[92:93], vcc, s[92:93]\n"            /* c2 */
-        "v_max_f32 v42, v43, v42\n"
-        "v_max_f32 v43, v37, v37\n"
-        "v_max_f32 v43, v43, v44\n"
-        "L_gsel_%=:\n"
-        /* clause s76 decided from above (s[72:73] for the lhs, s[74:75] for the rhs): every lane takes that operand */
-        "s_bitcmp1_b64 s[72:73], s76\n"
-        "s_cselect_b64 s[94:95], exec, 0\n"
-        "s_andn2_b64 vcc, vcc, s[94:95]\n"
-        "s_andn2_b64 s[92:93], s[92:93], s[94:95]\n"
-        "s_bitcmp1_b64 s[74:75], s76\n"
-        "s_cselect_b64 s[94:95], exec, 0\n"
-        "s_or_b64 vcc, vcc, s[94:95]\n"
-        "s_or_b64 s[92:93], s[92:93], s[94:95]\n"
-        "v_cndmask_b32 v40, v42, v38, s[92:93]\n"
-        "v_cndmask_b32 v41, v43, v39, s[92:93]\n"
-        "v_cndmask_b32 v40, v36, v40, vcc\n"
-        "v_cndmask_b32 v41, v37, v41, vcc\n"
-        "s_setpc_b64 s[36:37]\n"
-        /* division: s[58:59] = lanes whose divisor v[38:39] contains zero (the handlers' tests, tile_interp_asm.hpp) */
-        "L_gdiv_%=:\n"
-        "v_cmp_ge_f32 s[58:59], 0, v38\n v_cmp_le_f32 vcc, 0, v39\n"
-        "s_and_b64 s[58:59], s[58:59], vcc\n s_branch L_idiv_%=\n"
-        "L_gdivi_%=:\n"                                  /* a constant divisor */
-        "v_cmp_lg_f32 s[58:59], 0, v38\n s_nop 0\n"
-        "s_not_b64 s[58:59], s[58:59]\n s_branch L_idiv_%=\n"
-        "L_end_%=:\n"
-        :
-        : [lane8] "v"(lane8), [io] "s"(ioaddr)
-        : "memory", "vcc", "scc",
-          "s34", "s35", "s36", "s37", "s38", "s39",
-          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
-          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-          "s72", "s73", "s74", "s75", "s76",
-          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
-          "s97", "s98", "s99",
-          "v32", "v33", "v34", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
-          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15",
-          "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
-          "v31", "v35", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
-          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
-          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
-          "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", TI_V10(8), TI_V10(9), TI_V10(10),
-          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117");
-    res->x = io[384 + lane];
-    res->y = io[448 + lane];
-    const uint32_t* const iw = reinterpret_cast<const uint32_t*>(io);
-    chl[0] = iw[512 + lane];
-    chl[1] = iw[576 + lane];
-    chr[0] = iw[640 + lane];
-    chr[1] = iw[704 + lane];
-}
+ *    sqrt's [0, ..] over an interval whose negative part is NaN to the float pass, asin / acos outside [-1, 1] (tapes with those
+ *    never run loose: mpr_tape::loose_ok). */
 
 /* ---- the scheduled forward walk (interval_gen.hpp; round 5) ----
  * code: the walk to run (exact or loose, of the kind the stage needs); code_exact: the exact walk of the same kind, which a loose

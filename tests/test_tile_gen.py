@@ -1,4 +1,5 @@
-"""The first tile stage runs the ROOT tape's interval walks as machine code generated on the host (csrc/tile_gen.cpp:
+"""The tile stages' BACKWARD walks and the normals pass's Deriv walk as machine code generated on the host (csrc/tile_gen.cpp; the
+forward walk: csrc/interval_gen.cpp, tests/test_interval_gen.py) —
 one short instruction sequence per clause, slots and immediates in the instruction words).  Here that code is
 disassembled with the ROCm assembler's llvm-mc and compared with the instructions it is meant to be — no GPU needed;
 tests/test_gpu_render.py runs it against the interpreter and the oracle."""
@@ -35,45 +36,7 @@ def one(mpr, c, which=0):
     """the code of a tape with the single clause c (x, y, z in slots 1, 2, 3), without the epilogue"""
     code = generated(mpr, [clause(0, 1, 2, 3), c, clause(0, (c >> 8) & 0xFF)], which)
     assert code[-1] == "s_setpc_b64 s[38:39]"
-    return code[:-3] if which == 0 else code[:-1]
-
-
-def test_forward_rows(mpr):
-    OP = mpr.OP
-    # slot s is v[68 + 2 s] (lower end), v[69 + 2 s] (upper end); round-up mode: lower ends as minus the rounded-up negation
-    assert one(mpr, clause(OP["ADD_LHS_RHS"], 4, 1, 2)) == [
-        "v_add_f32_e64 v40, -v70, -v72", "v_add_f32_e32 v77, v71, v73", "v_xor_b32_e32 v76, 0x80000000, v40"]
-    assert one(mpr, clause(OP["ADD_LHS_IMM"], 4, 4, 0, PI)) == [
-        "v_sub_f32_e32 v40, 0xc0490fdb, v76", "v_add_f32_e32 v77, 0x40490fdb, v77", "v_xor_b32_e32 v76, 0x80000000, v40"]
-    assert one(mpr, clause(OP["SUB_LHS_IMM"], 4, 1, 0, PI)) == [
-        "v_sub_f32_e32 v40, 0x40490fdb, v70", "v_subrev_f32_e32 v77, 0x40490fdb, v71", "v_xor_b32_e32 v76, 0x80000000, v40"]
-    assert one(mpr, clause(OP["SUB_IMM_RHS"], 4, 0, 2, PI)) == [
-        "v_subrev_f32_e32 v40, 0x40490fdb, v73", "v_sub_f32_e32 v77, 0x40490fdb, v72", "v_xor_b32_e32 v76, 0x80000000, v40"]
-    assert one(mpr, clause(OP["SUB_LHS_RHS"], 4, 1, 2)) == [
-        "v_sub_f32_e32 v40, v73, v70", "v_sub_f32_e32 v77, v71, v72", "v_xor_b32_e32 v76, 0x80000000, v40"]
-    # a negative factor swaps the ends, decided when the code is made
-    assert one(mpr, clause(OP["MUL_LHS_IMM"], 4, 1, 0, PI))[1:3] == ["v_mul_f32_e64 v40, -v70, v42", "v_mul_f32_e32 v77, v71, v42"]
-    assert one(mpr, clause(OP["MUL_LHS_IMM"], 4, 1, 0, MINUS_PI))[1:3] == ["v_mul_f32_e64 v40, -v71, v42", "v_mul_f32_e32 v77, v70, v42"]
-    assert one(mpr, clause(OP["NEG_LHS"], 4, 4)) == [
-        "v_xor_b32_e32 v40, 0x80000000, v77", "v_xor_b32_e32 v77, 0x80000000, v76", "v_mov_b32_e32 v76, v40"]
-    assert one(mpr, clause(OP["SIN_LHS"], 4, 1)) == ["v_mov_b32_e32 v76, -1.0", "v_mov_b32_e32 v77, 1.0"]
-    assert one(mpr, clause(OP["COPY_LHS"], 4, 4)) == []
-    # the interpreter's routines, called: operands v[36:39], result v[40:41], entry points in SGPR pairs
-    assert one(mpr, clause(OP["MUL_LHS_RHS"], 4, 1, 2)) == [
-        "v_mov_b32_e32 v36, v70", "v_mov_b32_e32 v37, v71", "v_mov_b32_e32 v38, v72", "v_mov_b32_e32 v39, v73",
-        "s_swappc_b64 s[36:37], s[66:67]", "v_mov_b32_e32 v76, v40", "v_mov_b32_e32 v77, v41"]
-    assert one(mpr, clause(OP["SQRT_LHS"], 4, 1))[2] == "s_swappc_b64 s[36:37], s[68:69]"
-    assert one(mpr, clause(OP["DIV_IMM_RHS"], 4, 0, 2, PI))[:5] == [
-        "v_mov_b32_e32 v36, 0x40490fdb", "v_mov_b32_e32 v37, v36", "v_mov_b32_e32 v38, v72", "v_mov_b32_e32 v39, v73",
-        "s_swappc_b64 s[36:37], s[82:83]"]
-    # min / max: the routine leaves the lanes' decisions in vcc (did not choose the lhs) and s[92:93] (chose the rhs); bit k
-    # of v56 / v58 keeps them for the backward walk
-    # ... and s76 tells the routine which clause it is (a stage below the first has decisions from above to impose)
-    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[0] == "s_movk_i32 s76, 0x0"
-    assert one(mpr, clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI))[5:] == [
-        "s_swappc_b64 s[36:37], s[80:81]", "v_mov_b32_e32 v76, v40", "v_mov_b32_e32 v77, v41", "v_mov_b32_e32 v42, 1",
-        "v_cndmask_b32_e64 v43, v42, 0, vcc", "v_or_b32_e32 v56, v56, v43", "v_cndmask_b32_e64 v43, 0, v42, s[92:93]",
-        "v_or_b32_e32 v58, v58, v43"]
+    return code[:-1]
 
 
 def test_backward_rows(mpr):
@@ -170,7 +133,7 @@ def test_whole_tapes(mpr):
     words = [int(w) for w in np.asarray(tape.data)]
     allowed |= {"v_mul_f32_dpp", "v_mov_b32_dpp", "v_cmp_lt_f32_e32", "v_cmp_ge_f32_e32", "v_cmp_ne_u32_e64", "s_or_b64", "s_andn2_b64"}
     allowed |= {"s_bitcmp1_b32", "s_bitcmp1_b64", "s_cbranch_scc0", "s_cbranch_scc1", "s_branch"}
-    for which in (0, 1, 2, 3):
+    for which in (1, 2, 3):
         code = generated(mpr, words, which)
         assert code is not None and code[-1] == "s_setpc_b64 s[38:39]"
         assert {l.split()[0] for l in code} <= allowed
@@ -181,46 +144,10 @@ def test_whole_tapes(mpr):
             assert sum(l.startswith("s_bitcmp1_b32") for l in code) == len(words) - 2
         elif which == 2:
             assert sum(l.startswith("s_andn2_b64 vcc") for l in code) == tape.num_choices
-        else:
-            assert sum(l.startswith("v_or_b32_e32 v56") or l.startswith("v_or_b32_e32 v57") for l in code) == tape.num_choices
     # tapes the conventions do not fit are left to the interpreter
     for name in ("architecture", "prospero"):
         t = mpr.Tape(mpr.model(name))
-        assert generated(mpr, [int(w) for w in np.asarray(t.data)], 0) is None
-
-
-def test_forward_walk_with_guarded_dead_runs(mpr, tapes):
-    """which = 4: the forward walk a frame's lean last stage runs — its tiles walk their parent's tape as the ROOT tape's code with
-    the parent's decisions imposed (s[72:73] decided for the lhs, s[74:75] for the rhs, wave-uniform), and runs of clauses that are
-    dead under those decisions are jumped over (csrc/voxel_gen.hpp: tape_dead_runs, the analysis tests/test_voxel_gen.py checks by
-    symbolic execution).  With nothing decided it runs exactly the plain forward walk; a decision skips whole clauses only."""
-    from test_voxel_gen import disassemble, walk
-    words = [int(w) for w in tapes("bear").data]
-    arr = np.array(words, dtype=np.uint64)
-    buf = (ctypes.c_uint32 * 65536)()
-    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 0, buf, 65536)
-    plain = list(buf[:n])
-    n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 4, buf, 65536)
-    guarded = list(buf[:n])
-    assert n > len(plain)
-    text = disassemble(guarded)
-    guards = [k for k, l in enumerate(text) if l.startswith("s_bitcmp1_b64 s[72:73]") or l.startswith("s_bitcmp1_b64 s[74:75]")]
-    assert len(guards) >= 30 and all(text[k + 1].startswith("s_cbranch_scc1") for k in guards)
-    ptext = [l for l in disassemble(plain) if not l.startswith("s_setpc_b64 s[38:39]")]
-    assert walk(guarded, 0, 0) == ptext
-    # decided: fewer instructions, and what runs is the plain walk with whole clauses missing (a subsequence)
-    rng = np.random.default_rng(3)
-    for trial in range(6):
-        dl = int(rng.integers(0, 1 << 27)) & ~int(rng.integers(0, 1 << 27))
-        dr = int(rng.integers(0, 1 << 27)) & ~dl & ~int(rng.integers(0, 1 << 27))
-        got = walk(guarded, dl, dr)
-        it = iter(ptext)
-        assert all(any(x == y for y in it) for x in got)
-        assert len(got) < len(ptext)
-    # tapes without a min / max clause have nothing to guard: no such code
-    sphere = [int(w) for w in tapes("sphere").data]
-    arr = np.array(sphere, dtype=np.uint64)
-    assert mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 4, buf, 65536) == 0
+        assert generated(mpr, [int(w) for w in np.asarray(t.data)], 1) is None
 
 
 def test_deriv_walk_with_guarded_dead_runs(mpr, tapes):
