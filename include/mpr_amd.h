@@ -96,9 +96,9 @@ int32_t mpr_tape_flags(const mpr_tape* t);             /* bit1: unsupported opco
 /* Does every interval operation of the tape stay, over the WHOLE view of a frame with this matrix (column-major, (dim + 1)^2; z: the
  * 2-D frame's), where the reference's interval routines are inclusion-isotone — operands finite and inside the function's domain
  * (inc/gpu_interval.hpp: log's zero bound :382-390, the NaN ends of asin / acos :306-324, a divisor that holds zero :162-190 are
- * where they are not)?  1 / 0; frames of a view that is not keep the reference's literal procedure (every stage from the 64^3
- * tiles, the correctly rounded enclosures: csrc/frame_domain.hpp).  trace: null, or 2 * length doubles for the enclosure of every
- * clause's result (tests). */
+ * where they are not)?  1 / 0.  A 3-D frame nobody reads starts at the 16^3 tiles either way: unverified when the view is tame,
+ * verified against the 64^3 tiles it skips when it is not (csrc/frame_domain.hpp).  trace: null, or 2 * length doubles for the
+ * enclosure of every clause's result (tests). */
 int mpr_tape_frame_is_tame(const mpr_tape* t, int dim, const float* mat, float z, double* trace);
 void mpr_tape_free(mpr_tape* t);
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -186,9 +187,12 @@ struct mpr_context {
     int* skip0_flag_host = nullptr;    /* host-coherent; 1: some 16^3 tile did not do what its parent would have made it do */
     int* skip0_flag_dev = nullptr;
     bool skip0_verify = true;          /* MPR_SKIP0_CHECK=0 (development): such frames go unverified */
-    uint64_t skip0_veto_serial = 0;    /* the tape whose last verified frame failed: its next frames start at the 64^3 tiles ... */
-    int skip0_veto_left = 0;           /* ... this many of them, then one tries again */
-    int skip0_veto_span = 64;          /* ... twice as many after every failure in a row */
+    /* per tape (by serial) whose last verified frame failed: its next frames start at the 64^3 tiles — `left` of them, then one tries
+     * again —, twice as many after every failure in a row (`span`), 64 again once a verified frame has passed (one triple
+     * for the whole context let two alternating tapes overwrite each other's veto, and never came down) */
+    struct Skip0Veto { int left = 0, span = 64; };
+    std::map<uint64_t, Skip0Veto> skip0_veto;
+    bool side_compare_pending = false;  /* a verification queued on the side stream has not been waited for (frame_begin does) */
     long long frames_restarted = 0;    /* frames that started over (the pool grew, a shortcut's veto, ...): mpr_debug_frame_stats */
     long long pool_growths = 0;
     bool pool_grow_pending = false;    /* the last frame's pushes filled more than 3/4 of a pool this context sized itself: it doubles before the next
@@ -881,7 +885,6 @@ struct Frame {
     int nstages = 0;
     bool reference = false;                /* the reference's way: every stage from the 64 px tiles down, every tape pushed */
     bool skip0 = false;                    /* starts at the 16^3 tiles */
-    bool tame = false;                     /* frame_domain.hpp: every interval operation stays where the reference's routines are isotone */
     bool skip0_checked = false;            /* skip0 of a frame that is not tame: verified against the 64^3 tiles before the float pass */
     mprk::Skip0ParentsArgs skip0_args;
     bool lean_first = false;               /* the first stage walks forward only and leaves records, no tapes */
@@ -922,6 +925,12 @@ static int frame_begin(Frame& f)
     const float z = f.z;
     const int32_t* const owner = f.owner;
     const bool brute = f.brute;
+    if (c && c->side_compare_pending) {
+        /* a frame that started over while its verification was still queued on the side stream: that one reads the
+         * children's notes this frame's first stage is about to rewrite, and raises a flag this frame is about to clear */
+        HIP_TRY(hipEventSynchronize(c->ev_done));
+        c->side_compare_pending = false;
+    }
     int rc = begin_frame(c, tape, owner);
     if (rc) return rc;
     if (!mat) return mpr::set_error(MPR_ERR_INVALID, "null matrix");
@@ -977,7 +986,7 @@ static int frame_begin(Frame& f)
      * themselves what the 64^3 tile would have decided for them): not where a NaN end or log's zero bound takes over — a
      * shape that leaves a function's domain somewhere in the view keeps the 64^3 stage (frame_domain.hpp) */
     bool tame = false;
-    if (!reference && (skip0 || c->tile_gen_loose)) {
+    if (!reference && skip0) {                /* (the only thing the answer decides: whether the shortcut is verified) */
         if (!c->tame_check) {
             tame = true;
         } else {
@@ -998,8 +1007,9 @@ static int frame_begin(Frame& f)
     if (skip0 && !tame && c->skip0_verify) {
         const bool can = c->gen_ok && c->gen_nchoices <= 64 && !(c->debug_tiles & 3) && c->tile_gen == 1 &&
                          mprk::tile_stage_gen_possible(nslots, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
-        const bool vetoed = c->skip0_veto_serial == tape->serial && c->skip0_veto_left > 0;
-        if (vetoed) --c->skip0_veto_left;
+        auto veto = c->skip0_veto.find(tape->serial);
+        const bool vetoed = veto != c->skip0_veto.end() && veto->second.left > 0;
+        if (vetoed) --veto->second.left;
         if (!can || vetoed) skip0 = false;
         else skip0_checked = true;
     }
@@ -1077,7 +1087,7 @@ static int frame_begin(Frame& f)
     }
     f.S = S; f.s = s; f.cnt = cnt; f.heat = heat; f.nslots = nslots; f.choice_cap = choice_cap;
     for (int k = 0; k < 3; ++k) f.stage_list[k] = stage_list[k];
-    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.tame = tame; f.skip0_checked = skip0_checked; f.lean_first = lean_first;
+    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.skip0_checked = skip0_checked; f.lean_first = lean_first;
     f.count = count; f.stage_choice_cap = stage_choice_cap; f.hint = hint;
     return MPR_OK;
 }
@@ -1186,8 +1196,7 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
         const bool verified_stage = f.skip0_checked && si == 1;
         if (verified_stage) {
             if (!a.gen_fwd || a.gen_parent) {          /* (not expected: frame_begin asked the same questions) */
-                c->skip0_veto_serial = tape->serial;
-                c->skip0_veto_left = 64;
+                c->skip0_veto[tape->serial].left = 64;
                 return FRAME_AGAIN;
             }
             a.self_info = c->skip0_children;
@@ -1393,6 +1402,7 @@ static int frame_tile_stage(Frame& f, int si)
                 HIP_TRY(hipStreamWaitEvent(c->side, c->ev_stage, 0));
                 mprk::launch_skip0_compare(c->side, f.skip0_args, c->skip0_children, c->skip0_flag_dev);
                 HIP_TRY(hipEventRecord(c->ev_done, c->side));
+                c->side_compare_pending = true;
             }
         }
         if (c->stage0_only) {
@@ -1669,11 +1679,16 @@ static bool skip0_verdict_failed(mpr_context* c, const mpr_tape* tape)
     c->skip0_unchecked = false;
     const bool normals_veto = c->skip0_normals_veto;
     c->skip0_normals_veto = false;
-    if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0 && !normals_veto) return false;
+    if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0 && !normals_veto) {
+        auto it = c->skip0_veto.find(tape->serial);
+        if (it != c->skip0_veto.end()) c->skip0_veto.erase(it);        /* a verified frame passed: the next failure starts at 64 again */
+        return false;
+    }
     /* (a view that changes may pass later: the tape tries again after 64 frames, after 128 if that fails too, ... 4096) */
-    c->skip0_veto_span = c->skip0_veto_serial == tape->serial ? std::min(c->skip0_veto_span * 2, 4096) : 64;
-    c->skip0_veto_serial = tape->serial;
-    c->skip0_veto_left = c->skip0_veto_span;
+    mpr_context::Skip0Veto& v = c->skip0_veto[tape->serial];
+    v.left = v.span;
+    v.span = std::min(v.span * 2, 4096);
+    if (c->skip0_veto.size() > 64) c->skip0_veto.erase(c->skip0_veto.begin());      /* (tapes long gone) */
     ++c->skip0_vetoes;
     return true;
 }
@@ -1699,6 +1714,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         }
         if (f.skip0_checked && !blocking) {
             HIP_TRY(hipEventSynchronize(c->ev_done));        /* (long there: two tile stages have been waited for since) */
+            c->side_compare_pending = false;
             c->skip0_unchecked = true;
             if (skip0_verdict_failed(c, tape)) continue;
         }

@@ -45,6 +45,9 @@ Iv div(const Iv& a, const Iv& b)
     return out(*std::min_element(p, p + 4), *std::max_element(p, p + 4));
 }
 bool holds_zero(const Iv& v) { return v.lo <= 0.0 && v.hi >= 0.0; }
+/* a divisor the device's float routines could see as holding zero: an end below the smallest normal number may round or flush to
+ * zero there, and the routine then returns [-inf, inf] (the same margin the logarithm's lower end has) */
+bool near_zero(const Iv& v) { return !((v.lo >= (double)FLT_MIN && v.hi >= (double)FLT_MIN) || (v.lo <= -(double)FLT_MIN && v.hi <= -(double)FLT_MIN)); }
 
 }   // namespace
 
@@ -69,7 +72,7 @@ bool frame_is_tame(const uint64_t* cl, int n, int dim, const float* mat, float z
         r[i] = out(lo, hi);
         if (!finite(r[i])) return false;
     }
-    if (holds_zero(r[dim])) return false;
+    if (near_zero(r[dim])) return false;
     for (int k = 0; k < dim; ++k) {
         axes[k] = div(r[k], r[dim]);
         if (!finite(axes[k])) return false;
@@ -144,15 +147,15 @@ bool frame_is_tame(const uint64_t* cl, int n, int dim, const float* mat, float z
             case MPR_OP_SUB_IMM_RHS: v = out(K.lo - b.hi, K.hi - b.lo); break;
             case MPR_OP_SUB_LHS_RHS: v = out(a.lo - b.hi, a.hi - b.lo); break;
             case MPR_OP_DIV_LHS_IMM:
-                if (holds_zero(K)) return false;
+                if (near_zero(K)) return false;
                 v = div(a, K);
                 break;
             case MPR_OP_DIV_IMM_RHS:
-                if (holds_zero(b)) return false;
+                if (near_zero(b)) return false;
                 v = div(K, b);
                 break;
             case MPR_OP_DIV_LHS_RHS:
-                if (holds_zero(b)) return false;
+                if (near_zero(b)) return false;
                 v = div(a, b);
                 break;
             case MPR_OP_COPY_IMM: v = K; break;

@@ -3,11 +3,14 @@
  * its domain where the reference's interval routines are inclusion-isotone (narrower operands -> a result inside the wider
  * operands' result)?
  *
- * Why it matters.  Two things this library does are the reference's procedure only as long as the interval routines are isotone:
- *  - frames that start at the 16^3 tiles with the root tape (context.hip: skip0) instead of walking the 64^3 tiles first and handing
- *    their shortened tapes down: a child then decides by itself what its parent would have decided for it — the same, if the
- *    child's intervals lie inside the parent's;
- *  - the wider enclosures of frames nobody reads (tile_gen_asm.hpp: TG_LOOSE_ROUTINES).
+ * Why it matters.  A frame that starts at the 16^3 tiles with the root tape (context.hip: skip0) instead of walking the 64^3 tiles
+ * first and handing their shortened tapes down is the reference's procedure only as long as the interval routines are isotone: a
+ * child then decides by itself what its parent would have decided for it — the same, if the child's intervals lie inside the
+ * parent's.  What the answer decides (and all it decides): a TAME frame takes that start unverified; a frame that is not takes it
+ * too, VERIFIED — the 64^3 tiles are walked beside the frame, every 16^3 tile is held against its parent, the normals pass imposes
+ * the parents' decisions, and a frame that fails is rendered again from the 64^3 tiles (kernels.hpp: Skip0ParentsArgs).  (The loose
+ * enclosures of frames nobody reads do not ask this question: they are gated by the tape — mpr_tape::loose_ok — and by the loose
+ * walk's own request for the exact one, interval_gen.hpp.)
  * The reference's routines (inc/gpu_interval.hpp) are isotone wherever their operands are finite and inside the function's domain,
  * and NOT where a special case takes over: log's lower bound 0 for x.lo <= 0 (:382-390), the NaN ends of asin / acos of an interval
  * that leaves [-1, 1] (:306-324; fmin / fmax then DROP them: a min / max with such an operand returns the other one's bounds), sqrt's

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "device_math.hpp"
 #include "kernels.hpp"
@@ -11,14 +12,23 @@
 namespace mprk {
 
 /* hipFuncSetAttribute belongs to the function ON THE DEVICE THAT IS CURRENT: a process that drives several devices (one host
- * thread per GPU, benchmark/render_table_multi.cpp) opts in once per device, not once per process.  true the first time. */
-inline bool first_use_on_this_device(std::atomic<unsigned long long>& done_mask)
-{
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    return (done_mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
-}
+ * thread per GPU, benchmark/render_table_multi.cpp) opts in once per device, not once per process.  A second thread on the same
+ * device waits until the first one has set the attributes (it could launch a kernel that needs the opt-in before). */
+struct OncePerDevice {
+    std::mutex m;
+    unsigned long long done = 0;
+    template <class F>
+    void run(F&& f)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        std::lock_guard<std::mutex> lock(m);
+        if (done & bit) return;
+        f();
+        done |= bit;
+    }
+};
 
 struct int4_ { int x, y, z, w; };
 /* src/context.cu:23-30 */

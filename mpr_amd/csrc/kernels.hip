@@ -1438,12 +1438,13 @@ void launch_skip0_compare(hipStream_t s, const Skip0ParentsArgs& a, const unsign
 /* gfx950 offers 160 KiB of LDS per workgroup; anything above the 64 KiB default must be opted in */
 static void opt_in_once()
 {
-    static std::atomic<unsigned long long> done{0};
-    if (!first_use_on_this_device(done)) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static OncePerDevice once;
+    once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
 }
 /* mask_filled_tiles, src/context.cu:471-493, as its own launch (heatmap frames only) */
 __global__ void k_mask_filled_tiles(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image)

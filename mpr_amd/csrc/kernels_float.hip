@@ -368,11 +368,12 @@ static void allow_big_lds(K kernel)
 }
 static void opt_in_once()
 {
-    static std::atomic<unsigned long long> done{0};
-    if (!first_use_on_this_device(done)) return;
-    allow_big_lds(k_eval_voxels<2>);
-    allow_big_lds(k_eval_voxels<3>);
-    allow_big_lds(k_eval_normals_q);
+    static OncePerDevice once;
+    once.run([] {
+        allow_big_lds(k_eval_voxels<2>);
+        allow_big_lds(k_eval_voxels<3>);
+        allow_big_lds(k_eval_normals_q);
+    });
 }
 size_t voxel_lds_bytes(int nslots) { return (size_t)nslots * 256 * 4; }
 void launch_eval_voxels(hipStream_t s, int dim, const VoxelArgs& a)

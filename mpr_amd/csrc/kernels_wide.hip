@@ -420,11 +420,11 @@ size_t wide_stage_lds_bytes(int nclauses)
 bool wide_stage_fits(int nclauses) { return wide_stage_lds_bytes(nclauses) <= 150 * 1024; }
 void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int threads_forced)
 {
-    static std::atomic<unsigned long long> done{0};
-    if (first_use_on_this_device(done)) {
+    static OncePerDevice once;
+    once.run([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_eval_tiles_wide<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    });
     const size_t lds = wide_stage_lds_bytes(w.nclauses);
     /* one wavefront per tile when the levels are narrow (no cross-wave barriers), four otherwise */
     const int width = w.nclauses / (w.nlevels > 0 ? w.nlevels : 1);
