@@ -369,6 +369,8 @@ def main():
     ctx = m.Context(S, device=local_rank, flags=m.CTX_TIMING_FLOAT)
     kernel_ms = {}
     frames_timed = [0]
+    timing_gather = [False]
+    gather_events = []
 
     if world > 1:
         from mpr_amd.multigpu import TileParallelRenderer
@@ -382,9 +384,18 @@ def main():
         # the collective, all on the device: no host synchronisation inside a frame
         ctx_stream = torch.cuda.ExternalStream(ctx.stream)
 
+        gather_events = []          # (start, end) around the collective on the context's stream, one pair per timed frame
+
         def all_gather(out, inp):
             with torch.cuda.stream(ctx_stream):
-                dist.all_gather_into_tensor(out, inp)
+                if timing_gather[0]:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(ctx_stream)
+                    dist.all_gather_into_tensor(out, inp)
+                    e1.record(ctx_stream)
+                    gather_events.append((e0, e1))
+                else:
+                    dist.all_gather_into_tensor(out, inp)
 
         tpr = TileParallelRenderer(ctx, m, rank, world, make_buffer, all_gather, dim=3)
         tpr.plan(tape, T, feedback=os.environ.get("MPR_BENCH_FEEDBACK") == "1")     # default: the stage-0 proxy deal, no frame in advance
@@ -407,7 +418,7 @@ def main():
         frames_timed[0] += 1
 
     verified = None
-    if world > 1 and os.environ.get("MPR_BENCH_VERIFY") == "1":
+    if world > 1:           # (always: one frame and a single-GPU frame; VERDICT r4 next-8 — one driver run tells the whole story)
         # the gathered frame of every rank against a full single-GPU frame
         frame()
         got_h, got_n = ctx.image.copy(), ctx.normals.copy()
@@ -422,6 +433,7 @@ def main():
         frame()
     barrier()
     sync()
+    timing_gather[0] = True
     t0 = time.perf_counter()
     per = []
     for _ in range(args.steps):
@@ -431,6 +443,8 @@ def main():
     sync()
     barrier()
     total_s = time.perf_counter() - t0
+    timing_gather[0] = False
+    gather_ms = [e0.elapsed_time(e1) for e0, e1 in gather_events]
     if dist is not None:
         tt = torch.tensor([total_s], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -481,8 +495,15 @@ def main():
                        "voxel_tiles": int(work["voxel_tiles"])},
             "roofline": roofline,
         }
-        if verified is not None:
+        if world > 1:
+            gm, gs = stats(gather_ms) if gather_ms else (None, None)
             out["verified_against_single_gpu"] = verified
+            out["collective"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                                 "shared_one_gpu": share,      # (MPR_BENCH_SHARE_GPU=1: a check of the code path, not a measurement)
+                                 "all_gather_ms_mean_rank0": None if gm is None else round(gm, 4), "all_gather_ms_std_rank0": None if gs is None else round(gs, 4),
+                                 "bytes_per_rank": int(tpr.per_rank * 4), "note": "HIP events around all_gather_into_tensor on the context's stream, "
+                                 "rank 0, the timed frames; the wait for the slowest rank's columns is inside"}
+            out["kernel_ms_rank0"] = {k: round(v, 4) for k, v in avg.items()}
 
     # ---- the same frame the reference's way throughout (every tile stage evaluated from the 64^3 tiles down, every tape pushed:
     #      the state a reader of tiles / tapes asks for), and the FIRST frame of a tape the context has not seen ----

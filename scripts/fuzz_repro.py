@@ -1,4 +1,4 @@
-"""Round 5: the seeds scripts/fuzz_sweep.py reported, with the scheduled interval walks on and off."""
+"""Seeds scripts/fuzz_sweep.py reports, frame by frame, with the loose enclosures on and off.  usage: fuzz_repro.py SEED:SIZE ..."""
 import faulthandler, os, sys
 faulthandler.enable()
 import numpy as np
@@ -11,7 +11,6 @@ src = open(os.path.join(ROOT, "tests", "test_gpu_fuzz_shapes.py")).read().split(
 src = src.replace("from conftest import view2, view3", "").replace("from helpers import check_default_path, compare_frame, compare_reader_frame", "")
 ns = {}
 exec(src, ns)
-exec(open(os.path.join(ROOT, "scripts", "fuzz_sweep.py")).read().split("first, count =")[0].split("def random_view3")[1].join(["def random_view3", ""]), ns) if False else None
 
 def random_view3(rng):
     V = np.eye(4, dtype=np.float32)
@@ -31,9 +30,8 @@ for seed, size in pairs:
     S = int(rng.choice([128, 256]))
     view = T if rng.random() < 0.6 else random_view3(rng)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view, 4), threads=16)
-    for sched in ("1", "0"):
+    for sched in ("-",):
         for loose in ("1", "0"):
-            os.environ["MPR_TILE_GEN_SCHED"] = sched
             os.environ["MPR_TILE_GEN_LOOSE"] = loose
             ctx = mpr.Context(S)
             out = []

@@ -1,5 +1,5 @@
 """Development aid (gpurun): a wider one-off sweep of tests/test_gpu_fuzz_shapes.py's random shapes than the suite keeps —
-default frames (3 in a row) in 3-D and 2-D against the oracle; prints the seeds that differ (as it goes: about two seeds a second,\nmost of it the oracle on the host).  usage: fuzz_sweep.py FIRST COUNT [ORACLE_THREADS]   (scripts/r05_fuzz.sh runs a dozen of these side by side)"""
+default frames (3 in a row) in 3-D and 2-D against the oracle; prints the seeds that differ (as it goes: about two seeds a second,\nmost of it the oracle on the host).  usage: fuzz_sweep.py FIRST COUNT [ORACLE_THREADS]   (scripts/fuzz_sweep_parallel.sh runs a dozen of these side by side)"""
 import os
 import sys
 

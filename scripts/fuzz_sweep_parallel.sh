@@ -1,6 +1,6 @@
 #!/bin/bash
 # scripts/fuzz_sweep.py over many seeds, a dozen processes side by side (the oracle on the host's cores is most of the time)
-# usage: r05_fuzz.sh FIRST PER_PROCESS PROCESSES TAG
+# usage: fuzz_sweep_parallel.sh FIRST PER_PROCESS PROCESSES TAG
 cd "$(dirname "$0")/.." || exit 1
 FIRST=${1:-1000}; PER=${2:-170}; N=${3:-12}; TAG=${4:-r05_fuzz}
 mkdir -p gpurun_out/$TAG

@@ -1,5 +1,6 @@
-"""Round 5 probe: per-kernel times, stage forms, redo rate of the loose scheduled walks, frame time — for a few models / sizes,
-with the scheduled interval walks on and off (MPR_TILE_GEN_SCHED).  Prints one JSON line per configuration."""
+"""Per-kernel times (HIP events: CTX_TIMING), stage forms, the share of wavefronts whose loose walk asked for the exact one
+(MPR_DEBUG_REDO) and the frame time without any of that, for a few 3-D models / sizes.  One JSON line per configuration.
+usage: stage_probe.py [MODEL:SIZE ...]"""
 import ctypes
 import json
 import os
@@ -12,8 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(model, S, frames, sched, reference=False):
-    os.environ["MPR_TILE_GEN_SCHED"] = "1" if sched else "0"
+def run(model, S, frames):
     os.environ["MPR_DEBUG_REDO"] = "1"
     import mpr_amd as m
     T = np.eye(4, dtype=np.float32)
@@ -42,7 +42,7 @@ def run(model, S, frames, sched, reference=False):
     ms = (time.perf_counter() - t0) / frames * 1e3
     tiles = ctx.frame_tiles()
     ctx.close()
-    print(json.dumps({"model": model, "S": S, "sched": sched, "ms_per_frame": round(ms, 4), "forms": forms,
+    print(json.dumps({"model": model, "S": S, "ms_per_frame": round(ms, 4), "forms": forms,
                       "kernel_ms": {k: round(v, 4) for k, v in per.items()}, "gen_waves": int(out[0]), "redone": int(out[1]),
                       "tiles": tiles}), flush=True)
 
@@ -52,5 +52,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         cfgs = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
     for model, S in cfgs:
-        for sched in (True, False):
-            run(model, S, 30 if S <= 1024 else 8, sched)
+        run(model, S, 30 if S <= 1024 else 8)
