@@ -52,6 +52,20 @@ static void save_pgm(const std::string& path, const std::vector<int32_t>& img, i
             f.put((char)(maxv ? std::min(255, img[x + y * size] * 255 / maxv) : 0));
 }
 
+/* the normals image: the three packed components as RGB (libfive::Heightmap::saveNormalPNG's picture, as a PPM) */
+static void save_ppm_normals(const std::string& path, const std::vector<uint32_t>& n, int size)
+{
+    std::ofstream f(path, std::ios::binary);
+    f << "P6\n" << size << " " << size << "\n255\n";
+    for (int y = size - 1; y >= 0; --y)
+        for (int x = 0; x < size; ++x) {
+            const uint32_t v = n[(size_t)x + (size_t)y * size];
+            f.put((char)(v & 0xFF));
+            f.put((char)((v >> 8) & 0xFF));
+            f.put((char)((v >> 16) & 0xFF));
+        }
+}
+
 int main(int argc, char** argv)
 {
     const int dim = argc > 1 ? std::atoi(argv[1]) : 2;
@@ -82,6 +96,7 @@ int main(int argc, char** argv)
             std::cout << size << " ";
             const double mean = get_stats([&]() { c.render3D(tape, T); });
             save_pgm("out_gpu_depth_" + std::to_string(size) + ".pgm", c.stages[3].filled, size, size);
+            save_ppm_normals("out_gpu_norm_" + std::to_string(size) + ".ppm", c.normals, size);     /* (render_3d_table.cpp:64-69: saveNormalPNG) */
             if (mean > 750) break;
         }
     }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mpr_amd.h"
+#include "../../include/mpr_amd_test.h"
 #include "internal.hpp"
 #include "frame_domain.hpp"
 #include "tape_builder.hpp"

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/mpr_amd.h"
+#include "../../include/mpr_amd_test.h"
 #include "../../include/mpr_effects_tables.h"
 #include "internal.hpp"
 #include "kernels.hpp"

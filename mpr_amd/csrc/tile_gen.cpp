@@ -7,6 +7,7 @@
 #include <utility>
 
 #include "../../include/mpr_clause.h"
+#include "../../include/mpr_amd_test.h"
 #include "gfx950_emit.hpp"
 #include "internal.hpp"
 #include "interval_gen.hpp"
@@ -515,8 +516,7 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     c->walk_words = g.words;
     c->nchoices = g.nchoices;
     c->vox_min_run = vox_min_run;
-    int window = 0;                                           /* development: MPR_IGEN_WINDOW=1: the tape's own order */
-    if (const char* e = getenv("MPR_IGEN_WINDOW")) window = atoi(e);
+    const int window = 0;
     for (int kind = 0; kind < 3; ++kind)
         for (int loose = 0; loose < 2; ++loose) {
             const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window, 3, false, loose ? IGEN_LEAN_VGPRS : 0);

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/mpr_clause.h"
+#include "../../include/mpr_amd_test.h"
 #include "gfx950_emit.hpp"
 
 namespace mpr {

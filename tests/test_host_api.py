@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for hdr in ("mpr_amd.h", "mpr_clause.h"):
+    for hdr in ("mpr_amd.h", "mpr_amd_test.h", "mpr_clause.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         for m in re.finditer(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(mpr_[a-z0-9_]+)\s*\(", text, flags=re.M):
