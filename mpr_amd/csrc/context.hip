@@ -1368,8 +1368,14 @@ static int frame_tile_stage(Frame& f, int si)
             const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, ((size_t)160 << 10) / mprk::wide_stage_lds_bytes(c->sched_nclauses)));
             wide_limit = 2 * std::max(c->cus, 1) * (int)per_cu;
         }
+        /* (a rank's first stage holds the whole frame's tiles, the other ranks' dead: what counts is its own — architecture 2048^3 dealt to
+         * eight ranks is 4096 tiles each, a level-parallel stage, not 64 wavefronts stepping through 1296 clauses twice: 0.29 ms of a
+         * rank's 0.68, round 5) */
+        int first_stage_tiles = count;
+        if (si == 0 && owner && !c->owner_host.empty())
+            first_stage_tiles = (int)((long long)std::count(c->owner_host.begin(), c->owner_host.end(), rank) * (count / (long long)c->owner_host.size()));
         const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) && !(c->flags & MPR_CTX_SERIAL_STAGES) &&
-                              (si == 0 ? count <= 8192 : (prev_wide && count <= wide_limit));
+                              (si == 0 ? first_stage_tiles <= 8192 : (prev_wide && count <= wide_limit));
         const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();
         /* no tapes from this stage unless the frame is inspected or this tape's last measurement said they pay */
@@ -1550,8 +1556,10 @@ static int frame_float_pass(Frame& f)
             HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
             mprk::launch_eval_voxels_gen(s, dim, v, c->gen_code + c->gen_vox_at, use_grid, c->tile_source, c->groups, c->choice_masks, group_cap,
                                          c->vox_counters, c->gen_dec[1], c->gen_nchoices,
-                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : count >= (1 << 18) ? 8 : 4);      /* (measured: bear 1024^3 0.816 ms
-                                                                                           with 8, 0.831 with 4; 256^3 0.128 / 0.113) */
+                                         /* tiles per claim: about four claims per wavefront — few tiles (a small frame, a rank's eighth of one)
+                                          * take short runs, so that no wavefront is left with a whole run while the others have none; at most
+                                          * 8 (measured: bear 1024^3 0.816 ms with 8, 0.831 with 4; 256^3 0.128 / 0.113) */
+                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(8, count / (4 * std::max(use_grid, 1)))));
             jitted = on_root_code = true;
         }
         if (!cnt && !heat && !jitted) {

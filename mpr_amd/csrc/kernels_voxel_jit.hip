@@ -1056,9 +1056,16 @@ k_eval_voxels_gen(GenVoxelArgs j)
     const int nruns = (a.count + run_len - 1) / run_len;
     for (int turn = 0; turn < VG_LISTS; ++turn) {
         const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
+        const int list_runs = (nruns - list + VG_LISTS - 1) / VG_LISTS;
         for (;;) {
             int q = 0;
-            if (lane == 0) q = atomicAdd(j.tile_counter + list * VG_COUNTER_STRIDE, 1);
+            if (lane == 0) {
+                /* a wavefront that has come to HELP with another list looks before it claims: when the frame ends every wavefront asks
+                 * every list, and 7168 claims on a word with nothing left take their 9 ns one after the other — a third of a rank's
+                 * float pass in an 8-way deal (round 5; a look before EVERY claim cost the hand-outs of the whole frame more) */
+                if (turn > 0 && __hip_atomic_load(j.tile_counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= list_runs) q = list_runs;
+                else q = atomicAdd(j.tile_counter + list * VG_COUNTER_STRIDE, 1);
+            }
             const int run = __builtin_amdgcn_readfirstlane(q) * VG_LISTS + list;
             if (run >= nruns) break;
             for (int t = run * run_len; t < min(run * run_len + run_len, a.count); ++t) {
