@@ -208,6 +208,10 @@ struct mpr_context {
     uint64_t lean_first_veto = 0;      /* the tape whose frame found a later stage that needs the tapes after all */
     uint64_t lean_first_serial = 0;    /* ... frames of this tape since it became resident */
     unsigned lean_first_frames = 0;
+    uint64_t tapes_hint_serial = 0;    /* a tape whose last stage pushes (hint: per-tile tapes): only every 32nd of its frames keeps the groups' records and
+                                        * measures the tapes again — the bookkeeping of a form the frame does not take cost architecture 1024^3 0.1 ms of
+                                        * 0.79 once the stages' atomics were out of the way (round 5) */
+    unsigned tapes_hint_frames = 0;
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     /* the scheduled interval forward walks (interval_gen.hpp) in gen_code: [kind][exact, loose] */
     int gen_iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gen_iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
@@ -887,6 +891,7 @@ struct Frame {
     bool reference = false;                /* the reference's way: every stage from the 64 px tiles down, every tape pushed */
     bool skip0 = false;                    /* starts at the 16^3 tiles */
     bool skip0_checked = false;            /* skip0 of a frame that is not tame: verified against the 64^3 tiles before the float pass */
+    bool sample_groups = true;             /* the last stage keeps its groups' records / measures its tapes (false: 31 of 32 frames of a tape that pushes) */
     mprk::Skip0ParentsArgs skip0_args;
     bool lean_first = false;               /* the first stage walks forward only and leaves records, no tapes */
     bool tiles_only = false;               /* a reader's re-render: tile stages only */
@@ -1018,6 +1023,14 @@ static int frame_begin(Frame& f)
      * pushes nothing (group form), the float pass and the normals pass run the root tape's code.  Every 32nd frame of the tape is
      * an ordinary one (its last stage's sample keeps the hint honest); a frame that finds a later stage in need of tapes after all
      * starts over and the tape stays off this path */
+    bool sample_groups = true;
+    if (!reference && hint == mpr_context::HINT_TAPES && c->measure_len_forced < 0 && !c->debug_choices && !c->groups_always) {
+        if (c->tapes_hint_serial != tape->serial) {
+            c->tapes_hint_serial = tape->serial;
+            c->tapes_hint_frames = 0;
+        }
+        sample_groups = (c->tapes_hint_frames++ % 32u) == 31u;
+    }
     bool lean_first = false;
     if (!reference && dim == 3 && nstages == 3 && c->lean_first && hint == mpr_context::HINT_GROUPS && c->lean_first_veto != tape->serial && c->gen_ok && c->tile_gen == 1 &&
         !(c->wide_stage0 && c->sched_ok) && c->tiles_asm && c->tiles_vgpr && (skip0 || c->tile_gen_chain) &&
@@ -1088,7 +1101,7 @@ static int frame_begin(Frame& f)
     }
     f.S = S; f.s = s; f.cnt = cnt; f.heat = heat; f.nslots = nslots; f.choice_cap = choice_cap;
     for (int k = 0; k < 3; ++k) f.stage_list[k] = stage_list[k];
-    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.skip0_checked = skip0_checked; f.lean_first = lean_first;
+    f.nstages = nstages; f.reference = reference; f.skip0 = skip0; f.tiles_only = tiles_only; f.key = key; f.skip0_checked = skip0_checked; f.lean_first = lean_first; f.sample_groups = sample_groups;
     f.count = count; f.stage_choice_cap = stage_choice_cap; f.hint = hint;
     return MPR_OK;
 }
@@ -1376,7 +1389,7 @@ static int frame_tile_stage(Frame& f, int si)
             first_stage_tiles = (int)((long long)std::count(c->owner_host.begin(), c->owner_host.end(), rank) * (count / (long long)c->owner_host.size()));
         const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) && !(c->flags & MPR_CTX_SERIAL_STAGES) &&
                               (si == 0 ? first_stage_tiles <= 8192 : (prev_wide && count <= wide_limit));
-        const bool groups_now = last && count > 0 && !wide_now && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
+        const bool groups_now = last && count > 0 && !wide_now && f.sample_groups && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();
         /* no tapes from this stage unless the frame is inspected or this tape's last measurement said they pay */
         const bool try_lean = groups_now && !reference && hint != mpr_context::HINT_TAPES && (dim == 2 || c->normals_asm);
@@ -1464,7 +1477,12 @@ static int frame_tile_stage(Frame& f, int si)
              * slower, involute_gear_2d 4.3x -> 5x slower) */
             /* (which groups fall into the sample varies from frame to frame — list order is the compaction's — so a tape near the
              * threshold is kept where it is: leaving a form takes 15 % more than staying out of it) */
-            const double limit = hint == mpr_context::HINT_GROUPS ? 2.3 : hint == mpr_context::HINT_TAPES ? 1.7 : 2.0;
+            /* (round 5: with the tile stages' same-address atomic gone a pushing last stage costs what its walks cost, and per-tile
+             * tapes win earlier — scripts/ab_frames.py, never / always the group form: architecture 1024^3 0.69 / 0.77 ms, 2048^3
+             * 1.56 / 1.71, involute_gear_3d 1.64 / 1.84, hello_world 0.526 / 0.592; bear (1.03x) stays: the threshold 2.0 -> 1.4) */
+            /* (a tape whose float walk the host generated — k_eval_voxels_gen, 3.4x the interpreter on bear — keeps 2.0) */
+            const double mid = vox_gen_next ? 2.0 : 1.4;
+            const double limit = hint == mpr_context::HINT_GROUPS ? mid + 0.2 : hint == mpr_context::HINT_TAPES ? mid - 0.2 : mid;
             const bool pays = (double)act3[2] <= limit * (double)act3[1];
             if (!pays) group_form = false;
             if (!reference) {

@@ -42,7 +42,11 @@ def test_architecture_2048_full_frame(mpr, orc, tapes):
     cnt, ref = compare_frame(mpr, orc, tapes("architecture"), 3, 2048, view3())
     assert (ref.image > 0).sum() > 1000000
     kinds = check_default_path(mpr, ref, tapes("architecture"), 3, 2048, view3())
-    assert all(k[0].startswith("k_eval_voxels_jit_groups") for k in kinds) and [k[1] for k in kinds] == [False, False, False], kinds
+    # architecture's 8^3 tiles shorten their tapes about 1.6x (a sample of groups, frame by frame: 1.5 .. 1.7) — past the
+    # threshold (context.hip: `pays`, 1.4) from which the last stage pushes them and the float pass walks each tile's own; a
+    # frame whose sample says otherwise takes the group form and pushes nothing.  Either way the oracle's frame (above).
+    assert all(k == ("k_eval_voxels_asm<3>", True) or (k[0].startswith("k_eval_voxels_jit_groups") and not k[1]) for k in kinds), kinds
+    assert kinds[-1] == ("k_eval_voxels_asm<3>", True), kinds
 
 
 def test_architecture_2048_sharded_over_three_contexts(mpr, orc, tapes):
