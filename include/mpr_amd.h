@@ -124,6 +124,13 @@ typedef struct mpr_ctx_options {
                                   SURVEY.md 8(d) (F / R per group of 64 list entries; the level-parallel kernel has no such
                                   groups and reports its own clause counts) */
 
+#define MPR_CTX_PARANOID 16    /* render2D / render3D render every frame that took a shortcut (a start at the 16^3 tiles, loose
+                                  enclosures, a last tile stage that pushes no tapes, generated code) a second time the
+                                  reference's way — every stage from the 64 px tiles down, the reference's enclosures, every tape
+                                  pushed and walked — and compare heights and normals of the two on the device
+                                  (mpr_ctx_paranoid_stats).  Twice the time and more: for tests and for callers that want the
+                                  equivalence argument of csrc/context.hip checked frame by frame rather than trusted */
+
 int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out);
 int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out);
 void mpr_ctx_destroy(mpr_context* ctx);
@@ -131,6 +138,9 @@ int32_t mpr_ctx_image_size(const mpr_context* ctx);    /* Context::image_size_px
 /* device memory the context holds right now: images, tile lists, the tape pool (which starts small and doubles when a frame's
  * pushes do not fit, unless mpr_ctx_options::pool_clauses names a capacity), the float pass's code regions and records */
 int64_t mpr_ctx_resident_bytes(const mpr_context* ctx);
+/* MPR_CTX_PARANOID: out = {frames rendered, frames rendered a second time the reference's way, cells (heights + normals) in which
+ * the two renderings of a frame differed — 0, or the shortcuts are not the reference's procedure for that tape and view} */
+int mpr_ctx_paranoid_stats(const mpr_context* ctx, int64_t out[3]);
 
 /* Context::render2D (src/context.cu:1136-1280).  Blocking: returns after the device has
  * finished, like the reference's cudaDeviceSynchronize at :1279. */

@@ -25,6 +25,7 @@ TILE_DTYPE = np.dtype([("position", "<i4"), ("tape", "<i4"), ("next", "<i4")])
 
 CTX_TIMING = 1
 CTX_COUNTERS = 2
+CTX_PARANOID = 16
 CTX_SERIAL_STAGES = 4
 CTX_TIMING_FLOAT = 8
 
@@ -612,6 +613,15 @@ class Context:
         """Frames whose shortcut past the 64^3 tiles failed its verification against those tiles and were rendered again from them."""
         return int(lib().mpr_ctx_skip0_vetoes(self._h))
 
+    def paranoid_stats(self):
+        """(frames rendered, frames rendered again the reference's way, cells in which the two renderings differed): CTX_PARANOID."""
+        out = (ctypes.c_int64 * 3)()
+        f = lib().mpr_ctx_paranoid_stats
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _check(f(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def dev_filled(self, stage=3):
         return lib().mpr_dev_filled(self._h, stage)
 
@@ -777,6 +787,17 @@ def dev_loose_gen(op, imm=0.0, other=(0.0, 0.0), x_is_rhs=False, first=0, count=
     f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
     _check(f(device, op, imm, other[0], other[1], int(x_is_rhs), first, count, out))
     return dict(bad=int(out[0]), example=int(out[1]), tested=int(out[2]), asked_for_exact=int(out[3]), widest=int(out[4]))
+
+
+def dev_float_in_enclosure(op, imm=0.0, first=0, count=1 << 32, device=0):
+    """The float pass's f(x) against the exact interval routine's enclosure of [x, x] on the bit patterns [first, first + count):
+    dict(tested, outside, nan_mismatch, example_outside, farthest (units of the end's last place), example_nan)."""
+    out = (ctypes.c_uint64 * 6)()
+    f = lib().mpr_test_float_in_enclosure
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    _check(f(device, op, imm, first, count, out))
+    return dict(tested=int(out[0]), outside=int(out[1]), nan_mismatch=int(out[2]), example_outside=int(out[3]), farthest=int(out[4]), example_nan=int(out[5]))
 
 
 def dev_sqrt_all(first=0, count=1 << 32, device=0):

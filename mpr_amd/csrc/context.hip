@@ -201,6 +201,12 @@ struct mpr_context {
                                         * they push is a matter of timing, the fill level moves by a few per cent from frame to frame): round 5 */
     bool skip0_normals_veto = false;   /* the last frame's normals pass could not take the 64^3 tiles' decisions (frame_normals_pass) */
     long long skip0_vetoes = 0;        /* frames rendered again (mpr_ctx_skip0_vetoes: tests) */
+    /* MPR_CTX_PARANOID: every frame that took a shortcut is rendered again the reference's way and the two frames' heights and normals
+     * are compared on the device (render_checked) */
+    int* paranoid_image = nullptr;
+    uint32_t* paranoid_normals = nullptr;
+    unsigned long long* paranoid_count = nullptr;      /* device: cells that differ (heights, normals) */
+    long long paranoid_frames = 0, paranoid_compared = 0, paranoid_cells = 0;
     /* frames that start at the 16^3 tiles, of a tape whose float pass and normals pass run on its root code with records: nobody
      * walks the tapes the first stage pushes (the sample of the last stage apart: such frames take none; every 32nd frame is an
      * ordinary one and refreshes the hint) -> no backward walk in that stage, records only (TileStageArgs::gen_forward_only) */
@@ -565,6 +571,9 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_check) (void)hipEventDestroy(c->ev_check);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->paranoid_image) (void)hipFree(c->paranoid_image);
+    if (c->paranoid_normals) (void)hipFree(c->paranoid_normals);
+    if (c->paranoid_count) (void)hipFree(c->paranoid_count);
     if (c->skip0_parents) (void)hipFree(c->skip0_parents);
     if (c->skip0_children) (void)hipFree(c->skip0_children);
     if (c->skip0_flag_host) (void)hipHostFree(c->skip0_flag_host);
@@ -891,6 +900,7 @@ struct Frame {
     bool reference = false;                /* the reference's way: every stage from the 64 px tiles down, every tape pushed */
     bool skip0 = false;                    /* starts at the 16^3 tiles */
     bool skip0_checked = false;            /* skip0 of a frame that is not tame: verified against the 64^3 tiles before the float pass */
+    bool used_loose = false;               /* a tile stage ran the loose interval code (interval_gen.hpp) */
     bool sample_groups = true;             /* the last stage keeps its groups' records / measures its tapes (false: 31 of 32 frames of a tape that pushes) */
     mprk::Skip0ParentsArgs skip0_args;
     bool lean_first = false;               /* the first stage walks forward only and leaves records, no tapes */
@@ -1224,6 +1234,7 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             a.gen_fwd2_exact = c->gen_code + c->gen_iw_at[kind][0];
             a.gen_fwd2 = a.gen_loose && c->gen_iw_dw[kind][1] > 0 ? c->gen_code + c->gen_iw_at[kind][1] : a.gen_fwd2_exact;
             if (a.gen_fwd2 == a.gen_fwd2_exact) a.gen_loose = false;
+            if (a.gen_loose && count > 0) f.used_loose = true;
             a.gen_redo_count = c->redo_count;
         }
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
@@ -1692,7 +1703,8 @@ static int frame_finish(Frame& f)
     c->frame_pending = true;
     c->pending_dim = f.dim;
     c->last_frame_lean = f.lean_now && !f.tiles_only;
-    c->last_frame_fast = (f.lean_now || f.skip0) && !f.tiles_only;
+    /* (looser enclosures decide less: tile lists and tapes of such a frame are sound, not the reference's) */
+    c->last_frame_fast = (f.lean_now || f.skip0 || f.used_loose) && !f.tiles_only;
     c->last_key = f.key;
     if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != f.tape->serial)) c->last_tape.reset(new mpr_tape(*f.tape));
     return f.blocking ? mpr_ctx_sync(c) : MPR_OK;
@@ -1795,8 +1807,54 @@ static int ensure_full_frame(mpr_context* c)
     return rc;
 }
 
+/* MPR_CTX_PARANOID: the frame both ways.  A frame that took none of the shortcuts (an instrumented one, MPR_LAST_STAGE_PUSH=1) IS the
+ * reference's procedure and is only counted.  Otherwise its heights and normals are put aside, the frame is rendered again the
+ * reference's way — every stage from the 64 px tiles down, exact enclosures, every tape pushed, float pass and normals pass on the
+ * tapes the tiles carry — and the images are compared cell by cell on the device.  The context is left holding the second frame. */
+static int render_checked(mpr_context* c, const mpr_tape* tape, int dim, const float* mat, float z, bool blocking)
+{
+    int rc = render_frame(c, tape, dim, mat, z, nullptr, 0, false, blocking);
+    if (rc || !c || !(c->flags & MPR_CTX_PARANOID)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++c->paranoid_frames;
+    if (!c->last_frame_fast) return MPR_OK;
+    const size_t n = (size_t)c->S * c->S;
+    if (!c->paranoid_image) {
+        if (hipMalloc(&c->paranoid_image, n * sizeof(int)) != hipSuccess || hipMalloc(&c->paranoid_normals, n * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(&c->paranoid_count, 2 * sizeof(unsigned long long)) != hipSuccess)
+            return mpr::set_error(MPR_ERR_ALLOC, "no memory for the second frame of a paranoid context");
+    }
+    HIP_TRY(hipMemcpyAsync(c->paranoid_image, c->filled[3], n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    if (dim == 3) HIP_TRY(hipMemcpyAsync(c->paranoid_normals, c->normals, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->force_reference = true;
+    rc = render_frame(c, tape, dim, mat, z, nullptr, 0, false, true);
+    c->force_reference = false;
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->paranoid_count, 0, 2 * sizeof(unsigned long long), c->stream));
+    mprk::launch_count_differences(c->stream, c->paranoid_image, c->filled[3], n, c->paranoid_count);
+    if (dim == 3) mprk::launch_count_differences(c->stream, reinterpret_cast<const int*>(c->paranoid_normals), reinterpret_cast<const int*>(c->normals), n, c->paranoid_count + 1);
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->paranoid_count, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++c->paranoid_compared;
+    c->paranoid_cells += (long long)(h[0] + h[1]);
+    return MPR_OK;
+}
+
 extern "C" {
 
+/* {frames rendered, frames that took a shortcut and were rendered again the reference's way, cells (heights + normals) in which the
+ * two renderings of a frame differed} since the context was made (MPR_CTX_PARANOID) */
+int mpr_ctx_paranoid_stats(const mpr_context* c, int64_t out[3])
+{
+    if (!c || !out) return mpr::set_error(MPR_ERR_INVALID, "null argument");
+    out[0] = c->paranoid_frames;
+    out[1] = c->paranoid_compared;
+    out[2] = c->paranoid_cells;
+    return MPR_OK;
+}
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
 int64_t mpr_ctx_skip0_vetoes(const mpr_context* c) { return c ? c->skip0_vetoes : 0; }
 /* development (MPR_DEBUG_REDO=1): wavefronts that ran a scheduled forward walk since the context was made, and how many of them had
@@ -1852,11 +1910,11 @@ int mpr_ctx_sync(mpr_context* c)
 
 int mpr_render2d(mpr_context* c, const mpr_tape* t, const float m[9], float z)
 {
-    return render_frame(c, t, 2, m, z, nullptr, 0, false, true);
+    return render_checked(c, t, 2, m, z, true);
 }
 int mpr_render3d(mpr_context* c, const mpr_tape* t, const float m[16])
 {
-    return render_frame(c, t, 3, m, 0.0f, nullptr, 0, false, true);
+    return render_checked(c, t, 3, m, 0.0f, true);
 }
 /* Context::render2D_heatmap / render3D_heatmap (inc/context.hpp:51-58, src/context.cu:1984-2339): a
  * normal frame whose tile and pixel kernels also accumulate the words they walk, spread over the
@@ -1893,11 +1951,11 @@ int mpr_render2d_brute(mpr_context* c, const mpr_tape* t, const float m[9], floa
 }
 int mpr_render2d_async(mpr_context* c, const mpr_tape* t, const float m[9], float z)
 {
-    return render_frame(c, t, 2, m, z, nullptr, 0, false, false);
+    return render_checked(c, t, 2, m, z, false);
 }
 int mpr_render3d_async(mpr_context* c, const mpr_tape* t, const float m[16])
 {
-    return render_frame(c, t, 3, m, 0.0f, nullptr, 0, false, false);
+    return render_checked(c, t, 3, m, 0.0f, false);
 }
 /* Per 64 x 64 column the number of first-stage tiles the interval evaluation leaves ambiguous: the work proxy the column deal of
  * SURVEY.md 8(e) uses (every rank runs the cheap 64 px stage over the whole frame, identically, and deals the columns by
@@ -2382,6 +2440,19 @@ extern "C" int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float o
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, d.p, 5 * 8, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+extern "C" int mpr_test_float_in_enclosure(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t out[6])
+{
+    if (!out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf d;
+    HIP_TRY(d.alloc(6 * 8));
+    HIP_TRY(hipMemset(d.p, 0, 6 * 8));
+    mprk::launch_test_float_in_enclosure(nullptr, op, imm, first, count, (unsigned long long*)d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d.p, 6 * 8, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
 /* development aid (scripts/walk_cycles.py): mean cycles per scheduled forward walk (interval_gen.hpp) of `clauses`, per wavefront, with

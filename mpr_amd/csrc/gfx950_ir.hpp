@@ -17,7 +17,8 @@ namespace ir {
 enum class K : uint8_t {
     NONE,
     V,      /* virtual vector register */
-    S,      /* virtual scalar register pair (a lane mask) */
+    S,      /* virtual scalar register pair (a lane mask); as a 32-bit source: its first register */
+    SH,     /* the second register of a virtual scalar register pair (32-bit sources) */
     PV,     /* physical vector register */
     PS,     /* physical scalar register: a pair's first register for 64-bit operands */
     IMM,    /* inline constant: the hardware's source code (128..248) */
@@ -28,11 +29,12 @@ enum class K : uint8_t {
 struct Opnd {
     K k = K::NONE;
     int32_t id = 0;
-    bool is_reg() const { return k == K::V || k == K::S || k == K::PV || k == K::PS || k == K::VCC; }
+    bool is_reg() const { return k == K::V || k == K::S || k == K::SH || k == K::PV || k == K::PS || k == K::VCC; }
     bool operator==(const Opnd& o) const { return k == o.k && id == o.id; }
 };
 inline Opnd V(int id) { return {K::V, id}; }
 inline Opnd S(int id) { return {K::S, id}; }
+inline Opnd SH(int id) { return {K::SH, id}; }
 inline Opnd PV(int r) { return {K::PV, r}; }
 inline Opnd PS(int r) { return {K::PS, r}; }
 inline Opnd IMM(int code) { return {K::IMM, code}; }
@@ -42,7 +44,7 @@ inline Opnd VCC() { return {K::VCC, 0}; }
 inline Opnd NONE() { return {}; }
 constexpr int C_ZERO = 128, C_ONE_I = 129, C_MINUS1_I = 193, C_HALF = 240, C_ONE = 242, C_MONE = 243, C_TWO = 244, C_FOUR = 246;
 
-enum class Fmt : uint8_t { VOP1, VOP2, VOP3, VOPC, SOP1, SOP2, SOPC, SOPK, SOPP, LABEL };
+enum class Fmt : uint8_t { VOP1, VOP2, VOP3, VOPC, SOP1, SOP2, SOPC, SOPK, SOPP, DS, LABEL };
 enum : uint16_t {
     F_TRANS = 1,        /* quarter-rate transcendental: its result needs a wait state before a non-transcendental reads it */
     F_HALF = 2,         /* issues at half rate (compares, selects) */
@@ -58,13 +60,14 @@ enum class Op : uint8_t {
     V_MOV, V_EXP, V_LOG, V_RCP, V_SQRT,
     V_CNDMASK, V_ADD_F32, V_SUB_F32, V_SUBREV_F32, V_MUL_F32, V_MIN_F32, V_MAX_F32, V_MIN_U32, V_MAX_U32, V_ASHRREV_I32,
     V_AND, V_OR, V_XOR, V_ADD_U32, V_SUB_U32,
-    V_MAX3_F32, V_MED3_F32, V_FMA_F32, V_LSHL_OR, V_BFE_U32,
+    V_MAX3_F32, V_MED3_F32, V_FMA_F32, V_LSHL_OR, V_BFE_U32, V_WRITELANE,
     C_CLASS, C_LT, C_EQ, C_LE, C_GT, C_LG, C_GE, C_O, C_U, C_NGE, C_NLG, C_NGT, C_NLE, C_NEQ, C_NLT,
     C_LT_I32, C_GT_I32, C_LT_U32, C_EQ_U32, C_LE_U32, C_GT_U32, C_NE_U32, C_GE_U32,
     S_MOV_B32, S_MOV_B64, S_NOT_B64, S_SETPC, S_SWAPPC,
     S_AND_B64, S_OR_B64, S_ANDN2_B64, S_ORN2_B64, S_XOR_B64, S_CSELECT_B64,
     S_BITCMP1_B64, S_CMP_LG_U64, S_CMP_EQ_U64,
     S_MOVK,
+    DS_WRITE_B128,
     S_NOP, S_BRANCH, S_CBRANCH_SCC0, S_CBRANCH_SCC1, S_CBRANCH_VCCZ, S_CBRANCH_VCCNZ,
     LABEL,
     COUNT
@@ -105,6 +108,8 @@ inline const OpInfo& info(Op op)
         {"v_fma_f32", Fmt::VOP3, 0, 0x1cb, 3, 0},
         {"v_lshl_or_b32", Fmt::VOP3, 0, 0x200, 3, 0},
         {"v_bfe_u32", Fmt::VOP3, 0, 0x1c8, 3, 0},
+        /* dst[lane src1] = src0 (a scalar); the other lanes keep their values: src[2] = dst, for the dependencies only */
+        {"v_writelane_b32", Fmt::VOP3, 0, 0x28a, 2, 0},
         {"v_cmp_class_f32", Fmt::VOPC, 0x10, 0x10, 2, F_HALF},
         {"v_cmp_lt_f32", Fmt::VOPC, 0x41, 0x41, 2, F_HALF},
         {"v_cmp_eq_f32", Fmt::VOPC, 0x42, 0x42, 2, F_HALF},
@@ -143,6 +148,8 @@ inline const OpInfo& info(Op op)
         {"s_cmp_lg_u64", Fmt::SOPC, 0x13, 0, 2, F_B64 | F_DEF_SCC},
         {"s_cmp_eq_u64", Fmt::SOPC, 0x12, 0, 2, F_B64 | F_DEF_SCC},
         {"s_movk_i32", Fmt::SOPK, 0, 0, 0, 0},
+        /* src[0] = address, src[1] = the first of four data registers, imm = byte offset; nothing moves across it */
+        {"ds_write_b128", Fmt::DS, 0xdf, 0, 2, F_BARRIER},
         {"s_nop", Fmt::SOPP, 0, 0, 0, 0},
         {"s_branch", Fmt::SOPP, 2, 0, 0, F_BARRIER},
         {"s_cbranch_scc0", Fmt::SOPP, 4, 0, 0, F_BARRIER | F_RD_SCC},
@@ -170,7 +177,7 @@ struct Inst {
 };
 
 /* ---- physical forms ---- */
-inline bool phys(const Opnd& o) { return o.k != K::V && o.k != K::S; }
+inline bool phys(const Opnd& o) { return o.k != K::V && o.k != K::S && o.k != K::SH; }
 /* the 9-bit source field of a physical operand */
 inline uint32_t src_code(const Opnd& o)
 {
@@ -206,7 +213,7 @@ inline int size_dw(const Inst& i)
 {
     const OpInfo& f = info(i.op);
     if (f.fmt == Fmt::LABEL) return 0;
-    if (f.fmt == Fmt::VOP3) return 2;
+    if (f.fmt == Fmt::VOP3 || f.fmt == Fmt::DS) return 2;
     if (f.fmt == Fmt::VOP1 || f.fmt == Fmt::VOP2 || f.fmt == Fmt::VOPC) return fits_e32(i) ? (i.has_lit() ? 2 : 1) : 2;
     return i.has_lit() ? 2 : 1;
 }
@@ -241,7 +248,7 @@ inline bool encode(const Inst& i, std::vector<uint32_t>& out)
             else d = (uint32_t)i.dst.id;
             if (f.fmt != Fmt::VOPC && i.dst.k != K::PV) return false;
             out.push_back(0xD0000000u | (uint32_t)f.e64 << 16 | (uint32_t)i.abs << 8 | d);
-            out.push_back(src_code(i.src[0]) | src_code(i.src[1]) << 9 | src_code(i.src[2]) << 18 | (uint32_t)i.neg << 29);
+            out.push_back(src_code(i.src[0]) | src_code(i.src[1]) << 9 | (i.op == Op::V_WRITELANE ? 0u : src_code(i.src[2]) << 18) | (uint32_t)i.neg << 29);
             return true;
         }
         case Fmt::SOP1: {
@@ -258,6 +265,11 @@ inline bool encode(const Inst& i, std::vector<uint32_t>& out)
         }
         case Fmt::SOPC:
             out.push_back(0xBF000000u | (uint32_t)f.e32 << 16 | src_code(i.src[1]) << 8 | src_code(i.src[0]));
+            return true;
+        case Fmt::DS:
+            if (i.src[0].k != K::PV || i.src[1].k != K::PV || i.imm < 0 || i.imm > 0xFFFF) return false;
+            out.push_back(0xD8000000u | (uint32_t)f.e32 << 17 | (uint32_t)i.imm);
+            out.push_back((uint32_t)i.src[0].id | (uint32_t)i.src[1].id << 8);
             return true;
         case Fmt::SOPK:
             out.push_back(0xB0000000u | (uint32_t)i.dst.id << 16 | ((uint32_t)i.imm & 0xFFFFu));
@@ -277,6 +289,7 @@ inline std::string opnd_text(const Opnd& o, bool pair, bool as_float, uint32_t l
     switch (o.k) {
         case K::V: snprintf(b, sizeof b, "%%v%d", o.id); return b;
         case K::S: snprintf(b, sizeof b, "%%s%d", o.id); return b;
+        case K::SH: snprintf(b, sizeof b, "%%s%d.hi", o.id); return b;
         case K::PV: snprintf(b, sizeof b, "v%d", o.id); return b;
         case K::PS:
             if (pair) snprintf(b, sizeof b, "s[%d:%d]", o.id, o.id + 1);
@@ -313,6 +326,11 @@ inline std::string text(const Inst& i)
     if (f.fmt == Fmt::SOPP) {
         if (i.is_branch() && !i.resolved) snprintf(b, sizeof b, "%s L%d", f.name, -i.imm - 1);
         else snprintf(b, sizeof b, "%s %d", f.name, (int)(int16_t)i.imm);
+        return b;
+    }
+    if (f.fmt == Fmt::DS) {
+        if (i.imm) snprintf(b, sizeof b, "%s v%d, v[%d:%d] offset:%d", f.name, i.src[0].id, i.src[1].id, i.src[1].id + 3, i.imm);
+        else snprintf(b, sizeof b, "%s v%d, v[%d:%d]", f.name, i.src[0].id, i.src[1].id, i.src[1].id + 3);
         return b;
     }
     if (f.fmt == Fmt::SOPK) { snprintf(b, sizeof b, "%s s%d, 0x%x", f.name, i.dst.id, (unsigned)i.imm & 0xFFFFu); return b; }

@@ -23,6 +23,8 @@ constexpr uint32_t SIGN = 0x80000000u;
 /* fixed registers of the code (interval_gen.hpp) */
 constexpr int R_OUT_LO = 36, R_OUT_HI = 37, R_ARG = 36, R_RES = 40, R_MAG = 42, R_DEC = 56;
 constexpr int S_RET_ROUTINE = 36, S_RET_CODE = 38, S_BAD = 40, S_REDO = 60, S_DEC_L = 72, S_DEC_R = 74;
+/* IW_FIRST_MASKS: the lanes that decided anything, the register with the LDS address of the lane's entry of the current group of 64 */
+constexpr int S_ANY = 78, R_CHOICE_ADDR = 60;
 
 struct IV {
     Opnd a, b;          /* exact: lo, hi; loose: -lo, hi */
@@ -402,7 +404,7 @@ struct Gen {
             c1 = cmp(Op::C_GT, A.a, B.b, 1);                        /* x.lo > y.hi */
             c2 = cmp(Op::C_GT, B.a, A.b, 1);                        /* y.lo > x.hi */
         }
-        if (kind != IW_FIRST) {
+        if (kind != IW_FIRST && kind != IW_FIRST_MASKS) {
             /* decided above: the chosen operand as it is — the other one may never have been computed (a guarded run) */
             Opnd al, ar;
             imposed(k, &al, &ar);
@@ -410,11 +412,28 @@ struct Gen {
             o.a = sel(a1, B.a, ar);
             o.b = sel(b1, B.b, ar);
         }
+        if (kind == IW_FIRST_MASKS) {
+            /* the interpreters' record of a choice (tile_interp_asm.hpp: 16 bytes in LDS, the lanes that chose the lhs / the rhs): lane
+             * k & 63 of v56..v59 takes the four halves, 64 choices go out with one store */
+            e(Op::V_WRITELANE, PV(R_DEC), c1, INT(k & 63), PV(R_DEC));
+            e(Op::V_WRITELANE, PV(R_DEC + 1), SH(c1.id), INT(k & 63), PV(R_DEC + 1));
+            e(Op::V_WRITELANE, PV(R_DEC + 2), c2, INT(k & 63), PV(R_DEC + 2));
+            e(Op::V_WRITELANE, PV(R_DEC + 3), SH(c2.id), INT(k & 63), PV(R_DEC + 3));
+            e(Op::S_OR_B64, PS(S_ANY), PS(S_ANY), c1);
+            e(Op::S_OR_B64, PS(S_ANY), PS(S_ANY), c2);
+            if ((k & 63) == 63) flush_choices(k >> 6);
+            return o;
+        }
         Opnd t = sel(INT(0), INT(1), c1);
         e(Op::V_LSHL_OR, PV(R_DEC + (k >> 5)), t, INT(k & 31), PV(R_DEC + (k >> 5)));
         Opnd u = sel(INT(0), INT(1), c2);
         e(Op::V_LSHL_OR, PV(R_DEC + 2 + (k >> 5)), u, INT(k & 31), PV(R_DEC + 2 + (k >> 5)));
         return o;
+    }
+    void flush_choices(int group)
+    {
+        Inst& w = e(Op::DS_WRITE_B128, NONE(), PV(R_CHOICE_ADDR), PV(R_DEC));
+        w.imm = group * 1024;      /* (an LDS store has read its data registers when the next instruction issues: no wait before they are written again) */
     }
     IV l_sqrt(IV A)
     {
@@ -534,6 +553,7 @@ int key_of(const Opnd& o)
     switch (o.k) {
         case K::V: return KEY_V + o.id;
         case K::S: return KEY_S + o.id;
+        case K::SH: return KEY_S + o.id;
         case K::PV: return KEY_PV + o.id;
         case K::PS: return KEY_PS + o.id;
         case K::VCC: return KEY_VCC;
@@ -672,12 +692,23 @@ struct Pools {
     std::vector<int> v_unsafe, v_safe;      /* vector registers a call may / may not clobber */
     std::vector<int> s_pairs;
 };
-Pools pools_for(bool loose, int vgpr_limit)
+Pools pools_for(bool loose, int vgpr_limit, bool big)
 {
     Pools p;
     /* (vgpr_limit: the harness that runs the code names only the vector registers below it: a wavefront with fewer registers) */
     auto range = [vgpr_limit](std::vector<int>& v, int a, int b, int step = 1) { for (int r = a; r <= b; r += step) if (step != 1 || vgpr_limit <= 0 || r < vgpr_limit) v.push_back(r); };
-    if (loose) {
+    if (loose && big) {
+        /* IW_FIRST_MASKS: the registers tile_gen_asm.hpp: tile_gen_forward_big names (those of the interpreter with 93 slots in
+         * registers: the kernel that runs it has them anyway) but the output pair, the accumulators, v56..v59 and the address in v60 */
+        range(p.v_safe, 0, 35);
+        range(p.v_safe, 38, 41);
+        range(p.v_safe, 46, 55);
+        range(p.v_safe, 61, 253);
+        range(p.s_pairs, 0, 30, 2);
+        range(p.s_pairs, 42, 58, 2);
+        range(p.s_pairs, 62, 70, 2);
+        range(p.s_pairs, 80, 98, 2);
+    } else if (loose) {
         /* no calls: everything but the output pair, the magnitude accumulators and the decision words */
         range(p.v_safe, 60, 117);
         range(p.v_safe, 0, 35);
@@ -702,7 +733,7 @@ Pools pools_for(bool loose, int vgpr_limit)
     return p;
 }
 
-bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limit, int* max_v, int* max_s)
+bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limit, bool big, int* max_v, int* max_s)
 {
     const int n = (int)code.size();
     std::vector<int> vdef(nv, -1), vlast(nv, -1), sdef(ns, -1), slast(ns, -1);
@@ -715,14 +746,14 @@ bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limi
         for (int k = 0; k < 3; ++k) {
             const Opnd& o = in.src[k];
             if (o.k == K::V) vlast[o.id] = j;
-            else if (o.k == K::S) slast[o.id] = j;
+            else if (o.k == K::S || o.k == K::SH) slast[o.id] = j;
             else if (o.k == K::PV && !pv_written[o.id]) pv_last[o.id] = j;
         }
         if (in.dst.k == K::V) { if (vdef[in.dst.id] < 0) vdef[in.dst.id] = j; vlast[in.dst.id] = std::max(vlast[in.dst.id], j); }
         else if (in.dst.k == K::S) { if (sdef[in.dst.id] < 0) sdef[in.dst.id] = j; slast[in.dst.id] = std::max(slast[in.dst.id], j); }
         else if (in.dst.k == K::PV) pv_written[in.dst.id] = 1;
     }
-    Pools pools = pools_for(loose, vgpr_limit);
+    Pools pools = pools_for(loose, vgpr_limit, big);
     std::vector<char> safe_reg(256, 0), pool_reg(256, 0);
     for (int r : pools.v_safe) safe_reg[r] = pool_reg[r] = 1;
     for (int r : pools.v_unsafe) pool_reg[r] = 1;
@@ -759,10 +790,10 @@ bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limi
                 const int id = o.id;
                 o = PV(vphys[id]);
                 if (vlast[id] == j && std::find(rel_v.begin(), rel_v.end(), id) == rel_v.end()) rel_v.push_back(id);
-            } else if (o.k == K::S) {
+            } else if (o.k == K::S || o.k == K::SH) {
                 if (sphys[o.id] < 0) return false;
                 const int id = o.id;
-                o = PS(sphys[id]);
+                o = PS(sphys[id] + (o.k == K::SH ? 1 : 0));
                 if (slast[id] == j && std::find(rel_s.begin(), rel_s.end(), id) == rel_s.end()) rel_s.push_back(id);
             }
         }
@@ -888,7 +919,9 @@ void insert_wait_states(std::vector<Inst>& code, int* nops)
 IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text, int vgpr_limit, bool report_only)
 {
     IntervalCode g;
-    if (!cl || len < 2 || kind < IW_FIRST || kind > IW_BELOW_GUARDED) return g;
+    if (!cl || len < 2 || kind < IW_FIRST || kind > IW_FIRST_MASKS) return g;
+    if (kind == IW_FIRST_MASKS && !loose) return g;           /* (tapes with asin / acos / atan: the interpreter) */
+    if (kind == IW_FIRST_MASKS) report_only = true;
     int end = -1, nch = 0;
     for (int i = 1; i < len; ++i) {
         const uint32_t op = mpr_cl_op(cl[i]);
@@ -908,7 +941,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             }
         }
     }
-    if (end < 0 || nch > IGEN_MAX_CHOICES) return g;
+    if (end < 0 || nch > (kind == IW_FIRST_MASKS ? IGEN_MAX_CHOICES_MASKS : IGEN_MAX_CHOICES)) return g;
 
     std::vector<DeadRun> runs;
     if (kind == IW_BELOW_GUARDED) {
@@ -934,6 +967,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             e.e(Op::V_SUB_F32, PV(R_MAG + 2), PV(5), PV(4));
             e.e(Op::V_MOV, PV(R_MAG + 3), INT(0));
             e.e(Op::S_MOV_B64, PS(S_BAD), INT(0));
+            if (kind == IW_FIRST_MASKS) e.e(Op::S_MOV_B64, PS(S_ANY), INT(0));
         }
         for (int a = 0; a < 3; ++a) {
             IV v;
@@ -1049,6 +1083,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
     if (!defined[(size_t)rs]) return g;
     const IV R = slot[(size_t)rs];
     const int redo_label = end + 1;
+    if (kind == IW_FIRST_MASKS && (choice & 63) != 0) e.flush_choices(choice >> 6);
     if (loose) {
         Opnd m1 = e.op2(Op::V_ADD_F32, PV(R_MAG), PV(R_MAG + 1));
         Opnd m2 = e.op2(Op::V_ADD_F32, PV(R_MAG + 2), PV(R_MAG + 3));
@@ -1099,7 +1134,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             }
         }
         int mv = 0, ms = 0;
-        if (!allocate(code, e.nv, e.ns, loose, vgpr_limit, &mv, &ms)) {
+        if (!allocate(code, e.nv, e.ns, loose, vgpr_limit, kind == IW_FIRST_MASKS, &mv, &ms)) {
             if (window > 0 && w == window && w == 1) return g;
             continue;
         }

@@ -17,16 +17,27 @@
  *  - LOOSE (frames nobody reads; tile_gen_asm.hpp explains what such a frame owes the reference): sound, slightly wider
  *    enclosures on NEGATED lower bounds (a value is (-lo, hi), so that both ends round up and sums, differences and products by
  *    constants take two instructions), products by the four-products rule, exp / log / sqrt / reciprocals from the hardware's
- *    base-2 instructions widened by their error bound, constants' reciprocals rounded on the host.  The loose walk is straight-
- *    line code: instead of testing each operand where it is used it keeps two sticky flags — the largest magnitude any product,
- *    square, quotient or exponential produced (v42..v45; below 2^120 at the end: no infinity and hence no NaN ever existed, every
- *    loose value is an ordinary real enclosure) and the lanes in which an operand left its routine's domain (s[40:41]: a negative
- *    radicand, a logarithm's lower end that is not a positive normal number, a divisor that holds zero) — and when either is
- *    raised at the end the WHOLE walk runs again on the exact code (s[60:61]: the harness's redo entry).
+ *    base-2 instructions widened by their error bound (two units in the last place assumed, checked on every float:
+ *    tests/test_gpu_primitives.py: test_loose_interval_code_on_every_float), constants' reciprocals rounded on the host.
+ *    Infinite ends are ordinary (an exp that overflows has the upper end +inf, a quotient by an interval that holds zero is
+ *    [-inf, inf]).  The loose walk is straight-line code: instead of testing each operand where it is used it keeps two sticky
+ *    flags — the lanes in which an operand left its routine's domain (s[40:41]: a negative radicand, a logarithm's lower end that
+ *    is not a positive normal number, 0 x inf in a product) and a NaN accumulator (v42..v45: the sum of the widths hi - lo of the
+ *    axes and of every product / square / quotient / exponential; a NaN end anywhere makes it a NaN, and inf - inf does) — and
+ *    when either is raised at the end the WHOLE walk runs again on the exact code (s[60:61]: the harness's redo entry; 0.1 % of
+ *    bear's wavefronts).  vgpr_limit = IGEN_LEAN_VGPRS: the code names v0..v63 only (tile_gen_asm.hpp: tile_gen_forward2_lean).
  *
  * Kinds of walk: FIRST (nobody above decided anything), BELOW (a stage below the first: the parent tile's decisions
  * s[72:73] / s[74:75] are imposed on the min / max clauses), BELOW_GUARDED (also jumps over the runs of clauses those decisions
  * leave dead — voxel_gen.hpp: tape_dead_runs; for stages that push no tapes).
+ *
+ * FIRST_MASKS (loose only; report_only implied: the code returns with the lanes that ask for the exact walk in s[40:41]): a first stage's
+ * walk for tapes beyond 24 slots / 64 min / max clauses — architecture has 93 and 488 — in the kernel whose interpreter keeps 93
+ * slots in registers (tile_interp_asm.hpp: tile_interp_asm_vgpr): values live in v0..v253 (linear scan: a tape whose live values
+ * do not fit is not taken), and a choice is recorded the way that interpreter's forward walk records it, for ITS backward walk to
+ * read: 16 bytes in LDS per min / max clause, the lanes that chose the lhs and the lanes that chose the rhs (v_writelane_b32 of the
+ * four halves into lane k & 63 of v56..v59, one ds_write_b128 per 64 choices at v60 + 1024 (k >> 6): v60 = the lane's entry of the
+ * first group); s[78:79] = the lanes that decided anything.
  *
  * Register conventions of the code (the harness: tile_gen_asm.hpp: tile_gen_forward2)
  *   in:  v0..v5 = x.lo, x.hi, y.lo, y.hi, z.lo, z.hi; s[72:73] / s[74:75] decided above; v56..v59 = 0; round-up mode, all lanes on
@@ -40,7 +51,7 @@
 
 namespace mpr {
 
-enum IntervalWalkKind : int { IW_FIRST = 0, IW_BELOW = 1, IW_BELOW_GUARDED = 2 };
+enum IntervalWalkKind : int { IW_FIRST = 0, IW_BELOW = 1, IW_BELOW_GUARDED = 2, IW_FIRST_MASKS = 3 };
 
 struct IntervalCode {
     bool ok = false;
@@ -53,6 +64,7 @@ struct IntervalCode {
 };
 
 constexpr int IGEN_MAX_CHOICES = 64;
+constexpr int IGEN_MAX_CHOICES_MASKS = 4096;    /* (the store's 16-bit offset: 64 groups of 64 entries of 16 bytes) */
 /* loose walks name vector registers below this only (interval_gen_build: vgpr_limit): the tile stages run them in wavefronts of 80
  * registers, six to a SIMD instead of four (tile_gen_asm.hpp: tile_gen_forward2_lean) */
 constexpr int IGEN_LEAN_VGPRS = 64;

@@ -1284,6 +1284,54 @@ void launch_test_loose_gen(hipStream_t s, const uint32_t* code, int op, float im
 {
     hipLaunchKernelGGL(k_test_loose_gen, dim3(6144), dim3(64), 0, s, code, op, imm, other_lo, other_hi, x_is_rhs, first, count, out);
 }
+/* Is the float pass's f(x) inside the exact interval routine's enclosure of [x, x]?  Every bit pattern of [first, first + count):
+ * out = {tested (x not a NaN), outside (both are numbers, f(x) beyond an end), one a NaN and the other not, a bit pattern outside,
+ * the largest distance beyond an end in units of the end's last place (saturated at 2^40), a bit pattern of the NaN kind}.  The
+ * premise the frames with looser enclosures rest on (a min / max the reference decides and a looser walk leaves undecided picks the
+ * same operand in the float pass) holds wherever this counts nothing. */
+__global__ void __launch_bounds__(64)
+k_test_float_in_enclosure(int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    const int lane = threadIdx.x;
+    unsigned long long tested = 0, outside = 0, nan_kind = 0, ex_out = 0, ex_nan = 0, far = 0;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 64; base < count; base += (unsigned long long)gridDim.x * 64) {
+        const uint32_t bits = (uint32_t)(first + base + lane);
+        const bool mine = base + lane < count;
+        float x = mpr_u2f(bits);
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(x));         /* round to nearest: the float pass's mode */
+        float fx = float_clause((uint32_t)op, x, x, imm);
+        float d1 = x, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
+        round_up_begin(fx, d1, d2, d3, d4, d5);
+        int c = 0;
+        const ival e = interval_clause((uint32_t)op, iv(d1, d1), iv(d1, d1), imm, c);
+        if (!mine || x != x) continue;
+        ++tested;
+        const bool fn = fx != fx, en = e.lo != e.lo || e.hi != e.hi;
+        if (fn || en) {
+            if (fn != en) { ++nan_kind; ex_nan = bits; }
+            continue;
+        }
+        if (fx < e.lo || fx > e.hi) {
+            ++outside;
+            ex_out = bits;
+            const float end = fx < e.lo ? e.lo : e.hi;
+            /* distance in units of the last place of the end (ordered integers of the two floats) */
+            auto ord = [](float v) { const int32_t b = (int32_t)mpr_f2u(v); return (long long)(b < 0 ? (int32_t)0x80000000 - b : b); };
+            long long dist = ord(fx) - ord(end);
+            if (dist < 0) dist = -dist;
+            if ((unsigned long long)dist > far) far = (unsigned long long)dist;
+        }
+    }
+    round_nearest_begin();
+    atomicAdd(&out[0], tested);
+    if (outside) { atomicAdd(&out[1], outside); out[3] = ex_out; }
+    if (nan_kind) { atomicAdd(&out[2], nan_kind); out[5] = ex_nan; }
+    atomicMax(&out[4], far);
+}
+void launch_test_float_in_enclosure(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_test_float_in_enclosure, dim3(6144), dim3(64), 0, s, op, imm, first, count, out);
+}
 /* development (scripts/walk_cycles.py): cycles a wavefront needs for one scheduled forward walk (tile_gen_forward2: the harness's LDS traffic
  * included) on tiles of a 16^3-stage-like grid; out[wave] = mean over reps.  code == null: the harness alone. */
 __global__ void __launch_bounds__(64, 4)
@@ -1424,6 +1472,18 @@ k_skip0_compare(Skip0ParentsArgs a, const unsigned long long* __restrict__ child
         }
     }
     if (bad) *reinterpret_cast<volatile int*>(flag) = 1;
+}
+/* MPR_CTX_PARANOID: cells in which two images differ, added to *out */
+__global__ void k_count_differences(const int* __restrict__ a, const int* __restrict__ b, size_t n, unsigned long long* out)
+{
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += a[i] != b[i];
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+void launch_count_differences(hipStream_t s, const int* a, const int* b, size_t n, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_count_differences, dim3(1024), dim3(256), 0, s, a, b, n, out);
 }
 void launch_skip0_parents(hipStream_t s, const Skip0ParentsArgs& a)
 {

@@ -190,10 +190,12 @@ struct Skip0ParentsArgs {
     float mat[16] = {0};
 };
 void launch_skip0_parents(hipStream_t s, const Skip0ParentsArgs& a);
+void launch_count_differences(hipStream_t s, const int* a, const int* b, size_t n, unsigned long long* out);
 void launch_test_interval_gen(hipStream_t s, const uint32_t* code, int loose, int n, const float* a_lo, const float* a_hi, const float* b_lo, const float* b_hi,
                               float* out_lo, float* out_hi, int* choice, int* asks_exact);
 void launch_test_loose_gen(hipStream_t s, const uint32_t* code, int op, float imm, float other_lo, float other_hi, int x_is_rhs, unsigned long long first,
                            unsigned long long count, unsigned long long* out);
+void launch_test_float_in_enclosure(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_debug_walk_cycles(hipStream_t s, const uint32_t* code, const uint32_t* code_exact, int reps, long long* out, unsigned int* redone, int waves);
 /* children: [64 a.count][SKIP0_INFO_U64], what the frame's first stage left (TileStageArgs::self_info); flag: host-coherent
  * memory, set to 1, never cleared.  A child that did not make a decision of its parent's again gets the reference's walk — the

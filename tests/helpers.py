@@ -73,6 +73,18 @@ def check_default_path(mpr, ref, tape, dim, S, mat, z=0.0, frames=3):
             bad = int((ctx.normals != ref.normals).sum())
             assert bad == 0, "normals of the default path differ at %d pixels (%s)" % (bad, kinds[-1])
     ctx.close()
+    # ... and the same frames in a context that renders every frame that took a shortcut a second time, the reference's way, and
+    # compares the two on the device (MPR_CTX_PARANOID): what a caller without an oracle can ask for
+    ctx = mpr.Context(S, flags=mpr.CTX_PARANOID)
+    for _ in range(2):
+        if dim == 2:
+            ctx.render2D(tape, mat, z)
+        else:
+            ctx.render3D(tape, mat)
+        assert np.array_equal(ctx.image, ref.filled[3])
+    frames_seen, again, cells = ctx.paranoid_stats()
+    assert frames_seen == 2 and cells == 0, (frames_seen, again, cells)
+    ctx.close()
     return kinds
 
 
