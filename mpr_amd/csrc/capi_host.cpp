@@ -13,6 +13,8 @@
 #include "../../include/mpr_amd.h"
 #include "../../include/mpr_amd_test.h"
 #include "internal.hpp"
+#include "interval_gen.hpp"
+#include "tile_gen.hpp"
 #include "frame_domain.hpp"
 #include "tape_builder.hpp"
 #include "tree.hpp"
@@ -134,6 +136,14 @@ static void finish_tape(mpr_tape* t)
     t->schedule = mpr::build_schedule(t->clauses.data(), (int32_t)t->clauses.size());
     /* the tape's walks as machine code, here and not in the first frame that renders it (0.4 ms of host time for bear) */
     t->code = mpr::build_tape_code(t->clauses.data(), (int)t->clauses.size(), mpr::TAPE_CODE_DEFAULT_MIN_RUN);
+    if (!t->code && t->loose_ok && t->num_slots > mpr::TILE_GEN_MAX_SLOTS && t->num_slots <= 94) {
+        /* (prospero: 32 000 instructions, 70 ms here; architecture: 6800, 20 ms) */
+        const mpr::IntervalCode ic = mpr::interval_gen_build(t->clauses.data(), (int)t->clauses.size(), mpr::IW_FIRST_MASKS, true);
+        if (ic.ok) {
+            t->big_fwd = std::make_shared<const std::vector<uint32_t>>(ic.words);
+            t->big_end = ic.walk_words;
+        }
+    }
     static std::atomic<uint64_t> serial{1};
     t->serial = serial++;
 }

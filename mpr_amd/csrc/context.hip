@@ -221,6 +221,15 @@ struct mpr_context {
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     /* the scheduled interval forward walks (interval_gen.hpp) in gen_code: [kind][exact, loose] */
     int gen_iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gen_iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    /* the resident tape's first-stage walk for the kernel with 93 slots in registers (internal.hpp: mpr_tape::big_fwd), or none */
+    uint32_t* big_code = nullptr;
+    uint32_t* big_stage = nullptr;
+    size_t big_cap_dw = 0;
+    bool big_ok = false;
+    int big_end = 0;
+    std::shared_ptr<const std::vector<uint32_t>> big_resident;
+    bool tile_gen_big = true;          /* MPR_TILE_GEN_BIG=0 (development): such tapes' first stages walk on the interpreter */
+    int big_min_tiles = 8193;          /* MPR_TILE_GEN_BIG_TILES: first stages of at least this many tiles take it rather than the level-parallel kernel (which wins up to its own limit of 8192: scripts/probe_big.py) */
     unsigned int* redo_count = nullptr;   /* MPR_DEBUG_REDO=1: {wavefronts that ran generated forward code, of them: redone on the exact code} */
     bool tile_gen_lean = true;         /* MPR_TILE_GEN_LEAN=0: loose stages that push nothing in the 128-register kernel too (four wavefronts per SIMD) */
     unsigned char* redo_flags = nullptr;  /* per workgroup of a lean stage: the launch behind it runs the wavefronts flagged here */
@@ -470,6 +479,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->wide_force = getenv("MPR_WIDE_FORCE") != nullptr;
     if (const char* e = getenv("MPR_TILES_ASM")) c->tiles_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILES_VGPR")) c->tiles_vgpr = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_BIG")) c->tile_gen_big = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_GEN_BIG_TILES")) c->big_min_tiles = atoi(e);
     if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->reference_frames = atoi(e) != 0;
     if (const char* e = getenv("MPR_SKIP_STAGE0")) c->skip_stage0 = atoi(e) != 0;
     if (const char* e = getenv("MPR_MEASURE_LEN")) c->measure_len_forced = atoi(e);
@@ -574,6 +585,8 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->paranoid_image) (void)hipFree(c->paranoid_image);
     if (c->paranoid_normals) (void)hipFree(c->paranoid_normals);
     if (c->paranoid_count) (void)hipFree(c->paranoid_count);
+    if (c->big_code) free_executable(c->big_code);
+    if (c->big_stage) (void)hipFree(c->big_stage);
     if (c->skip0_parents) (void)hipFree(c->skip0_parents);
     if (c->skip0_children) (void)hipFree(c->skip0_children);
     if (c->skip0_flag_host) (void)hipHostFree(c->skip0_flag_host);
@@ -726,6 +739,30 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                             c->gen_iw_dw[k][l] = code->iw_dw[k][l];
                         }
                 }
+            }
+        }
+        c->big_ok = false;
+        if (tape->big_fwd && c->tile_gen_big && c->tiles_asm && c->tiles_vgpr) {
+            const size_t ndw = tape->big_fwd->size();
+            if (ndw > c->big_cap_dw) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                free_executable(c->big_code);
+                if (c->big_stage) (void)hipFree(c->big_stage);
+                c->big_code = nullptr;
+                c->big_stage = nullptr;
+                c->big_cap_dw = 0;
+                const size_t want = (ndw + 1023) & ~(size_t)1023;
+                c->big_code = static_cast<uint32_t*>(alloc_executable(c->device, want * sizeof(uint32_t)));
+                if (c->big_code && hipMalloc((void**)&c->big_stage, want * sizeof(uint32_t)) == hipSuccess) c->big_cap_dw = want;
+                else (void)hipGetLastError();
+            }
+            if (c->big_cap_dw >= ndw) {
+                c->big_resident = tape->big_fwd;
+                HIP_TRY(hipMemcpyAsync(c->big_stage, tape->big_fwd->data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                mprk::launch_install_code(c->stream, c->big_code, c->big_stage, ndw, std::max(c->cus, 1));
+                HIP_TRY(hipGetLastError());
+                c->big_ok = true;
+                c->big_end = tape->big_end;
             }
         }
         /* the tape's level schedule for the wide first-stage kernel */
@@ -1116,6 +1153,16 @@ static int frame_begin(Frame& f)
     return MPR_OK;
 }
 
+/* does stage si (not level-parallel) run the tape's loose first-stage walk (mpr_tape::big_fwd)?  The first stage of a frame nobody
+ * reads, every tile on the root tape, in the kernel that keeps 93 slots in registers */
+static bool stage_takes_big_walk(const Frame& f, int si, bool wide_now)
+{
+    const mpr_context* const c = f.c;
+    return si == 0 && !f.skip0 && !wide_now && !f.reference && c->big_ok && f.count > 0 && !f.heat && !f.cnt && !(c->debug_tiles & 3) &&
+           c->tape_serial == f.tape->serial && f.tape->loose_ok && c->tile_gen_loose &&
+           mprk::tile_stage_big_possible(f.nslots, f.stage_choice_cap, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
+}
+
 /* Tile stages on the root tape's generated code (tile_gen.hpp): which code stage si runs, which records it reads and writes */
 static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bool try_lean, mprk::TileStageArgs& a)
 {
@@ -1237,9 +1284,19 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             if (a.gen_loose && count > 0) f.used_loose = true;
             a.gen_redo_count = c->redo_count;
         }
+        /* a first stage of a tape beyond the generators' 24 slots / 64 min / max clauses, on the kernel with 93 slots in registers: the
+         * tape's loose forward walk in front of the interpreter's backward walk (interval_gen.hpp: IW_FIRST_MASKS) — frames nobody reads */
+        const bool big_here = stage_takes_big_walk(f, si, wide_now) && !a.gen_fwd;
+        if (big_here) {
+            a.big_fwd = c->big_code;
+            a.big_end = c->big_end;
+            a.big_nchoices = tape->num_choices;
+            a.gen_redo_count = c->redo_count;
+            f.used_loose = true;
+        }
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
-        std::string f = count <= 0 ? "none" : wide_now ? "wide" : !a.gen_fwd ? "interp" : "gen";
+        std::string f = count <= 0 ? "none" : wide_now ? "wide" : big_here ? "interp+loosefwd" : !a.gen_fwd ? "interp" : "gen";
         if (a.gen_fwd && count > 0) {
             if (a.gen_parent) f += "/parent";
             if (a.gen_guarded) f += "+guards";
@@ -1398,7 +1455,10 @@ static int frame_tile_stage(Frame& f, int si)
         int first_stage_tiles = count;
         if (si == 0 && owner && !c->owner_host.empty())
             first_stage_tiles = (int)((long long)std::count(c->owner_host.begin(), c->owner_host.end(), rank) * (count / (long long)c->owner_host.size()));
-        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) && !(c->flags & MPR_CTX_SERIAL_STAGES) &&
+        /* (a first stage of a couple of thousand tiles and more: the tape's loose walk as generated code, 64 tiles to the wavefront, is
+         * through before the level-parallel kernel has walked its workgroup-per-tile: scripts/probe_big.py) */
+        const bool big_first = si == 0 && first_stage_tiles >= c->big_min_tiles && stage_takes_big_walk(f, si, false);
+        const bool wide_now = count > 0 && c->wide_stage0 && c->sched_ok && !heat && !(c->debug_tiles & 11) && !(c->flags & MPR_CTX_SERIAL_STAGES) && !big_first &&
                               (si == 0 ? first_stage_tiles <= 8192 : (prev_wide && count <= wide_limit));
         const bool groups_now = last && count > 0 && !wide_now && f.sample_groups && c->voxel_jit && c->voxel_asm && c->voxel_groups && !cnt && !heat && c->cus > 0 &&
                                 mprk::jit_slot_class(nslots) != 0 && stage_cap <= mprk::jit_max_choices();

@@ -37,6 +37,11 @@ struct mpr_tape {
     uint64_t serial = 0;             /* identity, so a context can cache per-tape state */
     mpr::TapeSchedule schedule;      /* dependency levels for the wide first-stage kernel (ok == false: not usable) */
     std::shared_ptr<const mpr::TapeCode> code;   /* its walks as machine code, or null */
+    /* tapes the generators above do not take (more than 24 slots or 64 min / max clauses) but the interpreter with 93 slots in registers
+     * does: a first stage's loose forward walk that records its choices for the interpreter's backward walk (interval_gen.hpp:
+     * IW_FIRST_MASKS), or null (asin / acos / atan, or more live values than there are registers) */
+    std::shared_ptr<const std::vector<uint32_t>> big_fwd;
+    int32_t big_end = 0;             /* index of the end clause */
 };
 
 namespace mpr {

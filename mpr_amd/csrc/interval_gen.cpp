@@ -703,11 +703,8 @@ Pools pools_for(bool loose, int vgpr_limit, bool big)
         range(p.v_safe, 0, 35);
         range(p.v_safe, 38, 41);
         range(p.v_safe, 46, 55);
-        range(p.v_safe, 61, 253);
-        range(p.s_pairs, 0, 30, 2);
-        range(p.s_pairs, 42, 58, 2);
-        range(p.s_pairs, 62, 70, 2);
-        range(p.s_pairs, 80, 98, 2);
+        range(p.v_safe, 64, 253);      /* (v61..v63, v254, v255: the compiler's, around the harness) */
+        range(p.s_pairs, 0, 30, 2);    /* (lane masks live a few instructions: sixteen pairs are plenty, the rest stay the compiler's) */
     } else if (loose) {
         /* no calls: everything but the output pair, the magnitude accumulators and the decision words */
         range(p.v_safe, 60, 117);

@@ -330,6 +330,25 @@ k_eval_tiles(TileStageArgs a)
             }
         }
     } else if (ASM && !LEAN) {
+        bool walked = false;
+        if constexpr (VS == TI_VS_MAX_SLOTS) {
+            if (a.big_fwd && tape == 0) {
+                uint64_t any = 0, asks = 0;
+                tile_gen_forward_big(a.big_fwd, smem, a.choice_cap, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi), make_float2(vz.lo, vz.hi),
+                                     &res_vs, &any, &asks);
+                if (a.gen_redo_count && lane == 0) atomicAdd(a.gen_redo_count + ((asks & alive_mask) ? 1 : 0), 1u);
+                if ((asks & alive_mask) == 0) {
+                    walked = true;
+                    ci = a.big_nchoices;
+                    any_choice = any & alive_mask;
+                    fwd_words = a.big_end;
+                    nclauses = a.big_end - 1;
+                    end_index = a.big_end;
+                    d = tro[end_index];
+                }
+            }
+        }
+        if (!walked) {
         const TileInterpResult ir =
             VS ? tile_interp_asm_vgpr<(VS ? VS : TI_VS_MAX_SLOTS)>(tro, (uint32_t)(tape + 1), smem, lane, alive_mask, a.choice_cap, &first_block,
                                       2u * ((uint32_t)(head0 >> 8) & 0xFFu), 2u * ((uint32_t)(head0 >> 16) & 0xFFu),
@@ -342,6 +361,7 @@ k_eval_tiles(TileStageArgs a)
         nclauses = ir.words - 1;
         end_index = ir.end_index;
         d = tro[end_index];
+        }
     } else if (!LEAN) {
         int base = tape + 1;
         uint64_t blk = tro[base + lane];
@@ -1555,6 +1575,12 @@ static bool tile_stage_uses_asm(int nslots, long long pool_cap, bool compiled_wa
 bool tile_stage_gen_possible(int nslots, long long pool_cap, bool compiled_walk, bool vgpr_slots, int debug)
 {
     return tile_stage_uses_asm(nslots, pool_cap, compiled_walk, debug) && vgpr_slots && nslots <= TI_VS_SMALL_SLOTS;
+}
+/* ... and for "this launch runs the kernel with 93 slots in registers", the one that takes TileStageArgs::big_fwd */
+bool tile_stage_big_possible(int nslots, int choice_cap, long long pool_cap, bool compiled_walk, bool vgpr_slots, int debug)
+{
+    return tile_stage_uses_asm(nslots, pool_cap, compiled_walk, debug) && vgpr_slots && !(debug & 4) &&
+           tile_stage_vgpr_class(nslots, choice_cap) == TI_VS_MAX_SLOTS;
 }
 bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
 {

@@ -90,6 +90,11 @@ struct TileStageArgs {
     unsigned char* redo_flags = nullptr;
     const unsigned char* only_flagged = nullptr;
     unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
+    /* k_eval_tiles<.., 93>, tiles on the ROOT tape (a first stage; frames nobody reads): the tape's loose forward walk with the choices
+     * recorded for the interpreter's backward walk (interval_gen.hpp: IW_FIRST_MASKS); a wavefront in which a live tile asks for the
+     * exact walk runs the interpreter's.  big_end: index of the end clause, big_nchoices: min / max clauses */
+    const uint32_t* big_fwd = nullptr;
+    int big_end = 0, big_nchoices = 0;
     bool gen_guarded = false;            /* with gen_parent: the walk that jumps over the runs the parents' decisions leave dead (interval_gen.hpp:
                                           * IW_BELOW_GUARDED; stages that push nothing) */
     bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened
@@ -216,6 +221,7 @@ size_t tile_stage_lds_bytes(int nslots, int choice_cap);
 /* returns whether the launch ran the root tape's generated code (a.gen_fwd given and tile_stage_gen_possible) */
 bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a);
 bool tile_stage_gen_possible(int nslots, long long pool_cap, bool compiled_walk, bool vgpr_slots, int debug);
+bool tile_stage_big_possible(int nslots, int choice_cap, long long pool_cap, bool compiled_walk, bool vgpr_slots, int debug);
 /* host-generated code (tile_gen.hpp) into executable memory: copied by a kernel, then every CU drops its instruction cache */
 void launch_install_code(hipStream_t s, uint32_t* exec_dst, const uint32_t* src, size_t dwords, int cus);
 bool wide_stage_fits(int nclauses);

@@ -189,6 +189,50 @@ DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, in
     if (bad_lane) *bad_lane = iw[768 + lane];
 }
 
+/* A first stage's walk of a tape beyond 24 slots / 64 min / max clauses (interval_gen.hpp: IW_FIRST_MASKS; loose, no routines) inside
+ * the kernel whose interpreter keeps 93 slots in registers: the code names v0..v60 and v64..v253, records its choices where that
+ * interpreter's forward walk records them — smem: ulonglong2[choice_cap], then [8][64] floats of scratch (tile_interp_asm.hpp:
+ * tile_interp_asm_vgpr) — and returns the lanes that decided anything and the lanes that ask for the exact walk (the caller
+ * runs the interpreter then: nothing the code wrote is kept). */
+DEV void tile_gen_forward_big(const uint32_t* code, unsigned char* smem, int choice_cap, int lane, float2 x, float2 y, float2 z,
+                              float2* res, uint64_t* any_choice, uint64_t* asks_exact)
+{
+    float* const io = reinterpret_cast<float*>(smem + (size_t)choice_cap * 16);
+    io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
+    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
+    const uint32_t caddr = rdfirst((uint32_t)(uintptr_t)smem);
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    uint32_t anylo = 0, anyhi = 0, badlo = 0, badhi = 0;
+    asm volatile(
+        "v_add_u32 v32, %[io], %[lane4]\n"
+        "ds_read_b32 v0, v32\n ds_read_b32 v1, v32 offset:256\n ds_read_b32 v2, v32 offset:512\n"
+        "ds_read_b32 v3, v32 offset:768\n ds_read_b32 v4, v32 offset:1024\n ds_read_b32 v5, v32 offset:1280\n"
+        "v_lshlrev_b32 v60, 2, %[lane4]\n"
+        "v_add_u32 v60, %[caddr], v60\n"                    /* the lane's entry of the first 64 choices */
+        "s_mov_b32 s34, %[clo]\n s_mov_b32 s35, %[chi]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_swappc_b64 s[38:39], s[34:35]\n"
+        "v_add_u32 v32, %[io], %[lane4]\n"
+        "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
+        "s_mov_b32 %[anylo], s78\n s_mov_b32 %[anyhi], s79\n s_mov_b32 %[badlo], s40\n s_mov_b32 %[badhi], s41\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [anylo] "=&s"(anylo), [anyhi] "=&s"(anyhi), [badlo] "=&s"(badlo), [badhi] "=&s"(badhi)
+        : [lane4] "v"(lane4), [io] "s"(ioaddr), [caddr] "s"(caddr), [clo] "s"(clo), [chi] "s"(chi)
+        : "memory", "vcc", "scc",
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
+          "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s78", "s79",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", TI_V10(1), TI_V10(2), TI_V10(3), TI_V10(4), TI_V10(5), "v60",
+          "v64", "v65", "v66", "v67", "v68", "v69", TI_V10(7), TI_V10(8), TI_V10(9), TI_V10(10), TI_V10(11),
+          TI_V10(12), TI_V10(13), TI_V10(14), TI_V10(15), TI_V10(16), TI_V10(17), TI_V10(18), TI_V10(19), TI_V10(20),
+          TI_V10(21), TI_V10(22), TI_V10(23), TI_V10(24), "v250", "v251", "v252", "v253");
+    res->x = io[384 + lane];
+    res->y = io[448 + lane];
+    *any_choice = ((uint64_t)anyhi << 32) | anylo;
+    *asks_exact = ((uint64_t)badhi << 32) | badlo;
+}
+
 /* The backward walk.  Per lane in: active (bit = slot: the end clause's out slot for a pushing lane, 0 otherwise), pos = pool
  * index of the last word written (the end clause), first = first index of its chunk, run_end = first index past its run of
  * chunks; the decisions.  Out: pos and first where the walk stopped (the head goes to pos - 1), overflow (ran out of chunks),

@@ -115,6 +115,8 @@ class Emu:
         self.trans_written = {}                    # hazard bookkeeping: vgpr -> executed index of a transcendental write
         self.sgpr_valu_written = {}                # sgpr base -> executed index of a VALU write
         self.hazards = []
+        self.lane_writes = {}                      # v_writelane_b32: vgpr -> lane -> (scalar pair, half, the mask written)
+        self.choice_masks = {}                     # ds_write_b128 of v[56:59]: choice -> (lanes that chose the lhs, the rhs)
 
     @staticmethod
     def parse(line):
@@ -183,6 +185,11 @@ class Emu:
                 w = self.trans_written.get(int(m.group(1)))
                 if w is not None and self.executed - w < 1:
                     self.hazards.append((idx, "transcendental result read with no wait state: " + name + " " + ", ".join(ops)))
+        if name == "v_writelane_b32":
+            r = int(ops[1][1:]) & ~1
+            w = self.sgpr_valu_written.get(r)
+            if w is not None and self.executed - w < 2:
+                self.hazards.append((idx, "scalar register read %d instruction(s) after a VALU wrote it: %s" % (self.executed - w, ", ".join(ops))))
         if name == "v_cndmask_b32" and len(ops) == 4:
             r = self.sreg(ops[3])
             w = self.sgpr_valu_written.get(r)
@@ -223,6 +230,23 @@ class Emu:
                 continue
             if name.startswith("s_"):
                 self.salu(name, ops)
+            elif name == "v_writelane_b32":
+                # one lane of a register takes half of a lane mask (the masks here are n lanes wide: kept whole, with the half's name)
+                s_ = int(ops[1][1:])
+                if (s_ & ~1) not in self.mask:
+                    raise ValueError("lane mask s[%d:%d] read before it is written" % (s_ & ~1, (s_ & ~1) + 1))
+                self.lane_writes.setdefault(int(ops[0][1:]), {})[int(ops[2])] = (s_ & ~1, s_ & 1, self.mask[s_ & ~1].copy())
+            elif name == "ds_write_b128":
+                m = re.fullmatch(r"v\[(\d+):(\d+)\](?: offset:(\d+))?", ops[1].strip())
+                assert ops[0] == "v60" and m and (int(m.group(1)), int(m.group(2))) == (56, 59), ops
+                group = int(m.group(3) or 0) // 1024
+                for lane in range(64):
+                    parts = [self.lane_writes.get(r, {}).get(lane) for r in (56, 57, 58, 59)]
+                    if any(p is None for p in parts):
+                        continue
+                    assert parts[0][:2] == (parts[1][0], 0) and parts[1][1] == 1 and parts[2][:2] == (parts[3][0], 0) and parts[3][1] == 1, (lane, [p[:2] for p in parts])
+                    assert (parts[0][2] == parts[1][2]).all() and (parts[2][2] == parts[3][2]).all()
+                    self.choice_masks[group * 64 + lane] = (parts[0][2], parts[2][2])
             else:
                 self.valu(name, ops)
             i = nxt

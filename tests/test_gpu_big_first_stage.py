@@ -1,0 +1,87 @@
+"""First stages of tapes beyond the generators' 24 slots / 64 min / max clauses on the tape's own loose forward walk (csrc/interval_gen.hpp:
+IW_FIRST_MASKS, host-generated code in the kernel whose interpreter keeps 93 slots in registers) in front of that interpreter's backward
+walk: architecture from 1536^3 on by default (32 768 first-stage tiles at 2048^3: past the level-parallel kernel's limit; 0.33 ms on the
+interpreter, 0.215 ms this way), any size with MPR_TILE_GEN_BIG_TILES=1.  The walk decides no more than the reference's: the tapes it
+pushes are supersets, the frame's heights and normals the oracle's, and a reader gets the frame rendered again the reference's way."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import view2, view3
+from helpers import check_default_path, compare_reader_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def redo_counts(mpr, ctx):
+    out = (ctypes.c_uint32 * 2)()
+    mpr.lib().mpr_debug_redo_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    mpr.lib().mpr_debug_redo_counts(ctx._h, out)
+    return int(out[0]), int(out[1])
+
+
+@pytest.mark.parametrize("name,dim,S", [("architecture", 3, 256), ("architecture", 3, 512), ("prospero", 2, 512), ("prospero", 2, 1024)])
+def test_first_stage_on_the_loose_walk_matches_the_oracle(mpr, orc, tapes, name, dim, S, monkeypatch):
+    monkeypatch.setenv("MPR_TILE_GEN_BIG_TILES", "1")
+    monkeypatch.setenv("MPR_DEBUG_REDO", "1")
+    tape = tapes(name)
+    mat = view3() if dim == 3 else view2()
+    ref = orc.Frame(tape.data, dim, S, mpr.colmajor(mat, dim + 1), threads=0)
+    ctx = mpr.Context(S)
+    for _ in range(3):
+        if dim == 3:
+            ctx.render3D(tape, mat)
+            assert np.array_equal(ctx.normals, ref.normals)
+        else:
+            ctx.render2D(tape, mat)
+        assert np.array_equal(ctx.image, ref.filled[3])
+        assert ctx.tile_stage_forms().startswith("0:interp+loosefwd"), ctx.tile_stage_forms()
+    walks, fell_back = redo_counts(mpr, ctx)
+    assert walks > 0 and fell_back == 0, (walks, fell_back)      # (nothing in these views leaves a routine's domain)
+    ctx.close()
+    check_default_path(mpr, ref, tape, dim, S, mat)              # (... and both renderings of the frame compared on the device)
+    if dim == 3:
+        # a reader after such frames: the reference's tiles and tapes, stage by stage
+        ctx, _ = compare_reader_frame(mpr, orc, tape, S, mat, ref=ref, frames=2)
+        ctx.close()
+
+
+def test_wavefronts_that_leave_a_domain_fall_back_on_the_interpreter(mpr, orc, monkeypatch):
+    """sqrt of a value that is negative in the far third of the view (a wavefront of the first stage at 512^3 is one z layer of 64 tiles):
+    the loose walk raises its flag there (the reference's NaN is near) and the wavefront runs the interpreter's forward walk instead —
+    same frame."""
+    X, Y, Z = mpr.Tree.X(), mpr.Tree.Y(), mpr.Tree.Z()
+    terms = [(X - (i % 13) * 0.11 + 0.6) * (Y + (i % 7) * 0.13 - 0.4) + Z * (0.01 * i) for i in range(40)]
+    prod = terms[0]
+    for s_ in terms[1:]:
+        prod = mpr.tmax(prod * 0.5, s_)
+    total = terms[0]
+    for s_ in terms[1:]:
+        total = total + s_
+    t = mpr.tmin(mpr.tmin(prod - 0.2, total * 0.01 - 0.05), mpr.sqrt(Z + 0.25) - 0.6 + X * X)
+    tape = mpr.Tape(t)
+    assert tape.num_slots > 24
+    monkeypatch.setenv("MPR_TILE_GEN_BIG_TILES", "1")
+    monkeypatch.setenv("MPR_DEBUG_REDO", "1")
+    S = 512
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
+    ctx = mpr.Context(S)
+    for _ in range(2):
+        ctx.render3D(tape, view3())
+        assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals)
+        assert ctx.tile_stage_forms().startswith("0:interp+loosefwd"), ctx.tile_stage_forms()
+    walks, fell_back = redo_counts(mpr, ctx)
+    assert 0 < fell_back < walks, (walks, fell_back)
+    ctx.close()
+    check_default_path(mpr, ref, tape, 3, S, view3())
+
+
+def test_switched_off(mpr, orc, tapes, monkeypatch):
+    monkeypatch.setenv("MPR_TILE_GEN_BIG", "0")
+    monkeypatch.setenv("MPR_TILE_GEN_BIG_TILES", "1")
+    tape = tapes("architecture")
+    ctx = mpr.Context(256)
+    ctx.render3D(tape, view3())
+    assert "loosefwd" not in ctx.tile_stage_forms()
+    ctx.close()

@@ -17,7 +17,7 @@ from gfx_emu import Emu, f2u, u2f
 
 LLVM_MC = "/opt/rocm/lib/llvm/bin/llvm-mc"
 pytestmark = pytest.mark.skipif(not os.path.exists(LLVM_MC), reason="llvm-mc not found")
-FIRST, BELOW, GUARDED = 0, 1, 2
+FIRST, BELOW, GUARDED, MASKS = 0, 1, 2, 3
 ROUTINE_OP = {68: "SQRT_LHS", 82: "DIV_LHS_RHS", 84: "DIV_LHS_RHS", 86: "ASIN_LHS", 88: "ACOS_LHS", 90: "ATAN_LHS", 98: "EXP_LHS", 96: "LOG_LHS"}
 
 
@@ -31,7 +31,8 @@ def generate(mpr, words, kind, loose, window=0, min_run=3):
     txt = ctypes.create_string_buffer(8_000_000)
     info = (ctypes.c_int32 * 8)()
     # (loose = 3: loose code for the harness with 64 vector registers, as the tile stages run it)
-    n = f(arr.ctypes.data, len(arr), kind, 3 if loose else 0, window, min_run, buf, 400000, txt, 8_000_000, info)
+    # (MASKS: the first-stage walk of tapes of up to 93 slots, all registers)
+    n = f(arr.ctypes.data, len(arr), kind, (1 if kind == MASKS else 3) if loose else 0, window, min_run, buf, 400000, txt, 8_000_000, info)
     if n < 0:
         return None
     names = ["instructions", "nops", "window", "max_vgprs", "max_sgpr_pairs", "nchoices", "est_cycles"]
@@ -339,3 +340,52 @@ def test_the_schedule_is_shorter_than_the_tape_order(mpr, tapes):
     assert max(int(r) for l in lines for r in re.findall(r"\bv(\d+)", l)) <= 63
     # tapes the loose arithmetic does not take (asin / acos / atan: the exact routines only)
     assert generate(mpr, [int(w) for w in tapes("trig").data], FIRST, True) is None
+
+
+@pytest.mark.parametrize("name", ["architecture", "hello_world", "bear", "smooth", "two_spheres", "many_slots"])
+def test_masks_code_of_a_first_stage_encloses_the_oracle_and_records_its_choices(mpr, orc, tapes, name):
+    """IW_FIRST_MASKS (csrc/interval_gen.hpp): the loose first-stage walk of tapes beyond 24 slots / 64 min / max clauses — architecture:
+    93 and 488 — with the choices recorded as the interpreter records them (16 bytes per min / max clause: the lanes that chose the
+    lhs, the lanes that chose the rhs), for the interpreter's backward walk.  The assembler's words; no missing wait state; the
+    enclosures hold the oracle's; a lane the code records as decided the oracle decides the same way; s[78:79] = the lanes that
+    decided anything."""
+    words = [int(w) for w in tapes(name).data]
+    g = generate(mpr, words, MASKS, True)
+    if name == "many_slots":
+        assert g is None            # 150 values alive at once: 300 registers
+        return
+    lines, sizes, info = checked_code(mpr, words, MASKS, True)
+    assert any(l.startswith("ds_write_b128 v60, v[56:59]") for l in lines)
+    nch = info["nchoices"]
+    assert sum(l.startswith("ds_write_b128") for l in lines) == (nch + 63) // 64
+    if name == "architecture":
+        assert nch == 488 and 150 < info["max_vgprs"] <= 243 and info["instructions"] < 7500, info
+    rng = np.random.default_rng(5)
+    clean = 0
+    for trial in range(2):
+        x, y, z = tiles(rng, 96)
+        (elo, ehi), choices = oracle_walk(mpr, orc, words, x, y, z)
+        n = len(x[0])
+        emu = Emu(lines, sizes, n, rng=rng, perturb=True, call=oracle_call(mpr, orc))
+        for a, (lo_, hi_) in enumerate((x, y, z)):
+            emu.v[2 * a] = f2u(lo_)
+            emu.v[2 * a + 1] = f2u(hi_)
+        assert emu.run() == "done"
+        assert not emu.hazards, emu.hazards[:3]
+        lo, hi = u2f(emu.v[36]), u2f(emu.v[37])
+        ok = ~emu.mask[40]                                        # s[40:41]: the lanes that ask for the exact walk
+        clean += int(ok.sum())
+        assert (lo[ok] <= elo[ok]).all() and (hi[ok] >= ehi[ok]).all(), name
+        assert sorted(emu.choice_masks)[:nch] == list(range(nch))
+        anyone = np.zeros(n, dtype=bool)
+        for k in range(nch):
+            ml, mr = emu.choice_masks[k]
+            assert not (ml & mr).any()
+            assert not (ml & ok & (choices[k] != 1)).any() and not (mr & ok & (choices[k] != 2)).any(), (name, k)
+            anyone |= ml | mr
+        assert (emu.mask[78] == anyone).all()
+        # ... and it decides nearly everything the oracle decides
+        decided_o = sum(int(((c != 0) & ok).sum()) for c in choices)
+        decided_g = sum(int(((emu.choice_masks[k][0] | emu.choice_masks[k][1]) & ok).sum()) for k in range(nch))
+        assert decided_g >= 0.98 * decided_o, (decided_g, decided_o)
+    assert clean > 100
