@@ -77,6 +77,9 @@ int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t 
  * scheduler's cycle estimate.  Returns the number of dwords, -1 for a tape the generator does not take */
 int mpr_test_interval_gen(const uint64_t* clauses, int32_t len, int32_t kind, int32_t loose, int32_t window, int32_t min_run, uint32_t* out,
                           int32_t cap, char* text_out, int32_t text_cap, int32_t* info);
+/* One clause (x in every operand it has) through the host-generated float walk (csrc/voxel_gen.hpp) on every bit pattern of [first, first +
+ * count) against the float pass's definition (csrc/device_math.hpp: float_clause): out = {tested, differing, an input that differs} */
+int mpr_test_float_gen_all(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t out[3]);
 /* Is the float pass's f(x) (csrc/device_math.hpp: float_clause; every form of the float pass is held bit for bit against it) inside
  * the exact interval routine's enclosure of [x, x] (interval_clause: the reference's inc/gpu_interval.hpp:306-390)?  Every bit
  * pattern of [first, first + count): out = {tested, f(x) beyond an end, one of the two a NaN and the other not, a bit pattern

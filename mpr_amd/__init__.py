@@ -789,6 +789,17 @@ def dev_loose_gen(op, imm=0.0, other=(0.0, 0.0), x_is_rhs=False, first=0, count=
     return dict(bad=int(out[0]), example=int(out[1]), tested=int(out[2]), asked_for_exact=int(out[3]), widest=int(out[4]))
 
 
+def dev_float_gen_all(op, imm=0.0, first=0, count=1 << 32, device=0):
+    """One clause through the host-generated float walk on the bit patterns [first, first + count) against float_clause:
+    dict(tested, bad, example)."""
+    out = (ctypes.c_uint64 * 3)()
+    f = lib().mpr_test_float_gen_all
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    _check(f(device, op, imm, first, count, out))
+    return dict(tested=int(out[0]), bad=int(out[1]), example=int(out[2]))
+
+
 def dev_float_in_enclosure(op, imm=0.0, first=0, count=1 << 32, device=0):
     """The float pass's f(x) against the exact interval routine's enclosure of [x, x] on the bit patterns [first, first + count):
     dict(tested, outside, nan_mismatch, example_outside, farthest (units of the end's last place), example_nan)."""

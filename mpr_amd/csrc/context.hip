@@ -2676,6 +2676,39 @@ int mpr_test_float_op_gen(int32_t device, int32_t op, int32_t variant, uint64_t 
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
+/* a clause with one operand (x in the lhs, and in the rhs where the opcode has one) through the host-generated float walk on every bit
+ * pattern of [first, first + count) against the float pass's definition: out = {tested, differing, an input that differs} */
+int mpr_test_float_gen_all(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t out[3])
+{
+    if (!out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t immbits;
+    memcpy(&immbits, &imm, 4);
+    const bool has_r = op == MPR_OP_ADD_LHS_RHS || op == MPR_OP_MUL_LHS_RHS || op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS || op == MPR_OP_SUB_IMM_RHS ||
+                       op == MPR_OP_SUB_LHS_RHS || op == MPR_OP_DIV_IMM_RHS || op == MPR_OP_DIV_LHS_RHS;
+    const bool has_l = !(op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_DIV_IMM_RHS);
+    const uint64_t tape[3] = {mpr_cl_make(0, 1, 2, 3, 0), mpr_cl_make((uint32_t)op, 4, has_l ? 1 : 0, has_r ? 2 : 0, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
+    const mpr::VoxelGen g = mpr::voxel_gen_build(tape, 3, 1);
+    if (!g.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "no generated code for this clause");
+    const size_t cbytes = (g.code.size() + 64) * sizeof(uint32_t);
+    DevBuf dc, d;
+    HIP_TRY(dc.alloc(cbytes));
+    HIP_TRY(d.alloc(3 * 8));
+    HIP_TRY(hipMemset(d.p, 0, 3 * 8));
+    HIP_TRY(hipMemcpy(dc.p, g.code.data(), g.code.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    uint32_t* code = static_cast<uint32_t*>(alloc_executable(device, cbytes));
+    if (!code) return mpr::set_error(MPR_ERR_UNSUPPORTED, "no executable device memory");
+    int cus = 1;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    mprk::launch_install_code(nullptr, code, (const uint32_t*)dc.p, g.code.size(), std::max(cus, 1));
+    mprk::launch_test_float_gen_all(nullptr, code, op, imm, first, count, (unsigned long long*)d.p);
+    const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+    free_executable(code);
+    HIP_TRY(e1);
+    HIP_TRY(e2);
+    HIP_TRY(hipMemcpy(out, d.p, 3 * 8, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
 /* the square-root routine of the float interpreters / generated code on the bit patterns [first, first + count): number of results
  * that differ from the correctly rounded root, and one such input */
 int mpr_test_sqrt_all(int32_t device, uint64_t first, uint64_t count, uint64_t* mismatches, uint32_t* example)

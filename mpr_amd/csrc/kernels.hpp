@@ -258,6 +258,7 @@ int voxel_gen_counter_ints();
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
                             int nchoices, int run = 0);
+void launch_test_float_gen_all(hipStream_t s, const uint32_t* code, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
                            unsigned long long dr);
 void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a,

@@ -1141,6 +1141,30 @@ void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const flo
     hipLaunchKernelGGL(k_test_float_gen, dim3((n + 63) / 64), dim3(64), 0, s, code, n, a, b, out, dl, dr);
 }
 
+/* a clause of one operand (or with a constant) through the host-generated code on every bit pattern of [first, first + count), against
+ * float_clause (device_math.hpp: the float pass's definition): out = {tested, results that differ (two NaNs are the same), an input} */
+__global__ void __launch_bounds__(64)
+k_test_float_gen_all(const uint32_t* code, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    const int lane = threadIdx.x;
+    unsigned long long tested = 0, bad = 0, example = 0;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 64; base < count; base += (unsigned long long)gridDim.x * 64) {
+        const uint32_t bits = (uint32_t)(first + base + lane);
+        const float x = mpr_u2f(bits);
+        const float got = vox_gen_run(code, x, x, 0.0f, 0ull, 0ull);
+        const float want = float_clause((uint32_t)op, x, x, imm);
+        if (base + lane >= count) continue;
+        ++tested;
+        if (mpr_f2u(got) != mpr_f2u(want) && !(got != got && want != want)) { ++bad; example = bits; }
+    }
+    atomicAdd(&out[0], tested);
+    if (bad) { atomicAdd(&out[1], bad); out[2] = example; }
+}
+void launch_test_float_gen_all(hipStream_t s, const uint32_t* code, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_test_float_gen_all, dim3(6144), dim3(64), 0, s, code, op, imm, first, count, out);
+}
+
 /* one clause through the translator and the generated code: tape3 as for k_test_float_asm */
 __global__ void __launch_bounds__(64)
 k_test_float_jit(const uint64_t* tape3, uint32_t* code, uint32_t region_dwords, int n, const float* a, const float* b, float* out)

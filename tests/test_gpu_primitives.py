@@ -334,3 +334,15 @@ def test_float_values_against_the_exact_enclosures_on_every_float(mpr, opname, o
 def test_float_values_of_operations_with_a_constant_inside_the_exact_enclosures(mpr, opname, imm):
     r = mpr.dev_float_in_enclosure(mpr.OP[opname], imm=imm)
     assert r["tested"] == (1 << 32) - 2 * ((1 << 23) - 1) and r["outside"] == 0, (opname, imm, r, hex(r["example_outside"]))
+
+
+@pytest.mark.parametrize("opname,imm", [("EXP_LHS", 0.0), ("LOG_LHS", 0.0), ("SQRT_LHS", 0.0), ("SQUARE_LHS", 0.0), ("NEG_LHS", 0.0), ("ABS_LHS", 0.0),
+                                        ("DIV_LHS_IMM", 3.7), ("DIV_LHS_IMM", -0.3), ("DIV_LHS_IMM", 30.55555534362793), ("DIV_LHS_IMM", 4.0),
+                                        ("DIV_LHS_IMM", 1e-12), ("MUL_LHS_IMM", -2.5), ("ADD_LHS_IMM", 0.3), ("SUB_IMM_RHS", 1.0), ("DIV_IMM_RHS", 1.0),
+                                        ("MIN_LHS_IMM", 0.25), ("MAX_LHS_IMM", -0.0)])
+def test_host_generated_float_code_on_every_float(mpr, opname, imm):
+    """One clause through the float pass's host-generated code (csrc/voxel_gen.cpp) on all 2^32 bit patterns against the float pass's
+    definition (csrc/device_math.hpp: float_clause = include/mpr_fmath.h, which the oracle shares): the same bits, or two NaNs — the
+    in-line paths, their range tests and the routines behind them, with nothing sampled."""
+    r = mpr.dev_float_gen_all(mpr.OP[opname], imm=imm)
+    assert r["tested"] == 1 << 32 and r["bad"] == 0, (opname, imm, r, hex(r["example"]))
