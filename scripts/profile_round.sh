@@ -12,7 +12,8 @@ export TMPDIR=/tmp
 cd $ROOT
 BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-also"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- $BENCH > $OUT/stats.log 2>&1
+# (the default line's 20 + 100 frames: a context's first dozen frames run at lower clocks, and 25 frames per leg would be mostly those)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python $ROOT/bench.py --no-cpu --no-also > $OUT/stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq -o q -- $BENCH > $OUT/pmc_sq.log 2>&1

@@ -37,7 +37,7 @@ ks = find("stats", "*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu --no-also\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-also      (the default 20 warm-up + 100 timed frames, + 35 full_frames, + 12 first_frames)\n")
         f.write("name,calls,total_ns,average_ns,percentage\n")
         for r in rows:
             f.write('"%s",%s,%s,%s,%s\n' % (r.get("Name"), r.get("Calls"), r.get("TotalDurationNs"),
