@@ -142,6 +142,8 @@ static void finish_tape(mpr_tape* t)
         if (ic.ok) {
             t->big_fwd = std::make_shared<const std::vector<uint32_t>>(ic.words);
             t->big_end = ic.walk_words;
+            std::vector<uint32_t> bw = mpr::tile_gen_build_big_backward(t->clauses.data(), (int)t->clauses.size());
+            if (!bw.empty()) t->big_bwd = std::make_shared<const std::vector<uint32_t>>(std::move(bw));
         }
     }
     static std::atomic<uint64_t> serial{1};

@@ -227,6 +227,9 @@ struct mpr_context {
     size_t big_cap_dw = 0;
     bool big_ok = false;
     int big_end = 0;
+    size_t big_bwd_at = 0;             /* dwords into big_code where the backward walk starts (0: none) */
+    bool raw_reads = false;            /* MPR_DEBUG_RAW_READS=1 (tests): readers get the tiles and tapes of the frame AS IT RAN, no second rendering */
+    bool tile_gen_big_bwd = true;      /* MPR_TILE_GEN_BIG_BWD=0 (development): the interpreter's backward walk behind the generated forward walk */
     std::shared_ptr<const std::vector<uint32_t>> big_resident;
     bool tile_gen_big = true;          /* MPR_TILE_GEN_BIG=0 (development): such tapes' first stages walk on the interpreter */
     int big_min_tiles = 8193;          /* MPR_TILE_GEN_BIG_TILES: first stages of at least this many tiles take it rather than the level-parallel kernel (which wins up to its own limit of 8192: scripts/probe_big.py) */
@@ -481,6 +484,8 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILES_VGPR")) c->tiles_vgpr = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_BIG")) c->tile_gen_big = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_BIG_TILES")) c->big_min_tiles = atoi(e);
+    if (const char* e = getenv("MPR_TILE_GEN_BIG_BWD")) c->tile_gen_big_bwd = atoi(e) != 0;
+    c->raw_reads = getenv("MPR_DEBUG_RAW_READS") != nullptr;
     if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->reference_frames = atoi(e) != 0;
     if (const char* e = getenv("MPR_SKIP_STAGE0")) c->skip_stage0 = atoi(e) != 0;
     if (const char* e = getenv("MPR_MEASURE_LEN")) c->measure_len_forced = atoi(e);
@@ -743,7 +748,8 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
         }
         c->big_ok = false;
         if (tape->big_fwd && c->tile_gen_big && c->tiles_asm && c->tiles_vgpr) {
-            const size_t ndw = tape->big_fwd->size();
+            const size_t fdw = (tape->big_fwd->size() + 63) & ~(size_t)63;
+            const size_t ndw = fdw + (tape->big_bwd ? tape->big_bwd->size() : 0);
             if (ndw > c->big_cap_dw) {
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 free_executable(c->big_code);
@@ -758,7 +764,12 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
             }
             if (c->big_cap_dw >= ndw) {
                 c->big_resident = tape->big_fwd;
-                HIP_TRY(hipMemcpyAsync(c->big_stage, tape->big_fwd->data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                std::vector<uint32_t> all(ndw, 0xBF800000u);
+                std::copy(tape->big_fwd->begin(), tape->big_fwd->end(), all.begin());
+                if (tape->big_bwd) std::copy(tape->big_bwd->begin(), tape->big_bwd->end(), all.begin() + (long)fdw);
+                c->big_bwd_at = tape->big_bwd ? fdw : 0;
+                HIP_TRY(hipMemcpyAsync(c->big_stage, all.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));       /* (the staging vector goes out of scope) */
                 mprk::launch_install_code(c->stream, c->big_code, c->big_stage, ndw, std::max(c->cus, 1));
                 HIP_TRY(hipGetLastError());
                 c->big_ok = true;
@@ -1291,12 +1302,13 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             a.big_fwd = c->big_code;
             a.big_end = c->big_end;
             a.big_nchoices = tape->num_choices;
+            if (c->big_bwd_at && c->tile_gen_big_bwd) a.big_bwd = c->big_code + c->big_bwd_at;
             a.gen_redo_count = c->redo_count;
             f.used_loose = true;
         }
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
-        std::string f = count <= 0 ? "none" : wide_now ? "wide" : big_here ? "interp+loosefwd" : !a.gen_fwd ? "interp" : "gen";
+        std::string f = count <= 0 ? "none" : wide_now ? "wide" : big_here ? (a.big_bwd ? "loosefwd+genbwd" : "interp+loosefwd") : !a.gen_fwd ? "interp" : "gen";
         if (a.gen_fwd && count > 0) {
             if (a.gen_parent) f += "/parent";
             if (a.gen_guarded) f += "+guards";
@@ -1856,7 +1868,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
  * sent stay where mpr_unpack_* put them. */
 static int ensure_full_frame(mpr_context* c)
 {
-    if (!c->last_frame_fast) return MPR_OK;
+    if (!c->last_frame_fast || c->raw_reads) return MPR_OK;
     if (!c->last_tape) return mpr::set_error(MPR_ERR_INVALID, "no tape to render the last frame's tapes from");
     const mpr_context::FrameKey k = c->last_key;
     c->force_reference = true;

@@ -42,6 +42,8 @@ struct mpr_tape {
      * IW_FIRST_MASKS), or null (asin / acos / atan, or more live values than there are registers) */
     std::shared_ptr<const std::vector<uint32_t>> big_fwd;
     int32_t big_end = 0;             /* index of the end clause */
+    /* ... and the backward walk to go with it (tile_gen.hpp: tile_gen_build_big_backward), or null */
+    std::shared_ptr<const std::vector<uint32_t>> big_bwd;
 };
 
 namespace mpr {

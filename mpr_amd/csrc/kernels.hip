@@ -587,6 +587,33 @@ k_eval_tiles(TileStageArgs a)
             for (int off = 32; off > 0; off >>= 1) kept = max(kept, __shfl_xor(kept, off));
             kept_minmax = kept;
             d = tro[tape];
+        } else if (VS == TI_VS_MAX_SLOTS && a.big_bwd && tape == 0) {
+            /* backward walk by the root tape's generated code for many-slot tapes (tile_gen.hpp: tile_gen_build_big_backward): the
+             * choices are where the forward walk — generated or the interpreter's — recorded them */
+            TileGenPush gp;
+            gp.active = (writing && i_out < 32) ? (1u << i_out) : 0u;
+            const uint32_t act1 = (writing && i_out >= 32 && i_out < 64) ? (1u << (i_out - 32)) : 0u;
+            const uint32_t act2 = (writing && i_out >= 64) ? (1u << (i_out - 64)) : 0u;
+            gp.pos = (uint32_t)(out_index + out_offset);
+            gp.first = (uint32_t)out_index;
+            gp.run_end = (uint32_t)run_end;
+            gp.overflow = 0;
+            gp.kept = 0;
+            const long long lim = a.pool_cap - 65;
+            const uint32_t plim = (uint32_t)(lim < 0 ? 0 : (lim > 0x7FFFFF00ll ? 0x7FFFFF00ll : lim));
+            tile_gen_backward_big(a.big_bwd, tro, smem, a.choice_cap, lane, gp, act1, act2, plim);
+            if (writing) {
+                out_index = (int)gp.first;
+                out_offset = (int)(gp.pos - gp.first);
+                overflow = gp.overflow != 0;
+            }
+            writing = push && !overflow;
+            live = ballot(writing);
+            bwd_words = a.big_end;
+            int kept = writing ? (int)gp.kept : 0;
+            for (int off = 32; off > 0; off >>= 1) kept = max(kept, __shfl_xor(kept, off));
+            kept_minmax = kept;
+            d = tro[tape];
         } else if (ASM) {
             /* backward walk by the assembly interpreter (tile_interp_asm.hpp) */
             TilePushState st;

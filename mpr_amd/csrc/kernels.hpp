@@ -95,6 +95,7 @@ struct TileStageArgs {
      * exact walk runs the interpreter's.  big_end: index of the end clause, big_nchoices: min / max clauses */
     const uint32_t* big_fwd = nullptr;
     int big_end = 0, big_nchoices = 0;
+    const uint32_t* big_bwd = nullptr;         /* ... and the tape's generated backward walk for the tiles that push (tile_gen.hpp: tile_gen_build_big_backward) */
     bool gen_guarded = false;            /* with gen_parent: the walk that jumps over the runs the parents' decisions leave dead (interval_gen.hpp:
                                           * IW_BELOW_GUARDED; stages that push nothing) */
     bool gen_loose = false;              /* with gen_fwd, frames nobody reads: exp / log enclosures from the hardware's v_exp_f32 / v_log_f32, widened

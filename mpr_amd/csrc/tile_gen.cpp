@@ -93,6 +93,71 @@ void backward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uin
     store_word(e, 35, W1, cur_hi);
 }
 
+/* ---- the backward walk of a FIRST stage for tapes beyond 24 slots / 64 min / max clauses (tile_gen.hpp: tile_gen_build_big_backward) ----
+ * backward_clause with the active slots in three registers (slot s: bit s & 31 of v60 / v64 / v65) and the lanes' choices taken from
+ * where the forward walk — the interpreter's, or the generated one that records its choices the same way (interval_gen.hpp:
+ * IW_FIRST_MASKS) — left them: 16 bytes of LDS per min / max clause, the lanes that chose the lhs and the lanes that chose the rhs.
+ * Every lane reads the clause's entry (v[66:69]; the read for the next min / max clause is issued as soon as this one's bits are out),
+ * takes the word of its half (s[64:65] = lanes 32..63) and its own bit of it (v74 = lane & 31).  v75 = LDS address of choice 0. */
+int big_active(int slot) { return slot < 32 ? 60 : slot < 64 ? 64 : 65; }
+void big_read_choice(Emit& e, int choice)
+{
+    e.d(0xD9FE0000u | (uint32_t)(16 * choice));              /* ds_read_b128 v[66:69], v75 offset:16 * choice */
+    e.d(75u | 66u << 24);
+}
+void big_backward_clause(Emit& e, uint32_t op, int o, int l, int r, uint32_t W0, uint32_t W1, int choice, uint32_t& cur_hi)
+{
+    const int AO = big_active(o), AL = big_active(l), AR = big_active(r);
+    e.vop3(V3_BFE_U32, 32, Emit::V(AO), Emit::I(o & 31), Emit::I(1));            /* is the out slot active for this lane? */
+    if (!mpr_op_is_minmax(op)) {
+        take_word(e, 32);
+        if (l != o && r != o) e.vop2_lit(V_AND, AO, ~(1u << (o & 31)), AO);
+        if (l != 0 && l != o) e.vop3(V3_LSHL_OR, AL, Emit::V(32), Emit::I(l & 31), Emit::V(AL));
+        if (r != 0 && r != o && r != l) e.vop3(V3_LSHL_OR, AR, Emit::V(32), Emit::I(r & 31), Emit::V(AR));
+        e.mov_lit(46, W0);
+        store_word(e, 32, W1, cur_hi);
+        return;
+    }
+    e.d(0xBF8CC07Fu);                                                            /* s_waitcnt lgkmcnt(0): the clause's entry */
+    e.vop3(V3_CNDMASK, 36, Emit::V(66), Emit::V(67), 64);
+    e.vop3(V3_BFE_U32, 33, Emit::V(36), Emit::V(74), Emit::I(1));                /* chose lhs */
+    e.vop3(V3_CNDMASK, 37, Emit::V(68), Emit::V(69), 64);
+    e.vop3(V3_BFE_U32, 34, Emit::V(37), Emit::V(74), Emit::I(1));                /* chose rhs */
+    if (choice > 0) big_read_choice(e, choice - 1);
+    e.vop2(V_OR, 36, Emit::V(33), 34);
+    e.vop2(V_XOR, 36, Emit::I(1), 36);
+    e.vop2(V_AND, 36, Emit::V(36), 32);                                          /* undecided and active: keeps the min / max */
+    e.vop2(V_ADD_U32, 54, Emit::V(54), 36);
+    const bool dropL = l == o, dropR = r != 0 && r == o;
+    if (!dropL && !dropR) {
+        e.mov(35, Emit::V(32));
+    } else if (dropL && dropR) {
+        e.mov(35, Emit::V(36));
+    } else {
+        e.vop2(V_XOR, 35, Emit::I(1), dropL ? 33 : 34);
+        e.vop2(V_AND, 35, Emit::V(35), 32);
+    }
+    take_word(e, 35);
+    e.vop2(V_XOR, 37, Emit::I(1), 34);
+    e.vop2(V_AND, 37, Emit::V(37), 32);                                          /* lhs stays live: active, did not choose rhs */
+    if (r != 0) {
+        e.vop2(V_XOR, 38, Emit::I(1), 33);
+        e.vop2(V_AND, 38, Emit::V(38), 32);
+    }
+    e.vop2_lit(V_AND, AO, ~(1u << (o & 31)), AO);
+    if (l != 0) e.vop3(V3_LSHL_OR, AL, Emit::V(37), Emit::I(l & 31), Emit::V(AL));
+    if (r != 0) e.vop3(V3_LSHL_OR, AR, Emit::V(38), Emit::I(r & 31), Emit::V(AR));
+    e.vopc(VC_NE_U32, Emit::I(0), 33);
+    e.mov_lit(46, W0);
+    e.mov_lit(39, (W0 & ~0xFFu) | MPR_OP_COPY_LHS);
+    e.vop2(V_CNDMASK, 46, Emit::V(46), 39);
+    e.vopc(VC_NE_U32, Emit::I(0), 34);
+    e.mov_lit(40, (W0 & ~0xFFu) | (r != 0 ? MPR_OP_COPY_RHS : MPR_OP_COPY_IMM));
+    e.nop(0);
+    e.vop2(V_CNDMASK, 46, Emit::V(46), 40);
+    store_word(e, 35, W1, cur_hi);
+}
+
 /* ---- the backward walk for tapes that are shortened again, and for the stages that shorten them ----
  * The tape a stage below the first shortens is its parent's: not the root tape under the parent's decisions, but the very
  * words the parent's walk emitted — a clause it turned into a COPY keeps its unused operand field, the reference's walk (and
@@ -492,6 +557,36 @@ TileGen tile_gen_build(const uint64_t* clauses, int len)
     return g;
 }
 
+std::vector<uint32_t> tile_gen_build_big_backward(const uint64_t* clauses, int len, int* nchoices)
+{
+    std::vector<uint32_t> out;
+    if (!clauses || len < 2) return out;
+    int end = -1, nch = 0;
+    for (int i = 1; i < len; ++i) {
+        const uint64_t w = clauses[i];
+        const uint32_t op = (uint32_t)w & 0xFF;
+        if (op == MPR_OP_INVALID) { end = i; break; }
+        if (op == MPR_OP_JUMP || op >= MPR_OP_COUNT) return out;
+        const int o = (int)(w >> 8) & 0xFF, l = (int)(w >> 16) & 0xFF, r = (int)(w >> 24) & 0xFF;
+        if (o == 0 || o >= 96 || l >= 96 || r >= 96) return out;
+        if (mpr_op_is_minmax(op)) ++nch;
+    }
+    if (end < 0 || nch > 4096 || ((int)(clauses[end] >> 8) & 0xFF) >= 96) return out;
+    Emit b{out};
+    if (nch > 0) big_read_choice(b, nch - 1);
+    int choice = nch;
+    uint32_t cur_hi = 0;                                      /* the harness enters with v47 = 0 */
+    for (int i = end - 1; i >= 1; --i) {
+        const uint64_t w = clauses[i];
+        const uint32_t op = (uint32_t)w & 0xFF;
+        if (mpr_op_is_minmax(op)) --choice;
+        big_backward_clause(b, op, (int)(w >> 8) & 0xFF, (int)(w >> 16) & 0xFF, (int)(w >> 24) & 0xFF, (uint32_t)w, (uint32_t)(w >> 32), choice, cur_hi);
+    }
+    b.setpc(TG_RET_CODE);
+    if (nchoices) *nchoices = nch;
+    return out;
+}
+
 }  // namespace mpr
 
 namespace mpr {
@@ -532,6 +627,13 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
 
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
+    if (which == 6) {                    /* the backward walk for tapes of up to 96 slots (tile_gen_build_big_backward) */
+        const std::vector<uint32_t> c = mpr::tile_gen_build_big_backward(clauses, len);
+        if (c.empty()) return -1;
+        if (out && (int)c.size() <= cap)
+            for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
+        return (int)c.size();
+    }
     const mpr::TileGen g = mpr::tile_gen_build(clauses, len);
     if (!g.ok || which < 1 || which > 5 || which == 4) return -1;        /* (0 / 4 were round 4's forward walks: mpr_test_interval_gen) */
     const std::vector<uint32_t>& c = which == 5 ? g.deriv_guarded : which == 3 ? g.bwd_full : which == 2 ? g.deriv : g.bwd;

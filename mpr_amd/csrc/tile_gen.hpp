@@ -65,4 +65,12 @@ struct TileGen {
  * above (a slot beyond 23, more than 64 min / max clauses, a jump or an unknown opcode) — the interpreter walks it. */
 TileGen tile_gen_build(const uint64_t* clauses, int len);
 
+/* The backward walk (tape pushing, reference src/context.cu:323-458) of a FIRST stage for tapes those conventions do not fit but the
+ * interpreter with 93 slots in registers does (slots 0..95, up to 4096 min / max clauses): the same per-lane walk as TileGen::bwd — the
+ * clause's out slot active? take a word of the lane's chunk, mark the operands, store the clause, a decided min / max as the COPY it
+ * becomes — with the active slots in three registers and the choices read from the 16-byte-per-clause records the forward walk left in
+ * LDS (the interpreter's format: interval_gen.hpp: IW_FIRST_MASKS writes the same).  Run by tile_gen_asm.hpp: tile_gen_backward_big.
+ * Empty: the tape does not fit. */
+std::vector<uint32_t> tile_gen_build_big_backward(const uint64_t* clauses, int len, int* nchoices = nullptr);
+
 }  // namespace mpr

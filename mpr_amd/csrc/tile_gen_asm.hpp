@@ -313,6 +313,80 @@ DEV void tile_gen_backward(const uint32_t* code, const uint64_t* pool, unsigned 
     st.kept_hi = io[832 + lane];
 }
 
+/* The backward walk of a first stage for tapes beyond 24 slots / 64 min / max clauses (tile_gen.hpp: tile_gen_build_big_backward) inside the
+ * kernel whose interpreter keeps 93 slots in registers.  smem: ulonglong2[choice_cap] — the forward walk's records of its choices —, then
+ * [8][64] words of scratch (tile_interp_asm.hpp: tile_interp_asm_vgpr).  active3: the lane's active slots (bit s & 31 of word s >> 5). */
+DEV void tile_gen_backward_big(const uint32_t* code, const uint64_t* pool, unsigned char* smem, int choice_cap, int lane, TileGenPush& st,
+                               uint32_t active1, uint32_t active2, uint32_t pool_limit)
+{
+    uint32_t* const io = reinterpret_cast<uint32_t*>(smem + (size_t)choice_cap * 16);
+    io[lane] = st.active; io[64 + lane] = active1; io[128 + lane] = active2; io[192 + lane] = st.pos; io[256 + lane] = st.first; io[320 + lane] = st.run_end;
+    const uint32_t ioaddr = rdfirst((uint32_t)(uintptr_t)io);
+    const uint32_t caddr = rdfirst((uint32_t)(uintptr_t)smem);
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const uint32_t clo = rdfirst((uint32_t)(uintptr_t)code), chi = rdfirst((uint32_t)((uintptr_t)code >> 32));
+    const uint32_t plo = rdfirst((uint32_t)(uintptr_t)pool), phi = rdfirst((uint32_t)((uintptr_t)pool >> 32));
+    const uint32_t plim = rdfirst(pool_limit);
+    asm volatile(
+        "v_add_u32 v32, %[io], %[lane4]\n"
+        "ds_read_b32 v60, v32\n ds_read_b32 v64, v32 offset:256\n ds_read_b32 v65, v32 offset:512\n"
+        "ds_read_b32 v61, v32 offset:768\n ds_read_b32 v62, v32 offset:1024\n ds_read_b32 v63, v32 offset:1280\n"
+        "v_mov_b32 v47, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n"
+        "v_lshrrev_b32 v74, 2, %[lane4]\n v_and_b32 v74, 31, v74\n"
+        "v_mov_b32 v75, %[caddr]\n"
+        "s_mov_b32 s64, 0\n s_mov_b32 s65, -1\n"                 /* lanes 32..63 */
+        "s_mov_b32 s76, %[plo]\n s_mov_b32 s77, %[phi]\n s_mov_b32 s98, %[plim]\n"
+        "s_getpc_b64 s[40:41]\n"
+        "L_pc_%=:\n"
+        TG_ADDR(62, 63, "L_chunk")
+        "s_mov_b32 s34, %[clo]\n"
+        "s_mov_b32 s35, %[chi]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_swappc_b64 s[38:39], s[34:35]\n"
+        "v_add_u32 v32, %[io], %[lane4]\n"
+        "ds_write_b32 v32, v61\n ds_write_b32 v32, v62 offset:256\n"
+        "ds_write_b32 v32, v55 offset:512\n ds_write_b32 v32, v54 offset:768\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_branch L_end_%=\n"
+        /* some lane's chunk is full: tile_gen_backward's routine with three words of active slots to clear for a lane out of room */
+        "L_chunk_%=:\n"
+        "v_cmp_eq_u32 vcc, v61, v62\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_mov_b32 v52, v62\n"
+        "v_add_u32 v62, 64, v62\n"
+        "v_cmp_ge_u32 vcc, v62, v63\n"
+        "v_cmp_gt_u32 s[92:93], v62, s98\n"
+        "s_or_b64 vcc, vcc, s[92:93]\n"
+        "v_cndmask_b32 v60, v60, 0, vcc\n"
+        "v_cndmask_b32 v64, v64, 0, vcc\n"
+        "v_cndmask_b32 v65, v65, 0, vcc\n"
+        "v_cndmask_b32 v32, v32, 0, vcc\n"
+        "v_cndmask_b32 v35, v35, 0, vcc\n"
+        "v_cndmask_b32 v55, v55, 1, vcc\n"
+        "s_andn2_b64 exec, exec, vcc\n"
+        "v_add_lshl_u32 v44, v62, 63, 3\n"
+        "v_lshlrev_b32 v45, 3, v52\n"
+        "v_mov_b32 v48, 1\n"
+        "v_mov_b32 v49, 0xffffff81\n"
+        "v_mov_b32 v50, 1\n"
+        "v_mov_b32 v51, 127\n"
+        "global_store_dwordx2 v44, v[48:49], s[76:77]\n"
+        "global_store_dwordx2 v45, v[50:51], s[76:77]\n"
+        "v_add_u32 v61, 62, v62\n"
+        "s_mov_b64 exec, -1\n"
+        "s_setpc_b64 s[36:37]\n"
+        "L_end_%=:\n"
+        :
+        : [lane4] "v"(lane4), [io] "s"(ioaddr), [caddr] "s"(caddr), [clo] "s"(clo), [chi] "s"(chi), [plo] "s"(plo), [phi] "s"(phi), [plim] "s"(plim)
+        : "memory", "vcc", "scc", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s62", "s63", "s64", "s65", "s76", "s77", "s92", "s93", "s98",
+          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
+          "v54", "v55", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v74", "v75");
+    st.pos = io[lane];
+    st.first = io[64 + lane];
+    st.overflow = io[128 + lane];
+    st.kept = io[192 + lane];
+}
+
 /* The backward walk for tapes that are shortened again (tile_gen.cpp: backward_full_clause).  decided_lhs / decided_rhs:
  * min / max clauses that are copies already on the tape being shortened; parent_presence: that tape's clauses, one bit per
  * clause of the root tape (TILE_GEN_PRESENCE_WORDS dwords; null: all of them — the first stage); the presence bits of the

@@ -1,7 +1,8 @@
-"""First stages of tapes beyond the generators' 24 slots / 64 min / max clauses on the tape's own loose forward walk (csrc/interval_gen.hpp:
-IW_FIRST_MASKS, host-generated code in the kernel whose interpreter keeps 93 slots in registers) in front of that interpreter's backward
-walk: architecture from 1536^3 on by default (32 768 first-stage tiles at 2048^3: past the level-parallel kernel's limit; 0.33 ms on the
-interpreter, 0.215 ms this way), any size with MPR_TILE_GEN_BIG_TILES=1.  The walk decides no more than the reference's: the tapes it
+"""First stages of tapes beyond the generators' 24 slots / 64 min / max clauses on the tape's own walks as host-generated code in the kernel whose
+interpreter keeps 93 slots in registers: the loose forward walk (csrc/interval_gen.hpp: IW_FIRST_MASKS), which records its choices the way
+the interpreter does, and the backward walk that reads them (csrc/tile_gen.hpp: tile_gen_build_big_backward).  architecture from 1536^3 on
+by default (32 768 first-stage tiles at 2048^3: past the level-parallel kernel's limit; 0.33 ms on the interpreter, 0.215 ms with the
+generated forward walk, 0.13 ms with both), any size with MPR_TILE_GEN_BIG_TILES=1.  The walk decides no more than the reference's: the tapes it
 pushes are supersets, the frame's heights and normals the oracle's, and a reader gets the frame rendered again the reference's way."""
 import ctypes
 
@@ -36,7 +37,7 @@ def test_first_stage_on_the_loose_walk_matches_the_oracle(mpr, orc, tapes, name,
         else:
             ctx.render2D(tape, mat)
         assert np.array_equal(ctx.image, ref.filled[3])
-        assert ctx.tile_stage_forms().startswith("0:interp+loosefwd"), ctx.tile_stage_forms()
+        assert ctx.tile_stage_forms().startswith("0:loosefwd+genbwd"), ctx.tile_stage_forms()
     walks, fell_back = redo_counts(mpr, ctx)
     assert walks > 0 and fell_back == 0, (walks, fell_back)      # (nothing in these views leaves a routine's domain)
     ctx.close()
@@ -70,7 +71,7 @@ def test_wavefronts_that_leave_a_domain_fall_back_on_the_interpreter(mpr, orc, m
     for _ in range(2):
         ctx.render3D(tape, view3())
         assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals)
-        assert ctx.tile_stage_forms().startswith("0:interp+loosefwd"), ctx.tile_stage_forms()
+        assert ctx.tile_stage_forms().startswith("0:loosefwd+genbwd"), ctx.tile_stage_forms()
     walks, fell_back = redo_counts(mpr, ctx)
     assert 0 < fell_back < walks, (walks, fell_back)
     ctx.close()
@@ -85,3 +86,31 @@ def test_switched_off(mpr, orc, tapes, monkeypatch):
     ctx.render3D(tape, view3())
     assert "loosefwd" not in ctx.tile_stage_forms()
     ctx.close()
+
+
+@pytest.mark.parametrize("name,dim,S", [("architecture", 3, 256), ("architecture", 3, 512), ("prospero", 2, 512)])
+def test_generated_backward_walk_pushes_the_interpreters_tapes(mpr, orc, tapes, name, dim, S, monkeypatch):
+    """The same forward walk (same choices), then the generated backward walk in one context and the interpreter's in another: every
+    first-stage tile that pushes must carry the same clause sequence (MPR_DEBUG_RAW_READS: the tiles and tapes of the frame as it ran —
+    a reader otherwise gets the frame rendered again the reference's way)."""
+    monkeypatch.setenv("MPR_TILE_GEN_BIG_TILES", "1")
+    monkeypatch.setenv("MPR_DEBUG_RAW_READS", "1")
+    tape = tapes(name)
+    mat = view3() if dim == 3 else view2()
+    got = []
+    for bwd in ("1", "0"):
+        monkeypatch.setenv("MPR_TILE_GEN_BIG_BWD", bwd)
+        ctx = mpr.Context(S)
+        (ctx.render3D if dim == 3 else ctx.render2D)(tape, mat)
+        assert ctx.tile_stage_forms().startswith("0:loosefwd+genbwd" if bwd == "1" else "0:interp+loosefwd"), ctx.tile_stage_forms()
+        tiles = ctx.stages[0].tiles
+        pool = ctx.tape_data
+        live = tiles[(tiles["position"] != -1) & (tiles["next"] != -1)]
+        order = np.argsort(live["position"])
+        length, digest = orc.tiles_digest(pool, live[order])
+        got.append((live["position"][order].copy(), length, digest, int((live["tape"] != 0).sum())))
+        ctx.close()
+    a, b = got
+    assert a[3] > 0 and a[3] == b[3]                 # tiles with a tape of their own
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert (a[1] < len(tape.data)).any()             # ... shorter than the root tape

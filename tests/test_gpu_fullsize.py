@@ -46,11 +46,11 @@ def test_architecture_2048_full_frame(mpr, orc, tapes):
     # threshold (context.hip: `pays`, 1.4) from which the last stage pushes them and the float pass walks each tile's own; a
     # frame whose sample says otherwise takes the group form and pushes nothing.  Either way the oracle's frame (above).
     assert all(k == ("k_eval_voxels_asm<3>", True) or (k[0].startswith("k_eval_voxels_jit_groups") and not k[1]) for k in kinds), kinds
-    # its first stage (32 768 tiles: past the level-parallel kernel's limit) on the tape's loose forward walk as host-generated code in front
-    # of the interpreter's backward walk (tests/test_gpu_big_first_stage.py)
+    # its first stage (32 768 tiles: past the level-parallel kernel's limit) on the tape's own walks as host-generated code: the loose forward
+    # walk and the backward walk that reads its choices (tests/test_gpu_big_first_stage.py)
     ctx = mpr.Context(2048)
     ctx.render3D(tapes("architecture"), view3())
-    assert ctx.tile_stage_forms().startswith("0:interp+loosefwd"), ctx.tile_stage_forms()
+    assert ctx.tile_stage_forms().startswith("0:loosefwd+genbwd"), ctx.tile_stage_forms()
     assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals)
     ctx.close()
 

@@ -64,6 +64,41 @@ def test_backward_rows(mpr):
     assert "v_mov_b32_e32 v40, 0x4041b" in code                     # COPY_IMM
 
 
+def test_backward_rows_for_tapes_of_up_to_96_slots(mpr, tapes):
+    """tile_gen_build_big_backward (a first stage's tape pushing for tapes the other generators do not take): backward_rows with the
+    active slots in v60 / v64 / v65 and the lanes' choices read from the forward walk's 16-byte records in LDS."""
+    OP = mpr.OP
+    take = ["v_cmp_eq_u32_e32 vcc, v61, v62", "s_cbranch_vccz 1", "s_swappc_b64 s[36:37], s[62:63]"]
+    store = ["v_lshlrev_b32_e32 v44, 3, v61", "s_mov_b64 exec, vcc", "global_store_dwordx2 v44, v[46:47], s[76:77]", "s_mov_b64 exec, -1"]
+    # out slot 70 (bit 6 of v65), operands 33 (bit 1 of v64) and 2 (v60)
+    assert one(mpr, clause(OP["ADD_LHS_RHS"], 70, 33, 2), 6) == [
+        "v_bfe_u32 v32, v65, 6, 1", "v_sub_u32_e32 v61, v61, v32"] + take + [
+        "v_and_b32_e32 v65, 0xffffffbf, v65", "v_lshl_or_b32 v64, v32, 1, v64", "v_lshl_or_b32 v60, v32, 2, v60",
+        "v_mov_b32_e32 v46, 0x221460e", "v_cmp_ne_u32_e32 vcc, 0, v32"] + store
+    # min: the clause's record was asked for when the walk began (the only one: nothing to ask for behind it), every lane takes the word of
+    # its half and its own bit
+    code = generated(mpr, [clause(0, 1, 2, 3), clause(OP["MIN_LHS_RHS"], 40, 1, 2), clause(0, 40)], 6)
+    assert code[0] == "ds_read_b128 v[66:69], v75" and code[-1] == "s_setpc_b64 s[38:39]"
+    assert code[1:7] == ["v_bfe_u32 v32, v64, 8, 1", "s_waitcnt lgkmcnt(0)", "v_cndmask_b32_e64 v36, v66, v67, s[64:65]", "v_bfe_u32 v33, v36, v74, 1",
+                         "v_cndmask_b32_e64 v37, v68, v69, s[64:65]", "v_bfe_u32 v34, v37, v74, 1"]
+    assert "v_add_u32_e32 v54, v54, v36" in code                      # min / max clauses the lane's tape keeps
+    assert code[-5:-1] == store
+    # two of them: the earlier one's record is asked for as soon as the later one's bits are out
+    code = generated(mpr, [clause(0, 1, 2, 3), clause(OP["MAX_LHS_IMM"], 4, 1, 0, PI), clause(OP["MIN_LHS_RHS"], 5, 4, 2), clause(0, 5)], 6)
+    assert code[0] == "ds_read_b128 v[66:69], v75 offset:16"
+    k = code.index("v_bfe_u32 v34, v37, v74, 1")
+    assert code[k + 1] == "ds_read_b128 v[66:69], v75" and code.count("s_waitcnt lgkmcnt(0)") == 2
+    # whole tapes: architecture (93 slots, 488 min / max clauses), prospero; a slot beyond 95 is not taken
+    for name, nch in (("architecture", 488), ("prospero", 2354)):
+        words = [int(w) for w in tapes(name).data]
+        arr = np.array(words, dtype=np.uint64)
+        buf = (ctypes.c_uint32 * 400000)()
+        n = mpr.lib().mpr_test_tile_gen(arr.ctypes.data, len(arr), 6, buf, 400000)
+        assert 10000 < n < 400000
+        assert sum(1 for d in buf[:n] if (d & 0xFFFF0000) == 0xD9FE0000) == nch      # one ds_read_b128 per min / max clause
+    assert generated(mpr, [clause(0, 1, 2, 3), clause(OP["NEG_LHS"], 96, 1), clause(0, 96)], 6) is None
+
+
 def test_backward_rows_for_tapes_that_are_shortened_again(mpr):
     """which = 3: the walk a stage below the first pushes by, and the one that writes tapes such a stage will shorten.  The tape
     being shortened is the PARENT's: s[0..23] hold one bit per clause of the root tape (is it on that tape?), a clause decided
