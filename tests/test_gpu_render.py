@@ -794,8 +794,10 @@ def test_tape_pool_sized_by_the_frames(mpr, orc, tapes):
     after = sum(c.resident_bytes() for c in ctxs)
     print("three contexts at 2048^3: %.2f GB at creation, %.2f GB after frames of architecture" % (before / 2**30, after / 2**30))
     # (round 2: 3 x 3.28 GB for the pools alone; round 5: a pool more than 3/4 full after a frame doubles before the next one, so that no
-    # later frame — whose pushes run a few per cent higher or lower with the timing of the fills — has to grow it in the middle: 3.4 GB)
-    assert after < 4 * 2**30, after
+    # later frame — whose pushes run a few per cent higher or lower with the timing of the fills — has to grow it in the middle: 3.4 GB;
+    # later in round 5 architecture's last stage pushes per-tile tapes again (the faster form since the stages' atomic went) and its
+    # first stage decides a little less (looser enclosures): one doubling more in each context, 4.2 GB — three reference pools: 9.8)
+    assert after < 5 * 2**30, after
     assert np.array_equal(ctxs[0].image, ctxs[2].image)
     # reading tiles / tapes makes a frame the reference's way: the pool grows as far as that needs, and the tapes are complete
     cnt = ctxs[0].counters()
