@@ -137,7 +137,7 @@ static void finish_tape(mpr_tape* t)
     /* the tape's walks as machine code, here and not in the first frame that renders it (0.4 ms of host time for bear) */
     t->code = mpr::build_tape_code(t->clauses.data(), (int)t->clauses.size(), mpr::TAPE_CODE_DEFAULT_MIN_RUN);
     if (!t->code && t->loose_ok && t->num_slots > mpr::TILE_GEN_MAX_SLOTS && t->num_slots <= 94) {
-        /* (prospero: 32 000 instructions, 70 ms here; architecture: 6800, 20 ms) */
+        /* (prospero: 32 000 + 48 000 instructions, 25 of the 36 ms its tape takes to make; architecture: 6800 + 19 000, 4 of 7 ms) */
         const mpr::IntervalCode ic = mpr::interval_gen_build(t->clauses.data(), (int)t->clauses.size(), mpr::IW_FIRST_MASKS, true);
         if (ic.ok) {
             t->big_fwd = std::make_shared<const std::vector<uint32_t>>(ic.words);
