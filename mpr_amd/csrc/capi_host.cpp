@@ -136,14 +136,21 @@ static void finish_tape(mpr_tape* t)
     t->schedule = mpr::build_schedule(t->clauses.data(), (int32_t)t->clauses.size());
     /* the tape's walks as machine code, here and not in the first frame that renders it (0.4 ms of host time for bear) */
     t->code = mpr::build_tape_code(t->clauses.data(), (int)t->clauses.size(), mpr::TAPE_CODE_DEFAULT_MIN_RUN);
-    if (!t->code && t->loose_ok && t->num_slots > mpr::TILE_GEN_MAX_SLOTS && t->num_slots <= 94) {
+    if (!t->code && t->num_slots > mpr::TILE_GEN_MAX_SLOTS && t->num_slots <= 94) {
         /* (prospero: 32 000 + 48 000 instructions, 25 of the 36 ms its tape takes to make; architecture: 6800 + 19 000, 4 of 7 ms) */
-        const mpr::IntervalCode ic = mpr::interval_gen_build(t->clauses.data(), (int)t->clauses.size(), mpr::IW_FIRST_MASKS, true);
-        if (ic.ok) {
-            t->big_fwd = std::make_shared<const std::vector<uint32_t>>(ic.words);
-            t->big_end = ic.walk_words;
-            std::vector<uint32_t> bw = mpr::tile_gen_build_big_backward(t->clauses.data(), (int)t->clauses.size());
-            if (!bw.empty()) t->big_bwd = std::make_shared<const std::vector<uint32_t>>(std::move(bw));
+        /* the backward walk: any such tape (it reads whatever forward walk's choices); the loose forward walk: tapes the loose arithmetic takes */
+        std::vector<uint32_t> bw = mpr::tile_gen_build_big_backward(t->clauses.data(), (int)t->clauses.size());
+        if (!bw.empty()) {
+            t->big_bwd = std::make_shared<const std::vector<uint32_t>>(std::move(bw));
+            for (size_t i = 1; i < t->clauses.size(); ++i)
+                if (mpr_cl_op(t->clauses[i]) == MPR_OP_INVALID) { t->big_end = (int32_t)i; break; }
+        }
+        if (t->loose_ok) {
+            const mpr::IntervalCode ic = mpr::interval_gen_build(t->clauses.data(), (int)t->clauses.size(), mpr::IW_FIRST_MASKS, true);
+            if (ic.ok) {
+                t->big_fwd = std::make_shared<const std::vector<uint32_t>>(ic.words);
+                t->big_end = ic.walk_words;
+            }
         }
     }
     static std::atomic<uint64_t> serial{1};

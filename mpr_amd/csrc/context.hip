@@ -227,7 +227,8 @@ struct mpr_context {
     size_t big_cap_dw = 0;
     bool big_ok = false;
     int big_end = 0;
-    size_t big_bwd_at = 0;             /* dwords into big_code where the backward walk starts (0: none) */
+    size_t big_bwd_at = 0;             /* dwords into big_code where the backward walk starts */
+    bool big_bwd_ok = false;           /* ... and whether there is one */
     bool raw_reads = false;            /* MPR_DEBUG_RAW_READS=1 (tests): readers get the tiles and tapes of the frame AS IT RAN, no second rendering */
     bool tile_gen_big_bwd = true;      /* MPR_TILE_GEN_BIG_BWD=0 (development): the interpreter's backward walk behind the generated forward walk */
     std::shared_ptr<const std::vector<uint32_t>> big_resident;
@@ -747,8 +748,9 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
             }
         }
         c->big_ok = false;
-        if (tape->big_fwd && c->tile_gen_big && c->tiles_asm && c->tiles_vgpr) {
-            const size_t fdw = (tape->big_fwd->size() + 63) & ~(size_t)63;
+        c->big_bwd_ok = false;
+        if ((tape->big_fwd || tape->big_bwd) && c->tile_gen_big && c->tiles_asm && c->tiles_vgpr) {
+            const size_t fdw = tape->big_fwd ? ((tape->big_fwd->size() + 63) & ~(size_t)63) : 0;
             const size_t ndw = fdw + (tape->big_bwd ? tape->big_bwd->size() : 0);
             if (ndw > c->big_cap_dw) {
                 HIP_TRY(hipStreamSynchronize(c->stream));
@@ -765,14 +767,15 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
             if (c->big_cap_dw >= ndw) {
                 c->big_resident = tape->big_fwd;
                 std::vector<uint32_t> all(ndw, 0xBF800000u);
-                std::copy(tape->big_fwd->begin(), tape->big_fwd->end(), all.begin());
+                if (tape->big_fwd) std::copy(tape->big_fwd->begin(), tape->big_fwd->end(), all.begin());
                 if (tape->big_bwd) std::copy(tape->big_bwd->begin(), tape->big_bwd->end(), all.begin() + (long)fdw);
-                c->big_bwd_at = tape->big_bwd ? fdw : 0;
+                c->big_bwd_at = fdw;
                 HIP_TRY(hipMemcpyAsync(c->big_stage, all.data(), ndw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));       /* (the staging vector goes out of scope) */
                 mprk::launch_install_code(c->stream, c->big_code, c->big_stage, ndw, std::max(c->cus, 1));
                 HIP_TRY(hipGetLastError());
-                c->big_ok = true;
+                c->big_ok = tape->big_fwd != nullptr;
+                c->big_bwd_ok = tape->big_bwd != nullptr;
                 c->big_end = tape->big_end;
             }
         }
@@ -1302,13 +1305,23 @@ static int stage_pick_code(Frame& f, int si, int i, bool last, bool wide_now, bo
             a.big_fwd = c->big_code;
             a.big_end = c->big_end;
             a.big_nchoices = tape->num_choices;
-            if (c->big_bwd_at && c->tile_gen_big_bwd) a.big_bwd = c->big_code + c->big_bwd_at;
+            if (c->big_bwd_ok && c->tile_gen_big_bwd) a.big_bwd = c->big_code + c->big_bwd_at;
             a.gen_redo_count = c->redo_count;
             f.used_loose = true;
         }
+        /* ... and for tapes the loose arithmetic does not take (asin / acos / atan: the gears): the interpreter's forward walk — the
+         * reference's enclosures — and the generated backward walk behind it (it reads the choices where either forward walk puts them,
+         * and pushes the interpreter's tapes word for word) */
+        const bool bwd_only_here = !big_here && si == 0 && !f.skip0 && !wide_now && !reference && c->big_bwd_ok && c->tile_gen_big_bwd && count > 0 && !heat &&
+                                   !cnt && !(c->debug_tiles & 3) && c->tape_serial == tape->serial && !a.gen_fwd &&
+                                   mprk::tile_stage_big_possible(f.nslots, f.stage_choice_cap, c->pool_cap, !c->tiles_asm, c->tiles_vgpr, c->debug_tiles);
+        if (bwd_only_here) {
+            a.big_bwd = c->big_code + c->big_bwd_at;
+            a.big_end = c->big_end;
+        }
         /* what this stage runs, for mpr_ctx_tile_stage_forms (tests assert the path they mean to exercise) */
         if (si == (skip0 ? 1 : 0)) c->stage_forms.clear();
-        std::string f = count <= 0 ? "none" : wide_now ? "wide" : big_here ? (a.big_bwd ? "loosefwd+genbwd" : "interp+loosefwd") : !a.gen_fwd ? "interp" : "gen";
+        std::string f = count <= 0 ? "none" : wide_now ? "wide" : big_here ? (a.big_bwd ? "loosefwd+genbwd" : "interp+loosefwd") : bwd_only_here ? "interp+genbwd" : !a.gen_fwd ? "interp" : "gen";
         if (a.gen_fwd && count > 0) {
             if (a.gen_parent) f += "/parent";
             if (a.gen_guarded) f += "+guards";

@@ -114,3 +114,40 @@ def test_generated_backward_walk_pushes_the_interpreters_tapes(mpr, orc, tapes, 
     assert a[3] > 0 and a[3] == b[3]                 # tiles with a tape of their own
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert (a[1] < len(tape.data)).any()             # ... shorter than the root tape
+
+
+@pytest.mark.parametrize("name,dim,S", [("involute_gear_3d", 3, 256), ("involute_gear_2d", 2, 1024)])
+def test_generated_backward_walk_behind_the_interpreters_forward_walk(mpr, orc, tapes, name, dim, S, monkeypatch):
+    """Tapes the loose arithmetic does not take (acos / atan: the gears) keep the interpreter's forward walk — the reference's enclosures
+    — in a first stage that is not level-parallel (by default: more than 8192 tiles; here: the level-parallel kernel switched off), and
+    get the generated backward walk behind it: the same tapes as the interpreter's backward walk pushes, word for word, and the oracle's
+    frame."""
+    monkeypatch.setenv("MPR_WIDE_STAGE0", "0")
+    monkeypatch.setenv("MPR_DEBUG_RAW_READS", "1")
+    tape = tapes(name)
+    mat = view3() if dim == 3 else view2()
+    ref = orc.Frame(tape.data, dim, S, mpr.colmajor(mat, dim + 1), threads=0)
+    got = []
+    for bwd in ("1", "0"):
+        monkeypatch.setenv("MPR_TILE_GEN_BIG_BWD", bwd)
+        ctx = mpr.Context(S)
+        for _ in range(2):
+            (ctx.render3D if dim == 3 else ctx.render2D)(tape, mat)
+            assert np.array_equal(ctx.image, ref.filled[3])
+            if dim == 3:
+                assert np.array_equal(ctx.normals, ref.normals)
+        assert ctx.tile_stage_forms().startswith("0:interp+genbwd" if bwd == "1" else "0:interp "), ctx.tile_stage_forms()
+        tiles = ctx.stages[0].tiles
+        pool = ctx.tape_data
+        live = tiles[(tiles["position"] != -1) & (tiles["next"] != -1)]
+        order = np.argsort(live["position"])
+        length, digest = orc.tiles_digest(pool, live[order])
+        got.append((live["position"][order].copy(), length, digest))
+        # ... and these ARE the reference's first-stage tiles and tapes (exact enclosures): the oracle's
+        rt = ref.tiles[0]
+        rlive = rt[(rt["position"] != -1) & (rt["next"] != -1)]
+        ro = np.argsort(rlive["position"])
+        rlen, rdig = orc.tiles_digest(ref.pool, rlive[ro])
+        assert np.array_equal(live["position"][order], rlive["position"][ro]) and np.array_equal(length, rlen) and np.array_equal(digest, rdig)
+        ctx.close()
+    assert all(np.array_equal(x, y) for x, y in zip(got[0], got[1]))
