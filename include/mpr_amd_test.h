@@ -46,6 +46,13 @@ int mpr_test_interval_gen_op(int32_t device, int32_t op, int32_t loose, int32_t 
  * for the exact walk, [4] = the widest result beyond the exact one in units of 2^-24 of max(|value|, 1) */
 int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float other_lo, float other_hi, int32_t x_is_rhs, uint64_t first, uint64_t count,
                        uint64_t out[5]);
+/* the TIGHT code of one SIN_LHS / COS_LHS clause (csrc/interval_gen.hpp: the second enclosure, from the hardware's v_sin_f32 / v_cos_f32
+ * on the monotone pieces) on every bit pattern x of [first, first + count) as [x, x], [x, x + w] (w < 8) and the interval to a scrambled
+ * copy of its bits, against the float pass's own sinf / cosf at the ends, the middle and around the multiples of pi / 2 inside:
+ * out[0] = intervals whose enclosure misses a value (must be 0), [1] = one such pattern (| variant << 32), [2] = intervals tested,
+ * [3] = lanes that asked for the exact walk, [4] = the instruction's largest error for |x| <= 1024 in units of 2^-40, [5] / [6] =
+ * intervals narrower than 1 whose enclosure is / is not narrower than 1 */
+int mpr_test_tight_trig(int32_t device, int32_t is_sin, uint64_t first, uint64_t count, uint64_t out[7]);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,
                       float imm, float* out4);

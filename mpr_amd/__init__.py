@@ -789,6 +789,18 @@ def dev_loose_gen(op, imm=0.0, other=(0.0, 0.0), x_is_rhs=False, first=0, count=
     return dict(bad=int(out[0]), example=int(out[1]), tested=int(out[2]), asked_for_exact=int(out[3]), widest=int(out[4]))
 
 
+def dev_tight_trig(is_sin, first=0, count=1 << 32, device=0):
+    """The TIGHT code of one SIN_LHS / COS_LHS clause on the bit patterns [first, first + count) against the float pass's sinf / cosf:
+    dict(bad, example, tested, asked_for_exact, hw_error (the instruction's largest error for |x| <= 1024), narrow, wide)."""
+    out = (ctypes.c_uint64 * 7)()
+    f = lib().mpr_test_tight_trig
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    _check(f(device, int(is_sin), first, count, out))
+    return dict(bad=int(out[0]), example=int(out[1]), tested=int(out[2]), asked_for_exact=int(out[3]), hw_error=int(out[4]) * 2.0 ** -40,
+                narrow=int(out[5]), wide=int(out[6]))
+
+
 def dev_float_gen_all(op, imm=0.0, first=0, count=1 << 32, device=0):
     """One clause through the host-generated float walk on the bit patterns [first, first + count) against float_clause:
     dict(tested, bad, example)."""

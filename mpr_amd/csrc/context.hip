@@ -219,8 +219,10 @@ struct mpr_context {
                                         * 0.79 once the stages' atomics were out of the way (round 5) */
     unsigned tapes_hint_frames = 0;
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
-    /* the scheduled interval forward walks (interval_gen.hpp) in gen_code: [kind][exact, loose] */
-    int gen_iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gen_iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    /* the scheduled interval forward walks (interval_gen.hpp) in gen_code: [kind][exact, loose, tight] */
+    int gen_iw_at[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gen_iw_dw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    bool tile_tight = true;            /* MPR_TILE_TIGHT=0: the last tile stage of a frame nobody reads hands the float pass every tile the reference's
+                                        * enclosures leave ambiguous (round 6: with it, those a sound sin / cos enclosure decides stay away) */
     /* the resident tape's first-stage walk for the kernel with 93 slots in registers (internal.hpp: mpr_tape::big_fwd), or none */
     uint32_t* big_code = nullptr;
     uint32_t* big_stage = nullptr;
@@ -467,6 +469,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_GEN")) c->voxel_gen = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LEAN")) c->tile_gen_lean = atoi(e) != 0;
+    if (const char* e = getenv("MPR_TILE_TIGHT")) c->tile_tight = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_REDO"))
         if (atoi(e) != 0 && hipMalloc((void**)&c->redo_count, 2 * sizeof(unsigned int)) == hipSuccess) (void)hipMemset(c->redo_count, 0, 2 * sizeof(unsigned int));
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
@@ -740,7 +743,7 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
                     c->gen_words = code->walk_words;
                     c->gen_nchoices = code->nchoices;
                     for (int k = 0; k < 3; ++k)
-                        for (int l = 0; l < 2; ++l) {
+                        for (int l = 0; l < 3; ++l) {
                             c->gen_iw_at[k][l] = code->iw_at[k][l];
                             c->gen_iw_dw[k][l] = code->iw_dw[k][l];
                         }
@@ -1418,15 +1421,23 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
             HIP_TRY(hipMalloc((void**)&c->redo_flags, nwg * 2 + 64));
             c->redo_flags_cap = nwg * 2 + 64;
         }
-        a.lean = true;
+        a.lean = 1;
+        /* the last stage: with a second, tight enclosure where the tape has a sin / cos (interval_gen.hpp) — the tiles it decides
+         * stay out of the float pass */
+        const int kind = !a.gen_parent ? mpr::IW_FIRST : a.gen_guarded ? mpr::IW_BELOW_GUARDED : mpr::IW_BELOW;
+        const bool tight_here = last && a.groups && a.no_push && c->tile_tight && c->gen_iw_dw[kind][2] > 0;
+        if (tight_here) {
+            a.lean = 2;
+            a.gen_fwd2 = c->gen_code + c->gen_iw_at[kind][2];
+        }
         a.redo_flags = c->redo_flags;
         (void)mprk::launch_eval_tiles(s, dim, a);
-        a.lean = false;
+        a.lean = 0;
         a.redo_flags = nullptr;
         a.only_flagged = c->redo_flags;
         a.gen_fwd2 = a.gen_fwd2_exact;
         (void)mprk::launch_eval_tiles(s, dim, a);
-        c->stage_forms += "+lean";
+        c->stage_forms += tight_here ? "+lean+tight" : "+lean";
     } else {
         const bool ran_gen = mprk::launch_eval_tiles(s, dim, a);
         if (a.gen_fwd && !ran_gen)          /* the records this frame counts on would not exist */
@@ -2458,7 +2469,7 @@ struct OneClauseCode {
     uint32_t* code = nullptr;
     ~OneClauseCode() { free_executable(code); }
     /* tape {head (1, 2, 3), clause (out 4, lhs 1, rhs 2 where the opcode has one), end (4)} -> installed code */
-    int make(int device, int op, float imm, bool loose)
+    int make(int device, int op, float imm, bool loose, bool tight = false)
     {
         uint32_t immbits;
         memcpy(&immbits, &imm, 4);
@@ -2466,7 +2477,7 @@ struct OneClauseCode {
         const bool has_r = op == MPR_OP_ADD_LHS_RHS || op == MPR_OP_MUL_LHS_RHS || op == MPR_OP_MIN_LHS_RHS || op == MPR_OP_MAX_LHS_RHS ||
                            op == MPR_OP_SUB_IMM_RHS || op == MPR_OP_SUB_LHS_RHS || op == MPR_OP_DIV_IMM_RHS || op == MPR_OP_DIV_LHS_RHS || op == MPR_OP_COPY_RHS;
         const uint64_t tape[3] = {mpr_cl_make(0, 1, 2, 3, 0), mpr_cl_make((uint32_t)op, 4, has_l ? 1 : 0, has_r ? 2 : 0, immbits), mpr_cl_make(0, 4, 0, 0, 0)};
-        const mpr::IntervalCode g = mpr::interval_gen_build(tape, 3, mpr::IW_FIRST, loose, 0, 3, false, loose ? mpr::IGEN_LEAN_VGPRS : 0, loose);
+        const mpr::IntervalCode g = mpr::interval_gen_build(tape, 3, mpr::IW_FIRST, loose, 0, 3, false, tight ? mpr::IGEN_TIGHT_VGPRS : loose ? mpr::IGEN_LEAN_VGPRS : 0, loose, tight);
         if (!g.ok) return mpr::set_error(MPR_ERR_UNSUPPORTED, "the generator does not take this clause");
         const size_t n = (g.words.size() + 127) & ~(size_t)63;
         code = static_cast<uint32_t*>(alloc_executable(device, n * sizeof(uint32_t)));
@@ -2525,6 +2536,22 @@ extern "C" int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float o
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, d.p, 5 * 8, hipMemcpyDeviceToHost));
+    return MPR_OK;
+}
+extern "C" int mpr_test_tight_trig(int32_t device, int32_t is_sin, uint64_t first, uint64_t count, uint64_t out[7])
+{
+    if (!out) return mpr::set_error(MPR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    OneClauseCode oc;
+    const int rc = oc.make(device, is_sin ? MPR_OP_SIN_LHS : MPR_OP_COS_LHS, 0.0f, true, true);
+    if (rc) return rc;
+    DevBuf d;
+    HIP_TRY(d.alloc(7 * 8));
+    HIP_TRY(hipMemset(d.p, 0, 7 * 8));
+    mprk::launch_test_tight_trig(nullptr, oc.code, is_sin, first, count, (unsigned long long*)d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d.p, 7 * 8, hipMemcpyDeviceToHost));
     return MPR_OK;
 }
 extern "C" int mpr_test_float_in_enclosure(int32_t device, int32_t op, float imm, uint64_t first, uint64_t count, uint64_t out[6])

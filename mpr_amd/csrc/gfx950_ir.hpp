@@ -57,7 +57,7 @@ enum : uint16_t {
     F_CALL = 256,       /* s_swappc_b64: clobbers what the called routine may */
 };
 enum class Op : uint8_t {
-    V_MOV, V_EXP, V_LOG, V_RCP, V_SQRT,
+    V_MOV, V_EXP, V_LOG, V_RCP, V_SQRT, V_SIN, V_COS, V_FLOOR,
     V_CNDMASK, V_ADD_F32, V_SUB_F32, V_SUBREV_F32, V_MUL_F32, V_MIN_F32, V_MAX_F32, V_MIN_U32, V_MAX_U32, V_ASHRREV_I32,
     V_AND, V_OR, V_XOR, V_ADD_U32, V_SUB_U32,
     V_MAX3_F32, V_MED3_F32, V_FMA_F32, V_LSHL_OR, V_BFE_U32, V_WRITELANE,
@@ -88,6 +88,9 @@ inline const OpInfo& info(Op op)
         {"v_log_f32", Fmt::VOP1, 0x21, 0x161, 1, F_TRANS},
         {"v_rcp_f32", Fmt::VOP1, 0x22, 0x162, 1, F_TRANS},
         {"v_sqrt_f32", Fmt::VOP1, 0x27, 0x167, 1, F_TRANS},
+        {"v_sin_f32", Fmt::VOP1, 0x29, 0x169, 1, F_TRANS},      /* argument in revolutions, |x| <= 256 */
+        {"v_cos_f32", Fmt::VOP1, 0x2a, 0x16a, 1, F_TRANS},
+        {"v_floor_f32", Fmt::VOP1, 0x1f, 0x15f, 1, 0},
         {"v_cndmask_b32", Fmt::VOP2, 0, 0x100, 3, F_HALF},
         {"v_add_f32", Fmt::VOP2, 1, 0x101, 2, F_COMMUTES},
         {"v_sub_f32", Fmt::VOP2, 2, 0x102, 2, 0},
@@ -310,6 +313,7 @@ inline std::string opnd_text(const Opnd& o, bool pair, bool as_float, uint32_t l
                 case 245: return "-2.0";
                 case 246: return "4.0";
                 case 247: return "-4.0";
+                case 248: return "0.15915494";
                 default: break;
             }
             snprintf(b, sizeof b, "?%d", o.id);

@@ -16,10 +16,11 @@ struct TapeCode {
     std::vector<uint32_t> words;
     int fwd_dw = 0, bwd_dw = 0, deriv_dw = 0, full_dw = 0, vox_dw = 0, fwdg_dw = 0, derivg_dw = 0;   /* (in this order; fwdg / derivg: the guarded walks) */
     int walk_words = 0, nchoices = 0;
-    /* round 5 (interval_gen.hpp), behind the seven: the scheduled interval forward walks [kind: first / below / below, guarded][exact, loose]:
-     * where in `words`, and how many dwords (0: none — loose: the tape has clauses the loose arithmetic does not take) */
-    int iw_at[3][2] = {{0, 0}, {0, 0}, {0, 0}}, iw_dw[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-    int iw_instructions[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    /* round 5 (interval_gen.hpp), behind the seven: the scheduled interval forward walks [kind: first / below / below, guarded][exact, loose,
+     * round 6: tight]: where in `words`, and how many dwords (0: none — loose: the tape has clauses the loose arithmetic does not take; tight:
+     * or no sin / cos) */
+    int iw_at[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, iw_dw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    int iw_instructions[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     int vox_min_run = 0;             /* the shortest guarded run the float walk was generated with */
 };
 constexpr int TAPE_CODE_DEFAULT_MIN_RUN = 5;

@@ -22,9 +22,16 @@ using namespace ir;
 constexpr uint32_t SIGN = 0x80000000u;
 /* fixed registers of the code (interval_gen.hpp) */
 constexpr int R_OUT_LO = 36, R_OUT_HI = 37, R_ARG = 36, R_RES = 40, R_MAG = 42, R_DEC = 56;
+/* tight code (interval_gen.hpp): the second result and the NaN accumulator of the values that lead to it */
+constexpr int R_TOUT_LO = 38, R_TOUT_HI = 39, R_TNAN = 40;
+/* |sin x - v_sin_f32(x / 2 pi)| and the float pass's own |sinf x - sin x| (include/mpr_fmath.h) together, with room to spare: the
+ * instruction's error is measured on every float of the domain by tests/test_gpu_primitives.py::test_tight_sin_cos_code_on_every_float */
+constexpr uint32_t TIGHT_TRIG_EPS = 0x37000000u;          /* 2^-17 */
 constexpr int S_RET_ROUTINE = 36, S_RET_CODE = 38, S_BAD = 40, S_REDO = 60, S_DEC_L = 72, S_DEC_R = 74;
 /* IW_FIRST_MASKS: the lanes that decided anything, the register with the LDS address of the lane's entry of the current group of 64 */
 constexpr int S_ANY = 78, R_CHOICE_ADDR = 60;
+/* tight code: the lanes in which an operand of the tight values left its routine's domain (no second verdict for them) */
+constexpr int S_TBAD = 76;
 
 struct IV {
     Opnd a, b;          /* exact: lo, hi; loose: -lo, hi */
@@ -55,6 +62,10 @@ struct Gen {
     bool loose = false;
     int kind = IW_FIRST;
     int mag_next = 0;
+    bool quiet = false;                 /* the tight twin of a clause: an operand outside its routine's domain or a NaN costs the lane its
+                                         * second verdict (s[76:77], v40), not the wavefront its walk */
+    int imposed_k = -1;                 /* the clause whose imposed decisions imp_l / imp_r hold */
+    Opnd imp_l, imp_r;
     std::map<uint32_t, Opnd> kregs;     /* loose: constants kept in registers (defined in the prologue) */
     std::vector<Inst> prologue_consts;
 
@@ -94,6 +105,7 @@ struct Gen {
             case 0xc0000000u: return IMM(245);
             case 0x40800000u: return IMM(246);
             case 0xc0800000u: return IMM(247);
+            case 0x3e22f983u: return IMM(248);        /* 1 / 2 pi */
             default: return LIT();
         }
     }
@@ -304,12 +316,16 @@ struct Gen {
     /* the sum of the widths of what the products gave: a NaN as soon as one of them is (v42..v45 in turn) */
     IV nan_checked(IV o)
     {
-        const int r = R_MAG + (mag_next++ & 3);
         Opnd t = op2(Op::V_ADD_F32, o.a, o.b);
+        if (quiet) {
+            e(Op::V_ADD_F32, PV(R_TNAN), PV(R_TNAN), t);
+            return o;
+        }
+        const int r = R_MAG + (mag_next++ & 3);
         e(Op::V_ADD_F32, PV(r), PV(r), t);
         return o;
     }
-    void bad_if(Opnd lanes) { e(Op::S_OR_B64, PS(S_BAD), PS(S_BAD), lanes); }
+    void bad_if(Opnd lanes) { const int r = quiet ? S_TBAD : S_BAD; e(Op::S_OR_B64, PS(r), PS(r), lanes); }
     IV l_add(IV A, IV B)
     {
         IV o; o.a = op2(Op::V_ADD_F32, A.a, B.a);
@@ -408,6 +424,7 @@ struct Gen {
             /* decided above: the chosen operand as it is — the other one may never have been computed (a guarded run) */
             Opnd al, ar;
             imposed(k, &al, &ar);
+            imposed_k = k; imp_l = al; imp_r = ar;
             Opnd a1 = sel(o.a, A.a, al), b1 = sel(o.b, A.b, al);
             o.a = sel(a1, B.a, ar);
             o.b = sel(b1, B.b, ar);
@@ -428,6 +445,81 @@ struct Gen {
         e(Op::V_LSHL_OR, PV(R_DEC + (k >> 5)), t, INT(k & 31), PV(R_DEC + (k >> 5)));
         Opnd u = sel(INT(0), INT(1), c2);
         e(Op::V_LSHL_OR, PV(R_DEC + 2 + (k >> 5)), u, INT(k & 31), PV(R_DEC + 2 + (k >> 5)));
+        return o;
+    }
+    /* the tight twin of a min / max clause: the enclosure of min / max (whatever this tile's wide walk decided: a sound decision
+     * is a fact about the values, and the enclosure holds either way), with what was decided ABOVE imposed as the wide walk imposes
+     * it — the float pass walks the tape with those decisions applied, facts or not */
+    IV l_minmax_tight(bool is_min, IV A, IV B, int k)
+    {
+        IV o;
+        if (is_min) {
+            o.a = op2(Op::V_MAX_F32, A.a, B.a);
+            o.b = op2(Op::V_MIN_F32, A.b, B.b);
+        } else {
+            o.a = op2(Op::V_MIN_F32, A.a, B.a);
+            o.b = op2(Op::V_MAX_F32, A.b, B.b);
+        }
+        if (kind != IW_FIRST && kind != IW_FIRST_MASKS) {
+            Opnd al = imp_l, ar = imp_r;
+            if (imposed_k != k) { imposed(k, &al, &ar); imposed_k = k; imp_l = al; imp_r = ar; }
+            Opnd a1 = sel(o.a, A.a, al), b1 = sel(o.b, A.b, al);
+            o.a = sel(a1, B.a, ar);
+            o.b = sel(b1, B.b, ar);
+        }
+        return o;
+    }
+    /* sin / cos of an interval (tight code only; the reference's and the loose code's enclosure is [-1, 1] whatever the argument:
+     * inc/gpu_interval.hpp:353, the range reduction behind it, :355-375, is dead code).  The functions are monotone between their
+     * extrema: [min, max] of the values at the ends unless a maximum (a minimum) lies inside, which the integer parts of the ends
+     * in revolutions tell.  The hardware's v_sin_f32 / v_cos_f32 take revolutions; everything is padded: the ends by what the
+     * product with 1 / 2 pi and the sums below can be off (so that an extremum near an end counts as inside), the values by
+     * TIGHT_TRIG_EPS + |x| 2^-22 (the instruction's error, the argument's, and the float pass's own sinf / cosf against the real
+     * function).  Beyond |x| = 1024 the pad grows by |x| - 1024: both extrema count as inside, the result is [-1, 1]; an end that
+     * is a NaN is caught by the accumulator. */
+    IV l_sincos(IV A, bool is_sin)
+    {
+        Opnd w = op2(Op::V_ADD_F32, A.a, A.b);
+        e(Op::V_ADD_F32, PV(R_TNAN), PV(R_TNAN), w);
+        Opnd nvl = lit2(Op::V_MUL_F32, 0x3e22f983u, A.a);           /* -lo / 2 pi */
+        Opnd vh = lit2(Op::V_MUL_F32, 0x3e22f983u, A.b);
+        Opnd am = op2(Op::V_MAX_F32, A.a, A.b, 0, 3);               /* max(|lo|, |hi|) */
+        Opnd ex0 = lit2(Op::V_SUBREV_F32, 0x44800000u, am);         /* |x| - 1024 */
+        Opnd ex = op2(Op::V_MAX_F32, INT(0), ex0);
+        Opnd p0 = lit2(Op::V_MUL_F32, 0x34800000u, am);             /* |x| 2^-22 */
+        Opnd p1 = lit2(Op::V_ADD_F32, 0x35000000u, p0);             /* + 2^-21 */
+        Opnd pad = op2(Op::V_ADD_F32, p1, ex);
+        Opnd E = lit2(Op::V_ADD_F32, TIGHT_TRIG_EPS, p0);
+        Opnd th = op2(Op::V_ADD_F32, vh, pad);                      /* the upper end in revolutions, padded */
+        Opnd tl = op2(Op::V_ADD_F32, nvl, pad);                     /* minus the lower end, padded */
+        /* maxima at k + omax revolutions, minima at k + omin: one inside <=> floor(hi - o) > floor(lo - o) */
+        Opnd hmax_arg, lmax_arg, hmin_arg, lmin_arg;
+        if (is_sin) {                                               /* maxima at 1/4, minima at 3/4 */
+            hmax_arg = lit2(Op::V_ADD_F32, 0xbe800000u, th);
+            lmax_arg = lit2(Op::V_ADD_F32, 0x3e800000u, tl);
+            hmin_arg = lit2(Op::V_ADD_F32, 0x3e800000u, th);
+            lmin_arg = lit2(Op::V_ADD_F32, 0xbe800000u, tl);
+        } else {                                                    /* maxima at 0, minima at 1/2 */
+            hmax_arg = th;
+            lmax_arg = tl;
+            hmin_arg = op2(Op::V_ADD_F32, IMM(C_HALF), th);
+            lmin_arg = op2(Op::V_ADD_F32, IMM(241), tl);
+        }
+        Opnd fh_max = op1(Op::V_FLOOR, hmax_arg), fl_max = op1(Op::V_FLOOR, lmax_arg, 1);
+        Opnd fh_min = op1(Op::V_FLOOR, hmin_arg), fl_min = op1(Op::V_FLOOR, lmin_arg, 1);
+        Opnd has_max = cmp(Op::C_LT, fl_max, fh_max);
+        Opnd has_min = cmp(Op::C_LT, fl_min, fh_min);
+        const Op f = is_sin ? Op::V_SIN : Op::V_COS;
+        Opnd c_lo = op1(f, nvl, 1);
+        Opnd c_hi = op1(f, vh);
+        Opnd mx0 = op2(Op::V_MAX_F32, c_lo, c_hi);
+        Opnd nm0 = op2(Op::V_MAX_F32, c_lo, c_hi, 3);
+        Opnd mx1 = op2(Op::V_ADD_F32, mx0, E);
+        Opnd nm1 = op2(Op::V_ADD_F32, nm0, E);
+        Opnd mx2 = op2(Op::V_MIN_F32, IMM(C_ONE), mx1);
+        Opnd nm2 = op2(Op::V_MIN_F32, IMM(C_ONE), nm1);
+        IV o; o.b = sel(mx2, IMM(C_ONE), has_max);
+        o.a = sel(nm2, IMM(C_ONE), has_min);
         return o;
     }
     void flush_choices(int group)
@@ -692,7 +784,7 @@ struct Pools {
     std::vector<int> v_unsafe, v_safe;      /* vector registers a call may / may not clobber */
     std::vector<int> s_pairs;
 };
-Pools pools_for(bool loose, int vgpr_limit, bool big)
+Pools pools_for(bool loose, int vgpr_limit, bool big, bool tight)
 {
     Pools p;
     /* (vgpr_limit: the harness that runs the code names only the vector registers below it: a wavefront with fewer registers) */
@@ -709,7 +801,7 @@ Pools pools_for(bool loose, int vgpr_limit, bool big)
         /* no calls: everything but the output pair, the magnitude accumulators and the decision words */
         range(p.v_safe, 60, 117);
         range(p.v_safe, 0, 35);
-        range(p.v_safe, 38, 41);
+        range(p.v_safe, tight ? 41 : 38, 41);     /* (tight code: v38 / v39 the second result, v40 its NaN accumulator) */
         range(p.v_safe, 46, 55);
         range(p.s_pairs, 0, 30, 2);
         range(p.s_pairs, 42, 58, 2);
@@ -730,7 +822,7 @@ Pools pools_for(bool loose, int vgpr_limit, bool big)
     return p;
 }
 
-bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limit, bool big, int* max_v, int* max_s)
+bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limit, bool big, bool tight, int* max_v, int* max_s)
 {
     const int n = (int)code.size();
     std::vector<int> vdef(nv, -1), vlast(nv, -1), sdef(ns, -1), slast(ns, -1);
@@ -750,7 +842,7 @@ bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limi
         else if (in.dst.k == K::S) { if (sdef[in.dst.id] < 0) sdef[in.dst.id] = j; slast[in.dst.id] = std::max(slast[in.dst.id], j); }
         else if (in.dst.k == K::PV) pv_written[in.dst.id] = 1;
     }
-    Pools pools = pools_for(loose, vgpr_limit, big);
+    Pools pools = pools_for(loose, vgpr_limit, big, tight);
     std::vector<char> safe_reg(256, 0), pool_reg(256, 0);
     for (int r : pools.v_safe) safe_reg[r] = pool_reg[r] = 1;
     for (int r : pools.v_unsafe) pool_reg[r] = 1;
@@ -913,19 +1005,22 @@ void insert_wait_states(std::vector<Inst>& code, int* nops)
 
 }  // namespace
 
-IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text, int vgpr_limit, bool report_only)
+IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loose, int window, int min_run, bool keep_text, int vgpr_limit, bool report_only,
+                                bool tight)
 {
     IntervalCode g;
     if (!cl || len < 2 || kind < IW_FIRST || kind > IW_FIRST_MASKS) return g;
     if (kind == IW_FIRST_MASKS && !loose) return g;           /* (tapes with asin / acos / atan: the interpreter) */
     if (kind == IW_FIRST_MASKS) report_only = true;
-    int end = -1, nch = 0;
+    if (tight && (!loose || kind == IW_FIRST_MASKS)) return g;
+    int end = -1, nch = 0, ntrig = 0;
     for (int i = 1; i < len; ++i) {
         const uint32_t op = mpr_cl_op(cl[i]);
         if (op == MPR_OP_INVALID) { end = i; break; }
         if (op == MPR_OP_JUMP || op >= MPR_OP_COUNT || mpr_cl_out(cl[i]) == 0) return g;
         if ((uses_l(op) && mpr_cl_lhs(cl[i]) == 0) || (uses_r(op) && mpr_cl_rhs(cl[i]) == 0)) return g;
         if (mpr_op_is_minmax(op)) ++nch;
+        if (op == MPR_OP_SIN_LHS || op == MPR_OP_COS_LHS) ++ntrig;
         if (loose) {
             if (op == MPR_OP_ASIN_LHS || op == MPR_OP_ACOS_LHS || op == MPR_OP_ATAN_LHS) return g;
             if (op == MPR_OP_DIV_LHS_IMM) {
@@ -939,6 +1034,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
         }
     }
     if (end < 0 || nch > (kind == IW_FIRST_MASKS ? IGEN_MAX_CHOICES_MASKS : IGEN_MAX_CHOICES)) return g;
+    if (tight && ntrig == 0) return g;                      /* nothing to tighten */
 
     std::vector<DeadRun> runs;
     if (kind == IW_BELOW_GUARDED) {
@@ -951,8 +1047,8 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
     Gen e;
     e.loose = loose;
     e.kind = kind;
-    std::vector<IV> slot(256);
-    std::vector<char> defined(256, 0);
+    std::vector<IV> slot(256), tslot(256);                  /* tslot / has_t: the tight value of a slot that depends on a sin / cos */
+    std::vector<char> defined(256, 0), has_t(256, 0);
     /* prologue: the axes */
     e.clause = 0;
     {
@@ -965,6 +1061,10 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             e.e(Op::V_MOV, PV(R_MAG + 3), INT(0));
             e.e(Op::S_MOV_B64, PS(S_BAD), INT(0));
             if (kind == IW_FIRST_MASKS) e.e(Op::S_MOV_B64, PS(S_ANY), INT(0));
+            if (tight) {
+                e.e(Op::V_MOV, PV(R_TNAN), INT(0));
+                e.e(Op::S_MOV_B64, PS(S_TBAD), INT(0));
+            }
         }
         for (int a = 0; a < 3; ++a) {
             IV v;
@@ -974,6 +1074,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             /* (a later axis in the same slot replaces an earlier one, as the interpreters' stores do) */
             slot[(size_t)hs[a]] = v;
             defined[(size_t)hs[a]] = 1;
+            has_t[(size_t)hs[a]] = 0;
         }
     }
     const size_t consts_at = e.code.size();
@@ -1006,33 +1107,54 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
         if (uses_r(op)) B = get(r);
         bool okc = true;
         if (loose) {
-            switch (op) {
-                case MPR_OP_SQUARE_LHS: O = e.l_square(A); break;
-                case MPR_OP_SQRT_LHS: O = e.l_sqrt(A); break;
-                case MPR_OP_NEG_LHS: O = e.l_neg(A); break;
-                case MPR_OP_SIN_LHS:
-                case MPR_OP_COS_LHS: O.a = e.movk(0x3f800000u); O.b = O.a; break;
-                case MPR_OP_EXP_LHS: O = e.l_exp(A); break;
-                case MPR_OP_ABS_LHS: O = e.l_abs(A); break;
-                case MPR_OP_LOG_LHS: O = e.l_log(A); break;
-                case MPR_OP_ADD_LHS_IMM: O = e.l_add_imm(A, K); break;
-                case MPR_OP_ADD_LHS_RHS: O = e.l_add(A, B); break;
-                case MPR_OP_MUL_LHS_IMM: O = e.l_mul_imm(A, K); break;
-                case MPR_OP_MUL_LHS_RHS: O = e.l_mul(A, B); break;
-                case MPR_OP_MIN_LHS_IMM: O = e.l_minmax(true, A, e.l_const(K), choice); break;
-                case MPR_OP_MIN_LHS_RHS: O = e.l_minmax(true, A, B, choice); break;
-                case MPR_OP_MAX_LHS_IMM: O = e.l_minmax(false, A, e.l_const(K), choice); break;
-                case MPR_OP_MAX_LHS_RHS: O = e.l_minmax(false, A, B, choice); break;
-                case MPR_OP_SUB_LHS_IMM: O = e.l_add_imm(A, K ^ SIGN); break;
-                case MPR_OP_SUB_IMM_RHS: O = e.l_add_imm(e.l_neg(B), K); break;
-                case MPR_OP_SUB_LHS_RHS: O = e.l_sub(A, B); break;
-                case MPR_OP_DIV_LHS_IMM: O = e.l_div_imm(A, K); break;
-                case MPR_OP_DIV_IMM_RHS: O = e.l_div(e.l_const(K), B); break;
-                case MPR_OP_DIV_LHS_RHS: O = e.l_div(A, B); break;
-                case MPR_OP_COPY_IMM: O = e.l_const(K); break;
-                case MPR_OP_COPY_LHS: O = A; break;
-                case MPR_OP_COPY_RHS: O = B; break;
-                default: okc = false; break;
+            /* twin: the clause again on the operands' tight values (tight code, clauses that depend on a sin / cos) */
+            auto loose_clause = [&](IV A, IV B, bool twin, IV* O) -> bool {
+                switch (op) {
+                    case MPR_OP_SQUARE_LHS: *O = e.l_square(A); break;
+                    case MPR_OP_SQRT_LHS: *O = e.l_sqrt(A); break;
+                    case MPR_OP_NEG_LHS: *O = e.l_neg(A); break;
+                    case MPR_OP_SIN_LHS:
+                    case MPR_OP_COS_LHS:
+                        if (twin) *O = e.l_sincos(A, op == MPR_OP_SIN_LHS);
+                        else { O->a = e.movk(0x3f800000u); O->b = O->a; }
+                        break;
+                    case MPR_OP_EXP_LHS: *O = e.l_exp(A); break;
+                    case MPR_OP_ABS_LHS: *O = e.l_abs(A); break;
+                    case MPR_OP_LOG_LHS: *O = e.l_log(A); break;
+                    case MPR_OP_ADD_LHS_IMM: *O = e.l_add_imm(A, K); break;
+                    case MPR_OP_ADD_LHS_RHS: *O = e.l_add(A, B); break;
+                    case MPR_OP_MUL_LHS_IMM: *O = e.l_mul_imm(A, K); break;
+                    case MPR_OP_MUL_LHS_RHS: *O = e.l_mul(A, B); break;
+                    case MPR_OP_MIN_LHS_IMM: *O = twin ? e.l_minmax_tight(true, A, e.l_const(K), choice) : e.l_minmax(true, A, e.l_const(K), choice); break;
+                    case MPR_OP_MIN_LHS_RHS: *O = twin ? e.l_minmax_tight(true, A, B, choice) : e.l_minmax(true, A, B, choice); break;
+                    case MPR_OP_MAX_LHS_IMM: *O = twin ? e.l_minmax_tight(false, A, e.l_const(K), choice) : e.l_minmax(false, A, e.l_const(K), choice); break;
+                    case MPR_OP_MAX_LHS_RHS: *O = twin ? e.l_minmax_tight(false, A, B, choice) : e.l_minmax(false, A, B, choice); break;
+                    case MPR_OP_SUB_LHS_IMM: *O = e.l_add_imm(A, K ^ SIGN); break;
+                    case MPR_OP_SUB_IMM_RHS: *O = e.l_add_imm(e.l_neg(B), K); break;
+                    case MPR_OP_SUB_LHS_RHS: *O = e.l_sub(A, B); break;
+                    case MPR_OP_DIV_LHS_IMM: *O = e.l_div_imm(A, K); break;
+                    case MPR_OP_DIV_IMM_RHS: *O = e.l_div(e.l_const(K), B); break;
+                    case MPR_OP_DIV_LHS_RHS: *O = e.l_div(A, B); break;
+                    case MPR_OP_COPY_IMM: *O = e.l_const(K); break;
+                    case MPR_OP_COPY_LHS: *O = A; break;
+                    case MPR_OP_COPY_RHS: *O = B; break;
+                    default: return false;
+                }
+                return true;
+            };
+            okc = loose_clause(A, B, false, &O);
+            if (okc && tight) {
+                const bool tl = uses_l(op) && has_t[(size_t)l], tr = uses_r(op) && has_t[(size_t)r];
+                if (tl || tr || op == MPR_OP_SIN_LHS || op == MPR_OP_COS_LHS) {
+                    IV T;
+                    e.quiet = true;
+                    okc = loose_clause(tl ? tslot[(size_t)l] : A, tr ? tslot[(size_t)r] : B, true, &T);
+                    e.quiet = false;
+                    tslot[(size_t)o] = T;
+                    has_t[(size_t)o] = 1;
+                } else {
+                    has_t[(size_t)o] = 0;
+                }
             }
         } else {
             auto kiv = [&](uint32_t k) { IV c; c.a = e.movk(k); c.b = c.a; return c; };
@@ -1095,6 +1217,16 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
         ++e.clause;
         e.e(Op::V_XOR, PV(R_OUT_LO), Gen::const_src(SIGN), R.a, NONE(), 0, 0, SIGN);
         e.e(Op::V_MOV, PV(R_OUT_HI), R.b);
+        if (tight) {
+            /* the second result: the result's tight value; [-inf, inf] in the lanes whose tight values met a NaN or left a domain */
+            const IV T = has_t[(size_t)rs] ? tslot[(size_t)rs] : R;
+            Opnd tn = e.cmp(Op::C_U, PV(R_TNAN), PV(R_TNAN));
+            Opnd kill = e.sop(Op::S_OR_B64, tn, PS(S_TBAD));
+            Opnd inf = e.movk(0x7f800000u);
+            Opnd ta = e.sel(T.a, inf, kill), tb = e.sel(T.b, inf, kill);
+            e.e(Op::V_XOR, PV(R_TOUT_LO), Gen::const_src(SIGN), ta, NONE(), 0, 0, SIGN);
+            e.e(Op::V_MOV, PV(R_TOUT_HI), tb);
+        }
         e.e(Op::S_SETPC, NONE(), PS(S_RET_CODE));
         if (!report_only) {
             Inst& l = e.e(Op::LABEL, NONE());
@@ -1131,7 +1263,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
             }
         }
         int mv = 0, ms = 0;
-        if (!allocate(code, e.nv, e.ns, loose, vgpr_limit, kind == IW_FIRST_MASKS, &mv, &ms)) {
+        if (!allocate(code, e.nv, e.ns, loose, vgpr_limit, kind == IW_FIRST_MASKS, tight, &mv, &ms)) {
             if (window > 0 && w == window && w == 1) return g;
             continue;
         }
@@ -1175,6 +1307,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
         g.est_cycles = cycles;
         break;
     }
+    g.tight = tight;
     g.nchoices = nch;
     g.walk_words = end;
     g.result_slot = rs;
@@ -1188,8 +1321,8 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
 extern "C" int mpr_test_interval_gen(const uint64_t* clauses, int32_t len, int32_t kind, int32_t loose, int32_t window, int32_t min_run,
                                      uint32_t* out, int32_t cap, char* text_out, int32_t text_cap, int32_t* info)
 {
-    /* (loose & 2: the code for the harness with 64 vector registers, as the tile stages run it; & 4: report_only) */
-    const mpr::IntervalCode g = mpr::interval_gen_build(clauses, len, kind, (loose & 1) != 0, window, min_run, text_out != nullptr, (loose & 2) ? mpr::IGEN_LEAN_VGPRS : 0, (loose & 4) != 0);
+    /* (loose & 2: the code for the harness with 64 vector registers, as the tile stages run it; & 4: report_only; & 8: tight) */
+    const mpr::IntervalCode g = mpr::interval_gen_build(clauses, len, kind, (loose & 1) != 0, window, min_run, text_out != nullptr, (loose & 2) ? ((loose & 8) ? mpr::IGEN_TIGHT_VGPRS : mpr::IGEN_LEAN_VGPRS) : 0, (loose & 4) != 0, (loose & 8) != 0);
     if (!g.ok) return -1;
     if (info) {
         info[0] = g.instructions; info[1] = g.nops; info[2] = g.window; info[3] = g.max_vgprs; info[4] = g.max_sgpr_pairs;

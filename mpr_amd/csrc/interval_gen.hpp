@@ -61,6 +61,7 @@ struct IntervalCode {
     int max_vgprs = 0, max_sgpr_pairs = 0;
     int nchoices = 0, walk_words = 0, result_slot = 0;
     int est_cycles = 0;                 /* the scheduler's own estimate for a lone wavefront */
+    bool tight = false;                 /* the code also leaves the second, tight result (v[38:39]) */
 };
 
 constexpr int IGEN_MAX_CHOICES = 64;
@@ -68,12 +69,22 @@ constexpr int IGEN_MAX_CHOICES_MASKS = 4096;    /* (the store's 16-bit offset: 6
 /* loose walks name vector registers below this only (interval_gen_build: vgpr_limit): the tile stages run them in wavefronts of 80
  * registers, six to a SIMD instead of four (tile_gen_asm.hpp: tile_gen_forward2_lean) */
 constexpr int IGEN_LEAN_VGPRS = 64;
+/* ... tight code below this (it carries the values that depend on a sin / cos twice): 96 registers, five to a SIMD */
+constexpr int IGEN_TIGHT_VGPRS = 80;
 
 /* clauses: head, operations, end (the host copy of a root tape).  loose: see above (false for tapes with asin / acos / atan
  * clauses or a constant divisor outside 2^-100 .. 2^100: ok == false).  window: clauses the scheduler may look ahead (0: the
  * default, shrunk until the registers suffice; 1: the tape's own order).  min_run: shortest dead run worth a guard.
  * report_only (loose, tests): no branch to the redo entry — the code returns with the lanes that ask for the exact walk in s[40:41]. */
+/* tight (loose code of the kinds FIRST / BELOW / BELOW_GUARDED; ok == false for a tape without sin / cos: nothing to tighten): the
+ * code also leaves, in v[38:39], a SECOND enclosure of the result, from sin / cos enclosed by their monotone pieces where the
+ * reference — and everything above — has [-1, 1] whatever the argument (inc/gpu_interval.hpp:353; the range reduction behind it,
+ * :355-375, is dead code).  Everything the walk leaves otherwise — v[36:37], the decisions, the lanes that ask for the exact walk —
+ * is what the code without it leaves: the clauses that depend on a sin / cos are computed twice, on the wide and on the tight
+ * values of their operands.  The tight values decide nothing and are recorded nowhere; what was decided ABOVE is imposed on them as
+ * on the wide ones.  A lane whose tight values met a NaN or left a routine's domain gets [-inf, inf].  What the second result is for:
+ * kernels.hip: k_eval_tiles<.., LEAN> — a smallest tile it proves empty or filled skips the float pass. */
 IntervalCode interval_gen_build(const uint64_t* clauses, int len, int kind, bool loose, int window = 0, int min_run = 3, bool keep_text = false, int vgpr_limit = 0,
-                                bool report_only = false);
+                                bool report_only = false, bool tight = false);
 
 }  // namespace mpr

@@ -153,8 +153,10 @@ __device__ __noinline__ float2 interval_rare(uint32_t op, float2 l, float2 r, fl
  * TileStageArgs::gen_fwd / gen_bwd): a frame's first stage */
 /* LEAN (with GEN; TileStageArgs::lean): a stage that runs LOOSE scheduled code and neither pushes nor measures — 80 vector registers
  * instead of 128, six wavefronts per SIMD instead of four: the stage is bound by what its few wavefronts leave idle, not by issue */
-template <int DIM, bool ASM, int VS = 0, bool GEN = false, bool LEAN = false>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
-__global__ void __launch_bounds__(64, LEAN ? 6 : VS == TI_VS_SMALL_SLOTS ? 4 : VS ? 2 : 0)
+/* LEAN == 2 (TileStageArgs::lean == 2): the loose code is TIGHT code (interval_gen.hpp) — 96 vector registers, five wavefronts per SIMD — and the
+ * tiles its second enclosure decides skip the float pass */
+template <int DIM, bool ASM, int VS = 0, bool GEN = false, int LEAN = 0>      /* VS: 0, or the slots the register file is built for (24: 4 waves per SIMD, 93: 2) */
+__global__ void __launch_bounds__(64, LEAN == 2 ? 5 : LEAN ? 6 : VS == TI_VS_SMALL_SLOTS ? 4 : VS ? 2 : 0)
 k_eval_tiles(TileStageArgs a)
 {
     static_assert(!GEN || (ASM && VS == TI_VS_SMALL_SLOTS), "generated code runs on the small register slot file");
@@ -270,6 +272,7 @@ k_eval_tiles(TileStageArgs a)
     int end_index = 0;                 /* pool index of the end clause */
     uint64_t d = 0;
     float2 res_vs = make_float2(0.0f, 0.0f);
+    float2 res_tight = make_float2(-1.0f, 1.0f);    /* LEAN == 2: the second, tight enclosure of the result */
     uint32_t chl[2] = {0, 0}, chr[2] = {0, 0};      /* GEN: this lane's decisions (bit k: chose lhs / rhs at min / max clause k) */
     unsigned long long above_l = 0, above_r = 0;    /* ... what the parent tile decided for all of them (a.gen_parent) */
     unsigned long long gen_keeps = ~0ull;           /* ... the min / max clauses the tape they walk keeps */
@@ -296,8 +299,8 @@ k_eval_tiles(TileStageArgs a)
         gen_keeps = keeps;
         if (LEAN) {
             uint32_t redone = 0;
-            tile_gen_forward2_lean(a.gen_fwd2, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi), make_float2(vz.lo, vz.hi),
-                                   &res_vs, chl, chr, above_l, above_r, &redone);
+            tile_gen_forward2_lean<LEAN == 2>(a.gen_fwd2, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi), make_float2(vz.lo, vz.hi),
+                                              &res_vs, chl, chr, above_l, above_r, &redone, nullptr, LEAN == 2 ? &res_tight : nullptr);
             redone = __builtin_amdgcn_readfirstlane(redone);
             if (lane == 0) a.redo_flags[blockIdx.x] = redone ? 1 : 0;
             if (a.gen_redo_count && lane == 0) atomicAdd(a.gen_redo_count + (redone ? 1 : 0), 1u);
@@ -448,6 +451,17 @@ k_eval_tiles(TileStageArgs a)
         } else {
             ambiguous = true;
             verdict = SKIP0_AMBIGUOUS;
+        }
+    }
+    if (LEAN == 2 && ambiguous) {
+        /* the reference's enclosures leave the tile to the float pass; the tight one may not (TileStageArgs::lean).  For the records
+         * below the tile stays ambiguous; the float pass's list is made of the positions that are left */
+        if (res_tight.x > 0.0f) {                             /* no voxel of it is inside */
+            a.tiles[gidx].position = -1;
+        } else if (res_tight.y < 0.0f) {                      /* every voxel of it is: what the float pass would draw */
+            a.tiles[gidx].position = -1;
+            if (DIM == 3) atomicMax(&a.image[pos.w], pos.z);
+            else a.image[pos.w] = 1;
         }
     }
     if (GEN && a.self_info && valid) {
@@ -1331,6 +1345,97 @@ void launch_test_loose_gen(hipStream_t s, const uint32_t* code, int op, float im
 {
     hipLaunchKernelGGL(k_test_loose_gen, dim3(6144), dim3(64), 0, s, code, op, imm, other_lo, other_hi, x_is_rhs, first, count, out);
 }
+/* The TIGHT code of one SIN_LHS / COS_LHS clause (interval_gen.hpp) on every float of a range of bit patterns — as [x, x], as [x, x + w]
+ * with w up to 8 (extrema inside, or not), and as the interval between x and a scrambled copy of its bits — against the float pass's own
+ * sinf / cosf (include/mpr_fmath.h) at the ends, at the middle, and at the floats next to every multiple of pi / 2 inside (up to
+ * eight of them from the lower end): out[0] = intervals whose second enclosure misses one of those values (must be 0), [1] = one such
+ * bit pattern, [2] = intervals tested, [3] = lanes that asked for the exact walk (none: sin / cos have no domain to leave), [4] = the
+ * largest |v_sin_f32 / v_cos_f32(x / 2 pi) - the real function| met for |x| <= 1024, in units of 2^-40, [5] = intervals of width below
+ * 1 whose enclosure is narrower than 1 (it is worth something), [6] = those whose enclosure is not.  What the sound second verdict of
+ * the last tile stage rests on: checked on the instructions themselves. */
+__global__ void __launch_bounds__(64, 5)
+k_test_tight_trig(const uint32_t* code, int is_sin, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gen_io[4096];
+    const int lane = threadIdx.x;
+    unsigned long long bad = 0, tested = 0, example = 0, asked = 0, worst = 0, narrow = 0, wide = 0;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 64; base < count; base += (unsigned long long)gridDim.x * 64) {
+        const uint32_t bits = (uint32_t)(first + base + lane);
+        const bool mine = base + lane < count;
+        const float x = mpr_u2f(bits);
+        const uint32_t bits2 = (bits * 2654435761u) ^ 0x9E3779B9u;
+        const float x2 = mpr_u2f(bits2);
+        if (mine && __builtin_fabsf(x) <= 1024.0f) {
+            const float rev = x * 0.15915494f;
+            const float hw = is_sin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+            const double tr = is_sin ? sin((double)x) : cos((double)x);
+            const double err = __builtin_fabs((double)hw - tr) * 1099511627776.0;
+            const unsigned long long u = (unsigned long long)(err < 1e18 ? err : 1e18);
+            if (u > worst) worst = u;
+        }
+        for (int variant = 0; variant < 3; ++variant) {
+            float in_lo = x, in_hi = x;
+            if (variant == 1) in_hi = x + (float)(bits2 & 0xFFFFu) * (8.0f / 65536.0f);
+            if (variant == 2) { in_lo = x < x2 ? x : x2; in_hi = x < x2 ? x2 : x; }
+            const bool usable = mine && in_lo == in_lo && in_hi == in_hi && in_lo <= in_hi;
+            if (!usable) { in_lo = 1.0f; in_hi = 2.0f; }
+            /* the values the enclosure has to hold (round-to-nearest: the float pass's mode) */
+            float vmin = 2.0f, vmax = -2.0f;
+            auto take = [&](float p) {
+                if (!(p >= in_lo && p <= in_hi) || __builtin_fabsf(p) == __builtin_inff()) return;
+                const float v = is_sin ? mpr_sinf(p) : mpr_cosf(p);
+                vmin = v < vmin ? v : vmin;
+                vmax = v > vmax ? v : vmax;
+            };
+            take(in_lo);
+            take(in_hi);
+            take((float)(0.5 * ((double)in_lo + (double)in_hi)));
+            if (__builtin_fabsf(in_lo) < 1e9f) {
+                const double q = 1.5707963267948966;
+                const double j0 = __builtin_ceil((double)in_lo / q);
+                for (int j = 0; j < 8; ++j) {
+                    const float p = (float)((j0 + j) * q);
+                    take(p);
+                    take(mpr_u2f(mpr_f2u(p) + 1u));
+                    take(mpr_u2f(mpr_f2u(p) - 1u));
+                }
+            }
+            float d0 = 0.0f, d1 = 0.0f;
+            round_up_begin(in_lo, in_hi, vmin, vmax, d0, d1);
+            float2 res = make_float2(0.0f, 0.0f), tight = make_float2(0.0f, 0.0f);
+            uint32_t chl[2] = {0, 0}, chr[2] = {0, 0}, redone = 0, asks = 0;
+            tile_gen_forward2_lean<true>(code, gen_io, lane, make_float2(in_lo, in_hi), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), &res, chl, chr, 0, 0,
+                                         &redone, &asks, &tight);
+            asm volatile("" : "+v"(tight.x), "+v"(tight.y), "+v"(res.x), "+v"(res.y));
+            round_nearest_begin();
+            if (!usable) continue;
+            ++tested;
+            if (asks) { ++asked; continue; }
+            const bool ok = tight.x <= vmin && tight.y >= vmax && tight.x >= -1.0f && tight.y <= 1.0f && res.x == -1.0f && res.y == 1.0f;
+            if (!ok) {
+                ++bad;
+                example = bits | ((unsigned long long)variant << 32);
+            }
+            if (in_hi - in_lo < 1.0f && __builtin_fabsf(in_hi) <= 1024.0f && __builtin_fabsf(in_lo) <= 1024.0f) {
+                if (tight.y - tight.x < 1.0f) ++narrow;
+                else ++wide;
+            }
+        }
+    }
+    if (bad) {
+        atomicAdd(&out[0], bad);
+        out[1] = example;
+    }
+    atomicAdd(&out[2], tested);
+    atomicAdd(&out[3], asked);
+    atomicMax(&out[4], worst);
+    atomicAdd(&out[5], narrow);
+    atomicAdd(&out[6], wide);
+}
+void launch_test_tight_trig(hipStream_t s, const uint32_t* code, int is_sin, unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    hipLaunchKernelGGL(k_test_tight_trig, dim3(5120), dim3(64), 0, s, code, is_sin, first, count, out);
+}
 /* Is the float pass's f(x) inside the exact interval routine's enclosure of [x, x]?  Every bit pattern of [first, first + count):
  * out = {tested (x not a NaN), outside (both are numbers, f(x) beyond an end), one a NaN and the other not, a bit pattern outside,
  * the largest distance beyond an end in units of the end's last place (saturated at 2^40), a bit pattern of the NaN kind}.  The
@@ -1621,7 +1726,8 @@ bool launch_eval_tiles(hipStream_t s, int dim, const TileStageArgs& a)
         ((a.gen_bwd_full || a.gen_forward_only) ? true : a.gen_parent ? a.no_push : !a.groups)) {
         const size_t lds_gen = (size_t)std::max(a.choice_cap, 1) * 16 + 4096;
         if (a.lean && dim == 3) {
-            hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true, true>), dim3(groups), dim3(64), lds_gen, s, a);
+            if (a.lean == 2) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true, 2>), dim3(groups), dim3(64), lds_gen, s, a);
+            else hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true, 1>), dim3(groups), dim3(64), lds_gen, s, a);
             return true;
         }
         if (dim == 3) hipLaunchKernelGGL((k_eval_tiles<3, true, TI_VS_SMALL_SLOTS, true>), dim3(groups), dim3(64), lds_gen, s, a);

@@ -84,9 +84,14 @@ struct TileStageArgs {
     const uint32_t* gen_fwd2 = nullptr;        /* round 5: the scheduled forward walk this stage runs (interval_gen.hpp: the kind the stage needs, loose or
                                                 * exact) and the exact walk of the same kind a loose one falls back on (null: gen_fwd's code and harness) */
     const uint32_t* gen_fwd2_exact = nullptr;
-    bool lean = false;                         /* run as k_eval_tiles<.., LEAN>: gen_fwd2 is loose code for 64 vector registers, the stage neither pushes nor
+    int lean = 0;                         /* run as k_eval_tiles<.., LEAN>: gen_fwd2 is loose code for 64 vector registers, the stage neither pushes nor
                                                 * measures, six wavefronts per SIMD.  A wavefront whose walk asks for the exact code (or that belongs to the
                                                 * stage's sample) only raises redo_flags[its workgroup]: a second launch (only_flagged) runs those */
+    /* lean == 2: gen_fwd2 is TIGHT code (interval_gen.hpp; it names 80 vector registers: five wavefronts per SIMD) and this is the last tile
+     * stage of a frame nobody reads: a tile the reference's enclosures leave ambiguous and the second, tight enclosure proves empty or filled
+     * stays what it is for the records (the group's masks, which the float and normals passes read) but leaves the list the float pass walks —
+     * filled: its height is drawn here.  Sound: the tight enclosure holds every value the float pass would compute for the tile's voxels on the
+     * tape it would walk (the root tape with what was decided above imposed) */
     unsigned char* redo_flags = nullptr;
     const unsigned char* only_flagged = nullptr;
     unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
@@ -199,6 +204,7 @@ void launch_skip0_parents(hipStream_t s, const Skip0ParentsArgs& a);
 void launch_count_differences(hipStream_t s, const int* a, const int* b, size_t n, unsigned long long* out);
 void launch_test_interval_gen(hipStream_t s, const uint32_t* code, int loose, int n, const float* a_lo, const float* a_hi, const float* b_lo, const float* b_hi,
                               float* out_lo, float* out_hi, int* choice, int* asks_exact);
+void launch_test_tight_trig(hipStream_t s, const uint32_t* code, int is_sin, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_loose_gen(hipStream_t s, const uint32_t* code, int op, float imm, float other_lo, float other_hi, int x_is_rhs, unsigned long long first,
                            unsigned long long count, unsigned long long* out);
 void launch_test_float_in_enclosure(hipStream_t s, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);

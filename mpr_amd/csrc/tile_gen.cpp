@@ -613,8 +613,9 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     c->vox_min_run = vox_min_run;
     const int window = 0;
     for (int kind = 0; kind < 3; ++kind)
-        for (int loose = 0; loose < 2; ++loose) {
-            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window, 3, false, loose ? IGEN_LEAN_VGPRS : 0);
+        for (int loose = 0; loose < 3; ++loose) {         /* (2: loose and tight) */
+            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window, 3, false, loose == 2 ? IGEN_TIGHT_VGPRS : loose ? IGEN_LEAN_VGPRS : 0,
+                                                       false, loose == 2);
             if (!ic.ok) continue;
             c->iw_at[kind][loose] = (int)c->words.size();
             c->iw_dw[kind][loose] = (int)ic.words.size();

@@ -123,9 +123,12 @@ DEV void tile_gen_forward2(const uint32_t* code, const uint32_t* code_exact, uns
 /* The same for LOOSE code that names v0..v63 only (interval_gen.hpp: IGEN_LEAN_VGPRS): no routines to call, a fifth of the vector
  * registers left to the compiler — the kernel around it runs six wavefronts per SIMD.  A walk that asks for the exact code is not
  * redone here: *redone = 1 and the results are garbage (k_eval_tiles<.., LEAN> hands the wavefront's tiles to the launch behind it). */
+/* TIGHT: the code is tight code (interval_gen.hpp: it names v0..v79 and s[76:77] as well, and leaves a second enclosure of the
+ * result in v[38:39]: *tight); the kernel around it runs five wavefronts per SIMD. */
+template <bool TIGHT = false>
 DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, int lane, float2 x, float2 y, float2 z,
                                 float2* res, uint32_t* chl, uint32_t* chr, unsigned long long decided_lhs, unsigned long long decided_rhs,
-                                uint32_t* redone, uint32_t* bad_lane = nullptr)
+                                uint32_t* redone, uint32_t* bad_lane = nullptr, float2* tight = nullptr)
 {
     float* const io = reinterpret_cast<float*>(smem_io);
     io[lane] = x.x; io[64 + lane] = x.y; io[128 + lane] = y.x; io[192 + lane] = y.y; io[256 + lane] = z.x; io[320 + lane] = z.y;
@@ -138,46 +141,54 @@ DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, in
         u[4] = (uint32_t)(uintptr_t)code; u[5] = (uint32_t)((uintptr_t)code >> 32);
         u[8] = 0;
     }
-    asm volatile(
-        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
-        "ds_read_b32 v0, v32\n ds_read_b32 v1, v32 offset:256\n ds_read_b32 v2, v32 offset:512\n"
-        "ds_read_b32 v3, v32 offset:768\n ds_read_b32 v4, v32 offset:1024\n ds_read_b32 v5, v32 offset:1280\n"
-        "v_mov_b32 v33, %[io]\n"
-        "ds_read_b128 v[44:47], v33 offset:3840\n ds_read_b64 v[48:49], v33 offset:3856\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_readfirstlane_b32 s72, v44\n v_readfirstlane_b32 s73, v45\n v_readfirstlane_b32 s74, v46\n v_readfirstlane_b32 s75, v47\n"
-        "v_readfirstlane_b32 s34, v48\n v_readfirstlane_b32 s35, v49\n"
-        "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
-        "s_getpc_b64 s[40:41]\n"
-        "L_pc_%=:\n"
-        TG_ADDR(60, 61, "L_redo")
-        "s_swappc_b64 s[38:39], s[34:35]\n"
-        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"
-        "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"
-        "ds_write_b32 v32, v56 offset:2048\n ds_write_b32 v32, v57 offset:2304\n"
-        "ds_write_b32 v32, v58 offset:2560\n ds_write_b32 v32, v59 offset:2816\n"
-        "v_cndmask_b32 v54, 0, 1, s[40:41]\n"             /* (the lanes that ask for the exact walk, of code that only reports them: tests) */
-        "ds_write_b32 v32, v54 offset:3072\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_branch L_end_%=\n"
-        "L_redo_%=:\n"
-        "v_mov_b32 v33, %[io]\n v_mov_b32 v54, 1\n"
-        "ds_write_b32 v33, v54 offset:3872\n"
-        "s_waitcnt lgkmcnt(0)\n"
+#define TG_LEAN_TEXT                                                                                                      \
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"                                                    \
+        "ds_read_b32 v0, v32\n ds_read_b32 v1, v32 offset:256\n ds_read_b32 v2, v32 offset:512\n"                         \
+        "ds_read_b32 v3, v32 offset:768\n ds_read_b32 v4, v32 offset:1024\n ds_read_b32 v5, v32 offset:1280\n"            \
+        "v_mov_b32 v33, %[io]\n"                                                                                          \
+        "ds_read_b128 v[44:47], v33 offset:3840\n ds_read_b64 v[48:49], v33 offset:3856\n"                                \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                          \
+        "v_readfirstlane_b32 s72, v44\n v_readfirstlane_b32 s73, v45\n v_readfirstlane_b32 s74, v46\n v_readfirstlane_b32 s75, v47\n" \
+        "v_readfirstlane_b32 s34, v48\n v_readfirstlane_b32 s35, v49\n"                                                   \
+        "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"                                     \
+        "s_getpc_b64 s[40:41]\n"                                                                                          \
+        "L_pc_%=:\n"                                                                                                      \
+        TG_ADDR(60, 61, "L_redo")                                                                                         \
+        "s_swappc_b64 s[38:39], s[34:35]\n"                                                                               \
+        "v_lshrrev_b32 v32, 1, %[lane8]\n v_add_u32 v32, %[io], v32\n"                                                    \
+        "ds_write_b32 v32, v36 offset:1536\n ds_write_b32 v32, v37 offset:1792\n"                                         \
+        "ds_write_b32 v32, v56 offset:2048\n ds_write_b32 v32, v57 offset:2304\n"                                         \
+        "ds_write_b32 v32, v58 offset:2560\n ds_write_b32 v32, v59 offset:2816\n"                                         \
+        "v_cndmask_b32 v54, 0, 1, s[40:41]\n"             /* (the lanes that ask for the exact walk, of code that only reports them: tests) */ \
+        "ds_write_b32 v32, v54 offset:3072\n"                                                                             \
+        "ds_write_b32 v32, v38 offset:3328\n ds_write_b32 v32, v39 offset:3584\n"     /* (tight code: the second result) */ \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                          \
+        "s_branch L_end_%=\n"                                                                                             \
+        "L_redo_%=:\n"                                                                                                    \
+        "v_mov_b32 v33, %[io]\n v_mov_b32 v54, 1\n"                                                                       \
+        "ds_write_b32 v33, v54 offset:3872\n"                                                                             \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                          \
         "L_end_%=:\n"
-        :
-        : [lane8] "v"(lane8), [io] "s"(ioaddr)
-        : "memory", "vcc", "scc",
-          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19",
-          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",
-          "s34", "s35", "s36", "s37", "s38", "s39",
-          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
-          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-          "s72", "s73", "s74", "s75",
-          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
-          "s97", "s98", "s99",
-          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", TI_V10(1), TI_V10(2), TI_V10(3), TI_V10(4), TI_V10(5),
-          "v60", "v61", "v62", "v63");
+#define TG_LEAN_CLOBBERS                                                                                                  \
+          "memory", "vcc", "scc",                                                                                         \
+          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", \
+          "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31",                             \
+          "s34", "s35", "s36", "s37", "s38", "s39",                                                                       \
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",        \
+          "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", \
+          "s72", "s73", "s74", "s75",                                                                                     \
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", \
+          "s97", "s98", "s99",                                                                                            \
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", TI_V10(1), TI_V10(2), TI_V10(3), TI_V10(4), TI_V10(5), \
+          "v60", "v61", "v62", "v63"
+    if constexpr (TIGHT) {
+        asm volatile(TG_LEAN_TEXT : : [lane8] "v"(lane8), [io] "s"(ioaddr)
+                     : TG_LEAN_CLOBBERS, "s76", "s77", "v64", "v65", "v66", "v67", "v68", "v69", TI_V10(7));
+    } else {
+        asm volatile(TG_LEAN_TEXT : : [lane8] "v"(lane8), [io] "s"(ioaddr) : TG_LEAN_CLOBBERS);
+    }
+#undef TG_LEAN_TEXT
+#undef TG_LEAN_CLOBBERS
     res->x = io[384 + lane];
     res->y = io[448 + lane];
     const uint32_t* const iw = reinterpret_cast<const uint32_t*>(io);
@@ -187,6 +198,10 @@ DEV void tile_gen_forward2_lean(const uint32_t* code, unsigned char* smem_io, in
     chr[1] = iw[704 + lane];
     *redone = iw[968];
     if (bad_lane) *bad_lane = iw[768 + lane];
+    if (tight) {
+        tight->x = io[832 + lane];
+        tight->y = io[896 + lane];
+    }
 }
 
 /* A first stage's walk of a tape beyond 24 slots / 64 min / max clauses (interval_gen.hpp: IW_FIRST_MASKS; loose, no routines) inside

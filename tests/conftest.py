@@ -58,6 +58,14 @@ def tapes(mpr):
             d2 = mpr.sqrt((X - 0.3) * (X - 0.3) + (Y - 0.1) * (Y - 0.1) + Z * Z) - 0.3
             blend = mpr.log(mpr.exp(d1 * -64.0) + mpr.exp(d2 * -64.0)) / -64.0
             t = mpr.tmax(mpr.tmin(blend, mpr.sqrt(X * X + (Y + 0.6) * (Y + 0.6) + Z * Z) / 3.0 - 0.1), Z - 0.25)
+        elif name == "trig_blend":    # sin / cos the way bear has them (a rotation by an angle that depends on the position) + a ripple, min / max, an exp / log blend
+            ang = mpr.exp(-mpr.sqrt(X * X + Y * Y + Z * Z)) * 2.5
+            xr = X * mpr.cos(ang) - Y * mpr.sin(ang)
+            yr = X * mpr.sin(ang) + Y * mpr.cos(ang)
+            bar = mpr.tmax(mpr.tmax(mpr.tabs(xr) - 0.55, mpr.tabs(yr) - 0.2), mpr.tabs(Z) - 0.35)
+            ball = mpr.sqrt((X - 0.3) * (X - 0.3) + (Y + 0.4) * (Y + 0.4) + Z * Z) - 0.3 + mpr.sin(X * 14.0) * mpr.cos(Y * 9.0) * 0.04
+            blend = mpr.log(mpr.exp(bar * -24.0) + mpr.exp(ball * -24.0)) / -24.0
+            t = mpr.tmin(blend, mpr.sqrt(X * X + (Y - 0.6) * (Y - 0.6) + (Z - 0.2) * (Z - 0.2)) - 0.15)
         elif name == "many_slots":    # > 128 simultaneously live values: every s_i is used by a product and, later, a sum
             terms = [(X - (i % 13) * 0.11 + 0.6) * (Y + (i % 7) * 0.13 - 0.4) + Z * (0.01 * i) for i in range(150)]
             prod = terms[0]

@@ -14,9 +14,11 @@ import numpy as np
 F32_MAX = np.float32(3.4028234663852886e38)
 SIGN = np.uint32(0x80000000)
 INLINE_F = {"0.5": 0x3F000000, "-0.5": 0xBF000000, "1.0": 0x3F800000, "-1.0": 0xBF800000, "2.0": 0x40000000, "-2.0": 0xC0000000,
-            "4.0": 0x40800000, "-4.0": 0xC0800000}
+            "4.0": 0x40800000, "-4.0": 0xC0800000, "0.15915494": 0x3E22F983}
 FLOAT_OPS = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_min_f32", "v_max_f32", "v_max3_f32", "v_med3_f32", "v_fma_f32",
-             "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_sqrt_f32", "v_cndmask_b32"}
+             "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_sqrt_f32", "v_cndmask_b32", "v_sin_f32", "v_cos_f32", "v_floor_f32"}
+TRIG_ABS_ERROR = 2.0 ** -19        # what v_sin_f32 / v_cos_f32 are moved by at most when `perturb` is set (measured on the chip: see
+                                   # tests/test_gpu_primitives.py::test_tight_sin_cos_code_on_every_float)
 
 
 def f2u(x):
@@ -178,7 +180,7 @@ class Emu:
         is_valu = name.startswith("v_")
         if not is_valu:
             return
-        trans = name in ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_sqrt_f32")
+        trans = name in ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32")
         for o in self.vreads(name, ops):
             m = re.fullmatch(r"-?\|?v(\d+)\|?", o)
             if m and not trans:
@@ -369,6 +371,21 @@ class Emu:
                 else:
                     y = np.sqrt(x)
             r = f2u(self.approx(y, x))
+        elif base in ("v_sin_f32", "v_cos_f32"):
+            # the argument in revolutions; beyond 256 of them the instructions return 0 / 1
+            trans = True
+            x = u2f(self.src_bits(ops[1], True)).astype(np.float64)
+            with np.errstate(all="ignore"):
+                y = np.sin(2 * np.pi * x) if base == "v_sin_f32" else np.cos(2 * np.pi * x)
+                y = np.where(np.abs(x) > 256.0, 0.0 if base == "v_sin_f32" else 1.0, y)
+                if self.perturb:
+                    y = np.clip(y + self.rng.uniform(-TRIG_ABS_ERROR, TRIG_ABS_ERROR, size=self.n), -1.0, 1.0)
+                y = np.where(np.isfinite(x), y, np.nan)
+                r = f2u(y.astype(np.float32))
+        elif base == "v_floor_f32":
+            x = u2f(self.src_bits(ops[1], True))
+            with np.errstate(all="ignore"):
+                r = f2u(np.floor(x).astype(np.float32))
         else:
             raise ValueError("vector instruction " + name)
         self.v[d] = r

@@ -1,0 +1,90 @@
+"""The last tile stage's SECOND verdict (round 6; csrc/interval_gen.hpp: tight code, csrc/kernels.hpp: TileStageArgs::lean == 2).
+
+The reference's interval sin / cos is [-1, 1] whatever the argument (inc/gpu_interval.hpp:353; the range reduction behind it is dead
+code), and every tile a sin / cos has a say in stays ambiguous down to the voxels: 584 644 smallest tiles of bear 1024^3 go to the
+float pass, 63 % of which a sound enclosure of sin / cos proves empty or filled (scripts/tight_cull_study.py).  In frames nobody
+reads the last tile stage computes that second enclosure beside the reference's walk — which it leaves as it is: decisions, records
+— and keeps the tiles it decides out of the float pass.  Held against the oracle here: heights and normals equal, fewer tiles walked;
+the arithmetic it rests on, on every float."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import view3
+from helpers import check_default_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fn", ["sin", "cos"])
+def test_tight_sin_cos_code_on_every_float(mpr, fn):
+    """Every float x as [x, x], [x, x + w] (w < 8) and the interval to a scrambled copy of its bits through the tight code of one
+    clause on the chip: the second enclosure holds the float pass's own sinf / cosf at the ends, the middle and next to every
+    multiple of pi / 2 inside; the first one stays [-1, 1].  And what v_sin_f32 / v_cos_f32 are off by at most (|x| <= 1024): the
+    padding in csrc/interval_gen.cpp (TIGHT_TRIG_EPS = 2^-17) is eight times that or more."""
+    r = mpr.dev_tight_trig(fn == "sin")
+    assert r["tested"] > 3 * ((1 << 32) - (1 << 25)) and r["bad"] == 0, (fn, r, hex(r["example"]))
+    assert r["asked_for_exact"] == 0, r
+    assert r["hw_error"] <= 2.0 ** -20, r
+    assert r["narrow"] > 50 * max(r["wide"], 1), r
+
+
+def frames(mpr, tape, S, mat, n=3, tight=True):
+    if not tight:
+        os.environ["MPR_TILE_TIGHT"] = "0"
+    try:
+        ctx = mpr.Context(S)
+    finally:
+        os.environ.pop("MPR_TILE_TIGHT", None)
+    out = []
+    for _ in range(n):
+        ctx.render3D(tape, mat)
+        out.append((ctx.image.copy(), ctx.normals.copy(), ctx.tile_stage_forms(), ctx.frame_tiles()[2], ctx.float_kernel()))
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("trig_blend", 256), ("trig_blend", 512)])
+def test_frames_with_the_second_verdict_equal_the_oracle_and_walk_fewer_tiles(mpr, orc, tapes, name, S):
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    assert (ref.image > 0).sum() > 1000
+    with_it = frames(mpr, tape, S, view3())
+    without = frames(mpr, tape, S, view3(), tight=False)
+    for image, normals, forms, walked, kernel in with_it + without:
+        assert np.array_equal(image, ref.image), (forms, int((image != ref.image).sum()))
+        assert np.array_equal(normals, ref.normals), (forms, int((normals != ref.normals).sum()))
+    # frames from the second on take the form that pushes nothing from the last stage (the first measures the tapes)
+    assert all("+lean+tight" in f[2] for f in with_it[1:]), [f[2] for f in with_it]
+    assert not any("+tight" in f[2] for f in without), [f[2] for f in without]
+    a, b = with_it[-1][3], without[-1][3]
+    assert b == ref.counters["voxel_tiles"] or b > 0
+    assert a < 0.85 * b, (name, S, a, b)
+    # ... and the whole default path once more through the suite's usual check, CTX_PARANOID included
+    check_default_path(mpr, ref, tape, 3, S, view3())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_general_views_with_the_second_verdict(mpr, orc, tapes, seed):
+    """rotated, sheared, zoomed, perspective views of the two shapes with sin / cos"""
+    rng = np.random.default_rng(600 + seed)
+    name = ["bear", "trig_blend"][seed % 2]
+    S = [128, 256][(seed // 2) % 2]
+    A = np.eye(4, dtype=np.float32)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    A[:3, :3] = (q * rng.uniform(0.7, 1.4)).astype(np.float32)
+    A[:3, :3] += rng.uniform(-0.15, 0.15, (3, 3)).astype(np.float32)
+    A[:3, 3] = rng.uniform(-0.2, 0.2, 3).astype(np.float32)
+    A[3, rng.integers(0, 3)] = np.float32(rng.uniform(-0.3, 0.3))
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(A, 4), threads=0, keep_pool=False)
+    for image, normals, forms, walked, kernel in frames(mpr, tape, S, A):
+        assert np.array_equal(image, ref.image), (seed, forms, int((image != ref.image).sum()))
+        assert np.array_equal(normals, ref.normals), (seed, forms, int((normals != ref.normals).sum()))
+    ctx = mpr.Context(S, flags=mpr.CTX_PARANOID)
+    for _ in range(3):
+        ctx.render3D(tape, A)
+    seen, again, cells = ctx.paranoid_stats()
+    assert seen == 3 and cells == 0, (seed, seen, again, cells)
+    ctx.close()

@@ -21,7 +21,7 @@ FIRST, BELOW, GUARDED, MASKS = 0, 1, 2, 3
 ROUTINE_OP = {68: "SQRT_LHS", 82: "DIV_LHS_RHS", 84: "DIV_LHS_RHS", 86: "ASIN_LHS", 88: "ACOS_LHS", 90: "ATAN_LHS", 98: "EXP_LHS", 96: "LOG_LHS"}
 
 
-def generate(mpr, words, kind, loose, window=0, min_run=3):
+def generate(mpr, words, kind, loose, window=0, min_run=3, tight=False):
     f = mpr.lib().mpr_test_interval_gen
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
@@ -32,7 +32,8 @@ def generate(mpr, words, kind, loose, window=0, min_run=3):
     info = (ctypes.c_int32 * 8)()
     # (loose = 3: loose code for the harness with 64 vector registers, as the tile stages run it)
     # (MASKS: the first-stage walk of tapes of up to 93 slots, all registers)
-    n = f(arr.ctypes.data, len(arr), kind, (1 if kind == MASKS else 3) if loose else 0, window, min_run, buf, 400000, txt, 8_000_000, info)
+    # (+ 8: tight code — a second enclosure of the result in v[38:39], for the harness with 80 vector registers)
+    n = f(arr.ctypes.data, len(arr), kind, ((1 if kind == MASKS else 3) if loose else 0) | (8 if tight else 0), window, min_run, buf, 400000, txt, 8_000_000, info)
     if n < 0:
         return None
     names = ["instructions", "nops", "window", "max_vgprs", "max_sgpr_pairs", "nchoices", "est_cycles"]
@@ -52,8 +53,8 @@ def assemble(lines):
     return out
 
 
-def checked_code(mpr, words, kind, loose, window=0, min_run=3):
-    g = generate(mpr, words, kind, loose, window, min_run)
+def checked_code(mpr, words, kind, loose, window=0, min_run=3, tight=False):
+    g = generate(mpr, words, kind, loose, window, min_run, tight)
     assert g is not None
     code, lines, info = g
     enc = assemble(lines)
@@ -389,3 +390,101 @@ def test_masks_code_of_a_first_stage_encloses_the_oracle_and_records_its_choices
         decided_g = sum(int(((emu.choice_masks[k][0] | emu.choice_masks[k][1]) & ok).sum()) for k in range(nch))
         assert decided_g >= 0.98 * decided_o, (decided_g, decided_o)
     assert clean > 100
+
+
+# ---- tight code (round 6): a second enclosure of the result, with sin / cos enclosed by their monotone pieces ----
+def float_walk(mpr, orc, words, px, py, pz, dec_l=0, dec_r=0):
+    """the float pass's value of the tape at points (float32 arrays), with what was decided above applied (a decided min / max is the
+    chosen operand: the tape the float pass walks)"""
+    OP = mpr.OP
+    minmax = {OP["MIN_LHS_IMM"], OP["MIN_LHS_RHS"], OP["MAX_LHS_IMM"], OP["MAX_LHS_RHS"]}
+    op, o, l, r, imm = tape_fields(words)
+    slots = {int(o[0]): px, int(l[0]): py, int(r[0]): pz}
+    zero = np.zeros(len(px), np.float32)
+    k = 0
+    for i in range(1, len(words)):
+        if op[i] == 0:
+            return slots[int(o[i])]
+        A = slots.get(int(l[i]), zero)
+        B = slots.get(int(r[i]), zero)
+        K = u2f(np.array([imm[i]], dtype=np.uint32))[0]
+        if op[i] in minmax:
+            if dec_l >> k & 1:
+                out = A
+            elif dec_r >> k & 1:
+                out = B if r[i] != 0 else np.full(len(px), K, np.float32)
+            else:
+                out = orc.float_op(int(op[i]), A, B, float(K))
+            k += 1
+        else:
+            out = orc.float_op(int(op[i]), A, B, float(K))
+        slots[int(o[i])] = out
+    raise AssertionError("no end clause")
+
+
+def small_tiles(rng, n, c=None, h0=None, sizes=(1 / 64, 1 / 256, 1 / 512)):
+    out = []
+    for a in range(3):
+        cc = rng.uniform(-1, 1, n) if c is None else rng.uniform(c[a] - h0 * 0.9, c[a] + h0 * 0.9, n)
+        h = rng.choice(sizes, n)
+        out.append(((cc - h).astype(np.float32), (cc + h).astype(np.float32)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["bear", "trig_blend"])
+@pytest.mark.parametrize("kind", [FIRST, BELOW, GUARDED])
+def test_tight_code_leaves_the_walk_as_it_is_and_its_second_enclosure_holds_the_float_values(mpr, orc, tapes, name, kind):
+    """Tight code (csrc/interval_gen.hpp): the assembler's words; no missing wait state; everything the loose code leaves — the
+    result, every lane's decisions, the lanes that ask for the exact walk — bit for bit what the code without the second result
+    leaves; the second enclosure lies inside the first and holds the float pass's value (the oracle's float routines, clause by
+    clause, on the tape with what was decided above applied) at the corners, the centre and random points of every tile; and on
+    tiles the size of a frame's smallest it decides a good part of what the wide one leaves open."""
+    words = [int(w) for w in tapes(name).data]
+    lines_t, sizes_t, info_t = checked_code(mpr, words, kind, True, tight=True)
+    lines_w, sizes_w, info_w = checked_code(mpr, words, kind, True)
+    assert any(l.startswith("v_sin_f32") or l.startswith("v_cos_f32") for l in lines_t) and not any("v_cos_f32" in l or "v_sin_f32" in l for l in lines_w)
+    assert max(int(r) for l in lines_t for r in re.findall(r"\bv(\d+)", l)) <= 79
+    rng = np.random.default_rng(31 + kind)
+    decided_w = decided_t = total = 0
+    for trial in range(4):
+        if kind == FIRST:
+            dl = dr = 0
+            x, y, z = small_tiles(rng, 128)
+        else:
+            dl, dr, c, h = parent_decisions(mpr, orc, words, rng)
+            x, y, z = small_tiles(rng, 128, c, h)
+        # the same walk: no perturbation, so that the two codes see the same instruction results
+        lo_w, hi_w, cl_w, cr_w, emu_w = run_code(mpr, orc, lines_w, sizes_w, x, y, z, dl, dr, np.random.default_rng(1))
+        lo, hi, cl, cr, emu = run_code(mpr, orc, lines_t, sizes_t, x, y, z, dl, dr, np.random.default_rng(1))
+        assert not emu.hazards, emu.hazards[:3]
+        assert same_bits(lo, lo_w).all() and same_bits(hi, hi_w).all() and (emu.bad == emu_w.bad).all()
+        live = np.uint64(sum(1 << k for k in live_choices(mpr, words, dl, dr)))      # (a clause a guard jumps over records whatever its registers hold)
+        assert ((cl & live) == (cl_w & live)).all() and ((cr & live) == (cr_w & live)).all()
+        # the second enclosure, the instructions moved by what the chip may move them
+        lo, hi, cl, cr, emu = run_code(mpr, orc, lines_t, sizes_t, x, y, z, dl, dr, rng, perturb=True)
+        tlo, thi = u2f(emu.v[38]), u2f(emu.v[39])
+        ok = ~emu.bad
+        assert not np.isnan(tlo[ok]).any() and not np.isnan(thi[ok]).any()
+        assert (tlo[ok] >= lo[ok] - 1e-5 * np.abs(lo[ok])).all() and (thi[ok] <= hi[ok] + 1e-5 * np.abs(hi[ok])).all()
+        for s in range(12):
+            if s < 8:
+                f = [np.float32((s >> a) & 1) for a in range(3)]
+            elif s == 8:
+                f = [np.float32(0.5)] * 3
+            else:
+                f = [rng.uniform(0, 1, len(x[0])).astype(np.float32) for _ in range(3)]
+            pts = [np.minimum(np.maximum((b[0] + (b[1] - b[0]) * f[a]).astype(np.float32), b[0]), b[1]) for a, b in enumerate((x, y, z))]
+            v = float_walk(mpr, orc, words, *pts, dl, dr)
+            good = ok & ~np.isnan(v)
+            assert (v[good] >= tlo[good]).all() and (v[good] <= thi[good]).all(), (name, kind, s, int((~((v >= tlo) & (v <= thi)) & good).sum()))
+        total += int(ok.sum())
+        decided_w += int((((lo > 0) | (hi < 0)) & ok).sum())
+        decided_t += int((((tlo > 0) | (thi < 0)) & ok).sum())
+    assert decided_t >= decided_w
+    if name == "bear" and kind == FIRST:
+        assert decided_t - decided_w >= (total - decided_w) // 3, (decided_w, decided_t, total)      # (of what the wide one leaves open)
+
+
+def test_tight_code_only_where_there_is_something_to_tighten(mpr, tapes):
+    assert generate(mpr, [int(w) for w in tapes("smooth").data], FIRST, True, tight=True) is None      # no sin / cos
+    assert generate(mpr, [int(w) for w in tapes("bear").data], FIRST, False, tight=True) is None        # exact code has one result
