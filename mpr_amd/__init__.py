@@ -597,6 +597,13 @@ class Context:
         _check(lib().mpr_ctx_frame_tiles(self._h, _ptr(a)))
         return a[:3].tolist(), a[3:6].tolist(), int(a[6])
 
+    def tiles_walked(self):
+        """Development: tiles the last frame's float pass walked (context made with MPR_DEBUG_WALKED=1; float pass by column), or -1."""
+        f = lib().mpr_debug_tiles_walked
+        f.restype = ctypes.c_longlong
+        f.argtypes = [ctypes.c_void_p]
+        return int(f(self._h))
+
     def float_kernel(self):
         """Name of the kernel the last frame's float pass ran as (mpr_ctx_float_kernel)."""
         return lib().mpr_ctx_float_kernel(self._h).decode()

@@ -90,3 +90,49 @@ def test_general_views_with_the_second_verdict(mpr, orc, tapes, seed):
     seen, again, cells = ctx.paranoid_stats()
     assert seen == 3 and cells == 0, (seed, seen, again, cells)
     ctx.close()
+
+
+@pytest.mark.parametrize("name,S", [("bear", 512), ("trig_blend", 256), ("smooth", 256)])
+def test_float_pass_by_column_stops_at_the_first_hidden_tile(mpr, orc, tapes, name, S, monkeypatch):
+    """Round 6: the float pass of frames on the root tape's generated code takes a COLUMN of smallest tiles — those over one 4 x 4
+    footprint of pixels, linked by k_link_columns — per wavefront and walks it front to back until a tile is hidden
+    (k_eval_voxels_gen_cols).  The oracle's heights and normals; no more tiles walked than listed, and fewer than the pass that hands
+    tiles out one by one in z order walks (MPR_VOXEL_COLS=0: there every listed tile that is not yet hidden when its turn comes)."""
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    monkeypatch.setenv("MPR_DEBUG_WALKED", "1")
+    ctx = mpr.Context(S)
+    monkeypatch.setenv("MPR_VOXEL_COLS", "0")
+    old = mpr.Context(S)
+    for k in range(4):
+        ctx.render3D(tape, view3())
+        old.render3D(tape, view3())
+        for c in (ctx, old):
+            assert np.array_equal(c.image, ref.image), (k, c.float_kernel(), int((c.image != ref.image).sum()))
+            assert np.array_equal(c.normals, ref.normals), (k, c.float_kernel())
+    assert ctx.float_kernel() == "k_eval_voxels_gen_cols<3>" and old.float_kernel() == "k_eval_voxels_gen<3>"
+    listed, walked = ctx.frame_tiles()[2], ctx.tiles_walked()
+    assert old.tiles_walked() <= 0                      # (not counted there)
+    assert 0 < walked <= listed, (walked, listed)
+    print("%s %d: %d tiles listed, %d walked" % (name, S, listed, walked))
+    ctx.close()
+    old.close()
+
+
+@pytest.mark.parametrize("seed,size", [(41777, 3), (48461, 8), (48813, 3), (50609, 3), (52835, 3)])
+def test_filled_tiles_of_the_bottom_layer_stay_with_the_float_pass(mpr, orc, seed, size):
+    """scripts/paranoid_sweep.py over seeds 40000..53999 (round 6, profiles/r06_paranoid_sweep.txt) against the first version of the
+    second verdict: five shapes with 1 to 28 pixels at height 0 where the oracle has 3.  A FILLED tile's height is its z index in its
+    level's image, and 0 there is "nothing" (reference src/context.cu:664-692: copy_filled): the reference's own filled tiles of the
+    bottom layer draw nothing, while a tile of that layer it leaves AMBIGUOUS is drawn voxel by voxel, up to height 3.  A tile of the
+    bottom layer the second verdict proves filled therefore stays with the float pass."""
+    from test_gpu_fuzz_shapes import fuzz_tape
+    tape = fuzz_tape(mpr, seed, size)
+    rng = np.random.default_rng(seed * 7 + size)
+    S = int(rng.choice([128, 256]))
+    assert rng.random() < 0.5                        # (the sweep's view for these seeds: the benchmark's)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    for image, normals, forms, walked, kernel in frames(mpr, tape, S, view3()):
+        assert "+tight" in forms, forms
+        assert np.array_equal(image, ref.image), (forms, int((image != ref.image).sum()))
+        assert np.array_equal(normals, ref.normals), (forms, int((normals != ref.normals).sum()))
