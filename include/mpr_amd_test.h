@@ -53,7 +53,7 @@ int mpr_test_loose_gen(int32_t device, int32_t op, float imm, float other_lo, fl
  * [3] = lanes that asked for the exact walk, [4] = the instruction's largest error beyond |x| 2^-22 (its argument's roundings) for |x| <= 1024 in units of 2^-40, [5] / [6] =
  * intervals narrower than 1 whose enclosure is / is not narrower than 1 */
 int mpr_test_tight_trig(int32_t device, int32_t is_sin, uint64_t first, uint64_t count, uint64_t out[7]);
-/* development: tiles the last frame's float pass walked (a context made with MPR_DEBUG_WALKED=1 in the environment, float pass by column); -1: not counted */
+/* development: tiles the last frame's float pass walked (a context made with MPR_DEBUG_WALKED=1 in the environment; k_eval_voxels_gen); -1: not counted */
 long long mpr_debug_tiles_walked(mpr_context* ctx);
 /* forward-mode derivative primitive: 4 floats (dx,dy,dz,v) per operand */
 int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, const float* b4,

@@ -598,7 +598,7 @@ class Context:
         return a[:3].tolist(), a[3:6].tolist(), int(a[6])
 
     def tiles_walked(self):
-        """Development: tiles the last frame's float pass walked (context made with MPR_DEBUG_WALKED=1; float pass by column), or -1."""
+        """Development: tiles the last frame's float pass walked (context made with MPR_DEBUG_WALKED=1; k_eval_voxels_gen: the tiles it did not find hidden), or -1."""
         f = lib().mpr_debug_tiles_walked
         f.restype = ctypes.c_longlong
         f.argtypes = [ctypes.c_void_p]

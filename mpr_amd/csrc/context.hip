@@ -145,18 +145,7 @@ struct mpr_context {
     int* group_list = nullptr;             /* those groups in list order, then their number (k_list_alive_groups) */
     size_t group_alive_cap = 0, group_list_cap = 0;
     int* vox_counters = nullptr;           /* the float pass on the root tape's code: its tile counters (kernels_voxel_jit.hip: VG_LISTS) */
-    /* ... by column (round 6; kernels_voxel_jit.hip: k_eval_voxels_gen_cols): the last stage's survivors linked by column */
-    unsigned long long* col_head = nullptr;
-    size_t col_head_cap = 0;
-    int* col_link = nullptr;
-    size_t col_link_cap = 0;
-    unsigned col_tag = 0;                  /* the frame's tag in col_head */
-    int* col_counters = nullptr;           /* two sets of counters, used in turn */
-    unsigned col_launches = 0;
-    bool voxel_cols = true;                /* MPR_VOXEL_COLS=0: that float pass tile by tile, front to back (round 3's) */
-    int voxel_cols_run = 0;                /* MPR_VOXEL_COLS_RUN (development): columns per claim */
-    int* walked_dev = nullptr;             /* MPR_DEBUG_WALKED=1: tiles the float pass by column walked, 32 x 32 ints */
-    long long last_walked = -1;
+    int* walked_dev = nullptr;             /* MPR_DEBUG_WALKED=1: tiles the float pass on the root tape's code walked (the others it found hidden), 32 x 32 ints */
     int* tile_source = nullptr;            /* per smallest tile: its index in the last tile stage's list (the float pass on the root tape's code) */
     size_t tile_source_cap = 0;
 
@@ -257,7 +246,6 @@ struct mpr_context {
     bool voxel_gen = true;             /* MPR_VOXEL_GEN=0: the float pass never runs the root tape's host-generated code */
     int voxel_gen_min_run = 5;         /* MPR_VOXEL_GEN_RUN (development): shortest run of dead clauses that gets a guard (0: none) */
     int vox_grid_cache[2] = {0, 0};
-    int vox_cols_grid = 0;
     int voxel_gen_tiles = 0;           /* MPR_VOXEL_GEN_TILES (development): consecutive tiles a wavefront takes per atomic (default 4) */
     int voxel_gen_wgs = 0;             /* MPR_VOXEL_GEN_WGS (development): at most this many persistent workgroups per CU */
     bool tile_gen_chain = true;        /* MPR_TILE_GEN_CHAIN=0: only a frame's first stage (and, in frames that start at the 16^3 tiles, the last) */
@@ -483,10 +471,11 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LEAN")) c->tile_gen_lean = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_TIGHT")) c->tile_tight = atoi(e) != 0;
-    if (const char* e = getenv("MPR_VOXEL_COLS")) c->voxel_cols = atoi(e) != 0;
-    if (const char* e = getenv("MPR_VOXEL_COLS_RUN")) c->voxel_cols_run = atoi(e);
     if (const char* e = getenv("MPR_DEBUG_WALKED"))
-        if (atoi(e) != 0 && hipMalloc((void**)&c->walked_dev, 1024 * sizeof(int)) != hipSuccess) c->walked_dev = nullptr;
+        if (atoi(e) != 0) {
+            if (hipMalloc((void**)&c->walked_dev, 1024 * sizeof(int)) != hipSuccess) c->walked_dev = nullptr;
+            else (void)hipMemset(c->walked_dev, 0, 1024 * sizeof(int));
+        }
     if (const char* e = getenv("MPR_DEBUG_REDO"))
         if (atoi(e) != 0 && hipMalloc((void**)&c->redo_count, 2 * sizeof(unsigned int)) == hipSuccess) (void)hipMemset(c->redo_count, 0, 2 * sizeof(unsigned int));
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
@@ -633,9 +622,6 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->group_list) (void)hipFree(c->group_list);
     if (c->tile_source) (void)hipFree(c->tile_source);
     if (c->vox_counters) (void)hipFree(c->vox_counters);
-    if (c->col_head) (void)hipFree(c->col_head);
-    if (c->col_link) (void)hipFree(c->col_link);
-    if (c->col_counters) (void)hipFree(c->col_counters);
     if (c->walked_dev) (void)hipFree(c->walked_dev);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
@@ -990,7 +976,6 @@ struct Frame {
     bool presence_recorded = false;        /* ... with the clauses of the tapes they pushed */
     bool last_recorded = false;            /* ... down to the smallest tiles */
     bool vox_gen_planned = false;          /* the last stage's compaction kept, per smallest tile, where it sat in that stage's list */
-    bool vox_cols = false;                 /* ... or linked the stage's survivors by column instead: the float pass by column */
     bool group_form = false;               /* the last stage recorded its groups' tapes and decisions, and the float pass takes them */
     bool lean_now = false;                 /* the last stage pushed no tapes */
     int group_stage = 0, group_count = 0, group_cap = 1;
@@ -1569,34 +1554,13 @@ static int frame_tile_stage(Frame& f, int si)
         const bool vox_gen_next = last && groups_now && dim == 3 && i == 2 && decisions_recorded && c->voxel_gen && c->gen_ok && c->gen_vox_dw > 0 &&
                                   c->cus > 0;
         vox_gen_planned = vox_gen_next;
-        /* ... by column: the survivors linked by column, no list of them */
-        const bool vox_cols_next = vox_gen_next && c->voxel_cols && count > 0 && (tps & (tps - 1)) == 0;
-        f.vox_cols = vox_cols_next;
-        if (vox_cols_next) {
-            const size_t old_cap = c->col_head_cap;
-            rc = ensure_buffer(&c->col_head, &c->col_head_cap, (size_t)tps * tps);
-            if (rc) return rc;
-            if (c->col_head_cap != old_cap) {           /* (a fresh array: no entry may carry a tag by accident) */
-                HIP_TRY(hipMemsetAsync(c->col_head, 0, c->col_head_cap * sizeof(unsigned long long), s));
-                c->col_tag = 0;
-            }
-            rc = ensure_buffer(&c->col_link, &c->col_link_cap, (size_t)count);
-            if (rc) return rc;
-            if (++c->col_tag == 0) {                    /* (the tag wrapped: start over) */
-                HIP_TRY(hipMemsetAsync(c->col_head, 0, c->col_head_cap * sizeof(unsigned long long), s));
-                c->col_tag = 1;
-            }
-        } else if (vox_gen_next) {
+        if (vox_gen_next) {
             rc = ensure_buffer(&c->tile_source, &c->tile_source_cap, (size_t)std::max(count, 1));
             if (rc) return rc;
         }
         auto compact = [&](bool mark_groups) -> int {
             const int seq = ++c->pub_seq;
-            if (mark_groups && vox_cols_next) {
-                TimedScope ts(c, "compact_copy");
-                mprk::launch_link_columns(s, c->tiles[i], count, tps, c->filled[i], c->num_active, c->col_head, c->col_link, c->col_tag, c->pub_dev, seq,
-                                          (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub), c->tape_index);
-            } else if (zs) {
+            if (zs) {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
                                              c->zs_hist, c->zs_cursor, c->pub_dev, seq, (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub),
@@ -1609,7 +1573,7 @@ static int frame_tile_stage(Frame& f, int si)
                                                mark_groups ? c->group_alive : nullptr, c->tape_index,
                                                (mark_groups && vox_gen_next) ? c->tile_source : nullptr);
             }
-            if (mark_groups && !vox_gen_next && !vox_cols_next) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
+            if (mark_groups && !vox_gen_next) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
             return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
         };
         if (count > 0) {
@@ -1716,41 +1680,19 @@ static int frame_float_pass(Frame& f)
         bool jitted = false, on_root_code = false;
         /* The root tape's host-generated float walk (voxel_gen.hpp), the tiles' decisions as bits: frames whose tile stages kept their
          * tiles' records down to the stage above the last one, whose last stage recorded its groups' masks */
-        if (vox_gen_planned && group_form && !brute && f.vox_cols) {
-            /* by column (kernels_voxel_jit.hip: k_eval_voxels_gen_cols) over the last tile stage's own list */
-            static_assert(sizeof(int) == 4, "");
-            if (c->vox_cols_grid == 0) c->vox_cols_grid = mprk::voxel_gen_cols_grid(dim, c->cus);
-            const int use_grid = c->voxel_gen_wgs > 0 ? std::min(c->vox_cols_grid, c->voxel_gen_wgs * c->cus) : c->vox_cols_grid;
-            const size_t cints = (size_t)mprk::voxel_gen_counter_ints();
-            if (!c->col_counters) {
-                HIP_TRY(hipMalloc((void**)&c->col_counters, 2 * cints * sizeof(int)));
-                HIP_TRY(hipMemsetAsync(c->col_counters, 0, 2 * cints * sizeof(int), s));
-            }
-            int* const cur = c->col_counters + (c->col_launches & 1) * cints;
-            int* const nxt = c->col_counters + ((c->col_launches + 1) & 1) * cints;
-            ++c->col_launches;
-            mprk::VoxelArgs cv = v;
-            cv.tiles = c->tiles[group_stage];
-            cv.count = group_count;
-            const int ncols = v.tps * v.tps;
-            /* columns per claim: about eight claims per wavefront, at most 16 columns */
-            const int run = c->voxel_cols_run > 0 ? c->voxel_cols_run : std::max(1, std::min(16, ncols / (8 * std::max(use_grid, 1))));
-            if (c->walked_dev) HIP_TRY(hipMemsetAsync(c->walked_dev, 0, 1024 * sizeof(int), s));
-            mprk::launch_eval_voxels_gen_cols(s, cv, c->gen_code + c->gen_vox_at, use_grid, c->col_head, c->col_link, c->col_tag, c->groups, c->choice_masks,
-                                              group_cap, cur, nxt, c->gen_dec[1], c->gen_nchoices, run, c->walked_dev);
-            jitted = on_root_code = true;
-        } else if (vox_gen_planned && group_form && !brute) {
+        if (vox_gen_planned && group_form && !brute) {
             int& grid = c->vox_grid_cache[dim - 2];
             if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
             const int use_grid = c->voxel_gen_wgs > 0 ? std::min(grid, c->voxel_gen_wgs * c->cus) : grid;
             if (!c->vox_counters) HIP_TRY(hipMalloc((void**)&c->vox_counters, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int)));
             HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
+            if (c->walked_dev) HIP_TRY(hipMemsetAsync(c->walked_dev, 0, 1024 * sizeof(int), s));
             mprk::launch_eval_voxels_gen(s, dim, v, c->gen_code + c->gen_vox_at, use_grid, c->tile_source, c->groups, c->choice_masks, group_cap,
                                          c->vox_counters, c->gen_dec[1], c->gen_nchoices,
                                          /* tiles per claim: about four claims per wavefront — few tiles (a small frame, a rank's eighth of one)
                                           * take short runs, so that no wavefront is left with a whole run while the others have none; at most
                                           * 8 (measured: bear 1024^3 0.816 ms with 8, 0.831 with 4; 256^3 0.128 / 0.113) */
-                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(8, count / (4 * std::max(use_grid, 1)))));
+                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(8, count / (4 * std::max(use_grid, 1)))), c->walked_dev);
             jitted = on_root_code = true;
         }
         if (!cnt && !heat && !jitted) {
@@ -1778,7 +1720,7 @@ static int frame_float_pass(Frame& f)
             return FRAME_AGAIN_REFERENCE;
         }
         if (on_root_code) {
-            snprintf(c->float_kernel, sizeof c->float_kernel, f.vox_cols ? "k_eval_voxels_gen_cols<%d>" : "k_eval_voxels_gen<%d>", dim);
+            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_gen<%d>", dim);
         } else if (jitted) {
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
                      mprk::jit_slot_class(nslots));
@@ -2061,7 +2003,7 @@ int mpr_ctx_frame_tiles(mpr_context* c, int64_t out[7])
     return MPR_OK;
 }
 
-/* development (MPR_DEBUG_WALKED=1 when the context was made): tiles the last frame's float pass by column walked; -1: not counted */
+/* development (MPR_DEBUG_WALKED=1 when the context was made): tiles the last frame's float pass on the root tape's code walked; -1: not counted */
 extern "C" long long mpr_debug_tiles_walked(mpr_context* c)
 {
     if (!c || !c->walked_dev) return -1;

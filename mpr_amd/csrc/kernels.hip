@@ -1098,65 +1098,6 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
 }
 
 
-/* ------------------------------------------------------------------------------------ */
-/* The last tile stage's survivors BY COLUMN (round 6), for the float pass that works through a  */
-/* column of smallest tiles — the tiles over one 4 x 4 footprint of pixels — front to back in ONE */
-/* wavefront (kernels_voxel_jit.hip: k_eval_voxels_gen_cols): second mask_filled_tiles, then every */
-/* survivor is pushed onto its column's list (head[column] = {frame tag, index + 1}, link[index] =  */
-/* the one before + 1; the tag makes a stale head of an earlier frame an empty one: nothing to     */
-/* clear).  No sort, no scan, no second list: one launch where the z-sorted compaction takes three, */
-/* and the float pass stops a column at the first tile it finds hidden — handed out tile by tile,   */
-/* the tiles behind a surface were mostly walked before the tiles in front of them had drawn it.    */
-/* ------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(1024)
-k_link_columns(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ num_active,
-               unsigned long long* __restrict__ head, int* __restrict__ link, unsigned tag, int* __restrict__ pub, int seq, CopyFilled cf,
-               const unsigned long long* __restrict__ tape_index)
-{
-    if ((int)blockIdx.x >= cf.first_block) {
-        copy_filled_block<3>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
-        return;
-    }
-    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = gidx < count;
-    int position = -1;
-    if (valid) position = tiles[gidx].position;
-    bool active = valid && position != -1;
-    int col = 0;
-    if (active) {
-        const int4_ p = unpack(position, tps);
-        col = p.w;
-        if (image[p.w] > p.z) {
-            active = false;
-            tiles[gidx].position = -1;
-        }
-    }
-    if (active) {
-        const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned)(gidx + 1);
-        const unsigned long long prev = atomicExch(&head[col], mine);
-        link[gidx] = (unsigned)(prev >> 32) == tag ? (int)(unsigned)prev : 0;
-    }
-    if (valid) tiles[gidx].next = -1;             /* copy_active_tiles resets next (:650) */
-    /* the survivor count, one atomic per 1024 tiles, and the hand-over to the host by the last workgroup (k_compact_subdivide) */
-    const uint64_t mask = ballot(active);
-    __shared__ int wave_count[16];
-    const int wave = threadIdx.x >> 6;
-    if (lane == 0) wave_count[wave] = __popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-        const int nw = (blockDim.x + 63) >> 6;
-        for (int w = 0; w < nw; ++w) total += wave_count[w];
-        if (total) atomicAdd(num_active, total);
-        if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
-            const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish_counts(pub, seq, n0, 0, 0, num_active + 4, tape_index);
-        }
-    }
-}
-
 /* copy_filled — reference :664-692 */
 template <int DIM>
 __global__ void k_copy_filled(const int* __restrict__ prev, int* __restrict__ image, int size)
@@ -1896,14 +1837,6 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
-void launch_link_columns(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, int* num_active, unsigned long long* head, int* link,
-                         unsigned tag, int* pub, int seq, int* next_image, int next_size, const unsigned long long* tape_index)
-{
-    const unsigned blocks = (unsigned)((count + 1023) / 1024);
-    unsigned extra = 0;
-    const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)blocks, &extra);
-    hipLaunchKernelGGL(k_link_columns, dim3(blocks + extra), dim3(1024), 0, s, tiles, count, tps, image, num_active, head, link, tag, pub, seq, cf, tape_index);
-}
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
                             int* need, unsigned char* group_alive, const unsigned long long* tape_index, int* source_out)

@@ -261,19 +261,10 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
  * tiles, source[t] = tile t's index in the last tile stage's list (launch_compact_*: source_out), groups / masks of that stage,
  * parent_records: the records of the tiles of the stage above it; tile_counter: voxel_gen_counter_ints() zeroed ints */
 int voxel_gen_grid(int dim, int cus);
-/* ... by COLUMN (round 6; kernels_voxel_jit.hip: k_eval_voxels_gen_cols): a.tiles = the LAST TILE STAGE's list, whose survivors
- * launch_link_columns linked by column (head: tps x tps entries {tag, index + 1}; link: per tile); col_counter / next_counter: two sets of
- * voxel_gen_counter_ints() ints, used in turn (each launch clears the other's); walked: null, or 32 x 32 ints (development) */
-int voxel_gen_cols_grid(int dim, int cus);
-void launch_eval_voxels_gen_cols(hipStream_t s, const VoxelArgs& a, const uint32_t* code, int grid, const unsigned long long* head, const int* link, unsigned tag,
-                                 const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* col_counter, int* next_counter,
-                                 const unsigned long long* parent_records, int nchoices, int run, int* walked);
-void launch_link_columns(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, int* num_active, unsigned long long* head, int* link,
-                         unsigned tag, int* pub, int seq, int* next_image, int next_size, const unsigned long long* tape_index);
 int voxel_gen_counter_ints();
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
-                            int nchoices, int run = 0);
+                            int nchoices, int run = 0, int* walked = nullptr);
 void launch_test_float_gen_all(hipStream_t s, const uint32_t* code, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
                            unsigned long long dr);

@@ -1034,6 +1034,7 @@ struct GenVoxelArgs {
     const unsigned long long* parent_records;   /* records of the tiles of the stage above (GEN_RECORD_U64 words each) */
     int nchoices;                      /* min / max clauses of the root tape */
     int run;                           /* consecutive tiles a wavefront takes per atomic */
+    int* walked;                       /* development: += tiles walked (null: not counted) */
 };
 
 /* A wavefront per smallest tile, in list order (front to back: the tiles behind a surface find it drawn).  Nothing is shared
@@ -1054,6 +1055,7 @@ k_eval_voxels_gen(GenVoxelArgs j)
     const unsigned long long all = j.nchoices >= 64 ? ~0ull : ((1ull << j.nchoices) - 1ull);
     const int run_len = j.run;
     const int nruns = (a.count + run_len - 1) / run_len;
+    int nwalked = 0;
     for (int turn = 0; turn < VG_LISTS; ++turn) {
         const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
         const int list_runs = (nruns - list + VG_LISTS - 1) / VG_LISTS;
@@ -1092,9 +1094,11 @@ k_eval_voxels_gen(GenVoxelArgs j)
                 const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
                 const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
                 vox.finish(a, res);
+                ++nwalked;
             }
         }
     }
+    if (j.walked && lane == 0 && nwalked) atomicAdd(j.walked + (blockIdx.x & 31) * 32, nwalked);
 }
 
 int voxel_gen_counter_ints() { return VG_LISTS * VG_COUNTER_STRIDE; }
@@ -1108,10 +1112,11 @@ int voxel_gen_grid(int dim, int cus)
 }
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
-                            int nchoices, int run)
+                            int nchoices, int run, int* walked)
 {
     if (a.count <= 0) return;
     GenVoxelArgs j;
+    j.walked = walked;
     j.run = run > 0 ? run : VG_RUN;
     j.v = a;
     j.code = code;
@@ -1125,143 +1130,6 @@ void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const ui
     const dim3 g(std::min(grid, a.count)), b(64);
     if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_gen<3>, g, b, 0, s, j);
     else hipLaunchKernelGGL(k_eval_voxels_gen<2>, g, b, 0, s, j);
-}
-
-/* ---- the same pass BY COLUMN (round 6) ----------------------------------------------------------------------------
- * A column = the smallest tiles over one 4 x 4 footprint of pixels (kernels.hip: k_link_columns links the last tile stage's
- * survivors by column).  One wavefront takes a column and walks its tiles from the nearest back, until one is hidden: every tile
- * behind it is too.  Handed out tile by tile in z order (k_eval_voxels_gen) a frame's 6000 wavefronts are layers apart, and a tile
- * behind a surface is usually walked before the tile in front of it has drawn the surface — bear 1024^3: 213 k tiles in the list,
- * about 200 k walked, of which 126 k show.  Columns are independent (a tile draws into its own footprint only), so no order
- * between them matters, and no list has to be sorted: a column's few tiles are ranked by the wavefront itself.
- * v.tiles: the LAST TILE STAGE's list (a tile's index there = its group and child, as GenVoxelArgs::source gives it). */
-struct ColVoxelArgs {
-    VoxelArgs v;
-    const uint32_t* code;
-    const unsigned long long* head;    /* [tps * tps]: {frame tag, index + 1 of the column's last tile linked} */
-    const int* link;                   /* per tile of the list: index + 1 of the one linked before it, 0: none */
-    unsigned tag;
-    const GroupInfo* groups;
-    const ulonglong2* choice_masks;
-    int choice_cap;
-    int* col_counter;                  /* VG_LISTS counters, VG_COUNTER_STRIDE ints apart, zero when the kernel starts */
-    int* next_counter;                 /* the set the NEXT launch uses: cleared here (no memset launch between frames) */
-    const unsigned long long* parent_records;
-    int nchoices;
-    int run;                           /* consecutive columns a wavefront takes per atomic */
-    int* walked;                       /* development: += tiles walked (null: not counted) */
-};
-template <int DIM>
-__global__ void __launch_bounds__(64, 6)
-k_eval_voxels_gen_cols(ColVoxelArgs j)
-{
-    const VoxelArgs& a = j.v;
-    const int lane = threadIdx.x;
-    const unsigned long long all = j.nchoices >= 64 ? ~0ull : ((1ull << j.nchoices) - 1ull);
-    const int run_len = j.run;
-    const int ncols = a.tps * a.tps;
-    const int nruns = (ncols + run_len - 1) / run_len;
-    const int zbits = 32 - __builtin_clz((unsigned)(a.tps > 1 ? a.tps - 1 : 1));
-    int nwalked = 0;
-    if (blockIdx.x == 0 && lane < VG_LISTS) j.next_counter[lane * VG_COUNTER_STRIDE] = 0;
-    for (int turn = 0; turn < VG_LISTS; ++turn) {
-        const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
-        const int list_runs = (nruns - list + VG_LISTS - 1) / VG_LISTS;
-        for (;;) {
-            int q = 0;
-            if (lane == 0) {
-                if (turn > 0 && __hip_atomic_load(j.col_counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= list_runs) q = list_runs;
-                else q = atomicAdd(j.col_counter + list * VG_COUNTER_STRIDE, 1);
-            }
-            const int run = __builtin_amdgcn_readfirstlane(q) * VG_LISTS + list;
-            if (run >= nruns) break;
-            /* the run's heads in one load */
-            const int c0 = run * run_len;
-            unsigned long long hd = 0;
-            if (lane < run_len && c0 + lane < ncols) hd = j.head[c0 + lane];
-            uint64_t full = ballot((unsigned)(hd >> 32) == j.tag && (unsigned)hd != 0u);
-            while (full) {
-                const int cl = __ffsll((long long)full) - 1;
-                full &= full - 1;
-                int node = (int)rdlane((uint32_t)hd, (uint32_t)cl) - 1;
-                while (node >= 0) {
-                    /* up to 64 of the column's tiles, one to a lane */
-                    int my_pos = -1, my_node = -1, n = 0;
-                    while (node >= 0 && n < 64) {
-                        const int pos = __builtin_amdgcn_readfirstlane(a.tiles[node].position);
-                        const int nxt = __builtin_amdgcn_readfirstlane(j.link[node]);
-                        if (lane == n) { my_pos = pos; my_node = node; }
-                        node = nxt - 1;
-                        ++n;
-                    }
-                    const int sh2 = 2 * (31 - __builtin_clz((unsigned)a.tps));
-                    const int my_z = ((a.tps & (a.tps - 1)) == 0) ? (my_pos >> sh2) : (my_pos / (a.tps * a.tps));
-                    uint64_t left = ballot(my_pos >= 0);
-                    while (left) {
-                        /* the nearest of those left: the largest z */
-                        uint64_t cand = left;
-                        for (int b = zbits - 1; b >= 0; --b) {
-                            const uint64_t m = ballot((my_z >> b) & 1) & cand;
-                            if (m) cand = m;
-                        }
-                        const int bl = __ffsll((long long)cand) - 1;
-                        left &= ~(1ull << bl);
-                        const int position = (int)rdlane((uint32_t)my_pos, (uint32_t)bl);
-                        JitVoxel<DIM> vox;
-                        if (!vox.setup(a, position, lane)) break;           /* hidden: so is everything behind it */
-                        const int src = (int)rdlane((uint32_t)my_node, (uint32_t)bl);
-                        const int g = src >> 6, c = src & 63;
-                        const GroupInfo gi = j.groups[g];
-                        unsigned long long L = 0, R = 0, K = all;
-                        if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
-                            const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
-                            L = rfl64(rec[0]);
-                            R = rfl64(rec[1]);
-                            K = rfl64(rec[2]);
-                        }
-                        const bool kept = (K >> lane) & 1ull;
-                        const int i = __popcll(K & ((1ull << lane) - 1ull));
-                        ulonglong2 mk = make_ulonglong2(0ull, 0ull);
-                        if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
-                        const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
-                        const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
-                        vox.finish(a, res);
-                        ++nwalked;
-                    }
-                }
-            }
-        }
-    }
-    if (j.walked && lane == 0 && nwalked) atomicAdd(j.walked + (blockIdx.x & 31) * 32, nwalked);
-}
-int voxel_gen_cols_grid(int dim, int cus)
-{
-    int per_cu = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen_cols<3>, 64, 0);
-    (void)dim;
-    if (e != hipSuccess || per_cu <= 0) per_cu = 16;
-    return per_cu * cus;
-}
-void launch_eval_voxels_gen_cols(hipStream_t s, const VoxelArgs& a, const uint32_t* code, int grid, const unsigned long long* head, const int* link, unsigned tag,
-                                 const GroupInfo* groups, const ulonglong2* choice_masks, int choice_cap, int* col_counter, int* next_counter,
-                                 const unsigned long long* parent_records, int nchoices, int run, int* walked)
-{
-    ColVoxelArgs j;
-    j.v = a;
-    j.code = code;
-    j.head = head;
-    j.link = link;
-    j.tag = tag;
-    j.groups = groups;
-    j.choice_masks = choice_masks;
-    j.choice_cap = choice_cap;
-    j.col_counter = col_counter;
-    j.next_counter = next_counter;
-    j.parent_records = parent_records;
-    j.nchoices = nchoices;
-    j.run = run > 0 ? (run > 64 ? 64 : run) : 2;
-    j.walked = walked;
-    hipLaunchKernelGGL(k_eval_voxels_gen_cols<3>, dim3(grid), dim3(64), 0, s, j);
 }
 
 /* one tape through the host-generated code: a and b in the x and y slots, the tile's decisions wave-uniform */

@@ -92,31 +92,23 @@ def test_general_views_with_the_second_verdict(mpr, orc, tapes, seed):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,S", [("bear", 512), ("trig_blend", 256), ("smooth", 256)])
-def test_float_pass_by_column_stops_at_the_first_hidden_tile(mpr, orc, tapes, name, S, monkeypatch):
-    """Round 6: the float pass of frames on the root tape's generated code takes a COLUMN of smallest tiles — those over one 4 x 4
-    footprint of pixels, linked by k_link_columns — per wavefront and walks it front to back until a tile is hidden
-    (k_eval_voxels_gen_cols).  The oracle's heights and normals; no more tiles walked than listed, and fewer than the pass that hands
-    tiles out one by one in z order walks (MPR_VOXEL_COLS=0: there every listed tile that is not yet hidden when its turn comes)."""
+@pytest.mark.parametrize("name,S", [("bear", 512), ("trig_blend", 256)])
+def test_tiles_the_float_pass_walks(mpr, orc, tapes, name, S, monkeypatch):
+    """What the bench line's algorithmic bytes are counted over (bench.py: roofline.units): the tiles the float pass lists after the
+    second verdict, and those of them it walks — the others it finds hidden behind the heights drawn so far (development counter,
+    MPR_DEBUG_WALKED=1)."""
     tape = tapes(name)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
     monkeypatch.setenv("MPR_DEBUG_WALKED", "1")
     ctx = mpr.Context(S)
-    monkeypatch.setenv("MPR_VOXEL_COLS", "0")
-    old = mpr.Context(S)
     for k in range(4):
         ctx.render3D(tape, view3())
-        old.render3D(tape, view3())
-        for c in (ctx, old):
-            assert np.array_equal(c.image, ref.image), (k, c.float_kernel(), int((c.image != ref.image).sum()))
-            assert np.array_equal(c.normals, ref.normals), (k, c.float_kernel())
-    assert ctx.float_kernel() == "k_eval_voxels_gen_cols<3>" and old.float_kernel() == "k_eval_voxels_gen<3>"
+        assert np.array_equal(ctx.image, ref.image) and np.array_equal(ctx.normals, ref.normals), k
+    assert ctx.float_kernel() == "k_eval_voxels_gen<3>"
     listed, walked = ctx.frame_tiles()[2], ctx.tiles_walked()
-    assert old.tiles_walked() <= 0                      # (not counted there)
-    assert 0 < walked <= listed, (walked, listed)
-    print("%s %d: %d tiles listed, %d walked" % (name, S, listed, walked))
+    assert 0 < walked <= listed < ref.counters["voxel_tiles"], (walked, listed, ref.counters["voxel_tiles"])
+    print("%s %d: the reference lists %d tiles, the second verdict leaves %d, %d walked" % (name, S, ref.counters["voxel_tiles"], listed, walked))
     ctx.close()
-    old.close()
 
 
 @pytest.mark.parametrize("seed,size", [(41777, 3), (48461, 8), (48813, 3), (50609, 3), (52835, 3)])
