@@ -675,17 +675,24 @@ static int begin_frame(mpr_context* c, const mpr_tape* tape, const int32_t* owne
     if (c->frame_pending) HIP_TRY(hipStreamSynchronize(c->stream));
     c->frame_pending = false;
     if (c->pool_auto && c->pool_grow_pending && c->pool_cap < (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) {
-        const long long bigger = std::min<long long>(c->pool_cap * 2, (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK);
+        /* (by half, not by the whole — three architecture 2048^3 contexts went from under 3 GB to 4.2 — and, no frame being
+         * in flight, the old pool goes before the new one comes: the peak is the new pool, not old + new) */
+        const long long bigger = std::min<long long>(c->pool_cap + c->pool_cap / 2, (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK);
+        const long long old_cap = c->pool_cap;
+        (void)hipFree(c->pool);
+        c->pool = nullptr;
         uint64_t* fresh = nullptr;
         if (hipMalloc((void**)&fresh, ((size_t)bigger + 128) * sizeof(uint64_t)) == hipSuccess) {
-            (void)hipFree(c->pool);
             c->pool = fresh;
             c->pool_cap = bigger;
-            c->tape_serial = 0;
             ++c->pool_growths;
         } else {
             (void)hipGetLastError();
+            if (hipMalloc((void**)&fresh, ((size_t)old_cap + 128) * sizeof(uint64_t)) != hipSuccess)
+                return mpr::set_error(MPR_ERR_ALLOC, "no memory for the tape pool");
+            c->pool = fresh;
         }
+        c->tape_serial = 0;
     }
     c->pool_grow_pending = false;
     if (c->pool_auto && (long long)len + 4096 >= c->pool_cap) {
@@ -1438,7 +1445,8 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
             a.gen_fwd2 = c->gen_code + c->gen_iw_at[kind][2];
         }
         a.redo_flags = c->redo_flags;
-        (void)mprk::launch_eval_tiles(s, dim, a);
+        if (!mprk::launch_eval_tiles(s, dim, a))        /* (the launch behind it reads flags only this kernel writes: ADVICE r5) */
+            return mpr::set_error(MPR_ERR_INVALID, "internal: a lean tile stage planned on generated code ran another kernel");
         a.lean = 0;
         a.redo_flags = nullptr;
         a.only_flagged = c->redo_flags;
@@ -1816,15 +1824,17 @@ static int frame_finish(Frame& f)
 
 /* the comparison has been waited for: did the frame's shortcut past the 64^3 tiles fail its verification?  Then the tape's
  * next frames start at those tiles (the caller renders this one again) */
-static bool skip0_verdict_failed(mpr_context* c, const mpr_tape* tape)
+static bool skip0_verdict_failed(mpr_context* c, const mpr_tape* tape, bool whole_frame = true)
 {
     if (!c->skip0_unchecked) return false;
     c->skip0_unchecked = false;
     const bool normals_veto = c->skip0_normals_veto;
     c->skip0_normals_veto = false;
     if (*reinterpret_cast<volatile int*>(c->skip0_flag_host) == 0 && !normals_veto) {
+        /* a verified frame passed: the next failure starts at 64 again.  (whole_frame == false: only the tiles' verdict is in, the
+         * normals pass has yet to accept the frame — its veto would find the entry gone and start at 64 every time: ADVICE r5) */
         auto it = c->skip0_veto.find(tape->serial);
-        if (it != c->skip0_veto.end()) c->skip0_veto.erase(it);        /* a verified frame passed: the next failure starts at 64 again */
+        if (whole_frame && it != c->skip0_veto.end()) c->skip0_veto.erase(it);
         return false;
     }
     /* (a view that changes may pass later: the tape tries again after 64 frames, after 128 if that fails too, ... 4096) */
@@ -1859,7 +1869,7 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
             HIP_TRY(hipEventSynchronize(c->ev_done));        /* (long there: two tile stages have been waited for since) */
             c->side_compare_pending = false;
             c->skip0_unchecked = true;
-            if (skip0_verdict_failed(c, tape)) continue;
+            if (skip0_verdict_failed(c, tape, false)) continue;
         }
         if (!f.tiles_only) {          /* (a reader's re-render: tiles and tapes are the reference's now; heights and normals were all along) */
             rc = frame_float_pass(f);
@@ -1875,8 +1885,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
                 if (rc) return rc;
             }
         }
-        if (f.skip0_checked && !blocking && c->skip0_normals_veto) {
-            c->skip0_unchecked = true;
+        if (f.skip0_checked && !blocking) {
+            c->skip0_unchecked = true;              /* (the tiles' verdict stands; this adds the normals pass's and clears a passed tape's entry) */
             if (skip0_verdict_failed(c, tape)) continue;
         }
         if (f.skip0_checked && blocking) {
@@ -1925,9 +1935,20 @@ static int render_checked(mpr_context* c, const mpr_tape* tape, int dim, const f
     if (!c->last_frame_fast) return MPR_OK;
     const size_t n = (size_t)c->S * c->S;
     if (!c->paranoid_image) {
-        if (hipMalloc(&c->paranoid_image, n * sizeof(int)) != hipSuccess || hipMalloc(&c->paranoid_normals, n * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc(&c->paranoid_count, 2 * sizeof(unsigned long long)) != hipSuccess)
+        int* pi = nullptr;
+        uint32_t* pn = nullptr;
+        unsigned long long* pc = nullptr;
+        if (hipMalloc((void**)&pi, n * sizeof(int)) != hipSuccess || hipMalloc((void**)&pn, n * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&pc, 2 * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (pi) (void)hipFree(pi);
+            if (pn) (void)hipFree(pn);
+            if (pc) (void)hipFree(pc);
             return mpr::set_error(MPR_ERR_ALLOC, "no memory for the second frame of a paranoid context");
+        }
+        c->paranoid_image = pi;             /* (all three or none: ADVICE r5) */
+        c->paranoid_normals = pn;
+        c->paranoid_count = pc;
     }
     HIP_TRY(hipMemcpyAsync(c->paranoid_image, c->filled[3], n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     if (dim == 3) HIP_TRY(hipMemcpyAsync(c->paranoid_normals, c->normals, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));

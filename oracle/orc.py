@@ -60,6 +60,8 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = os.path.join(_HERE, "liboracle.so")
+    if os.environ.get("MPR_ORACLE_ASAN") == "1":       # scripts/segv_hunt.sh: the build with AddressSanitizer (make -C oracle asan)
+        path = os.path.join(_HERE, "liboracle_asan.so")
     if not os.path.exists(path):
         build()
     L = ctypes.CDLL(path)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# one of the twelve processes of round 5's fuzz sweep (seeds 2700..2869) died of a segmentation fault.  The same
+# sweep again, twelve processes side by side, python's faulthandler on (the Python-level stack of a fatal signal names the call that
+# died: the oracle through ctypes, or the library), core dumps allowed; leg "asan": the ORACLE built with -fsanitize=address
+# (oracle/Makefile: liboracle_asan.so, loaded when MPR_ORACLE_ASAN=1) under LD_PRELOAD of the sanitizer's runtime.
+# usage: segv_hunt.sh ROUNDS [asan]      -> gpurun_out/r06_segv/
+cd "$(dirname "$0")/.." || exit 1
+ROUNDS=${1:-3}; LEG=${2:-plain}
+OUT=gpurun_out/r06_segv; mkdir -p $OUT
+ulimit -c unlimited
+export PYTHONFAULTHANDLER=1
+if [ "$LEG" = asan ]; then
+  make -s -C oracle asan || exit 1
+  export MPR_ORACLE_ASAN=1
+  export LD_PRELOAD=$(gcc -print-file-name=libasan.so)
+  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
+fi
+for r in $(seq 1 $ROUNDS); do
+  for i in $(seq 0 11); do
+    python scripts/fuzz_sweep.py $((1000 + i * 170)) 170 16 > $OUT/${LEG}_r${r}_part_$i.log 2>&1 &
+  done
+  wait
+  echo "== $LEG round $r: $(grep -l '^seeds' $OUT/${LEG}_r${r}_part_*.log | wc -l) of 12 processes finished; $(grep -h '^seeds' $OUT/${LEG}_r${r}_part_*.log | awk '{s+=$6} END {print s}') frames differ"
+  grep -l "Fatal Python error\|Segmentation\|AddressSanitizer\|Traceback" $OUT/${LEG}_r${r}_part_*.log | while read f; do echo "--- $f"; grep -n -A25 "Fatal Python error\|AddressSanitizer\|Traceback" $f | head -60; done
+done

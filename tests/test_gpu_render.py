@@ -798,7 +798,7 @@ def test_tape_pool_sized_by_the_frames(mpr, orc, tapes):
     # later frame — whose pushes run a few per cent higher or lower with the timing of the fills — has to grow it in the middle: 3.4 GB;
     # later in round 5 architecture's last stage pushes per-tile tapes again (the faster form since the stages' atomic went) and its
     # first stage decides a little less (looser enclosures): one doubling more in each context, 4.2 GB — three reference pools: 9.8)
-    assert after < 5 * 2**30, after
+    assert after < 4.5 * 2**30, after            # (round 6: a pool grows by half, not by the whole)
     assert np.array_equal(ctxs[0].image, ctxs[2].image)
     # reading tiles / tapes makes a frame the reference's way: the pool grows as far as that needs, and the tapes are complete
     cnt = ctxs[0].counters()
