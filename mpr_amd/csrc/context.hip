@@ -75,7 +75,7 @@ struct mpr_context {
     int* col_list_dev = nullptr;
     int* zs_hist = nullptr;            /* front-to-back compaction (3-D): per-layer counts and cursors */
     int* zs_cursor = nullptr;
-    int zsort = 3;                     /* MPR_ZSORT: bit0 = tile stages, bit1 = the list of the float pass */
+    int zsort = 3;                     /* bit0 = tile stages, bit1 = the list of the float pass: handed on front to back (no switch since round 6) */
     float* heat = nullptr;             /* render*_heatmap: S x S floats, allocated on first use */
     bool heat_frame = false;           /* the frame being issued accumulates into heat */
     int* h_pinned = nullptr;           /* small pinned scratch for read-backs */
@@ -112,7 +112,7 @@ struct mpr_context {
     bool last_frame_fast = false;      /* the last frame took one of the shortcuts above ... */
     bool last_frame_lean = false;      /* ... this one: no tapes from its last tile stage */
     bool skip_stage0 = true;           /* MPR_SKIP_STAGE0=0: never start at the 16^3 tiles */
-    int measure_len_forced = -1;       /* MPR_MEASURE_LEN (development): groups per run of the last stage's sample */
+    int measure_len_forced = -1;       /* (no switch since round 6) groups per run of the last stage's sample, or -1: the frame's own choice */
     struct FrameKey {
         int dim = 0, rank = 0;
         bool parted = false;
@@ -127,8 +127,8 @@ struct mpr_context {
     bool tiles_vgpr = true;            /* MPR_TILES_VGPR=0 (development): tile stages keep every slot file in LDS */
     bool tiles_asm = true;             /* MPR_TILES_ASM=0 (development): compiled forward / backward walks in the tile stages */
     bool groups_always = false;        /* MPR_VOXEL_GROUPS=2 (development): group form whatever the tapes' lengths */
-    int jit_slots = 0;                 /* MPR_JIT_SLOTS (development): code slots per workgroup of the group form (default 16) */
-    int jit_wgs_per_cu = 0;            /* MPR_JIT_WGS (development): workgroups per CU of the group form's persistent grid */
+    int jit_slots = 0;                 /* (no switch since round 6) code slots per workgroup of the group form, 0: 16 */
+    int jit_wgs_per_cu = 0;            /* (no switch since round 6) workgroups per CU of the group form's persistent grid, 0: what fits */
     int jit_gap = 0;                   /* MPR_JIT_GAP (development): dwords between code slots of the group form's ring */
     bool jit_always_invalidate = false;/* MPR_VOXEL_JIT=3 (development): the group form invalidates the instruction cache after every translation */
     bool jit_validated_arch = false;   /* gfx950: the ring's one-invalidate-per-trip was validated there and nowhere else */
@@ -145,6 +145,12 @@ struct mpr_context {
     int* group_list = nullptr;             /* those groups in list order, then their number (k_list_alive_groups) */
     size_t group_alive_cap = 0, group_list_cap = 0;
     int* vox_counters = nullptr;           /* the float pass on the root tape's code: its tile counters (kernels_voxel_jit.hip: VG_LISTS) */
+    /* ... by footprint segments (round 6; kernels.hip: k_compact_footprints, kernels_voxel_jit.hip: k_eval_voxels_gen_fp) */
+    unsigned* fp_items = nullptr;
+    size_t fp_items_cap = 0;
+    int* fp_meta = nullptr;                /* {segments appended, their total} */
+    int fp_grid = 0;
+    bool voxel_fp = true;                  /* MPR_VOXEL_FP=0: that float pass tile by tile in z order (round 3's list) */
     int* walked_dev = nullptr;             /* MPR_DEBUG_WALKED=1: tiles the float pass on the root tape's code walked (the others it found hidden), 32 x 32 ints */
     int* tile_source = nullptr;            /* per smallest tile: its index in the last tile stage's list (the float pass on the root tape's code) */
     size_t tile_source_cap = 0;
@@ -168,13 +174,13 @@ struct mpr_context {
     std::shared_ptr<const mpr::TapeCode> resident_code;   /* what gen_code holds (kept alive: the upload is asynchronous) */
     int gen_vox_at = 0, gen_derivg_at = 0, gen_derivg_dw = 0;   /* where the float walk / the guarded forward walk / the guarded
                                                                                    Deriv walk start in gen_code (dwords) */
-    bool normals_guards = true;        /* MPR_NORMALS_GUARDS=0: the normals pass runs the plain Deriv walk */
+    bool normals_guards = true;        /* the normals pass runs the Deriv walk that jumps over what every pixel of the wavefront left dead (no switch since round 6) */
     /* frame_domain.hpp: does the last (tape, view) asked about keep every interval operation where the reference's routines are
      * isotone (the shortcuts below that are only then the reference's procedure: skip0, the loose enclosures) */
     uint64_t tame_serial = 0;
     FrameKey tame_key;
     bool tame_value = false;
-    bool tame_check = true;            /* MPR_TAME_CHECK=0 (development): every frame counts as tame */
+    bool tame_check = true;            /* (no switch since round 6: false = every frame counts as tame) */
     /* frames that start at the 16^3 tiles and are not tame: the 64^3 tiles walked beside the frame, every 16^3 tile held against
      * its parent before the float pass is launched (kernels.hpp: launch_skip0_parents / launch_skip0_compare) */
     hipStream_t side = nullptr;
@@ -222,6 +228,8 @@ struct mpr_context {
     bool tile_gen_loose = true;        /* MPR_TILE_GEN_LOOSE=0: frames nobody reads keep the correctly rounded exp / log enclosures in their tile stages */
     /* the scheduled interval forward walks (interval_gen.hpp) in gen_code: [kind][exact, loose, tight] */
     int gen_iw_at[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gen_iw_dw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    unsigned char* tight_skip = nullptr;   /* per tile of the last stage's list (TileStageArgs::tight_skip) */
+    size_t tight_skip_cap = 0;
     bool tile_tight = true;            /* MPR_TILE_TIGHT=0: the last tile stage of a frame nobody reads hands the float pass every tile the reference's
                                         * enclosures leave ambiguous (round 6: with it, those a sound sin / cos enclosure decides stay away) */
     /* the resident tape's first-stage walk for the kernel with 93 slots in registers (internal.hpp: mpr_tape::big_fwd), or none */
@@ -247,7 +255,7 @@ struct mpr_context {
     int voxel_gen_min_run = 5;         /* MPR_VOXEL_GEN_RUN (development): shortest run of dead clauses that gets a guard (0: none) */
     int vox_grid_cache[2] = {0, 0};
     int voxel_gen_tiles = 0;           /* MPR_VOXEL_GEN_TILES (development): consecutive tiles a wavefront takes per atomic (default 4) */
-    int voxel_gen_wgs = 0;             /* MPR_VOXEL_GEN_WGS (development): at most this many persistent workgroups per CU */
+    int voxel_gen_wgs = 0;             /* (no switch since round 6) at most this many persistent workgroups per CU, 0: what fits */
     bool tile_gen_chain = true;        /* MPR_TILE_GEN_CHAIN=0: only a frame's first stage (and, in frames that start at the 16^3 tiles, the last) */
     void* sched_recs = nullptr;        /* the resident tape's level schedule (tape_schedule.hpp), or unused */
     int* sched_levels = nullptr;
@@ -259,14 +267,14 @@ struct mpr_context {
     bool wide_stage0 = true;           /* MPR_WIDE_STAGE0=0: first stage with the one-lane-per-tile kernel */
     int wide_later = -1;               /* MPR_WIDE_LATER: later stages run level-parallel too while they have at most this many
                                           tiles and the stage before did (0: never; default: two rounds of workgroups on the chip) */
-    int wide_threads = 0;              /* MPR_WIDE_THREADS (development): workgroup size of the level-parallel kernel */
+    int wide_threads = 0;              /* (no switch since round 6) workgroup size of the level-parallel kernel, 0: by the tape */
     uint32_t* wide_bits[2] = {nullptr, nullptr};   /* kernels_wide.hip: inherited-tape tables, ping-pong between stages */
     size_t wide_bits_cap[2] = {0, 0};
     /* development switches, read once when the context is created (never per frame) */
     bool wide_force = false;           /* MPR_WIDE_FORCE: level-parallel first stage whatever the DAG's shape */
-    bool dynamic_choices = true;       /* MPR_DYNAMIC_CHOICES=0: size every stage's choice array by the root tape */
+    bool dynamic_choices = true;       /* a stage's choice array sized by what the stage above reported, not by the root tape (no switch since round 6) */
     int debug_tiles = 0;               /* MPR_DEBUG_TILES: 1 = skip tape pushing, 2 = skip the arithmetic, 4 = cycle breakdown */
-    bool debug_choices = false;        /* MPR_DEBUG_CHOICES */
+    bool debug_choices = false;        /* (no switch since round 6) print the stages' samples */
     int tape_len = 0;
 
     mpr_counters last = {};
@@ -453,8 +461,6 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_VOXEL_JIT")) { c->voxel_jit = atoi(e) != 0; c->voxel_jit_tiles = atoi(e) == 2; c->jit_always_invalidate = atoi(e) == 3; }
     if (const char* e = getenv("MPR_VOXEL_GROUPS")) { c->voxel_groups = atoi(e) != 0; c->groups_always = atoi(e) == 2; }
     if (const char* e = getenv("MPR_JIT_GAP")) c->jit_gap = atoi(e);
-    if (const char* e = getenv("MPR_JIT_WGS")) c->jit_wgs_per_cu = atoi(e);
-    if (const char* e = getenv("MPR_JIT_SLOTS")) c->jit_slots = atoi(e);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, opt->device) == hipSuccess) {
@@ -463,7 +469,6 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
             c->jit_validated_arch = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
         }
     }
-    if (const char* e = getenv("MPR_ZSORT")) c->zsort = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_ASM")) c->normals_asm = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN")) c->tile_gen = atoi(e);
     if (const char* e = getenv("MPR_NORMALS_GEN")) c->normals_gen = atoi(e) != 0;
@@ -471,6 +476,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_TILE_GEN_GUARDS")) c->tile_gen_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_LEAN")) c->tile_gen_lean = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_TIGHT")) c->tile_tight = atoi(e) != 0;
+    if (const char* e = getenv("MPR_VOXEL_FP")) c->voxel_fp = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_WALKED"))
         if (atoi(e) != 0) {
             if (hipMalloc((void**)&c->walked_dev, 1024 * sizeof(int)) != hipSuccess) c->walked_dev = nullptr;
@@ -479,12 +485,9 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     if (const char* e = getenv("MPR_DEBUG_REDO"))
         if (atoi(e) != 0 && hipMalloc((void**)&c->redo_count, 2 * sizeof(unsigned int)) == hipSuccess) (void)hipMemset(c->redo_count, 0, 2 * sizeof(unsigned int));
     if (const char* e = getenv("MPR_TILE_GEN_LOOSE")) c->tile_gen_loose = atoi(e) != 0;
-    if (const char* e = getenv("MPR_TAME_CHECK")) c->tame_check = atoi(e) != 0;
     if (const char* e = getenv("MPR_SKIP0_CHECK")) c->skip0_verify = atoi(e) != 0;
     if (const char* e = getenv("MPR_LEAN_FIRST")) c->lean_first = atoi(e) != 0;
-    if (const char* e = getenv("MPR_NORMALS_GUARDS")) c->normals_guards = atoi(e) != 0;
     if (const char* e = getenv("MPR_VOXEL_GEN_RUN")) c->voxel_gen_min_run = atoi(e);
-    if (const char* e = getenv("MPR_VOXEL_GEN_WGS")) c->voxel_gen_wgs = atoi(e);
     if (const char* e = getenv("MPR_VOXEL_GEN_TILES")) c->voxel_gen_tiles = atoi(e);
     if (const char* e = getenv("MPR_TILE_GEN_LAST")) c->tile_gen_last = atoi(e) != 0;
     if (const char* e = getenv("MPR_TILE_GEN_CHAIN")) c->tile_gen_chain = atoi(e) != 0;
@@ -498,21 +501,14 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     c->raw_reads = getenv("MPR_DEBUG_RAW_READS") != nullptr;
     if (const char* e = getenv("MPR_LAST_STAGE_PUSH")) c->reference_frames = atoi(e) != 0;
     if (const char* e = getenv("MPR_SKIP_STAGE0")) c->skip_stage0 = atoi(e) != 0;
-    if (const char* e = getenv("MPR_MEASURE_LEN")) c->measure_len_forced = atoi(e);
     if (const char* e = getenv("MPR_WIDE_LATER")) c->wide_later = atoi(e);
-    if (const char* e = getenv("MPR_WIDE_THREADS")) c->wide_threads = atoi(e);
-    if (const char* e = getenv("MPR_DYNAMIC_CHOICES")) c->dynamic_choices = atoi(e) != 0;
     if (const char* e = getenv("MPR_DEBUG_TILES")) c->debug_tiles = atoi(e);
-    c->debug_choices = getenv("MPR_DEBUG_CHOICES") != nullptr;
     /* Tape pool.  The reference allocates NUM_SUBTAPES * 64 clauses whatever the frame (inc/parameters.hpp:14-22: 328 MB, 3.28 GB
      * with BIG_SERVER); a frame of bear 1024^3 that leaves the reference's tapes behind fills 1.1 GB of it, an ordinary frame
      * (no tapes from its last tile stage) under 0.2 GB, prospero 1024^2 a few MB.  A capacity the caller names is kept, with
      * the reference's behaviour when it runs out (tiles keep their parents' tapes, src/context.cu:336-347).  Otherwise: 2 M
      * clauses (16 MB) per 256 px of image side to begin with, at least 4 M, doubled on demand. */
     c->pool_auto = opt->pool_clauses <= 0;
-    if (const char* e = getenv("MPR_POOL_CLAUSES")) {                  /* development: a fixed capacity without touching the caller */
-        if (atoll(e) > 0) { c->pool_cap = atoll(e); c->pool_auto = false; }
-    }
     if (c->pool_auto) c->pool_cap = std::max<long long>(4ll << 20, (long long)(S / 256) * (2ll << 20));
     else if (c->pool_cap == 0) c->pool_cap = opt->pool_clauses;
     if (c->pool_cap > 0x7FFFFFFFll) c->pool_cap = 0x7FFFFFFFll;   /* tape indices are int32 (inc/context.hpp:25) */
@@ -622,6 +618,9 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->group_list) (void)hipFree(c->group_list);
     if (c->tile_source) (void)hipFree(c->tile_source);
     if (c->vox_counters) (void)hipFree(c->vox_counters);
+    if (c->fp_items) (void)hipFree(c->fp_items);
+    if (c->fp_meta) (void)hipFree(c->fp_meta);
+    if (c->tight_skip) (void)hipFree(c->tight_skip);
     if (c->walked_dev) (void)hipFree(c->walked_dev);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
@@ -983,6 +982,9 @@ struct Frame {
     bool presence_recorded = false;        /* ... with the clauses of the tapes they pushed */
     bool last_recorded = false;            /* ... down to the smallest tiles */
     bool vox_gen_planned = false;          /* the last stage's compaction kept, per smallest tile, where it sat in that stage's list */
+    bool vox_counters_cleared = false;     /* ... and cleared the float pass's work counters */
+    bool vox_fp = false;                   /* ... or made footprint segments of the stage's list instead: the float pass by segments */
+    bool tight_skip_valid = false;         /* the last tile stage was followed by the second verdict in a launch of its own: c->tight_skip */
     bool group_form = false;               /* the last stage recorded its groups' tapes and decisions, and the float pass takes them */
     bool lean_now = false;                 /* the last stage pushed no tapes */
     int group_stage = 0, group_count = 0, group_cap = 1;
@@ -1457,6 +1459,32 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
         const bool ran_gen = mprk::launch_eval_tiles(s, dim, a);
         if (a.gen_fwd && !ran_gen)          /* the records this frame counts on would not exist */
             return mpr::set_error(MPR_ERR_INVALID, "internal: a tile stage planned on generated code ran another kernel");
+        /* a last stage that pushed its tapes (a frame somebody reads, or whose float pass wants per-tile tapes) on the root tape's generated
+         * code, the float pass on that code too: the second verdict in a launch of its own (TileStageArgs::verdict_only) — the tiles it
+         * decides stay in the reference's lists and skip the float pass's walk */
+        const int tk = c->gen_iw_dw[mpr::IW_BELOW_GUARDED][2] > 0 ? mpr::IW_BELOW_GUARDED : mpr::IW_BELOW;
+        /* (not in a frame rendered again FOR a reader or for MPR_CTX_PARANOID's comparison: that one is the reference's way and nothing else) */
+        if (ran_gen && last && dim == 3 && a.gen_parent && a.gen_bwd_full && a.groups && c->tile_tight && c->tile_gen_lean && !c->force_reference && !cnt && !heat && !(a.debug & 36) &&
+            c->gen_iw_dw[tk][2] > 0 && tape->loose_ok && c->tile_gen_loose) {
+            int rc2 = ensure_buffer(&c->tight_skip, &c->tight_skip_cap, (size_t)count + 64);
+            if (rc2) return rc2;
+            mprk::TileStageArgs v = a;
+            v.lean = 2;
+            v.verdict_only = true;
+            v.tight_skip = c->tight_skip;
+            v.gen_fwd2 = c->gen_code + c->gen_iw_at[tk][2];
+            v.gen_guarded = tk == mpr::IW_BELOW_GUARDED;
+            v.redo_flags = nullptr;
+            v.only_flagged = nullptr;
+            v.len_stats = nullptr;
+            v.self_info = nullptr;
+            v.gen_redo_count = nullptr;
+            v.next_choices = nullptr;
+            if (mprk::launch_eval_tiles(s, dim, v)) {
+                f.tight_skip_valid = true;
+                c->stage_forms += "+verdict";
+            }
+        }
     }
     return MPR_OK;
 }
@@ -1562,18 +1590,40 @@ static int frame_tile_stage(Frame& f, int si)
         const bool vox_gen_next = last && groups_now && dim == 3 && i == 2 && decisions_recorded && c->voxel_gen && c->gen_ok && c->gen_vox_dw > 0 &&
                                   c->cus > 0;
         vox_gen_planned = vox_gen_next;
+        /* ... by footprint segments: no list of tiles, the stage's own list in blocks of 64 siblings */
+        const bool vox_fp_next = vox_gen_next && c->voxel_fp && count > 0 && (count & 63) == 0;
+        f.vox_fp = vox_fp_next;
         if (vox_gen_next) {
-            rc = ensure_buffer(&c->tile_source, &c->tile_source_cap, (size_t)std::max(count, 1));
-            if (rc) return rc;
+            if (vox_fp_next) {
+                rc = ensure_buffer(&c->fp_items, &c->fp_items_cap, (size_t)count / 4 + 64);
+                if (rc) return rc;
+                if (!c->fp_meta) {
+                    HIP_TRY(hipMalloc((void**)&c->fp_meta, 4 * sizeof(int)));
+                    HIP_TRY(hipMemsetAsync(c->fp_meta, 0, 4 * sizeof(int), s));
+                }
+            } else {
+                rc = ensure_buffer(&c->tile_source, &c->tile_source_cap, (size_t)std::max(count, 1));
+                if (rc) return rc;
+            }
+            if (!c->vox_counters) HIP_TRY(hipMalloc((void**)&c->vox_counters, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int)));
         }
+        f.vox_counters_cleared = false;
         auto compact = [&](bool mark_groups) -> int {
             const int seq = ++c->pub_seq;
-            if (zs) {
+            if (mark_groups && vox_fp_next) {
+                TimedScope ts(c, "compact_copy");
+                mprk::launch_compact_footprints(s, c->tiles[i], count, tps, c->filled[i], c->num_active, c->fp_items, c->fp_meta, c->vox_counters,
+                                                mprk::voxel_gen_counter_lists(), mprk::voxel_gen_counter_ints() / mprk::voxel_gen_counter_lists(), c->pub_dev, seq,
+                                                (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub), c->tape_index);
+                f.vox_counters_cleared = true;
+            } else if (zs) {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_zsorted(s, last, c->tiles[i], count, tps, c->filled[i], c->tiles[next],
                                              c->zs_hist, c->zs_cursor, c->pub_dev, seq, (last && tiles_only) ? nullptr : c->filled[next], S / (tile_size_px / sub),
                                              c->num_active + 4, mark_groups ? c->group_alive : nullptr, c->tape_index,
-                                             (mark_groups && vox_gen_next) ? c->tile_source : nullptr);
+                                             (mark_groups && vox_gen_next) ? c->tile_source : nullptr,
+                                             (mark_groups && vox_gen_next) ? c->vox_counters : nullptr, mprk::voxel_gen_counter_ints());
+                if (mark_groups && vox_gen_next) f.vox_counters_cleared = true;
             } else {
                 TimedScope ts(c, last ? "compact_copy" : "compact_subdivide");
                 mprk::launch_compact_subdivide(s, dim, last, c->tiles[i], count, tps, c->filled[i], c->num_active, c->tiles[next],
@@ -1581,7 +1631,7 @@ static int frame_tile_stage(Frame& f, int si)
                                                mark_groups ? c->group_alive : nullptr, c->tape_index,
                                                (mark_groups && vox_gen_next) ? c->tile_source : nullptr);
             }
-            if (mark_groups && !vox_gen_next) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
+            if (mark_groups && !vox_gen_next && !vox_fp_next) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
             return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
         };
         if (count > 0) {
@@ -1631,6 +1681,15 @@ static int frame_tile_stage(Frame& f, int si)
             }
             rc = compact(false);
             if (rc) return rc;
+        }
+        if (f.vox_fp && !(vox_gen_planned && group_form)) {
+            /* segments were made of the stage's list and the float pass takes the list of tiles after all (per-tile tapes: this frame's
+             * sample said they pay, or the stage pushed them anyway): the list */
+            if (!(try_lean && !group_form && count > 0)) {          /* (that re-run compacted already) */
+                rc = compact(false);
+                if (rc) return rc;
+            }
+            f.vox_fp = false;
         }
         if (count > 0 && (act3[4] & 0x80000000) && c->pool_auto && c->pool_cap < (long long)MPR_NUM_SUBTAPES_BIG * MPR_SUBTAPE_CHUNK) {
             /* a push of this stage found the pool full and its tile kept the parent's tape (the reference's silent fallback):
@@ -1688,19 +1747,33 @@ static int frame_float_pass(Frame& f)
         bool jitted = false, on_root_code = false;
         /* The root tape's host-generated float walk (voxel_gen.hpp), the tiles' decisions as bits: frames whose tile stages kept their
          * tiles' records down to the stage above the last one, whose last stage recorded its groups' masks */
-        if (vox_gen_planned && group_form && !brute) {
+        if (vox_gen_planned && group_form && !brute && f.vox_fp) {
+            /* by footprint segments over the last tile stage's own list (kernels_voxel_jit.hip: k_eval_voxels_gen_fp) */
+            if (c->fp_grid == 0) c->fp_grid = mprk::voxel_gen_fp_grid(c->cus);
+            mprk::VoxelArgs fv = v;
+            fv.tiles = c->tiles[group_stage];
+            fv.count = group_count;
+            if (c->walked_dev) HIP_TRY(hipMemsetAsync(c->walked_dev, 0, 1024 * sizeof(int), s));
+            /* segments per claim: about four claims per wavefront (a segment is two or three tiles), at most 4 */
+            const int run = c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(4, count / (10 * std::max(c->fp_grid, 1))));
+            mprk::launch_eval_voxels_gen_fp(s, fv, c->gen_code + c->gen_vox_at, c->fp_grid, c->fp_items, c->fp_meta, c->groups, c->choice_masks, group_cap,
+                                            c->vox_counters, c->gen_dec[1], c->gen_nchoices, run, c->walked_dev, f.tight_skip_valid ? c->tight_skip : nullptr);
+            jitted = on_root_code = true;
+        } else if (vox_gen_planned && group_form && !brute) {
             int& grid = c->vox_grid_cache[dim - 2];
             if (grid == 0) grid = mprk::voxel_gen_grid(dim, c->cus);
             const int use_grid = c->voxel_gen_wgs > 0 ? std::min(grid, c->voxel_gen_wgs * c->cus) : grid;
             if (!c->vox_counters) HIP_TRY(hipMalloc((void**)&c->vox_counters, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int)));
-            HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
+            if (!f.vox_counters_cleared)            /* (the z-sorting compaction's scan clears them on the way) */
+                HIP_TRY(hipMemsetAsync(c->vox_counters, 0, (size_t)mprk::voxel_gen_counter_ints() * sizeof(int), s));
             if (c->walked_dev) HIP_TRY(hipMemsetAsync(c->walked_dev, 0, 1024 * sizeof(int), s));
             mprk::launch_eval_voxels_gen(s, dim, v, c->gen_code + c->gen_vox_at, use_grid, c->tile_source, c->groups, c->choice_masks, group_cap,
                                          c->vox_counters, c->gen_dec[1], c->gen_nchoices,
                                          /* tiles per claim: about four claims per wavefront — few tiles (a small frame, a rank's eighth of one)
                                           * take short runs, so that no wavefront is left with a whole run while the others have none; at most
                                           * 8 (measured: bear 1024^3 0.816 ms with 8, 0.831 with 4; 256^3 0.128 / 0.113) */
-                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(8, count / (4 * std::max(use_grid, 1)))), c->walked_dev);
+                                         c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(8, count / (4 * std::max(use_grid, 1)))), c->walked_dev,
+                                         f.tight_skip_valid ? c->tight_skip : nullptr);
             jitted = on_root_code = true;
         }
         if (!cnt && !heat && !jitted) {
@@ -1728,7 +1801,7 @@ static int frame_float_pass(Frame& f)
             return FRAME_AGAIN_REFERENCE;
         }
         if (on_root_code) {
-            snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_gen<%d>", dim);
+            snprintf(c->float_kernel, sizeof c->float_kernel, f.vox_fp ? "k_eval_voxels_gen_fp<%d>" : "k_eval_voxels_gen<%d>", dim);
         } else if (jitted) {
             snprintf(c->float_kernel, sizeof c->float_kernel, "k_eval_voxels_jit%s<%d, %d>", group_form && !brute ? "_groups" : "", dim,
                      mprk::jit_slot_class(nslots));

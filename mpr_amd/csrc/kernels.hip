@@ -186,16 +186,17 @@ k_eval_tiles(TileStageArgs a)
     /* mask_filled_tiles before evaluation (3-D).  Fused here it also sees fills of waves of this very
      * launch (same image, less work); heatmap frames count work, so they run the reference's separate
      * pass (k_mask_filled_tiles) instead and get the reference's deterministic set of evaluated tiles */
+    if (LEAN == 2 && a.verdict_only && valid) a.tight_skip[gidx] = 0;
     if (DIM == 3 && alive && !a.heat && !a.no_mask) {
         if (a.image[pos.w] > pos.z) {
             alive = false;
-            a.tiles[gidx].position = -1;
+            if (!(LEAN == 2 && a.verdict_only)) a.tiles[gidx].position = -1;      /* (verdict_only: the list is somebody else's) */
         }
     }
     const uint64_t alive_mask = ballot(alive);
     if (alive_mask == 0) {
         if (GEN && a.self_info && valid) a.self_info[(size_t)gidx * SKIP0_INFO_U64 + 2] = SKIP0_UNSEEN;
-        if (LEAN && lane == 0) a.redo_flags[blockIdx.x] = 0;
+        if (LEAN && lane == 0 && a.redo_flags) a.redo_flags[blockIdx.x] = 0;
         return;
     }
     const int leader = __ffsll((long long)alive_mask) - 1;
@@ -207,7 +208,7 @@ k_eval_tiles(TileStageArgs a)
                                          (unsigned)((int)blockIdx.x - a.measure_at[1]) < (unsigned)a.measure_len);
     const bool gen_wave = GEN && !(a.gen_parent && sampled && !a.gen_bwd_full);
     if (LEAN && !gen_wave) {                         /* a group of the sample walks its parent's tape: the launch behind this one */
-        if (lane == 0) a.redo_flags[blockIdx.x] = 1;
+        if (lane == 0 && a.redo_flags) a.redo_flags[blockIdx.x] = 1;
         return;
     }
     if (ASM && !gen_wave && !LEAN) first_block = a.tape_ro[tape + 1 + lane];
@@ -286,7 +287,8 @@ k_eval_tiles(TileStageArgs a)
          * this tile's choices */
         unsigned long long keeps = a.gen_nchoices >= 64 ? ~0ull : ((1ull << a.gen_nchoices) - 1ull);
         int walked = a.gen_words - 1;               /* clauses of the tape these tiles walk (the sample's statistics) */
-        if (a.gen_parent && tape != 0) {
+        /* (verdict_only: the stage before this launch left every tile its own tape; the parents all have records: TileStageArgs::verdict_only) */
+        if (a.gen_parent && (tape != 0 || (LEAN == 2 && a.verdict_only))) {
             parent_rec = a.gen_parent + (size_t)__builtin_amdgcn_readlane(node.next, leader) * GEN_RECORD_U64;
             above_l = parent_rec[0];
             above_r = parent_rec[1];
@@ -302,9 +304,17 @@ k_eval_tiles(TileStageArgs a)
             tile_gen_forward2_lean<LEAN == 2>(a.gen_fwd2, gen_io, lane, make_float2(vx.lo, vx.hi), make_float2(vy.lo, vy.hi), make_float2(vz.lo, vz.hi),
                                               &res_vs, chl, chr, above_l, above_r, &redone, nullptr, LEAN == 2 ? &res_tight : nullptr);
             redone = __builtin_amdgcn_readfirstlane(redone);
-            if (lane == 0) a.redo_flags[blockIdx.x] = redone ? 1 : 0;
+            if (lane == 0 && a.redo_flags) a.redo_flags[blockIdx.x] = redone ? 1 : 0;
             if (a.gen_redo_count && lane == 0) atomicAdd(a.gen_redo_count + (redone ? 1 : 0), 1u);
             if (redone) return;                      /* nothing has been written yet: the launch behind this one takes these tiles */
+            if (LEAN == 2 && a.verdict_only) {
+                /* the second verdict and nothing else.  (Filled tiles are DRAWN by the float pass, voxel by voxel: the bottom layer's too) */
+                if (alive && !(res_vs.x > 0.0f) && !(res_vs.y < 0.0f)) {
+                    if (res_tight.x > 0.0f) a.tight_skip[gidx] = 1;
+                    else if (res_tight.y < 0.0f) a.tight_skip[gidx] = 2;
+                }
+                return;
+            }
         } else if (a.debug & 32) {                          /* development: no walk at all, every tile empty (what the rest of the kernel costs) */
             res_vs = make_float2(1.0f, 2.0f);
         } else {
@@ -1016,10 +1026,12 @@ k_zs_hist(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __re
 /* one workgroup: cursor[z] = number of survivors in front of layer z; hist is cleared for the next use */
 __global__ void __launch_bounds__(ZS_MAX_BINS)
 k_zs_scan(int* __restrict__ hist, int* __restrict__ cursor, int tps, int* __restrict__ pub, int seq, int* __restrict__ need,
-          const unsigned long long* __restrict__ tape_index)
+          const unsigned long long* __restrict__ tape_index, int* __restrict__ clear, int nclear)
 {
     __shared__ int sc[ZS_MAX_BINS];
     const int t = threadIdx.x;
+    /* (the last stage's: the float pass's work counters, so that no memset launch stands between the two) */
+    for (int i = t; i < nclear; i += ZS_MAX_BINS) clear[i] = 0;
     const int z = tps - 1 - t;                 /* thread 0 = nearest layer */
     const int mine = (t < tps) ? hist[z] : 0;
     if (t < tps) hist[z] = 0;
@@ -1097,6 +1109,82 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
     }
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* The last tile stage's survivors as FOOTPRINT SEGMENTS (round 6), for the float pass on the root tape's code     */
+/* (kernels_voxel_jit.hip: k_eval_voxels_gen_fp).  The stage's list is made of blocks of 64 siblings — the 4 x 4 x 4 */
+/* children of one 16^3 tile, lane = x + 4 y + 16 z — so the four tiles over one 4 x 4 footprint of pixels inside a  */
+/* block sit 16 lanes apart: a segment = (block, footprint) with at least one survivor, 4 bits for which.  No sort:   */
+/* the blocks are in the order the stage above handed them on (front to back by its z layers), and ONE wavefront of  */
+/* the float pass takes a segment's tiles from the nearest back and stops at the first hidden one — handed out tile   */
+/* by tile in z order (k_zs_*), a tile behind a surface is as a rule walked before the tile in front of it, in another */
+/* wavefront, has drawn the surface (bear 1024^3: 160 k walks where 132 k show anything).  Second mask_filled_tiles,   */
+/* copy_filled and the hand-over of the count ride along as in k_compact_subdivide.                                    */
+/* meta: [0] segments appended so far, [1] = the total, set (and [0] cleared) by the last workgroup; clear: the float   */
+/* pass's work counters, zeroed by it too.                                                                              */
+/* ------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(1024)
+k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ num_active,
+                     unsigned* __restrict__ items, int* __restrict__ meta, int* __restrict__ clear, int nclear, int cstride, int* __restrict__ pub, int seq,
+                     CopyFilled cf, const unsigned long long* __restrict__ tape_index)
+{
+    if ((int)blockIdx.x >= cf.first_block) {
+        copy_filled_block<3>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
+        return;
+    }
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = gidx < count;
+    int position = -1;
+    if (valid) position = tiles[gidx].position;
+    bool active = valid && position != -1;
+    if (active) {
+        const int4_ p = unpack(position, tps);
+        if (image[p.w] > p.z) {
+            active = false;
+            tiles[gidx].position = -1;
+        }
+    }
+    if (valid) tiles[gidx].next = -1;             /* copy_active_tiles resets next (:650) */
+    const uint64_t mask = ballot(active);
+    const uint32_t m16 = (uint32_t)((mask | (mask >> 16) | (mask >> 32) | (mask >> 48)) & 0xFFFFull);
+    __shared__ int wave_tiles[16], wave_items[16], wave_base[16];
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        wave_tiles[wave] = __popcll(mask);
+        wave_items[wave] = __popc(m16);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tiles_total = 0, items_total = 0;
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 0; w < nw; ++w) {
+            wave_base[w] = items_total;
+            items_total += wave_items[w];
+            tiles_total += wave_tiles[w];
+        }
+        if (tiles_total) atomicAdd(num_active, tiles_total);
+        const int b0 = items_total ? atomicAdd(meta, items_total) : 0;
+        for (int w = 0; w < nw; ++w) wave_base[w] += b0;
+    }
+    __syncthreads();
+    if (lane < 16 && ((m16 >> lane) & 1u)) {
+        const uint32_t zbits = (uint32_t)((mask >> lane) & 1ull) | (uint32_t)((mask >> (lane + 16)) & 1ull) << 1 |
+                               (uint32_t)((mask >> (lane + 32)) & 1ull) << 2 | (uint32_t)((mask >> (lane + 48)) & 1ull) << 3;
+        items[wave_base[wave] + __popc(m16 & ((1u << lane) - 1u))] = (uint32_t)gidx | zbits << 28;       /* gidx = block * 64 + footprint */
+    }
+    if (threadIdx.x == 0) {
+        /* the last workgroup through here has every count (k_compact_subdivide: no fence needed, its own additions have returned) */
+        if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
+            const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ni = __hip_atomic_exchange(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(meta + 1, ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < nclear; ++i) __hip_atomic_store(clear + i * cstride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish_counts(pub, seq, n0, 0, 0, num_active + 4, tape_index);
+        }
+    }
+}
 
 /* copy_filled — reference :664-692 */
 template <int DIM>
@@ -1837,16 +1925,25 @@ void launch_compact_subdivide(hipStream_t s, int dim, bool last, mpr_tile_node* 
     }
 }
 bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
+void launch_compact_footprints(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, int* num_active, unsigned* items, int* meta,
+                               int* clear, int nclear, int cstride, int* pub, int seq, int* next_image, int next_size, const unsigned long long* tape_index)
+{
+    const unsigned blocks = (unsigned)((count + 1023) / 1024);
+    unsigned extra = 0;
+    const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)blocks, &extra);
+    hipLaunchKernelGGL(k_compact_footprints, dim3(blocks + extra), dim3(1024), 0, s, tiles, count, tps, image, num_active, items, meta, clear, nclear, cstride, pub, seq, cf,
+                       tape_index);
+}
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
-                            int* need, unsigned char* group_alive, const unsigned long long* tape_index, int* source_out)
+                            int* need, unsigned char* group_alive, const unsigned long long* tape_index, int* source_out, int* clear, int nclear)
 {
     const unsigned nb = (unsigned)((count + 1023) / 1024);
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)nb, &extra);
     const dim3 g(nb), b(1024);
     hipLaunchKernelGGL(k_zs_hist, dim3(nb + extra), b, 0, s, tiles, count, tps, image, hist, cf);
-    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need, tape_index);
+    hipLaunchKernelGGL(k_zs_scan, dim3(1), dim3(ZS_MAX_BINS), 0, s, hist, cursor, tps, pub, seq, need, tape_index, clear, clear ? nclear : 0);
     if (last) hipLaunchKernelGGL(k_zs_scatter<true>, g, b, 0, s, tiles, count, tps, cursor, out, group_alive, source_out);
     else hipLaunchKernelGGL(k_zs_scatter<false>, g, b, 0, s, tiles, count, tps, cursor, out, nullptr, nullptr);
 }

@@ -92,6 +92,13 @@ struct TileStageArgs {
      * stays what it is for the records (the group's masks, which the float and normals passes read) but leaves the list the float pass walks —
      * filled: its height is drawn here.  Sound: the tight enclosure holds every value the float pass would compute for the tile's voxels on the
      * tape it would walk (the root tape with what was decided above imposed) */
+    /* verdict_only (with lean == 2): a launch BEHIND a last stage that ran another way (a frame that leaves the reference's tiles and tapes:
+     * exact enclosures, every tape pushed): the tight code once more over the stage's list, nothing written but tight_skip[tile] — 1: the
+     * float pass need not walk it (provably empty), 2: it draws it without walking (provably filled), 0: as ever.  The lists, tapes and
+     * records stay the reference's.  Sound where the loose walk raises no flag: there the exact decisions the tile's own tape carries are
+     * facts about the float values, and the tight enclosure with the PARENT's decisions imposed holds them (a flagged wavefront: no verdict) */
+    bool verdict_only = false;
+    unsigned char* tight_skip = nullptr;
     unsigned char* redo_flags = nullptr;
     const unsigned char* only_flagged = nullptr;
     unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
@@ -221,7 +228,7 @@ bool zsort_supported(int tps);
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,
                             int* need, unsigned char* group_alive = nullptr, const unsigned long long* tape_index = nullptr,
-                            int* source_out = nullptr);
+                            int* source_out = nullptr, int* clear = nullptr, int nclear = 0);     /* clear: nclear ints the scan zeroes on the way */
 void launch_list_alive_groups(hipStream_t s, const unsigned char* alive, int ngroups, int* list);
 void launch_mask_filled(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image);
 size_t tile_stage_lds_bytes(int nslots, int choice_cap);
@@ -262,9 +269,19 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
  * parent_records: the records of the tiles of the stage above it; tile_counter: voxel_gen_counter_ints() zeroed ints */
 int voxel_gen_grid(int dim, int cus);
 int voxel_gen_counter_ints();
+/* ... by FOOTPRINT SEGMENTS (round 6; kernels.hip: k_compact_footprints makes them of the last tile stage's list, in place of the z-sorted
+ * list of tiles; kernels_voxel_jit.hip: k_eval_voxels_gen_fp): items: one word per segment (capacity: a quarter of the stage's tiles);
+ * meta: 2 ints, zero before the first use; a.tiles = the LAST TILE STAGE's list; counter: voxel_gen_counter_ints() ints the compaction clears */
+int voxel_gen_fp_grid(int cus);
+void launch_compact_footprints(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, int* num_active, unsigned* items, int* meta,
+                               int* clear, int nclear, int cstride, int* pub, int seq, int* next_image, int next_size, const unsigned long long* tape_index);
+int voxel_gen_counter_lists();      /* the float pass's work counters: this many, voxel_gen_counter_ints() / this apart */
+void launch_eval_voxels_gen_fp(hipStream_t s, const VoxelArgs& a, const uint32_t* code, int grid, const unsigned* items, const int* meta, const GroupInfo* groups,
+                               const ulonglong2* choice_masks, int choice_cap, int* counter, const unsigned long long* parent_records, int nchoices, int run,
+                               int* walked, const unsigned char* skip);
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
-                            int nchoices, int run = 0, int* walked = nullptr);
+                            int nchoices, int run = 0, int* walked = nullptr, const unsigned char* skip = nullptr);
 void launch_test_float_gen_all(hipStream_t s, const uint32_t* code, int op, float imm, unsigned long long first, unsigned long long count, unsigned long long* out);
 void launch_test_float_gen(hipStream_t s, const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl,
                            unsigned long long dr);

@@ -1035,6 +1035,8 @@ struct GenVoxelArgs {
     int nchoices;                      /* min / max clauses of the root tape */
     int run;                           /* consecutive tiles a wavefront takes per atomic */
     int* walked;                       /* development: += tiles walked (null: not counted) */
+    const unsigned char* skip;         /* null, or per tile of the last tile stage's list (TileStageArgs::tight_skip): 1 = provably empty, not walked;
+                                        * 2 = provably filled, drawn without a walk */
 };
 
 /* A wavefront per smallest tile, in list order (front to back: the tiles behind a surface find it drawn).  Nothing is shared
@@ -1072,9 +1074,15 @@ k_eval_voxels_gen(GenVoxelArgs j)
             if (run >= nruns) break;
             for (int t = run * run_len; t < min(run * run_len + run_len, a.count); ++t) {
                 const int position = __builtin_amdgcn_readfirstlane(a.tiles[t].position);
+                const int src = __builtin_amdgcn_readfirstlane(j.source[t]);
+                const int verdict = j.skip ? __builtin_amdgcn_readfirstlane((int)j.skip[src]) : 0;
+                if (verdict == 1) continue;
                 JitVoxel<DIM> vox;
                 if (!vox.setup(a, position, lane)) continue;
-                const int src = __builtin_amdgcn_readfirstlane(j.source[t]);
+                if (verdict == 2) {
+                    vox.finish(a, -1.0f);
+                    continue;
+                }
                 const int g = src >> 6, c = src & 63;
                 const GroupInfo gi = j.groups[g];
                 /* what the tile above decided (and everything above it), and the min / max clauses its tape keeps: the group's
@@ -1102,6 +1110,7 @@ k_eval_voxels_gen(GenVoxelArgs j)
 }
 
 int voxel_gen_counter_ints() { return VG_LISTS * VG_COUNTER_STRIDE; }
+int voxel_gen_counter_lists() { return VG_LISTS; }
 int voxel_gen_grid(int dim, int cus)
 {
     int per_cu = 0;
@@ -1112,11 +1121,12 @@ int voxel_gen_grid(int dim, int cus)
 }
 void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const uint32_t* code, int grid, const int* source, const GroupInfo* groups,
                             const ulonglong2* choice_masks, int choice_cap, int* tile_counter, const unsigned long long* parent_records,
-                            int nchoices, int run, int* walked)
+                            int nchoices, int run, int* walked, const unsigned char* skip)
 {
     if (a.count <= 0) return;
     GenVoxelArgs j;
     j.walked = walked;
+    j.skip = skip;
     j.run = run > 0 ? run : VG_RUN;
     j.v = a;
     j.code = code;
@@ -1130,6 +1140,116 @@ void launch_eval_voxels_gen(hipStream_t s, int dim, const VoxelArgs& a, const ui
     const dim3 g(std::min(grid, a.count)), b(64);
     if (dim == 3) hipLaunchKernelGGL(k_eval_voxels_gen<3>, g, b, 0, s, j);
     else hipLaunchKernelGGL(k_eval_voxels_gen<2>, g, b, 0, s, j);
+}
+
+/* ---- the same pass by FOOTPRINT SEGMENTS (round 6; kernels.hip: k_compact_footprints) -----------------------------------
+ * A segment = the (up to four) surviving tiles over one 4 x 4 footprint of pixels inside one block of 64 siblings, nearest first.
+ * One wavefront walks them in that order and stops at the first hidden one; the group's record and masks are fetched once per
+ * segment.  v.tiles: the LAST TILE STAGE's list (an item's low 28 bits = block * 64 + footprint, the top 4 = which z). */
+struct FpVoxelArgs {
+    VoxelArgs v;
+    const uint32_t* code;
+    const unsigned* items;
+    const int* meta;                   /* [1] = number of segments */
+    const GroupInfo* groups;
+    const ulonglong2* choice_masks;
+    int choice_cap;
+    int* counter;                      /* VG_LISTS counters, VG_COUNTER_STRIDE ints apart, zero when the kernel starts */
+    const unsigned long long* parent_records;
+    int nchoices;
+    int run;                           /* consecutive segments a wavefront takes per atomic */
+    int* walked;                       /* development: += tiles walked (null: not counted) */
+    const unsigned char* skip;         /* GenVoxelArgs::skip */
+};
+template <int DIM>
+__global__ void __launch_bounds__(64, 6)
+k_eval_voxels_gen_fp(FpVoxelArgs j)
+{
+    const VoxelArgs& a = j.v;
+    const int lane = threadIdx.x;
+    const unsigned long long all = j.nchoices >= 64 ? ~0ull : ((1ull << j.nchoices) - 1ull);
+    const int run_len = j.run;
+    const int total = __builtin_amdgcn_readfirstlane(__hip_atomic_load(j.meta + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int nruns = (total + run_len - 1) / run_len;
+    int nwalked = 0;
+    for (int turn = 0; turn < VG_LISTS; ++turn) {
+        const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
+        const int list_runs = (nruns - list + VG_LISTS - 1) / VG_LISTS;
+        for (;;) {
+            int q = 0;
+            if (lane == 0) {
+                if (turn > 0 && __hip_atomic_load(j.counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= list_runs) q = list_runs;
+                else q = atomicAdd(j.counter + list * VG_COUNTER_STRIDE, 1);
+            }
+            const int run = __builtin_amdgcn_readfirstlane(q) * VG_LISTS + list;
+            if (run >= nruns) break;
+            for (int t = run * run_len; t < min(run * run_len + run_len, total); ++t) {
+                const uint32_t item = __builtin_amdgcn_readfirstlane(j.items[t]);
+                const int base = (int)(item & 0x0FFFFFFFu);
+                const uint32_t zbits = item >> 28;
+                const int g = base >> 6, f = base & 15;
+                const GroupInfo gi = j.groups[g];
+                unsigned long long L = 0, R = 0, K = all;
+                if (__builtin_amdgcn_readfirstlane(gi.tape) != 0) {
+                    const unsigned long long* const rec = j.parent_records + (size_t)__builtin_amdgcn_readfirstlane(gi.parent) * GEN_RECORD_U64;
+                    L = rfl64(rec[0]);
+                    R = rfl64(rec[1]);
+                    K = rfl64(rec[2]);
+                }
+                /* lane k: root clause k is the i-th clause the group's tape keeps; its mask's bit c = tile c's decision there */
+                const bool kept = (K >> lane) & 1ull;
+                const int i = __popcll(K & ((1ull << lane) - 1ull));
+                ulonglong2 mk = make_ulonglong2(0ull, 0ull);
+                if (kept && i < __builtin_amdgcn_readfirstlane(gi.nchoices)) mk = j.choice_masks[(size_t)g * j.choice_cap + i];
+                for (int z = 3; z >= 0; --z) {
+                    if (!((zbits >> z) & 1u)) continue;
+                    const int c = z * 16 + f, src = (base & ~63) + c;
+                    const int verdict = j.skip ? __builtin_amdgcn_readfirstlane((int)j.skip[src]) : 0;
+                    if (verdict == 1) continue;
+                    const int position = __builtin_amdgcn_readfirstlane(a.tiles[src].position);
+                    if (position < 0) continue;
+                    JitVoxel<DIM> vox;
+                    if (!vox.setup(a, position, lane)) break;               /* hidden: so is everything behind it */
+                    if (verdict == 2) {
+                        vox.finish(a, -1.0f);
+                        continue;
+                    }
+                    const uint64_t dl = L | ballot((mk.x >> c) & 1ull), dr = R | ballot((mk.y >> c) & 1ull);
+                    const float res = vox_gen_run(j.code, vox.vx, vox.vy, vox.vz, dl, dr);
+                    vox.finish(a, res);
+                    ++nwalked;
+                }
+            }
+        }
+    }
+    if (j.walked && lane == 0 && nwalked) atomicAdd(j.walked + (blockIdx.x & 31) * 32, nwalked);
+}
+int voxel_gen_fp_grid(int cus)
+{
+    int per_cu = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_voxels_gen_fp<3>, 64, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = 16;
+    return per_cu * cus;
+}
+void launch_eval_voxels_gen_fp(hipStream_t s, const VoxelArgs& a, const uint32_t* code, int grid, const unsigned* items, const int* meta, const GroupInfo* groups,
+                               const ulonglong2* choice_masks, int choice_cap, int* counter, const unsigned long long* parent_records, int nchoices, int run,
+                               int* walked, const unsigned char* skip)
+{
+    FpVoxelArgs j;
+    j.v = a;
+    j.code = code;
+    j.items = items;
+    j.meta = meta;
+    j.groups = groups;
+    j.choice_masks = choice_masks;
+    j.choice_cap = choice_cap;
+    j.counter = counter;
+    j.parent_records = parent_records;
+    j.nchoices = nchoices;
+    j.run = run > 0 ? run : 2;
+    j.walked = walked;
+    j.skip = skip;
+    hipLaunchKernelGGL(k_eval_voxels_gen_fp<3>, dim3(grid), dim3(64), 0, s, j);
 }
 
 /* one tape through the host-generated code: a and b in the x and y slots, the tile's decisions wave-uniform */

@@ -431,7 +431,7 @@ void launch_eval_tiles_wide(hipStream_t s, int dim, const WideStageArgs& w, int 
     int threads = (width >= 48) ? 256 : 64;
     /* a frame with no more tiles than compute units (256 at 1024^2): sixteen wavefronts per tile shorten
      * both the levels (one clause per thread) and the serial ranking / writing loops */
-    if (threads_forced > 0) threads = threads_forced;       /* MPR_WIDE_THREADS (development) */
+    if (threads_forced > 0) threads = threads_forced;       /* (development) */
     else if (width >= 192 && w.t.count <= 256) threads = 1024;
     else if (width >= 192 && w.t.count <= 1024) threads = 512;
     /* ... and with thousands of tiles and levels of moderate width two wavefronts per tile (twice the tiles in

@@ -22,7 +22,7 @@ T = np.eye(4, dtype=np.float32)
 T[3, 2] = 0.3
 T2 = np.eye(3, dtype=np.float32)
 settings = [{}, {"MPR_TILE_GEN_LOOSE": "0"}, {"MPR_TILE_GEN_LOOSE": "0", "MPR_TILE_GEN_GUARDS": "0"},
-            {"MPR_TILE_GEN_LOOSE": "0", "MPR_VOXEL_GEN": "0"}, {"MPR_TILE_GEN_LOOSE": "0", "MPR_NORMALS_GUARDS": "0"},
+            {"MPR_TILE_GEN_LOOSE": "0", "MPR_VOXEL_GEN": "0"},
             {"MPR_TILE_GEN_LOOSE": "0", "MPR_TILE_GEN_LAST": "0"}, {"MPR_TILE_GEN_LOOSE": "0", "MPR_SKIP_STAGE0": "0"},
             {"MPR_LAST_STAGE_PUSH": "1"}, {"MPR_LAST_STAGE_PUSH": "1", "MPR_VOXEL_GEN": "0"},
             {"MPR_LAST_STAGE_PUSH": "1", "MPR_VOXEL_GEN": "0", "MPR_VOXEL_GROUPS": "0"},

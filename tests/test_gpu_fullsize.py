@@ -34,8 +34,8 @@ def test_bear_1024_full_frame(mpr, orc, tapes):
     assert (ref.image > 0).sum() > 300000
     assert cnt["voxel_tiles"] > 500000
     kinds = check_default_path(mpr, ref, tapes("bear"), 3, 1024, view3())
-    # the root tape's host-generated float walk with the tiles' decisions as bits; no tapes from the last tile stage
-    assert all(k[0] == "k_eval_voxels_gen<3>" for k in kinds) and [k[1] for k in kinds] == [False, False, False], kinds
+    # the root tape's host-generated float walk with the tiles' decisions as bits, by footprint segments (round 6); no tapes from the last tile stage
+    assert all(k[0] == "k_eval_voxels_gen_fp<3>" for k in kinds) and [k[1] for k in kinds] == [False, False, False], kinds
 
 
 def test_architecture_2048_full_frame(mpr, orc, tapes):

@@ -333,11 +333,22 @@ def test_float_pass_on_the_root_tapes_host_generated_code(mpr, orc, tapes, name,
     dead clause (=1), and as the device-translated group form gives them (MPR_VOXEL_GEN=0)."""
     tape = tapes(name)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
-    ctxs = [(mpr.Context(S), "k_eval_voxels_gen<3>")]
+    # (round 6: by footprint segments — k_eval_voxels_gen_fp: the tiles over one 4 x 4 footprint inside a block of siblings in one
+    # wavefront, nearest first, until one is hidden — unless MPR_VOXEL_FP=0: tile by tile down a z-sorted list, round 3's kernel)
+    ctxs = [(mpr.Context(S), "k_eval_voxels_gen_fp<3>")]
+    monkeypatch.setenv("MPR_VOXEL_FP", "0")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen<3>"))
     monkeypatch.setenv("MPR_VOXEL_GEN_RUN", "0")
     ctxs.append((mpr.Context(S), "k_eval_voxels_gen<3>"))
+    monkeypatch.delenv("MPR_VOXEL_FP")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen_fp<3>"))
     monkeypatch.setenv("MPR_VOXEL_GEN_RUN", "1")
-    ctxs.append((mpr.Context(S), "k_eval_voxels_gen<3>"))
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen_fp<3>"))
+    monkeypatch.setenv("MPR_VOXEL_GEN_TILES", "1")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen_fp<3>"))
+    monkeypatch.setenv("MPR_VOXEL_GEN_TILES", "7")
+    ctxs.append((mpr.Context(S), "k_eval_voxels_gen_fp<3>"))
+    monkeypatch.delenv("MPR_VOXEL_GEN_TILES")
     monkeypatch.delenv("MPR_VOXEL_GEN_RUN")
     monkeypatch.setenv("MPR_VOXEL_GEN", "0")
     monkeypatch.setenv("MPR_VOXEL_GROUPS", "2")    # (without the host's code the group form is the faster one only up to 1.4x shortening: trig's sample says 1.5 - 1.9)
@@ -445,7 +456,7 @@ def test_first_stage_that_leaves_records_and_no_tapes(mpr, orc, tapes, monkeypat
         ctx.render3D(tape, view3())
         assert np.array_equal(ctx.image, ref.filled[3]) and np.array_equal(ctx.normals, ref.normals), k
         kinds.append("+fwdonly" in ctx.tile_stage_forms().split()[0])
-        assert ctx.tile_stage_forms().startswith("1:gen") and ctx.float_kernel() == "k_eval_voxels_gen<3>" and ctx.normals_kernel() == "k_eval_normals_gen"
+        assert ctx.tile_stage_forms().startswith("1:gen") and ctx.float_kernel() == "k_eval_voxels_gen_fp<3>" and ctx.normals_kernel() == "k_eval_normals_gen"
     # (the very first frame of a fresh context may start over — its pool grows — and then already knows the hint)
     first = kinds.index(True)
     assert first <= 1 and kinds[first:first + 31] == [True] * 31 and kinds[first + 31] is False and kinds[first + 32:] == [True] * (35 - first - 31), kinds
@@ -550,7 +561,7 @@ def test_frames_without_last_stage_tapes(mpr, orc, tapes, name, S, monkeypatch):
         bad = np.flatnonzero(ctx.normals.ravel() != ref.normals.ravel())
         assert bad.size == 0, (bad.size, kinds, [(hex(ctx.normals.ravel()[i]), hex(ref.normals.ravel()[i])) for i in bad[:5]])
     if name == "bear":
-        assert kinds == [(False, "k_eval_voxels_gen")] * 4, kinds                  # no tapes from the very first frame
+        assert kinds == [(False, "k_eval_voxels_gen_fp")] * 4, kinds                  # no tapes from the very first frame
     if name == "involute_gear_3d":
         assert all(k == (True, "k_eval_voxels_asm") for k in kinds), kinds         # per-tile tapes: measured by the first frame, known after
     # the reference's state on request: tiles and tapes as a frame rendered the reference's way leaves them
@@ -676,7 +687,7 @@ def test_readers_tapes_on_chains_of_generated_stages_match_the_oracle(mpr, orc, 
     if how == "always":
         assert ctx.normals_kernel() == ("k_eval_normals_gen" if chain == "1" else "k_eval_normals_asm"), ctx.normals_kernel()
     elif chain == "1" or ctx.skip0_vetoes() == 0:
-        assert ctx.normals_kernel() == "k_eval_normals_gen" and ctx.float_kernel() == "k_eval_voxels_gen<3>", (ctx.normals_kernel(), ctx.float_kernel())
+        assert ctx.normals_kernel() == "k_eval_normals_gen" and ctx.float_kernel() == "k_eval_voxels_gen_fp<3>", (ctx.normals_kernel(), ctx.float_kernel())
     else:
         # (bear at 256^3: the frame's start at the 16^3 tiles fails its verification against the 64^3 ones, the frames start there —
         # and without the chain of records the stages below the first one, and the passes behind them, are the interpreters')

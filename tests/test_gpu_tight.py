@@ -104,11 +104,20 @@ def test_tiles_the_float_pass_walks(mpr, orc, tapes, name, S, monkeypatch):
     for k in range(4):
         ctx.render3D(tape, view3())
         assert np.array_equal(ctx.image, ref.image) and np.array_equal(ctx.normals, ref.normals), k
-    assert ctx.float_kernel() == "k_eval_voxels_gen<3>"
-    listed, walked = ctx.frame_tiles()[2], ctx.tiles_walked()
-    assert 0 < walked <= listed < ref.counters["voxel_tiles"], (walked, listed, ref.counters["voxel_tiles"])
-    print("%s %d: the reference lists %d tiles, the second verdict leaves %d, %d walked" % (name, S, ref.counters["voxel_tiles"], listed, walked))
+    monkeypatch.setenv("MPR_VOXEL_FP", "0")
+    old = mpr.Context(S)
+    for k in range(4):
+        old.render3D(tape, view3())
+        assert np.array_equal(old.image, ref.image) and np.array_equal(old.normals, ref.normals), k
+    assert ctx.float_kernel() == "k_eval_voxels_gen_fp<3>" and old.float_kernel() == "k_eval_voxels_gen<3>"
+    listed, walked, walked_old = ctx.frame_tiles()[2], ctx.tiles_walked(), old.tiles_walked()
+    assert listed == old.frame_tiles()[2]
+    # by footprint segments no more tiles are walked than tile by tile in z order (a tile behind a surface waits for the one in front)
+    assert 0 < walked <= walked_old * 1.02 <= listed * 1.02 and listed < ref.counters["voxel_tiles"], (walked, walked_old, listed, ref.counters["voxel_tiles"])
+    print("%s %d: the reference lists %d tiles, the second verdict leaves %d; %d walked by segments, %d tile by tile" % (
+        name, S, ref.counters["voxel_tiles"], listed, walked, walked_old))
     ctx.close()
+    old.close()
 
 
 @pytest.mark.parametrize("seed,size", [(41777, 3), (48461, 8), (48813, 3), (50609, 3), (52835, 3)])
@@ -128,3 +137,45 @@ def test_filled_tiles_of_the_bottom_layer_stay_with_the_float_pass(mpr, orc, see
         assert "+tight" in forms, forms
         assert np.array_equal(image, ref.image), (forms, int((image != ref.image).sum()))
         assert np.array_equal(normals, ref.normals), (forms, int((normals != ref.normals).sum()))
+
+
+@pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("trig_blend", 256)])
+def test_frames_that_leave_the_references_tiles_and_tapes_take_the_second_verdict_in_a_launch_of_its_own(mpr, orc, tapes, name, S, monkeypatch):
+    """MPR_LAST_STAGE_PUSH=1 (bench.py: full_frames): every stage from the 64^3 tiles down on the reference's enclosures, every tape
+    pushed, the float pass over the reference's list of smallest tiles.  Behind the last stage the tight code runs once more
+    (TileStageArgs::verdict_only: '+verdict'): the lists, tapes and records stay the reference's — what a reader gets is held against
+    the oracle tile by tile and tape by tape — and the tiles the second verdict decides are not walked by the float pass."""
+    from helpers import active_positions
+    tape = tapes(name)
+    ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
+    monkeypatch.setenv("MPR_LAST_STAGE_PUSH", "1")
+    monkeypatch.setenv("MPR_DEBUG_WALKED", "1")
+    ctx = mpr.Context(S)
+    monkeypatch.setenv("MPR_TILE_TIGHT", "0")
+    plain = mpr.Context(S)
+    for k in range(3):
+        for c in (ctx, plain):
+            c.render3D(tape, view3())
+            assert np.array_equal(c.image, ref.image), (k, c.tile_stage_forms(), int((c.image != ref.image).sum()))
+            assert np.array_equal(c.normals, ref.normals), (k, c.tile_stage_forms(), int((c.normals != ref.normals).sum()))
+    assert ctx.tile_stage_forms().endswith("+verdict") and "+verdict" not in plain.tile_stage_forms(), (ctx.tile_stage_forms(), plain.tile_stage_forms())
+    assert ctx.float_kernel() == plain.float_kernel() == "k_eval_voxels_gen_fp<3>"
+    assert ctx.frame_tiles()[2] == plain.frame_tiles()[2] == ref.counters["voxel_tiles"]         # the reference's list
+    assert 0 < ctx.tiles_walked() < 0.9 * plain.tiles_walked(), (ctx.tiles_walked(), plain.tiles_walked())
+    # the frame's tiles and tapes as it left them (no second rendering: the context's frames are the reference's way already)
+    assert ctx.last_stage_pushed()
+    pool = ctx.tape_data
+    for s in (0, 1, 2):
+        g_next, r_next = ctx.stages[s + 1].tiles, ref.tiles[s + 1]
+        assert g_next.size == r_next.size, s
+        g_live, r_live = g_next[g_next["position"] != -1], r_next[r_next["position"] != -1]
+        go, ro = np.argsort(g_live["position"]), np.argsort(r_live["position"])
+        assert np.array_equal(g_live["position"][go], r_live["position"][ro]), "survivor sets differ after stage %d" % s
+        if g_live.size:
+            glen, ghash = orc.tiles_digest(pool, g_live[go])
+            rlen, rhash = orc.tiles_digest(ref.pool, r_live[ro])
+            assert np.array_equal(glen, rlen) and np.array_equal(ghash, rhash), "shortened tapes differ after stage %d" % s
+    for s in (0, 1, 2, 3):
+        assert np.array_equal(ctx.stages[s].filled, ref.filled[s]), "filled image of stage %d differs" % s
+    ctx.close()
+    plain.close()
