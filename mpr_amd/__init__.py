@@ -87,6 +87,28 @@ def build(force=False):
     return LIB_PATH
 
 
+TEST_LIB_PATH = os.environ.get("MPR_AMD_TEST_LIB", os.path.join(_HERE, "libmpr_amd_test.so"))
+
+
+class _Libs:
+    """libmpr_amd.so — and, for the entry points of include/mpr_amd_test.h (`mpr_test_*`, `mpr_debug_*`: single primitives and code
+    generators for the parity suite, development counters), libmpr_amd_test.so: the same sources compiled with those entry points
+    in (round 6: the product library exports none of them).  Loaded on first use."""
+
+    def __init__(self, product):
+        object.__setattr__(self, "_product", product)
+        object.__setattr__(self, "_test", None)
+
+    def __getattr__(self, name):
+        if name.startswith("mpr_test_") or name.startswith("mpr_debug_"):
+            if self._test is None:
+                if not os.path.exists(TEST_LIB_PATH):
+                    raise MprError("libmpr_amd_test.so is missing: run mpr_amd.build()")
+                object.__setattr__(self, "_test", ctypes.CDLL(TEST_LIB_PATH))
+            return getattr(self._test, name)
+        return getattr(self._product, name)
+
+
 def lib():
     """Load libmpr_amd.so; raises MprError when it has not been built."""
     global _LIB
@@ -103,7 +125,7 @@ def lib():
             import torch  # noqa: F401
         except Exception:
             pass
-    L = ctypes.CDLL(LIB_PATH)
+    L = _Libs(ctypes.CDLL(LIB_PATH))
     vp, i32, f32, P = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.POINTER
     L.mpr_last_error.restype = ctypes.c_char_p
     L.mpr_version.restype = ctypes.c_char_p

@@ -2055,6 +2055,7 @@ int mpr_ctx_paranoid_stats(const mpr_context* c, int64_t out[3])
 }
 int32_t mpr_ctx_last_stage_pushed(const mpr_context* c) { return c ? (c->last_frame_lean ? 0 : 1) : 0; }
 int64_t mpr_ctx_skip0_vetoes(const mpr_context* c) { return c ? c->skip0_vetoes : 0; }
+#ifdef MPR_TEST_HOOKS
 /* development (MPR_DEBUG_REDO=1): wavefronts that ran a scheduled forward walk since the context was made, and how many of them had
  * their loose walk redone on the exact code */
 /* development: {capacity of the tape pool in clauses, times it grew, frames that started over, frames whose start at the 16^3 tiles
@@ -2081,6 +2082,7 @@ extern "C" int mpr_debug_redo_counts(mpr_context* c, uint32_t out[2])
     out[1] = h[1];
     return MPR_OK;
 }
+#endif  /* MPR_TEST_HOOKS */
 const char* mpr_ctx_tile_stage_forms(const mpr_context* c) { return c ? c->stage_forms.c_str() : ""; }
 /* tiles of the last frame AS IT RAN (no re-render: a frame nobody reads may start at the 16^3 tiles and cull with looser bounds than
  * the reference): per stage the tiles evaluated and the tiles left ambiguous, then the smallest tiles handed to the float pass */
@@ -2097,6 +2099,7 @@ int mpr_ctx_frame_tiles(mpr_context* c, int64_t out[7])
     return MPR_OK;
 }
 
+#ifdef MPR_TEST_HOOKS
 /* development (MPR_DEBUG_WALKED=1 when the context was made): tiles the last frame's float pass on the root tape's code walked; -1: not counted */
 extern "C" long long mpr_debug_tiles_walked(mpr_context* c)
 {
@@ -2108,6 +2111,7 @@ extern "C" long long mpr_debug_tiles_walked(mpr_context* c)
     for (int i = 0; i < 1024; ++i) n += host[i];
     return n;
 }
+#endif  /* MPR_TEST_HOOKS */
 
 int mpr_ctx_sync(mpr_context* c)
 {
@@ -2513,6 +2517,7 @@ int mpr_get_timings(mpr_context* c, const char** names, float* ms, int32_t cap, 
     return MPR_OK;
 }
 
+#ifdef MPR_TEST_HOOKS
 /* ---- primitive self-tests ---- */
 namespace {
 struct DevBuf {
@@ -2909,4 +2914,5 @@ int mpr_test_deriv_op(int32_t device, int32_t op, int32_t n, const float* a4, co
     return MPR_OK;
 }
 
+#endif  /* MPR_TEST_HOOKS */
 }  // extern "C"

@@ -1317,6 +1317,7 @@ IntervalCode interval_gen_build(const uint64_t* cl, int len, int kind, bool loos
 
 }  // namespace mpr
 
+#ifdef MPR_TEST_HOOKS
 /* test entry: the code's words and, line by line, its assembler text (lines separated by '\n' in text_out) */
 extern "C" int mpr_test_interval_gen(const uint64_t* clauses, int32_t len, int32_t kind, int32_t loose, int32_t window, int32_t min_run,
                                      uint32_t* out, int32_t cap, char* text_out, int32_t text_cap, int32_t* info)
@@ -1338,3 +1339,4 @@ extern "C" int mpr_test_interval_gen(const uint64_t* clauses, int32_t len, int32
     }
     return (int)g.words.size();
 }
+#endif  /* MPR_TEST_HOOKS */

@@ -1123,6 +1123,8 @@ k_zs_scatter(mpr_tile_node* __restrict__ tiles, int count, int tps, int* __restr
 /* meta: [0] segments appended so far, [1] = the total, set (and [0] cleared) by the last workgroup; clear: the float   */
 /* pass's work counters, zeroed by it too.                                                                              */
 /* ------------------------------------------------------------------------------------ */
+constexpr int FP_CHUNKS = 8;            /* chunks of 1024 tiles a workgroup of k_compact_footprints takes: three atomics per 8192 tiles (same-address atomics
+                                         * take ~9 ns each, one after the other: per 1024 tiles they were two thirds of the kernel's 32 us) */
 __global__ void __launch_bounds__(1024)
 k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ num_active,
                      unsigned* __restrict__ items, int* __restrict__ meta, int* __restrict__ clear, int nclear, int cstride, int* __restrict__ pub, int seq,
@@ -1132,46 +1134,57 @@ k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, cons
         copy_filled_block<3>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
         return;
     }
-    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool valid = gidx < count;
-    int position = -1;
-    if (valid) position = tiles[gidx].position;
-    bool active = valid && position != -1;
-    if (active) {
-        const int4_ p = unpack(position, tps);
-        if (image[p.w] > p.z) {
-            active = false;
-            tiles[gidx].position = -1;
-        }
-    }
-    if (valid) tiles[gidx].next = -1;             /* copy_active_tiles resets next (:650) */
-    const uint64_t mask = ballot(active);
-    const uint32_t m16 = (uint32_t)((mask | (mask >> 16) | (mask >> 32) | (mask >> 48)) & 0xFFFFull);
-    __shared__ int wave_tiles[16], wave_items[16], wave_base[16];
     const int wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        wave_tiles[wave] = __popcll(mask);
-        wave_items[wave] = __popc(m16);
+    __shared__ int wave_tiles[16], wave_items[FP_CHUNKS][16], wave_base[FP_CHUNKS][16];
+    uint64_t masks[FP_CHUNKS];
+    int tiles_mine = 0;
+#pragma unroll
+    for (int k = 0; k < FP_CHUNKS; ++k) {
+        const int gidx = (blockIdx.x * FP_CHUNKS + k) * 1024 + (int)threadIdx.x;
+        const bool valid = gidx < count;
+        int position = -1;
+        if (valid) position = tiles[gidx].position;
+        bool active = valid && position != -1;
+        if (active) {
+            const int4_ p = unpack(position, tps);
+            if (image[p.w] > p.z) {
+                active = false;
+                tiles[gidx].position = -1;
+            }
+        }
+        if (valid) tiles[gidx].next = -1;         /* copy_active_tiles resets next (:650) */
+        masks[k] = ballot(active);
+        const uint32_t m16 = (uint32_t)((masks[k] | (masks[k] >> 16) | (masks[k] >> 32) | (masks[k] >> 48)) & 0xFFFFull);
+        tiles_mine += __popcll(masks[k]);
+        if (lane == 0) wave_items[k][wave] = __popc(m16);
     }
+    if (lane == 0) wave_tiles[wave] = tiles_mine;
     __syncthreads();
     if (threadIdx.x == 0) {
         int tiles_total = 0, items_total = 0;
-        const int nw = (blockDim.x + 63) >> 6;
-        for (int w = 0; w < nw; ++w) {
-            wave_base[w] = items_total;
-            items_total += wave_items[w];
-            tiles_total += wave_tiles[w];
-        }
+        for (int w = 0; w < 16; ++w) tiles_total += wave_tiles[w];
+        for (int k = 0; k < FP_CHUNKS; ++k)
+            for (int w = 0; w < 16; ++w) {
+                wave_base[k][w] = items_total;
+                items_total += wave_items[k][w];
+            }
         if (tiles_total) atomicAdd(num_active, tiles_total);
         const int b0 = items_total ? atomicAdd(meta, items_total) : 0;
-        for (int w = 0; w < nw; ++w) wave_base[w] += b0;
+        for (int k = 0; k < FP_CHUNKS; ++k)
+            for (int w = 0; w < 16; ++w) wave_base[k][w] += b0;
     }
     __syncthreads();
-    if (lane < 16 && ((m16 >> lane) & 1u)) {
-        const uint32_t zbits = (uint32_t)((mask >> lane) & 1ull) | (uint32_t)((mask >> (lane + 16)) & 1ull) << 1 |
-                               (uint32_t)((mask >> (lane + 32)) & 1ull) << 2 | (uint32_t)((mask >> (lane + 48)) & 1ull) << 3;
-        items[wave_base[wave] + __popc(m16 & ((1u << lane) - 1u))] = (uint32_t)gidx | zbits << 28;       /* gidx = block * 64 + footprint */
+#pragma unroll
+    for (int k = 0; k < FP_CHUNKS; ++k) {
+        const uint64_t mask = masks[k];
+        const uint32_t m16 = (uint32_t)((mask | (mask >> 16) | (mask >> 32) | (mask >> 48)) & 0xFFFFull);
+        if (lane < 16 && ((m16 >> lane) & 1u)) {
+            const int gidx = (blockIdx.x * FP_CHUNKS + k) * 1024 + (int)threadIdx.x;
+            const uint32_t zbits = (uint32_t)((mask >> lane) & 1ull) | (uint32_t)((mask >> (lane + 16)) & 1ull) << 1 |
+                                   (uint32_t)((mask >> (lane + 32)) & 1ull) << 2 | (uint32_t)((mask >> (lane + 48)) & 1ull) << 3;
+            items[wave_base[k][wave] + __popc(m16 & ((1u << lane) - 1u))] = (uint32_t)gidx | zbits << 28;       /* gidx = block * 64 + footprint */
+        }
     }
     if (threadIdx.x == 0) {
         /* the last workgroup through here has every count (k_compact_subdivide: no fence needed, its own additions have returned) */
@@ -1264,6 +1277,7 @@ __global__ void k_unpack_planned(int* __restrict__ heights, uint32_t* __restrict
     if (with_normals) normals[x + y * S] = (uint32_t)in_all[(size_t)capacity * 4096 + src];
 }
 
+#ifdef MPR_TEST_HOOKS
 /* ------------------------------------------------------------------------------------ */
 /* primitive test kernels (parity fuzzing against the oracle)                            */
 /* ------------------------------------------------------------------------------------ */
@@ -1634,6 +1648,7 @@ __global__ void k_test_deriv(int op, int n, const float4* a, const float4* b, fl
     }
 }
 
+#endif  /* MPR_TEST_HOOKS */
 /* ---- frames that start at the 16^3 tiles: the 64^3 tiles they skip, walked beside the frame (kernels.hpp) ---- */
 __global__ void __launch_bounds__(64, 4)
 k_skip0_parents(Skip0ParentsArgs a)
@@ -1928,7 +1943,7 @@ bool zsort_supported(int tps) { return tps <= ZS_MAX_BINS; }
 void launch_compact_footprints(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, int* num_active, unsigned* items, int* meta,
                                int* clear, int nclear, int cstride, int* pub, int seq, int* next_image, int next_size, const unsigned long long* tape_index)
 {
-    const unsigned blocks = (unsigned)((count + 1023) / 1024);
+    const unsigned blocks = (unsigned)((count + 1024 * FP_CHUNKS - 1) / (1024 * FP_CHUNKS));
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)blocks, &extra);
     hipLaunchKernelGGL(k_compact_footprints, dim3(blocks + extra), dim3(1024), 0, s, tiles, count, tps, image, num_active, items, meta, clear, nclear, cstride, pub, seq, cf,
@@ -1979,6 +1994,7 @@ void launch_unpack(hipStream_t s, int* heights, uint32_t* normals, int S, const 
     hipLaunchKernelGGL(k_unpack_columns, dim3(64, ncols), dim3(64), 0, s, heights, normals, S, col_list, ncols,
                        capacity, with_normals, in);
 }
+#ifdef MPR_TEST_HOOKS
 void launch_test_interval(hipStream_t s, int op, int n, const float* a_lo, const float* a_hi, const float* b_lo,
                           const float* b_hi, float imm, float* out_lo, float* out_hi, int* choice)
 {
@@ -2005,4 +2021,5 @@ void launch_test_deriv(hipStream_t s, int op, int n, const float* a, const float
                        (const float4*)b, imm, (float4*)out);
 }
 
+#endif  /* MPR_TEST_HOOKS */
 }  // namespace mprk

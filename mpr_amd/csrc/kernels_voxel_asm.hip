@@ -500,6 +500,7 @@ k_eval_voxels_asm(VoxelArgs a)
     }
 }
 
+#ifdef MPR_TEST_HOOKS
 /* one clause through the assembly interpreter: tape3 = {head (x,y,z in slots 1,2,3), the clause
  * (lhs = slot 1, rhs = slot 2, out = slot 4), end (result slot 4)} */
 __global__ void __launch_bounds__(64)
@@ -554,6 +555,7 @@ void launch_test_sqrt_all(hipStream_t s, unsigned long long first, unsigned long
     hipLaunchKernelGGL(k_test_sqrt_all, dim3(4096), dim3(256), 0, s, first, count, out);
 }
 
+#endif  /* MPR_TEST_HOOKS */
 size_t voxel_asm_lds_bytes(int nslots) { return (size_t)nslots * 256; }
 void launch_eval_voxels_asm(hipStream_t s, int dim, const VoxelArgs& a)
 {

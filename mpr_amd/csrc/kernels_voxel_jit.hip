@@ -1252,6 +1252,7 @@ void launch_eval_voxels_gen_fp(hipStream_t s, const VoxelArgs& a, const uint32_t
     hipLaunchKernelGGL(k_eval_voxels_gen_fp<3>, dim3(grid), dim3(64), 0, s, j);
 }
 
+#ifdef MPR_TEST_HOOKS
 /* one tape through the host-generated code: a and b in the x and y slots, the tile's decisions wave-uniform */
 __global__ void __launch_bounds__(64)
 k_test_float_gen(const uint32_t* code, int n, const float* a, const float* b, float* out, unsigned long long dl, unsigned long long dr)
@@ -1311,6 +1312,7 @@ void launch_test_float_jit(hipStream_t s, const uint64_t* tape3, uint32_t* code,
     hipLaunchKernelGGL(k_test_float_jit, dim3((n + 63) / 64), dim3(64), 0, s, tape3, code, region_dwords, n, a, b, out);
 }
 
+#endif  /* MPR_TEST_HOOKS */
 int jit_max_choices() { return jt::JIT_MAX_CHOICES; }
 int jit_slot_class(int nslots)
 {
@@ -1379,6 +1381,7 @@ void launch_eval_voxels_jit(hipStream_t s, int dim, const VoxelArgs& a, uint32_t
 
 }  // namespace mprk
 
+#ifdef MPR_TEST_HOOKS
 /* What the translator makes of one clause (host restatement of its `dword = T + (T & mask) + base`, for the test that
  * disassembles the rows): table 0 tile form, 1 group form; row = the opcode, 30 (division by a constant), or 32.. */
 extern "C" int mpr_test_jit_row(int32_t table, int32_t row, uint32_t clause_lo, uint32_t imm_bits, int32_t choice, uint32_t* out, int32_t cap)
@@ -1404,3 +1407,4 @@ extern "C" int mpr_test_jit_row(int32_t table, int32_t row, uint32_t clause_lo, 
     return n;
 }
 
+#endif  /* MPR_TEST_HOOKS */

@@ -626,6 +626,7 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
 }
 }  // namespace mpr
 
+#ifdef MPR_TEST_HOOKS
 extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t which, uint32_t* out, int32_t cap)
 {
     if (which == 6) {                    /* the backward walk for tapes of up to 96 slots (tile_gen_build_big_backward) */
@@ -642,3 +643,4 @@ extern "C" int mpr_test_tile_gen(const uint64_t* clauses, int32_t len, int32_t w
         for (size_t i = 0; i < c.size(); ++i) out[i] = c[i];
     return (int)c.size();
 }
+#endif  /* MPR_TEST_HOOKS */

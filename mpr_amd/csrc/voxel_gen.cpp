@@ -456,6 +456,7 @@ VoxelGen voxel_gen_build(const uint64_t* clauses, int len, int min_run)
 
 }  // namespace mpr
 
+#ifdef MPR_TEST_HOOKS
 extern "C" int mpr_test_voxel_gen(const uint64_t* clauses, int32_t len, int32_t min_run, uint32_t* out, int32_t cap, int32_t* info)
 {
     const mpr::VoxelGen g = mpr::voxel_gen_build(clauses, len, min_run);
@@ -469,3 +470,4 @@ extern "C" int mpr_test_voxel_gen(const uint64_t* clauses, int32_t len, int32_t 
         for (size_t i = 0; i < g.code.size(); ++i) out[i] = g.code[i];
     return (int)g.code.size();
 }
+#endif  /* MPR_TEST_HOOKS */

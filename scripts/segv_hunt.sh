@@ -22,4 +22,12 @@ for r in $(seq 1 $ROUNDS); do
   wait
   echo "== $LEG round $r: $(grep -l '^seeds' $OUT/${LEG}_r${r}_part_*.log | wc -l) of 12 processes finished; $(grep -h '^seeds' $OUT/${LEG}_r${r}_part_*.log | awk '{s+=$6} END {print s}') frames differ"
   grep -l "Fatal Python error\|Segmentation\|AddressSanitizer\|Traceback" $OUT/${LEG}_r${r}_part_*.log | while read f; do echo "--- $f"; grep -n -A25 "Fatal Python error\|AddressSanitizer\|Traceback" $f | head -60; done
+  # a core file (core_pattern "core": the repository's root): the C-level stack of every thread
+  for c in core core.*; do
+    [ -f "$c" ] || continue
+    echo "--- $c"
+    timeout 300 /opt/rocm/bin/rocgdb -batch -ex "bt 60" -ex "thread apply all bt 12" $(which python) $c 2>&1 | grep -v "^\[New LWP\|^warning\|^Reading\|^Download" | head -220 | tee $OUT/${LEG}_r${r}_core_bt.txt
+    rm -f core core.*
+    break
+  done
 done

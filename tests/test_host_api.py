@@ -10,9 +10,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
+def declared_functions(headers=("mpr_amd.h", "mpr_clause.h")):
     names = set()
-    for hdr in ("mpr_amd.h", "mpr_amd_test.h", "mpr_clause.h"):
+    for hdr in headers:
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         for m in re.finditer(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(mpr_[a-z0-9_]+)\s*\(", text, flags=re.M):
@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol(mpr):
     assert len(names) > 40
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_test_hooks_live_in_their_own_library(mpr):
+    """The parity suite's single primitives and code generators and the development counters (include/mpr_amd_test.h) are entry points
+    of libmpr_amd_test.so — the same sources compiled with -DMPR_TEST_HOOKS — and of that library only (round 6): the product
+    library exports no mpr_test_* / mpr_debug_* symbol; the test library exports the boundary as well (it is the product plus hooks)."""
+    product, test = ctypes.CDLL(mpr.LIB_PATH), ctypes.CDLL(mpr.TEST_LIB_PATH)
+    hooks = declared_functions(("mpr_amd_test.h",))
+    assert len(hooks) >= 20 and all(n.startswith("mpr_test_") or n.startswith("mpr_debug_") for n in hooks), hooks
+    assert not [n for n in hooks if not hasattr(test, n)]
+    assert not [n for n in hooks if hasattr(product, n)]
+    assert not [n for n in declared_functions() if not hasattr(test, n)]
 
 
 def test_no_gpu_fails_loudly(mpr):
