@@ -15,13 +15,20 @@ if [ "$LEG" = asan ]; then
   export LD_PRELOAD=$(gcc -print-file-name=libasan.so)
   export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
 fi
+if [ "$LEG" = hostasan ]; then
+  # the LIBRARY's host side instrumented (make -C mpr_amd/csrc asan: libmpr_amd_asan.so; device code as it is), clang's runtime preloaded
+  make -s -j8 -C mpr_amd/csrc asan || exit 1
+  export MPR_AMD_LIB=$PWD/mpr_amd/libmpr_amd_asan.so
+  export LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
+fi
 for r in $(seq 1 $ROUNDS); do
   for i in $(seq 0 11); do
     python scripts/fuzz_sweep.py $((1000 + i * 170)) 170 16 > $OUT/${LEG}_r${r}_part_$i.log 2>&1 &
   done
   wait
   echo "== $LEG round $r: $(grep -l '^seeds' $OUT/${LEG}_r${r}_part_*.log | wc -l) of 12 processes finished; $(grep -h '^seeds' $OUT/${LEG}_r${r}_part_*.log | awk '{s+=$6} END {print s}') frames differ"
-  grep -l "Fatal Python error\|Segmentation\|AddressSanitizer\|Traceback" $OUT/${LEG}_r${r}_part_*.log | while read f; do echo "--- $f"; grep -n -A25 "Fatal Python error\|AddressSanitizer\|Traceback" $f | head -60; done
+  grep -l "Fatal Python error\|Segmentation\|AddressSanitizer\|Traceback" $OUT/${LEG}_r${r}_part_*.log | while read f; do echo "--- $f"; grep -n -A45 "Fatal Python error\|AddressSanitizer\|Traceback" $f | cut -c1-200 | head -120; done
   # a core file (core_pattern "core": the repository's root): the C-level stack of every thread
   for c in core core.*; do
     [ -f "$c" ] || continue

@@ -25,6 +25,12 @@ def random_view3(rng):
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+# HUNT_CHURN=1: what the oracle did to the process besides computing — large host buffers allocated, written and freed every iteration
+# (its frame, pool and images copied out), and an OpenMP team of 16 that has run (torch's CPU kernels use libgomp as the oracle does)
+CHURN = os.environ.get("HUNT_CHURN") == "1"
+if CHURN:
+    import torch
+    torch.set_num_threads(16)
 T = np.eye(4, dtype=np.float32); T[3, 2] = 0.3
 T2 = np.eye(3, dtype=np.float32)
 n = 0
@@ -35,10 +41,18 @@ for r in range(rounds):
             rng = np.random.default_rng(seed * 7 + size)
             S = int(rng.choice([128, 256]))
             view = T if rng.random() < 0.6 else random_view3(rng)
+            if CHURN:
+                bufs = [np.full(int(rng.integers(1, 40)) << 20, 7, dtype=np.uint8) for _ in range(4)]
+                a = torch.rand(256, 256)
+                (a @ a).sum().item()
+                del bufs
             ctx = mpr.Context(S)
             for k in range(3):
                 ctx.render3D(tape, view)
             ctx.close()
+            if CHURN:
+                bufs = [np.full(int(rng.integers(1, 40)) << 20, 9, dtype=np.uint8) for _ in range(2)]
+                del bufs
             ctx = mpr.Context(256)
             for k in range(2):
                 ctx.render2D(tape, T2, 0.1)

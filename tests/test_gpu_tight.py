@@ -179,3 +179,20 @@ def test_frames_that_leave_the_references_tiles_and_tapes_take_the_second_verdic
         assert np.array_equal(ctx.stages[s].filled, ref.filled[s]), "filled image of stage %d differs" % s
     ctx.close()
     plain.close()
+
+
+@pytest.mark.parametrize("switch,absent", [("MPR_TILE_GEN_GUARDS", "+guards"), ("MPR_TILE_GEN_LEAN", "+lean")])
+def test_last_stage_without_guards_and_in_the_128_register_kernel(mpr, orc, tapes, switch, absent, monkeypatch):
+    """The two switches of the loose last stage that had no test of their own: the forward walk that does not jump
+    over what the parent's decisions left dead, and the loose stage in the ordinary kernel (four wavefronts per SIMD, no second
+    verdict: that rides in the lean kernel).  The oracle's heights and normals either way."""
+    tape = tapes("bear")
+    ref = orc.Frame(tape.data, 3, 256, mpr.colmajor(view3(), 4), threads=0, keep_pool=False)
+    monkeypatch.setenv(switch, "0")
+    ctx = mpr.Context(256)
+    for k in range(3):
+        ctx.render3D(tape, view3())
+        assert np.array_equal(ctx.image, ref.image) and np.array_equal(ctx.normals, ref.normals), (switch, k, ctx.tile_stage_forms())
+    last = ctx.tile_stage_forms().split()[-1]
+    assert absent not in last and "+loose" in last, ctx.tile_stage_forms()
+    ctx.close()
