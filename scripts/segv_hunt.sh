@@ -19,7 +19,11 @@ if [ "$LEG" = hostasan ]; then
   # the LIBRARY's host side instrumented (make -C mpr_amd/csrc asan: libmpr_amd_asan.so; device code as it is), clang's runtime preloaded
   make -s -j8 -C mpr_amd/csrc asan || exit 1
   export MPR_AMD_LIB=$PWD/mpr_amd/libmpr_amd_asan.so
-  export LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+  # (ROCm's own sanitizer runtime intercepts hsa_amd_memory_pool_allocate for the GPU sanitizer this pool does not offer and aborts in the
+  # first context; gcc's runtime speaks the same interface: under the name the library asks for)
+  mkdir -p /tmp/fakert && ln -sf $(gcc -print-file-name=libasan.so) /tmp/fakert/libclang_rt.asan-x86_64.so
+  export LD_LIBRARY_PATH=/tmp/fakert:$LD_LIBRARY_PATH
+  export LD_PRELOAD=$(gcc -print-file-name=libasan.so)
   export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
 fi
 for r in $(seq 1 $ROUNDS); do
