@@ -160,7 +160,8 @@ def roofline_of(work, S, vox_ms, kname, avg, ms_per_step, world, model, walked=N
         try:
             with open(mixp) as f:
                 mix = json.load(f)
-            m = mix.get(kname.split("<")[0], {}).get(model)
+            # (k_eval_voxels_gen_fp walks the same generated code as k_eval_voxels_gen: only the hand-out differs)
+            m = mix.get(kname.split("<")[0].replace("_gen_fp", "_gen"), {}).get(model)
             if m:
                 # the instruction stream's classes (scripts/valu_mix.py: generated-code templates + routines x the tape's opcode
                 # histogram) scaled to the measured total; each class against its own measured ceiling

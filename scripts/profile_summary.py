@@ -72,7 +72,7 @@ def first(prefixes, table):
 SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CU_CYCLES", "SQ_WAVES")
 sq = {c: per_kernel("pmc_sq", c) for c in SQ}
 seen = set(fetch) | set(write) | set(sq[SQ[0]])
-names = {"eval_voxels_f": first(("k_eval_voxels_gen<3", "k_eval_voxels_jit_groups<3", "k_eval_voxels_jit<3", "k_eval_voxels_asm<3", "k_eval_voxels<3"), seen),
+names = {"eval_voxels_f": first(("k_eval_voxels_gen_fp<3", "k_eval_voxels_gen<3", "k_eval_voxels_jit_groups<3", "k_eval_voxels_jit<3", "k_eval_voxels_asm<3", "k_eval_voxels<3"), seen),
          "eval_tiles_i": first(("k_eval_tiles<3, true",), seen), "eval_tiles_wide": first(("k_eval_tiles_wide<3>",), seen),
          "eval_pixels_d": first(("mprk::k_eval_normals_gen", "k_eval_normals_gen", "mprk::k_eval_normals_asm", "k_eval_normals_asm"), seen)}
 out = {"_note": "KiB counters x1024; read bytes doubled per the gfx950 FETCH_SIZE correction; "
