@@ -1591,7 +1591,8 @@ static int frame_tile_stage(Frame& f, int si)
                                   c->cus > 0;
         vox_gen_planned = vox_gen_next;
         /* ... by footprint segments: no list of tiles, the stage's own list in blocks of 64 siblings */
-        const bool vox_fp_next = vox_gen_next && c->voxel_fp && count > 0 && (count & 63) == 0;
+        /* (not in a frame that leaves the reference's state behind: its list of smallest tiles is part of that state) */
+        const bool vox_fp_next = vox_gen_next && c->voxel_fp && !reference && count > 0 && (count & 63) == 0;
         f.vox_fp = vox_fp_next;
         if (vox_gen_next) {
             if (vox_fp_next) {
@@ -1889,7 +1890,7 @@ static int frame_finish(Frame& f)
     c->pending_dim = f.dim;
     c->last_frame_lean = f.lean_now && !f.tiles_only;
     /* (looser enclosures decide less: tile lists and tapes of such a frame are sound, not the reference's) */
-    c->last_frame_fast = (f.lean_now || f.skip0 || f.used_loose) && !f.tiles_only;
+    c->last_frame_fast = (f.lean_now || f.skip0 || f.used_loose || f.vox_fp) && !f.tiles_only;      /* (vox_fp: no list of smallest tiles was made) */
     c->last_key = f.key;
     if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != f.tape->serial)) c->last_tape.reset(new mpr_tape(*f.tape));
     return f.blocking ? mpr_ctx_sync(c) : MPR_OK;

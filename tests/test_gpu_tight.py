@@ -159,7 +159,7 @@ def test_frames_that_leave_the_references_tiles_and_tapes_take_the_second_verdic
             assert np.array_equal(c.image, ref.image), (k, c.tile_stage_forms(), int((c.image != ref.image).sum()))
             assert np.array_equal(c.normals, ref.normals), (k, c.tile_stage_forms(), int((c.normals != ref.normals).sum()))
     assert ctx.tile_stage_forms().endswith("+verdict") and "+verdict" not in plain.tile_stage_forms(), (ctx.tile_stage_forms(), plain.tile_stage_forms())
-    assert ctx.float_kernel() == plain.float_kernel() == "k_eval_voxels_gen_fp<3>"
+    assert ctx.float_kernel() == plain.float_kernel() == "k_eval_voxels_gen<3>"          # (the reference's list of smallest tiles, tile by tile)
     assert ctx.frame_tiles()[2] == plain.frame_tiles()[2] == ref.counters["voxel_tiles"]         # the reference's list
     assert 0 < ctx.tiles_walked() < (0.9 if S >= 512 else 1.0) * plain.tiles_walked(), (ctx.tiles_walked(), plain.tiles_walked())
     # the frame's tiles and tapes as it left them (no second rendering: the context's frames are the reference's way already)
