@@ -1755,8 +1755,10 @@ static int frame_float_pass(Frame& f)
             fv.tiles = c->tiles[group_stage];
             fv.count = group_count;
             if (c->walked_dev) HIP_TRY(hipMemsetAsync(c->walked_dev, 0, 1024 * sizeof(int), s));
-            /* segments per claim: about four claims per wavefront (a segment is two or three tiles), at most 4 */
-            const int run = c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(4, count / (10 * std::max(c->fp_grid, 1))));
+            /* segments per claim: one — two in large frames (measured, scripts/walked_probe.py: bear 1024^3 295 us with 1, 306 with 2, 310 with 3,
+             * 336 with 4; 2048^3 900 / 897 / 926 with 1 / 2 / 3): a segment is two or three tiles, and 80 000 claims over eight counters are 90 us
+             * of atomics beside a 300 us kernel */
+            const int run = c->voxel_gen_tiles > 0 ? c->voxel_gen_tiles : std::max(1, std::min(2, count / (24 * std::max(c->fp_grid, 1))));
             mprk::launch_eval_voxels_gen_fp(s, fv, c->gen_code + c->gen_vox_at, c->fp_grid, c->fp_items, c->fp_meta, c->groups, c->choice_masks, group_cap,
                                             c->vox_counters, c->gen_dec[1], c->gen_nchoices, run, c->walked_dev, f.tight_skip_valid ? c->tight_skip : nullptr);
             jitted = on_root_code = true;
