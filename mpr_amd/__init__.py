@@ -82,8 +82,8 @@ _LIB = None
 
 def build(force=False):
     """Compile libmpr_amd.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else []))
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(os.path.join(_HERE, "libmpr_amd_test.so")):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else []))
     return LIB_PATH
 
 
