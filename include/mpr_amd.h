@@ -133,6 +133,8 @@ typedef struct mpr_ctx_options {
 
 int mpr_ctx_create(int32_t device, int32_t image_size_px, mpr_context** out);
 int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out);
+/* frees everything the context holds except its two HIP streams, which stay with the process for its next context on the device
+ * (the HIP runtime's stream destruction is not safe against its own signal handlers: csrc/context.hip, acquire_stream) */
 void mpr_ctx_destroy(mpr_context* ctx);
 int32_t mpr_ctx_image_size(const mpr_context* ctx);    /* Context::image_size_px */
 /* device memory the context holds right now: images, tile lists, the tape pool (which starts small and doubles when a frame's

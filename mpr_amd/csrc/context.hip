@@ -18,6 +18,7 @@
 #include <string>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mpr_amd.h"
@@ -292,6 +293,39 @@ struct mpr_context {
         }                                                                                    \
     } while (0)
 
+/* Streams are recycled, never destroyed.  hipStreamDestroy of the HIP runtime torch bundles (ROCm 7.0's ROCclr: commandqueue.cpp,
+ * HostQueue::terminate, "Marker queued to ensure finish") deletes the stream's roc::VirtualGPU while the HSA signal handlers of its
+ * last commands may still wait for the runtime's handler thread; each of them then decrements a 64-bit counter at offset 0x98 of
+ * the freed object (`lock subq $1, 0x98(gpu)` at the head of the handler registered with hsa_amd_signal_async_handler) — a write
+ * after free into whatever the process' heap placed there next.  Found with scripts/heapguard.c: 1944 such writes in 24 processes
+ * of the fuzz sweep; round 5's segmentation fault was one that landed in a std::vector being read (profiles/r06_segv_hunt.txt).
+ * A context takes its two streams from the idle ones of its device and gives them back, drained, when it is destroyed. */
+namespace {
+std::mutex g_idle_streams_mutex;
+std::vector<std::pair<int, hipStream_t>> g_idle_streams;
+}
+
+static hipError_t acquire_stream(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_idle_streams_mutex);
+        for (size_t i = g_idle_streams.size(); i-- > 0;)
+            if (g_idle_streams[i].first == device) {
+                *out = g_idle_streams[i].second;
+                g_idle_streams.erase(g_idle_streams.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+static void release_stream(int device, hipStream_t s)
+{
+    (void)hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lock(g_idle_streams_mutex);
+    g_idle_streams.emplace_back(device, s);
+}
+
 static int ensure_tiles(mpr_context* c, int stage, size_t n)
 {
     if (n <= c->tiles_cap[stage]) return MPR_OK;
@@ -522,7 +556,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
             return MPR_ERR_ALLOC;                                    \
         }                                                            \
     } while (0)
-    CT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CT(acquire_stream(c->device, &c->stream));
     {
         /* the four filled images and the normals (src/context.cpp:21-27) live in one allocation, in this
          * order, so that one kernel resets them at the start of a frame (mprk::launch_begin_frame) */
@@ -558,7 +592,7 @@ int mpr_ctx_create_ex(const mpr_ctx_options* opt, mpr_context** out)
     CT(hipHostMalloc((void**)&c->skip0_flag_host, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->skip0_flag_host, 0, 16 * sizeof(int));
     CT(hipHostGetDevicePointer((void**)&c->skip0_flag_dev, c->skip0_flag_host, 0));
-    CT(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    CT(acquire_stream(c->device, &c->side));
     CT(hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
     CT(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
     CT(hipEventCreateWithFlags(&c->ev_check, hipEventDisableTiming));
@@ -586,8 +620,7 @@ void mpr_ctx_destroy(mpr_context* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) {
-        (void)hipStreamSynchronize(c->side);
-        (void)hipStreamDestroy(c->side);
+        release_stream(c->device, c->side);
     }
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
@@ -642,7 +675,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->sched_levels) (void)hipFree(c->sched_levels);
     if (c->sched_prev) (void)hipFree(c->sched_prev);
     if (c->sched_defs) (void)hipFree(c->sched_defs);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) release_stream(c->device, c->stream);
     delete c;
 }
 

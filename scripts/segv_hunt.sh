@@ -3,7 +3,8 @@
 # sweep again, twelve processes side by side, python's faulthandler on (the Python-level stack of a fatal signal names the call that
 # died: the oracle through ctypes, or the library), core dumps allowed; leg "asan": the ORACLE built with -fsanitize=address
 # (oracle/Makefile: liboracle_asan.so, loaded when MPR_ORACLE_ASAN=1) under LD_PRELOAD of the sanitizer's runtime.
-# usage: segv_hunt.sh ROUNDS [asan]      -> gpurun_out/r06_segv/
+# leg "guard": scripts/heapguard.c preloaded — freed blocks are parked and checked for writes (who freed the block that was written to).
+# usage: segv_hunt.sh ROUNDS [asan|hostasan|guard]      -> gpurun_out/r06_segv/
 cd "$(dirname "$0")/.." || exit 1
 ROUNDS=${1:-3}; LEG=${2:-plain}
 OUT=gpurun_out/r06_segv; mkdir -p $OUT
@@ -26,6 +27,11 @@ if [ "$LEG" = hostasan ]; then
   export LD_PRELOAD=$(gcc -print-file-name=libasan.so)
   export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
 fi
+if [ "$LEG" = guard ]; then
+  gcc -O2 -fPIC -shared -o /tmp/heapguard.so scripts/heapguard.c -ldl || exit 1
+  export LD_PRELOAD=/tmp/heapguard.so
+  export HEAPGUARD_LOG=$PWD/$OUT/heapguard
+fi
 for r in $(seq 1 $ROUNDS); do
   for i in $(seq 0 11); do
     python scripts/fuzz_sweep.py $((1000 + i * 170)) 170 16 > $OUT/${LEG}_r${r}_part_$i.log 2>&1 &
@@ -33,6 +39,10 @@ for r in $(seq 1 $ROUNDS); do
   wait
   echo "== $LEG round $r: $(grep -l '^seeds' $OUT/${LEG}_r${r}_part_*.log | wc -l) of 12 processes finished; $(grep -h '^seeds' $OUT/${LEG}_r${r}_part_*.log | awk '{s+=$6} END {print s}') frames differ"
   grep -l "Fatal Python error\|Segmentation\|AddressSanitizer\|Traceback" $OUT/${LEG}_r${r}_part_*.log | while read f; do echo "--- $f"; grep -n -A45 "Fatal Python error\|AddressSanitizer\|Traceback" $f | cut -c1-200 | head -120; done
+  if [ "$LEG" = guard ]; then
+    echo "-- heapguard: $(cat $OUT/heapguard.* 2>/dev/null | grep -c 'write after free') reports"
+    cat $OUT/heapguard.* 2>/dev/null | grep -A1 'write after free' | head -60
+  fi
   # a core file (core_pattern "core": the repository's root): the C-level stack of every thread
   for c in core core.*; do
     [ -f "$c" ] || continue

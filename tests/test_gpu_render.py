@@ -825,3 +825,27 @@ def test_tape_pool_sized_by_the_frames(mpr, orc, tapes):
     assert cnt["pool_overflowed"] == 0
     assert ctx.resident_bytes() > small and cnt["tape_index"] > 100e6
     ctx.close()
+
+
+def test_contexts_recycle_their_streams(mpr, tapes):
+    """A destroyed context's streams go to the next context of the device instead of hipStreamDestroy (context.hip: acquire_stream —
+    the HIP runtime's stream destruction frees its virtual device under signal handlers still to run, profiles/r06_segv_hunt.txt);
+    frames on a recycled stream are the frames of a fresh one."""
+    tape = tapes("sphere")
+    a = mpr.Context(128)
+    a.render3D(tape, view3())
+    first, image = a.stream, a.image.copy()
+    a.close()
+    seen = set()
+    for _ in range(4):
+        b = mpr.Context(128)
+        b.render3D(tape, view3())
+        assert np.array_equal(b.image, image)
+        seen.add(b.stream)
+        b.close()
+    assert len(seen) <= 2 and (first in seen or len(seen) == 1)
+    # two contexts alive at the same time do not share a stream
+    c, d = mpr.Context(64), mpr.Context(64)
+    assert c.stream != d.stream
+    c.close()
+    d.close()
