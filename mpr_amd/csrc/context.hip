@@ -231,6 +231,8 @@ struct mpr_context {
     int gen_iw_at[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gen_iw_dw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     unsigned char* tight_skip = nullptr;   /* per tile of the last stage's list (TileStageArgs::tight_skip) */
     size_t tight_skip_cap = 0;
+    int* tight_image = nullptr;            /* TileStageArgs::tight_image */
+    size_t tight_image_cap = 0;
     bool tile_tight = true;            /* MPR_TILE_TIGHT=0: the last tile stage of a frame nobody reads hands the float pass every tile the reference's
                                         * enclosures leave ambiguous (round 6: with it, those a sound sin / cos enclosure decides stay away) */
     /* the resident tape's first-stage walk for the kernel with 93 slots in registers (internal.hpp: mpr_tape::big_fwd), or none */
@@ -654,6 +656,7 @@ void mpr_ctx_destroy(mpr_context* c)
     if (c->fp_items) (void)hipFree(c->fp_items);
     if (c->fp_meta) (void)hipFree(c->fp_meta);
     if (c->tight_skip) (void)hipFree(c->tight_skip);
+    if (c->tight_image) (void)hipFree(c->tight_image);
     if (c->walked_dev) (void)hipFree(c->walked_dev);
     for (int i = 0; i < 2; ++i) if (c->wide_bits[i]) (void)hipFree(c->wide_bits[i]);
     if (c->choice_masks) (void)hipFree(c->choice_masks);
@@ -1017,6 +1020,7 @@ struct Frame {
     bool vox_gen_planned = false;          /* the last stage's compaction kept, per smallest tile, where it sat in that stage's list */
     bool vox_counters_cleared = false;     /* ... and cleared the float pass's work counters */
     bool vox_fp = false;                   /* ... or made footprint segments of the stage's list instead: the float pass by segments */
+    bool vox_fp_beside = false;            /* ... or both (a frame that leaves the reference's list behind): the list for its reader, the segments for the float pass */
     bool tight_skip_valid = false;         /* the last tile stage was followed by the second verdict in a launch of its own: c->tight_skip */
     bool group_form = false;               /* the last stage recorded its groups' tapes and decisions, and the float pass takes them */
     bool lean_now = false;                 /* the last stage pushed no tapes */
@@ -1505,6 +1509,13 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
             v.lean = 2;
             v.verdict_only = true;
             v.tight_skip = c->tight_skip;
+            if (c->voxel_fp) {
+                const size_t cells = (size_t)a.tps * a.tps;
+                rc2 = ensure_buffer(&c->tight_image, &c->tight_image_cap, cells);
+                if (rc2) return rc2;
+                HIP_TRY(hipMemsetAsync(c->tight_image, 0, cells * sizeof(int), s));
+                v.tight_image = c->tight_image;
+            }
             v.gen_fwd2 = c->gen_code + c->gen_iw_at[tk][2];
             v.gen_guarded = tk == mpr::IW_BELOW_GUARDED;
             v.redo_flags = nullptr;
@@ -1627,15 +1638,21 @@ static int frame_tile_stage(Frame& f, int si)
         /* (not in a frame that leaves the reference's state behind: its list of smallest tiles is part of that state) */
         const bool vox_fp_next = vox_gen_next && c->voxel_fp && !reference && count > 0 && (count & 63) == 0;
         f.vox_fp = vox_fp_next;
+        /* a frame that leaves the reference's state behind, its tiles through the second verdict (stage_launch: "+verdict"): the list the
+         * reference's way AND the segments, for a float pass that stops at the first hidden tile of a footprint (bear 1024^3: 478 -> 3xx us;
+         * the extra compaction 14) */
+        const bool vox_fp_beside = vox_gen_next && c->voxel_fp && reference && !c->force_reference && f.tight_skip_valid && count > 0 && (count & 63) == 0;
+        f.vox_fp_beside = false;
         if (vox_gen_next) {
-            if (vox_fp_next) {
+            if (vox_fp_next || vox_fp_beside) {
                 rc = ensure_buffer(&c->fp_items, &c->fp_items_cap, (size_t)count / 4 + 64);
                 if (rc) return rc;
                 if (!c->fp_meta) {
                     HIP_TRY(hipMalloc((void**)&c->fp_meta, 4 * sizeof(int)));
                     HIP_TRY(hipMemsetAsync(c->fp_meta, 0, 4 * sizeof(int), s));
                 }
-            } else {
+            }
+            if (!vox_fp_next) {
                 rc = ensure_buffer(&c->tile_source, &c->tile_source_cap, (size_t)std::max(count, 1));
                 if (rc) return rc;
             }
@@ -1666,6 +1683,13 @@ static int frame_tile_stage(Frame& f, int si)
                                                (mark_groups && vox_gen_next) ? c->tile_source : nullptr);
             }
             if (mark_groups && !vox_gen_next && !vox_fp_next) mprk::launch_list_alive_groups(s, c->group_alive, (count + 63) / 64, c->group_list);
+            if (mark_groups && vox_fp_beside) {
+                TimedScope ts(c, "compact_copy");
+                mprk::launch_footprint_segments(s, c->tiles[i], count, tps, c->filled[i], c->fp_items, c->fp_meta, c->vox_counters, mprk::voxel_gen_counter_lists(),
+                                                mprk::voxel_gen_counter_ints() / mprk::voxel_gen_counter_lists(), c->tight_skip, c->tight_image, c->filled[next], S);
+                f.vox_counters_cleared = true;
+                f.vox_fp_beside = true;
+            }
             return read_active(c, seq, act3);       /* the reference's blocking read-back (:1209, :1375) */
         };
         if (count > 0) {
@@ -1716,7 +1740,11 @@ static int frame_tile_stage(Frame& f, int si)
             rc = compact(false);
             if (rc) return rc;
         }
-        if (f.vox_fp && !(vox_gen_planned && group_form)) {
+        if (f.vox_fp_beside) {
+            if (vox_gen_planned && group_form) f.vox_fp = true;      /* (the list is there whichever the float pass takes) */
+            else f.vox_fp_beside = false;
+        }
+        if (f.vox_fp && !f.vox_fp_beside && !(vox_gen_planned && group_form)) {
             /* segments were made of the stage's list and the float pass takes the list of tiles after all (per-tile tapes: this frame's
              * sample said they pay, or the stage pushed them anyway): the list */
             if (!(try_lean && !group_form && count > 0)) {          /* (that re-run compacted already) */
@@ -1925,7 +1953,7 @@ static int frame_finish(Frame& f)
     c->pending_dim = f.dim;
     c->last_frame_lean = f.lean_now && !f.tiles_only;
     /* (looser enclosures decide less: tile lists and tapes of such a frame are sound, not the reference's) */
-    c->last_frame_fast = (f.lean_now || f.skip0 || f.used_loose || f.vox_fp) && !f.tiles_only;      /* (vox_fp: no list of smallest tiles was made) */
+    c->last_frame_fast = (f.lean_now || f.skip0 || f.used_loose || (f.vox_fp && !f.vox_fp_beside)) && !f.tiles_only;      /* (vox_fp: no list of smallest tiles was made) */
     c->last_key = f.key;
     if (c->last_frame_fast && (!c->last_tape || c->last_tape->serial != f.tape->serial)) c->last_tape.reset(new mpr_tape(*f.tape));
     return f.blocking ? mpr_ctx_sync(c) : MPR_OK;

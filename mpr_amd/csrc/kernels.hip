@@ -201,6 +201,10 @@ k_eval_tiles(TileStageArgs a)
     }
     const int leader = __ffsll((long long)alive_mask) - 1;
     const int tape = __builtin_amdgcn_readlane(node.tape, leader);
+    /* a lane without a tile walks along on the leader's: whatever it computed on tile 0 of the image — far from anything, where the loose
+     * arithmetic may well raise its flag — would send the whole wavefront to the exact code (a list most of whose entries are decided
+     * already, TileStageArgs::verdict_only: 62 % of bear's wavefronts lost their second verdict that way) */
+    if (LEAN && !alive) pos = unpack(__builtin_amdgcn_readlane(node.position, leader), a.tps);
     /* the tape's first 64 words travel under the interval arithmetic of the prologue */
     uint64_t first_block = 0;
     /* (see below: the groups of the sample; with a.gen_parent they walk their tape by the interpreter, which can also push it) */
@@ -311,7 +315,12 @@ k_eval_tiles(TileStageArgs a)
                 /* the second verdict and nothing else.  (Filled tiles are DRAWN by the float pass, voxel by voxel: the bottom layer's too) */
                 if (alive && !(res_vs.x > 0.0f) && !(res_vs.y < 0.0f)) {
                     if (res_tight.x > 0.0f) a.tight_skip[gidx] = 1;
-                    else if (res_tight.y < 0.0f) a.tight_skip[gidx] = 2;
+                    else if (res_tight.y < 0.0f) {
+                        /* (with an image of its own and above the bottom layer — a filled tile's height is its z index in its level's image, and
+                         * 0 there reads "nothing" — the segments' launch draws it from that image, k_compact_footprints: 3) */
+                        a.tight_skip[gidx] = (a.tight_image && pos.z > 0) ? 3 : 2;
+                        if (a.tight_image) atomicMax(&a.tight_image[pos.w], pos.z);
+                    }
                 }
                 return;
             }
@@ -1128,9 +1137,24 @@ constexpr int FP_CHUNKS = 8;            /* chunks of 1024 tiles a workgroup of k
 __global__ void __launch_bounds__(1024)
 k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, const int* __restrict__ image, int* __restrict__ num_active,
                      unsigned* __restrict__ items, int* __restrict__ meta, int* __restrict__ clear, int nclear, int cstride, int* __restrict__ pub, int seq,
-                     CopyFilled cf, const unsigned long long* __restrict__ tape_index)
+                     CopyFilled cf, const unsigned long long* __restrict__ tape_index, const unsigned char* __restrict__ skip, const int* __restrict__ tight_image)
 {
+    /* skip != null: SEGMENTS ONLY, of a list another compaction has been through already (a frame that leaves the reference's list of
+     * smallest tiles behind and takes its float pass by segments all the same): nothing of the list is touched, no count handed over,
+     * no copy_filled; tiles the second verdict found empty (skip[i] == 1: they stay in the reference's list) make no segment */
+    const bool segments_only = skip != nullptr;
     if ((int)blockIdx.x >= cf.first_block) {
+        if (segments_only) {
+            /* the tiles the second verdict found filled, drawn: what copy_filled does with the reference's image of filled tiles, on top of it
+             * (cf.prev = tight_image; one thread per pixel, nobody else writes the heights now) */
+            const long long idx = (long long)((int)blockIdx.x - cf.first_block) * blockDim.x + threadIdx.x;
+            if (idx < (long long)cf.size * cf.size) {
+                const int x = (int)(idx % cf.size), y = (int)(idx / cf.size);
+                const int t = cf.prev[x / 4 + (y / 4) * (cf.size / 4)];
+                if (t && cf.next[x + y * cf.size] < t * 4 + 3) cf.next[x + y * cf.size] = t * 4 + 3;
+            }
+            return;
+        }
         copy_filled_block<3>(cf, (int)blockIdx.x - cf.first_block, (int)blockDim.x, (int)threadIdx.x);
         return;
     }
@@ -1150,10 +1174,12 @@ k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, cons
             const int4_ p = unpack(position, tps);
             if (image[p.w] > p.z) {
                 active = false;
-                tiles[gidx].position = -1;
+                if (!segments_only) tiles[gidx].position = -1;
+            } else if (segments_only && (skip[gidx] == 1 || skip[gidx] == 3 || (tight_image && tight_image[p.w] > p.z))) {
+                active = false;                     /* provably empty / behind a tile the second verdict found filled */
             }
         }
-        if (valid) tiles[gidx].next = -1;         /* copy_active_tiles resets next (:650) */
+        if (valid && !segments_only) tiles[gidx].next = -1;         /* copy_active_tiles resets next (:650) */
         masks[k] = ballot(active);
         const uint32_t m16 = (uint32_t)((masks[k] | (masks[k] >> 16) | (masks[k] >> 32) | (masks[k] >> 48)) & 0xFFFFull);
         tiles_mine += __popcll(masks[k]);
@@ -1169,7 +1195,7 @@ k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, cons
                 wave_base[k][w] = items_total;
                 items_total += wave_items[k][w];
             }
-        if (tiles_total) atomicAdd(num_active, tiles_total);
+        if (tiles_total && !segments_only) atomicAdd(num_active, tiles_total);
         const int b0 = items_total ? atomicAdd(meta, items_total) : 0;
         for (int k = 0; k < FP_CHUNKS; ++k)
             for (int w = 0; w < 16; ++w) wave_base[k][w] += b0;
@@ -1188,13 +1214,16 @@ k_compact_footprints(mpr_tile_node* __restrict__ tiles, int count, int tps, cons
     }
     if (threadIdx.x == 0) {
         /* the last workgroup through here has every count (k_compact_subdivide: no fence needed, its own additions have returned) */
-        if (atomicAdd(num_active + 3, 1) == cf.first_block - 1) {
-            const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(num_active + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* const arrivals = segments_only ? meta + 2 : num_active + 3;
+        if (atomicAdd(arrivals, 1) == cf.first_block - 1) {
+            __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ni = __hip_atomic_exchange(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(meta + 1, ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < nclear; ++i) __hip_atomic_store(clear + i * cstride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish_counts(pub, seq, n0, 0, 0, num_active + 4, tape_index);
+            if (!segments_only) {
+                const int n0 = __hip_atomic_exchange(num_active + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish_counts(pub, seq, n0, 0, 0, num_active + 4, tape_index);
+            }
         }
     }
 }
@@ -1947,7 +1976,16 @@ void launch_compact_footprints(hipStream_t s, mpr_tile_node* tiles, int count, i
     unsigned extra = 0;
     const CopyFilled cf = copy_filled_args(image, next_image, next_size, (int)blocks, &extra);
     hipLaunchKernelGGL(k_compact_footprints, dim3(blocks + extra), dim3(1024), 0, s, tiles, count, tps, image, num_active, items, meta, clear, nclear, cstride, pub, seq, cf,
-                       tape_index);
+                       tape_index, (const unsigned char*)nullptr, (const int*)nullptr);
+}
+void launch_footprint_segments(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, unsigned* items, int* meta, int* clear, int nclear, int cstride,
+                               const unsigned char* skip, const int* tight_image, int* heights, int size)
+{
+    const unsigned blocks = (unsigned)((count + 1024 * FP_CHUNKS - 1) / (1024 * FP_CHUNKS));
+    unsigned extra = 0;
+    const CopyFilled cf = copy_filled_args(tight_image, tight_image ? heights : nullptr, size, (int)blocks, &extra);
+    hipLaunchKernelGGL(k_compact_footprints, dim3(blocks + extra), dim3(1024), 0, s, tiles, count, tps, image, (int*)nullptr, items, meta, clear, nclear, cstride, (int*)nullptr, 0, cf,
+                       (const unsigned long long*)nullptr, skip, tight_image);
 }
 void launch_compact_zsorted(hipStream_t s, bool last, mpr_tile_node* tiles, int count, int tps, const int* image,
                             mpr_tile_node* out, int* hist, int* cursor, int* pub, int seq, int* next_image, int next_size,

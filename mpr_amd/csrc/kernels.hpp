@@ -99,6 +99,9 @@ struct TileStageArgs {
      * facts about the float values, and the tight enclosure with the PARENT's decisions imposed holds them (a flagged wavefront: no verdict) */
     bool verdict_only = false;
     unsigned char* tight_skip = nullptr;
+    int* tight_image = nullptr;                /* verdict_only: null, or an image of the stage's tiles (tps x tps, zero before the launch): max z index of the tiles
+                                                * found filled per column — what hides the tiles behind them from the float pass's segments (the reference's own
+                                                * images stay as they are) */
     unsigned char* redo_flags = nullptr;
     const unsigned char* only_flagged = nullptr;
     unsigned int* gen_redo_count = nullptr;    /* development: wavefronts whose loose walk asked for the exact one */
@@ -275,6 +278,11 @@ int voxel_gen_counter_ints();
 int voxel_gen_fp_grid(int cus);
 void launch_compact_footprints(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, int* num_active, unsigned* items, int* meta,
                                int* clear, int nclear, int cstride, int* pub, int seq, int* next_image, int next_size, const unsigned long long* tape_index);
+/* the segments alone, of a list another compaction has been through (skip: one byte per tile, 1 = no segment for it; never null — a frame
+ * without a second verdict hands a zeroed array); meta: 4 ints; tight_image (TileStageArgs::tight_image; may be null): tiles behind its
+ * entries make no segment either, and the entries are drawn into heights (size x size pixels) */
+void launch_footprint_segments(hipStream_t s, mpr_tile_node* tiles, int count, int tps, const int* image, unsigned* items, int* meta, int* clear, int nclear, int cstride,
+                               const unsigned char* skip, const int* tight_image, int* heights, int size);
 int voxel_gen_counter_lists();      /* the float pass's work counters: this many, voxel_gen_counter_ints() / this apart */
 void launch_eval_voxels_gen_fp(hipStream_t s, const VoxelArgs& a, const uint32_t* code, int grid, const unsigned* items, const int* meta, const GroupInfo* groups,
                                const ulonglong2* choice_masks, int choice_cap, int* counter, const unsigned long long* parent_records, int nchoices, int run,

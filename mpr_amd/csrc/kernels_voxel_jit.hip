@@ -1036,7 +1036,7 @@ struct GenVoxelArgs {
     int run;                           /* consecutive tiles a wavefront takes per atomic */
     int* walked;                       /* development: += tiles walked (null: not counted) */
     const unsigned char* skip;         /* null, or per tile of the last tile stage's list (TileStageArgs::tight_skip): 1 = provably empty, not walked;
-                                        * 2 = provably filled, drawn without a walk */
+                                        * 2 = provably filled, drawn without a walk; 3 = the same (the segments' launch draws those: k_compact_footprints) */
 };
 
 /* A wavefront per smallest tile, in list order (front to back: the tiles behind a surface find it drawn).  Nothing is shared
@@ -1079,7 +1079,7 @@ k_eval_voxels_gen(GenVoxelArgs j)
                 if (verdict == 1) continue;
                 JitVoxel<DIM> vox;
                 if (!vox.setup(a, position, lane)) continue;
-                if (verdict == 2) {
+                if (verdict >= 2) {          /* (3: drawn from the second verdict's image where the segments' launch ran; once more does no harm) */
                     vox.finish(a, -1.0f);
                     continue;
                 }
@@ -1210,7 +1210,7 @@ k_eval_voxels_gen_fp(FpVoxelArgs j)
                     if (position < 0) continue;
                     JitVoxel<DIM> vox;
                     if (!vox.setup(a, position, lane)) break;               /* hidden: so is everything behind it */
-                    if (verdict == 2) {
+                    if (verdict >= 2) {          /* (3: drawn from the second verdict's image where the segments' launch ran; once more does no harm) */
                         vox.finish(a, -1.0f);
                         continue;
                     }

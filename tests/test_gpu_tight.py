@@ -142,26 +142,32 @@ def test_filled_tiles_of_the_bottom_layer_stay_with_the_float_pass(mpr, orc, see
 @pytest.mark.parametrize("name,S", [("bear", 256), ("bear", 512), ("trig_blend", 256)])
 def test_frames_that_leave_the_references_tiles_and_tapes_take_the_second_verdict_in_a_launch_of_its_own(mpr, orc, tapes, name, S, monkeypatch):
     """MPR_LAST_STAGE_PUSH=1 (bench.py: full_frames): every stage from the 64^3 tiles down on the reference's enclosures, every tape
-    pushed, the float pass over the reference's list of smallest tiles.  Behind the last stage the tight code runs once more
+    pushed, the reference's list of smallest tiles made.  Behind the last stage the tight code runs once more
     (TileStageArgs::verdict_only: '+verdict'): the lists, tapes and records stay the reference's — what a reader gets is held against
     the oracle tile by tile and tape by tape — and the tiles the second verdict decides are not walked by the float pass."""
     from helpers import active_positions
     tape = tapes(name)
     ref = orc.Frame(tape.data, 3, S, mpr.colmajor(view3(), 4), threads=0)
-    monkeypatch.setenv("MPR_LAST_STAGE_PUSH", "1")
     monkeypatch.setenv("MPR_DEBUG_WALKED", "1")
+    fast = mpr.Context(S)                        # (a frame nobody reads: the second verdict inside its last stage)
+    monkeypatch.setenv("MPR_LAST_STAGE_PUSH", "1")
     ctx = mpr.Context(S)
     monkeypatch.setenv("MPR_TILE_TIGHT", "0")
     plain = mpr.Context(S)
     for k in range(3):
-        for c in (ctx, plain):
+        for c in (ctx, plain, fast):
             c.render3D(tape, view3())
             assert np.array_equal(c.image, ref.image), (k, c.tile_stage_forms(), int((c.image != ref.image).sum()))
             assert np.array_equal(c.normals, ref.normals), (k, c.tile_stage_forms(), int((c.normals != ref.normals).sum()))
     assert ctx.tile_stage_forms().endswith("+verdict") and "+verdict" not in plain.tile_stage_forms(), (ctx.tile_stage_forms(), plain.tile_stage_forms())
-    assert ctx.float_kernel() == plain.float_kernel() == "k_eval_voxels_gen<3>"          # (the reference's list of smallest tiles, tile by tile)
+    # the float pass: by footprint segments made BESIDE the reference's list (context.hip: vox_fp_beside) / the list tile by tile
+    assert ctx.float_kernel() == "k_eval_voxels_gen_fp<3>" and plain.float_kernel() == "k_eval_voxels_gen<3>", (ctx.float_kernel(), plain.float_kernel())
     assert ctx.frame_tiles()[2] == plain.frame_tiles()[2] == ref.counters["voxel_tiles"]         # the reference's list
     assert 0 < ctx.tiles_walked() < (0.9 if S >= 512 else 1.0) * plain.tiles_walked(), (ctx.tiles_walked(), plain.tiles_walked())
+    # ... as many as in a frame nobody reads, give or take the order the wavefronts came in (the list is mostly decided tiles by then: lanes
+    # without a tile must not cost the wavefront its verdict — they did, kernels.hip: "a lane without a tile walks along on the leader's")
+    assert "+tight" in fast.tile_stage_forms() and ctx.tiles_walked() < 1.1 * fast.tiles_walked() + 64, (ctx.tiles_walked(), fast.tiles_walked())
+    fast.close()
     # the frame's tiles and tapes as it left them (no second rendering: the context's frames are the reference's way already)
     assert ctx.last_stage_pushed()
     pool = ctx.tape_data
