@@ -4,6 +4,7 @@
  */
 #include <algorithm>
 #include <cstring>
+#include <future>
 #include <new>
 #include <numeric>
 #include <stdexcept>
@@ -134,11 +135,16 @@ static void finish_tape(mpr_tape* t)
     t->num_slots = max_slot + 1;
     t->num_choices = choices;
     t->schedule = mpr::build_schedule(t->clauses.data(), (int32_t)t->clauses.size());
-    /* the tape's walks as machine code, here and not in the first frame that renders it (0.4 ms of host time for bear) */
+    /* the tape's walks as machine code, here and not in the first frame that renders it (bear: 7 ms of host time with eight cores — nine
+     * scheduled forward walks side by side, tile_gen.cpp: build_tape_code —, 30 on one; round 6 began at 70: interval_gen.cpp: schedule_region) */
     t->code = mpr::build_tape_code(t->clauses.data(), (int)t->clauses.size(), mpr::TAPE_CODE_DEFAULT_MIN_RUN);
     if (!t->code && t->num_slots > mpr::TILE_GEN_MAX_SLOTS && t->num_slots <= 94) {
         /* (prospero: 32 000 + 48 000 instructions, 25 of the 36 ms its tape takes to make; architecture: 6800 + 19 000, 4 of 7 ms) */
         /* the backward walk: any such tape (it reads whatever forward walk's choices); the loose forward walk: tapes the loose arithmetic takes */
+        /* (side by side: the forward walk is a third of the two) */
+        std::future<mpr::IntervalCode> fwd;
+        if (t->loose_ok)
+            fwd = std::async(std::launch::async, [t]() { return mpr::interval_gen_build(t->clauses.data(), (int)t->clauses.size(), mpr::IW_FIRST_MASKS, true); });
         std::vector<uint32_t> bw = mpr::tile_gen_build_big_backward(t->clauses.data(), (int)t->clauses.size());
         if (!bw.empty()) {
             t->big_bwd = std::make_shared<const std::vector<uint32_t>>(std::move(bw));
@@ -146,7 +152,7 @@ static void finish_tape(mpr_tape* t)
                 if (mpr_cl_op(t->clauses[i]) == MPR_OP_INVALID) { t->big_end = (int32_t)i; break; }
         }
         if (t->loose_ok) {
-            const mpr::IntervalCode ic = mpr::interval_gen_build(t->clauses.data(), (int)t->clauses.size(), mpr::IW_FIRST_MASKS, true);
+            const mpr::IntervalCode ic = fwd.get();
             if (ic.ok) {
                 t->big_fwd = std::make_shared<const std::vector<uint32_t>>(ic.words);
                 t->big_end = ic.walk_words;

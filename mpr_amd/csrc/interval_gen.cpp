@@ -675,107 +675,151 @@ struct Region {
 };
 
 /* orders code[b, e) in place; returns the schedule's length in cycles */
+/* (A tape of bear's size is 120 regions of 40 instructions per walk, nine walks per tape: the containers are flat and live in a scratch
+ * object per thread — as std::map / vector of vectors this function was two thirds of a tape's 70 ms.  Successors are kept in the order
+ * the edges were found: the order in which instructions become ready breaks ties below.) */
+struct SchedScratch {
+    struct Edge { int to, lat, next; };
+    std::vector<Edge> edges;
+    std::vector<int> head, tail, npred, prio, earliest, order, ready;
+    std::vector<std::pair<int, int>> regs;        /* (key, track) sorted by key once the region's keys are known */
+    std::vector<int> keys;
+    std::vector<int> track_def;
+    std::vector<std::vector<int>> track_readers;
+    std::vector<int> scc_readers, scc_junk;
+    std::vector<std::pair<int, int>> left;        /* (clause, instructions not yet issued), by clause */
+    std::vector<Inst> out;
+};
 int schedule_region(std::vector<Inst>& code, int b, int e, int window)
 {
     const int n = e - b;
     if (n <= 1) return n ? issue_cycles(code[b]) : 0;
-    std::vector<std::vector<std::pair<int, int>>> succ(n);      /* (successor, latency) */
-    std::vector<int> npred(n, 0);
+    thread_local SchedScratch S;
+    S.edges.clear();
+    S.head.assign((size_t)n, -1);
+    S.tail.assign((size_t)n, -1);
+    S.npred.assign((size_t)n, 0);
     auto edge = [&](int from, int to, int lat) {
         if (from == to) return;
-        succ[from].push_back({to, lat});
-        ++npred[to];
+        const int id = (int)S.edges.size();
+        S.edges.push_back({to, lat, -1});
+        if (S.tail[(size_t)from] < 0) S.head[(size_t)from] = id;
+        else S.edges[(size_t)S.tail[(size_t)from]].next = id;
+        S.tail[(size_t)from] = id;
+        ++S.npred[(size_t)to];
     };
-    struct Track { int def = -1; std::vector<int> readers; };
-    std::map<int, Track> regs;
+    /* the registers the region names, numbered */
+    S.keys.clear();
+    for (int j = 0; j < n; ++j) {
+        const Inst& in = code[b + j];
+        for (int k = 0; k < 3; ++k) {
+            const int key = key_of(in.src[k]);
+            if (key >= 0) S.keys.push_back(key);
+        }
+        const int dk = key_of(in.dst);
+        if (dk >= 0) S.keys.push_back(dk);
+    }
+    std::sort(S.keys.begin(), S.keys.end());
+    S.keys.erase(std::unique(S.keys.begin(), S.keys.end()), S.keys.end());
+    const size_t ntracks = S.keys.size();
+    S.track_def.assign(ntracks, -1);
+    if (S.track_readers.size() < ntracks) S.track_readers.resize(ntracks);
+    for (size_t t = 0; t < ntracks; ++t) S.track_readers[t].clear();
+    auto track_of = [&](int key) { return (size_t)(std::lower_bound(S.keys.begin(), S.keys.end(), key) - S.keys.begin()); };
     int scc_def = -1;
-    std::vector<int> scc_readers, scc_junk;                      /* writers nobody reads, since the last real definition */
+    S.scc_readers.clear();
+    S.scc_junk.clear();                                          /* writers nobody reads, since the last real definition */
     for (int j = 0; j < n; ++j) {
         const Inst& in = code[b + j];
         const uint16_t f = in.flags();
         for (int k = 0; k < 3; ++k) {
             const int key = key_of(in.src[k]);
             if (key < 0) continue;
-            Track& t = regs[key];
-            if (t.def >= 0) edge(t.def, j, result_latency(code[b + t.def], in));
-            t.readers.push_back(j);
+            const size_t t = track_of(key);
+            if (S.track_def[t] >= 0) edge(S.track_def[t], j, result_latency(code[b + S.track_def[t]], in));
+            S.track_readers[t].push_back(j);
         }
         if (f & F_RD_SCC) {
             if (scc_def >= 0) edge(scc_def, j, 4);
-            scc_readers.push_back(j);
+            S.scc_readers.push_back(j);
         }
         const int dk = key_of(in.dst);
         if (dk >= 0) {
-            Track& t = regs[dk];
-            if (t.def >= 0) edge(t.def, j, 1);
-            for (int r : t.readers) edge(r, j, 1);
-            t.def = j;
-            t.readers.clear();
+            const size_t t = track_of(dk);
+            if (S.track_def[t] >= 0) edge(S.track_def[t], j, 1);
+            for (int r : S.track_readers[t]) edge(r, j, 1);
+            S.track_def[t] = j;
+            S.track_readers[t].clear();
         }
         if (f & F_DEF_SCC) {
-            for (int r : scc_readers) edge(r, j, 1);
-            for (int w : scc_junk) edge(w, j, 1);
+            for (int r : S.scc_readers) edge(r, j, 1);
+            for (int w : S.scc_junk) edge(w, j, 1);
             if (scc_def >= 0) edge(scc_def, j, 1);
             scc_def = j;
-            scc_readers.clear();
-            scc_junk.clear();
+            S.scc_readers.clear();
+            S.scc_junk.clear();
         } else if (f & F_WR_SCC) {
-            for (int r : scc_readers) edge(r, j, 1);
-            if (scc_def >= 0 && scc_readers.empty()) edge(scc_def, j, 1);      /* (never between a definition and its reader) */
-            scc_junk.push_back(j);
+            for (int r : S.scc_readers) edge(r, j, 1);
+            if (scc_def >= 0 && S.scc_readers.empty()) edge(scc_def, j, 1);      /* (never between a definition and its reader) */
+            S.scc_junk.push_back(j);
         }
     }
     /* priority: the longest way to the end of the region */
-    std::vector<int> prio(n, 0);
+    S.prio.assign((size_t)n, 0);
     for (int j = n - 1; j >= 0; --j) {
         int p = issue_cycles(code[b + j]);
-        for (auto& s : succ[j]) p = std::max(p, s.second + prio[s.first]);
-        prio[j] = p;
+        for (int id = S.head[(size_t)j]; id >= 0; id = S.edges[(size_t)id].next) p = std::max(p, S.edges[(size_t)id].lat + S.prio[(size_t)S.edges[(size_t)id].to]);
+        S.prio[(size_t)j] = p;
     }
-    std::vector<int> earliest(n, 0), order;
-    order.reserve(n);
-    std::vector<char> done(n, 0);
-    std::vector<int> ready;
+    S.earliest.assign((size_t)n, 0);
+    S.order.clear();
+    S.ready.clear();
     for (int j = 0; j < n; ++j)
-        if (!npred[j]) ready.push_back(j);
+        if (!S.npred[(size_t)j]) S.ready.push_back(j);
     /* the window: clauses in tape order; an instruction may issue while its clause is within `window` of the oldest unfinished one */
-    std::map<int, int> left;        /* clause -> instructions not yet issued */
-    for (int j = 0; j < n; ++j) ++left[code[b + j].clause];
+    S.left.clear();
+    for (int j = 0; j < n; ++j) S.left.push_back({code[b + j].clause, 0});
+    std::sort(S.left.begin(), S.left.end());
+    S.left.erase(std::unique(S.left.begin(), S.left.end()), S.left.end());
+    auto left_of = [&](int clause) -> int& {
+        return std::lower_bound(S.left.begin(), S.left.end(), std::make_pair(clause, 0), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; })->second;
+    };
+    for (int j = 0; j < n; ++j) ++left_of(code[b + j].clause);
+    size_t oldest_at = 0;
     int now = 0;
-    while ((int)order.size() < n) {
-        const int oldest = left.begin()->first;
+    while ((int)S.order.size() < n) {
+        while (S.left[oldest_at].second == 0) ++oldest_at;
+        const int oldest = S.left[oldest_at].first;
         int best = -1;
         bool best_now = false;
-        for (int r : ready) {
+        for (int r : S.ready) {
             if (code[b + r].clause > oldest + window - 1) continue;
-            const bool is_now = earliest[r] <= now;
+            const bool is_now = S.earliest[(size_t)r] <= now;
             bool better;
             if (best < 0) better = true;
             else if (is_now != best_now) better = is_now;
-            else if (is_now) better = prio[r] > prio[best] || (prio[r] == prio[best] && r < best);
-            else better = earliest[r] < earliest[best] || (earliest[r] == earliest[best] && prio[r] > prio[best]);
+            else if (is_now) better = S.prio[(size_t)r] > S.prio[(size_t)best] || (S.prio[(size_t)r] == S.prio[(size_t)best] && r < best);
+            else better = S.earliest[(size_t)r] < S.earliest[(size_t)best] || (S.earliest[(size_t)r] == S.earliest[(size_t)best] && S.prio[(size_t)r] > S.prio[(size_t)best]);
             if (better) { best = r; best_now = is_now; }
         }
         if (best < 0) {             /* (cannot happen: the oldest clause's next instruction is always eligible) */
-            for (int r : ready)
+            for (int r : S.ready)
                 if (best < 0 || code[b + r].clause < code[b + best].clause) best = r;
         }
-        now = std::max(now, earliest[best]);
-        order.push_back(best);
-        done[best] = 1;
-        ready.erase(std::find(ready.begin(), ready.end(), best));
-        auto it = left.find(code[b + best].clause);
-        if (--it->second == 0) left.erase(it);
-        for (auto& s : succ[best]) {
-            earliest[s.first] = std::max(earliest[s.first], now + s.second);
-            if (--npred[s.first] == 0) ready.push_back(s.first);
+        now = std::max(now, S.earliest[(size_t)best]);
+        S.order.push_back(best);
+        S.ready.erase(std::find(S.ready.begin(), S.ready.end(), best));
+        --left_of(code[b + best].clause);
+        for (int id = S.head[(size_t)best]; id >= 0; id = S.edges[(size_t)id].next) {
+            const int to = S.edges[(size_t)id].to;
+            S.earliest[(size_t)to] = std::max(S.earliest[(size_t)to], now + S.edges[(size_t)id].lat);
+            if (--S.npred[(size_t)to] == 0) S.ready.push_back(to);
         }
         now += issue_cycles(code[b + best]);
     }
-    std::vector<Inst> out;
-    out.reserve(n);
-    for (int j : order) out.push_back(code[b + j]);
-    std::copy(out.begin(), out.end(), code.begin() + b);
+    S.out.clear();
+    for (int j : S.order) S.out.push_back(code[b + j]);
+    std::copy(S.out.begin(), S.out.end(), code.begin() + b);
     return now;
 }
 
@@ -930,18 +974,21 @@ bool allocate(std::vector<Inst>& code, int nv, int ns, bool loose, int vgpr_limi
  * Along every path: a branch hands its state to its label. */
 void insert_wait_states(std::vector<Inst>& code, int* nops)
 {
+    /* per register: the count of instructions issued so far when a VALU last wrote the scalar register / a transcendental last wrote the
+     * vector register (NEVER: no such write in sight); an age is `now - written` */
     struct State {
-        std::vector<int> s_age, t_age;      /* instructions since a VALU wrote the scalar register / a transcendental wrote the vector register */
-        State() : s_age(128, 99), t_age(256, 99) {}
+        enum { NEVER = -1000000 };
+        int now = 0;
+        std::vector<int> s_at, t_at;
+        State() : s_at(128, NEVER), t_at(256, NEVER) {}
+        int s_age(int r) const { return now - s_at[r]; }
+        int t_age(int r) const { return now - t_at[r]; }
+        /* the state another way into this place brings along (taken `o.now` instructions into ITS count): the younger write of the two */
         void merge(const State& o)
         {
-            for (size_t k = 0; k < s_age.size(); ++k) s_age[k] = std::min(s_age[k], o.s_age[k]);
-            for (size_t k = 0; k < t_age.size(); ++k) t_age[k] = std::min(t_age[k], o.t_age[k]);
-        }
-        void tick(int n)
-        {
-            for (int& a : s_age) a = std::min(99, a + n);
-            for (int& a : t_age) a = std::min(99, a + n);
+            const int shift = now - o.now;
+            for (size_t k = 0; k < s_at.size(); ++k) s_at[k] = std::max(s_at[k], o.s_at[k] == NEVER ? (int)NEVER : o.s_at[k] + shift);
+            for (size_t k = 0; k < t_at.size(); ++k) t_at[k] = std::max(t_at[k], o.t_at[k] == NEVER ? (int)NEVER : o.t_at[k] + shift);
         }
     };
     auto sreg = [](const Opnd& o) { return o.k == K::VCC ? 106 : o.k == K::PS ? o.id : -1; };
@@ -962,10 +1009,10 @@ void insert_wait_states(std::vector<Inst>& code, int* nops)
             for (int k = 0; k < 3; ++k) {
                 const int r = sreg(in.src[k]);
                 if (r >= 0) {
-                    need = std::max(need, 2 - st.s_age[r]);
-                    if (r + 1 < 128 && in.op == Op::V_CNDMASK && k == 2) need = std::max(need, 2 - st.s_age[r + 1]);
+                    need = std::max(need, 2 - st.s_age(r));
+                    if (r + 1 < 128 && in.op == Op::V_CNDMASK && k == 2) need = std::max(need, 2 - st.s_age(r + 1));
                 }
-                if (in.src[k].k == K::PV && !(in.flags() & F_TRANS)) need = std::max(need, 1 - st.t_age[in.src[k].id]);
+                if (in.src[k].k == K::PV && !(in.flags() & F_TRANS)) need = std::max(need, 1 - st.t_age(in.src[k].id));
             }
         }
         if (need > 0) {
@@ -974,30 +1021,35 @@ void insert_wait_states(std::vector<Inst>& code, int* nops)
             nop.imm = need - 1;
             nop.clause = in.clause;
             out.push_back(nop);
-            st.tick(need);
+            st.now += need;
             ++*nops;
         }
         out.push_back(in);
-        st.tick(1);
+        st.now += 1;
         if (in.is_valu()) {
             const int r = sreg(in.dst);
             if (r >= 0) {
-                st.s_age[r] = 0;
-                if (r + 1 < 128) st.s_age[r + 1] = 0;
+                st.s_at[r] = st.now;
+                if (r + 1 < 128) st.s_at[r + 1] = st.now;
             }
-            if (in.dst.k == K::PV) st.t_age[in.dst.id] = (in.flags() & F_TRANS) ? 0 : 99;
+            if (in.dst.k == K::PV) st.t_at[in.dst.id] = (in.flags() & F_TRANS) ? st.now : (int)State::NEVER;
         } else {
             const int r = sreg(in.dst);                 /* a scalar instruction's result needs no wait */
             if (r >= 0) {
-                st.s_age[r] = 99;
-                if (r + 1 < 128) st.s_age[r + 1] = 99;
+                st.s_at[r] = State::NEVER;
+                if (r + 1 < 128) st.s_at[r + 1] = State::NEVER;
             }
         }
         if (in.is_branch() && in.imm < 0) {
             const int label = -in.imm - 1;
             auto it = at_label.find(label);
             if (it == at_label.end()) at_label[label] = st;
-            else it->second.merge(st);
+            else {
+                /* (two ways to the same label: both as seen from the later one's count) */
+                State older = it->second;
+                it->second = st;
+                it->second.merge(older);
+            }
         }
     }
     code.swap(out);

@@ -1,6 +1,7 @@
 /* tile_gen.cpp — see tile_gen.hpp.  Instruction encodings: GFX9 family (gfx950); tests/test_tile_gen.py disassembles what
  * this file emits with the ROCm assembler and compares it with the instructions it is meant to be. */
 #include "tile_gen.hpp"
+#include <future>
 
 #include <algorithm>
 #include <cstdlib>
@@ -612,10 +613,17 @@ std::shared_ptr<const TapeCode> build_tape_code(const uint64_t* clauses, int len
     c->nchoices = g.nchoices;
     c->vox_min_run = vox_min_run;
     const int window = 0;
+    /* the nine scheduled forward walks — three kinds, each exact, loose and loose + tight — are independent of one another and 3 to 8 ms
+     * each for a tape of bear's size (list scheduling, register allocation, wait states): side by side, put together in a fixed order */
+    std::future<IntervalCode> walks[3][3];
     for (int kind = 0; kind < 3; ++kind)
-        for (int loose = 0; loose < 3; ++loose) {         /* (2: loose and tight) */
-            const IntervalCode ic = interval_gen_build(clauses, len, kind, loose != 0, window, 3, false, loose == 2 ? IGEN_TIGHT_VGPRS : loose ? IGEN_LEAN_VGPRS : 0,
-                                                       false, loose == 2);
+        for (int loose = 0; loose < 3; ++loose)           /* (2: loose and tight) */
+            walks[kind][loose] = std::async(std::launch::async, [=]() {
+                return interval_gen_build(clauses, len, kind, loose != 0, window, 3, false, loose == 2 ? IGEN_TIGHT_VGPRS : loose ? IGEN_LEAN_VGPRS : 0, false, loose == 2);
+            });
+    for (int kind = 0; kind < 3; ++kind)
+        for (int loose = 0; loose < 3; ++loose) {
+            const IntervalCode ic = walks[kind][loose].get();
             if (!ic.ok) continue;
             c->iw_at[kind][loose] = (int)c->words.size();
             c->iw_dw[kind][loose] = (int)ic.words.size();

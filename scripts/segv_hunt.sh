@@ -1,32 +1,16 @@
 #!/bin/bash
 # one of the twelve processes of round 5's fuzz sweep (seeds 2700..2869) died of a segmentation fault.  The same
 # sweep again, twelve processes side by side, python's faulthandler on (the Python-level stack of a fatal signal names the call that
-# died: the oracle through ctypes, or the library), core dumps allowed; leg "asan": the ORACLE built with -fsanitize=address
-# (oracle/Makefile: liboracle_asan.so, loaded when MPR_ORACLE_ASAN=1) under LD_PRELOAD of the sanitizer's runtime.
+# died: the oracle through ctypes, or the library), core dumps allowed.  (Two more legs were run in round 6 and taken out again, profiles/
+# r06_segv_hunt.txt section 3: the oracle built with the address sanitizer — clean —, and the library's host side built with it, which the
+# GPU boxes' runtime does not load.)
 # leg "guard": scripts/heapguard.c preloaded — freed blocks are parked and checked for writes (who freed the block that was written to).
-# usage: segv_hunt.sh ROUNDS [asan|hostasan|guard]      -> gpurun_out/r06_segv/
+# usage: segv_hunt.sh ROUNDS [plain|guard]      -> gpurun_out/r06_segv/
 cd "$(dirname "$0")/.." || exit 1
 ROUNDS=${1:-3}; LEG=${2:-plain}
 OUT=gpurun_out/r06_segv; mkdir -p $OUT
 ulimit -c unlimited
 export PYTHONFAULTHANDLER=1
-if [ "$LEG" = asan ]; then
-  make -s -C oracle asan || exit 1
-  export MPR_ORACLE_ASAN=1
-  export LD_PRELOAD=$(gcc -print-file-name=libasan.so)
-  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
-fi
-if [ "$LEG" = hostasan ]; then
-  # the LIBRARY's host side instrumented (make -C mpr_amd/csrc asan: libmpr_amd_asan.so; device code as it is), clang's runtime preloaded
-  make -s -j8 -C mpr_amd/csrc asan || exit 1
-  export MPR_AMD_LIB=$PWD/mpr_amd/libmpr_amd_asan.so
-  # (ROCm's own sanitizer runtime intercepts hsa_amd_memory_pool_allocate for the GPU sanitizer this pool does not offer and aborts in the
-  # first context; gcc's runtime speaks the same interface: under the name the library asks for)
-  mkdir -p /tmp/fakert && ln -sf $(gcc -print-file-name=libasan.so) /tmp/fakert/libclang_rt.asan-x86_64.so
-  export LD_LIBRARY_PATH=/tmp/fakert:$LD_LIBRARY_PATH
-  export LD_PRELOAD=$(gcc -print-file-name=libasan.so)
-  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1
-fi
 if [ "$LEG" = guard ]; then
   gcc -O2 -fPIC -shared -o /tmp/heapguard.so scripts/heapguard.c -ldl || exit 1
   export LD_PRELOAD=/tmp/heapguard.so
