@@ -135,8 +135,9 @@ static void finish_tape(mpr_tape* t)
     t->num_slots = max_slot + 1;
     t->num_choices = choices;
     t->schedule = mpr::build_schedule(t->clauses.data(), (int32_t)t->clauses.size());
-    /* the tape's walks as machine code, here and not in the first frame that renders it (bear: 7 ms of host time with eight cores — nine
-     * scheduled forward walks side by side, tile_gen.cpp: build_tape_code —, 30 on one; round 6 began at 70: interval_gen.cpp: schedule_region) */
+    /* the tape's walks as machine code, here and not in the first frame that renders it (bear: 3 ms on a GPU box's host — nine
+     * scheduled forward walks side by side, tile_gen.cpp: build_tape_code —, 30 on one slow core; round 6 began at 70: interval_gen.cpp:
+     * schedule_region; scripts/tape_times.py) */
     t->code = mpr::build_tape_code(t->clauses.data(), (int)t->clauses.size(), mpr::TAPE_CODE_DEFAULT_MIN_RUN);
     if (!t->code && t->num_slots > mpr::TILE_GEN_MAX_SLOTS && t->num_slots <= 94) {
         /* (prospero: 32 000 + 48 000 instructions, 25 of the 36 ms its tape takes to make; architecture: 6800 + 19 000, 4 of 7 ms) */
