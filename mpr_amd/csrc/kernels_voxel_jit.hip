@@ -1175,13 +1175,23 @@ k_eval_voxels_gen_fp(FpVoxelArgs j)
     for (int turn = 0; turn < VG_LISTS; ++turn) {
         const int list = (int)((blockIdx.x + (unsigned)turn) % VG_LISTS);
         const int list_runs = (nruns - list + VG_LISTS - 1) / VG_LISTS;
+        /* the first run of a wavefront's own list is dealt, not claimed: all the grid's wavefronts asking eight counters at the same moment
+         * waited 6 to 9 us for the answer (768 same-address atomics a counter, ~10 ns each).  The counters count from there. */
+        const int list_dealt = ((int)gridDim.x - list + VG_LISTS - 1) / VG_LISTS;
+        bool dealt = turn == 0;
         for (;;) {
             int q = 0;
-            if (lane == 0) {
-                if (turn > 0 && __hip_atomic_load(j.counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= list_runs) q = list_runs;
-                else q = atomicAdd(j.counter + list * VG_COUNTER_STRIDE, 1);
+            if (dealt) {
+                q = (int)blockIdx.x / VG_LISTS;
+                dealt = false;
+            } else {
+                if (lane == 0) {
+                    if (turn > 0 && __hip_atomic_load(j.counter + list * VG_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + list_dealt >= list_runs) q = list_runs;
+                    else q = atomicAdd(j.counter + list * VG_COUNTER_STRIDE, 1) + list_dealt;
+                }
+                q = __builtin_amdgcn_readfirstlane(q);
             }
-            const int run = __builtin_amdgcn_readfirstlane(q) * VG_LISTS + list;
+            const int run = q * VG_LISTS + list;
             if (run >= nruns) break;
             for (int t = run * run_len; t < min(run * run_len + run_len, total); ++t) {
                 const uint32_t item = __builtin_amdgcn_readfirstlane(j.items[t]);
