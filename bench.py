@@ -540,7 +540,12 @@ def main():
                               "value": round(S * S / (fm * 1e-3) / 1e6, 3), "unit": "Mpixel/s", "same_images": same,
                               "note": "MPR_LAST_STAGE_PUSH=1: every frame leaves the reference's tiles and tapes behind (what a frame costs "
                                       "when they are read back); images identical to the timed frames"}
-        fresh = [m.Tape(m.model(args.model)) for _ in range(min(args.steps, 12))]      # new tapes: nothing the context has learned applies
+        fresh, made = [], []
+        ftree = m.model(args.model)
+        for _ in range(min(args.steps, 12)):                                            # new tapes: nothing the context has learned applies
+            t1 = time.perf_counter()
+            fresh.append(m.Tape(ftree))
+            made.append((time.perf_counter() - t1) * 1e3)
         first = []
         for ft in fresh:
             sync()
@@ -549,7 +554,9 @@ def main():
             first.append((time.perf_counter() - t1) * 1e3)
         f1, f1s = stats(first[2:] if len(first) > 4 else first)
         out["first_frames"] = {"ms_per_frame_mean": round(f1, 4), "ms_per_frame_std": round(f1s, 4), "frames": len(first),
-                               "note": "render3D of a tape object the context sees for the first time (includes the tape's upload)"}
+                               "note": "render3D of a tape object the context sees for the first time (includes the tape's upload)",
+                               "tape_construction_ms": round(sorted(made)[len(made) // 2], 3),
+                               "tape_construction_note": "host time of mpr::Tape(tree), median: the clauses and the tape's walks as gfx950 code (not in ms_per_frame_mean)"}
 
     # ---- side measurement: prospero render2D 1024^2 (the published V100 number's config) ----
     if rank == 0 and world == 1 and not args.no_also:
