@@ -1006,6 +1006,7 @@ struct Frame {
     bool used_loose = false;               /* a tile stage ran the loose interval code (interval_gen.hpp) */
     bool sample_groups = true;             /* the last stage keeps its groups' records / measures its tapes (false: 31 of 32 frames of a tape that pushes) */
     mprk::Skip0ParentsArgs skip0_args;
+    bool skip0_side_pending = false;       /* the 64^3 tiles' walk beside the frame is prepared, not launched yet (launch_skip0_side) */
     bool lean_first = false;               /* the first stage walks forward only and leaves records, no tapes */
     bool tiles_only = false;               /* a reader's re-render: tile stages only */
     mpr_context::FrameKey key;
@@ -1185,10 +1186,6 @@ static int frame_begin(Frame& f)
             rc = ensure_buffer(&c->skip0_children, &c->skip0_children_cap, (size_t)count * 64 * mprk::SKIP0_INFO_U64);
             if (rc) return rc;
             *reinterpret_cast<volatile int*>(c->skip0_flag_host) = 0;
-            if (c->side_must_wait) {
-                HIP_TRY(hipStreamWaitEvent(c->side, c->ev_begin, 0));
-                c->side_must_wait = false;
-            }
             mprk::Skip0ParentsArgs& pa = f.skip0_args;
             pa.tape_ro = c->pool;
             pa.gen_fwd2_first = c->gen_iw_dw[0][0] ? c->gen_code + c->gen_iw_at[0][0] : nullptr;
@@ -1197,8 +1194,10 @@ static int frame_begin(Frame& f)
             pa.count = count;
             pa.tps = t0;
             std::memcpy(pa.mat, mat, sizeof(pa.mat));
-            mprk::launch_skip0_parents(c->side, pa);
-            HIP_TRY(hipEventRecord(c->ev_check, c->side));
+            /* launched BEHIND the frame's first stage (launch_skip0_side): in front of it its 64 wavefronts took 64 of the 4096 places that
+             * stage's wavefronts fill — 16 a compute unit, all at once — and the 64 left over started when the first of the others ended:
+             * a second round for one wavefront in 64, half of the stage's 99 us */
+            f.skip0_side_pending = true;
         }
         if (skip0) {
             c->last.tiles_in[0] = count;
@@ -1533,6 +1532,26 @@ static int stage_launch(Frame& f, int si, int i, int tps, bool last, bool wide_n
     return MPR_OK;
 }
 
+/* the 64^3 tiles' own walk, beside the frame: behind whatever the frame's stream has uploaded (the tape, its code) */
+static int launch_skip0_side(Frame& f)
+{
+    mpr_context* const c = f.c;
+    if (!f.skip0_side_pending) return MPR_OK;
+    f.skip0_side_pending = false;
+    if (c->side_must_wait) {
+        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_begin, 0));
+        c->side_must_wait = false;
+    }
+    /* ... and not beside that stage but behind it: side by side its 64 wavefronts ask for the same issue slots as the stage's 4096, one
+     * round of latency-bound exact walks both; beside the compaction and the last tile stage nobody misses them (its result is the
+     * normals pass's business, 400 us later) */
+    HIP_TRY(hipEventRecord(c->ev_stage, f.s));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_stage, 0));
+    mprk::launch_skip0_parents(c->side, f.skip0_args);
+    HIP_TRY(hipEventRecord(c->ev_check, c->side));
+    return MPR_OK;
+}
+
 /* one tile stage: evaluation, compaction (+ copy_filled), the survivor count */
 static int frame_tile_stage(Frame& f, int si)
 {
@@ -1608,6 +1627,8 @@ static int frame_tile_stage(Frame& f, int si)
         a.no_mask = c->stage0_only;
         if (count > 0) {
             rc = stage_launch(f, si, i, tps, last, wide_now, groups_now, try_lean, a);
+            if (rc) return rc;
+            rc = launch_skip0_side(f);
             if (rc) return rc;
             if (a.self_info && !f.blocking) {
                 /* a frame that does not block (the multi-GPU pipeline packs its columns behind it on the same stream) must have
@@ -1916,6 +1937,10 @@ static int frame_normals_pass(Frame& f)
             n.gen_nchoices = c->gen_nchoices;
             if (f.skip0_checked) {
                 /* the 64^3 tiles' decisions, walked beside the frame (kernels.hpp: NormalArgs::skip0_parents): long there */
+                {
+                    const int rcs = launch_skip0_side(f);          /* (launched behind the first stage; here for a frame that had none) */
+                    if (rcs) return rcs;
+                }
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_check, 0));
                 n.skip0_parents = c->skip0_parents;
             }
@@ -2029,6 +2054,8 @@ static int render_frame(mpr_context* c, const mpr_tape* tape, int dim, const flo
         if (f.skip0_checked && blocking) {
             /* every tile of the frame's first stage against its 64^3 parent, behind the frame: the side stream's walk of those
              * has long ended, nothing waits; the verdict is read once the frame has been waited for */
+            rc = launch_skip0_side(f);
+            if (rc) return rc;
             HIP_TRY(hipStreamWaitEvent(f.s, c->ev_check, 0));
             mprk::launch_skip0_compare(f.s, f.skip0_args, c->skip0_children, c->skip0_flag_dev);
             c->skip0_unchecked = true;
