@@ -488,3 +488,41 @@ def test_tight_code_leaves_the_walk_as_it_is_and_its_second_enclosure_holds_the_
 def test_tight_code_only_where_there_is_something_to_tighten(mpr, tapes):
     assert generate(mpr, [int(w) for w in tapes("smooth").data], FIRST, True, tight=True) is None      # no sin / cos
     assert generate(mpr, [int(w) for w in tapes("bear").data], FIRST, False, tight=True) is None        # exact code has one result
+
+
+def test_tapes_made_side_by_side_carry_the_same_code(mpr, tapes):
+    """A tape's nine scheduled walks are built side by side (tile_gen.cpp: build_tape_code, std::async) on per-thread scratch
+    (interval_gen.cpp: schedule_region); callers may make tapes from several threads at once.  Eight threads, three models: every tape
+    renders through the same code — the generator's output for its clauses, hashed, is what one thread alone produces."""
+    import hashlib
+    import threading
+
+    def digest(words):
+        h = hashlib.sha1()
+        for kind in (FIRST, BELOW, GUARDED):
+            for loose, tight in ((False, False), (True, False), (True, True)):
+                g = generate(mpr, words, kind, loose, tight=tight)
+                h.update(b"none" if g is None else np.asarray(g[0], dtype=np.uint32).tobytes())
+        return h.hexdigest()
+
+    names = ["bear", "hello_world", "trig_blend"]
+    alone = {n: digest(tapes(n).data) for n in names}
+    trees = {n: (mpr.model(n) if n != "trig_blend" else None) for n in names}
+    results, errors = [], []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                n = names[(k + rep) % len(names)]
+                t = mpr.Tape(trees[n]) if trees[n] is not None else mpr.Tape(tapes(n).data)
+                results.append((n, digest(t.data)))
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 24 and all(d == alone[n] for n, d in results)
